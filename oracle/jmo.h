@@ -1,0 +1,193 @@
+/*
+ * oracle/jmo.h -- CPU restatement of JM 19.0 lencod's data-parallel hot path.
+ *
+ * TEST INFRASTRUCTURE.  This is the parity oracle: a plain-C restatement of the
+ * reference's algorithms, one function per reference function, each citing the
+ * reference file:line it follows.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product path (jm_amd/,
+ * include/jmhip.h) never links, imports or calls anything in this directory.
+ *
+ * Pinning: every function here is checked (tests/test_oracle_*.py, -m "not gpu")
+ * against golden vectors captured from the reference itself -- the real lencod
+ * built by oracle/Makefile.ref and tapped by oracle/ref_tap.c -- and against the
+ * known-answer vectors of SURVEY.md Appendix C.
+ *
+ * Conventions mirrored from the reference:
+ *   imgpel  = uint16_t   (lcommon/inc/typedefs.h:36, IMGTYPE 1 lencod/inc/defines.h:37)
+ *   distblk = int64_t    (typedefs.h:39), all costs scaled <<5 (JCOST_CALC_SCALEUP,
+ *                         LAMBDA_ACCURACY_BITS 5: defines.h:46,130)
+ *   motion vectors in quarter-pel units, int16.
+ */
+#ifndef JMO_H
+#define JMO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t jmo_pel;
+typedef int64_t  jmo_dist;
+#define JMO_DIST_MAX   (((jmo_dist)INT32_MAX) << 5)   /* DISTBLK_MAX = INT_MAX << LAMBDA_ACCURACY_BITS, lencod/inc/defines.h */
+#define JMO_PAD_X 32   /* IMG_PAD_SIZE_X lencod/inc/defines.h:121 */
+#define JMO_PAD_Y 20   /* IMG_PAD_SIZE_Y lencod/inc/defines.h:122 */
+#define JMO_LAMBDA_BITS 5
+
+typedef struct { int16_t x, y; } jmo_mv;
+
+/* A reference picture as the ME sees it: up to 16 quarter-pel sub-planes
+ * (StorablePicture.p_curr_img_sub[4][4], lencod/inc/mbuffer.h), each a padded
+ * (H+2*PAD_Y) x (W+2*PAD_X) plane.  sub[j][i] points at picture sample (0,0)
+ * of the plane with vertical phase j, horizontal phase i; rows are `pitch`
+ * samples apart; samples at [-PAD_Y..H+PAD_Y-1][-PAD_X..W+PAD_X-1] are valid. */
+typedef struct {
+  int width, height;           /* size_x, size_y */
+  int pitch;                   /* >= width + 2*PAD_X */
+  const jmo_pel *sub[4][4];
+} jmo_refpic;
+
+/* ---- motion-estimation tables (lencod/src/mv_search.c:315-442) ---- */
+int  jmo_mvbits(int d);                                   /* mv_search.c:366-374 */
+void jmo_spiral(int search_range, jmo_mv *spiral);        /* mv_search.c:405-442, full-pel units */
+int  jmo_spiral_index(int dx, int dy);                    /* closed form of the same order */
+
+/* ---- block distortion (lencod/src/me_distortion.c) ---- */
+int      jmo_hadamard_sad4x4(const int16_t diff[16]);     /* me_distortion.c:175-258 */
+int      jmo_hadamard_sad8x8(const int16_t diff[64]);     /* me_distortion.c:266-341 */
+/* computeSAD me_distortion.c:349-426 (luma only: ChromaMEEnable=0).
+ * cand is the absolute quarter-pel position incl. pos_*_padded. */
+jmo_dist jmo_compute_sad (const jmo_refpic *ref, const jmo_pel *orig, int bsx, int bsy,
+                          jmo_dist min_mcost, int cand_x, int cand_y);
+/* computeSATD me_distortion.c:745-825 */
+jmo_dist jmo_compute_satd(const jmo_refpic *ref, const jmo_pel *orig, int bsx, int bsy,
+                          int test8x8, jmo_dist min_mcost, int cand_x, int cand_y);
+
+/* ---- integer-pel search ---- */
+typedef struct {
+  int pos_x, pos_y;          /* block position in the picture, full-pel (MEBlock.pos_x/pos_y) */
+  int bsx, bsy;              /* block size */
+  jmo_mv pred;               /* MV predictor, quarter-pel */
+  jmo_mv center;             /* in: search centre mv (quarter-pel, already rounded+clipped:
+                                mv_search.c:924-957); out: best mv */
+  int search_range;          /* full-pel: min(max_x,max_y)>>2, me_fullsearch.c:49 */
+  int lambda_factor;         /* lambda_factor[F_PEL] */
+  jmo_dist min_mcost;        /* in: initial bound (DISTBLK_MAX from BlockMotionSearch) */
+} jmo_fs_job;
+
+/* full_search_motion_estimation me_fullsearch.c:39-103 (rdopt on => no (0,0) bonus).
+ * orig: bsx*bsy contiguous samples (MEBlock.orig_pic[0]).  Returns min_mcost,
+ * updates job->center to the best mv.  If sad_evals != NULL it receives the
+ * number of candidates that reached the SAD computation (early-out statistics). */
+jmo_dist jmo_full_search(const jmo_refpic *ref, const jmo_pel *orig, jmo_fs_job *job,
+                         long *sad_evals);
+
+/* Fast full search (lencod/src/me_fullfast.c).
+ * jmo_ffs_setup : setup_fast_full_search :269-608 (no WP, no chroma ME) +
+ *                 update_full_search_large_blocks :195-260.
+ *   cur: the 16x16 luma MB, row-major 256 samples.  center: search centre mv (quarter-pel,
+ *   multiple of 4, already clipped :313-327).  block_sad[8][16][max_pos] (type 0 unused),
+ *   max_pos=(2R+1)^2, indexed [blocktype][4x4 raster index][spiral pos]. */
+void jmo_ffs_setup(const jmo_refpic *ref, const jmo_pel cur[256], int mb_x, int mb_y,
+                   jmo_mv center, int search_range, uint32_t *block_sad /*[8][16][max_pos]*/);
+/* fast_full_search_motion_estimation :618-689 (rdopt on). Returns min_mcost, *best_mv. */
+jmo_dist jmo_ffs_search(const uint32_t *block_sad, int max_pos_table, int blocktype, int block_index,
+                        jmo_mv center, jmo_mv pred, int search_range, int lambda_factor,
+                        int max_mvd, jmo_dist min_mcost, jmo_mv *best_mv);
+
+/* ---- sub-pel refinement: sub_pel_motion_estimation me_fullsearch.c:186-289 ----
+ * rdopt on; metric per stage: 0 = SAD, 2 = SATD(Hadamard) (MEDistortionHPel/QPel).
+ * start_hp/start_qp = p_Vid->start_me_refinement_hp/qp (mv_search.c:445-446). */
+typedef struct {
+  int pos_x, pos_y, bsx, bsy;
+  jmo_mv pred;
+  jmo_mv mv;                 /* in: int-pel result; out: refined */
+  int lambda_h, lambda_q;    /* lambda_factor[H_PEL], [Q_PEL] */
+  int metric_h, metric_q;
+  int start_hp, start_qp;
+  int test8x8;
+  jmo_dist min_mcost;        /* in: cost after int-pel (reset to MAX by caller if !start_hp, mv_search.c:971-974) */
+} jmo_subpel_job;
+jmo_dist jmo_sub_pel_search(const jmo_refpic *ref, const jmo_pel *orig, jmo_subpel_job *job);
+
+/* ---- transforms (lcommon/src/transform.c) ---- */
+void jmo_forward4x4(const int in[16], int out[16]);          /* :20-68  */
+void jmo_inverse4x4(const int in[16], int out[16]);          /* :70-118 */
+void jmo_hadamard4x4(const int in[16], int out[16]);         /* :121-168 */
+void jmo_ihadamard4x4(const int in[16], int out[16]);        /* :170-220 */
+void jmo_hadamard2x2(const int in[4], int out[4]);           /* :284-297 */
+void jmo_ihadamard2x2(const int in[4], int out[4]);          /* :299-312 */
+void jmo_forward8x8(const int in[64], int out[64]);          /* :353-448 */
+void jmo_inverse8x8(const int in[64], int out[64]);          /* :450-547 */
+
+/* ---- quantisation (lencod/src/quant4x4_normal.c, quant4x4_around.c, quant8x8_normal.c) ---- */
+typedef struct { int OffsetComp, ScaleComp, InvScaleComp; } jmo_qparam;   /* LevelQuantParams quant_params.h:17-21 */
+/* q_matrix.c:20-37 flat-matrix tables, q_offsets.c defaults */
+void jmo_qparams_4x4(int qp, int intra, int offset_bits_val, jmo_qparam out[16]);  /* [j*4+i] */
+void jmo_qparams_8x8(int qp, int intra, int offset_bits_val, jmo_qparam out[64]);
+/* quant_4x4_normal quant4x4_normal.c:39-115 (symbol_mode CAVLC => level clamp 2063).
+ * tblock: 16 coeffs row-major [j][i], overwritten with the dequantised values.
+ * level/run: 17 entries (0-terminated as in JM); returns nonzero flag; *coeff_cost accumulates. */
+int jmo_quant_4x4_normal(int tblock[16], const jmo_qparam qp16[16], int qp_per, int cavlc,
+                         const uint8_t *pos_scan /*16x2 (i,j)*/, const uint8_t *c_cost,
+                         int level[17], int run[17], int *coeff_cost);
+/* quant_4x4_around quant4x4_around.c:40-127 : additionally fills fadjust[16] */
+int jmo_quant_4x4_around(int tblock[16], const jmo_qparam qp16[16], int qp_per, int cavlc,
+                         const uint8_t *pos_scan, const uint8_t *c_cost, int adapt_rnd_weight,
+                         int level[17], int run[17], int *coeff_cost, int fadjust[16]);
+int jmo_quant_8x8_normal(int tblock[64], const jmo_qparam qp64[64], int qp_per, int cavlc,
+                         const uint8_t *pos_scan /*64x2*/, const uint8_t *c_cost,
+                         int level[65], int run[65], int *coeff_cost);
+extern const uint8_t JMO_SNGL_SCAN[16][2];       /* block.c:170 */
+extern const uint8_t JMO_SNGL_SCAN8x8[64][2];    /* transform8x8.c */
+extern const uint8_t JMO_COEFF_COST4x4[3][16];   /* block.c COEFF_COST4x4 */
+extern const uint8_t JMO_COEFF_COST8x8[2][64];
+
+/* residual_transform_quant_luma_4x4 block.c:661-725, one 4x4 block:
+ * orig/pred: 16 samples; returns nonzero; rec[16] reconstructed samples
+ * (sample_reconstruct lcommon/src/blk_prediction.c:48-62, DQ_BITS 6). */
+int jmo_rtq_luma_4x4(const jmo_pel orig[16], const jmo_pel pred[16], int qp, int intra,
+                     int adaptive_rounding /*0: quant_4x4_normal, 1: _around*/, int adapt_rnd_weight,
+                     int max_pel, int level[17], int run[17], int *coeff_cost,
+                     jmo_pel rec[16], int fadjust[16]);
+
+/* ---- sub-pel plane generation: getSubImagesLuma lencod/src/img_luma.c:611-679 ----
+ * src: W x H luma (pitch src_pitch).  dst: 16 planes, plane (j,i) at dst + (j*4+i)*plane_stride,
+ * each (H+2*PAD_Y) rows x pitch samples, picture origin at row PAD_Y, col PAD_X. */
+void jmo_sub_images_luma(const jmo_pel *src, int src_pitch, int width, int height,
+                         int max_pel, jmo_pel *dst, int pitch, long plane_stride);
+
+/* ---- deblocking: DeblockFrame lencod/src/loopFilter.c:63-71, DeblockMb :120-297,
+ *      loop_filter_normal.c (strengths :52-292, edge filters :301-757) ----
+ * Per-macroblock side information the filter reads from JM's Macroblock (lencod/inc/global.h). */
+typedef struct {
+  int16_t mb_type;           /* JM enum value: 0 PSKIP/BSKIP_DIRECT, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8,
+                                9 I4MB, 10 I16MB, 13 I8MB, 14 IPCM (lcommon/inc/types.h) */
+  int16_t slice_type;        /* 0 P, 1 B, 2 I, 3 SP, 4 SI (SliceType) */
+  int16_t qp;                /* MbQ->qp */
+  int16_t qpc[2];            /* MbQ->qpc[uv] */
+  int16_t cbp;               /* MbQ->cbp */
+  uint32_t cbp_blk;          /* low 16 bits of MbQ->cbp_blk (luma 4x4 coefficient flags) */
+  int16_t slice_nr;
+  int16_t df_disable_idc;    /* MbQ->DFDisableIdc */
+  int16_t df_alpha_c0;       /* MbQ->DFAlphaC0Offset */
+  int16_t df_beta;           /* MbQ->DFBetaOffset */
+  int16_t transform8x8;      /* MbQ->luma_transform_size_8x8_flag */
+  int16_t pad_;
+} jmo_db_mb;
+/* per 4x4 block: enc_picture->mv_info[y][x] reduced to what GetStrength* compares:
+ * mv per list and an integer identity for ref_pic[list] (-1 when ref_idx[list] == -1). */
+typedef struct { int16_t mv[2][2]; int32_t ref_id[2]; } jmo_db_motion;
+/* Deblock a whole frame in place (frame MBs, no MBAFF, 4:0:0 / 4:2:0 / 4:2:2).
+ * imgY/imgU/imgV point at picture sample (0,0); pitches in samples.
+ * direct_8x8_inference: active_sps->direct_8x8_inference_flag. */
+void jmo_deblock_frame(jmo_pel *imgY, int pitchY, jmo_pel *imgU, jmo_pel *imgV, int pitchC,
+                       int width, int height, int yuv_format /*0:400 1:420 2:422*/,
+                       const jmo_db_mb *mbs, const jmo_db_motion *motion /*[H/4][W/4]*/,
+                       int max_pel_y, int max_pel_c, int direct_8x8_inference);
+/* strength of one edge (16 bytes), exposed for kernel-level parity: dir 0 vertical, 1 horizontal */
+void jmo_deblock_strength(uint8_t str[16], int dir, int edge, int mb_addr, int mb_w,
+                          const jmo_db_mb *mbs, const jmo_db_motion *motion);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

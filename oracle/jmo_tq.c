@@ -1,0 +1,289 @@
+/*
+ * oracle/jmo_tq.c -- TEST INFRASTRUCTURE (parity oracle, see jmo.h).
+ * CPU restatement of JM 19.0 integer transforms and scalar quantisation:
+ *   lcommon/src/transform.c, lencod/src/quant4x4_normal.c, quant4x4_around.c,
+ *   quant8x8_normal.c, q_matrix.c (flat matrices), q_offsets.c (default offsets),
+ *   lencod/src/block.c:661-725, lcommon/src/blk_prediction.c:48-62.
+ */
+#include <string.h>
+#include "jmo.h"
+
+static inline int iabs_(int x) { return x < 0 ? -x : x; }
+static inline int imin_(int a, int b) { return a < b ? a : b; }
+static inline int rshift_rnd_sf(int x, int a) { return (x + (1 << (a - 1))) >> a; }   /* ifunctions.h:176 */
+static inline int clip1(int hi, int x) { return x < 0 ? 0 : (x > hi ? hi : x); }       /* ifunctions.h:191 */
+
+/* ---------------- 4-point stages, applied along rows then columns ---------------- */
+static inline void fwd4(const int *s, int ss, int *d, int ds)         /* transform.c:27-46 / :49-66 */
+{
+  int e0 = s[0] + s[3 * ss], e1 = s[ss] + s[2 * ss], o0 = s[ss] - s[2 * ss], o1 = s[0] - s[3 * ss];
+  d[0]      = e0 + e1;
+  d[ds]     = (o1 << 1) + o0;
+  d[2 * ds] = e0 - e1;
+  d[3 * ds] = o1 - (o0 << 1);
+}
+static inline void inv4(const int *s, int ss, int *d, int ds)         /* transform.c:79-96 / :99-117 */
+{
+  int e0 = s[0] + s[2 * ss], e1 = s[0] - s[2 * ss];
+  int o0 = (s[ss] >> 1) - s[3 * ss], o1 = s[ss] + (s[3 * ss] >> 1);
+  d[0] = e0 + o1; d[ds] = e1 + o0; d[2 * ds] = e1 - o0; d[3 * ds] = e0 - o1;
+}
+void jmo_forward4x4(const int in[16], int out[16])
+{
+  int t[16], i;
+  for (i = 0; i < 4; i++) fwd4(in + 4 * i, 1, t + 4 * i, 1);
+  for (i = 0; i < 4; i++) fwd4(t + i, 4, out + i, 4);
+}
+void jmo_inverse4x4(const int in[16], int out[16])
+{
+  int t[16], i;
+  for (i = 0; i < 4; i++) inv4(in + 4 * i, 1, t + 4 * i, 1);
+  for (i = 0; i < 4; i++) inv4(t + i, 4, out + i, 4);
+}
+/* hadamard4x4 transform.c:121-168 : rows (t0+t1, t3+t2, t0-t1, t3-t2), columns the same then >>1 */
+void jmo_hadamard4x4(const int in[16], int out[16])
+{
+  int t[16], i;
+  for (i = 0; i < 4; i++) {
+    const int *s = in + 4 * i;
+    int e0 = s[0] + s[3], e1 = s[1] + s[2], o0 = s[1] - s[2], o1 = s[0] - s[3];
+    t[4*i] = e0 + e1; t[4*i+1] = o1 + o0; t[4*i+2] = e0 - e1; t[4*i+3] = o1 - o0;
+  }
+  for (i = 0; i < 4; i++) {
+    int e0 = t[i] + t[12+i], e1 = t[4+i] + t[8+i], o0 = t[4+i] - t[8+i], o1 = t[i] - t[12+i];
+    out[i] = (e0 + e1) >> 1; out[4+i] = (o0 + o1) >> 1; out[8+i] = (e0 - e1) >> 1; out[12+i] = (o1 - o0) >> 1;
+  }
+}
+/* ihadamard4x4 transform.c:170-220 */
+void jmo_ihadamard4x4(const int in[16], int out[16])
+{
+  int t[16], i;
+  for (i = 0; i < 4; i++) {
+    const int *s = in + 4 * i;
+    int e0 = s[0] + s[2], e1 = s[0] - s[2], o0 = s[1] - s[3], o1 = s[1] + s[3];
+    t[4*i] = e0 + o1; t[4*i+1] = e1 + o0; t[4*i+2] = e1 - o0; t[4*i+3] = e0 - o1;
+  }
+  for (i = 0; i < 4; i++) {
+    int e0 = t[i] + t[8+i], e1 = t[i] - t[8+i], o0 = t[4+i] - t[12+i], o1 = t[4+i] + t[12+i];
+    out[i] = e0 + o1; out[4+i] = e1 + o0; out[8+i] = e1 - o0; out[12+i] = e0 - o1;
+  }
+}
+/* hadamard2x2 transform.c:284-297: in = {dc00, dc01(x+4), dc10(y+4), dc11} */
+void jmo_hadamard2x2(const int in[4], int out[4])
+{
+  int p0 = in[0] + in[1], p1 = in[0] - in[1], p2 = in[2] + in[3], p3 = in[2] - in[3];
+  out[0] = p0 + p2; out[1] = p1 + p3; out[2] = p0 - p2; out[3] = p1 - p3;
+}
+void jmo_ihadamard2x2(const int in[4], int out[4])                   /* transform.c:299-312 */
+{
+  int t0 = in[0] + in[1], t1 = in[0] - in[1], t2 = in[2] + in[3], t3 = in[2] - in[3];
+  out[0] = t0 + t2; out[1] = t1 + t3; out[2] = t0 - t2; out[3] = t1 - t3;
+}
+
+/* ---------------- 8-point stages ---------------- */
+static inline void fwd8(const int *s, int ss, int *d, int ds)         /* transform.c:364-401 */
+{
+  int p[8], a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, k;
+  for (k = 0; k < 8; k++) p[k] = s[k * ss];
+  a0 = p[0] + p[7]; a1 = p[1] + p[6]; a2 = p[2] + p[5]; a3 = p[3] + p[4];
+  b0 = a0 + a3; b1 = a1 + a2; b2 = a0 - a3; b3 = a1 - a2;
+  a0 = p[0] - p[7]; a1 = p[1] - p[6]; a2 = p[2] - p[5]; a3 = p[3] - p[4];
+  b4 = a1 + a2 + ((a0 >> 1) + a0);
+  b5 = a0 - a3 - ((a2 >> 1) + a2);
+  b6 = a0 + a3 - ((a1 >> 1) + a1);
+  b7 = a1 - a2 + ((a3 >> 1) + a3);
+  d[0]      = b0 + b1;
+  d[ds]     = b4 + (b7 >> 2);
+  d[2 * ds] = b2 + (b3 >> 1);
+  d[3 * ds] = b5 + (b6 >> 2);
+  d[4 * ds] = b0 - b1;
+  d[5 * ds] = b6 - (b5 >> 2);
+  d[6 * ds] = (b2 >> 1) - b3;
+  d[7 * ds] = (b4 >> 2) - b7;
+}
+static inline void inv8(const int *s, int ss, int *d, int ds)         /* transform.c:461-498 */
+{
+  int p[8], a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, k;
+  for (k = 0; k < 8; k++) p[k] = s[k * ss];
+  a0 = p[0] + p[4]; a1 = p[0] - p[4]; a2 = p[6] - (p[2] >> 1); a3 = p[2] + (p[6] >> 1);
+  b0 = a0 + a3; b2 = a1 - a2; b4 = a1 + a2; b6 = a0 - a3;
+  a0 = -p[3] + p[5] - p[7] - (p[7] >> 1);
+  a1 =  p[1] + p[7] - p[3] - (p[3] >> 1);
+  a2 = -p[1] + p[7] + p[5] + (p[5] >> 1);
+  a3 =  p[3] + p[5] + p[1] + (p[1] >> 1);
+  b1 = a0 + (a3 >> 2); b3 = a1 + (a2 >> 2); b5 = a2 - (a1 >> 2); b7 = a3 - (a0 >> 2);
+  d[0] = b0 + b7; d[ds] = b2 - b5; d[2 * ds] = b4 + b3; d[3 * ds] = b6 + b1;
+  d[4 * ds] = b6 - b1; d[5 * ds] = b4 - b3; d[6 * ds] = b2 + b5; d[7 * ds] = b0 - b7;
+}
+void jmo_forward8x8(const int in[64], int out[64])
+{
+  int t[64], i;
+  for (i = 0; i < 8; i++) fwd8(in + 8 * i, 1, t + 8 * i, 1);
+  for (i = 0; i < 8; i++) fwd8(t + i, 8, out + i, 8);
+}
+void jmo_inverse8x8(const int in[64], int out[64])
+{
+  int t[64], i;
+  for (i = 0; i < 8; i++) inv8(in + 8 * i, 1, t + 8 * i, 1);
+  for (i = 0; i < 8; i++) inv8(t + i, 8, out + i, 8);
+}
+
+/* ---------------- tables ---------------- */
+/* zig-zag frame scans, (i = horizontal, j = vertical) pairs: block.c:170-176, transform8x8.c:44-53 */
+const uint8_t JMO_SNGL_SCAN[16][2] = {
+  {0,0},{1,0},{0,1},{0,2},{1,1},{2,0},{3,0},{2,1},{1,2},{0,3},{1,3},{2,2},{3,1},{3,2},{2,3},{3,3}
+};
+const uint8_t JMO_SNGL_SCAN8x8[64][2] = {
+  {0,0},{1,0},{0,1},{0,2},{1,1},{2,0},{3,0},{2,1},{1,2},{0,3},{0,4},{1,3},{2,2},{3,1},{4,0},{5,0},
+  {4,1},{3,2},{2,3},{1,4},{0,5},{0,6},{1,5},{2,4},{3,3},{4,2},{5,1},{6,0},{7,0},{6,1},{5,2},{4,3},
+  {3,4},{2,5},{1,6},{0,7},{1,7},{2,6},{3,5},{4,4},{5,3},{6,2},{7,1},{7,2},{6,3},{5,4},{4,5},{3,6},
+  {2,7},{3,7},{4,6},{5,5},{6,4},{7,3},{7,4},{6,5},{5,6},{4,7},{5,7},{6,6},{7,5},{7,6},{6,7},{7,7}
+};
+/* coefficient-cost tables for thresholding: block.c:72-77, transform8x8.c:83-93 */
+const uint8_t JMO_COEFF_COST4x4[3][16] = {
+  {3,2,2,1,1,1,0,0,0,0,0,0,0,0,0,0},
+  {9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9},
+  {3,2,2,1,1,1,0,0,0,0,0,0,0,0,0,0}
+};
+const uint8_t JMO_COEFF_COST8x8[2][64] = {
+  {3,3,3,3,2,2,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,
+   0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0},
+  {9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,
+   9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9}
+};
+
+/* Flat-matrix quantiser scales (H.264 normAdjust tables) by position class.
+ * 4x4 (q_matrix.c:20-36): class 0 = both coords even, 1 = both odd, 2 = mixed. */
+static const int Q4[6][3]  = {{13107,5243,8066},{11916,4660,7490},{10082,4194,6554},{9362,3647,5825},{8192,3355,5243},{7282,2893,4559}};
+static const int DQ4[6][3] = {{10,16,13},{11,18,14},{13,20,16},{14,23,18},{16,25,20},{18,29,23}};
+static inline int cls4(int j, int i) { return ((i & 1) == 0 && (j & 1) == 0) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2); }
+/* 8x8 (q_matrix.c:38-167) */
+static const int Q8[6][6]  = {{13107,11428,20972,12222,16777,15481},{11916,10826,19174,11058,14980,14290},
+                              {10082,8943,15978,9675,12710,11985},{9362,8228,14913,8931,11984,11259},
+                              {8192,7346,13159,7740,10486,9777},{7282,6428,11570,6830,9118,8640}};
+static const int DQ8[6][6] = {{20,18,32,19,25,24},{22,19,35,21,28,26},{26,23,42,24,33,31},
+                              {28,25,45,26,35,33},{32,28,51,30,40,38},{36,32,58,34,46,43}};
+static inline int cls8(int j, int i)
+{
+  int i4 = i & 3, j4 = j & 3;
+  if (i4 == 0 && j4 == 0) return 0;
+  if ((i & 1) && (j & 1)) return 1;
+  if (i4 == 2 && j4 == 2) return 2;
+  if ((i4 == 0 && (j & 1)) || ((i & 1) && j4 == 0)) return 3;
+  if ((i4 == 0 && j4 == 2) || (i4 == 2 && j4 == 0)) return 4;
+  return 5;
+}
+
+/* q_params_4x4[pl][intra][qp] for flat matrices and a uniform offset value:
+ * set_default_quant4x4 q_matrix.c:566-577 + update_q_offset4x4 q_offsets.c:238-249
+ * (OffsetComp = offset << (Q_BITS + qp_per - OffsetBits), OffsetBits = 11). */
+void jmo_qparams_4x4(int qp, int intra, int offset_val, jmo_qparam out[16])
+{
+  int rem = qp % 6, per = qp / 6, i, j;
+  (void)intra;
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) {
+    out[j * 4 + i].ScaleComp    = Q4[rem][cls4(j, i)];
+    out[j * 4 + i].InvScaleComp = DQ4[rem][cls4(j, i)] << 4;
+    out[j * 4 + i].OffsetComp   = offset_val << (15 + per - 11);
+  }
+}
+void jmo_qparams_8x8(int qp, int intra, int offset_val, jmo_qparam out[64])
+{
+  int rem = qp % 6, per = qp / 6, i, j;
+  (void)intra;
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) {
+    out[j * 8 + i].ScaleComp    = Q8[rem][cls8(j, i)];
+    out[j * 8 + i].InvScaleComp = DQ8[rem][cls8(j, i)] << 4;
+    out[j * 8 + i].OffsetComp   = offset_val << (16 + per - 11);    /* q_offsets.c CalculateOffset8x8Param: Q_BITS_8 */
+  }
+}
+
+/* quant_4x4_normal quant4x4_normal.c:39-115 / quant_4x4_around quant4x4_around.c:40-127 */
+static int quant4x4_core(int tb[16], const jmo_qparam q[16], int qp_per, int cavlc,
+                         const uint8_t *scan, const uint8_t *c_cost, int level[17], int run[17],
+                         int *coeff_cost, int around, int arw, int fadjust[16])
+{
+  int q_bits = 15 + qp_per, k, r = 0, n = 0, nonzero = 0;
+  for (k = 0; k < 16; k++) {
+    int i = scan[2 * k], j = scan[2 * k + 1], idx = j * 4 + i, c = tb[idx];
+    if (c != 0) {
+      int scaled = iabs_(c) * q[idx].ScaleComp;
+      int lev = (scaled + q[idx].OffsetComp) >> q_bits;
+      if (lev != 0) {
+        if (cavlc) lev = imin_(lev, 2063);                                   /* CAVLC_LEVEL_LIMIT */
+        if (around) fadjust[idx] = rshift_rnd_sf(arw * (scaled - (lev << q_bits)), q_bits + 1);
+        *coeff_cost += (lev > 1) ? 999999 : c_cost[r];                       /* MAX_VALUE defines.h:124 */
+        lev = c < 0 ? -lev : lev;
+        tb[idx] = rshift_rnd_sf((lev * q[idx].InvScaleComp) << qp_per, 4);
+        level[n] = lev; run[n] = r; n++;
+        r = 0; nonzero = 1;
+      } else {
+        if (around) fadjust[idx] = 0;
+        tb[idx] = 0; r++;
+      }
+    } else {
+      if (around) fadjust[idx] = 0;
+      r++;
+    }
+  }
+  level[n] = 0;
+  return nonzero;
+}
+int jmo_quant_4x4_normal(int tb[16], const jmo_qparam q[16], int qp_per, int cavlc, const uint8_t *scan,
+                         const uint8_t *c_cost, int level[17], int run[17], int *coeff_cost)
+{
+  return quant4x4_core(tb, q, qp_per, cavlc, scan, c_cost, level, run, coeff_cost, 0, 0, 0);
+}
+int jmo_quant_4x4_around(int tb[16], const jmo_qparam q[16], int qp_per, int cavlc, const uint8_t *scan,
+                         const uint8_t *c_cost, int arw, int level[17], int run[17], int *coeff_cost, int fadjust[16])
+{
+  return quant4x4_core(tb, q, qp_per, cavlc, scan, c_cost, level, run, coeff_cost, 1, arw, fadjust);
+}
+
+/* quant_8x8_normal quant8x8_normal.c:43-107 (no CAVLC level clamp in this variant) */
+int jmo_quant_8x8_normal(int tb[64], const jmo_qparam q[64], int qp_per, int cavlc, const uint8_t *scan,
+                         const uint8_t *c_cost, int level[65], int run[65], int *coeff_cost)
+{
+  int q_bits = 16 + qp_per, k, r = 0, n = 0, nonzero = 0;
+  (void)cavlc;
+  for (k = 0; k < 64; k++) {
+    int i = scan[2 * k], j = scan[2 * k + 1], idx = j * 8 + i, c = tb[idx];
+    if (c != 0) {
+      int scaled = iabs_(c) * q[idx].ScaleComp;
+      int lev = (scaled + q[idx].OffsetComp) >> q_bits;
+      if (lev != 0) {
+        nonzero = 1;
+        *coeff_cost += (lev > 1) ? 999999 : c_cost[r];
+        lev = c < 0 ? -lev : lev;
+        tb[idx] = rshift_rnd_sf((lev * q[idx].InvScaleComp) << qp_per, 6);
+        level[n] = lev; run[n] = r; n++; r = 0;
+      } else { r++; tb[idx] = 0; }
+    } else r++;
+  }
+  level[n] = 0;
+  return nonzero;
+}
+
+/* residual_transform_quant_luma_4x4 block.c:661-725 for one block, flat matrices,
+ * default offsets (q_offsets.c:135-162: 682 intra / 342 inter), frame scan, disthres 0. */
+int jmo_rtq_luma_4x4(const jmo_pel orig[16], const jmo_pel pred[16], int qp, int intra, int adaptive_rounding,
+                     int arw, int max_pel, int level[17], int run[17], int *coeff_cost,
+                     jmo_pel rec[16], int fadjust[16])
+{
+  int res[16], tb[16], rr[16], k, any = 0, nonzero = 0;
+  jmo_qparam q[16];
+  for (k = 0; k < 16; k++) { res[k] = (int)orig[k] - (int)pred[k]; any |= res[k]; }
+  if (any) {                                                                  /* check_zero block.c:627 */
+    jmo_qparams_4x4(qp, intra, intra ? 682 : 342, q);
+    jmo_forward4x4(res, tb);
+    nonzero = quant4x4_core(tb, q, qp / 6, 1, &JMO_SNGL_SCAN[0][0], JMO_COEFF_COST4x4[0], level, run,
+                            coeff_cost, adaptive_rounding, arw, fadjust);
+  } else level[0] = 0;
+  if (nonzero) {
+    jmo_inverse4x4(tb, rr);
+    for (k = 0; k < 16; k++) rec[k] = (jmo_pel)clip1(max_pel, rshift_rnd_sf(rr[k], 6) + (int)pred[k]);  /* blk_prediction.c:60 */
+  } else {
+    for (k = 0; k < 16; k++) rec[k] = pred[k];
+  }
+  return nonzero;
+}

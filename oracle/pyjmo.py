@@ -1,0 +1,216 @@
+"""ctypes bindings for the CPU parity oracle (oracle/libjmo.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never by the product package jm_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PAD_X, PAD_Y = 32, 20
+DIST_MAX = (2 ** 31 - 1) << 5
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libjmo.so"])
+
+
+def _load():
+    so = os.path.join(_HERE, "libjmo.so")
+    if not os.path.exists(so):
+        build()
+    return C.CDLL(so)
+
+
+L = _load()
+
+
+class MV(C.Structure):
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16)]
+
+
+class RefPicS(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("pitch", C.c_int),
+                ("sub", (C.POINTER(C.c_uint16) * 4) * 4)]
+
+
+class FsJob(C.Structure):
+    _fields_ = [("pos_x", C.c_int), ("pos_y", C.c_int), ("bsx", C.c_int), ("bsy", C.c_int),
+                ("pred", MV), ("center", MV), ("search_range", C.c_int), ("lambda_factor", C.c_int),
+                ("min_mcost", C.c_int64)]
+
+
+class SubpelJob(C.Structure):
+    _fields_ = [("pos_x", C.c_int), ("pos_y", C.c_int), ("bsx", C.c_int), ("bsy", C.c_int),
+                ("pred", MV), ("mv", MV), ("lambda_h", C.c_int), ("lambda_q", C.c_int),
+                ("metric_h", C.c_int), ("metric_q", C.c_int), ("start_hp", C.c_int), ("start_qp", C.c_int),
+                ("test8x8", C.c_int), ("min_mcost", C.c_int64)]
+
+
+class QParam(C.Structure):
+    _fields_ = [("OffsetComp", C.c_int), ("ScaleComp", C.c_int), ("InvScaleComp", C.c_int)]
+
+
+class DbMb(C.Structure):
+    _fields_ = [("mb_type", C.c_int16), ("slice_type", C.c_int16), ("qp", C.c_int16), ("qpc", C.c_int16 * 2),
+                ("cbp", C.c_int16), ("cbp_blk", C.c_uint32), ("slice_nr", C.c_int16),
+                ("df_disable_idc", C.c_int16), ("df_alpha_c0", C.c_int16), ("df_beta", C.c_int16),
+                ("transform8x8", C.c_int16), ("pad_", C.c_int16)]
+
+
+class DbMotion(C.Structure):
+    _fields_ = [("mv", (C.c_int16 * 2) * 2), ("ref_id", C.c_int32 * 2)]
+
+
+L.jmo_full_search.restype = C.c_int64
+L.jmo_compute_sad.restype = C.c_int64
+L.jmo_compute_satd.restype = C.c_int64
+L.jmo_ffs_search.restype = C.c_int64
+L.jmo_sub_pel_search.restype = C.c_int64
+L.jmo_compute_sad.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]
+L.jmo_compute_satd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]
+L.jmo_sub_images_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_long]
+L.jmo_ffs_search.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, MV, MV, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]
+L.jmo_ffs_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, MV, C.c_int, C.c_void_p]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class RefPic:
+    """A reference picture with its 16 quarter-pel planes (getSubImagesLuma)."""
+
+    def __init__(self, luma, max_pel=255):
+        luma = np.ascontiguousarray(luma, dtype=np.uint16)
+        self.h, self.w = luma.shape
+        self.pitch = self.w + 2 * PAD_X
+        self.hp = self.h + 2 * PAD_Y
+        self.planes = np.zeros((16, self.hp, self.pitch), np.uint16)
+        L.jmo_sub_images_luma(_p(luma), self.w, self.w, self.h, max_pel, _p(self.planes), self.pitch,
+                              self.hp * self.pitch)
+        self.s = RefPicS(self.w, self.h, self.pitch)
+        base = self.planes.ctypes.data
+        for j in range(4):
+            for i in range(4):
+                off = ((j * 4 + i) * self.hp * self.pitch + PAD_Y * self.pitch + PAD_X) * 2
+                self.s.sub[j][i] = C.cast(base + off, C.POINTER(C.c_uint16))
+
+    def ptr(self):
+        return C.byref(self.s)
+
+    def planes_u8(self):
+        return self.planes.astype(np.uint8)
+
+
+def block_of(cur, x, y, w, h):
+    return np.ascontiguousarray(cur[y:y + h, x:x + w], dtype=np.uint16)
+
+
+def full_search(ref, cur, pos_x, pos_y, bsx, bsy, pred, center, R, lam, min_mcost=DIST_MAX):
+    job = FsJob(pos_x, pos_y, bsx, bsy, MV(*pred), MV(*center), R, lam, min_mcost)
+    orig = block_of(cur, pos_x, pos_y, bsx, bsy)
+    evals = C.c_long(0)
+    cost = L.jmo_full_search(ref.ptr(), _p(orig), C.byref(job), C.byref(evals))
+    return (job.center.x, job.center.y), cost, evals.value
+
+
+def sub_pel_search(ref, cur, pos_x, pos_y, bsx, bsy, pred, mv, lam_h, lam_q, metric_h, metric_q,
+                   start_hp, start_qp, test8x8, min_mcost):
+    job = SubpelJob(pos_x, pos_y, bsx, bsy, MV(*pred), MV(*mv), lam_h, lam_q, metric_h, metric_q,
+                    start_hp, start_qp, test8x8, min_mcost)
+    orig = block_of(cur, pos_x, pos_y, bsx, bsy)
+    cost = L.jmo_sub_pel_search(ref.ptr(), _p(orig), C.byref(job))
+    return (job.mv.x, job.mv.y), cost
+
+
+def ffs_setup(ref, cur, mb_x, mb_y, center, R):
+    max_pos = (2 * R + 1) ** 2
+    tab = np.zeros((8, 16, max_pos), np.uint32)
+    mb = block_of(cur, mb_x, mb_y, 16, 16)
+    L.jmo_ffs_setup(ref.ptr(), _p(mb), mb_x, mb_y, MV(*center), R, _p(tab))
+    return tab
+
+
+def ffs_search(tab, blocktype, block_index, center, pred, R, lam, max_mvd, min_mcost=DIST_MAX):
+    best = MV(0, 0)
+    cost = L.jmo_ffs_search(_p(tab), tab.shape[2], blocktype, block_index, MV(*center), MV(*pred), R, lam,
+                            max_mvd, min_mcost, C.byref(best))
+    return (best.x, best.y), cost
+
+
+def spiral(R):
+    n = max(9, (2 * R + 1) ** 2)
+    a = np.zeros((n, 2), np.int16)
+    L.jmo_spiral(R, _p(a))
+    return a
+
+
+def forward4x4(x):
+    x = np.ascontiguousarray(x, np.int32); o = np.zeros(16, np.int32); L.jmo_forward4x4(_p(x), _p(o)); return o
+
+
+def inverse4x4(x):
+    x = np.ascontiguousarray(x, np.int32); o = np.zeros(16, np.int32); L.jmo_inverse4x4(_p(x), _p(o)); return o
+
+
+def forward8x8(x):
+    x = np.ascontiguousarray(x, np.int32); o = np.zeros(64, np.int32); L.jmo_forward8x8(_p(x), _p(o)); return o
+
+
+def inverse8x8(x):
+    x = np.ascontiguousarray(x, np.int32); o = np.zeros(64, np.int32); L.jmo_inverse8x8(_p(x), _p(o)); return o
+
+
+def scan4x4():
+    return np.ctypeslib.as_array((C.c_uint8 * 32).in_dll(L, "JMO_SNGL_SCAN")).copy()
+
+
+def coeff_cost4x4(k=0):
+    return np.ctypeslib.as_array((C.c_uint8 * 48).in_dll(L, "JMO_COEFF_COST4x4")).reshape(3, 16)[k].copy()
+
+
+def quant_4x4(tblock, qparams, qp_per, cavlc, around=False, arw=0):
+    """qparams: (16,3) int32 [OffsetComp, ScaleComp, InvScaleComp] at [j*4+i]."""
+    tb = np.ascontiguousarray(tblock, np.int32).copy()
+    q = np.ascontiguousarray(qparams, np.int32)
+    level = np.zeros(17, np.int32); run = np.zeros(17, np.int32); cost = C.c_int(0)
+    fadj = np.zeros(16, np.int32)
+    sc, cc = scan4x4(), coeff_cost4x4(0)
+    if around:
+        nz = L.jmo_quant_4x4_around(_p(tb), _p(q), qp_per, cavlc, _p(sc), _p(cc), arw, _p(level), _p(run),
+                                    C.byref(cost), _p(fadj))
+    else:
+        nz = L.jmo_quant_4x4_normal(_p(tb), _p(q), qp_per, cavlc, _p(sc), _p(cc), _p(level), _p(run), C.byref(cost))
+    return tb, level, run, cost.value, nz, fadj
+
+
+def qparams_4x4(qp, intra, offset):
+    q = np.zeros((16, 3), np.int32)
+    L.jmo_qparams_4x4(qp, intra, offset, _p(q))
+    return q
+
+
+def deblock_frame(y, u, v, fmt, mbs, mot, maxy=255, maxc=255, d8=1):
+    """y,u,v uint8/uint16 planes (copied); mbs (N,12) int array in ref_tap order; mot (H/4,W/4,2,3)."""
+    Y = np.ascontiguousarray(y, np.uint16).copy()
+    U = np.ascontiguousarray(u, np.uint16).copy() if u is not None else None
+    V = np.ascontiguousarray(v, np.uint16).copy() if v is not None else None
+    h, w = Y.shape
+    n = mbs.shape[0]
+    arr = (DbMb * n)()
+    for i in range(n):
+        m = mbs[i]
+        arr[i] = DbMb(int(m[0]), int(m[1]), int(m[2]), (C.c_int16 * 2)(int(m[3]), int(m[4])), int(m[5]),
+                      int(m[6]) & 0xFFFF, int(m[7]), int(m[8]), int(m[9]), int(m[10]), int(m[11]), 0)
+    mo = np.zeros((h // 4, w // 4, 4), np.int32)      # packs {int16 mv[2][2]; int32 ref_id[2]} = 16 bytes
+    mv = mot[:, :, :, 0:2].astype(np.int16)            # [y][x][list][xy]
+    mo_bytes = np.zeros((h // 4, w // 4, 16), np.uint8)
+    mo_bytes[:, :, 0:8] = mv.reshape(h // 4, w // 4, 4).view(np.uint8).reshape(h // 4, w // 4, 8)
+    mo_bytes[:, :, 8:16] = mot[:, :, :, 2].astype(np.int32).reshape(h // 4, w // 4, 2).view(np.uint8).reshape(h // 4, w // 4, 8)
+    mo_bytes = np.ascontiguousarray(mo_bytes)
+    L.jmo_deblock_frame(_p(Y), w, _p(U) if U is not None else None, _p(V) if V is not None else None,
+                        U.shape[1] if U is not None else 0, w, h, fmt, arr, _p(mo_bytes), maxy, maxc, d8)
+    return Y, U, V

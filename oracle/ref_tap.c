@@ -1,0 +1,326 @@
+/*
+ * oracle/ref_tap.c -- TEST INFRASTRUCTURE: taps on the REAL reference encoder.
+ *
+ * Linked (by oracle/Makefile.ref, target `tap`) together with the unmodified JM 19.0
+ * lencod objects using GNU ld's --wrap, this file intercepts the reference's own
+ * hot-path entry points while the real encoder runs a real configuration, and dumps
+ * their inputs and outputs.  tests/golden/make_golden.py turns the dumps into the
+ * small committed fixtures that pin the oracle (and, through it, the HIP kernels).
+ *
+ * It is our own code written against JM's public headers; it contains no reference
+ * source.  It only builds where /root/reference is present and only into oracle/_ref/.
+ *
+ * Tapped (reference file:line):
+ *   full_search_motion_estimation      lencod/src/me_fullsearch.c:39
+ *   sub_pel_motion_estimation          lencod/src/me_fullsearch.c:186
+ *   setup_fast_full_search             lencod/src/me_fullfast.c:269
+ *   fast_full_search_motion_estimation lencod/src/me_fullfast.c:618
+ *   getSubImagesLuma                   lencod/src/img_luma.c:611
+ *   DeblockFrame                       lencod/src/loopFilter.c:63
+ *   forward4x4 / inverse4x4            lcommon/src/transform.c:20 / :70
+ *   quant_4x4_normal / quant_4x4_around  lencod/src/quant4x4_normal.c:39 / quant4x4_around.c:40
+ *   sample_reconstruct                 lcommon/src/blk_prediction.c:48
+ * Output directory: $JM_TAP_DIR (default "."); record budget: $JM_TAP_MAX (default 6000 per stream).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "global.h"
+#include "image.h"
+#include "mbuffer.h"
+#include "mv_search.h"
+#include "me_fullsearch.h"
+#include "me_fullfast.h"
+#include "transform.h"
+#include "quant4x4.h"
+#include "blk_prediction.h"
+#include "loop_filter.h"
+#include "img_luma.h"
+
+static FILE *tap_open(const char *name)
+{
+  char path[1024];
+  const char *d = getenv("JM_TAP_DIR");
+  snprintf(path, sizeof path, "%s/%s", d ? d : ".", name);
+  return fopen(path, "ab");
+}
+static int tap_max(void) { const char *m = getenv("JM_TAP_MAX"); return m ? atoi(m) : 6000; }
+static void put_i32(FILE *f, int v) { int32_t x = v; fwrite(&x, 4, 1, f); }
+static void put_i64(FILE *f, int64 v) { int64_t x = v; fwrite(&x, 8, 1, f); }
+static void put_plane(FILE *f, imgpel **rows, int y0, int x0, int h, int w)
+{
+  int y;
+  put_i32(f, h); put_i32(f, w);
+  for (y = 0; y < h; y++) fwrite(&rows[y0 + y][x0], sizeof(imgpel), (size_t)w, f);
+}
+
+static int g_refs_made = 0;        /* number of getSubImagesLuma calls so far = reference pictures produced */
+static int g_cur_dumped = -1;
+
+static void dump_cur_frame(VideoParameters *p_Vid)
+{
+  if (g_cur_dumped != g_refs_made) {
+    FILE *f = tap_open("cur_frames.bin");
+    put_i32(f, g_refs_made);
+    put_plane(f, p_Vid->pCurImg, 0, 0, p_Vid->height, p_Vid->width);
+    fclose(f);
+    g_cur_dumped = g_refs_made;
+  }
+}
+
+/* ------------------------------------------------------------------ ME: full search */
+extern distblk __real_full_search_motion_estimation(Macroblock *, MotionVector *, MEBlock *, distblk, int);
+distblk __wrap_full_search_motion_estimation(Macroblock *currMB, MotionVector *pred_mv, MEBlock *mv_block,
+                                             distblk min_mcost, int lambda_factor)
+{
+  static int n = 0;
+  MotionVector c = mv_block->mv[(int)mv_block->list];
+  distblk r = __real_full_search_motion_estimation(currMB, pred_mv, mv_block, min_mcost, lambda_factor);
+  if (n < tap_max()) {
+    FILE *f = tap_open("me_fs.bin");
+    dump_cur_frame(currMB->p_Vid);
+    put_i32(f, g_refs_made); put_i32(f, mv_block->ref_idx); put_i32(f, mv_block->blocktype);
+    put_i32(f, mv_block->pos_x); put_i32(f, mv_block->pos_y);
+    put_i32(f, mv_block->blocksize_x); put_i32(f, mv_block->blocksize_y);
+    put_i32(f, pred_mv->mv_x); put_i32(f, pred_mv->mv_y);
+    put_i32(f, c.mv_x); put_i32(f, c.mv_y);
+    put_i32(f, imin(mv_block->searchRange.max_x, mv_block->searchRange.max_y) >> 2);
+    put_i32(f, lambda_factor);
+    put_i64(f, min_mcost);
+    put_i32(f, mv_block->mv[(int)mv_block->list].mv_x); put_i32(f, mv_block->mv[(int)mv_block->list].mv_y);
+    put_i64(f, r);
+    fclose(f); n++;
+  }
+  return r;
+}
+
+/* ------------------------------------------------------------------ ME: sub-pel */
+extern distblk __real_sub_pel_motion_estimation(Macroblock *, MotionVector *, MEBlock *, distblk, int *);
+distblk __wrap_sub_pel_motion_estimation(Macroblock *currMB, MotionVector *pred, MEBlock *mv_block,
+                                         distblk min_mcost, int *lambda)
+{
+  static int n = 0;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  MotionVector in = mv_block->mv[(int)mv_block->list];
+  distblk r = __real_sub_pel_motion_estimation(currMB, pred, mv_block, min_mcost, lambda);
+  if (n < tap_max()) {
+    FILE *f = tap_open("me_subpel.bin");
+    dump_cur_frame(p_Vid);
+    put_i32(f, g_refs_made); put_i32(f, mv_block->ref_idx); put_i32(f, mv_block->blocktype);
+    put_i32(f, mv_block->pos_x); put_i32(f, mv_block->pos_y);
+    put_i32(f, mv_block->blocksize_x); put_i32(f, mv_block->blocksize_y);
+    put_i32(f, pred->mv_x); put_i32(f, pred->mv_y);
+    put_i32(f, in.mv_x); put_i32(f, in.mv_y);
+    put_i32(f, lambda[H_PEL]); put_i32(f, lambda[Q_PEL]);
+    put_i32(f, p_Vid->p_Inp->MEErrorMetric[H_PEL]); put_i32(f, p_Vid->p_Inp->MEErrorMetric[Q_PEL]);
+    put_i32(f, p_Vid->start_me_refinement_hp); put_i32(f, p_Vid->start_me_refinement_qp);
+    put_i32(f, mv_block->test8x8);
+    put_i64(f, min_mcost);
+    put_i32(f, mv_block->mv[(int)mv_block->list].mv_x); put_i32(f, mv_block->mv[(int)mv_block->list].mv_y);
+    put_i64(f, r);
+    fclose(f); n++;
+  }
+  return r;
+}
+
+/* ------------------------------------------------------------------ ME: fast full search */
+extern void __real_setup_fast_full_search(Macroblock *, MEBlock *, int);
+void __wrap_setup_fast_full_search(Macroblock *currMB, MEBlock *mv_block, int list)
+{
+  static int n = 0;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  __real_setup_fast_full_search(currMB, mv_block, list);
+  if (n < 40) {                                  /* tables are big: 7*16*max_pos u32 each */
+    MEFullFast *ff = p_Vid->p_ffast_me;
+    int ref = mv_block->ref_idx, R = ff->max_search_range[list][ref];
+    int max_pos = (2 * R + 1) * (2 * R + 1), t, k;
+    FILE *f = tap_open("me_ffs_setup.bin");
+    dump_cur_frame(p_Vid);
+    put_i32(f, g_refs_made); put_i32(f, ref); put_i32(f, currMB->pix_x); put_i32(f, currMB->opix_y);
+    put_i32(f, ff->search_center[list][ref].mv_x); put_i32(f, ff->search_center[list][ref].mv_y);
+    put_i32(f, R); put_i32(f, max_pos);
+    for (t = 1; t < 8; t++)
+      for (k = 0; k < 16; k++)
+        fwrite(ff->BlockSAD[list][ref][t][k], sizeof(distpel), (size_t)max_pos, f);
+    fclose(f); n++;
+  }
+}
+extern distblk __real_fast_full_search_motion_estimation(Macroblock *, MotionVector *, MEBlock *, distblk, int);
+distblk __wrap_fast_full_search_motion_estimation(Macroblock *currMB, MotionVector *pred_mv, MEBlock *mv_block,
+                                                  distblk min_mcost, int lambda_factor)
+{
+  static int n = 0;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  distblk r = __real_fast_full_search_motion_estimation(currMB, pred_mv, mv_block, min_mcost, lambda_factor);
+  if (n < tap_max()) {
+    int list = mv_block->list, ref = mv_block->ref_idx;
+    FILE *f = tap_open("me_ffs.bin");
+    dump_cur_frame(p_Vid);
+    put_i32(f, g_refs_made); put_i32(f, ref); put_i32(f, mv_block->blocktype);
+    put_i32(f, currMB->pix_x); put_i32(f, currMB->opix_y);
+    put_i32(f, mv_block->block_x); put_i32(f, mv_block->block_y);
+    put_i32(f, pred_mv->mv_x); put_i32(f, pred_mv->mv_y);
+    put_i32(f, p_Vid->p_ffast_me->search_center[list][ref].mv_x); put_i32(f, p_Vid->p_ffast_me->search_center[list][ref].mv_y);
+    put_i32(f, imax(mv_block->searchRange.max_x, mv_block->searchRange.max_y) >> 2);
+    put_i32(f, p_Vid->p_ffast_me->max_search_range[list][ref]);
+    put_i32(f, lambda_factor); put_i32(f, p_Vid->max_mvd);
+    put_i64(f, min_mcost);
+    put_i32(f, mv_block->mv[list].mv_x); put_i32(f, mv_block->mv[list].mv_y);
+    put_i64(f, r);
+    fclose(f); n++;
+  }
+  return r;
+}
+
+/* ------------------------------------------------------------------ sub-pel planes */
+extern void __real_getSubImagesLuma(VideoParameters *, StorablePicture *);
+void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
+{
+  __real_getSubImagesLuma(p_Vid, s);
+  if (g_refs_made < 4) {
+    FILE *f = tap_open("subimages.bin");
+    int j, i;
+    put_i32(f, g_refs_made); put_i32(f, s->size_x); put_i32(f, s->size_y); put_i32(f, p_Vid->max_imgpel_value);
+    put_plane(f, s->imgY, 0, 0, s->size_y, s->size_x);
+    for (j = 0; j < 4; j++)
+      for (i = 0; i < 4; i++)
+        put_plane(f, s->p_curr_img_sub[j][i], -IMG_PAD_SIZE_Y, -IMG_PAD_SIZE_X, s->size_y_padded, s->size_x_padded);
+    fclose(f);
+  }
+  g_refs_made++;
+}
+
+/* ------------------------------------------------------------------ deblocking */
+extern void __real_DeblockFrame(VideoParameters *, imgpel **, imgpel ***);
+void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
+{
+  static int n = 0;
+  FILE *f = NULL;
+  int cw = p_Vid->width_cr, chh = p_Vid->height_cr;
+  if (n < 4) {
+    unsigned i; int y, x;
+    StorablePicture *ids[64]; int nids = 0;
+    f = tap_open("deblock.bin");
+    put_i32(f, n); put_i32(f, p_Vid->width); put_i32(f, p_Vid->height); put_i32(f, p_Vid->yuv_format);
+    put_i32(f, p_Vid->max_pel_value_comp[0]); put_i32(f, p_Vid->max_pel_value_comp[1]);
+    put_i32(f, p_Vid->active_sps->direct_8x8_inference_flag);
+    put_i32(f, (int)p_Vid->PicSizeInMbs);
+    for (i = 0; i < p_Vid->PicSizeInMbs; i++) {
+      Macroblock *m = &p_Vid->mb_data[i];
+      put_i32(f, m->mb_type); put_i32(f, m->p_Slice->slice_type); put_i32(f, m->qp);
+      put_i32(f, m->qpc[0]); put_i32(f, m->qpc[1]); put_i32(f, m->cbp);
+      put_i32(f, (int)(m->cbp_blk & 0xFFFF)); put_i32(f, m->slice_nr); put_i32(f, m->DFDisableIdc);
+      put_i32(f, m->DFAlphaC0Offset); put_i32(f, m->DFBetaOffset); put_i32(f, m->luma_transform_size_8x8_flag);
+    }
+    for (y = 0; y < p_Vid->height / 4; y++)
+      for (x = 0; x < p_Vid->width / 4; x++) {
+        PicMotionParams *mp = &p_Vid->enc_picture->mv_info[y][x];
+        int l;
+        for (l = 0; l < 2; l++) {
+          int id = -1;
+          if (mp->ref_idx[l] != -1) {
+            int k; for (k = 0; k < nids; k++) if (ids[k] == mp->ref_pic[l]) break;
+            if (k == nids && nids < 64) ids[nids++] = mp->ref_pic[l];
+            id = k;
+          }
+          put_i32(f, mp->mv[l].mv_x); put_i32(f, mp->mv[l].mv_y); put_i32(f, id);
+        }
+      }
+    put_plane(f, imgY, 0, 0, p_Vid->height, p_Vid->width);
+    if (p_Vid->yuv_format != YUV400) { put_plane(f, imgUV[0], 0, 0, chh, cw); put_plane(f, imgUV[1], 0, 0, chh, cw); }
+  }
+  __real_DeblockFrame(p_Vid, imgY, imgUV);
+  if (f) {
+    put_plane(f, imgY, 0, 0, p_Vid->height, p_Vid->width);
+    if (p_Vid->yuv_format != YUV400) { put_plane(f, imgUV[0], 0, 0, chh, cw); put_plane(f, imgUV[1], 0, 0, chh, cw); }
+    fclose(f);
+  }
+  n++;
+}
+
+/* ------------------------------------------------------------------ transform / quant / reconstruct */
+extern void __real_forward4x4(int **, int **, int, int);
+void __wrap_forward4x4(int **block, int **tblock, int pos_y, int pos_x)
+{
+  static int n = 0;
+  int in[16], j, i;
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[j * 4 + i] = block[pos_y + j][pos_x + i];
+  __real_forward4x4(block, tblock, pos_y, pos_x);
+  if (n < tap_max() && (n % 7) == 0) {
+    FILE *f = tap_open("fwd4x4.bin");
+    for (j = 0; j < 16; j++) put_i32(f, in[j]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, tblock[pos_y + j][pos_x + i]);
+    fclose(f);
+  }
+  n++;
+}
+extern void __real_inverse4x4(int **, int **, int, int);
+void __wrap_inverse4x4(int **tblock, int **block, int pos_y, int pos_x)
+{
+  static int n = 0;
+  int in[16], j, i;
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[j * 4 + i] = tblock[pos_y + j][pos_x + i];
+  __real_inverse4x4(tblock, block, pos_y, pos_x);
+  if (n < tap_max() && (n % 7) == 0) {
+    FILE *f = tap_open("inv4x4.bin");
+    for (j = 0; j < 16; j++) put_i32(f, in[j]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, block[pos_y + j][pos_x + i]);
+    fclose(f);
+  }
+  n++;
+}
+
+static void tap_quant4x4(const char *name, int around, Macroblock *currMB, int **tblock, struct quant_methods *q,
+                         int (*real)(Macroblock *, int **, struct quant_methods *), int *ret)
+{
+  static int n[2] = {0, 0};
+  VideoParameters *p_Vid = currMB->p_Vid;
+  int in[16], j, i, cost_in = *q->coeff_cost, bx = q->block_x;
+  int qp_per = p_Vid->p_Quant->qp_per_matrix[q->qp];
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[j * 4 + i] = tblock[j][bx + i];
+  *ret = real(currMB, tblock, q);
+  if (n[around] < tap_max() && (n[around] % 5) == 0) {
+    FILE *f = tap_open(name);
+    put_i32(f, q->qp); put_i32(f, qp_per); put_i32(f, currMB->p_Slice->symbol_mode == CAVLC);
+    put_i32(f, p_Vid->AdaptRndWeight);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) {
+      put_i32(f, q->q_params[j][i].OffsetComp); put_i32(f, q->q_params[j][i].ScaleComp); put_i32(f, q->q_params[j][i].InvScaleComp);
+    }
+    for (j = 0; j < 16; j++) put_i32(f, in[j]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, tblock[j][bx + i]);
+    for (j = 0; j < 17; j++) put_i32(f, q->ACLevel[j]);       /* valid up to the 0 terminator */
+    for (j = 0; j < 17; j++) put_i32(f, q->ACRun[j]);
+    put_i32(f, *q->coeff_cost - cost_in); put_i32(f, *ret);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, around ? q->fadjust[j][bx + i] : 0);
+    fclose(f);
+  }
+  n[around]++;
+}
+extern int __real_quant_4x4_normal(Macroblock *, int **, struct quant_methods *);
+int __wrap_quant_4x4_normal(Macroblock *currMB, int **tblock, struct quant_methods *q)
+{
+  int r; tap_quant4x4("quant4x4_normal.bin", 0, currMB, tblock, q, __real_quant_4x4_normal, &r); return r;
+}
+extern int __real_quant_4x4_around(Macroblock *, int **, struct quant_methods *);
+int __wrap_quant_4x4_around(Macroblock *currMB, int **tblock, struct quant_methods *q)
+{
+  int r; tap_quant4x4("quant4x4_around.bin", 1, currMB, tblock, q, __real_quant_4x4_around, &r); return r;
+}
+
+extern void __real_sample_reconstruct(imgpel **, imgpel **, int **, int, int, int, int, int, int);
+void __wrap_sample_reconstruct(imgpel **curImg, imgpel **mpr, int **mb_rres, int mb_x, int opix_x,
+                               int width, int height, int max_imgpel_value, int dq_bits)
+{
+  static int n = 0;
+  __real_sample_reconstruct(curImg, mpr, mb_rres, mb_x, opix_x, width, height, max_imgpel_value, dq_bits);
+  if (n < tap_max() && width == 4 && height == 4 && (n % 5) == 0) {
+    FILE *f = tap_open("recon4x4.bin");
+    int j, i;
+    put_i32(f, max_imgpel_value); put_i32(f, dq_bits);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, mpr[j][mb_x + i]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, mb_rres[j][mb_x + i]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, curImg[j][opix_x + i]);
+    fclose(f);
+  }
+  n++;
+}

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the REAL reference encoder.
+
+Runs in the build container only (needs /root/reference and oracle/_ref/, built by
+`make -C oracle ref`).  It executes the unmodified JM 19.0 lencod -- plain and with the
+--wrap taps of oracle/ref_tap.c -- on the reference's own sample clips and configs, and
+stores what the reference's hot-path functions were given and what they returned:
+
+  tests/golden/qcif_fs.npz    FullSearch SR=16, 1 ref, baseline cfg: full_search / sub_pel ME
+                              call records, sub-pel plane digests, deblock in/out, 4x4
+                              transform / quant / reconstruct records
+  tests/golden/qcif_ffs.npz   FastFullSearch SR=16: BlockSAD tables + argmin records
+  tests/golden/qcif_422.npz   High 4:2:2, 8x8 transform, CABAC: deblock in/out (intra + inter)
+  tests/golden/qcif_main.npz  Main profile with a B frame: deblock in/out (two-list strengths)
+  tests/golden/md5.json       .264 / recon md5 of the BASELINE.json configurations at QCIF
+
+Fixtures are data only (inputs and expected outputs); no reference source is stored.
+"""
+import hashlib, json, os, shutil, subprocess, sys, tempfile
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference/bin"
+EXE = os.path.join(ROOT, "oracle/_ref/lencod.exe")
+TAP = os.path.join(ROOT, "oracle/_ref/lencod_tap.exe")
+DEC = os.path.join(ROOT, "oracle/_ref/ldecod.exe")
+OUT = os.path.join(ROOT, "tests/golden")
+
+
+def run(exe, cfg, overrides, workdir, tap=False, tap_max=6000):
+    # run as JM users do: from a directory holding the reference's cfg / yuv files (q_offset.cfg
+    # and friends are opened relative to the cwd), here a scratch dir of symlinks to them
+    for f in os.listdir(REF):
+        if not os.path.exists(os.path.join(workdir, f)):
+            os.symlink(os.path.join(REF, f), os.path.join(workdir, f))
+    args = [exe, "-d", cfg]
+    ov = dict(OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null")
+    ov.update(overrides)
+    for k, v in ov.items():
+        args += ["-p", f"{k}={v}"]
+    env = dict(os.environ)
+    if tap:
+        env["JM_TAP_DIR"] = workdir
+        env["JM_TAP_MAX"] = str(tap_max)
+    r = subprocess.run(args, cwd=workdir, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return ov
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+class Reader:
+    def __init__(self, path):
+        self.b = open(path, "rb").read() if os.path.exists(path) else b""
+        self.o = 0
+
+    def eof(self):
+        return self.o >= len(self.b)
+
+    def i32(self, n=1):
+        a = np.frombuffer(self.b, np.int32, n, self.o)
+        self.o += 4 * n
+        return a if n > 1 else int(a[0])
+
+    def i64(self):
+        a = np.frombuffer(self.b, np.int64, 1, self.o)
+        self.o += 8
+        return int(a[0])
+
+    def plane(self):
+        h, w = self.i32(), self.i32()
+        a = np.frombuffer(self.b, np.uint16, h * w, self.o).reshape(h, w)
+        self.o += 2 * h * w
+        return a
+
+
+def read_me(path, n32a, n32b):
+    """records: n32a int32, one int64 (min_mcost in), n32b int32 (mv out), one int64 (cost)."""
+    r, rows = Reader(path), []
+    while not r.eof():
+        a = list(r.i32(n32a)); mc = r.i64(); b = list(r.i32(n32b)); c = r.i64()
+        rows.append(a + [mc] + b + [c])
+    return np.array(rows, np.int64)
+
+
+def read_cur(path):
+    r, out = Reader(path), {}
+    while not r.eof():
+        k = r.i32(); out[k] = r.plane().astype(np.uint8)
+    return out
+
+
+def read_subimages(path):
+    r, out = Reader(path), []
+    while not r.eof():
+        idx, w, h, maxv = r.i32(), r.i32(), r.i32(), r.i32()
+        src = r.plane()
+        planes = [r.plane() for _ in range(16)]
+        out.append(dict(idx=idx, w=w, h=h, maxv=maxv, src=src.astype(np.uint8),
+                        sha=[hashlib.sha256(p.astype(np.uint8).tobytes()).hexdigest() for p in planes],
+                        planes=planes))
+    return out
+
+
+def read_deblock(path):
+    r, out = Reader(path), []
+    while not r.eof():
+        n, w, h, fmt, maxy, maxc, d8, nmb = [r.i32() for _ in range(8)]
+        mbs = r.i32(12 * nmb).reshape(nmb, 12).copy()
+        mot = r.i32((h // 4) * (w // 4) * 6).reshape(h // 4, w // 4, 2, 3).copy()
+        pre = [r.plane().astype(np.uint8)]
+        if fmt != 0:
+            pre += [r.plane().astype(np.uint8), r.plane().astype(np.uint8)]
+        post = [r.plane().astype(np.uint8)]
+        if fmt != 0:
+            post += [r.plane().astype(np.uint8), r.plane().astype(np.uint8)]
+        out.append(dict(n=n, w=w, h=h, fmt=fmt, maxy=maxy, maxc=maxc, d8=d8, mbs=mbs, mot=mot, pre=pre, post=post))
+    return out
+
+
+def read_i32_records(path, width):
+    if not os.path.exists(path):
+        return np.zeros((0, width), np.int32)
+    a = np.fromfile(path, np.int32)
+    return a.reshape(-1, width)
+
+
+def deblock_arrays(prefix, recs, d):
+    for i, r in enumerate(recs):
+        p = f"{prefix}{i}_"
+        d[p + "hdr"] = np.array([r["w"], r["h"], r["fmt"], r["maxy"], r["maxc"], r["d8"]], np.int32)
+        d[p + "mbs"] = r["mbs"].astype(np.int32)
+        d[p + "mot"] = r["mot"].astype(np.int32)
+        for k, nm in enumerate("yuv"[: len(r["pre"])]):
+            d[p + "pre_" + nm] = r["pre"][k]
+            d[p + "post_" + nm] = r["post"][k]
+
+
+def main():
+    md5s = {}
+    tmp = tempfile.mkdtemp(prefix="jmgold_")
+    try:
+        # ---- A: full search, 1 reference, 2 frames (I, P)
+        wa = os.path.join(tmp, "A"); os.makedirs(wa)
+        ov = dict(SearchMode=-1, SearchRange=16, NumberReferenceFrames=1, FramesToBeEncoded=2)
+        run(TAP, "encoder_baseline.cfg", ov, wa, tap=True)
+        tapped = md5(os.path.join(wa, "o.264"))
+        wa2 = os.path.join(tmp, "A2"); os.makedirs(wa2)
+        run(EXE, "encoder_baseline.cfg", ov, wa2)
+        assert tapped == md5(os.path.join(wa2, "o.264")), "taps changed the bitstream"
+        d = {}
+        cur = read_cur(os.path.join(wa, "cur_frames.bin"))
+        for k, v in cur.items():
+            d[f"cur{k}"] = v
+        subs = read_subimages(os.path.join(wa, "subimages.bin"))
+        for s in subs:
+            d[f"ref{s['idx']}_src"] = s["src"]
+            d[f"ref{s['idx']}_sha"] = np.array(s["sha"])
+        # one full set of planes, sparsely sampled, for quick localisation of a mismatch
+        d["ref0_plane_rows"] = np.stack([p[::23].astype(np.uint8) for p in subs[0]["planes"]])
+        d["me_fs"] = read_me(os.path.join(wa, "me_fs.bin"), 13, 2)
+        d["me_subpel"] = read_me(os.path.join(wa, "me_subpel.bin"), 18, 2)
+        deblock_arrays("db", read_deblock(os.path.join(wa, "deblock.bin")), d)
+        d["fwd4x4"] = read_i32_records(os.path.join(wa, "fwd4x4.bin"), 32)
+        d["inv4x4"] = read_i32_records(os.path.join(wa, "inv4x4.bin"), 32)
+        d["quant4x4_around"] = read_i32_records(os.path.join(wa, "quant4x4_around.bin"), 136)
+        d["recon4x4"] = read_i32_records(os.path.join(wa, "recon4x4.bin"), 50)
+        np.savez_compressed(os.path.join(OUT, "qcif_fs.npz"), **d)
+
+        # ---- A3: same without adaptive rounding -> quant_4x4_normal records
+        wa3 = os.path.join(tmp, "A3"); os.makedirs(wa3)
+        run(TAP, "encoder_baseline.cfg", dict(ov, AdaptiveRounding=0), wa3, tap=True)
+        qn = read_i32_records(os.path.join(wa3, "quant4x4_normal.bin"), 136)
+
+        # ---- B: fast full search
+        wb = os.path.join(tmp, "B"); os.makedirs(wb)
+        run(TAP, "encoder_baseline.cfg", dict(ov, SearchMode=0), wb, tap=True)
+        d = {"quant4x4_normal": qn}
+        for k, v in read_cur(os.path.join(wb, "cur_frames.bin")).items():
+            d[f"cur{k}"] = v
+        for s in read_subimages(os.path.join(wb, "subimages.bin")):
+            d[f"ref{s['idx']}_src"] = s["src"]
+        r, setups, tables = Reader(os.path.join(wb, "me_ffs_setup.bin")), [], []
+        while not r.eof():
+            hdr = list(r.i32(8))
+            tab = np.frombuffer(r.b, np.uint32, 7 * 16 * hdr[7], r.o).reshape(7, 16, hdr[7]); r.o += 4 * tab.size
+            setups.append(hdr + [int(hashlib.sha256(tab.astype(np.uint16).tobytes()).hexdigest()[:12], 16)])
+            tables.append(tab.astype(np.uint16))
+        d["ffs_setup"] = np.array(setups, np.int64)
+        d["ffs_table0"] = tables[0]
+        d["ffs_table7"] = tables[7]
+        d["me_ffs"] = read_me(os.path.join(wb, "me_ffs.bin"), 15, 2)
+        np.savez_compressed(os.path.join(OUT, "qcif_ffs.npz"), **d)
+
+        # ---- C: High 4:2:2, 8x8 transform (encoder_yuv422.cfg) -> deblock
+        wc = os.path.join(tmp, "C"); os.makedirs(wc)
+        run(TAP, "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2), wc, tap=True)
+        d = {}
+        deblock_arrays("db", read_deblock(os.path.join(wc, "deblock.bin")), d)
+        np.savez_compressed(os.path.join(OUT, "qcif_422.npz"), **d)
+
+        # ---- E: Main profile with B frames -> deblock with two lists
+        we = os.path.join(tmp, "E"); os.makedirs(we)
+        run(TAP, "encoder_main.cfg", dict(FramesToBeEncoded=3), we, tap=True)
+        d = {}
+        deblock_arrays("db", read_deblock(os.path.join(we, "deblock.bin")), d)
+        np.savez_compressed(os.path.join(OUT, "qcif_main.npz"), **d)
+
+        # ---- md5 goldens of whole-encoder runs
+        runs = {
+            "G0": ("encoder_baseline.cfg", {}),
+            "G1": ("encoder_baseline.cfg", dict(SearchMode=-1, SearchRange=16)),
+            "G1_1ref_2frames": ("encoder_baseline.cfg", ov),
+            "G3a": ("encoder_main.cfg", dict(SearchMode=3)),
+            "G3b": ("encoder_main.cfg", dict(SearchMode=3, Transform8x8Mode=1, ProfileIDC=100)),
+            "G4q": ("encoder_baseline.cfg", dict(SearchMode=-1, SearchRange=16, SliceMode=1, SliceArgument=33, AdaptiveRounding=0)),
+            "G5": ("encoder_yuv422.cfg", dict(NumberBFrames=0)),
+        }
+        for tag, (cfg, o) in runs.items():
+            w = os.path.join(tmp, tag); os.makedirs(w)
+            run(EXE, cfg, o, w)
+            md5s[tag] = dict(cfg=cfg, overrides={k: str(v) for k, v in o.items()},
+                             md5_264=md5(os.path.join(w, "o.264")), md5_recon=md5(os.path.join(w, "o_rec.yuv")),
+                             bytes_264=os.path.getsize(os.path.join(w, "o.264")))
+        json.dump(md5s, open(os.path.join(OUT, "md5.json"), "w"), indent=1, sort_keys=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
