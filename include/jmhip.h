@@ -1,0 +1,236 @@
+/*
+ * jmhip.h -- C ABI of libjmhip: the MI355X (gfx950) implementation of JM 19.0 lencod's
+ * data-parallel inner loop (integer / sub-pel motion estimation, 4x4 integer transform +
+ * quantisation + reconstruction, sub-pel reference planes, in-loop deblocking).
+ *
+ * Plain C: opaque context, POD structs, pointers and sizes.  No C++/torch types.  The
+ * library owns all device memory; the caller owns every host buffer.  Every entry point
+ * returns 0 on success or a negative JMHIP_E* code, and never calls exit(); the message is
+ * available from jmhip_last_error().  One host thread per context; all work of a context is
+ * issued on one HIP stream (the caller's, if given at creation).  Entry points taking host
+ * buffers are synchronous (they return after the results are in the host buffer); the
+ * `_dev` twins take device pointers, enqueue on the context's stream and return at once.
+ *
+ * There is NO CPU fallback: without a HIP device jmhip_create() fails.
+ *
+ * Each entry point names the reference interface it stands in for (JM 19.0, paths
+ * relative to the reference tree).  How a JM maintainer binds them: INTEGRATION.md.
+ *
+ * Sample type at the host boundary is JM's imgpel = uint16_t (lcommon/inc/typedefs.h:36);
+ * on the device 8-bit video is kept as uint8 (bit_depth 8 is the only depth in this round).
+ * Motion vectors are quarter-pel int16; costs are JM's distblk scaled by 32
+ * (JCOST_CALC_SCALEUP, lencod/inc/defines.h:46) and fit int32 for 8-bit video.
+ */
+#ifndef JMHIP_H
+#define JMHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JMHIP_OK            0
+#define JMHIP_EINVAL       -1   /* bad argument */
+#define JMHIP_ENODEV       -2   /* no usable HIP device / not gfx950 */
+#define JMHIP_ENOMEM       -3
+#define JMHIP_EHIP         -4   /* a HIP runtime call failed */
+#define JMHIP_EUNSUPPORTED -5
+
+#define JMHIP_PAD_X 32          /* IMG_PAD_SIZE_X, lencod/inc/defines.h:121 */
+#define JMHIP_PAD_Y 20          /* IMG_PAD_SIZE_Y, lencod/inc/defines.h:122 */
+#define JMHIP_NPART 41          /* 1+2+2+4+8+8+16 partitions of the 7 inter block types */
+#define JMHIP_MAX_SEARCH_RANGE 64
+
+typedef struct jmhip_ctx jmhip_ctx;
+
+typedef struct {
+  int32_t device;          /* HIP device ordinal */
+  int32_t width, height;   /* coded luma size, multiples of 16 (p_Vid->width / height) */
+  int32_t yuv_format;      /* 0 = 4:0:0, 1 = 4:2:0, 2 = 4:2:2 (ColorFormat, lcommon/inc/types.h) */
+  int32_t bit_depth;       /* 8 */
+  int32_t search_range;    /* SearchRange in full pels; <= JMHIP_MAX_SEARCH_RANGE */
+  int32_t num_ref_slots;   /* reference pictures kept resident (NumberReferenceFrames) */
+  void   *stream;          /* hipStream_t to use, or NULL for the default stream */
+} jmhip_config;
+
+int         jmhip_create(jmhip_ctx **out, const jmhip_config *cfg);
+void        jmhip_destroy(jmhip_ctx *ctx);
+const char *jmhip_last_error(const jmhip_ctx *ctx);     /* ctx may be NULL: error of the last failed create */
+int         jmhip_synchronize(jmhip_ctx *ctx);           /* wait for the context's stream */
+/* geometry of the resident padded planes: pitch (bytes), rows, bytes between the 16 sub-planes */
+int         jmhip_plane_geometry(const jmhip_ctx *ctx, int32_t *pitch, int32_t *rows, int64_t *plane_stride);
+
+/* ------------------------------------------------------------------------------------------
+ * Frames
+ * ------------------------------------------------------------------------------------------ */
+/* Current (source) luma: p_Vid->pCurImg, read by get_original_block (lencod/src/mv_search.c:786)
+ * and setup_fast_full_search (lencod/src/me_fullfast.c:333-337). */
+int jmhip_set_current(jmhip_ctx *ctx, const uint16_t *luma, int32_t pitch_samples);
+int jmhip_set_current_dev(jmhip_ctx *ctx, const uint8_t *d_luma, int32_t pitch_bytes);
+
+/* Reference picture `slot` := reconstructed luma; builds the 16 quarter-pel planes on the device.
+ * Replaces getSubImagesLuma(p_Vid, s) (lencod/src/img_luma.c:611-679), reached from
+ * UnifiedOneForthPix (lencod/src/image.c:2187) when a picture enters the DPB (mbuffer.c:2313). */
+int jmhip_set_reference(jmhip_ctx *ctx, int32_t slot, const uint16_t *luma, int32_t pitch_samples);
+int jmhip_set_reference_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_luma, int32_t pitch_bytes);
+/* Copy the planes back as JM lays them out: out[(j*4+i)] is plane p_curr_img_sub[j][i], each
+ * (height+2*PAD_Y) rows of (width+2*PAD_X) imgpel, top-left = padded origin.  For host-side MC. */
+int jmhip_get_subplanes(jmhip_ctx *ctx, int32_t slot, uint16_t *out);
+/* Device address of the 16 planes of a slot (uint8, see jmhip_plane_geometry). */
+const uint8_t *jmhip_subplanes_dev(jmhip_ctx *ctx, int32_t slot);
+
+/* ------------------------------------------------------------------------------------------
+ * Integer-pel motion estimation
+ *
+ * A job is one search window: one macroblock, one reference, one search centre, and the
+ * subset of the macroblock's 41 partitions that are searched around that centre, each with
+ * its own MV predictor.  It computes, for every position of the (2R+1)^2 window, the sixteen
+ * 4x4 SADs (setup_fast_full_search, me_fullfast.c:492-556), aggregates them to the selected
+ * partitions (update_full_search_large_blocks :195-260) and returns per partition
+ *     argmin_pos  (SAD << 5) + lambda * (mvbits[cand_x - pred_x] + mvbits[cand_y - pred_y])
+ * with ties resolved to the lowest index of JM's spiral (mv_search.c:405-442).  That is the
+ * result of
+ *   full_search_motion_estimation      (me_fullsearch.c:39-103, Macroblock.IntPelME, one job per
+ *                                       distinct search centre; max_mvd = 0), and of
+ *   fast_full_search_motion_estimation (me_fullfast.c:618-689, one job per macroblock/reference,
+ *                                       all partitions, max_mvd = p_Vid->max_mvd)
+ * for RDOptimization != 0 (no (0,0) bonus, bit-exactness checklist SURVEY.md 8a.4) and an
+ * initial min_mcost of DISTBLK_MAX (mv_search.c:871-872).
+ *
+ * Partition order p = 0..40 (blocktype, top-left 4x4 block in raster units bx,by):
+ *   0: 16x16 | 1,2: 16x8 (by=0,2) | 3,4: 8x16 (bx=0,2) | 5..8: 8x8 raster |
+ *   9..16: 8x4 (by=0..3, bx=0,2 raster) | 17..24: 4x8 (by=0,2, bx=0..3 raster) | 25..40: 4x4 raster
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int16_t  mb_x, mb_y;              /* macroblock position in luma samples (pix_x, opix_y) */
+  int16_t  center_x, center_y;      /* search centre MV, quarter-pel, already rounded to full-pel and clipped
+                                       (mv_search.c:931-957 / me_fullfast.c:313-327) */
+  int16_t  search_range;            /* full pels, <= config.search_range */
+  int16_t  max_mvd;                 /* 0: no guard; else candidates with max|mvd| >= max_mvd-1 are skipped (me_fullfast.c:638,671) */
+  int32_t  lambda;                  /* lambda_factor[F_PEL] */
+  uint64_t part_mask;               /* bit p set: search partition p */
+  int16_t  pred[JMHIP_NPART][2];    /* MV predictor per partition, quarter-pel */
+  int16_t  reserved_[2];
+} jmhip_me_job;                     /* 192 bytes */
+
+typedef struct { int16_t mv_x, mv_y; int32_t cost; } jmhip_me_best;     /* quarter-pel MV, min_mcost */
+typedef struct { jmhip_me_best best[JMHIP_NPART]; } jmhip_me_result;    /* 328 bytes; entries outside part_mask are untouched */
+
+int jmhip_me_fullsearch(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *jobs, int32_t njobs, jmhip_me_result *results);
+int jmhip_me_fullsearch_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, int32_t njobs, jmhip_me_result *d_results);
+
+/* The BlockSAD tables themselves, for a host that keeps JM's own argmin (setup_fast_full_search as
+ * bound to Macroblock.p_SetupFastFullPelSearch, lencod/inc/global.h:469): for each job (only mb_x,
+ * mb_y, center, search_range are read) writes table[7][16][max_pos] uint16 in JM's order
+ * [blocktype-1][4x4 raster index][spiral position], max_pos = (2*search_range+1)^2. */
+int jmhip_me_sad_tables(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *jobs, int32_t njobs, uint16_t *tables);
+
+/* ------------------------------------------------------------------------------------------
+ * Candidate-list distortion and sub-pel refinement
+ * ------------------------------------------------------------------------------------------ */
+#define JMHIP_METRIC_SAD  0          /* ERROR_SAD  */
+#define JMHIP_METRIC_SATD 2          /* ERROR_SATD (Hadamard) */
+
+/* computeSAD / computeSATD (me_distortion.c:349-426 / :745-825; MEBlock.computePred{F,H,Q}Pel,
+ * lencod/inc/global.h:316-318) evaluated without the early exit: full distortion << 5. */
+typedef struct {
+  int16_t pos_x, pos_y;             /* block position, luma samples (MEBlock.pos_x/pos_y) */
+  int16_t bsx, bsy;                 /* block size */
+  int16_t cand_x, cand_y;           /* candidate MV relative to the block, quarter-pel */
+  int16_t metric, test8x8;
+} jmhip_cand;
+int jmhip_me_eval(jmhip_ctx *ctx, int32_t slot, const jmhip_cand *cands, int32_t n, int32_t *dist);
+
+/* sub_pel_motion_estimation (me_fullsearch.c:186-289, Macroblock.SubPelME) for RDOptimization != 0:
+ * up to 9 half-pel then 9 quarter-pel candidates around `mv`. */
+typedef struct {
+  int16_t pos_x, pos_y, bsx, bsy;
+  int16_t pred_x, pred_y;
+  int16_t mv_x, mv_y;               /* in: integer-pel result */
+  int32_t lambda_h, lambda_q;       /* lambda_factor[H_PEL], [Q_PEL] */
+  int8_t  metric_h, metric_q;       /* JMHIP_METRIC_* */
+  int8_t  start_hp, start_qp;       /* p_Vid->start_me_refinement_hp / _qp (mv_search.c:445-446) */
+  int8_t  test8x8, reserved_[3];
+  int32_t min_mcost;                /* cost carried in when start_hp != 0; ignored (DISTBLK_MAX) otherwise */
+} jmhip_subpel_job;                 /* 36 bytes */
+int jmhip_me_subpel(jmhip_ctx *ctx, int32_t slot, const jmhip_subpel_job *jobs, int32_t n, jmhip_me_best *results);
+int jmhip_me_subpel_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_subpel_job *d_jobs, int32_t n, jmhip_me_best *d_results);
+
+/* ------------------------------------------------------------------------------------------
+ * 4x4 luma residual: transform, quantise, dequantise, inverse transform, reconstruct
+ *
+ * residual_transform_quant_luma_4x4 (lencod/src/block.c:661-725, Macroblock.
+ * residual_transform_quant_luma_4x4 global.h:465) = forward4x4 (lcommon/src/transform.c:20) +
+ * Slice.quant_4x4 (quant_4x4_normal lencod/src/quant4x4_normal.c:39 or quant_4x4_around
+ * quant4x4_around.c:40) + inverse4x4 (transform.c:70) + sample_reconstruct
+ * (lcommon/src/blk_prediction.c:48), batched over independent 4x4 blocks.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int32_t OffsetComp, ScaleComp, InvScaleComp; } jmhip_qparam;   /* LevelQuantParams, lcommon/inc/quant_params.h:17-21 */
+typedef struct {
+  jmhip_qparam q[16];               /* p_Quant->q_params_4x4[pl][intra][qp][j][i] at index j*4+i */
+  int32_t qp_per;                   /* p_Quant->qp_per_matrix[qp] */
+  int32_t cavlc;                    /* symbol_mode == CAVLC: clamp |level| to 2063 */
+  int32_t adaptive_rounding;        /* 0: quant_4x4_normal, 1: quant_4x4_around */
+  int32_t adapt_rnd_weight;         /* p_Vid->AdaptRndWeight */
+  int32_t max_pel;                  /* p_Vid->max_imgpel_value */
+  int32_t reserved_[3];
+} jmhip_tq_params;                  /* one per launch: uniform (plane, intra, qp) */
+typedef struct {
+  int16_t level[16];                /* ACLevel, zig-zag order, 0-terminated when fewer than 16 */
+  uint8_t run[16];                  /* ACRun */
+  int32_t coeff_cost;               /* contribution to *coeff_cost (999999 per |level| > 1) */
+  uint8_t nonzero;                  /* return value */
+  uint8_t any_residual;             /* check_zero(): 0 => JM leaves fadjust untouched */
+  uint8_t ncoef, reserved_;
+  uint8_t rec[16];                  /* reconstructed samples, row-major */
+  int16_t fadjust[16];              /* ARCofAdj4x4 update (quant_4x4_around only), row-major */
+} jmhip_tq_out;                     /* 104 bytes */
+/* orig / pred: n blocks x 16 samples row-major (uint8). */
+int jmhip_tq_luma4x4(jmhip_ctx *ctx, const jmhip_tq_params *prm, const uint8_t *orig, const uint8_t *pred,
+                     int32_t nblocks, jmhip_tq_out *out);
+int jmhip_tq_luma4x4_dev(jmhip_ctx *ctx, const jmhip_tq_params *prm, const uint8_t *d_orig, const uint8_t *d_pred,
+                         int32_t nblocks, jmhip_tq_out *d_out);
+/* the bare transforms, batched (n blocks x 16 int32, row-major): forward4x4 / inverse4x4 */
+int jmhip_forward4x4(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t *out);
+int jmhip_inverse4x4(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t *out);
+int jmhip_forward8x8(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t *out);   /* transform.c:353 */
+int jmhip_inverse8x8(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t *out);   /* transform.c:450 */
+
+/* ------------------------------------------------------------------------------------------
+ * In-loop deblocking of a whole frame
+ *
+ * DeblockFrame(p_Vid, imgY, imgUV) (lencod/src/loopFilter.c:63-71; DeblockMb :120-297, strengths and
+ * edge filters lencod/src/loop_filter_normal.c), frame pictures without MBAFF.  Results equal JM's
+ * raster-order in-place filtering.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int16_t  mb_type;          /* Macroblock.mb_type (JM enum value) */
+  int16_t  slice_type;       /* p_Slice->slice_type: 0 P, 1 B, 2 I, 3 SP, 4 SI */
+  int16_t  qp;               /* Macroblock.qp */
+  int16_t  qpc[2];           /* Macroblock.qpc[] */
+  int16_t  cbp;              /* Macroblock.cbp */
+  uint32_t cbp_blk;          /* Macroblock.cbp_blk & 0xFFFF */
+  int16_t  slice_nr;
+  int16_t  df_disable_idc, df_alpha_c0, df_beta;     /* DFDisableIdc, DFAlphaC0Offset, DFBetaOffset */
+  int16_t  transform8x8;     /* luma_transform_size_8x8_flag */
+  int16_t  reserved_;
+} jmhip_db_mb;               /* 28 bytes */
+typedef struct { int16_t mv[2][2]; int32_t ref_id[2]; } jmhip_db_motion;   /* per 4x4: mv[list][x,y], identity of ref_pic[list] or -1 */
+
+int jmhip_deblock_frame(jmhip_ctx *ctx, uint16_t *imgY, int32_t pitchY, uint16_t *imgU, uint16_t *imgV, int32_t pitchC,
+                        const jmhip_db_mb *mbs, const jmhip_db_motion *motion, int32_t direct_8x8_inference);
+int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pitchY, uint8_t *d_U, uint8_t *d_V, int32_t pitchC,
+                            const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int32_t direct_8x8_inference);
+
+/* ------------------------------------------------------------------------------------------
+ * Timing helper: elapsed milliseconds of the last `_dev` launch of each kind, measured with
+ * hipEvents on the context's stream (bench.py uses it for the roofline object).
+ * kind: 0 subplanes, 1 me_fullsearch, 2 me_subpel, 3 tq, 4 deblock.
+ * ------------------------------------------------------------------------------------------ */
+int jmhip_enable_timing(jmhip_ctx *ctx, int32_t on);
+int jmhip_last_kernel_ms(jmhip_ctx *ctx, int32_t kind, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JMHIP_H */

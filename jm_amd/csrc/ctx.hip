@@ -1,0 +1,235 @@
+// ctx.hip -- context, device-resident frames, host<->device staging for libjmhip.
+#include <stdarg.h>
+#include <stdlib.h>
+#include "jmhip_internal.h"
+
+char g_jmhip_create_err[512] = "";
+
+int jmhip_fail(jmhip_ctx *ctx, int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(ctx ? ctx->err : g_jmhip_create_err, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char *jmhip_last_error(const jmhip_ctx *ctx) { return ctx ? ctx->err : g_jmhip_create_err; }
+
+int jmhip_scratch(jmhip_ctx *ctx, int which, size_t bytes, void **out)
+{
+  void **p = which ? &ctx->d_scratch2 : &ctx->d_scratch;
+  size_t *sz = which ? &ctx->scratch2_bytes : &ctx->scratch_bytes;
+  if (*sz < bytes) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) HIPCHK(ctx, hipFree(*p));
+    *p = NULL; *sz = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipMalloc(p, want));
+    *sz = want;
+  }
+  *out = *p;
+  return JMHIP_OK;
+}
+
+void jmhip_time_begin(jmhip_ctx *ctx, int kind)
+{
+  if (ctx->timing) (void)hipEventRecord(ctx->ev0[kind], ctx->stream);
+}
+void jmhip_time_end(jmhip_ctx *ctx, int kind)
+{
+  if (ctx->timing) { (void)hipEventRecord(ctx->ev1[kind], ctx->stream); ctx->ev_valid[kind] = 1; }
+}
+
+static void spiral_fill(int R, int16_t *sp)   // JM spiral order, lencod/src/mv_search.c:405-442
+{
+  int k = 1;
+  sp[0] = sp[1] = 0;
+  for (int l = 1; l <= (R > 1 ? R : 1); l++) {
+    for (int i = -l + 1; i < l; i++) {
+      sp[2 * k] = (int16_t)i;  sp[2 * k + 1] = (int16_t)-l; k++;
+      sp[2 * k] = (int16_t)i;  sp[2 * k + 1] = (int16_t)l;  k++;
+    }
+    for (int i = -l; i <= l; i++) {
+      sp[2 * k] = (int16_t)-l; sp[2 * k + 1] = (int16_t)i; k++;
+      sp[2 * k] = (int16_t)l;  sp[2 * k + 1] = (int16_t)i; k++;
+    }
+  }
+}
+
+extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
+{
+  if (!out || !cfg) return jmhip_fail(NULL, JMHIP_EINVAL, "jmhip_create: null argument");
+  *out = NULL;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 15) || (cfg->height & 15))
+    return jmhip_fail(NULL, JMHIP_EINVAL, "width/height must be positive multiples of 16 (got %dx%d)", cfg->width, cfg->height);
+  if (cfg->bit_depth != 8) return jmhip_fail(NULL, JMHIP_EUNSUPPORTED, "bit_depth %d: only 8-bit video is implemented", cfg->bit_depth);
+  if (cfg->yuv_format < 0 || cfg->yuv_format > 2) return jmhip_fail(NULL, JMHIP_EUNSUPPORTED, "yuv_format %d unsupported", cfg->yuv_format);
+  if (cfg->search_range < 1 || cfg->search_range > JMHIP_MAX_SEARCH_RANGE)
+    return jmhip_fail(NULL, JMHIP_EINVAL, "search_range %d outside 1..%d", cfg->search_range, JMHIP_MAX_SEARCH_RANGE);
+  if (cfg->num_ref_slots < 1 || cfg->num_ref_slots > 32) return jmhip_fail(NULL, JMHIP_EINVAL, "num_ref_slots %d outside 1..32", cfg->num_ref_slots);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return jmhip_fail(NULL, JMHIP_ENODEV, "no HIP device (%s); libjmhip has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+  if (cfg->device < 0 || cfg->device >= ndev) return jmhip_fail(NULL, JMHIP_ENODEV, "device %d not in 0..%d", cfg->device, ndev - 1);
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess) return jmhip_fail(NULL, JMHIP_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return jmhip_fail(NULL, JMHIP_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return jmhip_fail(NULL, JMHIP_ENODEV, "device %d is %s; libjmhip is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+
+  jmhip_ctx *c = (jmhip_ctx *)calloc(1, sizeof(jmhip_ctx));
+  if (!c) return jmhip_fail(NULL, JMHIP_ENOMEM, "out of host memory");
+  c->cfg = *cfg;
+  c->stream = (hipStream_t)cfg->stream;
+  c->W = cfg->width; c->H = cfg->height;
+  c->Wp = c->W + 2 * JMHIP_PAD_X; c->Hp = c->H + 2 * JMHIP_PAD_Y;
+  c->pitch = (c->Wp + 63) & ~63;
+  c->plane_stride = (((int64_t)c->pitch * c->Hp) + 255) & ~(int64_t)255;
+  c->cw = cfg->yuv_format ? c->W / 2 : 0;
+  c->ch = cfg->yuv_format == 2 ? c->H : (cfg->yuv_format == 1 ? c->H / 2 : 0);
+  c->cur_pitch = (c->W + 63) & ~63;
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { jmhip_fail(NULL, JMHIP_EHIP, "%s: %s", #call, hipGetErrorString(e_)); jmhip_destroy(c); return JMHIP_EHIP; } } while (0)
+  CK(hipMalloc((void **)&c->d_cur, (size_t)c->cur_pitch * c->H));
+  c->d_sub = (uint8_t **)calloc(cfg->num_ref_slots, sizeof(uint8_t *));
+  for (int s = 0; s < cfg->num_ref_slots; s++) {
+    CK(hipMalloc((void **)&c->d_sub[s], (size_t)c->plane_stride * 16));
+    CK(hipMemsetAsync(c->d_sub[s], 0, (size_t)c->plane_stride * 16, c->stream));
+  }
+  c->h_stage_bytes = (size_t)c->Wp * c->Hp * 16 * sizeof(uint16_t);
+  CK(hipHostMalloc((void **)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+  CK(hipMalloc((void **)&c->d_stage, (size_t)c->cur_pitch * c->H * 3));
+  {
+    int R = cfg->search_range, n = (2 * R + 1) * (2 * R + 1);
+    int16_t *sp = (int16_t *)malloc((size_t)(n > 9 ? n : 9) * 4);
+    spiral_fill(R, sp);
+    CK(hipMalloc((void **)&c->d_spiral, (size_t)n * 4));
+    CK(hipMemcpy(c->d_spiral, sp, (size_t)n * 4, hipMemcpyHostToDevice));
+    free(sp);
+  }
+  for (int k = 0; k < JMHIP_NKINDS; k++) { CK(hipEventCreate(&c->ev0[k])); CK(hipEventCreate(&c->ev1[k])); }
+  CK(hipStreamSynchronize(c->stream));
+#undef CK
+  *out = c;
+  return JMHIP_OK;
+}
+
+extern "C" void jmhip_destroy(jmhip_ctx *c)
+{
+  if (!c) return;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->d_cur) (void)hipFree(c->d_cur);
+  if (c->d_sub) { for (int s = 0; s < c->cfg.num_ref_slots; s++) if (c->d_sub[s]) (void)hipFree(c->d_sub[s]); free(c->d_sub); }
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_scratch2) (void)hipFree(c->d_scratch2);
+  if (c->d_spiral) (void)hipFree(c->d_spiral);
+  for (int k = 0; k < JMHIP_NKINDS; k++) { if (c->ev0[k]) (void)hipEventDestroy(c->ev0[k]); if (c->ev1[k]) (void)hipEventDestroy(c->ev1[k]); }
+  free(c);
+}
+
+extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_plane_geometry(const jmhip_ctx *ctx, int32_t *pitch, int32_t *rows, int64_t *plane_stride)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (pitch) *pitch = ctx->pitch;
+  if (rows) *rows = ctx->Hp;
+  if (plane_stride) *plane_stride = ctx->plane_stride;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_enable_timing(jmhip_ctx *ctx, int32_t on)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  ctx->timing = on;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_last_kernel_ms(jmhip_ctx *ctx, int32_t kind, float *ms)
+{
+  if (!ctx || !ms || kind < 0 || kind >= JMHIP_NKINDS) return JMHIP_EINVAL;
+  if (!ctx->ev_valid[kind]) return jmhip_fail(ctx, JMHIP_EINVAL, "no timed launch of kind %d yet (jmhip_enable_timing first)", kind);
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev1[kind]));
+  HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0[kind], ctx->ev1[kind]));
+  return JMHIP_OK;
+}
+
+// narrow a host imgpel (uint16) plane into pinned u8 staging and copy it to `dst` (pitch dst_pitch)
+static int upload_u16_as_u8(jmhip_ctx *ctx, const uint16_t *src, int pitch_samples, int w, int h, uint8_t *dst, int dst_pitch)
+{
+  if ((size_t)w * h > ctx->h_stage_bytes) return jmhip_fail(ctx, JMHIP_EINVAL, "plane larger than staging");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // staging buffer reuse
+  uint8_t *st = ctx->h_stage;
+  for (int y = 0; y < h; y++) {
+    const uint16_t *s = src + (size_t)y * pitch_samples;
+    uint8_t *d = st + (size_t)y * w;
+    for (int x = 0; x < w; x++) d[x] = (uint8_t)s[x];
+  }
+  HIPCHK(ctx, hipMemcpy2DAsync(dst, dst_pitch, st, w, w, h, hipMemcpyHostToDevice, ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_set_current(jmhip_ctx *ctx, const uint16_t *luma, int32_t pitch_samples)
+{
+  if (!ctx || !luma || pitch_samples < ctx->W) return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_current: bad argument") : JMHIP_EINVAL;
+  int r = upload_u16_as_u8(ctx, luma, pitch_samples, ctx->W, ctx->H, ctx->d_cur, ctx->cur_pitch);
+  if (r) return r;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_set_current_dev(jmhip_ctx *ctx, const uint8_t *d_luma, int32_t pitch_bytes)
+{
+  if (!ctx || !d_luma || pitch_bytes < ctx->W) return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_current_dev: bad argument") : JMHIP_EINVAL;
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_cur, ctx->cur_pitch, d_luma, pitch_bytes, ctx->W, ctx->H, hipMemcpyDeviceToDevice, ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_set_reference_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_luma, int32_t pitch_bytes)
+{
+  if (!ctx || !d_luma || slot < 0 || slot >= ctx->cfg.num_ref_slots || pitch_bytes < ctx->W)
+    return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_dev: bad argument") : JMHIP_EINVAL;
+  return jmhip_launch_subplanes(ctx, d_luma, pitch_bytes, ctx->d_sub[slot]);
+}
+
+extern "C" int jmhip_set_reference(jmhip_ctx *ctx, int32_t slot, const uint16_t *luma, int32_t pitch_samples)
+{
+  if (!ctx || !luma || slot < 0 || slot >= ctx->cfg.num_ref_slots || pitch_samples < ctx->W)
+    return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference: bad argument") : JMHIP_EINVAL;
+  int r = upload_u16_as_u8(ctx, luma, pitch_samples, ctx->W, ctx->H, ctx->d_stage, ctx->cur_pitch);
+  if (r) return r;
+  r = jmhip_launch_subplanes(ctx, ctx->d_stage, ctx->cur_pitch, ctx->d_sub[slot]);
+  if (r) return r;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" const uint8_t *jmhip_subplanes_dev(jmhip_ctx *ctx, int32_t slot)
+{
+  if (!ctx || slot < 0 || slot >= ctx->cfg.num_ref_slots) return NULL;
+  return ctx->d_sub[slot];
+}
+
+extern "C" int jmhip_get_subplanes(jmhip_ctx *ctx, int32_t slot, uint16_t *out)
+{
+  if (!ctx || !out || slot < 0 || slot >= ctx->cfg.num_ref_slots) return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_get_subplanes: bad argument") : JMHIP_EINVAL;
+  // planes come back through the pinned staging area as u8 and are widened to imgpel on the host
+  size_t plane_px = (size_t)ctx->Wp * ctx->Hp;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 16; k++) {
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->h_stage, ctx->Wp, ctx->d_sub[slot] + (size_t)k * ctx->plane_stride, ctx->pitch,
+                                 ctx->Wp, ctx->Hp, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint16_t *o = out + (size_t)k * plane_px;
+    for (size_t i = 0; i < plane_px; i++) o[i] = ctx->h_stage[i];
+  }
+  return JMHIP_OK;
+}

@@ -1,0 +1,45 @@
+// jmhip_internal.h -- shared by the translation units of libjmhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/jmhip.h"
+
+#define JMHIP_NKINDS 5
+
+struct jmhip_ctx {
+  jmhip_config cfg;
+  hipStream_t stream;
+  int W, H;              // luma size
+  int Wp, Hp;            // padded: W + 64, H + 40
+  int pitch;             // bytes per row of a padded plane (multiple of 64)
+  int64_t plane_stride;  // bytes between sub-planes (multiple of 256)
+  int cw, ch;            // chroma plane size
+  uint8_t *d_cur;        // W x H current luma, pitch cur_pitch
+  int cur_pitch;
+  uint8_t **d_sub;       // [num_ref_slots] -> 16 planes
+  uint8_t *d_stage;      // staging for host uploads (W x H luma, u8)
+  uint8_t *h_stage;      // pinned host staging
+  size_t h_stage_bytes;
+  void *d_scratch; size_t scratch_bytes;     // grows on demand: jobs/results/tables for host entry points
+  void *d_scratch2; size_t scratch2_bytes;
+  int16_t *d_spiral;     // [(2R+1)^2][2] spiral offsets for R = cfg.search_range
+  int timing;
+  hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];
+  int ev_valid[JMHIP_NKINDS];
+  char err[512];
+};
+
+extern char g_jmhip_create_err[512];
+
+int jmhip_fail(jmhip_ctx *ctx, int code, const char *fmt, ...);
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return jmhip_fail(ctx, JMHIP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+int jmhip_scratch(jmhip_ctx *ctx, int which, size_t bytes, void **out);
+void jmhip_time_begin(jmhip_ctx *ctx, int kind);
+void jmhip_time_end(jmhip_ctx *ctx, int kind);
+
+// kernels' launchers (defined next to the kernels)
+int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);

@@ -1,0 +1,260 @@
+"""ctypes binding of libjmhip.so (include/jmhip.h).
+
+Mirrors the reference's operator surface for the hot path with JM's names in the docstrings:
+set_reference = getSubImagesLuma, me_fullsearch = full_search_motion_estimation /
+fast_full_search_motion_estimation, me_subpel = sub_pel_motion_estimation, tq_luma4x4 =
+residual_transform_quant_luma_4x4, deblock_frame = DeblockFrame.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NPART = 41
+PAD_X, PAD_Y = 32, 20
+
+# (blocktype, bx, by, w, h) of the 41 partitions in ABI order (units: luma samples)
+PARTITIONS = ([(1, 0, 0, 16, 16)] + [(2, 0, by, 16, 8) for by in (0, 8)] + [(3, bx, 0, 8, 16) for bx in (0, 8)] +
+              [(4, bx, by, 8, 8) for by in (0, 8) for bx in (0, 8)] +
+              [(5, bx, by, 8, 4) for by in (0, 4, 8, 12) for bx in (0, 8)] +
+              [(6, bx, by, 4, 8) for by in (0, 8) for bx in (0, 4, 8, 12)] +
+              [(7, bx, by, 4, 4) for by in (0, 4, 8, 12) for bx in (0, 4, 8, 12)])
+assert len(PARTITIONS) == NPART
+
+ME_JOB = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("center_x", "<i2"), ("center_y", "<i2"), ("search_range", "<i2"),
+                   ("max_mvd", "<i2"), ("lambda", "<i4"), ("part_mask", "<u8"), ("pred", "<i2", (NPART, 2)), ("reserved_", "<i2", (2,))])
+ME_BEST = np.dtype([("mv_x", "<i2"), ("mv_y", "<i2"), ("cost", "<i4")])
+ME_RESULT = np.dtype([("best", ME_BEST, (NPART,))])
+CAND = np.dtype([("pos_x", "<i2"), ("pos_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"), ("cand_x", "<i2"), ("cand_y", "<i2"),
+                 ("metric", "<i2"), ("test8x8", "<i2")])
+SUBPEL_JOB = np.dtype([("pos_x", "<i2"), ("pos_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"), ("pred_x", "<i2"), ("pred_y", "<i2"),
+                       ("mv_x", "<i2"), ("mv_y", "<i2"), ("lambda_h", "<i4"), ("lambda_q", "<i4"), ("metric_h", "i1"),
+                       ("metric_q", "i1"), ("start_hp", "i1"), ("start_qp", "i1"), ("test8x8", "i1"), ("reserved_", "i1", (3,)),
+                       ("min_mcost", "<i4")])
+TQ_PARAMS = np.dtype([("q", "<i4", (16, 3)), ("qp_per", "<i4"), ("cavlc", "<i4"), ("adaptive_rounding", "<i4"),
+                      ("adapt_rnd_weight", "<i4"), ("max_pel", "<i4"), ("reserved_", "<i4", (3,))])
+TQ_OUT = np.dtype([("level", "<i2", (16,)), ("run", "u1", (16,)), ("coeff_cost", "<i4"), ("nonzero", "u1"), ("any_residual", "u1"),
+                   ("ncoef", "u1"), ("reserved_", "u1"), ("rec", "u1", (16,)), ("fadjust", "<i2", (16,))])
+DB_MB = np.dtype([("mb_type", "<i2"), ("slice_type", "<i2"), ("qp", "<i2"), ("qpc", "<i2", (2,)), ("cbp", "<i2"), ("cbp_blk", "<u4"),
+                  ("slice_nr", "<i2"), ("df_disable_idc", "<i2"), ("df_alpha_c0", "<i2"), ("df_beta", "<i2"), ("transform8x8", "<i2"),
+                  ("reserved_", "<i2")])
+DB_MOTION = np.dtype([("mv", "<i2", (2, 2)), ("ref_id", "<i4", (2,))])
+assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
+assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16
+
+EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_plane_geometry",
+           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_reference", "jmhip_set_reference_dev",
+           "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
+           "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_tq_luma4x4",
+           "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
+           "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
+
+
+class JmHipError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("yuv_format", C.c_int32),
+                ("bit_depth", C.c_int32), ("search_range", C.c_int32), ("num_ref_slots", C.c_int32), ("stream", C.c_void_p)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libjmhip.so")
+
+
+def load_library():
+    """Load libjmhip.so; raises if it has not been built (python -m jm_amd.build)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise JmHipError(f"{path} is missing: build it with `python -m jm_amd.build` (there is no CPU fallback)")
+        lib = C.CDLL(path)
+        lib.jmhip_last_error.restype = C.c_char_p
+        lib.jmhip_last_error.argtypes = [C.c_void_p]
+        lib.jmhip_subplanes_dev.restype = C.c_void_p
+        lib.jmhip_subplanes_dev.argtypes = [C.c_void_p, C.c_int32]
+        lib.jmhip_destroy.restype = None
+        lib.jmhip_destroy.argtypes = [C.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))          # a device pointer (int), e.g. torch.Tensor.data_ptr()
+
+
+class JmHip:
+    """One libjmhip context = one GPU, one picture size, one stream."""
+
+    def __init__(self, width, height, search_range=32, num_ref_slots=1, yuv_format=1, device=0, stream=None):
+        self.lib = load_library()
+        self.cfg = _Config(device, width, height, yuv_format, 8, search_range, num_ref_slots, stream)
+        self.h = C.c_void_p()
+        rc = self.lib.jmhip_create(C.byref(self.h), C.byref(self.cfg))
+        if rc != 0:
+            raise JmHipError(f"jmhip_create failed ({rc}): {self.lib.jmhip_last_error(None).decode()}")
+        self.W, self.H, self.R = width, height, search_range
+        p, r, s = C.c_int32(), C.c_int32(), C.c_int64()
+        self._ck(self.lib.jmhip_plane_geometry(self.h, C.byref(p), C.byref(r), C.byref(s)))
+        self.pitch, self.rows, self.plane_stride = p.value, r.value, s.value
+
+    def close(self):
+        if self.h:
+            self.lib.jmhip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise JmHipError(f"libjmhip error {rc}: {self.lib.jmhip_last_error(self.h).decode()}")
+
+    def synchronize(self):
+        self._ck(self.lib.jmhip_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        self._ck(self.lib.jmhip_enable_timing(self.h, int(on)))
+
+    def last_kernel_ms(self, kind):
+        ms = C.c_float()
+        self._ck(self.lib.jmhip_last_kernel_ms(self.h, kind, C.byref(ms)))
+        return ms.value
+
+    # ---- frames
+    def set_current(self, luma):
+        """p_Vid->pCurImg := luma (H x W, any integer dtype, values 0..255)."""
+        a = np.ascontiguousarray(luma, np.uint16)
+        assert a.shape == (self.H, self.W)
+        self._ck(self.lib.jmhip_set_current(self.h, _vp(a), self.W))
+
+    def set_current_dev(self, dptr, pitch):
+        self._ck(self.lib.jmhip_set_current_dev(self.h, _vp(dptr), pitch))
+
+    def set_reference(self, slot, luma):
+        """getSubImagesLuma for reference `slot` (lencod/src/img_luma.c:611)."""
+        a = np.ascontiguousarray(luma, np.uint16)
+        assert a.shape == (self.H, self.W)
+        self._ck(self.lib.jmhip_set_reference(self.h, slot, _vp(a), self.W))
+
+    def set_reference_dev(self, slot, dptr, pitch):
+        self._ck(self.lib.jmhip_set_reference_dev(self.h, slot, _vp(dptr), pitch))
+
+    def get_subplanes(self, slot):
+        out = np.zeros((16, self.H + 2 * PAD_Y, self.W + 2 * PAD_X), np.uint16)
+        self._ck(self.lib.jmhip_get_subplanes(self.h, slot, _vp(out)))
+        return out
+
+    def subplanes_dev(self, slot):
+        return self.lib.jmhip_subplanes_dev(self.h, slot)
+
+    # ---- motion estimation
+    def me_fullsearch(self, slot, jobs):
+        jobs = np.ascontiguousarray(jobs, ME_JOB)
+        res = np.zeros(len(jobs), ME_RESULT)
+        self._ck(self.lib.jmhip_me_fullsearch(self.h, slot, _vp(jobs), len(jobs), _vp(res)))
+        return res
+
+    def me_fullsearch_dev(self, slot, d_jobs, n, d_results):
+        self._ck(self.lib.jmhip_me_fullsearch_dev(self.h, slot, _vp(d_jobs), n, _vp(d_results)))
+
+    def me_sad_tables(self, slot, jobs):
+        jobs = np.ascontiguousarray(jobs, ME_JOB)
+        R = int(jobs["search_range"][0])
+        out = np.zeros((len(jobs), 7, 16, (2 * R + 1) ** 2), np.uint16)
+        self._ck(self.lib.jmhip_me_sad_tables(self.h, slot, _vp(jobs), len(jobs), _vp(out)))
+        return out
+
+    def me_eval(self, slot, cands):
+        cands = np.ascontiguousarray(cands, CAND)
+        out = np.zeros(len(cands), np.int32)
+        self._ck(self.lib.jmhip_me_eval(self.h, slot, _vp(cands), len(cands), _vp(out)))
+        return out
+
+    def me_subpel(self, slot, jobs):
+        jobs = np.ascontiguousarray(jobs, SUBPEL_JOB)
+        out = np.zeros(len(jobs), ME_BEST)
+        self._ck(self.lib.jmhip_me_subpel(self.h, slot, _vp(jobs), len(jobs), _vp(out)))
+        return out
+
+    def me_subpel_dev(self, slot, d_jobs, n, d_out):
+        self._ck(self.lib.jmhip_me_subpel_dev(self.h, slot, _vp(d_jobs), n, _vp(d_out)))
+
+    # ---- transform / quant
+    @staticmethod
+    def tq_params(q, qp_per, cavlc=1, adaptive_rounding=0, adapt_rnd_weight=0, max_pel=255):
+        p = np.zeros(1, TQ_PARAMS)
+        p["q"][0] = np.asarray(q, np.int32).reshape(16, 3)
+        p["qp_per"], p["cavlc"], p["adaptive_rounding"] = qp_per, cavlc, adaptive_rounding
+        p["adapt_rnd_weight"], p["max_pel"] = adapt_rnd_weight, max_pel
+        return p
+
+    def tq_luma4x4(self, prm, orig, pred):
+        orig = np.ascontiguousarray(orig, np.uint8).reshape(-1, 16)
+        pred = np.ascontiguousarray(pred, np.uint8).reshape(-1, 16)
+        out = np.zeros(len(orig), TQ_OUT)
+        self._ck(self.lib.jmhip_tq_luma4x4(self.h, _vp(prm), _vp(orig), _vp(pred), len(orig), _vp(out)))
+        return out
+
+    def tq_luma4x4_dev(self, prm, d_orig, d_pred, n, d_out):
+        self._ck(self.lib.jmhip_tq_luma4x4_dev(self.h, _vp(prm), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
+
+    def _xform(self, fn, x, sz):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, sz * sz)
+        out = np.zeros_like(x)
+        self._ck(fn(self.h, _vp(x), len(x), _vp(out)))
+        return out
+
+    def forward4x4(self, x):
+        return self._xform(self.lib.jmhip_forward4x4, x, 4)
+
+    def inverse4x4(self, x):
+        return self._xform(self.lib.jmhip_inverse4x4, x, 4)
+
+    def forward8x8(self, x):
+        return self._xform(self.lib.jmhip_forward8x8, x, 8)
+
+    def inverse8x8(self, x):
+        return self._xform(self.lib.jmhip_inverse8x8, x, 8)
+
+    # ---- deblocking
+    def deblock_frame(self, y, u, v, mbs, motion, direct8x8=1):
+        """DeblockFrame (lencod/src/loopFilter.c:63); returns the filtered planes."""
+        Y = np.ascontiguousarray(y, np.uint16).copy()
+        U = np.ascontiguousarray(u, np.uint16).copy() if u is not None else None
+        V = np.ascontiguousarray(v, np.uint16).copy() if v is not None else None
+        mbs = np.ascontiguousarray(mbs, DB_MB)
+        motion = np.ascontiguousarray(motion, DB_MOTION)
+        self._ck(self.lib.jmhip_deblock_frame(self.h, _vp(Y), Y.shape[1], _vp(U), _vp(V), U.shape[1] if U is not None else 0,
+                                              _vp(mbs), _vp(motion), direct8x8))
+        return Y, U, V
+
+    def deblock_frame_dev(self, dY, pitchY, dU, dV, pitchC, d_mbs, d_motion, direct8x8=1):
+        self._ck(self.lib.jmhip_deblock_frame_dev(self.h, _vp(dY), pitchY, _vp(dU), _vp(dV), pitchC, _vp(d_mbs), _vp(d_motion), direct8x8))
+
+
+def db_arrays_from_tap(mbs12, mot):
+    """Convert the (N,12) macroblock rows and (H/4,W/4,2,3) motion array of the golden fixtures
+    (order of oracle/ref_tap.c) into DB_MB / DB_MOTION arrays."""
+    n = len(mbs12)
+    m = np.zeros(n, DB_MB)
+    m["mb_type"], m["slice_type"], m["qp"] = mbs12[:, 0], mbs12[:, 1], mbs12[:, 2]
+    m["qpc"][:, 0], m["qpc"][:, 1] = mbs12[:, 3], mbs12[:, 4]
+    m["cbp"], m["cbp_blk"], m["slice_nr"] = mbs12[:, 5], mbs12[:, 6] & 0xFFFF, mbs12[:, 7]
+    m["df_disable_idc"], m["df_alpha_c0"], m["df_beta"], m["transform8x8"] = mbs12[:, 8], mbs12[:, 9], mbs12[:, 10], mbs12[:, 11]
+    h4, w4 = mot.shape[:2]
+    mo = np.zeros((h4, w4), DB_MOTION)
+    mo["mv"] = mot[:, :, :, 0:2]
+    mo["ref_id"] = mot[:, :, :, 2]
+    return m, mo.reshape(-1)
