@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- encoded macroblocks/sec of the MI355X hot path on synthetic 1080p (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one P frame whose inputs are already resident in HBM:
+  K5  sub-pel planes of the reference      (getSubImagesLuma)
+  K1-3 full search, SR=32, 41 partitions    (full_search_motion_estimation, one window job per macroblock)
+  K4  9+9 sub-pel refinement, SATD          (sub_pel_motion_estimation)
+  K7/8 4x4 transform/quant/reconstruct      (residual_transform_quant_luma_4x4, 16 luma blocks per macroblock)
+  K9/10 deblocking of the frame             (DeblockFrame)
+The MV predictors, the prediction fed to the transform and the deblocking side information are synthetic
+inputs (the sequential mode decision that produces them in JM stays on the host: SURVEY.md 8b/8f).
+
+python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, one rank per GPU)
+N > 1 shards one tall frame of N 1080p bands (slices) one band per GPU; each step all-gathers the
+reconstructed bands over RCCL (the reference-frame exchange of SURVEY.md 8e) -- weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H_SRC, H = 1920, 1080, 1088
+R = 32
+QP = 28
+HALO = 544          # rows of neighbouring bands a band can reference: level-4 vertical MV limit 511.75 + 16 + taps, rounded to MBs
+
+
+def synth_luma(n_frames, seed=1234):
+    """SURVEY.md Appendix A generator (luma only), coded height 1088 by replicating the last row."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(H_SRC // 8 + 8, W // 8 + 8)).astype(np.float32)
+    base = np.kron(base, np.ones((8, 8), np.float32))
+    k = 5
+    b = np.cumsum(np.cumsum(np.pad(base, ((k, k), (k, k)), mode="edge"), 0), 1)
+    sm = (b[2 * k:, 2 * k:] - b[:-2 * k, 2 * k:] - b[2 * k:, :-2 * k] + b[:-2 * k, :-2 * k]) / (4 * k * k)
+    sm = sm[:H_SRC + 64, :W + 64]
+    frames = []
+    for n in range(n_frames):
+        dx, dy = 3 * n, 2 * n
+        y = sm[dy:dy + H_SRC, dx:dx + W] + rng.normal(0, 2, size=(H_SRC, W))
+        y = np.clip(np.rint(y), 0, 255).astype(np.uint8)
+        frames.append(np.concatenate([y, np.repeat(y[-1:], H - H_SRC, 0)], 0))
+    return frames
+
+
+def write_yuv(path, n_frames, seed=1234):
+    """the same clip as 4:2:0 YUV for lencod (Appendix A incl. chroma)."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(H_SRC // 8 + 8, W // 8 + 8)).astype(np.float32)
+    base = np.kron(base, np.ones((8, 8), np.float32))
+    k = 5
+    b = np.cumsum(np.cumsum(np.pad(base, ((k, k), (k, k)), mode="edge"), 0), 1)
+    sm = (b[2 * k:, 2 * k:] - b[:-2 * k, 2 * k:] - b[2 * k:, :-2 * k] + b[:-2 * k, :-2 * k]) / (4 * k * k)
+    sm = sm[:H_SRC + 64, :W + 64]
+    with open(path, "wb") as f:
+        for n in range(n_frames):
+            dx, dy = 3 * n, 2 * n
+            y = sm[dy:dy + H_SRC, dx:dx + W] + rng.normal(0, 2, size=(H_SRC, W))
+            y = np.clip(np.rint(y), 0, 255).astype(np.uint8)
+            u = np.clip(np.rint(128 + 0.25 * (y[::2, ::2].astype(np.float32) - 128)), 0, 255).astype(np.uint8)
+            v = np.clip(np.rint(128 - 0.25 * (y[::2, ::2].astype(np.float32) - 128)), 0, 255).astype(np.uint8)
+            f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+
+
+def cpu_baseline(max_seconds=240):
+    """JM's own CPU lencod (oracle/_ref/lencod.exe, built from the reference: kind "reference"), single thread,
+    on a bounded sample of the same workload: the first two frames (I + P) of the synthetic 1080p clip with
+    the BASELINE.json configs[1] settings.  Falls back to the oracle's C restatement of the full search
+    (kind "port") on a sample of macroblocks when the reference binary did not travel."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "lencod.exe")
+    cfg = os.path.join(ROOT, "tests", "golden", "jm_baseline.cfg")
+    if os.path.exists(exe) and os.access(exe, os.X_OK):
+        with tempfile.TemporaryDirectory() as tmp:
+            write_yuv(os.path.join(tmp, "syn1080p.yuv"), 2)
+            args = [exe, "-d", cfg]
+            for kv in ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", "OutputWidth=1920", "OutputHeight=1080",
+                       "FramesToBeEncoded=2", "SearchMode=-1", "SearchRange=32", "NumberReferenceFrames=1", "LevelIDC=51",
+                       "OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null"):
+                args += ["-p", kv]
+            try:
+                t0 = time.time()
+                r = subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=max_seconds)
+                wall = time.time() - t0
+                log = r.stdout.decode(errors="replace")
+                # per-frame line: "00001(P ) bits QP SnrY SnrU SnrV Time(ms) MET(ms) ..."
+                m = re.search(r"^\s*0*1\(\s*P\s*\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", log, re.M)
+                if r.returncode == 0 and m:
+                    p_ms, me_ms = int(m.group(1)), int(m.group(2))
+                    return {"value": round(8160 / (p_ms / 1000.0), 1), "unit": "macroblocks/s", "cores": 1, "kind": "reference",
+                            "sample": f"JM 19.0 lencod -O3, 1 thread: P frame of syn1080p (I+P encoded, {wall:.1f} s wall): "
+                                      f"{p_ms} ms total, {me_ms} ms ME; FullSearch SR=32, 1 ref, RDO on, CAVLC"}
+            except subprocess.TimeoutExpired:
+                pass
+    # port: the oracle's full search over the 41 partitions of a sample of macroblocks
+    from oracle import pyjmo as J
+    from jm_amd.lib import PARTITIONS
+    frames = synth_luma(2)
+    ref, cur = J.RefPic(frames[0]), frames[1]
+    t0, n = time.time(), 0
+    for mby in range(256, 256 + 16 * 2, 16):
+        for mbx in range(256, 256 + 16 * 6, 16):
+            for (bt, bx, by, w, h) in PARTITIONS:
+                J.full_search(ref, cur, mbx + bx, mby + by, w, h, (12, 8), (12, 8), R, 187)
+            n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
+            "sample": f"oracle jmo_full_search (C, -O2), integer-pel ME only, {n} macroblocks x 41 partitions, SR=32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from jm_amd import JmHip
+    from jm_amd.lib import ME_JOB, ME_RESULT, TQ_OUT, DB_MB, DB_MOTION, NPART
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    N = world
+    halo = HALO if N > 1 else 0
+    HL = H + 2 * halo                                   # rows of the local reference (own band + halos)
+
+    stream = torch.cuda.current_stream()
+    ctx = JmHip(W, HL, search_range=R, num_ref_slots=1, yuv_format=1, device=local, stream=stream.cuda_stream)
+
+    # ---------------- synthetic inputs, resident in HBM before the timed region
+    frames = synth_luma(2, seed=1234 + rank)
+    ref_band = torch.from_numpy(frames[0]).to(dev)                      # this band's reconstructed reference luma
+    cur_local = np.zeros((HL, W), np.uint8); cur_local[halo:halo + H] = frames[1]
+    d_cur = torch.from_numpy(cur_local).to(dev)
+    ctx.set_current_dev(d_cur.data_ptr(), W)
+    gathered = torch.empty((N, H, W), dtype=torch.uint8, device=dev) if N > 1 else None
+    local_ref = torch.empty((HL, W), dtype=torch.uint8, device=dev)
+
+    mbw, mbh = W // 16, H // 16
+    nmb = mbw * mbh
+    rng = np.random.default_rng(7 + rank)
+    jobs = np.zeros(nmb, ME_JOB)
+    jobs["mb_x"] = np.tile(np.arange(mbw) * 16, mbh)
+    jobs["mb_y"] = np.repeat(np.arange(mbh) * 16, mbw) + halo
+    jobs["search_range"], jobs["lambda"], jobs["part_mask"] = R, 187, np.uint64((1 << NPART) - 1)
+    # predictors: the clip's global motion (3,2) px = (12,8) quarter-pel +- 2 quarter-pels; one centre per MB
+    jobs["pred"] = np.array([12, 8], np.int16) + rng.integers(-2, 3, (nmb, NPART, 2)).astype(np.int16)
+    jobs["center_x"], jobs["center_y"] = 12, 8
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(nmb, -1)).to(dev)
+    d_int = torch.zeros((nmb, ME_RESULT.itemsize), dtype=torch.uint8, device=dev)
+    d_fin = torch.zeros((nmb, ME_RESULT.itemsize), dtype=torch.uint8, device=dev)
+    rprm = ctx.refine_params(187, 187, 2, 2, 0, 0, 0)
+
+    # transform/quant input: the band's 4x4 luma blocks, prediction = co-located reference block
+    def blocks_of(img):
+        return np.ascontiguousarray(img.reshape(H // 4, 4, W // 4, 4).transpose(0, 2, 1, 3).reshape(-1, 16))
+    d_orig = torch.from_numpy(blocks_of(frames[1])).to(dev)
+    d_pred = torch.from_numpy(blocks_of(frames[0])).to(dev)
+    nblk = d_orig.shape[0]
+    d_tq = torch.zeros((nblk, TQ_OUT.itemsize), dtype=torch.uint8, device=dev)
+    q = np.zeros((16, 3), np.int32)
+    sc, ds = {0: 8192, 1: 3355, 2: 5243}, {0: 16, 1: 25, 2: 20}           # qp % 6 == 4 rows of quant_coef / dequant_coef (q_matrix.c:20-36)
+    for j in range(4):
+        for i in range(4):
+            c = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 and j % 2) else 2)
+            q[j * 4 + i] = (342 << (15 + QP // 6 - 11), sc[c], ds[c] << 4)
+    tqp = ctx.tq_params(q, QP // 6, cavlc=1, adaptive_rounding=1, adapt_rnd_weight=4)
+
+    # deblocking input: pre-filter reconstruction (the current frame stands in for it) + synthetic side information
+    ch, cw = H // 2, W // 2
+    pre_y = torch.from_numpy(frames[1]).to(dev)
+    pre_c = torch.full((2, ch, cw), 128, dtype=torch.uint8, device=dev)
+    work_y, work_c = torch.empty_like(pre_y), torch.empty_like(pre_c)
+    mbs = np.zeros(nmb, DB_MB)
+    mbs["mb_type"] = rng.choice([0, 1, 1, 2, 3, 8, 8, 9, 10], nmb)
+    mbs["qp"], mbs["qpc"] = QP, QP - 1
+    mbs["cbp_blk"] = rng.integers(0, 1 << 16, nmb) * (rng.integers(0, 3, nmb) > 0)
+    mbs["cbp"] = np.where(mbs["cbp_blk"] != 0, 15, 0)
+    mbs["df_disable_idc"] = 2 if N > 1 else 0
+    mot = np.zeros((H // 4) * (W // 4), DB_MOTION)
+    mot["mv"][:, 0, :] = np.array([12, 8], np.int16) + rng.integers(-5, 6, (len(mot), 2)).astype(np.int16)
+    mot["ref_id"][:, 0], mot["ref_id"][:, 1] = 0, -1
+    d_mbs = torch.from_numpy(mbs.view(np.uint8).reshape(nmb, -1)).to(dev)
+    d_mot = torch.from_numpy(mot.view(np.uint8).reshape(len(mot), -1)).to(dev)
+    # deblock context works on the band itself (height H), not on the haloed reference
+    dctx = ctx if halo == 0 else JmHip(W, H, search_range=R, num_ref_slots=1, yuv_format=1, device=local, stream=stream.cuda_stream)
+
+    fs_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i, timed):
+        if N > 1:                                                       # reference-frame exchange over xGMI (RCCL)
+            dist.all_gather_into_tensor(gathered.view(-1), ref_band.view(-1))
+            lo, hi = rank * H - halo, (rank + 1) * H + halo
+            tall = gathered.view(N * H, W)
+            idx = torch.arange(lo, hi, device=dev).clamp_(0, N * H - 1)
+            torch.index_select(tall, 0, idx, out=local_ref)
+        else:
+            local_ref.copy_(ref_band)
+        ctx.set_reference_dev(0, local_ref.data_ptr(), W)               # K5
+        if timed:
+            fs_events[i][0].record(stream)
+        ctx.me_fullsearch_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr())           # K1-K3
+        if timed:
+            fs_events[i][1].record(stream)
+        ctx.me_refine_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr(), rprm, d_fin.data_ptr())   # K4
+        ctx.tq_luma4x4_dev(tqp, d_orig.data_ptr(), d_pred.data_ptr(), nblk, d_tq.data_ptr())     # K7/K8
+        work_y.copy_(pre_y); work_c.copy_(pre_c)
+        dctx.deblock_frame_dev(work_y.data_ptr(), W, work_c[0].data_ptr(), work_c[1].data_ptr(), cw, d_mbs.data_ptr(), d_mot.data_ptr(), 1)  # K9/K10
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fs_ms = float(np.mean([a.elapsed_time(b) for a, b in fs_events]))
+
+    # sanity: the search found the clip's motion for the 16x16 partition of interior macroblocks
+    res = d_fin.cpu().numpy().view(ME_RESULT).reshape(nmb)
+    interior = (jobs["mb_x"] > 64) & (jobs["mb_x"] < W - 80) & (jobs["mb_y"] - halo > 64) & (jobs["mb_y"] - halo < H_SRC - 80)
+    mv16 = res["best"][interior, 0]
+    motion_ok = float(np.mean((np.abs(mv16["mv_x"] - 12) <= 2) & (np.abs(mv16["mv_y"] - 8) <= 2)))
+
+    if rank == 0:
+        total_mb = nmb * N * args.steps
+        alg_bytes = (256 + (2 * R + 16) ** 2 + 328) * nmb                # per MB-reference, R=32: 6656 in + 328 out
+        out = {
+            "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
+            "value": round(total_mb / dt, 1), "unit": "macroblocks/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP P-frame hot path, FullSearch SR=32, 1 ref, QP 28",
+                       "macroblocks_per_step_per_gpu": nmb, "search_range": R, "partitions": NPART,
+                       "parallelism": "1 GPU" if N == 1 else f"{N} slices (1080p bands) one per GPU, RCCL all-gather of reconstructed bands per step",
+                       "kernel_path_only": "MV predictors / prediction / deblock side info are synthetic inputs; mode decision and entropy coding stay on the host",
+                       "motion_found_frac": round(motion_ok, 4)},
+            "roofline": {"kernel": "k_me_fullsearch (K1-K3 fused)", "bound": "hbm", "achieved": round(alg_bytes / (fs_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(alg_bytes / (fs_ms * 1e-3) / 8e12, 5), "traffic": None,
+                         "avg_kernel_ms": round(fs_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                         "valu_note": "SAD is VALU-bound: 8.8 G abs-diff/frame; see DESIGN.md for the v_sad_u8 roofline"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if N > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

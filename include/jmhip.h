@@ -156,6 +156,17 @@ typedef struct {
 int jmhip_me_subpel(jmhip_ctx *ctx, int32_t slot, const jmhip_subpel_job *jobs, int32_t n, jmhip_me_best *results);
 int jmhip_me_subpel_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_subpel_job *d_jobs, int32_t n, jmhip_me_best *d_results);
 
+/* BlockMotionSearch's hand-over from IntPelME to SubPelME (mv_search.c:960-981), device-resident: every
+ * partition searched by jobs[i] is refined starting from int_results[i].best[p]; out[i].best[p] receives
+ * the final MV and cost.  test8x8 = transform8x8_mode for block types 1-4 (mv_search.c:1630,1770). */
+typedef struct {
+  int32_t lambda_h, lambda_q;
+  int8_t  metric_h, metric_q, start_hp, start_qp;
+  int32_t transform8x8_mode;
+} jmhip_refine_params;
+int jmhip_me_refine_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, int32_t njobs, const jmhip_me_result *d_int_results,
+                        const jmhip_refine_params *prm, jmhip_me_result *d_out);
+
 /* ------------------------------------------------------------------------------------------
  * 4x4 luma residual: transform, quantise, dequantise, inverse transform, reconstruct
  *

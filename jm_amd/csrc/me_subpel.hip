@@ -122,12 +122,9 @@ __global__ __launch_bounds__(256) void k_me_eval(const jmhip_cand *__restrict__ 
 // JM's 3x3 spiral (mv_search.c:405-442 with search_range 1): position index -> (dx,dy)
 __device__ __constant__ int8_t c_sp9[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
 
-__global__ __launch_bounds__(64) void k_me_subpel(const jmhip_subpel_job *__restrict__ jobs, int n, jmhip_me_best *__restrict__ out,
-                                                  PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
+// one 16-lane group refines one block; every lane of the group returns the result
+__device__ jmhip_me_best subpel_group(const jmhip_subpel_job &j, int l, const PlaneSet &ps, const uint8_t *__restrict__ cur, int cur_pitch)
 {
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
-  const bool live = g < n;
-  jmhip_subpel_job j = jobs[live ? g : 0];
   const uint8_t *c = cur + (long)j.pos_y * cur_pitch + j.pos_x;
   const int pxp = j.pos_x << 2, pyp = j.pos_y << 2;
   int mvx = j.mv_x, mvy = j.mv_y;
@@ -155,16 +152,56 @@ __global__ __launch_bounds__(64) void k_me_subpel(const jmhip_subpel_job *__rest
       key = o < key ? o : key;
     }
     const int bl = (int)(key & 15);
-    long long bc = (long long)(key >> 4);
-    if (bc < min_mcost || bl >= start) {                                            // a real candidate won (or all were evaluated)
-      if (bc < min_mcost) { min_mcost = bc; mvx += c_sp9[bl][0] * step; mvy += c_sp9[bl][1] * step; }
-    }
+    const long long bc = (long long)(key >> 4);
+    if (bc < min_mcost) { min_mcost = bc; mvx += c_sp9[bl][0] * step; mvy += c_sp9[bl][1] * step; }
   }
-  if (live && l == 0) {
-    jmhip_me_best b; b.mv_x = (int16_t)mvx; b.mv_y = (int16_t)mvy;
-    b.cost = min_mcost > 0x7fffffffLL ? 0x7fffffff : (int32_t)min_mcost;
-    out[g] = b;
-  }
+  jmhip_me_best b; b.mv_x = (int16_t)mvx; b.mv_y = (int16_t)mvy;
+  b.cost = min_mcost > 0x7fffffffLL ? 0x7fffffff : (int32_t)min_mcost;
+  return b;
+}
+
+__global__ __launch_bounds__(64) void k_me_subpel(const jmhip_subpel_job *__restrict__ jobs, int n, jmhip_me_best *__restrict__ out,
+                                                  PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
+{
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const bool live = g < n;
+  jmhip_subpel_job j = jobs[live ? g : 0];
+  jmhip_me_best b = subpel_group(j, l, ps, cur, cur_pitch);
+  if (live && l == 0) out[g] = b;
+}
+
+// (blocktype-independent) geometry of the 41 partitions in ABI order: x, y, w, h in luma samples
+__device__ __constant__ uint8_t c_part_geom[JMHIP_NPART][4] = {
+  {0,0,16,16}, {0,0,16,8},{0,8,16,8}, {0,0,8,16},{8,0,8,16}, {0,0,8,8},{8,0,8,8},{0,8,8,8},{8,8,8,8},
+  {0,0,8,4},{8,0,8,4},{0,4,8,4},{8,4,8,4},{0,8,8,4},{8,8,8,4},{0,12,8,4},{8,12,8,4},
+  {0,0,4,8},{4,0,4,8},{8,0,4,8},{12,0,4,8},{0,8,4,8},{4,8,4,8},{8,8,4,8},{12,8,4,8},
+  {0,0,4,4},{4,0,4,4},{8,0,4,4},{12,0,4,4},{0,4,4,4},{4,4,4,4},{8,4,4,4},{12,4,4,4},
+  {0,8,4,4},{4,8,4,4},{8,8,4,4},{12,8,4,4},{0,12,4,4},{4,12,4,4},{8,12,4,4},{12,12,4,4}
+};
+
+// BlockMotionSearch glue (mv_search.c:960-981): the integer-pel winner of every searched partition of
+// every window job goes straight into the sub-pel refinement, all on the device.
+__global__ __launch_bounds__(64) void k_me_refine(const jmhip_me_job *__restrict__ jobs, int njobs, const jmhip_me_result *__restrict__ ires,
+                                                  jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
+                                                  PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
+{
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const int ji = g / JMHIP_NPART, p = g - ji * JMHIP_NPART;
+  const bool live = ji < njobs;
+  const jmhip_me_job *job = jobs + (live ? ji : 0);
+  const bool active = live && ((job->part_mask >> p) & 1);
+  jmhip_subpel_job j;
+  j.pos_x = (int16_t)(job->mb_x + c_part_geom[p][0]); j.pos_y = (int16_t)(job->mb_y + c_part_geom[p][1]);
+  j.bsx = c_part_geom[p][2]; j.bsy = c_part_geom[p][3];
+  j.pred_x = job->pred[p][0]; j.pred_y = job->pred[p][1];
+  const jmhip_me_best ib = ires[live ? ji : 0].best[p];
+  j.mv_x = ib.mv_x; j.mv_y = ib.mv_y;
+  j.lambda_h = prm.lambda_h; j.lambda_q = prm.lambda_q; j.metric_h = prm.metric_h; j.metric_q = prm.metric_q;
+  j.start_hp = prm.start_hp; j.start_qp = prm.start_qp;
+  j.test8x8 = (int8_t)(prm.transform8x8_mode && p <= 8);      // mv_search.c:1630 (types 1-3) / :1770 (type 4)
+  j.min_mcost = ib.cost;
+  jmhip_me_best b = subpel_group(j, l, ps, cur, cur_pitch);
+  if (active && l == 0) out[ji].best[p] = b;
 }
 
 static PlaneSet planes_of(jmhip_ctx *ctx, int slot)
@@ -206,6 +243,21 @@ extern "C" int jmhip_me_subpel(jmhip_ctx *ctx, int32_t slot, const jmhip_subpel_
   if ((r = jmhip_me_subpel_dev(ctx, slot, (const jmhip_subpel_job *)dj, n, (jmhip_me_best *)dr))) return r;
   HIPCHK(ctx, hipMemcpyAsync(results, dr, sizeof(jmhip_me_best) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_me_refine_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, int32_t njobs, const jmhip_me_result *d_int,
+                                   const jmhip_refine_params *prm, jmhip_me_result *d_out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!d_jobs || !d_int || !prm || !d_out || njobs < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_refine_dev: bad argument");
+  if (njobs == 0) return JMHIP_OK;
+  const long groups = (long)njobs * JMHIP_NPART;
+  jmhip_time_begin(ctx, 2);
+  hipLaunchKernelGGL(k_me_refine, dim3((unsigned)((groups + 3) / 4)), dim3(64), 0, ctx->stream, d_jobs, njobs, d_int, *prm, d_out,
+                     planes_of(ctx, slot), ctx->d_cur, ctx->cur_pitch);
+  jmhip_time_end(ctx, 2);
+  HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
 }
 

