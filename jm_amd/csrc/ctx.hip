@@ -83,6 +83,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   if (!c) return jmhip_fail(NULL, JMHIP_ENOMEM, "out of host memory");
   c->cfg = *cfg;
   c->stream = (hipStream_t)cfg->stream;
+  { const char *fg = getenv("JMHIP_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
   c->W = cfg->width; c->H = cfg->height;
   c->Wp = c->W + 2 * JMHIP_PAD_X; c->Hp = c->H + 2 * JMHIP_PAD_Y;
   c->pitch = (c->Wp + 63) & ~63;

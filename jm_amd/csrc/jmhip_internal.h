@@ -26,6 +26,7 @@ struct jmhip_ctx {
   void *d_scratch2; size_t scratch2_bytes;
   int16_t *d_spiral;     // [(2R+1)^2][2] spiral offsets for R = cfg.search_range
   int timing;
+  int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];
   int ev_valid[JMHIP_NKINDS];
   char err[512];

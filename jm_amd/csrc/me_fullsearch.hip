@@ -16,70 +16,13 @@
 // (cost << 16 | spiral index) in registers, and the workgroup min-reduces the 41 keys at the end.
 // Algorithmic HBM bytes per job: 256 + (2R+16)^2 in, 328 out; nothing else leaves the CU.
 #include "jmhip_internal.h"
-
-#define NP JMHIP_NPART
-
-__device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int mvbits(int d)
-{
-  int a = iabs_(d);
-  return a == 0 ? 1 : 2 * (31 - __clz(a)) + 3;
-}
-// index of (dx,dy) in JM's spiral
-__device__ __forceinline__ int spiral_index(int dx, int dy)
-{
-  int ax = iabs_(dx), ay = iabs_(dy), l = imax_(ax, ay);
-  if (l == 0) return 0;
-  int base = (2 * l - 1) * (2 * l - 1);
-  if (ay == l && ax < l) return base + 2 * (dx + l - 1) + (dy > 0);
-  return base + 2 * (2 * l - 1) + 2 * (dy + l) + (dx > 0);
-}
+#include "me_common.h"
 
 struct JobLds {
   int16_t pred[NP][2];
   uint64_t mask;
   int lambda, max_mvd, cx, cy, R;
 };
-
-// sixteen 4x4 SADs of the macroblock at window position (wx, wy); s_win rows are wpitch bytes
-__device__ __forceinline__ void sad16(const uint8_t *s_win, int wpitch, const uint32_t *s_cur, int wx, int wy, uint32_t s7[16])
-{
-#pragma unroll
-  for (int k = 0; k < 16; k++) s7[k] = 0;
-  const int sh = wx & 3;
-  const uint32_t *row = (const uint32_t *)(s_win + wy * wpitch + (wx & ~3));
-  const int wp4 = wpitch >> 2;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    uint32_t a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
-    uint32_t b0 = __builtin_amdgcn_alignbyte(a1, a0, sh);
-    uint32_t b1 = __builtin_amdgcn_alignbyte(a2, a1, sh);
-    uint32_t b2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
-    uint32_t b3 = __builtin_amdgcn_alignbyte(a4, a3, sh);
-    const int q = (r >> 2) * 4;
-    s7[q + 0] = __builtin_amdgcn_sad_u8(b0, s_cur[r * 4 + 0], s7[q + 0]);
-    s7[q + 1] = __builtin_amdgcn_sad_u8(b1, s_cur[r * 4 + 1], s7[q + 1]);
-    s7[q + 2] = __builtin_amdgcn_sad_u8(b2, s_cur[r * 4 + 2], s7[q + 2]);
-    s7[q + 3] = __builtin_amdgcn_sad_u8(b3, s_cur[r * 4 + 3], s7[q + 3]);
-    row += wp4;
-  }
-}
-
-// the 41 partition SADs in the ABI's partition order (jmhip.h)
-__device__ __forceinline__ void aggregate41(const uint32_t s7[16], uint32_t sp[NP])
-{
-#pragma unroll
-  for (int k = 0; k < 16; k++) sp[25 + k] = s7[k];                                        // 4x4
-#pragma unroll
-  for (int by = 0; by < 4; by++) { sp[9 + by * 2] = s7[by * 4] + s7[by * 4 + 1]; sp[9 + by * 2 + 1] = s7[by * 4 + 2] + s7[by * 4 + 3]; }   // 8x4
-#pragma unroll
-  for (int bx = 0; bx < 4; bx++) { sp[17 + bx] = s7[bx] + s7[4 + bx]; sp[21 + bx] = s7[8 + bx] + s7[12 + bx]; }                             // 4x8
-  sp[5] = sp[9] + sp[11];  sp[6] = sp[10] + sp[12];  sp[7] = sp[13] + sp[15];  sp[8] = sp[14] + sp[16];                                     // 8x8
-  sp[1] = sp[5] + sp[6];   sp[2] = sp[7] + sp[8];                                                                                           // 16x8
-  sp[3] = sp[5] + sp[7];   sp[4] = sp[6] + sp[8];                                                                                           // 8x16
-  sp[0] = sp[1] + sp[2];                                                                                                                    // 16x16
-}
 
 __device__ __forceinline__ void stage_job(const jmhip_me_job *__restrict__ job, const uint8_t *__restrict__ cur, int cur_pitch,
                                           const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
@@ -114,10 +57,11 @@ __device__ __forceinline__ void stage_job(const jmhip_me_job *__restrict__ job, 
 __global__ __launch_bounds__(256) void k_me_fullsearch(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
-                                                       const int16_t *__restrict__ spiral)
+                                                       const int16_t *__restrict__ spiral, int skip_fast)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const jmhip_me_job *job = jobs + blockIdx.x;
+  if (skip_fast && job_is_fast(job)) return;               // owned by k_me_fs_fast (me_fast.hip)
   const int R = job->search_range;
   const int wpitch = (2 * R + 16 + 4 + 3) & ~3;
   uint8_t *s_win = smem;                                                   // (2R+16) x wpitch
@@ -242,9 +186,11 @@ extern "C" int jmhip_me_fullsearch_dev(jmhip_ctx *ctx, int32_t slot, const jmhip
   if (!ctx) return JMHIP_EINVAL;
   if (!d_jobs || !d_results || njobs < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_fullsearch_dev: bad argument");
   if (njobs == 0) return JMHIP_OK;
+  const int use_fast = !ctx->force_generic;
   jmhip_time_begin(ctx, 1);
+  if (use_fast) jmhip_launch_me_fast(ctx, slot, d_jobs, njobs, d_results);
   hipLaunchKernelGGL(k_me_fullsearch, dim3(njobs), dim3(256), me_lds_bytes(ctx->cfg.search_range), ctx->stream,
-                     d_jobs, d_results, ctx->d_cur, ctx->cur_pitch, ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral);
+                     d_jobs, d_results, ctx->d_cur, ctx->cur_pitch, ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, use_fast);
   jmhip_time_end(ctx, 1);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
