@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[COPY_DWORDS > MERGE_DWORDS ? COPY_DWORDS : MERGE_DWORDS];   // window copies, later the wave-merge area
   __shared__ __attribute__((aligned(16))) uint32_t s_ry[65 * RYP];            // (lambda * mvbits(cand_y - pred_y[p])) << 7, [row][partition]
+  __shared__ uint32_t s_rx64[RYP];                                              // x rate of column 64, per partition
   const jmhip_me_job *__restrict__ job = jobs + blockIdx.x;
   if (!job_is_fast(job)) return;
 
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
       // raw rows are kept 22 dwords wide in the upper part of the copy area (copies 6,7 are built last from registers)
       s_mem[(NCOPY - 2) * CSTRIDE + r * (CPITCH + 2) + c] = v;
     }
+    if (tid < NP) s_rx64[tid] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - job->pred[tid][0])) << 7;
     // y-rate table
     for (int k = tid; k < n1 * NP; k += 256) {
       const int wy = k / NP, p = k - wy * NP;
@@ -258,17 +260,14 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
   if (n1 > 64 && wave >= 1) {
 #pragma unroll
     for (int p = 0; p < NP; p++) ex[p] = 0xffffffffu;
-    if (ex_live) {
-      uint32_t s7[16], sp[NP];
-      sad16((const uint8_t *)s_mem, CPITCH * 4, cw, 64, exq, s7);
-      aggregate41(s7, sp);
-      const int dxe = 64 - R, dye = exq - R;
-      const unsigned rk = col_rank(dye, dxe);
+    if (ex_live) {                                       // wx = 64 is 8-byte aligned in copy 0: same aligned-read SAD code
+      const uint2 *cp64 = (const uint2 *)(s_mem + 2 * (64 >> 3));
+      unsigned sa[16], sb[16], pa[NP];
+      sad_pair<false>(cp64, exq, cw, sa, sb);
+      aggregate41_shifted(sa, pa);
+      const unsigned rk = col_rank(exq - R, 64 - R);
 #pragma unroll
-      for (int p = 0; p < NP; p++) {
-        const unsigned rate = (unsigned)(lambda * (mvbits(cx + 4 * dxe - job->pred[p][0]) + mvbits(cy + 4 * dye - job->pred[p][1])));
-        ex[p] = (sp[p] << 12) + (rate << 7) + rk;
-      }
+      for (int p = 0; p < NP; p++) ex[p] = pa[p] + s_ry[exq * RYP + p] + s_rx64[p] + rk;
     }
   }
   __syncthreads();                                       // every wave is done reading the window copies
