@@ -84,6 +84,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   c->cfg = *cfg;
   c->stream = (hipStream_t)cfg->stream;
   { const char *fg = getenv("JMHIP_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
+  { const char *fg = getenv("JMHIP_DEBLOCK_DIAG"); c->force_db_diag = fg && fg[0] == '1'; }
   c->W = cfg->width; c->H = cfg->height;
   c->Wp = c->W + 2 * JMHIP_PAD_X; c->Hp = c->H + 2 * JMHIP_PAD_Y;
   c->pitch = (c->Wp + 63) & ~63;
@@ -109,6 +110,8 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
     CK(hipMemcpy(c->d_spiral, sp, (size_t)n * 4, hipMemcpyHostToDevice));
     free(sp);
   }
+  CK(hipMalloc(&c->d_db_prep, (size_t)(c->W / 16) * (c->H / 16) * 96));
+  CK(hipMalloc((void **)&c->d_db_sync, (size_t)(2 + 2 * (c->H / 16)) * sizeof(unsigned)));
   for (int k = 0; k < JMHIP_NKINDS; k++) { CK(hipEventCreate(&c->ev0[k])); CK(hipEventCreate(&c->ev1[k])); }
   CK(hipStreamSynchronize(c->stream));
 #undef CK
@@ -127,6 +130,8 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   if (c->d_spiral) (void)hipFree(c->d_spiral);
+  if (c->d_db_prep) (void)hipFree(c->d_db_prep);
+  if (c->d_db_sync) (void)hipFree(c->d_db_sync);
   for (int k = 0; k < JMHIP_NKINDS; k++) { if (c->ev0[k]) (void)hipEventDestroy(c->ev0[k]); if (c->ev1[k]) (void)hipEventDestroy(c->ev1[k]); }
   free(c);
 }

@@ -25,6 +25,9 @@ struct jmhip_ctx {
   void *d_scratch; size_t scratch_bytes;     // grows on demand: jobs/results/tables for host entry points
   void *d_scratch2; size_t scratch2_bytes;
   int16_t *d_spiral;     // [(2R+1)^2][2] spiral offsets for R = cfg.search_range
+  void *d_db_prep;       // deblocking: 96-byte strength/parameter record per macroblock (k_deblock_prep)
+  unsigned *d_db_sync;   // deblocking row pipeline: ticket, error, per-row progress words
+  int force_db_diag;     // JMHIP_DEBLOCK_DIAG=1: one launch per diagonal instead of the row pipeline (A/B testing)
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];
@@ -44,3 +47,5 @@ void jmhip_time_end(jmhip_ctx *ctx, int kind);
 
 // kernels' launchers (defined next to the kernels)
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);
+int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,
+                              const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8);
