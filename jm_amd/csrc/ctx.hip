@@ -110,8 +110,9 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
     CK(hipMemcpy(c->d_spiral, sp, (size_t)n * 4, hipMemcpyHostToDevice));
     free(sp);
   }
-  CK(hipMalloc(&c->d_db_prep, (size_t)(c->W / 16) * (c->H / 16) * 96));
-  CK(hipMalloc((void **)&c->d_db_sync, (size_t)(2 + 2 * (c->H / 16)) * sizeof(unsigned)));
+  CK(hipMalloc(&c->d_db_prep, (size_t)(c->W / 16) * (c->H / 16) * 192));
+  CK(hipMalloc((void **)&c->d_db_sync, 64 + (size_t)(c->H / 16) * 2 * 6 * 8));
+  CK(hipMalloc(&c->d_db_hand, (size_t)(c->W / 16) * (c->H / 16) * 192));
   for (int k = 0; k < JMHIP_NKINDS; k++) { CK(hipEventCreate(&c->ev0[k])); CK(hipEventCreate(&c->ev1[k])); }
   CK(hipStreamSynchronize(c->stream));
 #undef CK
@@ -132,8 +133,18 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   if (c->d_spiral) (void)hipFree(c->d_spiral);
   if (c->d_db_prep) (void)hipFree(c->d_db_prep);
   if (c->d_db_sync) (void)hipFree(c->d_db_sync);
+  if (c->d_db_hand) (void)hipFree(c->d_db_hand);
   for (int k = 0; k < JMHIP_NKINDS; k++) { if (c->ev0[k]) (void)hipEventDestroy(c->ev0[k]); if (c->ev1[k]) (void)hipEventDestroy(c->ev1[k]); }
   free(c);
+}
+
+// not part of the ABI: copies the deblocking pipeline's sync / profile words to the host (profiles/prof_deblock.py)
+extern "C" int jmhip_debug_read_db_sync(jmhip_ctx *ctx, void *out, size_t bytes)
+{
+  if (!ctx || !out || bytes > 64 + (size_t)(ctx->H / 16) * 2 * 6 * 8) return JMHIP_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(out, ctx->d_db_sync, bytes, hipMemcpyDeviceToHost));
+  return JMHIP_OK;
 }
 
 extern "C" int jmhip_synchronize(jmhip_ctx *ctx)

@@ -12,24 +12,27 @@
 //   k_deblock_prep  (fully parallel) boundary strengths of all 32 edge segments of every macroblock with
 //                   DeblockMb's skip rules folded in (strength 0 = leave the segment alone), and the
 //                   alpha / beta / indexA of the left edge, the top edge and the internal edges for Y, U, V:
-//                   one 96-byte record per macroblock.  Also zeroes the pipeline's progress words.
+//                   one 192-byte record per macroblock (tc0 included).  Also zeroes the pipeline's progress words.
 //   k_deblock_rows  one workgroup (one wave) per macroblock row and plane kind (luma | both chroma planes).
 //                   It walks the row left to right.  The tile (macroblock + 8 left columns + 4 top rows) lives
 //                   in LDS; lane = sample row for the vertical edges, lane = sample column for the
 //                   horizontal edges, the four edges of a direction are filtered in registers.  The left
-//                   neighbour is carried in LDS.  The top neighbour's bottom rows come from the row above:
-//                   a row publishes "macroblocks 0..k-1 are final in memory" in a progress word after
-//                   storing its samples write-through (sc1) and draining its stores; the row below polls
-//                   that word (relaxed, agent scope) until it covers the top-right neighbour and reads the
-//                   handed-over rows with sc1 loads (they bypass the CU's L1).  No fences, no grid barrier.
+//                   neighbour is carried in LDS.  The top neighbour's bottom rows come from the row above as
+//                   8-byte "granules" {tag, four samples}, each written by ONE write-through (sc1) store the
+//                   moment the four samples are final (columns 0..11 of a macroblock right after its horizontal
+//                   edges, columns 12..15 right after the vertical edges of the next macroblock), and read with
+//                   sc1 loads (they bypass the CU's L1) until the tag shows: the data is the flag, so there is no
+//                   fence, no drain, no progress counter and no grid barrier, and a row trails the row above by
+//                   about one and a half macroblocks.  Every image sample is stored by exactly one row (a row
+//                   leaves its bottom four rows to the row below, which filters them across its top edge).
 //                   Rows draw their index from an atomic ticket, so a row only ever waits for a row whose
 //                   workgroup has already started: no assumption about dispatch order.  Every spin is
 //                   bounded; a timeout sets an error word that all rows watch.
 //
-// What is stored when (luma; chroma is the same with 8-sample macroblocks and a 2-row top halo):
-//   after step x: rows 0..15 x columns 16x-8 .. 16x+7 (final: nothing later in this row touches them) and the
-//   top neighbour's rows -4..-1 x columns 16x .. 16x+15; after the last step also columns 16x+8 .. 16x+15.
-//   The row below may start macroblock x once progress >= min(x+2, W/16).  All stores are 8-byte aligned.
+// Image stores per step (luma; chroma is the same with 8-sample macroblocks and a 2-row top halo):
+//   rows 0..11 (0..15 in the bottom macroblock row) x columns 16x-8 .. 16x+7 -- final, nothing later in this row
+//   touches them -- and the top neighbour's rows -4..-1 x columns 16x .. 16x+15; after the last step also columns
+//   16x+8 .. 16x+15.  All stores are 8-byte aligned.
 #include "deblock_common.h"
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -37,15 +40,18 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 struct __attribute__((aligned(16))) DbPrep {
-  uint8_t bsY[2][4][4];      // [dir][edge][segment] luma strengths, 0 = nothing to do
-  uint8_t bsC[2][4][4];      // the same for chroma (indexed by the luma edge number)
-  uint8_t prm[3][3][3];      // [Y,U,V][left edge, top edge, internal][alpha, beta, indexA]
-  uint8_t pad_[5];
-};                           // 96 bytes
+  uint8_t bsY[2][4][4];      // [dir][segment][edge] luma strengths, 0 = nothing to do; a lane reads its four edges as one dword
+  uint8_t c0Y[2][4][4];      // CLIP_TAB[indexA][bS] of the same segments (loop_filter.h:39-45)
+  uint8_t bsC[2][4][4];      // chroma strengths (indexed by the luma edge number)
+  uint8_t c0C[2][2][4][4];   // [U,V][dir][segment][edge]
+  uint8_t ab[3][3][2];       // [Y,U,V][left edge, top edge, internal][alpha, beta]
+  uint8_t pad_[14];
+};                           // 192 bytes = 12 x 16
+#define PREP_VEC 12
 
 __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restrict__ mbs, const jmhip_db_motion *__restrict__ motion,
                                                       int mb_w, int mb_h, int fmt, int direct8x8, DbPrep *__restrict__ prep,
-                                                      unsigned *__restrict__ sync, int nsync)
+                                                      unsigned *__restrict__ sync, int nsync, unsigned long long *__restrict__ hand)
 {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) for (int k = tid; k < nsync; k += 256) sync[k] = 0;
@@ -75,17 +81,23 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restr
   if (!(edge || (dir == 0 ? left_ok : top_ok))) do_edge = false;
   const int S = do_edge ? strength_of(dir, edge, idx, addr, mb_w, mbs, motion) : 0;
   const int ecr = (fmt == 1 || fmt == 2) ? c_chroma_edge[dir][edge][fmt] : -4;
-  o->bsY[dir][edge][idx] = (uint8_t)(non8x8 ? S : 0);
-  o->bsC[dir][edge][idx] = (uint8_t)(ecr >= 0 ? S : 0);
-  if (l < 9) {
-    const int comp = l / 3, which = l - comp * 3;
-    const jmhip_db_mb *p = which == 0 ? (mbx ? &mbs[addr - 1] : q) : (which == 1 ? (mby ? &mbs[addr - mb_w] : q) : q);
+  // alpha / beta / indexA of this edge: the neighbour across edge 0, the macroblock itself inside (DeblockMb / EdgeLoop*: QP average)
+  const jmhip_db_mb *p = edge ? q : (dir == 0 ? (mbx ? &mbs[addr - 1] : q) : (mby ? &mbs[addr - mb_w] : q));
+  const int which = edge ? 2 : dir;
+  const int sc = S > 3 ? 3 : S;
+#pragma unroll
+  for (int comp = 0; comp < 3; comp++) {
     const int qq = comp ? q->qpc[comp - 1] : q->qp, qp = comp ? p->qpc[comp - 1] : p->qp;
     const int QP = (qp + qq + 1) >> 1;
     const int iA = clip3(0, 51, QP + q->df_alpha_c0), iB = clip3(0, 51, QP + q->df_beta);
-    o->prm[comp][which][0] = c_alpha[iA]; o->prm[comp][which][1] = c_beta[iB]; o->prm[comp][which][2] = (uint8_t)iA;
+    if (comp == 0) o->c0Y[dir][idx][edge] = c_tc0[iA][sc];
+    else o->c0C[comp - 1][dir][idx][edge] = c_tc0[iA][sc];
+    if (idx == 0 && edge < 2) { o->ab[comp][which][0] = c_alpha[iA]; o->ab[comp][which][1] = c_beta[iB]; }
   }
-  if (l < 5) o->pad_[l] = 0;
+  o->bsY[dir][idx][edge] = (uint8_t)(non8x8 ? S : 0);
+  o->bsC[dir][idx][edge] = (uint8_t)(ecr >= 0 ? S : 0);
+  if (l < 14) o->pad_[l] = 0;
+  if (l < 24) hand[(long)addr * 24 + l] = 0;        // hand-over granules of this macroblock: tag 0 = not there yet
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -139,106 +151,133 @@ __device__ __forceinline__ void chroma_edge4(int &L1r, int &L0r, int &R0r, int &
 
 struct RowArgs {
   uint8_t *Y, *U, *V; int pitchY, pitchC;
-  const DbPrep *prep; unsigned *sync;          // sync[0] ticket, sync[1] error, sync[2 + kind*mb_h + row] progress
+  const DbPrep *prep; unsigned *sync;          // sync[0] ticket, sync[1] error
+  unsigned long long *hand;                    // hand-over granules: per macroblock 16 luma + 8 chroma, zeroed by k_deblock_prep
   int mb_w, mb_h, fmt, nkinds;
 };
+#ifdef JMHIP_DB_PROFILE      // per-row cycle sums of the five phases of a step, read back by profiles/prof_deblock.py
+#define PROF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PROF(k) { const unsigned long long n_ = __builtin_readcyclecounter(); pf_acc[k] += n_ - pf_t; pf_t = n_; }
+#define PROF_OUT(kind) if (lane == 0) for (int k_ = 0; k_ < 6; k_++) ((unsigned long long *)(A.sync + 16))[((kind) * A.mb_h + row) * 6 + k_] = pf_acc[k_];
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_OUT(kind)
+#endif
+#define HAND_PER_MB 24                         // 8-byte granules per macroblock: [0,16) luma rows 12..15 x 4 dwords, [16,24) chroma
 
 #define DB_SPIN_LIMIT (1u << 21)
 
-// wave-uniform: wait until *flag >= need; false on timeout / pipeline error
-__device__ __forceinline__ bool wait_progress(gu32 *flag, unsigned need, gu32 *err)
+__device__ __forceinline__ void st8(uint8_t *p, uint32_t lo, uint32_t hi) { *(uint2 *)p = make_uint2(lo, hi); }
+// a granule = {tag 1, four samples}: ONE 8-byte write-through store, so a reader that sees the tag sees the samples
+__device__ __forceinline__ void put_granule(unsigned long long *g, uint32_t samples)
+{
+  __hip_atomic_store((gu64 *)g, (1ull << 32) | samples, RLX_AGENT);
+}
+__device__ __forceinline__ unsigned long long get_granule(const unsigned long long *g) { return __hip_atomic_load((gu64 *)g, RLX_AGENT); }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
+
+// wave-uniform: re-read this lane's granule (lanes with `mine`) until every tag is set; false on timeout / pipeline error
+__device__ __forceinline__ bool await_granules(const unsigned long long *g, bool mine, unsigned long long &v, gu32 *err)
 {
   for (unsigned spins = 0;; spins++) {
-    if (__hip_atomic_load(flag, RLX_AGENT) >= need) return true;
+    if (__all(!mine || (v >> 32) != 0)) return true;
     if ((spins & 31u) == 31u && __hip_atomic_load(err, RLX_AGENT) != 0) return false;
     if (spins > DB_SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); return false; }
     __builtin_amdgcn_s_sleep(1);
+    if (mine) v = get_granule(g);
   }
 }
-__device__ __forceinline__ void publish(gu32 *flag, unsigned value, int lane)
-{
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the write-through stores of this wave have landed
-  if (lane == 0) __hip_atomic_store(flag, value, RLX_AGENT);
-}
-__device__ __forceinline__ void st8(uint8_t *p, uint32_t lo, uint32_t hi)
-{
-  __hip_atomic_store((gu64 *)p, ((unsigned long long)hi << 32) | lo, RLX_AGENT);        // global_store_dwordx2 ... sc1
-}
-__device__ __forceinline__ uint2 ld8_sc1(const uint8_t *p)
-{
-  const unsigned long long v = __hip_atomic_load((gu64 *)p, RLX_AGENT);
-  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-}
-__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
+
+// Step structure of a row (both kinds).  At the top of step x the LDS tile already holds macroblock x (own samples,
+// top rows, carried left columns) and s_prep its strength record; registers hold the own samples / record of x+1.
+//   1. issue loads: own samples / record of x+2
+//   2. vertical edges; hand the row below the now-final last columns of macroblock x-1's bottom rows; ask for the
+//      hand-over granules of the top neighbour of x+1
+//   3. horizontal edges; hand over the first columns of macroblock x's bottom rows
+//   4. image stores (each sample is stored by exactly one row: a row leaves its bottom rows to the row below, which
+//      filters them across its top edge); build the tile of x+1 (wait for the granules only if they are not there yet)
+// A row therefore trails the row above by about 1.5 steps plus one store->load hop, not by whole-macroblock flags.
 
 // ---- luma row: tile rows -4..15 (index +4), columns -8..15 (byte index +8), pitch 24 bytes
 #define YP 24
-__device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, const uint8_t *s_tc0, uint8_t *s_prep)
+__device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_prep)
 {
   const int lane = threadIdx.x, mb_w = A.mb_w;
   uint32_t *tile = (uint32_t *)s_tile;
-  gu32 *err = (gu32 *)(A.sync + 1), *prog = (gu32 *)(A.sync + 2 + row), *up = (gu32 *)(A.sync + 2 + row - 1);
+  gu32 *err = (gu32 *)(A.sync + 1);
   uint8_t *rowp = A.Y + (long)(16 * row) * A.pitchY;
   const DbPrep *prow = A.prep + (long)row * mb_w;
-  bool alive = true;
+  const bool has_up = row > 0, has_down = row + 1 < A.mb_h;
+  const bool is_own = lane < 16, is_top = lane >= 16 && lane < 20 && has_up, is_pre = lane >= 32 && lane < 32 + PREP_VEC;
+  const bool is_gran = lane >= 16 && lane < 32 && has_up;                    // granule (lane-16) = top row (lane-16)>>2, dword (lane-16)&3
+  const uint8_t *own_p = rowp + (long)lane * A.pitchY;                        // is_own lanes: sample row `lane`
+  uint8_t *top_p = rowp + (long)(lane - 20) * A.pitchY;                       // is_top lanes: rows -4..-1
+  const unsigned long long *hand_up = A.hand + (long)(row - 1) * mb_w * HAND_PER_MB + (lane - 16);
+  unsigned long long *hand_me = A.hand + (long)row * mb_w * HAND_PER_MB;
+  const int own_rows = has_down ? 12 : 16;                                    // rows 12..15 are stored by the row below
 
-  uint4 own = make_uint4(0, 0, 0, 0), pre = make_uint4(0, 0, 0, 0);            // prefetched: own sample row / 16 bytes of the prep record
-  if (lane < 16) own = *(const uint4 *)(rowp + (long)lane * A.pitchY);
-  else if (lane >= 32 && lane < 38) pre = ((const uint4 *)prow)[lane - 32];
+  uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1;
+  unsigned long long gr = 0;
+  // ---- prologue: tile of macroblock 0, registers of macroblock 1
+  if (is_own) own1 = *(const uint4 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 32];
+  if (is_gran) gr = get_granule(hand_up);
+  if (is_own) { uint32_t *d = tile + (lane + 4) * 6 + 2; d[0] = own1.x; d[1] = own1.y; d[2] = own1.z; d[3] = own1.w; }
+  else if (is_pre) ((uint4 *)s_prep)[lane - 32] = pre1;
+  if (mb_w > 1) { if (is_own) own1 = *(const uint4 *)(own_p + 16); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 32]; }
+  if (has_up) {
+    if (!await_granules(hand_up, is_gran, gr, err)) return;
+    if (is_gran) tile[((lane - 16) >> 2) * 6 + 2 + ((lane - 16) & 3)] = (uint32_t)gr;
+  }
 
-  for (int x = 0; x < mb_w && alive; x++) {
-    // ---- top neighbour rows: wait for the row above to have finished macroblock x+1
-    uint2 t0 = make_uint2(0, 0), t1 = make_uint2(0, 0);
-    if (row > 0) {
-      alive = wait_progress(up, (unsigned)min(x + 2, mb_w), err);
-      if (!alive) break;
-      if (lane >= 16 && lane < 20) {
-        const uint8_t *tp = rowp + (long)(lane - 20) * A.pitchY + 16 * x;
-        t0 = ld8_sc1(tp); t1 = ld8_sc1(tp + 8);
-      }
-    }
-    // ---- tile: own rows, top rows, prep record
-    if (lane < 16) { uint32_t *d = tile + (lane + 4) * 6 + 2; d[0] = own.x; d[1] = own.y; d[2] = own.z; d[3] = own.w; }
-    else if (lane < 20) { uint32_t *d = tile + (lane - 16) * 6 + 2; d[0] = t0.x; d[1] = t0.y; d[2] = t1.x; d[3] = t1.y; }
-    else if (lane >= 32 && lane < 38) ((uint4 *)s_prep)[lane - 32] = pre;
+  PROF_DECL
+  for (int x = 0; x < mb_w; x++) {
     __syncthreads();
-    // prefetch the next macroblock's own rows and prep record (nobody else writes them before this row does)
-    if (x + 1 < mb_w) {
-      if (lane < 16) own = *(const uint4 *)(rowp + (long)lane * A.pitchY + 16 * (x + 1));
-      else if (lane >= 32 && lane < 38) pre = ((const uint4 *)(prow + x + 1))[lane - 32];
-    }
+    PROF(0)
+    // ---- 1. loads for the next steps
+    if (x + 2 < mb_w) { if (is_own) own2 = *(const uint4 *)(own_p + 16 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 32]; }
+
     const DbPrep *P = (const DbPrep *)s_prep;
-    // ---- vertical edges: lane = sample row, columns -4..15 in registers
+    // ---- 2. vertical edges: lane = sample row, columns -4..15 in registers
     if (lane < 16) {
       uint32_t *t = tile + (lane + 4) * 6 + 1;
-      const uint32_t w0 = t[0], w1 = t[1], w2 = t[2], w3 = t[3], w4 = t[4];
-      const uint32_t bs4 = *(const uint32_t *)&P->bsY[0][0][0] | *(const uint32_t *)&P->bsY[0][1][0] | *(const uint32_t *)&P->bsY[0][2][0] | *(const uint32_t *)&P->bsY[0][3][0];
-      if (bs4) {
+      const int seg = lane >> 2;
+      const uint32_t bs = *(const uint32_t *)&P->bsY[0][seg][0];
+      if (bs) {
+        const uint32_t c0 = *(const uint32_t *)&P->c0Y[0][seg][0];
+        const uint32_t abE = *(const uint16_t *)&P->ab[0][0][0], abI = *(const uint16_t *)&P->ab[0][2][0];
+        const uint32_t w[5] = {t[0], t[1], t[2], t[3], t[4]};
         int p[20];
-        const uint32_t w[5] = {w0, w1, w2, w3, w4};
 #pragma unroll
         for (int k = 0; k < 20; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
-        const int seg = lane >> 2;
-#define VEDGE(E) { const int bS = P->bsY[0][E][seg]; if (bS) { const uint8_t *q = P->prm[0][(E) ? 2 : 0]; \
-                     luma_edge<4 * (E), 20>(p, bS, q[0], q[1], s_tc0[q[2] * 4 + (bS > 3 ? 3 : bS)]); } }
+#define VEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; if (bS) { const uint32_t ab = (E) ? abI : abE; \
+                     luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); } }
         VEDGE(0) VEDGE(1) VEDGE(2) VEDGE(3)
 #undef VEDGE
 #pragma unroll
         for (int k = 0; k < 5; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
       }
+      // columns 12..15 of macroblock x-1 (tile columns -4..-1) are final now: hand its bottom rows to the row below
+      if (has_down && x > 0 && lane >= 12) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + (lane - 12) * 4 + 3, t[0]);
     }
     __syncthreads();
-    // ---- horizontal edges: lane = sample column, rows -4..15 in registers
+    PROF(1)
+    // the top neighbour of x+1: asked for as late as the horizontal edges can still hide the round trip, so that a row
+    // running close behind the row above finds the granules there at the first look
+    if (is_gran && x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB);
+    // ---- 3. horizontal edges: lane = sample column, rows -4..15 in registers
     if (lane < 16) {
-      const uint32_t bs4 = *(const uint32_t *)&P->bsY[1][0][0] | *(const uint32_t *)&P->bsY[1][1][0] | *(const uint32_t *)&P->bsY[1][2][0] | *(const uint32_t *)&P->bsY[1][3][0];
-      if (bs4) {
+      const int seg = lane >> 2;
+      const uint32_t bs = *(const uint32_t *)&P->bsY[1][seg][0];
+      if (bs) {
+        const uint32_t c0 = *(const uint32_t *)&P->c0Y[1][seg][0];
+        const uint32_t abE = *(const uint16_t *)&P->ab[0][1][0], abI = *(const uint16_t *)&P->ab[0][2][0];
         uint8_t *c = s_tile + 8 + lane;
         int p[20];
 #pragma unroll
         for (int k = 0; k < 20; k++) p[k] = c[k * YP];
-        const int seg = lane >> 2;
-#define HEDGE(E) { const int bS = P->bsY[1][E][seg]; if (bS) { const uint8_t *q = P->prm[0][(E) ? 2 : 1]; \
-                     luma_edge<4 * (E), 20>(p, bS, q[0], q[1], s_tc0[q[2] * 4 + (bS > 3 ? 3 : bS)]); } }
+#define HEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; if (bS) { const uint32_t ab = (E) ? abI : abE; \
+                     luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); } }
         HEDGE(0) HEDGE(1) HEDGE(2) HEDGE(3)
 #undef HEDGE
 #pragma unroll
@@ -246,92 +285,120 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, const uint8
       }
     }
     __syncthreads();
-    // ---- write-through stores, carry, publish
-    if (lane < 16) {
-      uint32_t *t = tile + (lane + 4) * 6;
-      uint8_t *g = rowp + (long)lane * A.pitchY + 16 * x;
-      if (x > 0) st8(g - 8, t[0], t[1]);
-      st8(g, t[2], t[3]);
-      if (x == mb_w - 1) st8(g + 8, t[4], t[5]);
-      t[0] = t[4]; t[1] = t[5];                                               // columns 8..15 become the next macroblock's -8..-1
-    } else if (lane < 20 && row > 0) {
-      const uint32_t *t = tile + (lane - 16) * 6 + 2;
-      uint8_t *g = rowp + (long)(lane - 20) * A.pitchY + 16 * x;
-      st8(g, t[0], t[1]); st8(g + 8, t[2], t[3]);
+    PROF(2)
+    // bottom rows 12..15 of macroblock x: columns 0..11 are final (12..15 too when this is the last macroblock of the row)
+    if (has_down && lane >= 48) {
+      const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
+      if (c4 < 3 || x == mb_w - 1) put_granule(hand_me + (long)x * HAND_PER_MB + r * 4 + c4, tile[(16 + r) * 6 + 2 + c4]);
     }
-    publish(prog, (unsigned)(x + 1), lane);
-    __syncthreads();
+    // ---- 4. image stores of step x, then the tile of x+1
+    if (is_own) {
+      uint32_t *t = tile + (lane + 4) * 6;
+      uint8_t *g = (uint8_t *)own_p + 16 * x;
+      const uint32_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3], c4 = t[4], c5 = t[5];
+      if (lane < own_rows) {
+        if (x > 0) st8(g - 8, c0, c1);
+        st8(g, c2, c3);
+        if (x == mb_w - 1) st8(g + 8, c4, c5);
+      }
+      t[0] = c4; t[1] = c5;                                                   // columns 8..15 become the next macroblock's -8..-1
+      t[2] = own1.x; t[3] = own1.y; t[4] = own1.z; t[5] = own1.w;
+    } else if (is_top) {
+      uint32_t *t = tile + (lane - 16) * 6 + 2;
+      uint8_t *g = top_p + 16 * x;
+      st8(g, t[0], t[1]); st8(g + 8, t[2], t[3]);
+    } else if (is_pre) ((uint4 *)s_prep)[lane - 32] = pre1;
+    PROF(3)
+    if (has_up && x + 1 < mb_w) {
+      if (!await_granules(hand_up + (long)(x + 1) * HAND_PER_MB, is_gran, gr, err)) return;
+      if (is_gran) tile[((lane - 16) >> 2) * 6 + 2 + ((lane - 16) & 3)] = (uint32_t)gr;
+    }
+    own1 = own2; pre1 = pre2;
+    PROF(4)
   }
+  PROF_OUT(0)
 }
 
 // ---- chroma row: both planes; per plane tile rows -2..RH-1 (index +2), columns -8..7 (byte index +8), pitch 16 bytes
 #define CPB 16
-__device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 planes x 18 rows x 16 */, const uint8_t *s_tc0, uint8_t *s_prep)
+__device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 planes x 18 rows x 16 */, uint8_t *s_prep)
 {
   const int lane = threadIdx.x, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8;
-  gu32 *err = (gu32 *)(A.sync + 1), *prog = (gu32 *)(A.sync + 2 + A.mb_h + row), *up = (gu32 *)(A.sync + 2 + A.mb_h + row - 1);
+  gu32 *err = (gu32 *)(A.sync + 1);
   const DbPrep *prow = A.prep + (long)row * mb_w;
-  // roles: lanes [0, 2RH): (plane, sample row) for loads / vertical edges / stores; lanes [0,16): (plane, column) for horizontal edges
-  const int uvr = lane / RH, rr = lane - uvr * RH;               // valid for lane < 2*RH
-  const bool is_row = lane < 2 * RH;
-  uint8_t *plane_r = (uvr ? A.V : A.U) + (long)(RH * row) * A.pitchC;
-  const int uvc = (lane >> 3) & 1, cc = lane & 7;                // valid for lane < 16
-  const bool is_top = lane >= 32 && lane < 36;                   // lanes 32..35: (plane, top row -2 / -1)
-  const int uvt = (lane - 32) >> 1, tr = (lane - 32) & 1;
-  uint8_t *plane_t = (uvt ? A.V : A.U) + (long)(RH * row) * A.pitchC;
-  bool alive = true;
+  const bool has_up = row > 0, has_down = row + 1 < A.mb_h;
+  // roles: lanes [0, 2RH): (plane, sample row) for loads / vertical edges / stores; lanes [0,16): (plane, column) for the
+  // horizontal edges; lanes 32..35: (plane, top row -2 / -1) image stores; lanes 40..51: the prep record;
+  // lanes 56..63: granule (lane-56) = plane (bit 2), top row (bit 1), dword (bit 0)
+  const bool is_own = lane < 2 * RH, is_top = lane >= 32 && lane < 36 && has_up, is_pre = lane >= 40 && lane < 40 + PREP_VEC;
+  const bool is_gran = lane >= 56 && has_up;
+  const int uvr = is_own ? lane / RH : 0, rr = lane - uvr * RH;
+  const uint8_t *own_p = (uvr ? A.V : A.U) + (long)(RH * row + rr) * A.pitchC;
+  uint8_t *own_t = s_tile + uvr * 18 * CPB + (rr + 2) * CPB;
+  const int uvc = (lane >> 3) & 1, cc = lane & 7;
+  const int uvt = (lane >> 1) & 1, tr = lane & 1;
+  uint8_t *top_p = (uvt ? A.V : A.U) + (long)(RH * row + tr - 2) * A.pitchC;
+  uint8_t *top_t = s_tile + uvt * 18 * CPB + tr * CPB;
+  const int gq = lane - 56;                                                  // granule index of is_gran lanes
+  uint32_t *gran_t = (uint32_t *)(s_tile + ((gq >> 2) & 1) * 18 * CPB + ((gq >> 1) & 1) * CPB + 8) + (gq & 1);
+  const unsigned long long *hand_up = A.hand + (long)(row - 1) * mb_w * HAND_PER_MB + 16 + gq;
+  unsigned long long *hand_me = A.hand + (long)row * mb_w * HAND_PER_MB + 16;
+  const bool store_own = has_down ? rr < RH - 2 : true;                      // the last two rows are stored by the row below
 
-  uint2 own = make_uint2(0, 0); uint4 pre = make_uint4(0, 0, 0, 0);
-  if (is_row) own = *(const uint2 *)(plane_r + (long)rr * A.pitchC);
-  if (lane >= 40 && lane < 46) pre = ((const uint4 *)prow)[lane - 40];
+  uint2 own1 = make_uint2(0, 0), own2 = own1;
+  uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1;
+  unsigned long long gr = 0;
+  if (is_own) own1 = *(const uint2 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 40];
+  if (is_gran) gr = get_granule(hand_up);
+  if (is_own) { uint32_t *d = (uint32_t *)(own_t + 8); d[0] = own1.x; d[1] = own1.y; }
+  else if (is_pre) ((uint4 *)s_prep)[lane - 40] = pre1;
+  if (mb_w > 1) { if (is_own) own1 = *(const uint2 *)(own_p + 8); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 40]; }
+  if (has_up) {
+    if (!await_granules(hand_up, is_gran, gr, err)) return;
+    if (is_gran) *gran_t = (uint32_t)gr;
+  }
 
-  for (int x = 0; x < mb_w && alive; x++) {
-    uint2 t0 = make_uint2(0, 0);
-    if (row > 0) {
-      alive = wait_progress(up, (unsigned)min(x + 2, mb_w), err);
-      if (!alive) break;
-      if (is_top) t0 = ld8_sc1(plane_t + (long)(tr - 2) * A.pitchC + 8 * x);
-    }
-    if (is_row) { uint32_t *d = (uint32_t *)(s_tile + uvr * 18 * CPB + (rr + 2) * CPB + 8); d[0] = own.x; d[1] = own.y; }
-    if (is_top) { uint32_t *d = (uint32_t *)(s_tile + uvt * 18 * CPB + tr * CPB + 8); d[0] = t0.x; d[1] = t0.y; }
-    if (lane >= 40 && lane < 46) ((uint4 *)s_prep)[lane - 40] = pre;
+  for (int x = 0; x < mb_w; x++) {
     __syncthreads();
-    if (x + 1 < mb_w) {
-      if (is_row) own = *(const uint2 *)(plane_r + (long)rr * A.pitchC + 8 * (x + 1));
-      if (lane >= 40 && lane < 46) pre = ((const uint4 *)(prow + x + 1))[lane - 40];
-    }
+    if (x + 2 < mb_w) { if (is_own) own2 = *(const uint2 *)(own_p + 8 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 40]; }
+
     const DbPrep *P = (const DbPrep *)s_prep;
     // ---- vertical edges (luma edges 0 and 2 -> chroma columns 0 and 4): lane = (plane, row), columns -4..7
-    if (is_row) {
-      const uint32_t bs4 = *(const uint32_t *)&P->bsC[0][0][0] | *(const uint32_t *)&P->bsC[0][2][0];
-      if (bs4) {
-        uint32_t *t = (uint32_t *)(s_tile + uvr * 18 * CPB + (rr + 2) * CPB + 4);
+    if (is_own) {
+      const int seg = RH == 8 ? (rr >> 1) : (rr >> 2);
+      const uint32_t bs = *(const uint32_t *)&P->bsC[0][seg][0] & 0x00ff00ffu;        // luma edges 0 and 2
+      uint32_t *t = (uint32_t *)(own_t + 4);
+      if (bs) {
+        const uint32_t c0 = *(const uint32_t *)&P->c0C[uvr][0][seg][0];
+        const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvr][0][0], abI = *(const uint16_t *)&P->ab[1 + uvr][2][0];
         const uint32_t w[3] = {t[0], t[1], t[2]};
         int p[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
-        const int seg = RH == 8 ? (rr >> 1) : (rr >> 2);
-        { const int bS = P->bsC[0][0][seg]; if (bS) { const uint8_t *q = P->prm[1 + uvr][0];
-            chroma_edge4(p[2], p[3], p[4], p[5], bS, q[0], q[1], s_tc0[q[2] * 4 + (bS > 3 ? 3 : bS)]); } }
-        { const int bS = P->bsC[0][2][seg]; if (bS) { const uint8_t *q = P->prm[1 + uvr][2];
-            chroma_edge4(p[6], p[7], p[8], p[9], bS, q[0], q[1], s_tc0[q[2] * 4 + (bS > 3 ? 3 : bS)]); } }
+        { const int bS = bs & 255; if (bS) chroma_edge4(p[2], p[3], p[4], p[5], bS, abE & 255, abE >> 8, c0 & 255); }
+        { const int bS = (bs >> 16) & 255; if (bS) chroma_edge4(p[6], p[7], p[8], p[9], bS, abI & 255, abI >> 8, (c0 >> 16) & 255); }
 #pragma unroll
         for (int k = 0; k < 3; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
       }
+      // columns 4..7 of macroblock x-1 (tile columns -4..-1) are final: hand its last two rows to the row below
+      if (has_down && x > 0 && rr >= RH - 2) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + uvr * 4 + (rr - (RH - 2)) * 2 + 1, t[0]);
     }
     __syncthreads();
+    if (is_gran && x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB);
     // ---- horizontal edges: lane = (plane, column), rows -2..RH-1
     if (lane < 16) {
-      const uint32_t bs4 = *(const uint32_t *)&P->bsC[1][0][0] | *(const uint32_t *)&P->bsC[1][1][0] | *(const uint32_t *)&P->bsC[1][2][0] | *(const uint32_t *)&P->bsC[1][3][0];
-      if (bs4) {
+      const int seg = cc >> 1;
+      const uint32_t bs = *(const uint32_t *)&P->bsC[1][seg][0];
+      if (bs) {
+        const uint32_t c0 = *(const uint32_t *)&P->c0C[uvc][1][seg][0];
+        const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvc][1][0], abI = *(const uint16_t *)&P->ab[1 + uvc][2][0];
         uint8_t *c = s_tile + uvc * 18 * CPB + 8 + cc;
         int p[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) p[k] = (k < RH + 2) ? c[k * CPB] : 0;
-        const int seg = cc >> 1;
         // chroma_edge[1][e][fmt]: 4:2:0 -> rows 0 (e=0), 4 (e=2); 4:2:2 -> rows 0, 4, 8, 12 (e = 0..3)
-#define CHEDGE(E, ROW) { const int bS = P->bsC[1][E][seg]; if (bS) { const uint8_t *q = P->prm[1 + uvc][(E) ? 2 : 1]; \
-                           chroma_edge4(p[ROW], p[(ROW) + 1], p[(ROW) + 2], p[(ROW) + 3], bS, q[0], q[1], s_tc0[q[2] * 4 + (bS > 3 ? 3 : bS)]); } }
+#define CHEDGE(E, ROW) { const int bS = (bs >> (8 * (E))) & 255; if (bS) { const uint32_t ab = (E) ? abI : abE; \
+                           chroma_edge4(p[ROW], p[(ROW) + 1], p[(ROW) + 2], p[(ROW) + 3], bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); } }
         CHEDGE(0, 0)
         if (fmt == 1) { CHEDGE(2, 4) }
         else { CHEDGE(1, 4) CHEDGE(2, 8) CHEDGE(3, 12) }
@@ -341,19 +408,30 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
       }
     }
     __syncthreads();
-    if (is_row) {
-      uint32_t *t = (uint32_t *)(s_tile + uvr * 18 * CPB + (rr + 2) * CPB);
-      uint8_t *g = plane_r + (long)rr * A.pitchC + 8 * x;
-      if (x > 0) st8(g - 8, t[0], t[1]);
-      if (x == mb_w - 1) st8(g, t[2], t[3]);
-      t[0] = t[2]; t[1] = t[3];
+    // last two rows of macroblock x: columns 0..3 are final (4..7 too when this is the last macroblock of the row)
+    if (has_down && lane >= 48 && lane < 56) {
+      const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1, c4 = q & 1;
+      if (c4 == 0 || x == mb_w - 1)
+        put_granule(hand_me + (long)x * HAND_PER_MB + q, *((const uint32_t *)(s_tile + uv * 18 * CPB + (RH + r) * CPB + 8) + c4));
     }
-    if (is_top && tr == 1 && row > 0) {
-      const uint32_t *t = (const uint32_t *)(s_tile + uvt * 18 * CPB + CPB + 8);
-      st8(plane_t - (long)A.pitchC + 8 * x, t[0], t[1]);
+    if (is_own) {
+      uint32_t *t = (uint32_t *)own_t;
+      uint8_t *g = (uint8_t *)own_p + 8 * x;
+      const uint32_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
+      if (store_own) {
+        if (x > 0) st8(g - 8, c0, c1);
+        if (x == mb_w - 1) st8(g, c2, c3);
+      }
+      t[0] = c2; t[1] = c3; t[2] = own1.x; t[3] = own1.y;
+    } else if (is_top) {
+      const uint32_t *t = (const uint32_t *)(top_t + 8);
+      st8(top_p + 8 * x, t[0], t[1]);
+    } else if (is_pre) ((uint4 *)s_prep)[lane - 40] = pre1;
+    if (has_up && x + 1 < mb_w) {
+      if (!await_granules(hand_up + (long)(x + 1) * HAND_PER_MB, is_gran, gr, err)) return;
+      if (is_gran) *gran_t = (uint32_t)gr;
     }
-    publish(prog, (unsigned)(x + 1), lane);
-    __syncthreads();
+    own1 = own2; pre1 = pre2;
   }
 }
 
@@ -361,17 +439,15 @@ __global__ __launch_bounds__(64) void k_deblock_rows(RowArgs A)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_tile[2 * 18 * CPB > 20 * YP ? 2 * 18 * CPB : 20 * YP];
   __shared__ __attribute__((aligned(16))) uint8_t s_prep[sizeof(DbPrep)];
-  __shared__ uint8_t s_tc0[52 * 4];
   __shared__ unsigned s_ticket;
   const int lane = threadIdx.x;
   if (lane == 0) s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT);
-  for (int k = lane; k < 52 * 4; k += 64) s_tc0[k] = c_tc0[k >> 2][k & 3];
   for (int k = lane; k < (int)sizeof(s_tile) / 4; k += 64) ((uint32_t *)s_tile)[k] = 0;
   __syncthreads();
   const int t = (int)s_ticket, row = t / A.nkinds, kind = t - row * A.nkinds;
   if (row >= A.mb_h) return;
-  if (kind == 0) luma_row(A, row, s_tile, s_tc0, s_prep);
-  else chroma_row(A, row, s_tile, s_tc0, s_prep);
+  if (kind == 0) luma_row(A, row, s_tile, s_prep);
+  else chroma_row(A, row, s_tile, s_prep);
 }
 
 // prep + rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
@@ -379,11 +455,11 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8)
 {
   const int mb_w = ctx->W / 16, mb_h = ctx->H / 16, nmb = mb_w * mb_h, fmt = ctx->cfg.yuv_format;
-  const int nkinds = fmt ? 2 : 1, nsync = 2 + 2 * mb_h;
+  const int nkinds = fmt ? 2 : 1, nsync = 2;
   hipLaunchKernelGGL(k_deblock_prep, dim3((nmb + 7) / 8), dim3(256), 0, ctx->stream, d_mbs, d_motion, mb_w, mb_h, fmt, direct8x8,
-                     (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync);
+                     (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync, (unsigned long long *)ctx->d_db_hand);
   RowArgs A;
-  A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync;
+  A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
   A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;
   hipLaunchKernelGGL(k_deblock_rows, dim3(nkinds * mb_h), dim3(64), 0, ctx->stream, A);
   return JMHIP_OK;

@@ -25,8 +25,9 @@ struct jmhip_ctx {
   void *d_scratch; size_t scratch_bytes;     // grows on demand: jobs/results/tables for host entry points
   void *d_scratch2; size_t scratch2_bytes;
   int16_t *d_spiral;     // [(2R+1)^2][2] spiral offsets for R = cfg.search_range
-  void *d_db_prep;       // deblocking: 96-byte strength/parameter record per macroblock (k_deblock_prep)
-  unsigned *d_db_sync;   // deblocking row pipeline: ticket, error, per-row progress words
+  void *d_db_prep;       // deblocking: 192-byte strength/parameter record per macroblock (k_deblock_prep)
+  unsigned *d_db_sync;   // deblocking row pipeline: ticket, error
+  void *d_db_hand;       // deblocking row pipeline: 24 8-byte hand-over granules per macroblock
   int force_db_diag;     // JMHIP_DEBLOCK_DIAG=1: one launch per diagonal instead of the row pipeline (A/B testing)
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)

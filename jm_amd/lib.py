@@ -64,7 +64,7 @@ class _Config(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libjmhip.so")
+    return os.environ.get("JMHIP_LIB") or os.path.join(_HERE, "libjmhip.so")
 
 
 def load_library():
