@@ -1,0 +1,385 @@
+/*
+ * jm_adapter.c -- host-side C glue that puts libjmhip (include/jmhip.h) behind JM 19.0 lencod's own call surface.
+ *
+ * JM is plain C and so is this file: it is compiled against JM's public headers and linked into the UNMODIFIED
+ * reference encoder objects with GNU ld's --wrap, so that every call the encoder makes to one of the hot-path
+ * functions below lands here, is served by the MI355X through the C ABI, and returns to JM's sequential control
+ * flow (mode decision, MV prediction, entropy coding) with exactly the values JM's own function would have
+ * produced.  The encoder.cfg / YUV-in -> Annex-B .264-out contract is untouched; the bitstream is bit-identical
+ * (tests/test_lencod_dropin.py compares md5s with CPU JM).
+ *
+ *   JM function (reference file:line)                              bound through                      served by
+ *   getSubImagesLuma            lencod/src/img_luma.c:611          UnifiedOneForthPix image.c:2187     jmhip_set_reference + jmhip_get_subplanes
+ *   full_search_motion_estimation lencod/src/me_fullsearch.c:39    Macroblock.IntPelME  mv_search.c:139-175   jmhip_me_fullsearch (one window job)
+ *   sub_pel_motion_estimation   lencod/src/me_fullsearch.c:186     Macroblock.SubPelME                 jmhip_me_subpel
+ *   setup_fast_full_search      lencod/src/me_fullfast.c:269       Macroblock.p_SetupFastFullPelSearch jmhip_me_sad_tables (BlockSAD tables; JM keeps its argmin)
+ *   DeblockFrame                lencod/src/loopFilter.c:63         image.c:236                         jmhip_deblock_frame
+ *   encode_one_slice            lencod/src/slice.c:431             image.c:210                         (hook only: uploads the current picture, then calls JM's own)
+ *
+ * A call whose configuration the device path does not implement (weighted prediction, chroma ME, SSE metric,
+ * RDOptimization=0's (0,0) bonus, field/MBAFF pictures, 4:4:4, bit depth > 8, search range > 64) is passed to JM's own
+ * function (__real_*) and counted; the counters are printed at exit.  JMHIP_ADAPTER=off passes everything through;
+ * JMHIP_ADAPTER_PARTS=interp,fs,subpel,ffs,deblock selects a subset.  There is no CPU restatement in here: either
+ * the GPU serves a call or JM's own code does.
+ *
+ * This is per-call, synchronous offload: it demonstrates the drop-in boundary and bit-exactness inside the real
+ * encoder.  Throughput comes from the batched entry points (bench.py); see INTEGRATION.md for how a maintainer
+ * batches macroblock rows of ME behind the same slots.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "global.h"
+#include "image.h"
+#include "mbuffer.h"
+#include "mb_access.h"
+#include "mv_search.h"
+#include "me_distortion.h"
+#include "me_fullsearch.h"
+#include "me_fullfast.h"
+#include "loop_filter.h"
+#include "img_luma.h"
+#include "slice.h"
+#include "jmhip.h"
+
+#define MAX_SLOTS 20
+
+static struct {
+  int         init_done, off;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock;
+  jmhip_ctx  *ctx;
+  int         W, H, fmt, R, nslots;
+  StorablePicture *slot_pic[MAX_SLOTS];
+  unsigned    slot_tick[MAX_SLOTS], tick;
+  uint16_t   *planes;                 /* 16 x (H+40) x (W+64) imgpel, jmhip_get_subplanes output */
+  uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
+  jmhip_db_mb     *dbmb;
+  jmhip_db_motion *dbmo;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed;
+} G;
+
+static void adapter_report(void)
+{
+  if (!G.init_done) return;
+  fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
+                  "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed);
+  if (G.ctx) jmhip_destroy(G.ctx);
+  G.ctx = NULL;
+}
+
+static void adapter_die(const char *what, int rc)
+{
+  fprintf(stderr, "jmhip adapter: %s failed (%d): %s\n", what, rc, jmhip_last_error(G.ctx));
+  exit(70);                                              /* no silent CPU fallback for a call the device accepted */
+}
+
+/* is `name` one of the comma-separated tokens of `list` (NULL list = everything) */
+static int has_part(const char *list, const char *name)
+{
+  const size_t n = strlen(name);
+  const char *p = list;
+  if (!list) return 1;
+  while (*p) {
+    const char *e = strchr(p, ',');
+    const size_t len = e ? (size_t)(e - p) : strlen(p);
+    if (len == n && !strncmp(p, name, n)) return 1;
+    if (!e) break;
+    p = e + 1;
+  }
+  return 0;
+}
+
+/* Create the context on first use; returns 0 when the device path cannot serve this sequence at all. */
+static int adapter_on(VideoParameters *p_Vid)
+{
+  if (!G.init_done) {
+    InputParameters *p_Inp = p_Vid->p_Inp;
+    const char *e = getenv("JMHIP_ADAPTER"), *parts = getenv("JMHIP_ADAPTER_PARTS");
+    jmhip_config cfg;
+    int rc;
+    G.init_done = 1;
+    atexit(adapter_report);
+    G.part_interp = has_part(parts, "interp"); G.part_fs = has_part(parts, "fs"); G.part_subpel = has_part(parts, "subpel");
+    G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
+    if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
+    if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
+        p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
+      fprintf(stderr, "jmhip adapter: configuration outside the device path (bit depth / 4:4:4 / interlace): JM's own code runs\n");
+      G.off = 1; return 0;
+    }
+    G.W = p_Vid->width; G.H = p_Vid->height; G.fmt = p_Vid->yuv_format;
+    G.R = imax(p_Inp->search_range[0], p_Inp->search_range[1]);
+    if (G.R > JMHIP_MAX_SEARCH_RANGE) { G.part_fs = G.part_ffs = 0; G.R = JMHIP_MAX_SEARCH_RANGE; }
+    if (G.R < 1) G.R = 1;
+    G.nslots = imin(MAX_SLOTS, p_Vid->max_num_references + 2);
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = getenv("JMHIP_DEVICE") ? atoi(getenv("JMHIP_DEVICE")) : 0;
+    cfg.width = G.W; cfg.height = G.H; cfg.yuv_format = G.fmt; cfg.bit_depth = 8; cfg.search_range = G.R; cfg.num_ref_slots = G.nslots;
+    rc = jmhip_create(&G.ctx, &cfg);
+    if (rc != JMHIP_OK) {                                /* the library has no CPU fallback; say so and stop */
+      fprintf(stderr, "jmhip adapter: jmhip_create failed (%d): %s\n", rc, jmhip_last_error(NULL));
+      exit(70);
+    }
+    G.planes = (uint16_t *)malloc((size_t)16 * (G.W + 2 * JMHIP_PAD_X) * (G.H + 2 * JMHIP_PAD_Y) * sizeof(uint16_t));
+    G.tables = (uint16_t *)malloc((size_t)7 * 16 * (2 * G.R + 1) * (2 * G.R + 1) * sizeof(uint16_t));
+    G.dbmb = (jmhip_db_mb *)calloc((size_t)(G.W / 16) * (G.H / 16), sizeof(jmhip_db_mb));
+    G.dbmo = (jmhip_db_motion *)calloc((size_t)(G.W / 4) * (G.H / 4), sizeof(jmhip_db_motion));
+    if (!G.planes || !G.tables || !G.dbmb || !G.dbmo) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+  }
+  return !G.off;
+}
+
+/* ------------------------------------------------------------------ reference pictures <-> device slots */
+static int slot_find(StorablePicture *s)
+{
+  int k;
+  for (k = 0; k < G.nslots; k++) if (G.slot_pic[k] == s) { G.slot_tick[k] = ++G.tick; return k; }
+  return -1;
+}
+static int slot_take(StorablePicture *s)
+{
+  int k, best = 0;
+  if ((k = slot_find(s)) >= 0) return k;
+  for (k = 0; k < G.nslots; k++) {
+    if (!G.slot_pic[k]) { best = k; break; }
+    if (G.slot_tick[k] < G.slot_tick[best]) best = k;
+  }
+  G.slot_pic[best] = s; G.slot_tick[best] = ++G.tick;
+  return best;
+}
+/* slot holding the sub-pel planes of `s`; a picture the slot ring has dropped is rebuilt from its luma */
+static int slot_of_reference(StorablePicture *s)
+{
+  int k = slot_find(s);
+  if (k < 0) {
+    int rc;
+    k = slot_take(s);
+    rc = jmhip_set_reference(G.ctx, k, s->imgY[0], (int)(s->imgY[1] - s->imgY[0]));
+    if (rc) adapter_die("jmhip_set_reference", rc);
+  }
+  return k;
+}
+
+/* ------------------------------------------------------------------ K5: sub-pel planes */
+extern void __real_getSubImagesLuma(VideoParameters *, StorablePicture *);
+void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
+{
+  int rc, k, j, i, y;
+  const int Wp = s->size_x + 2 * JMHIP_PAD_X, Hp = s->size_y + 2 * JMHIP_PAD_Y;
+  if (!adapter_on(p_Vid) || !G.part_interp || s->size_x != G.W || s->size_y != G.H ||
+      s->size_x_padded != Wp || s->size_y_padded != Hp) {
+    G.n_passed++;
+    __real_getSubImagesLuma(p_Vid, s);
+    if (G.ctx && !G.off) { k = slot_find(s); if (k >= 0) G.slot_pic[k] = NULL; }     /* device copy (if any) is stale now */
+    return;
+  }
+  k = slot_take(s);
+  if ((rc = jmhip_set_reference(G.ctx, k, s->imgY[0], (int)(s->imgY[1] - s->imgY[0])))) adapter_die("jmhip_set_reference", rc);
+  if ((rc = jmhip_get_subplanes(G.ctx, k, G.planes))) adapter_die("jmhip_get_subplanes", rc);
+  for (j = 0; j < 4; j++)                                   /* JM's host-side MC / RDO keep reading p_curr_img_sub */
+    for (i = 0; i < 4; i++) {
+      const uint16_t *src = G.planes + (size_t)(j * 4 + i) * Wp * Hp;
+      imgpel **dst = s->p_curr_img_sub[j][i];
+      for (y = 0; y < Hp; y++) memcpy(&dst[y - JMHIP_PAD_Y][-JMHIP_PAD_X], src + (size_t)y * Wp, (size_t)Wp * sizeof(imgpel));
+    }
+  G.n_interp++;
+}
+
+/* ------------------------------------------------------------------ current picture: uploaded once per coded picture */
+extern int __real_encode_one_slice(VideoParameters *, int, int);
+int __wrap_encode_one_slice(VideoParameters *p_Vid, int SliceGroupId, int TotalCodedMBs)
+{
+  if (TotalCodedMBs == 0 && adapter_on(p_Vid) && (G.part_fs || G.part_subpel || G.part_ffs) && p_Vid->structure == FRAME) {
+    int rc = jmhip_set_current(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]));
+    if (rc) adapter_die("jmhip_set_current", rc);
+    G.n_cur++;
+  }
+  return __real_encode_one_slice(p_Vid, SliceGroupId, TotalCodedMBs);
+}
+
+/* partition index of the ABI (jmhip.h) from JM's (blocktype, block_x, block_y) with block_* in 4x4 units */
+static int partition_of(const MEBlock *b)
+{
+  const int bx = b->block_x, by = b->block_y;
+  switch (b->blocktype) {
+  case 1: return 0;
+  case 2: return 1 + (by >> 1);
+  case 3: return 3 + (bx >> 1);
+  case 4: return 5 + (by >> 1) * 2 + (bx >> 1);
+  case 5: return 9 + by * 2 + (bx >> 1);
+  case 6: return 17 + (by >> 1) * 4 + bx;
+  case 7: return 25 + by * 4 + bx;
+  default: return -1;
+  }
+}
+static int me_common_ok(Macroblock *currMB, MEBlock *mv_block)
+{
+  VideoParameters *p_Vid = currMB->p_Vid;
+  Slice *currSlice = currMB->p_Slice;
+  return adapter_on(p_Vid) && p_Vid->structure == FRAME && !currSlice->mb_aff_frame_flag && !mv_block->ChromaMEEnable &&
+         !mv_block->apply_weights && G.n_cur > 0;
+}
+
+/* ------------------------------------------------------------------ K1-K3: full search (Macroblock.IntPelME) */
+extern distblk __real_full_search_motion_estimation(Macroblock *, MotionVector *, MEBlock *, distblk, int);
+distblk __wrap_full_search_motion_estimation(Macroblock *currMB, MotionVector *pred_mv, MEBlock *mv_block, distblk min_mcost, int lambda_factor)
+{
+  InputParameters *p_Inp = currMB->p_Inp;
+  Slice *currSlice = currMB->p_Slice;
+  const int list = mv_block->list, p = partition_of(mv_block);
+  const int R = imin(mv_block->searchRange.max_x, mv_block->searchRange.max_y) >> 2;
+  MotionVector *mv = &mv_block->mv[list];
+  jmhip_me_job job;
+  jmhip_me_result res;
+  int rc, slot;
+  if (!me_common_ok(currMB, mv_block) || !G.part_fs || !p_Inp->rdopt || mv_block->computePredFPel != computeSAD || p < 0 ||
+      R < 1 || R > G.R || lambda_factor < 0 || mv_block->pos_x != currMB->pix_x + 4 * mv_block->block_x ||
+      mv_block->pos_y != currMB->opix_y + 4 * mv_block->block_y) {
+    G.n_passed++;
+    return __real_full_search_motion_estimation(currMB, pred_mv, mv_block, min_mcost, lambda_factor);
+  }
+  slot = slot_of_reference(currSlice->listX[list + currMB->list_offset][(int)mv_block->ref_idx]);
+  memset(&job, 0, sizeof job);
+  job.mb_x = (int16_t)currMB->pix_x; job.mb_y = (int16_t)currMB->opix_y;
+  job.center_x = mv->mv_x; job.center_y = mv->mv_y;
+  job.search_range = (int16_t)R; job.max_mvd = 0; job.lambda = lambda_factor;
+  job.part_mask = 1ull << p;
+  job.pred[p][0] = pred_mv->mv_x; job.pred[p][1] = pred_mv->mv_y;
+  if ((rc = jmhip_me_fullsearch(G.ctx, slot, &job, 1, &res))) adapter_die("jmhip_me_fullsearch", rc);
+  G.n_fs++;
+  if ((distblk)res.best[p].cost < min_mcost) {            /* strict '<' against the cost carried in, me_fullsearch.c:89 */
+    mv->mv_x = res.best[p].mv_x; mv->mv_y = res.best[p].mv_y;
+    return (distblk)res.best[p].cost;
+  }
+  return min_mcost;
+}
+
+/* ------------------------------------------------------------------ K4: sub-pel refinement (Macroblock.SubPelME) */
+extern distblk __real_sub_pel_motion_estimation(Macroblock *, MotionVector *, MEBlock *, distblk, int *);
+distblk __wrap_sub_pel_motion_estimation(Macroblock *currMB, MotionVector *pred, MEBlock *mv_block, distblk min_mcost, int *lambda)
+{
+  VideoParameters *p_Vid = currMB->p_Vid;
+  InputParameters *p_Inp = currMB->p_Inp;
+  Slice *currSlice = currMB->p_Slice;
+  const int list = mv_block->list;
+  const int mh = p_Inp->MEErrorMetric[H_PEL], mq = p_Inp->MEErrorMetric[Q_PEL];
+  MotionVector *mv = &mv_block->mv[list];
+  jmhip_subpel_job job;
+  jmhip_me_best best;
+  int rc, slot;
+  if (!me_common_ok(currMB, mv_block) || !G.part_subpel || !p_Inp->rdopt || mv_block->search_pos2 != 9 || mv_block->search_pos4 != 9 ||
+      !((mh == ERROR_SAD && mv_block->computePredHPel == computeSAD) || (mh == ERROR_SATD && mv_block->computePredHPel == computeSATD)) ||
+      !((mq == ERROR_SAD && mv_block->computePredQPel == computeSAD) || (mq == ERROR_SATD && mv_block->computePredQPel == computeSATD)) ||
+      lambda[H_PEL] < 0 || lambda[Q_PEL] < 0) {
+    G.n_passed++;
+    return __real_sub_pel_motion_estimation(currMB, pred, mv_block, min_mcost, lambda);
+  }
+  slot = slot_of_reference(currSlice->listX[list + currMB->list_offset][(int)mv_block->ref_idx]);
+  memset(&job, 0, sizeof job);
+  job.pos_x = mv_block->pos_x; job.pos_y = mv_block->pos_y; job.bsx = mv_block->blocksize_x; job.bsy = mv_block->blocksize_y;
+  job.pred_x = pred->mv_x; job.pred_y = pred->mv_y; job.mv_x = mv->mv_x; job.mv_y = mv->mv_y;
+  job.lambda_h = lambda[H_PEL]; job.lambda_q = lambda[Q_PEL];
+  job.metric_h = (int8_t)mh; job.metric_q = (int8_t)mq;
+  job.start_hp = (int8_t)p_Vid->start_me_refinement_hp; job.start_qp = (int8_t)p_Vid->start_me_refinement_qp;
+  job.test8x8 = (int8_t)(mv_block->test8x8 != 0);
+  job.min_mcost = min_mcost > 0x7fffffff ? 0x7fffffff : (int32_t)min_mcost;
+  if ((rc = jmhip_me_subpel(G.ctx, slot, &job, 1, &best))) adapter_die("jmhip_me_subpel", rc);
+  G.n_subpel++;
+  mv->mv_x = best.mv_x; mv->mv_y = best.mv_y;
+  return (distblk)best.cost;
+}
+
+/* ------------------------------------------------------------------ K1/K2: fast full search tables (Macroblock.p_SetupFastFullPelSearch) */
+extern void __real_setup_fast_full_search(Macroblock *, MEBlock *, int);
+void __wrap_setup_fast_full_search(Macroblock *currMB, MEBlock *mv_block, int list)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  InputParameters *p_Inp = currSlice->p_Inp;
+  MEFullFast *ff = p_Vid->p_ffast_me;
+  const int ref = mv_block->ref_idx;
+  const int R = ff->max_search_range[list][ref], max_pos = (2 * R + 1) * (2 * R + 1), range_q = R << 2;
+  const int wp = ((p_Vid->active_pps->weighted_pred_flag && (currSlice->slice_type == P_SLICE || currSlice->slice_type == SP_SLICE)) ||
+                  (p_Vid->active_pps->weighted_bipred_idc && currSlice->slice_type == B_SLICE)) && p_Inp->UseWeightedReferenceME;
+  PixelPos block[4];
+  MotionVector pmv, c;
+  jmhip_me_job job;
+  int rc, slot, t, k, pos;
+  if (!me_common_ok(currMB, mv_block) || !G.part_ffs || wp || p_Inp->MEErrorMetric[F_PEL] != ERROR_SAD || R < 1 || R > G.R) {
+    G.n_passed++;
+    __real_setup_fast_full_search(currMB, mv_block, list);
+    return;
+  }
+  /* search centre = the 16x16 predictor rounded to full-pel and kept inside the level's MV range (me_fullfast.c:307-327) */
+  get_neighbors(currMB, block, 0, 0, 16);
+  currMB->GetMVPredictor(currMB, block, &pmv, (short)ref, p_Vid->enc_picture->mv_info, list, 0, 0, 16, 16);
+  c.mv_x = (short)(((pmv.mv_x + 2) >> 2) * 4);
+  c.mv_y = (short)(((pmv.mv_y + 2) >> 2) * 4);
+  if (!p_Inp->rdopt) { c.mv_x = (short)iClip3(-range_q, range_q, c.mv_x); c.mv_y = (short)iClip3(-range_q, range_q, c.mv_y); }
+  c.mv_x = (short)iClip3(p_Vid->MaxHmvR[4] + range_q, p_Vid->MaxHmvR[5] - range_q, c.mv_x);
+  c.mv_y = (short)iClip3(p_Vid->MaxVmvR[4] + range_q, p_Vid->MaxVmvR[5] - range_q, c.mv_y);
+  ff->search_center[list][ref] = c;
+  ff->search_center_padded[list][ref] = pad_MVs(c, mv_block);
+  if (!p_Inp->rdopt) {                                     /* spiral index of the (0,0) vector, me_fullfast.c:352-365 */
+    const int rx = -c.mv_x, ry = -c.mv_y;
+    for (pos = 0; pos < max_pos; pos++)
+      if (rx == p_Vid->spiral_qpel_search[pos].mv_x && ry == p_Vid->spiral_qpel_search[pos].mv_y) { ff->pos_00[list][ref] = pos; break; }
+  }
+  slot = slot_of_reference(currSlice->listX[list + currMB->list_offset][ref]);
+  memset(&job, 0, sizeof job);
+  job.mb_x = (int16_t)currMB->pix_x; job.mb_y = (int16_t)currMB->opix_y;
+  job.center_x = c.mv_x; job.center_y = c.mv_y; job.search_range = (int16_t)R;
+  if ((rc = jmhip_me_sad_tables(G.ctx, slot, &job, 1, G.tables))) adapter_die("jmhip_me_sad_tables", rc);
+  for (t = 1; t < 8; t++)                                  /* BlockSAD[list][ref][blocktype][4x4 raster index][spiral position], distpel */
+    for (k = 0; k < 16; k++) {
+      const uint16_t *src = G.tables + ((size_t)(t - 1) * 16 + k) * max_pos;
+      distpel *dst = ff->BlockSAD[list][ref][t][k];
+      for (pos = 0; pos < max_pos; pos++) dst[pos] = src[pos];
+    }
+  ff->search_setup_done[list][ref] = 1;
+  G.n_ffs++;
+}
+
+/* ------------------------------------------------------------------ K9/K10: deblocking */
+extern void __real_DeblockFrame(VideoParameters *, imgpel **, imgpel ***);
+void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
+{
+  StorablePicture *ids[64];
+  int nids = 0, rc, x, y, l, k;
+  unsigned i;
+  if (!adapter_on(p_Vid) || !G.part_deblock || p_Vid->structure != FRAME || p_Vid->mb_aff_frame_flag ||
+      (int)p_Vid->PicSizeInMbs != (G.W / 16) * (G.H / 16)) {
+    G.n_passed++;
+    __real_DeblockFrame(p_Vid, imgY, imgUV);
+    return;
+  }
+  for (i = 0; i < p_Vid->PicSizeInMbs; i++) {               /* what DeblockMb / GetStrength* read from Macroblock (lencod/inc/global.h) */
+    Macroblock *m = &p_Vid->mb_data[i];
+    jmhip_db_mb *d = &G.dbmb[i];
+    d->mb_type = m->mb_type; d->slice_type = (int16_t)m->p_Slice->slice_type; d->qp = (int16_t)m->qp;
+    d->qpc[0] = (int16_t)m->qpc[0]; d->qpc[1] = (int16_t)m->qpc[1]; d->cbp = (int16_t)m->cbp;
+    d->cbp_blk = (uint32_t)(m->cbp_blk & 0xFFFF); d->slice_nr = (int16_t)m->slice_nr;
+    d->df_disable_idc = (int16_t)m->DFDisableIdc; d->df_alpha_c0 = (int16_t)m->DFAlphaC0Offset; d->df_beta = (int16_t)m->DFBetaOffset;
+    d->transform8x8 = (int16_t)m->luma_transform_size_8x8_flag;
+  }
+  for (y = 0; y < G.H / 4; y++)
+    for (x = 0; x < G.W / 4; x++) {
+      PicMotionParams *mp = &p_Vid->enc_picture->mv_info[y][x];
+      jmhip_db_motion *d = &G.dbmo[(size_t)y * (G.W / 4) + x];
+      for (l = 0; l < 2; l++) {
+        int id = -1;
+        if (mp->ref_idx[l] != -1) {                          /* identity of ref_pic[l]: what compare_mvs' callers test (loop_filter_normal.c) */
+          for (k = 0; k < nids; k++) if (ids[k] == mp->ref_pic[l]) break;
+          if (k == nids && nids < 64) ids[nids++] = mp->ref_pic[l];
+          id = k;
+        }
+        d->mv[l][0] = mp->mv[l].mv_x; d->mv[l][1] = mp->mv[l].mv_y; d->ref_id[l] = id;
+      }
+    }
+  rc = jmhip_deblock_frame(G.ctx, imgY[0], (int)(imgY[1] - imgY[0]),
+                           G.fmt ? imgUV[0][0] : NULL, G.fmt ? imgUV[1][0] : NULL, G.fmt ? (int)(imgUV[0][1] - imgUV[0][0]) : 0,
+                           G.dbmb, G.dbmo, p_Vid->active_sps->direct_8x8_inference_flag);
+  if (rc) adapter_die("jmhip_deblock_frame", rc);
+  G.n_deblock++;
+}

@@ -1,0 +1,93 @@
+"""End-to-end drop-in parity: JM's own encoder with its hot path served by libjmhip must write the SAME bitstream.
+
+oracle/_ref/lencod_hip.exe = the unmodified reference lencod objects + jm_amd/adapter/jm_adapter.c (host C glue, ld --wrap)
++ jm_amd/libjmhip.so (oracle/Makefile.ref, target `hip`; built in the build container, travels to the GPU box).  It is run
+on the reference's own sample clips with the reference's own configurations (tests/golden/jm_*.cfg, values only) and the
+Annex-B output / reconstruction are compared by md5 with CPU JM's (tests/golden/md5.json, produced by the real lencod).
+The adapter's exit report must show that the device really served the calls (no silent pass-through)."""
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+EXE = os.path.join(ROOT, "oracle", "_ref", "lencod_hip.exe")
+CFG = {"encoder_baseline.cfg": "jm_baseline.cfg", "encoder_main.cfg": "jm_main.cfg", "encoder_yuv422.cfg": "jm_yuv422.cfg"}
+MD5 = json.load(open(os.path.join(G, "md5.json")))
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def run_lencod(exe, tag, tmp, env_extra=None):
+    e = MD5[tag]
+    for f in ("foreman_part_qcif.yuv", "foreman_part_qcif_422.yuv", "q_offset.cfg"):
+        shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
+    args = [exe, "-d", os.path.join(G, CFG[e["cfg"]])]
+    for k, v in dict(e["overrides"], OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
+        args += ["-p", f"{k}={v}"]
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run(args, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    return r, os.path.join(tmp, "o.264"), os.path.join(tmp, "o_rec.yuv")
+
+
+def counters(stderr):
+    m = re.search(r"jmhip adapter: on the MI355X: (\d+) getSubImagesLuma, (\d+) full_search_motion_estimation, (\d+) sub_pel_motion_estimation, "
+                  r"(\d+) setup_fast_full_search, (\d+) DeblockFrame \((\d+) current pictures uploaded\); passed to JM's own code: (\d+) calls", stderr)
+    assert m, stderr[-2000:]
+    return dict(zip(("interp", "fs", "subpel", "ffs", "deblock", "cur", "passed"), (int(x) for x in m.groups())))
+
+
+# tag -> which adapter counters must be non-zero (what that configuration exercises on the device)
+CASES = [
+    ("G1", ("interp", "fs", "subpel", "deblock")),              # BASELINE configs[0]: FullSearch SR=16, 5 refs, RDO, CAVLC
+    ("G0", ("interp", "ffs", "subpel", "deblock")),             # encoder_baseline.cfg as shipped: FastFullSearch SR=32
+    ("G1_1ref_2frames", ("interp", "fs", "subpel", "deblock")),
+    ("G4q", ("interp", "fs", "subpel", "deblock")),             # configs[3] shape: 3 slices, AdaptiveRounding off
+    ("G3a", ("interp", "deblock")),                             # Main, CABAC, B frame; EPZS keeps JM's own int-/sub-pel walk (me_epzs*.c)
+    ("G3b", ("interp", "deblock")),                             # + 8x8 transform (High): deblocking with transform_size_8x8 macroblocks
+    ("G5", ("interp", "ffs", "subpel", "deblock")),             # configs[4]: High 4:2:2, FFS, 5 refs
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,must_run", CASES)
+def test_lencod_with_libjmhip_writes_jm_bitstream(tmp_path, tag, must_run):
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing: run __graft_entry__.build() where /root/reference exists")
+    r, out264, rec = run_lencod(EXE, tag, str(tmp_path))
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
+    c = counters(err)
+    for k in must_run:
+        assert c[k] > 0, (tag, k, c)
+    assert md5(out264) == MD5[tag]["md5_264"], (tag, "bitstream differs from CPU JM", c)
+    assert md5(rec) == MD5[tag]["md5_recon"], (tag, "reconstruction differs from CPU JM", c)
+
+
+def test_adapter_fails_loudly_without_a_device(tmp_path):
+    """not gpu: on a box without a HIP device the adapter must stop the encoder, not fall back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    if not os.path.exists(EXE):
+        pytest.skip("lencod_hip.exe not built here")
+    r, out264, _ = run_lencod(EXE, "G1_1ref_2frames", str(tmp_path))
+    assert r.returncode != 0
+    assert b"jmhip_create failed" in r.stderr
+
+
+def test_adapter_off_is_plain_jm(tmp_path):
+    """not gpu: JMHIP_ADAPTER=off passes every call to JM's own functions -- the wrapped binary is the reference encoder."""
+    if not os.path.exists(EXE):
+        pytest.skip("lencod_hip.exe not built here")
+    r, out264, rec = run_lencod(EXE, "G1_1ref_2frames", str(tmp_path), {"JMHIP_ADAPTER": "off"})
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-1500:]
+    assert md5(out264) == MD5["G1_1ref_2frames"]["md5_264"]
