@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 W, H_SRC, H = 1920, 1080, 1088
 R = 32
 QP = 28
-HALO = 544          # rows of neighbouring bands a band can reference: level-4 vertical MV limit 511.75 + 16 + taps, rounded to MBs
+TRAFFIC_BYTES = 40640000   # HBM bytes per launch of k_me_fs_fast: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command,
+                           # corrected as MI355X_MICROARCH.md prescribes (profiles/r01_v3_kernel_stats.md); below the algorithmic 57.0 MB (L2 window overlap)
+MAX_VMV = 512       # level-4/5.1 vertical MV limit in pels (lencod/src/conformance.c:604-631): a search centre can sit this far away
 
 
 def synth_luma(n_frames, seed=1234):
@@ -137,11 +139,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from jm_amd import shard
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     N = world
-    halo = HALO if N > 1 else 0
+    band = shard.band_of(rank, N, (H // 16) * N)        # one tall picture of N 1080p bands, one band (slice) per GPU
+    halo = shard.halo_rows(R, MAX_VMV) if N > 1 else 0               # rows of neighbouring bands a band's search windows can read: 576
     HL = H + 2 * halo                                   # rows of the local reference (own band + halos)
 
     stream = torch.cuda.current_stream()
@@ -208,12 +212,8 @@ def main():
     fs_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i, timed):
-        if N > 1:                                                       # reference-frame exchange over xGMI (RCCL)
-            dist.all_gather_into_tensor(gathered.view(-1), ref_band.view(-1))
-            lo, hi = rank * H - halo, (rank + 1) * H + halo
-            tall = gathered.view(N * H, W)
-            idx = torch.arange(lo, hi, device=dev).clamp_(0, N * H - 1)
-            torch.index_select(tall, 0, idx, out=local_ref)
+        if N > 1:                                                       # reference-frame exchange over xGMI (RCCL): the one collective
+            shard.exchange_reference(ref_band, band, halo, N * H, gathered=gathered, out=local_ref)
         else:
             local_ref.copy_(ref_band)
         ctx.set_reference_dev(0, local_ref.data_ptr(), W)               # K5
@@ -265,10 +265,13 @@ def main():
                        "parallelism": "1 GPU" if N == 1 else f"{N} slices (1080p bands) one per GPU, RCCL all-gather of reconstructed bands per step",
                        "kernel_path_only": "MV predictors / prediction / deblock side info are synthetic inputs; mode decision and entropy coding stay on the host",
                        "motion_found_frac": round(motion_ok, 4)},
-            "roofline": {"kernel": "k_me_fullsearch (K1-K3 fused)", "bound": "hbm", "achieved": round(alg_bytes / (fs_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(alg_bytes / (fs_ms * 1e-3) / 8e12, 5), "traffic": None,
+            "roofline": {"kernel": "k_me_fs_fast (K1-K3 fused full search; + k_me_fullsearch for the jobs it declines)", "bound": "hbm",
+                         "achieved": round(alg_bytes / (fs_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(alg_bytes / (fs_ms * 1e-3) / 8e12, 5), "traffic": TRAFFIC_BYTES,
                          "avg_kernel_ms": round(fs_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_note": "SAD is VALU-bound: 8.8 G abs-diff/frame; see DESIGN.md for the v_sad_u8 roofline"},
+                         "valu_frac": round(nmb * (2 * R + 1) ** 2 * 256 / (fs_ms * 1e-3) / 144.8e12, 4),
+                         "valu_note": "the kernel is VALU-bound (155 abs-diff per algorithmic byte): valu_frac = achieved abs-diff/s over the "
+                                      "measured v_sad_u8 peak of 144.8 T abs-diff/s (profiles/r01_valu_rates.txt); DESIGN.md section 3"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

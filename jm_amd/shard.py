@@ -1,0 +1,81 @@
+"""Slice-per-GPU sharding of a picture and the one exchange step it needs.
+
+JM shards a picture only by slice: `SliceMode=1`, `SliceArgument = k * PicWidthInMbs` gives contiguous bands of k
+macroblock rows (lencod/src/slice.c:431 terminates a slice after SliceArgument macroblocks; configs[3] of BASELINE.json
+uses 8 bands of a 2160p picture).  Within a P picture the bands are independent for motion estimation, transform /
+quantisation and -- with DFDisableIdc=2 (lencod/src/loopFilter.c:159-165) -- deblocking; the only coupling is that
+the NEXT picture's motion search reads the whole reconstructed reference.  So each rank keeps its own band, and
+after deblocking every rank all-gathers the reconstructed bands (RCCL over xGMI on the GPU box, gloo in the CPU
+tests) and cuts out the rows its own search windows can reach: its band plus a halo above and below.
+
+Nothing in here computes samples; it is index arithmetic plus one collective.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class Band:
+    rank: int
+    first_mb_row: int      # first macroblock row of the band in the picture
+    mb_rows: int           # macroblock rows in the band (the last band may be shorter)
+    rows_per_band: int     # k = ceil(total / n): SliceArgument / PicWidthInMbs
+
+    @property
+    def y0(self):
+        return 16 * self.first_mb_row
+
+    @property
+    def height(self):
+        return 16 * self.mb_rows
+
+
+def slice_argument(pic_height_in_mbs, pic_width_in_mbs, n_bands):
+    """JM's SliceArgument for n_bands equal bands: ceil(rows / n) * PicWidthInMbs macroblocks per slice."""
+    return -(-pic_height_in_mbs // n_bands) * pic_width_in_mbs
+
+
+def band_of(rank, n_bands, pic_height_in_mbs):
+    """The band JM's slice partitioning gives rank `rank` of `n_bands`."""
+    k = -(-pic_height_in_mbs // n_bands)
+    first = min(rank * k, pic_height_in_mbs)
+    return Band(rank, first, max(0, min(k, pic_height_in_mbs - first)), k)
+
+
+def halo_rows(search_range, max_pred_pels):
+    """Rows above / below a band that its search windows can read: the search centre may sit `max_pred_pels` away from the
+    block (the level's vertical MV limit, lencod/src/conformance.c:604-631), the window adds `search_range`, a block 16, and
+    the 6-tap interpolation 3; rounded up to whole macroblock rows."""
+    return -(-(max_pred_pels + search_range + 16 + 3) // 16) * 16
+
+
+def reference_rows(band, halo, pic_height):
+    """Row indices of the full picture that make up the band's local reference: [y0 - halo, y0 + height + halo) clamped
+    into the picture (rows outside the picture are edge replicas, exactly what JM's padded planes hold there)."""
+    idx = torch.arange(band.y0 - halo, band.y0 + band.height + halo)
+    return idx.clamp_(0, pic_height - 1)
+
+
+def exchange_reference(own_band_rows, band, halo, pic_height, group=None, gathered=None, out=None):
+    """All-gather the reconstructed bands and return this rank's local reference (band + halos).
+
+    own_band_rows : (16 * rows_per_band, W) uint8 -- the rank's reconstructed band, padded with arbitrary rows when the
+                    band is shorter than rows_per_band (all_gather needs equal shapes)
+    returns       : (band.height + 2 * halo, W) uint8
+    The one collective of the path; `gathered` / `out` let the caller reuse buffers across pictures."""
+    world = dist.get_world_size(group)
+    rows, width = own_band_rows.shape
+    assert rows == 16 * band.rows_per_band, (rows, band)
+    if gathered is None:
+        gathered = torch.empty((world, rows, width), dtype=own_band_rows.dtype, device=own_band_rows.device)
+    dist.all_gather_into_tensor(gathered.view(-1), own_band_rows.contiguous().view(-1), group=group)
+    # bands are laid out back to back with a stride of 16*rows_per_band rows; picture row y lives at the same index as long as
+    # every band but the last is full, which is how band_of() partitions
+    tall = gathered.view(world * rows, width)
+    idx = reference_rows(band, halo, pic_height).to(own_band_rows.device)
+    if out is None:
+        out = torch.empty((idx.numel(), width), dtype=own_band_rows.dtype, device=own_band_rows.device)
+    torch.index_select(tall, 0, idx, out=out)
+    return out

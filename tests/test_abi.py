@@ -1,0 +1,56 @@
+"""The C-ABI boundary: libjmhip.so loads without a GPU, exports every entry point include/jmhip.h declares, its POD
+structs have the sizes the header documents, and creating a context without a device fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "jmhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(jmhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_entry_point_is_exported():
+    from jm_amd.lib import load_library
+    lib = load_library()
+    names = declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_the_header():
+    from jm_amd import lib as L
+    assert L.ME_JOB.itemsize == 192 and L.ME_RESULT.itemsize == 328
+    assert L.SUBPEL_JOB.itemsize == 36 and L.TQ_OUT.itemsize == 104
+    assert L.DB_MB.itemsize == 28 and L.DB_MOTION.itemsize == 16
+
+
+def test_partition_table_is_the_abi_order():
+    from jm_amd.lib import PARTITIONS, NPART
+    assert NPART == 41 and len(PARTITIONS) == 41
+    # (blocktype, x, y, w, h): 1 + 2 + 2 + 4 + 8 + 8 + 16 partitions, each tiling the macroblock
+    for bt, n in zip(range(1, 8), (1, 2, 2, 4, 8, 8, 16)):
+        parts = [p for p in PARTITIONS if p[0] == bt]
+        assert len(parts) == n
+        cover = np.zeros((16, 16), int)
+        for _, x, y, w, h in parts:
+            cover[y:y + h, x:x + w] += 1
+        assert (cover == 1).all()
+
+
+def test_create_without_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from jm_amd import JmHip
+    from jm_amd.lib import JmHipError
+    with pytest.raises(JmHipError) as e:
+        JmHip(176, 144)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)

@@ -1,0 +1,82 @@
+"""Multi-GPU path on CPU: world_size 2 and 3 over gloo.  Each rank owns one slice band of a picture; after the one
+collective (all-gather of reconstructed bands) every rank must hold exactly the rows of the full picture its search
+windows can reach, and the oracle's motion search on that local reference must equal the search on the full picture."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from jm_amd import shard
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _full_picture(h, w, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (h, w)).astype(np.uint8)
+
+
+def _worker(rank, world, port, h_mbs, w, halo, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H = 16 * h_mbs
+        full = _full_picture(H, w, 11)
+        band = shard.band_of(rank, world, h_mbs)
+        own = np.zeros((16 * band.rows_per_band, w), np.uint8)
+        own[:band.height] = full[band.y0:band.y0 + band.height]          # each rank only ever holds its own band
+        for rep in range(2):                                             # buffers are reusable across pictures
+            local = shard.exchange_reference(torch.from_numpy(own), band, halo, H)
+            want = full[np.clip(np.arange(band.y0 - halo, band.y0 + band.height + halo), 0, H - 1)]
+            ok = local.shape == want.shape and bool((local.numpy() == want).all())
+            if not ok:
+                break
+        # motion search on the local reference == on the full picture (oracle; search windows stay inside band + halo)
+        from oracle import pyjmo as J
+        cur = np.roll(full, (-2, 3), (0, 1))
+        ref_full, ref_loc = J.RefPic(full), J.RefPic(local.numpy())
+        y_off = band.y0 - halo                                           # local row 0 = picture row y_off (before clamping)
+        same = True
+        for mby in range(band.first_mb_row, band.first_mb_row + band.mb_rows):
+            y = 16 * mby
+            if y - 8 - 4 < max(0, y_off) or y + 16 + 8 + 4 > min(H, band.y0 + band.height + halo):
+                continue                                                 # window would leave the rows this rank holds
+            a = J.full_search(ref_full, cur, 16, y, 16, 16, (0, 0), (0, 0), 8, 187)
+            cur_loc = np.zeros_like(local.numpy()); cur_loc[y - y_off:y - y_off + 16] = cur[y:y + 16]
+            b = J.full_search(ref_loc, cur_loc, 16, y - y_off, 16, 16, (0, 0), (0, 0), 8, 187)
+            same &= (a[0], a[1]) == (b[0], b[1])
+        q.put((rank, ok, same, band.first_mb_row, band.mb_rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h_mbs", [(2, 8), (3, 8), (2, 5)])
+def test_band_exchange_gloo(world, h_mbs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h_mbs, 64, 32, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert all(r[2] for r in res), res
+    assert sum(r[4] for r in res) == h_mbs                               # the bands tile the picture
+    assert [r[3] for r in res] == [min(i * -(-h_mbs // world), h_mbs) for i in range(world)]
+
+
+def test_slice_argument_matches_jm_config():
+    # configs[3]: 2160p = 240 x 135 macroblocks, 8 slices -> SliceArgument 4080 (17 rows each, the last band 16)
+    assert shard.slice_argument(135, 240, 8) == 4080
+    bands = [shard.band_of(r, 8, 135) for r in range(8)]
+    assert [b.mb_rows for b in bands] == [17] * 7 + [16]
+    assert shard.halo_rows(32, 512) == 576
