@@ -101,52 +101,60 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// edge filters on registers: p[O..O+7] = L3 L2 L1 L0 | R0 R1 R2 R3   (EdgeLoopLumaVer/Hor, loop_filter_normal.c:301-581)
+// Edge filters on registers, branch-free: a step of the pipeline is a chain of eight dependent edge filters executed by a
+// single wave, so its duration is the number of instructions issued; exec-mask branches around four-instruction bodies cost
+// more than the bodies.  Every lane computes the normal (bS < 4) filter, the strong (bS = 4) filter is added only when some
+// lane of the wave needs it (wave-uniform branch), and v_cndmask selects per sample.
+__device__ __forceinline__ int med3i(int a, int b, int c)
+{
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int absdiff(int a, int b) { return (int)__builtin_amdgcn_sad_u16((unsigned)a, (unsigned)b, 0u); }   // samples are 0..255
+
+// p[O..O+7] = L3 L2 L1 L0 | R0 R1 R2 R3   (EdgeLoopLumaVer/Hor, loop_filter_normal.c:301-581)
 template <int O, int N>
-__device__ __forceinline__ void luma_edge(int (&p)[N], int bS, int alpha, int beta, int c0)
+__device__ __forceinline__ void luma_edge(int (&p)[N], int bS, int alpha, int beta, int c0, bool any_strong)
 {
   const int L3 = p[O], L2 = p[O + 1], L1 = p[O + 2], L0 = p[O + 3], R0 = p[O + 4], R1 = p[O + 5], R2 = p[O + 6], R3 = p[O + 7];
-  const int diff = R0 - L0, ad = iabs_(diff);
-  if (ad < alpha && iabs_(R0 - R1) < beta && iabs_(L0 - L1) < beta) {
-    const int aqb = iabs_(R0 - R2) < beta, apb = iabs_(L0 - L2) < beta;
-    if (bS == 4) {
-      const int small_gap = ad < ((alpha >> 2) + 2);
-      const int aq = aqb & small_gap, ap = apb & small_gap, RL0 = L0 + R0;
-      if (ap) {
-        p[O + 3] = (R1 + ((L1 + RL0) << 1) + L2 + 4) >> 3;
-        p[O + 2] = (L2 + L1 + RL0 + 2) >> 2;
-        p[O + 1] = (((L3 + L2) << 1) + L2 + L1 + RL0 + 4) >> 3;
-      } else p[O + 3] = ((L1 << 1) + L0 + R1 + 2) >> 2;
-      if (aq) {
-        p[O + 4] = (L1 + ((R1 + RL0) << 1) + R2 + 4) >> 3;
-        p[O + 5] = (R2 + R0 + L0 + R1 + 2) >> 2;
-        p[O + 6] = (((R3 + R2) << 1) + R2 + R1 + RL0 + 4) >> 3;
-      } else p[O + 4] = ((R1 << 1) + R0 + L1 + 2) >> 2;
-    } else {
-      const int RL0 = (L0 + R0 + 1) >> 1;
-      const int tc = c0 + apb + aqb;
-      const int dif = clip3(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
-      if (apb) p[O + 2] = L1 + clip3(-c0, c0, (L2 + RL0 - (L1 << 1)) >> 1);
-      p[O + 3] = clip3(0, 255, L0 + dif);
-      p[O + 4] = clip3(0, 255, R0 - dif);
-      if (aqb) p[O + 5] = R1 + clip3(-c0, c0, (R2 + RL0 - (R1 << 1)) >> 1);
-    }
+  const int diff = R0 - L0, ad = absdiff(R0, L0);
+  const bool on = ((int)(bS != 0) & (int)(ad < alpha) & (int)(absdiff(R0, R1) < beta) & (int)(absdiff(L0, L1) < beta)) != 0;
+  const bool apb = absdiff(L0, L2) < beta, aqb = absdiff(R0, R2) < beta;
+  // bS < 4
+  const int RL0 = (L0 + R0 + 1) >> 1;
+  const int tc = c0 + (int)apb + (int)aqb;
+  const int dif = med3i(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
+  int nL2 = L2, nR2 = R2;
+  int nL1 = apb ? L1 + med3i(-c0, c0, (L2 + RL0 - (L1 << 1)) >> 1) : L1;
+  int nR1 = aqb ? R1 + med3i(-c0, c0, (R2 + RL0 - (R1 << 1)) >> 1) : R1;
+  int nL0 = med3i(0, 255, L0 + dif), nR0 = med3i(0, 255, R0 - dif);
+  if (any_strong) {                                                           // bS == 4 somewhere in the wave
+    const bool st = bS == 4, sg = ad < ((alpha >> 2) + 2);
+    const bool ap = apb && sg, aq = aqb && sg;
+    const int S = L0 + R0;
+    const int sL0 = ap ? (R1 + ((L1 + S) << 1) + L2 + 4) >> 3 : ((L1 << 1) + L0 + R1 + 2) >> 2;
+    const int sL1 = ap ? (L2 + L1 + S + 2) >> 2 : L1;
+    const int sL2 = ap ? (((L3 + L2) << 1) + L2 + L1 + S + 4) >> 3 : L2;
+    const int sR0 = aq ? (L1 + ((R1 + S) << 1) + R2 + 4) >> 3 : ((R1 << 1) + R0 + L1 + 2) >> 2;
+    const int sR1 = aq ? (R2 + R0 + L0 + R1 + 2) >> 2 : R1;
+    const int sR2 = aq ? (((R3 + R2) << 1) + R2 + R1 + S + 4) >> 3 : R2;
+    nL0 = st ? sL0 : nL0; nL1 = st ? sL1 : nL1; nL2 = st ? sL2 : nL2;
+    nR0 = st ? sR0 : nR0; nR1 = st ? sR1 : nR1; nR2 = st ? sR2 : nR2;
+    p[O + 1] = on ? nL2 : L2; p[O + 6] = on ? nR2 : R2;
   }
+  p[O + 2] = on ? nL1 : L1; p[O + 3] = on ? nL0 : L0; p[O + 4] = on ? nR0 : R0; p[O + 5] = on ? nR1 : R1;
 }
-// p[O..O+3] = L1 L0 | R0 R1   (EdgeLoopChromaVer/Hor, loop_filter_normal.c:590-757)
+// L1 L0 | R0 R1   (EdgeLoopChromaVer/Hor, loop_filter_normal.c:590-757)
 __device__ __forceinline__ void chroma_edge4(int &L1r, int &L0r, int &R0r, int &R1r, int bS, int alpha, int beta, int c0)
 {
   const int L1 = L1r, L0 = L0r, R0 = R0r, R1 = R1r, diff = R0 - L0;
-  if (iabs_(diff) < alpha && iabs_(R0 - R1) < beta && iabs_(L0 - L1) < beta) {
-    if (bS == 4) {
-      L0r = ((L1 << 1) + L0 + R1 + 2) >> 2;
-      R0r = ((R1 << 1) + R0 + L1 + 2) >> 2;
-    } else {
-      const int tc = c0 + 1, dif = clip3(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
-      L0r = clip3(0, 255, L0 + dif);
-      R0r = clip3(0, 255, R0 - dif);
-    }
-  }
+  const bool on = ((int)(bS != 0) & (int)(absdiff(R0, L0) < alpha) & (int)(absdiff(R0, R1) < beta) & (int)(absdiff(L0, L1) < beta)) != 0;
+  const int tc = c0 + 1, dif = med3i(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
+  const bool st = bS == 4;
+  const int nL0 = st ? ((L1 << 1) + L0 + R1 + 2) >> 2 : med3i(0, 255, L0 + dif);
+  const int nR0 = st ? ((R1 << 1) + R0 + L1 + 2) >> 2 : med3i(0, 255, R0 - dif);
+  L0r = on ? nL0 : L0; R0r = on ? nR0 : R0;
 }
 
 struct RowArgs {
@@ -250,8 +258,8 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
         int p[20];
 #pragma unroll
         for (int k = 0; k < 20; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
-#define VEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; if (bS) { const uint32_t ab = (E) ? abI : abE; \
-                     luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); } }
+#define VEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; const uint32_t ab = (E) ? abI : abE; \
+                   if (__any(bS)) luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255, __any(bS == 4)); }
         VEDGE(0) VEDGE(1) VEDGE(2) VEDGE(3)
 #undef VEDGE
 #pragma unroll
@@ -276,8 +284,8 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
         int p[20];
 #pragma unroll
         for (int k = 0; k < 20; k++) p[k] = c[k * YP];
-#define HEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; if (bS) { const uint32_t ab = (E) ? abI : abE; \
-                     luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); } }
+#define HEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; const uint32_t ab = (E) ? abI : abE; \
+                   if (__any(bS)) luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255, __any(bS == 4)); }
         HEDGE(0) HEDGE(1) HEDGE(2) HEDGE(3)
 #undef HEDGE
 #pragma unroll
@@ -375,8 +383,8 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
         int p[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
-        { const int bS = bs & 255; if (bS) chroma_edge4(p[2], p[3], p[4], p[5], bS, abE & 255, abE >> 8, c0 & 255); }
-        { const int bS = (bs >> 16) & 255; if (bS) chroma_edge4(p[6], p[7], p[8], p[9], bS, abI & 255, abI >> 8, (c0 >> 16) & 255); }
+        chroma_edge4(p[2], p[3], p[4], p[5], bs & 255, abE & 255, abE >> 8, c0 & 255);
+        chroma_edge4(p[6], p[7], p[8], p[9], (bs >> 16) & 255, abI & 255, abI >> 8, (c0 >> 16) & 255);
 #pragma unroll
         for (int k = 0; k < 3; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
       }
@@ -397,8 +405,8 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
 #pragma unroll
         for (int k = 0; k < 18; k++) p[k] = (k < RH + 2) ? c[k * CPB] : 0;
         // chroma_edge[1][e][fmt]: 4:2:0 -> rows 0 (e=0), 4 (e=2); 4:2:2 -> rows 0, 4, 8, 12 (e = 0..3)
-#define CHEDGE(E, ROW) { const int bS = (bs >> (8 * (E))) & 255; if (bS) { const uint32_t ab = (E) ? abI : abE; \
-                           chroma_edge4(p[ROW], p[(ROW) + 1], p[(ROW) + 2], p[(ROW) + 3], bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); } }
+#define CHEDGE(E, ROW) { const uint32_t ab = (E) ? abI : abE; \
+                         chroma_edge4(p[ROW], p[(ROW) + 1], p[(ROW) + 2], p[(ROW) + 3], (bs >> (8 * (E))) & 255, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); }
         CHEDGE(0, 0)
         if (fmt == 1) { CHEDGE(2, 4) }
         else { CHEDGE(1, 4) CHEDGE(2, 8) CHEDGE(3, 12) }

@@ -50,3 +50,5 @@ void jmhip_time_end(jmhip_ctx *ctx, int kind);
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);
 int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8);
+void jmhip_launch_refine_mb(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, const jmhip_me_result *d_int,
+                            const jmhip_refine_params *prm, jmhip_me_result *d_out);

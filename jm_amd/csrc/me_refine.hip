@@ -1,0 +1,203 @@
+// me_refine.hip -- K4 for whole macroblocks: BlockMotionSearch's IntPelME -> SubPelME hand-over (lencod/src/mv_search.c:960-981)
+// for every searched partition of every window job, device resident (gfx950).
+//
+// Same result, bit for bit, as sub_pel_motion_estimation (lencod/src/me_fullsearch.c:186-289, RDOptimization != 0) applied to
+// each partition, and as the per-block kernel k_me_subpel (me_subpel.hip), with the distortions of
+//   computeSAD              me_distortion.c:349-426   (block origin through UMVLine4X, refbuf.h:22-26)
+//   computeSATD             me_distortion.c:745-825   (per 4x4 -- or per 8x8 when test8x8 -- sub-block origin through UMVLine4X)
+//   HadamardSAD4x4 / 8x8    me_distortion.c:175-258 / :266-341
+//
+// Mapping.  One workgroup = one window job = one macroblock.  Whatever the block type, a macroblock is sixteen 4x4 blocks, so
+// one refinement stage (9 candidates) of all 7 block types is 7 x 16 x 9 = 1008 equal work items "SAD / Hadamard-SATD of 4x4 block
+// b at candidate c of the partition of type t that contains b"; 256 lanes take four each, with no divergence between
+// block sizes and no idle candidate lanes.  An item reads its four reference rows as (unaligned) dwords straight from the
+// plane its candidate's quarter-pel phase selects, the current macroblock sits in LDS, and the per-(partition, candidate)
+// sums are formed with LDS atomics.  41 lanes then replay JM's sequential strict-'<' scan over the 9 costs.
+// With the 8x8 transform (test8x8, block types 1-4) the unit is an 8x8 block (Hadamard 8x8), led by the lane of its top-left 4x4.
+#include "jmhip_internal.h"
+
+struct PlaneSet2 { const uint8_t *base; int pitch; long plane_stride; int W, H; };
+
+__device__ __forceinline__ int iabs2_(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int mvbits2(int d) { int a = iabs2_(d); return a == 0 ? 1 : 2 * (31 - __clz(a)) + 3; }
+__device__ __forceinline__ const uint8_t *umv_line2(const PlaneSet2 &ps, int qy, int qx)
+{
+  const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), ps.H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), ps.W + 15);
+  return ps.base + ((qy & 3) * 4 + (qx & 3)) * ps.plane_stride + (long)(yy + JMHIP_PAD_Y) * ps.pitch + xx + JMHIP_PAD_X;
+}
+struct __attribute__((packed)) u32u { uint32_t v; };
+__device__ __forceinline__ uint32_t ld4(const uint8_t *p) { return ((const u32u *)p)->v; }
+
+// sum |H d H^T| of a 4x4 block given as four packed rows of the current and the reference samples
+__device__ __forceinline__ int hadamard4_rows(const uint32_t c[4], const uint32_t r[4])
+{
+  int m[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int a = (int)(c[i] & 255) - (int)(r[i] & 255), b = (int)((c[i] >> 8) & 255) - (int)((r[i] >> 8) & 255);
+    const int cc = (int)((c[i] >> 16) & 255) - (int)((r[i] >> 16) & 255), e = (int)(c[i] >> 24) - (int)(r[i] >> 24);
+    const int s0 = a + e, s1 = b + cc, s2 = b - cc, s3 = a - e;
+    m[4 * i] = s0 + s1; m[4 * i + 1] = s0 - s1; m[4 * i + 2] = s2 + s3; m[4 * i + 3] = s3 - s2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int a = m[i], b = m[4 + i], cc = m[8 + i], e = m[12 + i];
+    const int s0 = a + e, s1 = b + cc, s2 = b - cc, s3 = a - e;
+    s += iabs2_(s0 + s1) + iabs2_(s0 - s1) + iabs2_(s2 + s3) + iabs2_(s3 - s2);
+  }
+  return (s + 1) >> 1;
+}
+__device__ __forceinline__ int sad4_rows(const uint32_t c[4], const uint32_t r[4])
+{
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) s = __builtin_amdgcn_sad_u8(c[i], r[i], s);
+  return (int)s;
+}
+__device__ __forceinline__ void had8_1d2(int v[8])
+{
+  int a[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { a[i] = v[i] + v[i + 4]; a[i + 4] = v[i] - v[i + 4]; }
+  const int b[8] = {a[0] + a[2], a[1] + a[3], a[0] - a[2], a[1] - a[3], a[4] + a[6], a[5] + a[7], a[4] - a[6], a[5] - a[7]};
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[2 * i] = b[2 * i] + b[2 * i + 1]; v[2 * i + 1] = b[2 * i] - b[2 * i + 1]; }
+}
+// HadamardSAD8x8 of the 8x8 block whose current samples start at s_cur row `by`, dword `bx4` and whose reference starts at r
+__device__ int hadamard8_lds(const uint32_t *s_cur, int by, int bx4, const uint8_t *r, int pitch)
+{
+  int m[8][8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t c0 = s_cur[(by + j) * 4 + bx4], c1 = s_cur[(by + j) * 4 + bx4 + 1];
+    const uint32_t r0 = ld4(r + (long)j * pitch), r1 = ld4(r + (long)j * pitch + 4);
+    int v[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v[i] = (int)((c0 >> (8 * i)) & 255) - (int)((r0 >> (8 * i)) & 255); v[4 + i] = (int)((c1 >> (8 * i)) & 255) - (int)((r1 >> (8 * i)) & 255); }
+    had8_1d2(v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[j][i] = v[i];
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = m[j][i];
+    had8_1d2(v);
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += iabs2_(v[j]);
+  }
+  return (s + 2) >> 2;
+}
+
+__device__ __constant__ int8_t c_sp9b[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};   // mv_search.c:405-442, R = 1
+__device__ __constant__ uint8_t c_geom[JMHIP_NPART][4] = {           // x, y, w, h of the 41 partitions (ABI order, jmhip.h)
+  {0,0,16,16}, {0,0,16,8},{0,8,16,8}, {0,0,8,16},{8,0,8,16}, {0,0,8,8},{8,0,8,8},{0,8,8,8},{8,8,8,8},
+  {0,0,8,4},{8,0,8,4},{0,4,8,4},{8,4,8,4},{0,8,8,4},{8,8,8,4},{0,12,8,4},{8,12,8,4},
+  {0,0,4,8},{4,0,4,8},{8,0,4,8},{12,0,4,8},{0,8,4,8},{4,8,4,8},{8,8,4,8},{12,8,4,8},
+  {0,0,4,4},{4,0,4,4},{8,0,4,4},{12,0,4,4},{0,4,4,4},{4,4,4,4},{8,4,4,4},{12,4,4,4},
+  {0,8,4,4},{4,8,4,4},{8,8,4,4},{12,8,4,4},{0,12,4,4},{4,12,4,4},{8,12,4,4},{12,12,4,4}
+};
+// partition of block type t+1 that contains 4x4 block (bx4, by4)
+__device__ __forceinline__ int part_of(int t, int bx4, int by4)
+{
+  switch (t) {
+  case 0: return 0;
+  case 1: return 1 + (by4 >> 1);
+  case 2: return 3 + (bx4 >> 1);
+  case 3: return 5 + (by4 >> 1) * 2 + (bx4 >> 1);
+  case 4: return 9 + by4 * 2 + (bx4 >> 1);
+  case 5: return 17 + (by4 >> 1) * 4 + bx4;
+  default: return 25 + by4 * 4 + bx4;
+  }
+}
+
+#define NITEMS (7 * 16 * 9)
+#define COST_MAX 0x7fffffff
+
+__global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
+                                                      jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
+                                                      PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch)
+{
+  __shared__ uint32_t s_cur[64];                  // the current macroblock, 16 rows x 4 dwords
+  __shared__ int s_mv[JMHIP_NPART][2];            // per partition: the motion vector the running stage refines
+  __shared__ int s_min[JMHIP_NPART];              // min_mcost carried between the stages
+  __shared__ unsigned s_dist[JMHIP_NPART * 9];    // distortion of (partition, candidate), summed over its 4x4 / 8x8 blocks
+  const int tid = threadIdx.x;
+  const jmhip_me_job *job = jobs + blockIdx.x;
+  const uint64_t mask = job->part_mask;
+  const int mb_x = job->mb_x, mb_y = job->mb_y;
+  if (tid < 64) s_cur[tid] = *(const uint32_t *)(cur + (long)(mb_y + (tid >> 2)) * cur_pitch + mb_x + 4 * (tid & 3));
+  if (tid < JMHIP_NPART) {
+    const jmhip_me_best ib = ires[blockIdx.x].best[tid];
+    s_mv[tid][0] = ib.mv_x; s_mv[tid][1] = ib.mv_y;
+    s_min[tid] = prm.start_hp ? ib.cost : COST_MAX;                              // mv_search.c:971-974
+  }
+#pragma unroll 1
+  for (int stage = 0; stage < 2; stage++) {
+    const int step = stage == 0 ? 2 : 1, start = stage == 0 ? prm.start_hp : prm.start_qp;
+    const int lambda = stage == 0 ? prm.lambda_h : prm.lambda_q, metric = stage == 0 ? prm.metric_h : prm.metric_q;
+    for (int k = tid; k < JMHIP_NPART * 9; k += 256) s_dist[k] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int item = tid; item < NITEMS; item += 256) {
+      const int t = item / 144, rem = item - t * 144, cand = rem >> 4, b4 = rem & 15;
+      const int bx4 = b4 & 3, by4 = b4 >> 2, p = part_of(t, bx4, by4);
+      if (!((mask >> p) & 1) || cand < start) continue;
+      const int cx = s_mv[p][0] + c_sp9b[cand][0] * step, cy = s_mv[p][1] + c_sp9b[cand][1] * step;
+      const int t8 = prm.transform8x8_mode && p <= 8 && metric != JMHIP_METRIC_SAD;           // mv_search.c:1630 / :1770
+      int d;
+      if (metric == JMHIP_METRIC_SAD) {
+        // the whole block hangs off ONE clamped origin (computeSAD): offset of this 4x4 inside its partition
+        const int px = mb_x + c_geom[p][0], py = mb_y + c_geom[p][1];
+        const uint8_t *r = umv_line2(ps, (py << 2) + cy, (px << 2) + cx) + (long)(4 * by4 - c_geom[p][1]) * ps.pitch + (4 * bx4 - c_geom[p][0]);
+        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
+        const uint32_t rr[4] = {ld4(r), ld4(r + ps.pitch), ld4(r + 2L * ps.pitch), ld4(r + 3L * ps.pitch)};
+        d = sad4_rows(c, rr);
+      } else if (!t8) {
+        const uint8_t *r = umv_line2(ps, ((mb_y + 4 * by4) << 2) + cy, ((mb_x + 4 * bx4) << 2) + cx);
+        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
+        const uint32_t rr[4] = {ld4(r), ld4(r + ps.pitch), ld4(r + 2L * ps.pitch), ld4(r + 3L * ps.pitch)};
+        d = hadamard4_rows(c, rr);
+      } else {
+        if ((bx4 | by4) & 1) continue;                                           // the top-left 4x4 leads its 8x8 block
+        const uint8_t *r = umv_line2(ps, ((mb_y + 4 * by4) << 2) + cy, ((mb_x + 4 * bx4) << 2) + cx);
+        d = hadamard8_lds(s_cur, 4 * by4, bx4, r, ps.pitch);
+      }
+      atomicAdd(&s_dist[p * 9 + cand], (unsigned)d);
+    }
+    __syncthreads();
+    if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
+      const int p = tid, mvx = s_mv[p][0], mvy = s_mv[p][1], pred_x = job->pred[p][0], pred_y = job->pred[p][1];
+      int min_mcost = (stage == 1 && !prm.start_qp) ? COST_MAX : s_min[p];     // me_fullsearch.c:252-253
+      int best = 0;
+      const int carried = min_mcost;
+#pragma unroll
+      for (int l = 0; l < 9; l++) {
+        int cost;
+        if (l < start) cost = l == 0 ? carried : COST_MAX;                      // position 0 keeps the carried-in cost
+        else {
+          const int cx = mvx + c_sp9b[l][0] * step, cy = mvy + c_sp9b[l][1] * step;
+          cost = lambda * (mvbits2(cx - pred_x) + mvbits2(cy - pred_y)) + (int)(s_dist[p * 9 + l] << 5);
+        }
+        if (cost < min_mcost) { min_mcost = cost; best = l; }
+      }
+      s_mv[p][0] = mvx + c_sp9b[best][0] * step; s_mv[p][1] = mvy + c_sp9b[best][1] * step;
+      s_min[p] = min_mcost;
+    }
+    __syncthreads();
+  }
+  if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
+    jmhip_me_best b;
+    b.mv_x = (int16_t)s_mv[tid][0]; b.mv_y = (int16_t)s_mv[tid][1]; b.cost = s_min[tid];
+    out[blockIdx.x].best[tid] = b;
+  }
+}
+
+void jmhip_launch_refine_mb(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, const jmhip_me_result *d_int,
+                            const jmhip_refine_params *prm, jmhip_me_result *d_out)
+{
+  PlaneSet2 ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H;
+  hipLaunchKernelGGL(k_me_refine_mb, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch);
+}

@@ -13,6 +13,7 @@
 // group min-reduces (cost, position) keys, which reproduces the sequential strict-'<' scan.
 // Reads go straight to the planes (L2 resident: 16 planes x 2.2 MB at 1080p); algorithmic bytes per
 // block job: 18 candidates x bsx*bsy reference samples + bsx*bsy current samples.
+#include <stdlib.h>
 #include "jmhip_internal.h"
 
 struct PlaneSet { const uint8_t *base; int pitch; long plane_stride; int W, H; };
@@ -252,10 +253,12 @@ extern "C" int jmhip_me_refine_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_
   if (!ctx) return JMHIP_EINVAL;
   if (!d_jobs || !d_int || !prm || !d_out || njobs < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_refine_dev: bad argument");
   if (njobs == 0) return JMHIP_OK;
-  const long groups = (long)njobs * JMHIP_NPART;
   jmhip_time_begin(ctx, 2);
-  hipLaunchKernelGGL(k_me_refine, dim3((unsigned)((groups + 3) / 4)), dim3(64), 0, ctx->stream, d_jobs, njobs, d_int, *prm, d_out,
-                     planes_of(ctx, slot), ctx->d_cur, ctx->cur_pitch);
+  if (getenv("JMHIP_REFINE_PER_BLOCK")) {                 // the per-block kernel (one 16-lane group per partition): A/B testing
+    const long groups = (long)njobs * JMHIP_NPART;
+    hipLaunchKernelGGL(k_me_refine, dim3((unsigned)((groups + 3) / 4)), dim3(64), 0, ctx->stream, d_jobs, njobs, d_int, *prm, d_out,
+                       planes_of(ctx, slot), ctx->d_cur, ctx->cur_pitch);
+  } else jmhip_launch_refine_mb(ctx, slot, d_jobs, njobs, d_int, prm, d_out);
   jmhip_time_end(ctx, 2);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;

@@ -74,6 +74,13 @@ def load_library():
         path = library_path()
         if not os.path.exists(path):
             raise JmHipError(f"{path} is missing: build it with `python -m jm_amd.build` (there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy is
+        # loaded first serves both, and torch cannot see a device through a foreign copy ("No HIP GPUs are available"),
+        # so when the harness uses torch at all its runtime has to be the one in the process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         lib.jmhip_last_error.restype = C.c_char_p
         lib.jmhip_last_error.argtypes = [C.c_void_p]

@@ -105,6 +105,11 @@ class RefPic:
         return self.planes.astype(np.uint8)
 
 
+def mvbits(d):
+    """mvbits LUT of lencod/src/mv_search.c:366-374 (jmo_mvbits)."""
+    return int(L.jmo_mvbits(int(d)))
+
+
 def block_of(cur, x, y, w, h):
     return np.ascontiguousarray(cur[y:y + h, x:x + w], dtype=np.uint16)
 

@@ -263,6 +263,61 @@ def test_subpel_and_eval_vs_oracle(J, metric, test8x8, start):
     ctx.close()
 
 
+@pytest.mark.parametrize("metric,t8mode,start,seed", [(2, 0, 0, 1), (0, 0, 1, 2), (2, 1, 0, 3), (0, 0, 0, 4), (2, 0, 1, 5)])
+def test_refine_dev_vs_oracle(J, metric, t8mode, start, seed):
+    """jmhip_me_refine_dev (BlockMotionSearch's IntPelME -> SubPelME hand-over, all partitions of every window job, device
+    resident) against the oracle's sub_pel_motion_estimation: random integer MVs (incl. far outside the picture), random
+    predictors, partial partition masks, several jobs per macroblock."""
+    import torch
+    from jm_amd.lib import ME_JOB, ME_RESULT, PARTITIONS, NPART
+    w, h = 160, 96
+    ref, cur = synth_pair(w, h, 30 + seed)
+    rng = np.random.default_rng(seed)
+    ctx = make_ctx(w, h, R=8)
+    ctx.set_reference(0, ref); ctx.set_current(cur)
+    oref = J.RefPic(ref)
+    mbs = [(x, y) for y in range(0, h, 16) for x in range(0, w, 16)]
+    jobs = np.zeros(2 * len(mbs), ME_JOB)
+    ires = np.zeros(2 * len(mbs), ME_RESULT)
+    for i in range(len(jobs)):
+        x, y = mbs[i % len(mbs)]
+        jobs[i]["mb_x"], jobs[i]["mb_y"], jobs[i]["search_range"], jobs[i]["lambda"] = x, y, 8, 187
+        mask = int(rng.integers(1, 1 << 41)) if i >= len(mbs) else (1 << 41) - 1
+        jobs[i]["part_mask"] = np.uint64(mask)
+        far = rng.integers(0, 4) == 0
+        jobs[i]["pred"] = rng.integers(-40, 41, (41, 2))
+        ires[i]["best"]["mv_x"] = 4 * rng.integers(-50 if far else -10, 51 if far else 11, 41)
+        ires[i]["best"]["mv_y"] = 4 * rng.integers(-40 if far else -8, 41 if far else 9, 41)
+        for p, (bt, bx, by, bw, bh) in enumerate(PARTITIONS):       # the cost the integer search would have returned (used when start != 0)
+            mv = (int(ires[i]["best"][p]["mv_x"]), int(ires[i]["best"][p]["mv_y"]))
+            pred = jobs[i]["pred"][p]
+            sad = int(J.L.jmo_compute_sad(oref.ptr(), J._p(J.block_of(cur, x + bx, y + by, bw, bh)), bw, bh, J.DIST_MAX, (x + bx) * 4 + mv[0], (y + by) * 4 + mv[1]))
+            ires[i]["best"][p]["cost"] = sad + 187 * (J.mvbits(mv[0] - int(pred[0])) + J.mvbits(mv[1] - int(pred[1])))
+    dev = torch.device("cuda", 0)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1)).to(dev)
+    d_int = torch.from_numpy(ires.view(np.uint8).reshape(len(jobs), -1)).to(dev)
+    d_out = torch.full((len(jobs), ME_RESULT.itemsize), 0x5a, dtype=torch.uint8, device=dev)
+    prm = ctx.refine_params(187, 150, metric, metric, start, start, t8mode)
+    ctx.me_refine_dev(0, d_jobs.data_ptr(), len(jobs), d_int.data_ptr(), prm, d_out.data_ptr())
+    ctx.synchronize()
+    out = d_out.cpu().numpy().view(ME_RESULT).reshape(len(jobs))
+    untouched = np.frombuffer(bytes([0x5a] * 8), dtype=out["best"].dtype)[0]
+    for i in range(len(jobs)):
+        x, y = int(jobs[i]["mb_x"]), int(jobs[i]["mb_y"])
+        for p, (bt, bx, by, bw, bh) in enumerate(PARTITIONS):
+            got = out[i]["best"][p]
+            if not (int(jobs[i]["part_mask"]) >> p) & 1:
+                assert got == untouched, (i, p, "entry outside part_mask was written")
+                continue
+            mv = (int(ires[i]["best"][p]["mv_x"]), int(ires[i]["best"][p]["mv_y"]))
+            pred = tuple(int(v) for v in jobs[i]["pred"][p])
+            t8 = int(t8mode and p <= 8)
+            omv, ocost = J.sub_pel_search(oref, cur, x + bx, y + by, bw, bh, pred, mv, 187, 150, metric, metric, start, start, t8,
+                                          int(ires[i]["best"][p]["cost"]) if start else J.DIST_MAX)
+            assert (int(got["mv_x"]), int(got["mv_y"]), int(got["cost"])) == (omv[0], omv[1], ocost), (i, p)
+    ctx.close()
+
+
 # --------------------------------------------------------------------------- K7/K8 transform + quant
 def test_transforms_golden(J, fs):
     ctx = make_ctx(16, 16)
