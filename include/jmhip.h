@@ -207,6 +207,45 @@ int jmhip_inverse4x4(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t
 int jmhip_forward8x8(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t *out);   /* transform.c:353 */
 int jmhip_inverse8x8(jmhip_ctx *ctx, const int32_t *in, int32_t nblocks, int32_t *out);   /* transform.c:450 */
 
+/* 8x8 luma residual: residual_transform_quant_luma_8x8 (lencod/src/transform8x8.c:522-586) and, with prm.cavlc,
+ * residual_transform_quant_luma_8x8_cavlc (:604-672) = forward8x8 (lcommon/src/transform.c:353) + Slice.quant_8x8 /
+ * quant_8x8cavlc (quant_8x8_normal lencod/src/quant8x8_normal.c:43, quant_8x8cavlc_normal :123, quant_8x8_around
+ * quant8x8_around.c:43, quant_8x8cavlc_around :136) + inverse8x8 (transform.c:450) + sample_reconstruct (DQ_BITS_8 = 6),
+ * frame scan (SNGL_SCAN8x8 / SNGL_SCAN8x8_CAVLC), COEFF_COST8x8[0]. */
+typedef struct {
+  jmhip_qparam q[64];               /* p_Quant->q_params_8x8[pl][intra][qp][j][i] at index j*8+i */
+  int32_t qp_per, cavlc, adaptive_rounding, adapt_rnd_weight, max_pel;
+  int32_t reserved_[3];
+} jmhip_tq8_params;                 /* 800 bytes */
+typedef struct {
+  int16_t level[68];                /* cavlc 0: one 0-terminated list at [0..64]; cavlc 1: four lists of 17 at [17k..] (cofAC[k][0]) */
+  uint8_t run[68];
+  int32_t coeff_cost;
+  uint8_t nonzero, any_residual;    /* any_residual: check_zero() of the non-CAVLC path (0 => JM leaves fadjust untouched) */
+  uint8_t ncoef[4];                 /* entries in each list */
+  uint8_t reserved_[2];
+  uint8_t rec[64];                  /* reconstructed samples, row-major */
+  int16_t fadjust[64];              /* ARCofAdj8x8 update (adaptive rounding only), row-major */
+} jmhip_tq8_out;                    /* 408 bytes */
+int jmhip_tq_luma8x8(jmhip_ctx *ctx, const jmhip_tq8_params *prm, const uint8_t *orig, const uint8_t *pred, int32_t nblocks, jmhip_tq8_out *out);
+int jmhip_tq_luma8x8_dev(jmhip_ctx *ctx, const jmhip_tq8_params *prm, const uint8_t *d_orig, const uint8_t *d_pred, int32_t nblocks, jmhip_tq8_out *d_out);
+
+/* The DC transforms of lcommon/src/transform.c, batched over blocks of int32 (row-major):
+ *   HADAMARD4x4 :121 / IHADAMARD4x4 :170   16 values (Intra16x16 luma DC)
+ *   HADAMARD4x2 :220 / IHADAMARD4x2 :258   8 values, rows [2][4]; the inverse returns JM's transposed [4][2] layout (4:2:2 chroma DC)
+ *   HADAMARD2x2 :301 / IHADAMARD2x2 :316   4 values {dc00, dc01, dc10, dc11} (4:2:0 chroma DC) */
+#define JMHIP_DC_HADAMARD4x4  0
+#define JMHIP_DC_IHADAMARD4x4 1
+#define JMHIP_DC_HADAMARD4x2  2
+#define JMHIP_DC_IHADAMARD4x2 3
+#define JMHIP_DC_HADAMARD2x2  4
+#define JMHIP_DC_IHADAMARD2x2 5
+int jmhip_dc_transform(jmhip_ctx *ctx, int32_t kind, const int32_t *in, int32_t nblocks, int32_t *out);
+/* quant_dc4x4_normal (lencod/src/quant4x4_normal.c:200-259, Slice.quant_dc4x4): `blocks` (n x 16 int32, row-major) holds the
+ * transformed DC coefficients on entry and the quantised LEVELS on return, as JM leaves them for ihadamard4x4. */
+typedef struct { int16_t level[17]; uint8_t run[17]; uint8_t nonzero; } jmhip_dc_out;   /* 52 bytes */
+int jmhip_quant_dc4x4(jmhip_ctx *ctx, const jmhip_qparam *q, int32_t qp_per, int32_t cavlc, int32_t *blocks, int32_t nblocks, jmhip_dc_out *out);
+
 /* ------------------------------------------------------------------------------------------
  * In-loop deblocking of a whole frame
  *

@@ -39,6 +39,13 @@ TQ_PARAMS = np.dtype([("q", "<i4", (16, 3)), ("qp_per", "<i4"), ("cavlc", "<i4")
                       ("adapt_rnd_weight", "<i4"), ("max_pel", "<i4"), ("reserved_", "<i4", (3,))])
 TQ_OUT = np.dtype([("level", "<i2", (16,)), ("run", "u1", (16,)), ("coeff_cost", "<i4"), ("nonzero", "u1"), ("any_residual", "u1"),
                    ("ncoef", "u1"), ("reserved_", "u1"), ("rec", "u1", (16,)), ("fadjust", "<i2", (16,))])
+TQ8_PARAMS = np.dtype([("q", "<i4", (64, 3)), ("qp_per", "<i4"), ("cavlc", "<i4"), ("adaptive_rounding", "<i4"),
+                       ("adapt_rnd_weight", "<i4"), ("max_pel", "<i4"), ("reserved_", "<i4", (3,))])
+TQ8_OUT = np.dtype([("level", "<i2", (68,)), ("run", "u1", (68,)), ("coeff_cost", "<i4"), ("nonzero", "u1"), ("any_residual", "u1"),
+                    ("ncoef", "u1", (4,)), ("reserved_", "u1", (2,)), ("rec", "u1", (64,)), ("fadjust", "<i2", (64,))])
+DC_OUT = np.dtype([("level", "<i2", (17,)), ("run", "u1", (17,)), ("nonzero", "u1")])
+assert TQ8_PARAMS.itemsize == 800 and TQ8_OUT.itemsize == 408 and DC_OUT.itemsize == 52
+DC_KINDS = {"hadamard4x4": (0, 16), "ihadamard4x4": (1, 16), "hadamard4x2": (2, 8), "ihadamard4x2": (3, 8), "hadamard2x2": (4, 4), "ihadamard2x2": (5, 4)}
 DB_MB = np.dtype([("mb_type", "<i2"), ("slice_type", "<i2"), ("qp", "<i2"), ("qpc", "<i2", (2,)), ("cbp", "<i2"), ("cbp_blk", "<u4"),
                   ("slice_nr", "<i2"), ("df_disable_idc", "<i2"), ("df_alpha_c0", "<i2"), ("df_beta", "<i2"), ("transform8x8", "<i2"),
                   ("reserved_", "<i2")])
@@ -51,6 +58,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
+           "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -246,6 +254,41 @@ class JmHip:
 
     def inverse8x8(self, x):
         return self._xform(self.lib.jmhip_inverse8x8, x, 8)
+
+    @staticmethod
+    def tq8_params(q, qp_per, cavlc=0, adaptive_rounding=0, adapt_rnd_weight=0, max_pel=255):
+        p = np.zeros(1, TQ8_PARAMS)
+        p["q"][0] = np.asarray(q, np.int32).reshape(64, 3)
+        p["qp_per"], p["cavlc"], p["adaptive_rounding"] = qp_per, cavlc, adaptive_rounding
+        p["adapt_rnd_weight"], p["max_pel"] = adapt_rnd_weight, max_pel
+        return p
+
+    def tq_luma8x8(self, prm, orig, pred):
+        """residual_transform_quant_luma_8x8 (lencod/src/transform8x8.c:522 / :604 with prm.cavlc), batched."""
+        orig = np.ascontiguousarray(orig, np.uint8).reshape(-1, 64)
+        pred = np.ascontiguousarray(pred, np.uint8).reshape(-1, 64)
+        out = np.zeros(len(orig), TQ8_OUT)
+        self._ck(self.lib.jmhip_tq_luma8x8(self.h, _vp(prm), _vp(orig), _vp(pred), len(orig), _vp(out)))
+        return out
+
+    def tq_luma8x8_dev(self, prm, d_orig, d_pred, n, d_out):
+        self._ck(self.lib.jmhip_tq_luma8x8_dev(self.h, _vp(prm), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
+
+    def dc_transform(self, name, x):
+        """hadamard4x4 / ihadamard4x4 / hadamard4x2 / ihadamard4x2 / hadamard2x2 / ihadamard2x2 (lcommon/src/transform.c:121-330)."""
+        kind, per = DC_KINDS[name]
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, per)
+        out = np.zeros_like(x)
+        self._ck(self.lib.jmhip_dc_transform(self.h, kind, _vp(x), len(x), _vp(out)))
+        return out
+
+    def quant_dc4x4(self, qparam, qp_per, cavlc, blocks):
+        """quant_dc4x4_normal (lencod/src/quant4x4_normal.c:200); returns (levels left in the block, DC_OUT records)."""
+        q = np.ascontiguousarray(qparam, np.int32).reshape(3)
+        b = np.ascontiguousarray(blocks, np.int32).reshape(-1, 16).copy()
+        out = np.zeros(len(b), DC_OUT)
+        self._ck(self.lib.jmhip_quant_dc4x4(self.h, _vp(q), qp_per, cavlc, _vp(b), len(b), _vp(out)))
+        return b, out
 
     # ---- deblocking
     def deblock_frame(self, y, u, v, mbs, motion, direct8x8=1):

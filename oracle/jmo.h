@@ -115,6 +115,8 @@ void jmo_hadamard4x4(const int in[16], int out[16]);         /* :121-168 */
 void jmo_ihadamard4x4(const int in[16], int out[16]);        /* :170-220 */
 void jmo_hadamard2x2(const int in[4], int out[4]);           /* :284-297 */
 void jmo_ihadamard2x2(const int in[4], int out[4]);          /* :299-312 */
+void jmo_hadamard4x2(const int in[8], int out[8]);           /* :220-256, rows [2][4] */
+void jmo_ihadamard4x2(const int in[8], int out[8]);          /* :258-298, out transposed [4][2] */
 void jmo_forward8x8(const int in[64], int out[64]);          /* :353-448 */
 void jmo_inverse8x8(const int in[64], int out[64]);          /* :450-547 */
 
@@ -136,6 +138,16 @@ int jmo_quant_4x4_around(int tblock[16], const jmo_qparam qp16[16], int qp_per, 
 int jmo_quant_8x8_normal(int tblock[64], const jmo_qparam qp64[64], int qp_per, int cavlc,
                          const uint8_t *pos_scan /*64x2*/, const uint8_t *c_cost,
                          int level[65], int run[65], int *coeff_cost);
+/* quant_8x8_normal / _around / quant_8x8cavlc_normal / _around (variant 0..3), see jmo_tq.c */
+int jmo_quant_8x8(int tblock[64], const jmo_qparam qp64[64], int qp_per, int variant, const uint8_t *pos_scan, const uint8_t *c_cost,
+                  int adapt_rnd_weight, int level[68], int run[68], int *coeff_cost, int fadjust[64]);
+void jmo_scan8x8_cavlc(uint8_t out[64][2]);      /* SNGL_SCAN8x8_CAVLC, transform8x8.c */
+/* quant_dc4x4_normal quant4x4_normal.c:200-259 */
+int jmo_quant_dc4x4_normal(int tblock[16], const jmo_qparam *q, int qp_per, int cavlc, int level[17], int run[17]);
+/* residual_transform_quant_luma_8x8 / _cavlc transform8x8.c:522 / :604, one 8x8 block */
+int jmo_rtq_luma_8x8(const jmo_pel orig[64], const jmo_pel pred[64], const jmo_qparam q[64], int qp_per, int cavlc,
+                     int adaptive_rounding, int adapt_rnd_weight, int max_pel, int level[68], int run[68], int *coeff_cost,
+                     jmo_pel rec[64], int fadjust[64], int *any_residual);
 extern const uint8_t JMO_SNGL_SCAN[16][2];       /* block.c:170 */
 extern const uint8_t JMO_SNGL_SCAN8x8[64][2];    /* transform8x8.c */
 extern const uint8_t JMO_COEFF_COST4x4[3][16];   /* block.c COEFF_COST4x4 */

@@ -80,6 +80,29 @@ void jmo_ihadamard2x2(const int in[4], int out[4])                   /* transfor
   out[0] = t0 + t2; out[1] = t1 + t3; out[2] = t0 - t2; out[3] = t1 - t3;
 }
 
+/* hadamard4x2 transform.c:220-256: in = tblock rows [2][4] -> out [2][4] (4:2:2 chroma DC) */
+void jmo_hadamard4x2(const int in[8], int out[8])
+{
+  int t[8], i;
+  for (i = 0; i < 4; i++) { t[i] = in[i] + in[4 + i]; t[4 + i] = in[i] - in[4 + i]; }
+  for (i = 0; i < 2; i++) {
+    const int *p = t + 4 * i;
+    int t0 = p[0] + p[3], t1 = p[1] + p[2], t2 = p[1] - p[2], t3 = p[0] - p[3];
+    out[4*i] = t0 + t1; out[4*i+1] = t3 + t2; out[4*i+2] = t0 - t1; out[4*i+3] = t3 - t2;
+  }
+}
+/* ihadamard4x2 transform.c:258-298: in [2][4] -> out TRANSPOSED [4][2] (block[0..3][i], i = 0,1) */
+void jmo_ihadamard4x2(const int in[8], int out[8])
+{
+  int t[8], i;
+  for (i = 0; i < 4; i++) { t[i] = in[i] + in[4 + i]; t[4 + i] = in[i] - in[4 + i]; }
+  for (i = 0; i < 2; i++) {
+    const int *p = t + 4 * i;
+    int t0 = p[0] + p[2], t1 = p[0] - p[2], t2 = p[1] - p[3], t3 = p[1] + p[3];
+    out[0*2+i] = t0 + t3; out[1*2+i] = t1 + t2; out[2*2+i] = t1 - t2; out[3*2+i] = t0 - t3;
+  }
+}
+
 /* ---------------- 8-point stages ---------------- */
 static inline void fwd8(const int *s, int ss, int *d, int ds)         /* transform.c:364-401 */
 {
@@ -261,6 +284,95 @@ int jmo_quant_8x8_normal(int tb[64], const jmo_qparam q[64], int qp_per, int cav
     } else r++;
   }
   level[n] = 0;
+  return nonzero;
+}
+
+/* The four 8x8 quantisers in one restatement:
+ *   variant 0 quant_8x8_normal      quant8x8_normal.c:43-107     one 64-entry level/run list, frame zig-zag
+ *   variant 1 quant_8x8_around      quant8x8_around.c:43-123     + fadjust
+ *   variant 2 quant_8x8cavlc_normal quant8x8_normal.c:123-203    four 16-entry lists (scan quarter k -> list k), |level| <= 2063
+ *   variant 3 quant_8x8cavlc_around quant8x8_around.c:136-220    + fadjust
+ * scan: 64 (i,j) pairs as handed to the function by JM (SNGL_SCAN8x8 or SNGL_SCAN8x8_CAVLC, transform8x8.c).
+ * level / run: 68 entries; variants 0/1 use [0..64], variants 2/3 four lists of 17 at [17k ..]. */
+int jmo_quant_8x8(int tb[64], const jmo_qparam q[64], int qp_per, int variant, const uint8_t *scan, const uint8_t *c_cost,
+                  int arw, int level[68], int run[68], int *coeff_cost, int fadjust[64])
+{
+  const int q_bits = 16 + qp_per, cavlc = variant >= 2, around = variant & 1;
+  int k, nonzero = 0, r[4] = {0, 0, 0, 0}, n[4] = {0, 0, 0, 0};
+  for (k = 0; k < 64; k++) {
+    const int i = scan[2 * k], j = scan[2 * k + 1], idx = j * 8 + i, c = tb[idx], l = cavlc ? k >> 4 : 0;
+    int fadj = 0;
+    if (c != 0) {
+      const int scaled = iabs_(c) * q[idx].ScaleComp;
+      int lev = (scaled + q[idx].OffsetComp) >> q_bits;
+      if (lev != 0) {
+        if (cavlc) lev = imin_(lev, 2063);
+        if (around) fadj = rshift_rnd_sf(arw * (scaled - (lev << q_bits)), q_bits + 1);
+        nonzero = 1;
+        *coeff_cost += (lev > 1) ? 999999 : c_cost[r[l]];
+        lev = c < 0 ? -lev : lev;
+        tb[idx] = rshift_rnd_sf((lev * q[idx].InvScaleComp) << qp_per, 6);
+        level[17 * l * cavlc + n[l]] = lev; run[17 * l * cavlc + n[l]] = r[l]; n[l]++; r[l] = 0;
+      } else { r[l]++; tb[idx] = 0; }
+    } else r[l]++;
+    if (around) fadjust[idx] = fadj;
+  }
+  if (cavlc) for (k = 0; k < 4; k++) level[17 * k + n[k]] = 0;
+  else level[n[0]] = 0;
+  return nonzero;
+}
+/* the de-interleaved frame scan the CAVLC variants are given (transform8x8.c SNGL_SCAN8x8_CAVLC): list k takes zig-zag positions
+ * k, k+4, k+8, ... ; pinned against the table JM passes (tests/test_oracle_golden.py) */
+void jmo_scan8x8_cavlc(uint8_t out[64][2])
+{
+  int k, i;
+  for (k = 0; k < 4; k++) for (i = 0; i < 16; i++) { out[16 * k + i][0] = JMO_SNGL_SCAN8x8[4 * i + k][0]; out[16 * k + i][1] = JMO_SNGL_SCAN8x8[4 * i + k][1]; }
+}
+
+/* quant_dc4x4_normal quant4x4_normal.c:200-259: one LevelQuantParams for all 16 DC coefficients, q_bits + 1, the block is left
+ * holding the LEVELS (the caller runs ihadamard4x4 and dequantises afterwards) */
+int jmo_quant_dc4x4_normal(int tb[16], const jmo_qparam *q, int qp_per, int cavlc, int level[17], int run[17])
+{
+  const int q_bits = 15 + qp_per + 1;
+  int k, r = 0, n = 0, nonzero = 0;
+  for (k = 0; k < 16; k++) {
+    const int idx = JMO_SNGL_SCAN[k][1] * 4 + JMO_SNGL_SCAN[k][0], c = tb[idx];
+    if (c != 0) {
+      int lev = (iabs_(c) * q->ScaleComp + (q->OffsetComp << 1)) >> q_bits;
+      if (lev != 0) {
+        if (cavlc) lev = imin_(lev, 2063);
+        lev = c < 0 ? -lev : lev;
+        tb[idx] = lev; level[n] = lev; run[n] = r; n++; r = 0; nonzero = 1;
+      } else { r++; tb[idx] = 0; }
+    } else r++;
+  }
+  level[n] = 0;
+  return nonzero;
+}
+
+/* residual_transform_quant_luma_8x8 transform8x8.c:522-586 (cavlc = 0) / residual_transform_quant_luma_8x8_cavlc :604-672
+ * (cavlc = 1: no check_zero, de-interleaved scan, four lists), one 8x8 block, frame scan, disthres 0.
+ * any_residual (may be NULL): check_zero() of the non-CAVLC path; when it is 0 JM leaves fadjust untouched. */
+int jmo_rtq_luma_8x8(const jmo_pel orig[64], const jmo_pel pred[64], const jmo_qparam q[64], int qp_per, int cavlc,
+                     int adaptive_rounding, int arw, int max_pel, int level[68], int run[68], int *coeff_cost,
+                     jmo_pel rec[64], int fadjust[64], int *any_residual)
+{
+  int res[64], tb[64], rr[64], k, any = 0, nonzero = 0;
+  uint8_t scan_c[64][2];
+  for (k = 0; k < 64; k++) { res[k] = (int)orig[k] - (int)pred[k]; any |= res[k]; }
+  if (any_residual) *any_residual = any != 0;
+  if (cavlc || any) {
+    jmo_forward8x8(res, tb);
+    jmo_scan8x8_cavlc(scan_c);
+    nonzero = jmo_quant_8x8(tb, q, qp_per, 2 * cavlc + adaptive_rounding, cavlc ? &scan_c[0][0] : &JMO_SNGL_SCAN8x8[0][0],
+                            JMO_COEFF_COST8x8[0], arw, level, run, coeff_cost, fadjust);
+  } else level[0] = 0;
+  if (nonzero) {
+    jmo_inverse8x8(tb, rr);
+    for (k = 0; k < 64; k++) rec[k] = (jmo_pel)clip1(max_pel, rshift_rnd_sf(rr[k], 6) + (int)pred[k]);   /* DQ_BITS_8 = 6 */
+  } else {
+    for (k = 0; k < 64; k++) rec[k] = pred[k];
+  }
   return nonzero;
 }
 

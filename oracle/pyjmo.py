@@ -192,6 +192,58 @@ def quant_4x4(tblock, qparams, qp_per, cavlc, around=False, arw=0):
     return tb, level, run, cost.value, nz, fadj
 
 
+def _xf(fn, x, n):
+    x = np.ascontiguousarray(x, np.int32); o = np.zeros(n, np.int32); fn(_p(x), _p(o)); return o
+
+
+def hadamard4x4(x): return _xf(L.jmo_hadamard4x4, x, 16)
+def ihadamard4x4(x): return _xf(L.jmo_ihadamard4x4, x, 16)
+def hadamard4x2(x): return _xf(L.jmo_hadamard4x2, x, 8)
+def ihadamard4x2(x): return _xf(L.jmo_ihadamard4x2, x, 8)
+def hadamard2x2(x): return _xf(L.jmo_hadamard2x2, x, 4)
+def ihadamard2x2(x): return _xf(L.jmo_ihadamard2x2, x, 4)
+
+
+def scan8x8(cavlc=False):
+    if cavlc:
+        o = np.zeros((64, 2), np.uint8); L.jmo_scan8x8_cavlc(_p(o)); return o
+    return np.ctypeslib.as_array((C.c_uint8 * 128).in_dll(L, "JMO_SNGL_SCAN8x8")).reshape(64, 2).copy()
+
+
+def coeff_cost8x8(k=0):
+    return np.ctypeslib.as_array((C.c_uint8 * 128).in_dll(L, "JMO_COEFF_COST8x8")).reshape(2, 64)[k].copy()
+
+
+def quant_8x8(tblock, qparams, qp_per, variant, arw=0):
+    """variant 0 normal, 1 around, 2 cavlc_normal, 3 cavlc_around; qparams (64,3) at [j*8+i].
+    Returns (dequantised block, level[68], run[68], coeff_cost, nonzero, fadjust[64])."""
+    tb = np.ascontiguousarray(tblock, np.int32).copy()
+    q = np.ascontiguousarray(qparams, np.int32)
+    level = np.zeros(68, np.int32); run = np.zeros(68, np.int32); cost = C.c_int(0); fadj = np.zeros(64, np.int32)
+    sc, cc = scan8x8(variant >= 2), coeff_cost8x8(0)
+    nz = L.jmo_quant_8x8(_p(tb), _p(q), qp_per, variant, _p(sc), _p(cc), arw, _p(level), _p(run), C.byref(cost), _p(fadj))
+    return tb, level, run, cost.value, nz, fadj
+
+
+def quant_dc4x4(tblock, qparam, qp_per, cavlc):
+    tb = np.ascontiguousarray(tblock, np.int32).copy()
+    q = np.ascontiguousarray(qparam, np.int32)
+    level = np.zeros(17, np.int32); run = np.zeros(17, np.int32)
+    nz = L.jmo_quant_dc4x4_normal(_p(tb), _p(q), qp_per, cavlc, _p(level), _p(run))
+    return tb, level, run, nz
+
+
+def rtq_luma_8x8(orig, pred, qparams, qp_per, cavlc, around, arw, max_pel=255):
+    """Returns (nonzero, coeff_cost, rec[64], level[68], run[68], fadjust[64], any_residual)."""
+    o = np.ascontiguousarray(orig, np.uint16); p_ = np.ascontiguousarray(pred, np.uint16)
+    q = np.ascontiguousarray(qparams, np.int32)
+    level = np.zeros(68, np.int32); run = np.zeros(68, np.int32); cost = C.c_int(0)
+    rec = np.zeros(64, np.uint16); fadj = np.zeros(64, np.int32); anyr = C.c_int(0)
+    nz = L.jmo_rtq_luma_8x8(_p(o), _p(p_), _p(q), qp_per, cavlc, around, arw, max_pel, _p(level), _p(run), C.byref(cost),
+                            _p(rec), _p(fadj), C.byref(anyr))
+    return nz, cost.value, rec, level, run, fadj, anyr.value
+
+
 def qparams_4x4(qp, intra, offset):
     q = np.zeros((16, 3), np.int32)
     L.jmo_qparams_4x4(qp, intra, offset, _p(q))

@@ -324,3 +324,214 @@ void __wrap_sample_reconstruct(imgpel **curImg, imgpel **mpr, int **mb_rres, int
   }
   n++;
 }
+
+/* ================================================================== 8x8 transform / quantisation and the DC transforms
+ *   forward8x8 / inverse8x8                      lcommon/src/transform.c:353 / :450
+ *   hadamard4x4 / ihadamard4x4 / hadamard4x2 / ihadamard4x2 / hadamard2x2 / ihadamard2x2   transform.c:121-330
+ *   quant_8x8_normal / _around / quant_8x8cavlc_normal / _around   lencod/src/quant8x8_normal.c:43,:123 / quant8x8_around.c:43,:136
+ *   quant_dc4x4_normal                           lencod/src/quant4x4_normal.c:200
+ *   residual_transform_quant_luma_8x8 / _cavlc   lencod/src/transform8x8.c:522 / :604
+ */
+#include "quant8x8.h"
+#include "transform8x8.h"
+
+extern void __real_forward8x8(int **, int **, int, int);
+void __wrap_forward8x8(int **block, int **tblock, int pos_y, int pos_x)
+{
+  static int n = 0;
+  int in[64], j, i;
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) in[j * 8 + i] = block[pos_y + j][pos_x + i];
+  __real_forward8x8(block, tblock, pos_y, pos_x);
+  if (n < tap_max() && (n % 11) == 0) {
+    FILE *f = tap_open("fwd8x8.bin");
+    for (j = 0; j < 64; j++) put_i32(f, in[j]);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) put_i32(f, tblock[pos_y + j][pos_x + i]);
+    fclose(f);
+  }
+  n++;
+}
+extern void __real_inverse8x8(int **, int **, int);
+void __wrap_inverse8x8(int **tblock, int **block, int pos_x)
+{
+  static int n = 0;
+  int in[64], j, i;
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) in[j * 8 + i] = tblock[j][pos_x + i];
+  __real_inverse8x8(tblock, block, pos_x);
+  if (n < tap_max() && (n % 11) == 0) {
+    FILE *f = tap_open("inv8x8.bin");
+    for (j = 0; j < 64; j++) put_i32(f, in[j]);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) put_i32(f, block[j][pos_x + i]);
+    fclose(f);
+  }
+  n++;
+}
+
+#define TAP_DC(NAME, ROWS, FILEN)                                                            \
+  extern void __real_##NAME(int **, int **);                                                 \
+  void __wrap_##NAME(int **a, int **b)                                                       \
+  {                                                                                          \
+    static int n = 0;                                                                        \
+    int in[16], j, i;                                                                        \
+    for (j = 0; j < ROWS; j++) for (i = 0; i < 4; i++) in[j * 4 + i] = a[j][i];              \
+    __real_##NAME(a, b);                                                                     \
+    if (n < tap_max()) {                                                                     \
+      FILE *f = tap_open(FILEN);                                                             \
+      for (j = 0; j < ROWS * 4; j++) put_i32(f, in[j]);                                      \
+      for (j = 0; j < ROWS; j++) for (i = 0; i < 4; i++) put_i32(f, b[j][i]);                \
+      fclose(f);                                                                             \
+    }                                                                                        \
+    n++;                                                                                     \
+  }
+TAP_DC(hadamard4x4, 4, "hadamard4x4.bin")
+TAP_DC(ihadamard4x4, 4, "ihadamard4x4.bin")
+TAP_DC(hadamard4x2, 2, "hadamard4x2.bin")
+/* ihadamard4x2 writes its result transposed: block[0..3][0..1] (transform.c:258-298) */
+extern void __real_ihadamard4x2(int **, int **);
+void __wrap_ihadamard4x2(int **tblock, int **block)
+{
+  static int n = 0;
+  int in[8], j, i;
+  for (j = 0; j < 2; j++) for (i = 0; i < 4; i++) in[j * 4 + i] = tblock[j][i];
+  __real_ihadamard4x2(tblock, block);
+  if (n < tap_max()) {
+    FILE *f = tap_open("ihadamard4x2.bin");
+    for (j = 0; j < 8; j++) put_i32(f, in[j]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 2; i++) put_i32(f, block[j][i]);
+    fclose(f);
+  }
+  n++;
+}
+
+extern void __real_hadamard2x2(int **, int *);
+void __wrap_hadamard2x2(int **block, int tblock[4])
+{
+  static int n = 0;
+  int in[4] = {block[0][0], block[0][4], block[4][0], block[4][4]}, k;
+  __real_hadamard2x2(block, tblock);
+  if (n < tap_max()) {
+    FILE *f = tap_open("hadamard2x2.bin");
+    for (k = 0; k < 4; k++) put_i32(f, in[k]);
+    for (k = 0; k < 4; k++) put_i32(f, tblock[k]);
+    fclose(f);
+  }
+  n++;
+}
+extern void __real_ihadamard2x2(int *, int *);
+void __wrap_ihadamard2x2(int tblock[4], int block[4])
+{
+  static int n = 0;
+  int in[4] = {tblock[0], tblock[1], tblock[2], tblock[3]}, k;
+  __real_ihadamard2x2(tblock, block);
+  if (n < tap_max()) {
+    FILE *f = tap_open("ihadamard2x2.bin");
+    for (k = 0; k < 4; k++) put_i32(f, in[k]);
+    for (k = 0; k < 4; k++) put_i32(f, block[k]);
+    fclose(f);
+  }
+  n++;
+}
+
+/* record: qp qp_per AdaptRndWeight variant | 64 x {Offset,Scale,InvScale} | 64 x (i,j) scan | 64 c_cost | in[64] | out[64] |
+ *         4 x 17 levels | 4 x 17 runs | cost delta | return | fadjust[64]        (non-CAVLC variants use the first 65 level/run slots) */
+static void tap_quant8x8(int variant, Macroblock *currMB, int **tblock, struct quant_methods *q, int ***cofAC, int *ret,
+                         int (*real3)(Macroblock *, int **, struct quant_methods *),
+                         int (*real4)(Macroblock *, int **, struct quant_methods *, int ***))
+{
+  static int n[4] = {0, 0, 0, 0};
+  VideoParameters *p_Vid = currMB->p_Vid;
+  int in[64], j, i, k, cost_in = *q->coeff_cost, bx = q->block_x;
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) in[j * 8 + i] = tblock[j][bx + i];
+  *ret = cofAC ? real4(currMB, tblock, q, cofAC) : real3(currMB, tblock, q);
+  if (n[variant] < tap_max() / 4 && (n[variant] % 3) == 0) {
+    FILE *f = tap_open("quant8x8.bin");
+    put_i32(f, q->qp); put_i32(f, p_Vid->p_Quant->qp_per_matrix[q->qp]); put_i32(f, p_Vid->AdaptRndWeight); put_i32(f, variant);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) {
+      put_i32(f, q->q_params[j][i].OffsetComp); put_i32(f, q->q_params[j][i].ScaleComp); put_i32(f, q->q_params[j][i].InvScaleComp);
+    }
+    for (k = 0; k < 64; k++) { put_i32(f, q->pos_scan[k][0]); put_i32(f, q->pos_scan[k][1]); }
+    for (k = 0; k < 64; k++) put_i32(f, q->c_cost[k]);
+    for (k = 0; k < 64; k++) put_i32(f, in[k]);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) put_i32(f, tblock[j][bx + i]);
+    if (cofAC) {
+      for (k = 0; k < 4; k++) for (j = 0; j < 17; j++) put_i32(f, cofAC[k][0][j]);
+      for (k = 0; k < 4; k++) for (j = 0; j < 17; j++) put_i32(f, cofAC[k][1][j]);
+    } else {
+      for (j = 0; j < 68; j++) put_i32(f, j < 65 ? q->ACLevel[j] : 0);
+      for (j = 0; j < 68; j++) put_i32(f, j < 65 ? q->ACRun[j] : 0);
+    }
+    put_i32(f, *q->coeff_cost - cost_in); put_i32(f, *ret);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) put_i32(f, (variant & 1) ? q->fadjust[j][bx + i] : 0);
+    fclose(f);
+  }
+  n[variant]++;
+}
+extern int __real_quant_8x8_normal(Macroblock *, int **, struct quant_methods *);
+int __wrap_quant_8x8_normal(Macroblock *m, int **t, struct quant_methods *q) { int r; tap_quant8x8(0, m, t, q, NULL, &r, __real_quant_8x8_normal, NULL); return r; }
+extern int __real_quant_8x8_around(Macroblock *, int **, struct quant_methods *);
+int __wrap_quant_8x8_around(Macroblock *m, int **t, struct quant_methods *q) { int r; tap_quant8x8(1, m, t, q, NULL, &r, __real_quant_8x8_around, NULL); return r; }
+extern int __real_quant_8x8cavlc_normal(Macroblock *, int **, struct quant_methods *, int ***);
+int __wrap_quant_8x8cavlc_normal(Macroblock *m, int **t, struct quant_methods *q, int ***c) { int r; tap_quant8x8(2, m, t, q, c, &r, NULL, __real_quant_8x8cavlc_normal); return r; }
+extern int __real_quant_8x8cavlc_around(Macroblock *, int **, struct quant_methods *, int ***);
+int __wrap_quant_8x8cavlc_around(Macroblock *m, int **t, struct quant_methods *q, int ***c) { int r; tap_quant8x8(3, m, t, q, c, &r, NULL, __real_quant_8x8cavlc_around); return r; }
+
+extern int __real_quant_dc4x4_normal(Macroblock *, int **, int, int *, int *, LevelQuantParams *, const byte (*)[2]);
+int __wrap_quant_dc4x4_normal(Macroblock *currMB, int **tblock, int qp, int *DCLevel, int *DCRun, LevelQuantParams *qp44, const byte (*pos_scan)[2])
+{
+  static int n = 0;
+  int in[16], j, i, r;
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[j * 4 + i] = tblock[j][i];
+  r = __real_quant_dc4x4_normal(currMB, tblock, qp, DCLevel, DCRun, qp44, pos_scan);
+  if (n < tap_max()) {
+    FILE *f = tap_open("quant_dc4x4.bin");
+    put_i32(f, qp); put_i32(f, currMB->p_Vid->p_Quant->qp_per_matrix[qp]); put_i32(f, currMB->p_Slice->symbol_mode == CAVLC);
+    put_i32(f, qp44->OffsetComp); put_i32(f, qp44->ScaleComp); put_i32(f, qp44->InvScaleComp);
+    for (j = 0; j < 16; j++) put_i32(f, in[j]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, tblock[j][i]);
+    for (j = 0; j < 17; j++) put_i32(f, DCLevel[j]);
+    for (j = 0; j < 17; j++) put_i32(f, DCRun[j]);
+    put_i32(f, r);
+    fclose(f);
+  }
+  n++;
+  return r;
+}
+
+/* record: variant b8 intra qp qp_per AdaptRndWeight AdaptiveRounding max_pel | 64 x q_params | pred[64] | ores[64] |
+ *         return | cost delta | rec[64] | 4 x 17 levels | 4 x 17 runs */
+static int tap_rtq8x8(int variant, Macroblock *currMB, ColorPlane pl, int b8, int *coeff_cost, int intra,
+                      int (*real)(Macroblock *, ColorPlane, int, int *, int))
+{
+  static int n[2] = {0, 0};
+  VideoParameters *p_Vid = currMB->p_Vid;
+  Slice *currSlice = currMB->p_Slice;
+  const int bx = 8 * (b8 & 1), by = 8 * (b8 >> 1), qp = currMB->qp_scaled[pl], pl_off = b8 + (pl << 2);
+  int pred[64], ores[64], j, i, k, r, cost_in = *coeff_cost;
+  LevelQuantParams **qpar = p_Vid->p_Quant->q_params_8x8[pl][intra][qp];
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) { pred[j * 8 + i] = currSlice->mb_pred[pl][by + j][bx + i]; ores[j * 8 + i] = currSlice->mb_ores[pl][by + j][bx + i]; }
+  r = real(currMB, pl, b8, coeff_cost, intra);
+  if (pl == PLANE_Y && n[variant] < tap_max() / 4 && (n[variant] % 3) == 0) {
+    FILE *f = tap_open("rtq8x8.bin");
+    imgpel **img = p_Vid->enc_picture->p_curr_img;
+    put_i32(f, variant); put_i32(f, b8); put_i32(f, intra); put_i32(f, qp); put_i32(f, p_Vid->p_Quant->qp_per_matrix[qp]);
+    put_i32(f, p_Vid->AdaptRndWeight); put_i32(f, p_Vid->AdaptiveRounding); put_i32(f, p_Vid->max_imgpel_value);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) { put_i32(f, qpar[j][i].OffsetComp); put_i32(f, qpar[j][i].ScaleComp); put_i32(f, qpar[j][i].InvScaleComp); }
+    for (k = 0; k < 64; k++) put_i32(f, pred[k]);
+    for (k = 0; k < 64; k++) put_i32(f, ores[k]);
+    put_i32(f, r); put_i32(f, *coeff_cost - cost_in);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) put_i32(f, img[currMB->pix_y + by + j][currMB->pix_x + bx + i]);
+    if (variant) {
+      for (k = 0; k < 4; k++) for (j = 0; j < 17; j++) put_i32(f, currSlice->cofAC[pl_off][k][0][j]);
+      for (k = 0; k < 4; k++) for (j = 0; j < 17; j++) put_i32(f, currSlice->cofAC[pl_off][k][1][j]);
+    } else {
+      for (j = 0; j < 68; j++) put_i32(f, j < 65 ? currSlice->cofAC[pl_off][0][0][j] : 0);
+      for (j = 0; j < 68; j++) put_i32(f, j < 65 ? currSlice->cofAC[pl_off][0][1][j] : 0);
+    }
+    fclose(f);
+  }
+  n[variant]++;
+  return r;
+}
+extern int __real_residual_transform_quant_luma_8x8(Macroblock *, ColorPlane, int, int *, int);
+int __wrap_residual_transform_quant_luma_8x8(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra) { return tap_rtq8x8(0, m, pl, b8, cc, intra, __real_residual_transform_quant_luma_8x8); }
+extern int __real_residual_transform_quant_luma_8x8_cavlc(Macroblock *, ColorPlane, int, int *, int);
+int __wrap_residual_transform_quant_luma_8x8_cavlc(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra) { return tap_rtq8x8(1, m, pl, b8, cc, intra, __real_residual_transform_quant_luma_8x8_cavlc); }

@@ -208,6 +208,32 @@ def main():
         deblock_arrays("db", read_deblock(os.path.join(we, "deblock.bin")), d)
         np.savez_compressed(os.path.join(OUT, "qcif_main.npz"), **d)
 
+        # ---- D: 8x8 transform / quantisation and the DC transforms (High 4:2:2 CABAC + adaptive rounding; the same with CAVLC
+        #         and plain rounding; High 4:2:0 CAVLC for the 2x2 chroma DC transform)
+        d, q8, r8 = {}, [], []
+        for name, cfg, o in [("D", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2)),
+                             ("D2", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2, SymbolMode=0, AdaptiveRounding=0)),
+                             ("D3", "encoder_main.cfg", dict(FramesToBeEncoded=2, Transform8x8Mode=1, ProfileIDC=100, SymbolMode=0)),
+                             ("D4", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2, AdaptiveRounding=0))]:
+            w = os.path.join(tmp, name); os.makedirs(w)
+            run(TAP, cfg, o, w, tap=True)
+            q = read_i32_records(os.path.join(w, "quant8x8.bin"), 718)
+            r = read_i32_records(os.path.join(w, "rtq8x8.bin"), 530)
+            # keep the records that exercise something: at least one non-zero level, spread over the run
+            q = q[np.abs(q[:, 4 + 192 + 128 + 64 + 64 + 64:4 + 192 + 128 + 64 + 64 + 64 + 68]).sum(1) > 0]
+            q8.append(q[:: max(1, len(q) // 60)][:60]); r8.append(r[:: max(1, len(r) // 60)][:60])
+            for nm, wd in (("fwd8x8", 128), ("inv8x8", 128), ("hadamard4x4", 32), ("ihadamard4x4", 32), ("hadamard4x2", 16),
+                           ("ihadamard4x2", 16), ("hadamard2x2", 8), ("ihadamard2x2", 8), ("quant_dc4x4", 73)):
+                a = read_i32_records(os.path.join(w, nm + ".bin"), wd)
+                if len(a):
+                    a = np.unique(a, axis=0)
+                    a = a[np.abs(a).sum(1) > 0]
+                    d.setdefault(nm, []).append(a[:: max(1, len(a) // 80)][:80])
+        d = {k: np.concatenate(v) for k, v in d.items()}
+        d["quant8x8"] = np.concatenate(q8)
+        d["rtq8x8"] = np.concatenate(r8)
+        np.savez_compressed(os.path.join(OUT, "qcif_tq8.npz"), **d)
+
         # ---- md5 goldens of whole-encoder runs
         runs = {
             "G0": ("encoder_baseline.cfg", {}),

@@ -30,6 +30,7 @@ def test_struct_sizes_match_the_header():
     assert L.ME_JOB.itemsize == 192 and L.ME_RESULT.itemsize == 328
     assert L.SUBPEL_JOB.itemsize == 36 and L.TQ_OUT.itemsize == 104
     assert L.DB_MB.itemsize == 28 and L.DB_MOTION.itemsize == 16
+    assert L.TQ8_PARAMS.itemsize == 800 and L.TQ8_OUT.itemsize == 408 and L.DC_OUT.itemsize == 52
 
 
 def test_partition_table_is_the_abi_order():

@@ -373,6 +373,77 @@ def test_quant_golden_records_through_tq(J, fs):
     assert (got == out).all()
 
 
+# --------------------------------------------------------------------------- 8x8 transform/quant, DC transforms, DC quantiser
+@pytest.fixture(scope="module")
+def tq8():
+    return np.load(os.path.join(G, "qcif_tq8.npz"))
+
+
+def _lists_equal(got_l, got_r, want_l, want_r, cavlc):
+    for k in range(4 if cavlc else 1):
+        o = 17 * k if cavlc else 0
+        n = int(np.argmax(want_l[o:o + (17 if cavlc else 65)] == 0)) + 1
+        assert got_l[o:o + n].tolist() == want_l[o:o + n].tolist()
+        assert got_r[o:o + n - 1].tolist() == want_r[o:o + n - 1].tolist()
+
+
+def test_tq_luma8x8_golden_records(tq8):
+    """residual_transform_quant_luma_8x8 / _cavlc as the real encoder called them (4:2:2 High and 4:2:0 High, CABAC and CAVLC,
+    with and without adaptive rounding, the reference's q_offset.cfg offsets)."""
+    ctx = make_ctx(16, 16)
+    seen = set()
+    for r in tq8["rtq8x8"]:
+        variant, b8, intra, qp, qp_per, arw, ar_on, maxpel = (int(v) for v in r[:8])
+        pred, ores = r[200:264], r[264:328]
+        out = ctx.tq_luma8x8(ctx.tq8_params(r[8:200], qp_per, variant, ar_on, arw, maxpel), (pred + ores).astype(np.uint8), pred.astype(np.uint8))[0]
+        assert (int(out["nonzero"]), int(out["coeff_cost"])) == (int(r[328]), int(r[329]))
+        assert out["rec"].tolist() == r[330:394].tolist()
+        _lists_equal(out["level"].astype(np.int64), out["run"].astype(np.int64), r[394:462], r[462:530], variant == 1)
+        seen.add((variant, ar_on))
+    assert len(seen) >= 3
+    ctx.close()
+
+
+@pytest.mark.parametrize("qp,cavlc,around,seed", [(28, 0, 1, 1), (28, 1, 0, 2), (0, 0, 0, 3), (51, 1, 1, 4), (37, 0, 1, 5)])
+def test_tq_luma8x8_vs_oracle(J, qp, cavlc, around, seed):
+    rng = np.random.default_rng(seed)
+    n = 700
+    pred = rng.integers(0, 256, (n, 64)).astype(np.uint8)
+    amp = rng.choice([0, 1, 2, 6, 20, 80, 255], n)[:, None]
+    orig = np.clip(pred.astype(np.int64) + rng.integers(-1, 2, (n, 64)) * rng.integers(0, 256, (n, 64)) * amp // 255, 0, 255).astype(np.uint8)
+    orig[:5] = pred[:5]                                                # zero residual: check_zero path
+    q = np.zeros((64, 3), np.int32); J.L.jmo_qparams_8x8(qp, 0, 342, J._p(q))
+    ctx = make_ctx(16, 16)
+    out = ctx.tq_luma8x8(ctx.tq8_params(q, qp // 6, cavlc, around, 4), orig, pred)
+    for i in range(n):
+        nz, cost, rec, l, rn, fa, anyr = J.rtq_luma_8x8(orig[i], pred[i], q, qp // 6, cavlc, around, 4)
+        o = out[i]
+        assert (int(o["nonzero"]), int(o["coeff_cost"]), int(o["any_residual"])) == (nz, cost, anyr), i
+        assert o["rec"].tolist() == rec.tolist(), i
+        _lists_equal(o["level"].astype(np.int64), o["run"].astype(np.int64), l, rn, cavlc)
+        if around and (cavlc or anyr):
+            assert o["fadjust"].tolist() == fa.tolist(), i
+    ctx.close()
+
+
+def test_dc_transforms_and_dc_quant_golden_records(J, tq8):
+    ctx = make_ctx(16, 16)
+    for name, n in (("hadamard4x4", 16), ("ihadamard4x4", 16), ("hadamard4x2", 8), ("ihadamard4x2", 8), ("hadamard2x2", 4), ("ihadamard2x2", 4)):
+        recs = tq8[name]
+        got = ctx.dc_transform(name, recs[:, :n])
+        assert (got == recs[:, n:]).all(), name
+        x = np.random.default_rng(n).integers(-30000, 30000, (300, n)).astype(np.int32)      # and beyond what the clip produced: the oracle
+        assert (ctx.dc_transform(name, x) == np.stack([getattr(J, name)(v) for v in x])).all(), name
+    for r in tq8["quant_dc4x4"]:
+        qp, qp_per, cavlc = (int(v) for v in r[:3])
+        blk, out = ctx.quant_dc4x4(r[3:6], qp_per, cavlc, r[6:22])
+        assert blk[0].tolist() == r[22:38].tolist()
+        n = int(np.argmax(r[38:55] == 0)) + 1
+        assert out[0]["level"][:n].tolist() == r[38:38 + n].tolist() and out[0]["run"][:n - 1].tolist() == r[55:55 + n - 1].tolist()
+        assert int(out[0]["nonzero"]) == int(r[72])
+    ctx.close()
+
+
 # --------------------------------------------------------------------------- K9/K10 deblocking
 @pytest.mark.parametrize("name,frames,fmt", [("qcif_fs.npz", (0, 1), 1), ("qcif_422.npz", (0, 1), 2), ("qcif_main.npz", (0, 1, 2), 1)])
 def test_deblock_golden_frames(name, frames, fmt):

@@ -89,6 +89,86 @@ def test_quant4x4_normal_records(ffs):
     _check_quant(ffs["quant4x4_normal"], False)
 
 
+@pytest.fixture(scope="module")
+def tq8():
+    return np.load(os.path.join(G, "qcif_tq8.npz"))
+
+
+def _lists_equal(got_l, got_r, want_l, want_r, cavlc):
+    """JM writes each list up to and including its 0 terminator; entries behind it are stale."""
+    for k in range(4 if cavlc else 1):
+        o = 17 * k if cavlc else 0
+        n = int(np.argmax(want_l[o:o + (17 if cavlc else 65)] == 0)) + 1
+        assert got_l[o:o + n].tolist() == want_l[o:o + n].tolist()
+        assert got_r[o:o + n - 1].tolist() == want_r[o:o + n - 1].tolist()
+
+
+def test_transform8x8_and_dc_transform_records(tq8):
+    for rec in tq8["fwd8x8"]:
+        assert J.forward8x8(rec[:64]).tolist() == rec[64:].tolist()
+    for rec in tq8["inv8x8"]:
+        assert J.inverse8x8(rec[:64]).tolist() == rec[64:].tolist()
+    for name, fn, n in (("hadamard4x4", J.hadamard4x4, 16), ("ihadamard4x4", J.ihadamard4x4, 16), ("hadamard4x2", J.hadamard4x2, 8),
+                        ("ihadamard4x2", J.ihadamard4x2, 8), ("hadamard2x2", J.hadamard2x2, 4), ("ihadamard2x2", J.ihadamard2x2, 4)):
+        recs = tq8[name]
+        assert len(recs) >= 20, name
+        for rec in recs:
+            assert fn(rec[:n]).tolist() == rec[n:].tolist(), name
+
+
+def test_quant8x8_records(tq8):
+    """quant_8x8_normal / _around / quant_8x8cavlc_normal / _around as called by the real encoder."""
+    recs = tq8["quant8x8"]
+    seen = set()
+    for r in recs:
+        qp, qp_per, arw, variant = (int(v) for v in r[:4])
+        q = r[4:196].reshape(64, 3)
+        scan, ccost = r[196:324].reshape(64, 2), r[324:388]
+        tin, tout = r[388:452], r[452:516]
+        lev, run = r[516:584], r[584:652]
+        dcost, nz, fadj = int(r[652]), int(r[653]), r[654:718]
+        assert scan.tolist() == J.scan8x8(variant >= 2).tolist()            # the scan tables JM hands over are the restated ones
+        assert ccost.tolist() == J.coeff_cost8x8(0).tolist()
+        tb, l, rn, c, n, fa = J.quant_8x8(tin, q, qp_per, variant, arw)
+        assert tb.tolist() == tout.tolist()
+        _lists_equal(l, rn, lev, run, variant >= 2)
+        assert (c, n) == (dcost, nz)
+        if variant & 1:
+            assert fa.tolist() == fadj.tolist()
+        seen.add(variant)
+    assert seen == {0, 1, 2, 3}
+
+
+def test_quant_dc4x4_records(tq8):
+    recs = tq8["quant_dc4x4"]
+    assert len(recs) >= 20
+    for r in recs:
+        qp, qp_per, cavlc = (int(v) for v in r[:3])
+        tb, l, rn, nz = J.quant_dc4x4(r[6:22], r[3:6], qp_per, cavlc)
+        assert tb.tolist() == r[22:38].tolist()
+        n = int(np.argmax(r[38:55] == 0)) + 1
+        assert l[:n].tolist() == r[38:38 + n].tolist() and rn[:n - 1].tolist() == r[55:55 + n - 1].tolist()
+        assert nz == int(r[72])
+
+
+def test_residual_transform_quant_luma_8x8_records(tq8):
+    """residual_transform_quant_luma_8x8 and _cavlc end to end: prediction + residual in, reconstruction / levels / cost out."""
+    recs = tq8["rtq8x8"]
+    seen = set()
+    for r in recs:
+        variant, b8, intra, qp, qp_per, arw, ar_on, maxpel = (int(v) for v in r[:8])
+        q = r[8:200].reshape(64, 3)
+        pred, ores = r[200:264], r[264:328]
+        ret, dcost, rec = int(r[328]), int(r[329]), r[330:394]
+        lev, run = r[394:462], r[462:530]
+        nz, cost, grec, l, rn, fa, anyr = J.rtq_luma_8x8(pred + ores, pred, q, qp_per, variant, ar_on, arw, maxpel)
+        assert (nz, cost) == (ret, dcost)
+        assert grec.tolist() == rec.tolist()
+        _lists_equal(l, rn, lev, run, variant == 1)
+        seen.add((variant, ar_on))
+    assert len(seen) >= 3, seen
+
+
 def test_reconstruct_records(fs):
     for r in fs["recon4x4"]:
         maxv, dq = int(r[0]), int(r[1])
