@@ -199,13 +199,15 @@ __device__ __forceinline__ bool await_granules(const unsigned long long *g, bool
 
 // Step structure of a row (both kinds).  At the top of step x the LDS tile already holds macroblock x (own samples,
 // top rows, carried left columns) and s_prep its strength record; registers hold the own samples / record of x+1.
-//   1. issue loads: own samples / record of x+2
-//   2. vertical edges; hand the row below the now-final last columns of macroblock x-1's bottom rows; ask for the
-//      hand-over granules of the top neighbour of x+1
-//   3. horizontal edges; hand over the first columns of macroblock x's bottom rows
-//   4. image stores (each sample is stored by exactly one row: a row leaves its bottom rows to the row below, which
-//      filters them across its top edge); build the tile of x+1 (wait for the granules only if they are not there yet)
-// A row therefore trails the row above by about 1.5 steps plus one store->load hop, not by whole-macroblock flags.
+//   1. issue loads: the hand-over granules of the top neighbour of x, own samples / record of x+2
+//   2. vertical edges (they need no top rows); right after the first edge hand the row below the now-final last columns of
+//      macroblock x-1's bottom rows
+//   3. wait for the granules (normally there: the vertical edges hid the round trip) and put the top rows into the tile
+//   4. horizontal edges; hand over the first columns of macroblock x's bottom rows
+//   5. image stores (each sample is stored by exactly one row: a row leaves its bottom rows to the row below, which
+//      filters them across its top edge); the own rows of x+1 into the tile
+// The horizontal edges of macroblock x can start as soon as the row above is through the FIRST vertical edge of x+1: a row
+// trails the row above by well under one macroblock plus one store->load hop, not by whole-macroblock flags.
 
 // ---- luma row: tile rows -4..15 (index +4), columns -8..15 (byte index +8), pitch 24 bytes
 #define YP 24
@@ -227,22 +229,19 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
 
   uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1;
   unsigned long long gr = 0;
-  // ---- prologue: tile of macroblock 0, registers of macroblock 1
+  // ---- prologue: tile of macroblock 0 (own rows; the top rows arrive inside the step), registers of macroblock 1
   if (is_own) own1 = *(const uint4 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 32];
-  if (is_gran) gr = get_granule(hand_up);
   if (is_own) { uint32_t *d = tile + (lane + 4) * 6 + 2; d[0] = own1.x; d[1] = own1.y; d[2] = own1.z; d[3] = own1.w; }
   else if (is_pre) ((uint4 *)s_prep)[lane - 32] = pre1;
   if (mb_w > 1) { if (is_own) own1 = *(const uint4 *)(own_p + 16); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 32]; }
-  if (has_up) {
-    if (!await_granules(hand_up, is_gran, gr, err)) return;
-    if (is_gran) tile[((lane - 16) >> 2) * 6 + 2 + ((lane - 16) & 3)] = (uint32_t)gr;
-  }
 
   PROF_DECL
   for (int x = 0; x < mb_w; x++) {
     __syncthreads();
     PROF(0)
-    // ---- 1. loads for the next steps
+    // ---- 1. loads: the top neighbour's hand-over granules (needed only by the horizontal edges: the vertical edges hide the
+    //         round trip), own samples / record of x+2
+    if (is_gran) gr = get_granule(hand_up + (long)x * HAND_PER_MB);
     if (x + 2 < mb_w) { if (is_own) own2 = *(const uint4 *)(own_p + 16 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 32]; }
 
     const DbPrep *P = (const DbPrep *)s_prep;
@@ -251,6 +250,9 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
       uint32_t *t = tile + (lane + 4) * 6 + 1;
       const int seg = lane >> 2;
       const uint32_t bs = *(const uint32_t *)&P->bsY[0][seg][0];
+      // columns 12..15 of macroblock x-1 (tile columns -4..-1) are final after edge 0: its bottom rows go to the row below at once
+      unsigned long long *early = hand_me + (long)(x - 1) * HAND_PER_MB + (lane - 12) * 4 + 3;
+      const bool do_early = has_down && x > 0 && lane >= 12;
       if (bs) {
         const uint32_t c0 = *(const uint32_t *)&P->c0Y[0][seg][0];
         const uint32_t abE = *(const uint16_t *)&P->ab[0][0][0], abI = *(const uint16_t *)&P->ab[0][2][0];
@@ -260,19 +262,22 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
         for (int k = 0; k < 20; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
 #define VEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; const uint32_t ab = (E) ? abI : abE; \
                    if (__any(bS)) luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255, __any(bS == 4)); }
-        VEDGE(0) VEDGE(1) VEDGE(2) VEDGE(3)
+        VEDGE(0)
+        if (do_early) put_granule(early, pack4(p[0], p[1], p[2], p[3]));
+        VEDGE(1) VEDGE(2) VEDGE(3)
 #undef VEDGE
 #pragma unroll
         for (int k = 0; k < 5; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
-      }
-      // columns 12..15 of macroblock x-1 (tile columns -4..-1) are final now: hand its bottom rows to the row below
-      if (has_down && x > 0 && lane >= 12) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + (lane - 12) * 4 + 3, t[0]);
+      } else if (do_early) put_granule(early, t[0]);
+    }
+    PROF(1)
+    // ---- the top rows -4..-1 of macroblock x into the tile
+    if (has_up) {
+      if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) return;
+      if (is_gran) tile[((lane - 16) >> 2) * 6 + 2 + ((lane - 16) & 3)] = (uint32_t)gr;
     }
     __syncthreads();
-    PROF(1)
-    // the top neighbour of x+1: asked for as late as the horizontal edges can still hide the round trip, so that a row
-    // running close behind the row above finds the granules there at the first look
-    if (is_gran && x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB);
+    PROF(4)
     // ---- 3. horizontal edges: lane = sample column, rows -4..15 in registers
     if (lane < 16) {
       const int seg = lane >> 2;
@@ -299,7 +304,7 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
       const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
       if (c4 < 3 || x == mb_w - 1) put_granule(hand_me + (long)x * HAND_PER_MB + r * 4 + c4, tile[(16 + r) * 6 + 2 + c4]);
     }
-    // ---- 4. image stores of step x, then the tile of x+1
+    // ---- 4. image stores of step x, then the own rows of x+1 into the tile
     if (is_own) {
       uint32_t *t = tile + (lane + 4) * 6;
       uint8_t *g = (uint8_t *)own_p + 16 * x;
@@ -317,12 +322,7 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_
       st8(g, t[0], t[1]); st8(g + 8, t[2], t[3]);
     } else if (is_pre) ((uint4 *)s_prep)[lane - 32] = pre1;
     PROF(3)
-    if (has_up && x + 1 < mb_w) {
-      if (!await_granules(hand_up + (long)(x + 1) * HAND_PER_MB, is_gran, gr, err)) return;
-      if (is_gran) tile[((lane - 16) >> 2) * 6 + 2 + ((lane - 16) & 3)] = (uint32_t)gr;
-    }
     own1 = own2; pre1 = pre2;
-    PROF(4)
   }
   PROF_OUT(0)
 }
@@ -357,17 +357,13 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
   uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1;
   unsigned long long gr = 0;
   if (is_own) own1 = *(const uint2 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 40];
-  if (is_gran) gr = get_granule(hand_up);
   if (is_own) { uint32_t *d = (uint32_t *)(own_t + 8); d[0] = own1.x; d[1] = own1.y; }
   else if (is_pre) ((uint4 *)s_prep)[lane - 40] = pre1;
   if (mb_w > 1) { if (is_own) own1 = *(const uint2 *)(own_p + 8); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 40]; }
-  if (has_up) {
-    if (!await_granules(hand_up, is_gran, gr, err)) return;
-    if (is_gran) *gran_t = (uint32_t)gr;
-  }
 
   for (int x = 0; x < mb_w; x++) {
     __syncthreads();
+    if (is_gran) gr = get_granule(hand_up + (long)x * HAND_PER_MB);
     if (x + 2 < mb_w) { if (is_own) own2 = *(const uint2 *)(own_p + 8 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 40]; }
 
     const DbPrep *P = (const DbPrep *)s_prep;
@@ -376,6 +372,9 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
       const int seg = RH == 8 ? (rr >> 1) : (rr >> 2);
       const uint32_t bs = *(const uint32_t *)&P->bsC[0][seg][0] & 0x00ff00ffu;        // luma edges 0 and 2
       uint32_t *t = (uint32_t *)(own_t + 4);
+      // columns 4..7 of macroblock x-1 (tile columns -4..-1) are final after the first edge: hand its last two rows to the row below
+      unsigned long long *early = hand_me + (long)(x - 1) * HAND_PER_MB + uvr * 4 + (rr - (RH - 2)) * 2 + 1;
+      const bool do_early = has_down && x > 0 && rr >= RH - 2;
       if (bs) {
         const uint32_t c0 = *(const uint32_t *)&P->c0C[uvr][0][seg][0];
         const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvr][0][0], abI = *(const uint16_t *)&P->ab[1 + uvr][2][0];
@@ -384,15 +383,17 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
 #pragma unroll
         for (int k = 0; k < 12; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
         chroma_edge4(p[2], p[3], p[4], p[5], bs & 255, abE & 255, abE >> 8, c0 & 255);
+        if (do_early) put_granule(early, pack4(p[0], p[1], p[2], p[3]));
         chroma_edge4(p[6], p[7], p[8], p[9], (bs >> 16) & 255, abI & 255, abI >> 8, (c0 >> 16) & 255);
 #pragma unroll
         for (int k = 0; k < 3; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
-      }
-      // columns 4..7 of macroblock x-1 (tile columns -4..-1) are final: hand its last two rows to the row below
-      if (has_down && x > 0 && rr >= RH - 2) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + uvr * 4 + (rr - (RH - 2)) * 2 + 1, t[0]);
+      } else if (do_early) put_granule(early, t[0]);
+    }
+    if (has_up) {
+      if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) return;
+      if (is_gran) *gran_t = (uint32_t)gr;
     }
     __syncthreads();
-    if (is_gran && x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB);
     // ---- horizontal edges: lane = (plane, column), rows -2..RH-1
     if (lane < 16) {
       const int seg = cc >> 1;
@@ -435,10 +436,6 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 plane
       const uint32_t *t = (const uint32_t *)(top_t + 8);
       st8(top_p + 8 * x, t[0], t[1]);
     } else if (is_pre) ((uint4 *)s_prep)[lane - 40] = pre1;
-    if (has_up && x + 1 < mb_w) {
-      if (!await_granules(hand_up + (long)(x + 1) * HAND_PER_MB, is_gran, gr, err)) return;
-      if (is_gran) *gran_t = (uint32_t)gr;
-    }
     own1 = own2; pre1 = pre2;
   }
 }
