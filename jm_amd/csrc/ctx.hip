@@ -110,6 +110,8 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
     CK(hipMemcpy(c->d_spiral, sp, (size_t)n * 4, hipMemcpyHostToDevice));
     free(sp);
   }
+  CK(hipMalloc((void **)&c->d_me_declined, 64));
+  CK(hipMemsetAsync(c->d_me_declined, 0, 64, c->stream));
   CK(hipMalloc(&c->d_db_prep, (size_t)(c->W / 16) * (c->H / 16) * 192));
   CK(hipMalloc((void **)&c->d_db_sync, 64 + (size_t)(c->H / 16) * 2 * 6 * 8));
   CK(hipMalloc(&c->d_db_hand, (size_t)(c->W / 16) * (c->H / 16) * 192));
@@ -132,6 +134,7 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   if (c->d_scratch2) (void)hipFree(c->d_scratch2);
   if (c->d_spiral) (void)hipFree(c->d_spiral);
   if (c->d_db_prep) (void)hipFree(c->d_db_prep);
+  if (c->d_me_declined) (void)hipFree(c->d_me_declined);
   if (c->d_db_sync) (void)hipFree(c->d_db_sync);
   if (c->d_db_hand) (void)hipFree(c->d_db_hand);
   for (int k = 0; k < JMHIP_NKINDS; k++) { if (c->ev0[k]) (void)hipEventDestroy(c->ev0[k]); if (c->ev1[k]) (void)hipEventDestroy(c->ev1[k]); }

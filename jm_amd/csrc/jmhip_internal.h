@@ -25,6 +25,8 @@ struct jmhip_ctx {
   void *d_scratch; size_t scratch_bytes;     // grows on demand: jobs/results/tables for host entry points
   void *d_scratch2; size_t scratch2_bytes;
   int16_t *d_spiral;     // [(2R+1)^2][2] spiral offsets for R = cfg.search_range
+  unsigned *d_me_declined; // [2] jobs k_me_fs_fast left to k_me_fullsearch, ping-pong by launch parity
+  unsigned me_launches;
   void *d_db_prep;       // deblocking: 192-byte strength/parameter record per macroblock (k_deblock_prep)
   unsigned *d_db_sync;   // deblocking row pipeline: ticket, error
   void *d_db_hand;       // deblocking row pipeline: 24 8-byte hand-over granules per macroblock

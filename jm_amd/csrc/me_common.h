@@ -91,4 +91,4 @@ __device__ __forceinline__ bool job_is_fast(const jmhip_me_job *__restrict__ job
   return true;
 }
 
-void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results);
+void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined);

@@ -120,13 +120,16 @@ __device__ __forceinline__ double key_as_double(unsigned cost, unsigned idx)
 __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
-                                                       const int16_t *__restrict__ spiral)
+                                                       const int16_t *__restrict__ spiral, unsigned *__restrict__ declined)
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[COPY_DWORDS > MERGE_DWORDS ? COPY_DWORDS : MERGE_DWORDS];   // window copies, later the wave-merge area
   __shared__ __attribute__((aligned(16))) uint32_t s_ry[65 * RYP];            // (lambda * mvbits(cand_y - pred_y[p])) << 7, [row][partition]
   __shared__ uint32_t s_rx64[RYP];                                              // x rate of column 64, per partition
   const jmhip_me_job *__restrict__ job = jobs + blockIdx.x;
-  if (!job_is_fast(job)) return;
+  if (!job_is_fast(job)) {                                  // left to k_me_fullsearch, which only does real work when this counter is non-zero
+    if (threadIdx.x == 0) atomicAdd(declined, 1u);
+    return;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = job->search_range, n1 = 2 * R + 1, wrows = 2 * R + 16;
@@ -245,12 +248,10 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
       acc[p] = k < acc[p] ? k : acc[p];
     }
   }
-  // add the x rate (constant per lane); lanes outside the window drop out
+  // The x rate is constant per (lane, partition): it commutes with the minimum over rows, so it is added once, after the
+  // four waves' minima have been merged (below), by the wave that owns the partition -- not by every wave.
 #pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const unsigned rx = (unsigned)(lambda * mvbits(cx + 4 * dx - job->pred[p][0])) << 7;
-    acc[p] = (col_ok && acc[p] != 0xffffffffu) ? acc[p] + rx : 0xffffffffu;
-  }
+  for (int p = 0; p < NP; p++) acc[p] = col_ok ? acc[p] : 0xffffffffu;
 
   // ---- 65th column (R = 32): its 65 positions are spread over waves 1..3 (generic per-position code on
   //      copy 0, the plain window); keys use the same (cost << 7 | rank) form with a = 32.
@@ -280,41 +281,57 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
     for (int p = 0; p < NP; p++) s_ext[p * 66 + exq] = ex[p];
   }
   __syncthreads();
-  // ---- final: wave w reduces partitions p = w, w+4, ...: lanes merge the 4 waves (same column, comparable keys),
-  //      decode (cost, spiral index) into an order-preserving double and min-reduce across the wave
+  // ---- final: wave w reduces partitions p = w, w+4, ...  Lanes merge the 4 waves (same column: keys comparable) and add the
+  //      column's x rate.  Across columns only the cost part of a key is comparable; ties between columns are decided by JM's
+  //      spiral index.  Ties are rare, so: wave-min of the 32-bit cost; if exactly one candidate attains it, that lane decodes
+  //      its position and stores -- otherwise (cost, spiral index) keys as order-preserving doubles are min-reduced.
   {
     const uint64_t mask = job->part_mask;
     const int dxe = 64 - R;
 #pragma unroll 1
     for (int p = wave; p < NP; p += 4) {
       const unsigned k = umin3(s_mem[(0 * NP + p) * 64 + lane], s_mem[(1 * NP + p) * 64 + lane], s_mem[(2 * NP + p) * 64 + lane]);
-      const unsigned kk = min(k, s_mem[(3 * NP + p) * 64 + lane]);
-      double key = __longlong_as_double(0x7fe0000000000000LL);          // larger than any real key
-      if (kk != 0xffffffffu) key = key_as_double(kk >> 7, (unsigned)spiral_index(dx, rank_to_dy(kk & 127u, a)));
-      if (n1 > 64) {
-        const unsigned e = s_ext[p * 66 + lane];
-        if (e != 0xffffffffu) key = fmin(key, key_as_double(e >> 7, (unsigned)spiral_index(dxe, rank_to_dy(e & 127u, dxe))));
-        if (lane == 0) {
-          const unsigned e2 = s_ext[p * 66 + 64];
-          key = fmin(key, key_as_double(e2 >> 7, (unsigned)spiral_index(dxe, rank_to_dy(e2 & 127u, dxe))));
-        }
-      }
+      unsigned kk = min(k, s_mem[(3 * NP + p) * 64 + lane]);
+      if (kk != 0xffffffffu) kk += (unsigned)(lambda * mvbits(cx + 4 * dx - job->pred[p][0])) << 7;
+      unsigned e = 0xffffffffu, e2 = 0xffffffffu;
+      if (n1 > 64) { e = s_ext[p * 66 + lane]; if (lane == 0) e2 = s_ext[p * 66 + 64]; }
+      const unsigned c = kk >> 7, ce = e >> 7, ce2 = e2 >> 7;             // 0x1ffffff for "no candidate"
+      unsigned m = umin3(c, ce, ce2);
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) key = fmin(key, __shfl_xor(key, off, 64));
-      if (lane == 0 && ((mask >> p) & 1)) {
+      for (int off = 32; off >= 1; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+      const unsigned long long bc = __ballot(c == m), be = __ballot(ce == m), be2 = __ballot(ce2 == m);
+      unsigned idx, cost = m;
+      bool writer;
+      if (__popcll(bc) + __popcll(be) + __popcll(be2) == 1) {              // wave-uniform: a unique minimum
+        const bool mine = (c == m) | (ce == m) | (ce2 == m);
+        const unsigned key = c == m ? kk : (ce == m ? e : e2);
+        const int ddx = c == m ? dx : dxe, aa = c == m ? a : dxe;
+        idx = (unsigned)spiral_index(ddx, rank_to_dy(key & 127u, aa));
+        writer = mine;
+      } else {
+        double key = __longlong_as_double(0x7fe0000000000000LL);          // larger than any real key
+        if (kk != 0xffffffffu) key = key_as_double(kk >> 7, (unsigned)spiral_index(dx, rank_to_dy(kk & 127u, a)));
+        if (e != 0xffffffffu) key = fmin(key, key_as_double(e >> 7, (unsigned)spiral_index(dxe, rank_to_dy(e & 127u, dxe))));
+        if (e2 != 0xffffffffu) key = fmin(key, key_as_double(e2 >> 7, (unsigned)spiral_index(dxe, rank_to_dy(e2 & 127u, dxe))));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) key = fmin(key, __shfl_xor(key, off, 64));
         const unsigned long long kb = (unsigned long long)__double_as_longlong(key);
+        idx = (unsigned)(kb & 0xffffffffu);
+        cost = (unsigned)((kb >> 32) & 0x3fffffffu);
+        writer = lane == 0;
+      }
+      if (writer && ((mask >> p) & 1)) {
         jmhip_me_best b;
-        const unsigned idx = (unsigned)(kb & 0xffffffffu);
         b.mv_x = (int16_t)(cx + 4 * spiral[2 * idx]); b.mv_y = (int16_t)(cy + 4 * spiral[2 * idx + 1]);
-        b.cost = (int32_t)((kb >> 32) & 0x3fffffffu);
+        b.cost = (int32_t)cost;
         results[blockIdx.x].best[p] = b;
       }
     }
   }
 }
 
-void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results)
+void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined)
 {
   hipLaunchKernelGGL(k_me_fs_fast, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_results, ctx->d_cur, ctx->cur_pitch,
-                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral);
+                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, d_declined);
 }

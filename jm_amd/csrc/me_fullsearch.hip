@@ -57,11 +57,15 @@ __device__ __forceinline__ void stage_job(const jmhip_me_job *__restrict__ job, 
 __global__ __launch_bounds__(256) void k_me_fullsearch(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
-                                                       const int16_t *__restrict__ spiral, int skip_fast)
+                                                       const int16_t *__restrict__ spiral, int skip_fast,
+                                                       const unsigned *__restrict__ declined, unsigned *__restrict__ declined_next)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const jmhip_me_job *job = jobs + blockIdx.x;
-  if (skip_fast && job_is_fast(job)) return;               // owned by k_me_fs_fast (me_fast.hip)
+  if (skip_fast) {                                         // k_me_fs_fast ran before this launch and counted the jobs it left for us
+    if (blockIdx.x == 0 && threadIdx.x == 0) *declined_next = 0;          // the counter of the NEXT launch pair (ping-pong)
+    if (*declined == 0 || job_is_fast(job)) return;
+  }
   const int R = job->search_range;
   const int wpitch = (2 * R + 16 + 4 + 3) & ~3;
   uint8_t *s_win = smem;                                                   // (2R+16) x wpitch
@@ -188,9 +192,12 @@ extern "C" int jmhip_me_fullsearch_dev(jmhip_ctx *ctx, int32_t slot, const jmhip
   if (njobs == 0) return JMHIP_OK;
   const int use_fast = !ctx->force_generic;
   jmhip_time_begin(ctx, 1);
-  if (use_fast) jmhip_launch_me_fast(ctx, slot, d_jobs, njobs, d_results);
+  unsigned *dec = ctx->d_me_declined + (ctx->me_launches & 1), *dec_next = ctx->d_me_declined + ((ctx->me_launches + 1) & 1);
+  ctx->me_launches++;
+  if (use_fast) jmhip_launch_me_fast(ctx, slot, d_jobs, njobs, d_results, dec);
   hipLaunchKernelGGL(k_me_fullsearch, dim3(njobs), dim3(256), me_lds_bytes(ctx->cfg.search_range), ctx->stream,
-                     d_jobs, d_results, ctx->d_cur, ctx->cur_pitch, ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, use_fast);
+                     d_jobs, d_results, ctx->d_cur, ctx->cur_pitch, ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, use_fast,
+                     dec, dec_next);
   jmhip_time_end(ctx, 1);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
