@@ -25,7 +25,7 @@
 // ~1.5 VALU ops per (position, partition) instead of ~12 in the generic kernel.
 //
 // The last window row (2R+1 is odd) is a single-row step; for R = 32 the 65th column is evaluated by
-// one wave with the generic per-position code.  Per-lane minima are merged across the 4 waves
+// one wave with the generic per-position code.  Per-lane minima are merged across the waves
 // (same lane == same column, keys comparable), decoded to (cost, spiral index) and min-reduced.
 // All 41 partitions are always evaluated (no branches in the hot loop); part_mask selects what is stored.
 //
@@ -41,7 +41,10 @@
 #define NCOPY 8
 #define RYP 44                              // row pitch (dwords) of the y-rate table: 41 partitions padded to 11 x uint4
 #define COPY_DWORDS (NCOPY * CSTRIDE)
-#define MERGE_DWORDS (4 * NP * 64 + NP * 66)
+#define NW 8                                 // waves per job: 2 jobs per CU (LDS) x 8 waves = 4 waves per SIMD (<= 128 VGPRs)
+#define NT (NW * 64)
+#define NWH (NW / 2)                         // the waves' minima are merged in two rounds so the merge area fits into the copy area
+#define MERGE_DWORDS (NWH * NP * 64 + NP * 66)
 
 __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
 {
@@ -117,7 +120,7 @@ __device__ __forceinline__ double key_as_double(unsigned cost, unsigned idx)
   return __hiloint2double((int)(cost | 0x40000000u), (int)idx);
 }
 
-__global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
+__global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
                                                        const int16_t *__restrict__ spiral, unsigned *__restrict__ declined)
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
     const int x0 = job->mb_x + (cx >> 2) - R, y0 = job->mb_y + (cy >> 2) - R;
     const uint8_t *plane = ref00 + ((cy & 3) * 4 + (cx & 3)) * plane_stride;
     const bool inside = x0 >= -JMHIP_PAD_X && x0 + CPITCH * 4 + 8 <= W + JMHIP_PAD_X;      // no horizontal clamp needed
-    for (int k = tid; k < wrows * (CPITCH + 2); k += 256) {
+    for (int k = tid; k < wrows * (CPITCH + 2); k += NT) {
       const int r = k / (CPITCH + 2), c = k - r * (CPITCH + 2);                            // 22 dwords per row: bytes 0..87
       const int yy = min(max(y0 + r, -JMHIP_PAD_Y), H + JMHIP_PAD_Y - 1) + JMHIP_PAD_Y;
       const uint8_t *prow = plane + (long)yy * pitch + JMHIP_PAD_X;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
     }
     if (tid < NP) s_rx64[tid] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - job->pred[tid][0])) << 7;
     // y-rate table
-    for (int k = tid; k < n1 * NP; k += 256) {
+    for (int k = tid; k < n1 * NP; k += NT) {
       const int wy = k / NP, p = k - wy * NP;
       s_ry[wy * RYP + p] = (uint32_t)(lambda * mvbits(cy + 4 * (wy - R) - job->pred[p][1])) << 7;
     }
@@ -175,11 +178,12 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
   __syncthreads();
   // ---- stage 2: eight byte-shifted copies: copy s, row r, dword k = window bytes 4k+s .. 4k+s+3
   {
-    uint32_t d[7][3];                                     // this thread's items, read before anything is overwritten
+    constexpr int NIT = (WROWS_MAX * CPITCH + NT - 1) / NT;
+    uint32_t d[NIT][3];                                     // this thread's items, read before anything is overwritten
     const int total = wrows * CPITCH;
 #pragma unroll
-    for (int it = 0; it < 7; it++) {
-      const int k = tid + 256 * it;
+    for (int it = 0; it < NIT; it++) {
+      const int k = tid + NT * it;
       if (k < total) {
         const int r = k / CPITCH, c = k - r * CPITCH;
         const uint32_t *raw = s_mem + (NCOPY - 2) * CSTRIDE + r * (CPITCH + 2) + c;
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 7; it++) {
-      const int k = tid + 256 * it;
+    for (int it = 0; it < NIT; it++) {
+      const int k = tid + NT * it;
       if (k < total) {
         const uint32_t d0 = d[it][0], d1 = d[it][1], d2 = d[it][2];
         s_mem[0 * CSTRIDE + k] = d0;
@@ -214,10 +218,9 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
   for (int p = 0; p < NP; p++) acc[p] = 0xffffffffu;
 
   const int npairs = R;                                  // rows 0 .. 2R-1
-  const int per_wave = (npairs + 3) >> 2;
-  const int j0 = wave * per_wave, j1 = min(npairs, j0 + per_wave);
+  // pairs go round the waves; the two odd jobs (the last window row, the 65th column) go to the waves with the fewest pairs
 #pragma unroll 1
-  for (int j = j0; j < j1; j++) {
+  for (int j = wave; j < npairs; j += NW) {
     const int wy = 2 * j, dyA = wy - R;
     unsigned sa[16], sb[16], pa[NP], pb[NP];
     sad_pair<true>(cp, wy, cw, sa, sb);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
       }
     }
   }
-  if (wave == 0) {                                       // last row (2R): single-row step
+  if (wave == NW - 4) {                                  // last row (2R): single-row step
     const int wy = 2 * R;
     unsigned sa[16], sb[16], pa[NP];
     sad_pair<false>(cp, wy, cw, sa, sb);
@@ -256,9 +259,9 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
   // ---- 65th column (R = 32): its 65 positions are spread over waves 1..3 (generic per-position code on
   //      copy 0, the plain window); keys use the same (cost << 7 | rank) form with a = 32.
   unsigned ex[NP];
-  const int exq = (wave - 1) + 3 * lane;                 // position (row) index of this lane in column 64
-  const bool ex_live = n1 > 64 && wave >= 1 && exq < n1;
-  if (n1 > 64 && wave >= 1) {
+  const int exq = (wave - (NW - 3)) + 3 * lane;          // position (row) index of this lane in column 64: the last three waves
+  const bool ex_live = n1 > 64 && wave >= NW - 3 && exq < n1;
+  if (n1 > 64 && wave >= NW - 3) {
 #pragma unroll
     for (int p = 0; p < NP; p++) ex[p] = 0xffffffffu;
     if (ex_live) {                                       // wx = 64 is 8-byte aligned in copy 0: same aligned-read SAD code
@@ -272,16 +275,29 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
     }
   }
   __syncthreads();                                       // every wave is done reading the window copies
-  // ---- publish per-lane minima: s_mem[(w*NP + p)*64 + lane], extras behind them
-  uint32_t *s_ext = s_mem + 4 * NP * 64;                 // [NP][66]
+  // ---- publish per-lane minima in two rounds (upper half of the waves, then the lower half merged with them):
+  //      s_mem[(w*NP + p)*64 + lane], w < NW/2; the 65th column's keys behind them
+  uint32_t *s_ext = s_mem + NWH * NP * 64;               // [NP][66]
+  if (wave >= NWH) {
 #pragma unroll
-  for (int p = 0; p < NP; p++) s_mem[(wave * NP + p) * 64 + lane] = acc[p];
+    for (int p = 0; p < NP; p++) s_mem[((wave - NWH) * NP + p) * 64 + lane] = acc[p];
+  }
   if (ex_live) {
 #pragma unroll
     for (int p = 0; p < NP; p++) s_ext[p * 66 + exq] = ex[p];
   }
   __syncthreads();
-  // ---- final: wave w reduces partitions p = w, w+4, ...  Lanes merge the 4 waves (same column: keys comparable) and add the
+  if (wave < NWH) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) acc[p] = min(acc[p], s_mem[(wave * NP + p) * 64 + lane]);
+  }
+  __syncthreads();
+  if (wave < NWH) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) s_mem[(wave * NP + p) * 64 + lane] = acc[p];
+  }
+  __syncthreads();
+  // ---- final: wave w reduces partitions p = w, w+NW, ...  Lanes merge the waves (same column: keys comparable) and add the
   //      column's x rate.  Across columns only the cost part of a key is comparable; ties between columns are decided by JM's
   //      spiral index.  Ties are rare, so: wave-min of the 32-bit cost; if exactly one candidate attains it, that lane decodes
   //      its position and stores -- otherwise (cost, spiral index) keys as order-preserving doubles are min-reduced.
@@ -289,9 +305,10 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
     const uint64_t mask = job->part_mask;
     const int dxe = 64 - R;
 #pragma unroll 1
-    for (int p = wave; p < NP; p += 4) {
-      const unsigned k = umin3(s_mem[(0 * NP + p) * 64 + lane], s_mem[(1 * NP + p) * 64 + lane], s_mem[(2 * NP + p) * 64 + lane]);
-      unsigned kk = min(k, s_mem[(3 * NP + p) * 64 + lane]);
+    for (int p = wave; p < NP; p += NW) {
+      unsigned kk = s_mem[p * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NWH; w++) kk = min(kk, s_mem[(w * NP + p) * 64 + lane]);
       if (kk != 0xffffffffu) kk += (unsigned)(lambda * mvbits(cx + 4 * dx - job->pred[p][0])) << 7;
       unsigned e = 0xffffffffu, e2 = 0xffffffffu;
       if (n1 > 64) { e = s_ext[p * 66 + lane]; if (lane == 0) e2 = s_ext[p * 66 + 64]; }
@@ -332,6 +349,6 @@ __global__ __launch_bounds__(256, 2) void k_me_fs_fast(const jmhip_me_job *__res
 
 void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined)
 {
-  hipLaunchKernelGGL(k_me_fs_fast, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_results, ctx->d_cur, ctx->cur_pitch,
+  hipLaunchKernelGGL(k_me_fs_fast, dim3(njobs), dim3(NT), 0, ctx->stream, d_jobs, d_results, ctx->d_cur, ctx->cur_pitch,
                      ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, d_declined);
 }

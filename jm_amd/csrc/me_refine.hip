@@ -116,6 +116,8 @@ __device__ __forceinline__ int part_of(int t, int bx4, int by4)
 #define NITEMS (7 * 16 * 9)
 #define COST_MAX 0x7fffffff
 
+// T8MODE: prm.transform8x8_mode != 0 (the Hadamard 8x8 path costs ~64 VGPRs; without it the kernel runs at full occupancy)
+template <bool T8MODE>
 __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
                                                       jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
                                                       PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch)
@@ -140,32 +142,44 @@ __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__rest
     const int lambda = stage == 0 ? prm.lambda_h : prm.lambda_q, metric = stage == 0 ? prm.metric_h : prm.metric_q;
     for (int k = tid; k < JMHIP_NPART * 9; k += 256) s_dist[k] = 0;
     __syncthreads();
-#pragma unroll 1
-    for (int item = tid; item < NITEMS; item += 256) {
-      const int t = item / 144, rem = item - t * 144, cand = rem >> 4, b4 = rem & 15;
-      const int bx4 = b4 & 3, by4 = b4 >> 2, p = part_of(t, bx4, by4);
-      if (!((mask >> p) & 1) || cand < start) continue;
-      const int cx = s_mv[p][0] + c_sp9b[cand][0] * step, cy = s_mv[p][1] + c_sp9b[cand][1] * step;
-      const int t8 = prm.transform8x8_mode && p <= 8 && metric != JMHIP_METRIC_SAD;           // mv_search.c:1630 / :1770
-      int d;
-      if (metric == JMHIP_METRIC_SAD) {
-        // the whole block hangs off ONE clamped origin (computeSAD): offset of this 4x4 inside its partition
-        const int px = mb_x + c_geom[p][0], py = mb_y + c_geom[p][1];
-        const uint8_t *r = umv_line2(ps, (py << 2) + cy, (px << 2) + cx) + (long)(4 * by4 - c_geom[p][1]) * ps.pitch + (4 * bx4 - c_geom[p][0]);
-        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
-        const uint32_t rr[4] = {ld4(r), ld4(r + ps.pitch), ld4(r + 2L * ps.pitch), ld4(r + 3L * ps.pitch)};
-        d = sad4_rows(c, rr);
-      } else if (!t8) {
-        const uint8_t *r = umv_line2(ps, ((mb_y + 4 * by4) << 2) + cy, ((mb_x + 4 * bx4) << 2) + cx);
-        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
-        const uint32_t rr[4] = {ld4(r), ld4(r + ps.pitch), ld4(r + 2L * ps.pitch), ld4(r + 3L * ps.pitch)};
-        d = hadamard4_rows(c, rr);
-      } else {
-        if ((bx4 | by4) & 1) continue;                                           // the top-left 4x4 leads its 8x8 block
-        const uint8_t *r = umv_line2(ps, ((mb_y + 4 * by4) << 2) + cy, ((mb_x + 4 * bx4) << 2) + cx);
-        d = hadamard8_lds(s_cur, 4 * by4, bx4, r, ps.pitch);
+    // Two passes over this lane's four items: first every item's reference rows are requested (the planes are far larger than
+    // L2, a load is a trip to the Infinity Cache / HBM), then the distortions are computed -- one memory latency per stage
+    // instead of one per item.
+    uint32_t rr[4][4];
+    int meta[4];                                             // p * 16 + cand, or -1: nothing to do; bit 30: 8x8 leader (loads itself)
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int item = tid + 256 * it;
+      meta[it] = -1;
+      if (item < NITEMS) {
+        const int t = item / 144, rem = item - t * 144, cand = rem >> 4, b4 = rem & 15;
+        const int bx4 = b4 & 3, by4 = b4 >> 2, p = part_of(t, bx4, by4);
+        if (((mask >> p) & 1) && cand >= start) {
+          const int cx = s_mv[p][0] + c_sp9b[cand][0] * step, cy = s_mv[p][1] + c_sp9b[cand][1] * step;
+          const bool t8 = T8MODE && p <= 8 && metric != JMHIP_METRIC_SAD;                          // mv_search.c:1630 / :1770
+          const uint8_t *r;
+          if (metric == JMHIP_METRIC_SAD) {
+            // the whole block hangs off ONE clamped origin (computeSAD): offset of this 4x4 inside its partition
+            const int px = mb_x + c_geom[p][0], py = mb_y + c_geom[p][1];
+            r = umv_line2(ps, (py << 2) + cy, (px << 2) + cx) + (long)(4 * by4 - c_geom[p][1]) * ps.pitch + (4 * bx4 - c_geom[p][0]);
+          } else r = umv_line2(ps, ((mb_y + 4 * by4) << 2) + cy, ((mb_x + 4 * bx4) << 2) + cx);
+          if (!t8) {
+            meta[it] = p * 16 + cand;
+            rr[it][0] = ld4(r); rr[it][1] = ld4(r + ps.pitch); rr[it][2] = ld4(r + 2L * ps.pitch); rr[it][3] = ld4(r + 3L * ps.pitch);
+          } else if (T8MODE && !((bx4 | by4) & 1)) {         // the top-left 4x4 leads its 8x8 block (loads in place)
+            atomicAdd(&s_dist[p * 9 + cand], (unsigned)hadamard8_lds(s_cur, 4 * by4, bx4, r, ps.pitch));
+          }
+        }
       }
-      atomicAdd(&s_dist[p * 9 + cand], (unsigned)d);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      if (meta[it] >= 0) {
+        const int item = tid + 256 * it, b4 = item & 15, bx4 = b4 & 3, by4 = b4 >> 2;          // 144 = 9 * 16: b4 = item mod 16
+        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
+        const int d = metric == JMHIP_METRIC_SAD ? sad4_rows(c, rr[it]) : hadamard4_rows(c, rr[it]);
+        atomicAdd(&s_dist[(meta[it] >> 4) * 9 + (meta[it] & 15)], (unsigned)d);
+      }
     }
     __syncthreads();
     if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
@@ -199,5 +213,8 @@ void jmhip_launch_refine_mb(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs
                             const jmhip_refine_params *prm, jmhip_me_result *d_out)
 {
   PlaneSet2 ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H;
-  hipLaunchKernelGGL(k_me_refine_mb, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch);
+  if (prm->transform8x8_mode)
+    hipLaunchKernelGGL(k_me_refine_mb<true>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch);
+  else
+    hipLaunchKernelGGL(k_me_refine_mb<false>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch);
 }
