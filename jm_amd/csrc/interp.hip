@@ -56,19 +56,23 @@ __global__ __launch_bounds__(256) void k_subplanes(const uint8_t *__restrict__ s
   }
   __syncthreads();
 
-  const int tx = tid & 63, ty0 = tid >> 6;
-  const int x = x0 + tx;
-  if (x >= Wp) return;
-  for (int r = ty0; r < TH; r += 4) {
-    const int y = y0 + r;
-    if (y >= Hp) break;
-    const int p00 = s_src[r + 2][tx + 2], p00r = s_src[r + 2][tx + 3], p00d = s_src[r + 3][tx + 2];
-    const int p02 = clip255((s_h[r + 2][tx] + 16) >> 5), p02d = clip255((s_h[r + 3][tx] + 16) >> 5);
-    const int p20 = s_v[r][tx], p20r = s_v[r][tx + 1];
-    const int vv = tap6(s_h[r][tx], s_h[r + 1][tx], s_h[r + 2][tx], s_h[r + 3][tx], s_h[r + 4][tx], s_h[r + 5][tx]);
+  // each thread produces four horizontally adjacent samples of one row and stores them as one dword per plane: a wave
+  // writes 4 rows x 64 contiguous bytes per plane (the store path is what bounds this kernel)
+  const int tx = (tid & 15) * 4, r = tid >> 4;
+  const int x = x0 + tx, y = y0 + r;
+  if (x >= Wp || y >= Hp) return;
+  uint32_t o[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) o[k] = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int c = tx + q;
+    const int p00 = s_src[r + 2][c + 2], p00r = s_src[r + 2][c + 3], p00d = s_src[r + 3][c + 2];
+    const int p02 = clip255((s_h[r + 2][c] + 16) >> 5), p02d = clip255((s_h[r + 3][c] + 16) >> 5);
+    const int p20 = s_v[r][c], p20r = s_v[r][c + 1];
+    const int vv = tap6(s_h[r][c], s_h[r + 1][c], s_h[r + 2][c], s_h[r + 3][c], s_h[r + 4][c], s_h[r + 5][c]);
     const int p22 = clip255((vv + 512) >> 10);
-    uint8_t *o = dst + (long)y * pitch + x;
-#define ST(j, i, val) o[((j) * 4 + (i)) * plane_stride] = (uint8_t)(val)
+#define ST(j, i, val) o[(j) * 4 + (i)] |= (uint32_t)(val) << (8 * q)
 #define AV(a, b) (((a) + (b) + 1) >> 1)
     ST(0, 0, p00);            ST(0, 1, AV(p00, p02));   ST(0, 2, p02);            ST(0, 3, AV(p02, p00r));
     ST(1, 0, AV(p00, p20));   ST(1, 1, AV(p02, p20));   ST(1, 2, AV(p02, p22));   ST(1, 3, AV(p02, p20r));
@@ -77,6 +81,9 @@ __global__ __launch_bounds__(256) void k_subplanes(const uint8_t *__restrict__ s
 #undef ST
 #undef AV
   }
+  uint8_t *op = dst + (long)y * pitch + x;
+#pragma unroll
+  for (int k = 0; k < 16; k++) *(uint32_t *)(op + k * plane_stride) = o[k];
 }
 
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes)

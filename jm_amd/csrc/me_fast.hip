@@ -9,7 +9,8 @@
 //   v_min3_u32      1 op folds TWO candidate keys into the running minimum
 //   64-bit integer compare+select is 4.5x slower, v_alignbyte costs as much as the SAD it feeds.
 //
-// Mapping.  lane <-> window column (dx); a wave walks window rows two at a time:
+// Mapping.  lane <-> window column (dx); a wave walks window rows two at a time; eight waves share one job (two jobs fit a CU's
+// LDS, so 4 waves per SIMD at <= 128 VGPRs):
 //   * the search window is staged in LDS as EIGHT byte-shifted copies, so the lane at column wx reads
 //     its 16 reference bytes of a row as two ALIGNED ds_read_b64 from copy (wx & 7): no v_alignbyte, and
 //     the copy stride (== 8 dwords mod 64) spreads the 32 lanes of a read over all 64 banks;

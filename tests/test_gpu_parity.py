@@ -462,7 +462,7 @@ def test_deblock_golden_frames(name, frames, fmt):
 
 
 @pytest.mark.parametrize("w,h,fmt,seed", [(64, 48, 1, 1), (320, 192, 1, 2), (96, 64, 2, 3), (48, 48, 0, 4), (16, 16, 1, 5), (16, 64, 2, 6),
-                                          (1920, 1088, 1, 7), (704, 576, 2, 8)])
+                                          (1920, 1088, 1, 7), (704, 576, 2, 8), (3840, 2160, 1, 9)])
 def test_deblock_random_side_info_vs_oracle(J, w, h, fmt, seed):
     """random macroblock types / cbp / motion / slices / disable flags: the filter against the oracle."""
     from jm_amd.lib import DB_MB, DB_MOTION
@@ -479,7 +479,7 @@ def test_deblock_random_side_info_vs_oracle(J, w, h, fmt, seed):
     m12[:, 2] = rng.integers(20, 45, nmb); m12[:, 3] = m12[:, 2] - 2; m12[:, 4] = m12[:, 2] - 3
     m12[:, 6] = rng.integers(0, 1 << 16, nmb) * rng.integers(0, 2, nmb)
     m12[:, 5] = np.where(m12[:, 6] != 0, 15, 0)
-    m12[:, 7] = np.arange(nmb) // max(1, nmb // 3)
+    m12[:, 7] = np.arange(nmb) // max(1, nmb // (8 if h == 2160 else 3))         # slices: 8 bands at 2160p (BASELINE configs[3])
     m12[:, 8] = rng.choice([0, 0, 2, 1], nmb)
     m12[:, 9] = rng.integers(-3, 4, nmb); m12[:, 10] = rng.integers(-3, 4, nmb)
     m12[:, 11] = (m12[:, 0] == 13) | ((m12[:, 0] < 9) & (rng.integers(0, 4, nmb) == 0))
