@@ -163,15 +163,6 @@ struct RowArgs {
   unsigned long long *hand;                    // hand-over granules: per macroblock 16 luma + 8 chroma, zeroed by k_deblock_prep
   int mb_w, mb_h, fmt, nkinds;
 };
-#ifdef JMHIP_DB_PROFILE      // per-row cycle sums of the five phases of a step, read back by profiles/prof_deblock.py
-#define PROF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf_acc[6] = {0, 0, 0, 0, 0, 0};
-#define PROF(k) { const unsigned long long n_ = __builtin_readcyclecounter(); pf_acc[k] += n_ - pf_t; pf_t = n_; }
-#define PROF_OUT(kind) if (lane == 0) for (int k_ = 0; k_ < 6; k_++) ((unsigned long long *)(A.sync + 16))[((kind) * A.mb_h + row) * 6 + k_] = pf_acc[k_];
-#else
-#define PROF_DECL
-#define PROF(k)
-#define PROF_OUT(kind)
-#endif
 #define HAND_PER_MB 24                         // 8-byte granules per macroblock: [0,16) luma rows 12..15 x 4 dwords, [16,24) chroma
 
 #define DB_SPIN_LIMIT (1u << 21)
@@ -192,267 +183,268 @@ __device__ __forceinline__ bool await_granules(const unsigned long long *g, bool
     if (__all(!mine || (v >> 32) != 0)) return true;
     if ((spins & 31u) == 31u && __hip_atomic_load(err, RLX_AGENT) != 0) return false;
     if (spins > DB_SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); return false; }
-    __builtin_amdgcn_s_sleep(1);
     if (mine) v = get_granule(g);
   }
 }
 
-// Step structure of a row (both kinds).  At the top of step x the LDS tile already holds macroblock x (own samples,
-// top rows, carried left columns) and s_prep its strength record; registers hold the own samples / record of x+1.
-//   1. issue loads: the hand-over granules of the top neighbour of x, own samples / record of x+2
-//   2. vertical edges (they need no top rows); right after the first edge hand the row below the now-final last columns of
-//      macroblock x-1's bottom rows
-//   3. wait for the granules (normally there: the vertical edges hid the round trip) and put the top rows into the tile
-//   4. horizontal edges; hand over the first columns of macroblock x's bottom rows
-//   5. image stores (each sample is stored by exactly one row: a row leaves its bottom rows to the row below, which
-//      filters them across its top edge); the own rows of x+1 into the tile
-// The horizontal edges of macroblock x can start as soon as the row above is through the FIRST vertical edge of x+1: a row
-// trails the row above by well under one macroblock plus one store->load hop, not by whole-macroblock flags.
+// A row is walked by TWO waves of one workgroup (warp specialisation):
+//   the FILTER wave only runs the edge filters on LDS tiles -- per macroblock x: vertical edges V(x), barrier, horizontal
+//   edges H(x), barrier -- its instruction stream is the dependent chain that bounds the whole frame, so nothing else is in it;
+//   the MOVER wave does every memory operation around it, overlapped with the filters: it prefetches the own samples and the
+//   strength record two macroblocks ahead and puts them into the tile ring, polls the top neighbour's hand-over granules and
+//   puts the top rows in place (while V(x) runs: the vertical edges need no top rows), stores finished macroblock x-1 to the
+//   image as 16-byte rows and hands its bottom rows to the row below (while H(x) runs).
+// LDS: a ring of four tiles (macroblock x-1: being stored; x: being filtered; x+1: being filled), each rows -4..15 x 16
+// columns; the left neighbour's columns 12..15 are read and written by V(x) directly in tile x-1, so nothing is copied.
+// What is final when: after V(x) every sample of macroblock x-1 is final for this row (rows 12..15 still get the row below's
+// top edge: they are handed over, not stored); after H(x) rows -4..-1 of tile x hold the top neighbour's final bottom rows,
+// which THIS row stores.  Every image sample is stored by exactly one row.
+// A failed wait (timeout / pipeline error) raises s_abort; both waves leave at the next barrier.
 
-// ---- luma row: tile rows -4..15 (index +4), columns -8..15 (byte index +8), pitch 24 bytes
-#define YP 24
-__device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tile, uint8_t *s_prep)
+// ---- luma: tile rows -4..15 (index +4), 16 bytes per row
+#define YT_BYTES (20 * 16)
+__device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* 2 x sizeof(DbPrep) */, volatile int *s_abort)
 {
-  const int lane = threadIdx.x, mb_w = A.mb_w;
-  uint32_t *tile = (uint32_t *)s_tile;
+  const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w;
+  const bool filter_wave = tid < 64;
   gu32 *err = (gu32 *)(A.sync + 1);
   uint8_t *rowp = A.Y + (long)(16 * row) * A.pitchY;
   const DbPrep *prow = A.prep + (long)row * mb_w;
   const bool has_up = row > 0, has_down = row + 1 < A.mb_h;
-  const bool is_own = lane < 16, is_top = lane >= 16 && lane < 20 && has_up, is_pre = lane >= 32 && lane < 32 + PREP_VEC;
-  const bool is_gran = lane >= 16 && lane < 32 && has_up;                    // granule (lane-16) = top row (lane-16)>>2, dword (lane-16)&3
+  // mover roles
+  const bool is_own = lane < 16, is_gran = lane >= 16 && lane < 32 && has_up, is_pre = lane >= 32 && lane < 32 + PREP_VEC;
   const uint8_t *own_p = rowp + (long)lane * A.pitchY;                        // is_own lanes: sample row `lane`
-  uint8_t *top_p = rowp + (long)(lane - 20) * A.pitchY;                       // is_top lanes: rows -4..-1
   const unsigned long long *hand_up = A.hand + (long)(row - 1) * mb_w * HAND_PER_MB + (lane - 16);
   unsigned long long *hand_me = A.hand + (long)row * mb_w * HAND_PER_MB;
   const int own_rows = has_down ? 12 : 16;                                    // rows 12..15 are stored by the row below
+  const int srow = lane - 4;                                                  // store role: lanes 0..19 = picture rows -4..15
+  const bool is_store = lane < 20 && (srow >= 0 ? srow < own_rows : has_up);
 
   uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1;
   unsigned long long gr = 0;
-  // ---- prologue: tile of macroblock 0 (own rows; the top rows arrive inside the step), registers of macroblock 1
-  if (is_own) own1 = *(const uint4 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 32];
-  if (is_own) { uint32_t *d = tile + (lane + 4) * 6 + 2; d[0] = own1.x; d[1] = own1.y; d[2] = own1.z; d[3] = own1.w; }
-  else if (is_pre) ((uint4 *)s_prep)[lane - 32] = pre1;
-  if (mb_w > 1) { if (is_own) own1 = *(const uint4 *)(own_p + 16); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 32]; }
+  if (!filter_wave) {                                      // prologue: tile / record of macroblock 0, registers of macroblock 1
+    if (is_own) own1 = *(const uint4 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 32];
+    if (is_gran) gr = get_granule(hand_up);
+    if (is_own) *(uint4 *)(s_tiles + (lane + 4) * 16) = own1; else if (is_pre) ((uint4 *)s_preps)[lane - 32] = pre1;
+    if (mb_w > 1) { if (is_own) own1 = *(const uint4 *)(own_p + 16); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 32]; }
+  }
 
-  PROF_DECL
   for (int x = 0; x < mb_w; x++) {
-    __syncthreads();
-    PROF(0)
-    // ---- 1. loads: the top neighbour's hand-over granules (needed only by the horizontal edges: the vertical edges hide the
-    //         round trip), own samples / record of x+2
-    if (is_gran) gr = get_granule(hand_up + (long)x * HAND_PER_MB);
-    if (x + 2 < mb_w) { if (is_own) own2 = *(const uint4 *)(own_p + 16 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 32]; }
-
-    const DbPrep *P = (const DbPrep *)s_prep;
-    // ---- 2. vertical edges: lane = sample row, columns -4..15 in registers
-    if (lane < 16) {
-      uint32_t *t = tile + (lane + 4) * 6 + 1;
-      const int seg = lane >> 2;
-      const uint32_t bs = *(const uint32_t *)&P->bsY[0][seg][0];
-      // columns 12..15 of macroblock x-1 (tile columns -4..-1) are final after edge 0: its bottom rows go to the row below at once
-      unsigned long long *early = hand_me + (long)(x - 1) * HAND_PER_MB + (lane - 12) * 4 + 3;
-      const bool do_early = has_down && x > 0 && lane >= 12;
-      if (bs) {
-        const uint32_t c0 = *(const uint32_t *)&P->c0Y[0][seg][0];
-        const uint32_t abE = *(const uint16_t *)&P->ab[0][0][0], abI = *(const uint16_t *)&P->ab[0][2][0];
-        const uint32_t w[5] = {t[0], t[1], t[2], t[3], t[4]};
-        int p[20];
+    uint8_t *tc = s_tiles + (x & 3) * YT_BYTES, *tp = s_tiles + ((x + 3) & 3) * YT_BYTES, *tn = s_tiles + ((x + 1) & 3) * YT_BYTES;
+    const DbPrep *P = (const DbPrep *)(s_preps + (x & 1) * sizeof(DbPrep));
+    __syncthreads();                                       // tile x (own rows) and record x are in place; H(x-1) is done
+    if (*s_abort) return;
+    if (filter_wave) {
+      // ---- V(x): lane = sample row, columns -4..15 in registers (-4..-1 live in tile x-1)
+      if (lane < 16) {
+        const int seg = lane >> 2;
+        const uint32_t bs = *(const uint32_t *)&P->bsY[0][seg][0];
+        if (bs) {
+          uint32_t *tl = (uint32_t *)(tp + (lane + 4) * 16) + 3;
+          uint4 *tr = (uint4 *)(tc + (lane + 4) * 16);
+          const uint32_t c0 = *(const uint32_t *)&P->c0Y[0][seg][0];
+          const uint32_t abE = *(const uint16_t *)&P->ab[0][0][0], abI = *(const uint16_t *)&P->ab[0][2][0];
+          const uint4 v = *tr;
+          const uint32_t w[5] = {*tl, v.x, v.y, v.z, v.w};
+          int p[20];
 #pragma unroll
-        for (int k = 0; k < 20; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
+          for (int k = 0; k < 20; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
 #define VEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; const uint32_t ab = (E) ? abI : abE; \
                    if (__any(bS)) luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255, __any(bS == 4)); }
-        VEDGE(0)
-        if (do_early) put_granule(early, pack4(p[0], p[1], p[2], p[3]));
-        VEDGE(1) VEDGE(2) VEDGE(3)
+          VEDGE(0) VEDGE(1) VEDGE(2) VEDGE(3)
 #undef VEDGE
-#pragma unroll
-        for (int k = 0; k < 5; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
-      } else if (do_early) put_granule(early, t[0]);
+          *tl = pack4(p[0], p[1], p[2], p[3]);
+          *tr = make_uint4(pack4(p[4], p[5], p[6], p[7]), pack4(p[8], p[9], p[10], p[11]), pack4(p[12], p[13], p[14], p[15]), pack4(p[16], p[17], p[18], p[19]));
+        }
+      }
+    } else {
+      // ---- mover, while V(x) runs: bottom rows of x-1 (columns 0..11 are untouched by V(x)), the top rows of x, loads ahead
+      if (has_down && x > 0 && lane >= 48) {
+        const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
+        if (c4 < 3) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + r * 4 + c4, ((const uint32_t *)(tp + (16 + r) * 16))[c4]);
+      }
+      if (has_up) {
+        if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
+        if (is_gran) { ((uint32_t *)(tc + ((lane - 16) >> 2) * 16))[(lane - 16) & 3] = (uint32_t)gr; if (x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB); }
+      }
+      if (x + 2 < mb_w) { if (is_own) own2 = *(const uint4 *)(own_p + 16 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 32]; }
     }
-    PROF(1)
-    // ---- the top rows -4..-1 of macroblock x into the tile
-    if (has_up) {
-      if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) return;
-      if (is_gran) tile[((lane - 16) >> 2) * 6 + 2 + ((lane - 16) & 3)] = (uint32_t)gr;
-    }
-    __syncthreads();
-    PROF(4)
-    // ---- 3. horizontal edges: lane = sample column, rows -4..15 in registers
-    if (lane < 16) {
-      const int seg = lane >> 2;
-      const uint32_t bs = *(const uint32_t *)&P->bsY[1][seg][0];
-      if (bs) {
-        const uint32_t c0 = *(const uint32_t *)&P->c0Y[1][seg][0];
-        const uint32_t abE = *(const uint16_t *)&P->ab[0][1][0], abI = *(const uint16_t *)&P->ab[0][2][0];
-        uint8_t *c = s_tile + 8 + lane;
-        int p[20];
+    __syncthreads();                                       // V(x) done; the top rows of x are in the tile
+    if (*s_abort) return;
+    if (filter_wave) {
+      // ---- H(x): lane = sample column, rows -4..15 in registers
+      if (lane < 16) {
+        const int seg = lane >> 2;
+        const uint32_t bs = *(const uint32_t *)&P->bsY[1][seg][0];
+        if (bs) {
+          const uint32_t c0 = *(const uint32_t *)&P->c0Y[1][seg][0];
+          const uint32_t abE = *(const uint16_t *)&P->ab[0][1][0], abI = *(const uint16_t *)&P->ab[0][2][0];
+          uint8_t *c = tc + lane;
+          int p[20];
 #pragma unroll
-        for (int k = 0; k < 20; k++) p[k] = c[k * YP];
+          for (int k = 0; k < 20; k++) p[k] = c[k * 16];
 #define HEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; const uint32_t ab = (E) ? abI : abE; \
                    if (__any(bS)) luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255, __any(bS == 4)); }
-        HEDGE(0) HEDGE(1) HEDGE(2) HEDGE(3)
+          HEDGE(0) HEDGE(1) HEDGE(2) HEDGE(3)
 #undef HEDGE
 #pragma unroll
-        for (int k = 1; k < 19; k++) c[k * YP] = (uint8_t)p[k];
+          for (int k = 1; k < 19; k++) c[k * 16] = (uint8_t)p[k];
+        }
       }
-    }
-    __syncthreads();
-    PROF(2)
-    // bottom rows 12..15 of macroblock x: columns 0..11 are final (12..15 too when this is the last macroblock of the row)
-    if (has_down && lane >= 48) {
-      const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
-      if (c4 < 3 || x == mb_w - 1) put_granule(hand_me + (long)x * HAND_PER_MB + r * 4 + c4, tile[(16 + r) * 6 + 2 + c4]);
-    }
-    // ---- 4. image stores of step x, then the own rows of x+1 into the tile
-    if (is_own) {
-      uint32_t *t = tile + (lane + 4) * 6;
-      uint8_t *g = (uint8_t *)own_p + 16 * x;
-      const uint32_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3], c4 = t[4], c5 = t[5];
-      if (lane < own_rows) {
-        if (x > 0) st8(g - 8, c0, c1);
-        st8(g, c2, c3);
-        if (x == mb_w - 1) st8(g + 8, c4, c5);
+    } else {
+      // ---- mover, while H(x) runs: macroblock x-1 is final (V(x) is through its last columns): hand over, store; fill tile x+1
+      if (x > 0) {
+        if (has_down && lane >= 48 && lane < 52) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + (lane - 48) * 4 + 3, ((const uint32_t *)(tp + (16 + lane - 48) * 16))[3]);
+        if (is_store) *(uint4 *)(rowp + (long)srow * A.pitchY + 16 * (x - 1)) = *(const uint4 *)(tp + lane * 16);
       }
-      t[0] = c4; t[1] = c5;                                                   // columns 8..15 become the next macroblock's -8..-1
-      t[2] = own1.x; t[3] = own1.y; t[4] = own1.z; t[5] = own1.w;
-    } else if (is_top) {
-      uint32_t *t = tile + (lane - 16) * 6 + 2;
-      uint8_t *g = top_p + 16 * x;
-      st8(g, t[0], t[1]); st8(g + 8, t[2], t[3]);
-    } else if (is_pre) ((uint4 *)s_prep)[lane - 32] = pre1;
-    PROF(3)
-    own1 = own2; pre1 = pre2;
+      if (x + 1 < mb_w) { if (is_own) *(uint4 *)(tn + (lane + 4) * 16) = own1; else if (is_pre) ((uint4 *)(s_preps + ((x + 1) & 1) * sizeof(DbPrep)))[lane - 32] = pre1; }
+      own1 = own2; pre1 = pre2;
+    }
   }
-  PROF_OUT(0)
+  __syncthreads();                                         // H(mb_w-1) done
+  if (!filter_wave) {                                      // the last macroblock: all four column groups of its bottom rows, and the store
+    const uint8_t *tl = s_tiles + ((mb_w - 1) & 3) * YT_BYTES;
+    if (has_down && lane >= 48) put_granule(hand_me + (long)(mb_w - 1) * HAND_PER_MB + (lane - 48), ((const uint32_t *)(tl + (16 + ((lane - 48) >> 2)) * 16))[(lane - 48) & 3]);
+    if (is_store) *(uint4 *)(rowp + (long)srow * A.pitchY + 16 * (mb_w - 1)) = *(const uint4 *)(tl + lane * 16);
+  }
 }
 
-// ---- chroma row: both planes; per plane tile rows -2..RH-1 (index +2), columns -8..7 (byte index +8), pitch 16 bytes
-#define CPB 16
-__device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tile /* 2 planes x 18 rows x 16 */, uint8_t *s_prep)
+// ---- chroma: both planes; per plane tile rows -2..RH-1 (index +2), 8 bytes per row, 18 rows
+#define CT_PLANE (18 * 8)
+#define CT_BYTES (2 * CT_PLANE)
+__device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x CT_BYTES */, uint8_t *s_preps, volatile int *s_abort)
 {
-  const int lane = threadIdx.x, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8;
+  const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8;
+  const bool filter_wave = tid < 64;
   gu32 *err = (gu32 *)(A.sync + 1);
   const DbPrep *prow = A.prep + (long)row * mb_w;
   const bool has_up = row > 0, has_down = row + 1 < A.mb_h;
-  // roles: lanes [0, 2RH): (plane, sample row) for loads / vertical edges / stores; lanes [0,16): (plane, column) for the
-  // horizontal edges; lanes 32..35: (plane, top row -2 / -1) image stores; lanes 40..51: the prep record;
-  // lanes 56..63: granule (lane-56) = plane (bit 2), top row (bit 1), dword (bit 0)
-  const bool is_own = lane < 2 * RH, is_top = lane >= 32 && lane < 36 && has_up, is_pre = lane >= 40 && lane < 40 + PREP_VEC;
-  const bool is_gran = lane >= 56 && has_up;
-  const int uvr = is_own ? lane / RH : 0, rr = lane - uvr * RH;
-  const uint8_t *own_p = (uvr ? A.V : A.U) + (long)(RH * row + rr) * A.pitchC;
-  uint8_t *own_t = s_tile + uvr * 18 * CPB + (rr + 2) * CPB;
+  // filter roles: lanes [0, 2RH): (plane, sample row) for the vertical edges; lanes [0,16): (plane, column) for the horizontal edges
+  const bool is_vrow = lane < 2 * RH;
+  const int uvr = is_vrow ? lane / RH : 0, rr = lane - uvr * RH;
   const int uvc = (lane >> 3) & 1, cc = lane & 7;
-  const int uvt = (lane >> 1) & 1, tr = lane & 1;
-  uint8_t *top_p = (uvt ? A.V : A.U) + (long)(RH * row + tr - 2) * A.pitchC;
-  uint8_t *top_t = s_tile + uvt * 18 * CPB + tr * CPB;
-  const int gq = lane - 56;                                                  // granule index of is_gran lanes
-  uint32_t *gran_t = (uint32_t *)(s_tile + ((gq >> 2) & 1) * 18 * CPB + ((gq >> 1) & 1) * CPB + 8) + (gq & 1);
+  // mover roles: lanes [0, 2RH): own rows (loads); lanes [0, 2(RH+2)): store rows -2..RH-1 of a plane; lanes 40..51: the record;
+  // lanes 56..63: granule (lane-56) = plane (bit 2), top row (bit 1), dword (bit 0)
+  const bool is_own = is_vrow, is_pre = lane >= 40 && lane < 40 + PREP_VEC, is_gran = lane >= 56 && has_up;
+  const uint8_t *own_p = (uvr ? A.V : A.U) + (long)(RH * row + rr) * A.pitchC;
+  const int suv = lane / (RH + 2), srow = lane - suv * (RH + 2) - 2;          // store role
+  const bool is_store = lane < 2 * (RH + 2) && (srow >= 0 ? (has_down ? srow < RH - 2 : true) : has_up);
+  uint8_t *store_p = (suv ? A.V : A.U) + (long)(RH * row + srow) * A.pitchC;
+  const int gq = lane - 56;
+  const int goff = ((gq >> 2) & 1) * CT_PLANE + ((gq >> 1) & 1) * 8 + (gq & 1) * 4;   // granule -> tile byte offset (rows -2 / -1)
   const unsigned long long *hand_up = A.hand + (long)(row - 1) * mb_w * HAND_PER_MB + 16 + gq;
   unsigned long long *hand_me = A.hand + (long)row * mb_w * HAND_PER_MB + 16;
-  const bool store_own = has_down ? rr < RH - 2 : true;                      // the last two rows are stored by the row below
 
   uint2 own1 = make_uint2(0, 0), own2 = own1;
   uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1;
   unsigned long long gr = 0;
-  if (is_own) own1 = *(const uint2 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 40];
-  if (is_own) { uint32_t *d = (uint32_t *)(own_t + 8); d[0] = own1.x; d[1] = own1.y; }
-  else if (is_pre) ((uint4 *)s_prep)[lane - 40] = pre1;
-  if (mb_w > 1) { if (is_own) own1 = *(const uint2 *)(own_p + 8); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 40]; }
+  if (!filter_wave) {
+    if (is_own) own1 = *(const uint2 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 40];
+    if (is_gran) gr = get_granule(hand_up);
+    if (is_own) *(uint2 *)(s_tiles + uvr * CT_PLANE + (rr + 2) * 8) = own1; else if (is_pre) ((uint4 *)s_preps)[lane - 40] = pre1;
+    if (mb_w > 1) { if (is_own) own1 = *(const uint2 *)(own_p + 8); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 40]; }
+  }
 
   for (int x = 0; x < mb_w; x++) {
+    uint8_t *tc = s_tiles + (x & 3) * CT_BYTES, *tp = s_tiles + ((x + 3) & 3) * CT_BYTES, *tn = s_tiles + ((x + 1) & 3) * CT_BYTES;
+    const DbPrep *P = (const DbPrep *)(s_preps + (x & 1) * sizeof(DbPrep));
     __syncthreads();
-    if (is_gran) gr = get_granule(hand_up + (long)x * HAND_PER_MB);
-    if (x + 2 < mb_w) { if (is_own) own2 = *(const uint2 *)(own_p + 8 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 40]; }
-
-    const DbPrep *P = (const DbPrep *)s_prep;
-    // ---- vertical edges (luma edges 0 and 2 -> chroma columns 0 and 4): lane = (plane, row), columns -4..7
-    if (is_own) {
-      const int seg = RH == 8 ? (rr >> 1) : (rr >> 2);
-      const uint32_t bs = *(const uint32_t *)&P->bsC[0][seg][0] & 0x00ff00ffu;        // luma edges 0 and 2
-      uint32_t *t = (uint32_t *)(own_t + 4);
-      // columns 4..7 of macroblock x-1 (tile columns -4..-1) are final after the first edge: hand its last two rows to the row below
-      unsigned long long *early = hand_me + (long)(x - 1) * HAND_PER_MB + uvr * 4 + (rr - (RH - 2)) * 2 + 1;
-      const bool do_early = has_down && x > 0 && rr >= RH - 2;
-      if (bs) {
-        const uint32_t c0 = *(const uint32_t *)&P->c0C[uvr][0][seg][0];
-        const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvr][0][0], abI = *(const uint16_t *)&P->ab[1 + uvr][2][0];
-        const uint32_t w[3] = {t[0], t[1], t[2]};
-        int p[12];
+    if (*s_abort) return;
+    if (filter_wave) {
+      // ---- vertical edges (luma edges 0 and 2 -> chroma columns 0 and 4): lane = (plane, row), columns -4..7 (-4..-1 in tile x-1)
+      if (is_vrow) {
+        const int seg = RH == 8 ? (rr >> 1) : (rr >> 2);
+        const uint32_t bs = *(const uint32_t *)&P->bsC[0][seg][0] & 0x00ff00ffu;
+        if (bs) {
+          uint32_t *tl = (uint32_t *)(tp + uvr * CT_PLANE + (rr + 2) * 8) + 1;
+          uint2 *tr = (uint2 *)(tc + uvr * CT_PLANE + (rr + 2) * 8);
+          const uint32_t c0 = *(const uint32_t *)&P->c0C[uvr][0][seg][0];
+          const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvr][0][0], abI = *(const uint16_t *)&P->ab[1 + uvr][2][0];
+          const uint2 v = *tr;
+          const uint32_t w[3] = {*tl, v.x, v.y};
+          int p[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
-        chroma_edge4(p[2], p[3], p[4], p[5], bs & 255, abE & 255, abE >> 8, c0 & 255);
-        if (do_early) put_granule(early, pack4(p[0], p[1], p[2], p[3]));
-        chroma_edge4(p[6], p[7], p[8], p[9], (bs >> 16) & 255, abI & 255, abI >> 8, (c0 >> 16) & 255);
-#pragma unroll
-        for (int k = 0; k < 3; k++) t[k] = pack4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
-      } else if (do_early) put_granule(early, t[0]);
-    }
-    if (has_up) {
-      if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) return;
-      if (is_gran) *gran_t = (uint32_t)gr;
+          for (int k = 0; k < 12; k++) p[k] = (w[k >> 2] >> (8 * (k & 3))) & 255;
+          chroma_edge4(p[2], p[3], p[4], p[5], bs & 255, abE & 255, abE >> 8, c0 & 255);
+          chroma_edge4(p[6], p[7], p[8], p[9], (bs >> 16) & 255, abI & 255, abI >> 8, (c0 >> 16) & 255);
+          *tl = pack4(p[0], p[1], p[2], p[3]);
+          *tr = make_uint2(pack4(p[4], p[5], p[6], p[7]), pack4(p[8], p[9], p[10], p[11]));
+        }
+      }
+    } else {
+      // bottom two rows of x-1, columns 0..3 (untouched by V(x)); the top rows of x; loads ahead
+      if (has_down && x > 0 && lane >= 48 && lane < 56 && !(lane & 1)) {
+        const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1;
+        put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + q, *(const uint32_t *)(tp + uv * CT_PLANE + (RH + r) * 8));
+      }
+      if (has_up) {
+        if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
+        if (is_gran) { *(uint32_t *)(tc + goff) = (uint32_t)gr; if (x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB); }
+      }
+      if (x + 2 < mb_w) { if (is_own) own2 = *(const uint2 *)(own_p + 8 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 40]; }
     }
     __syncthreads();
-    // ---- horizontal edges: lane = (plane, column), rows -2..RH-1
-    if (lane < 16) {
-      const int seg = cc >> 1;
-      const uint32_t bs = *(const uint32_t *)&P->bsC[1][seg][0];
-      if (bs) {
-        const uint32_t c0 = *(const uint32_t *)&P->c0C[uvc][1][seg][0];
-        const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvc][1][0], abI = *(const uint16_t *)&P->ab[1 + uvc][2][0];
-        uint8_t *c = s_tile + uvc * 18 * CPB + 8 + cc;
-        int p[18];
+    if (*s_abort) return;
+    if (filter_wave) {
+      // ---- horizontal edges: lane = (plane, column), rows -2..RH-1
+      if (lane < 16) {
+        const int seg = cc >> 1;
+        const uint32_t bs = *(const uint32_t *)&P->bsC[1][seg][0];
+        if (bs) {
+          const uint32_t c0 = *(const uint32_t *)&P->c0C[uvc][1][seg][0];
+          const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvc][1][0], abI = *(const uint16_t *)&P->ab[1 + uvc][2][0];
+          uint8_t *c = tc + uvc * CT_PLANE + cc;
+          int p[18];
 #pragma unroll
-        for (int k = 0; k < 18; k++) p[k] = (k < RH + 2) ? c[k * CPB] : 0;
-        // chroma_edge[1][e][fmt]: 4:2:0 -> rows 0 (e=0), 4 (e=2); 4:2:2 -> rows 0, 4, 8, 12 (e = 0..3)
+          for (int k = 0; k < 18; k++) p[k] = (k < RH + 2) ? c[k * 8] : 0;
+          // chroma_edge[1][e][fmt]: 4:2:0 -> rows 0 (e=0), 4 (e=2); 4:2:2 -> rows 0, 4, 8, 12 (e = 0..3)
 #define CHEDGE(E, ROW) { const uint32_t ab = (E) ? abI : abE; \
                          chroma_edge4(p[ROW], p[(ROW) + 1], p[(ROW) + 2], p[(ROW) + 3], (bs >> (8 * (E))) & 255, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255); }
-        CHEDGE(0, 0)
-        if (fmt == 1) { CHEDGE(2, 4) }
-        else { CHEDGE(1, 4) CHEDGE(2, 8) CHEDGE(3, 12) }
+          CHEDGE(0, 0)
+          if (fmt == 1) { CHEDGE(2, 4) }
+          else { CHEDGE(1, 4) CHEDGE(2, 8) CHEDGE(3, 12) }
 #undef CHEDGE
 #pragma unroll
-        for (int k = 1; k < 17; k++) if (k < RH + 1) c[k * CPB] = (uint8_t)p[k];
+          for (int k = 1; k < 17; k++) if (k < RH + 1) c[k * 8] = (uint8_t)p[k];
+        }
       }
+    } else {
+      if (x > 0) {
+        if (has_down && lane >= 48 && lane < 56 && (lane & 1)) {
+          const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1;
+          put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + q, *((const uint32_t *)(tp + uv * CT_PLANE + (RH + r) * 8) + 1));
+        }
+        if (is_store) *(uint2 *)(store_p + 8 * (x - 1)) = *(const uint2 *)(tp + suv * CT_PLANE + (srow + 2) * 8);
+      }
+      if (x + 1 < mb_w) { if (is_own) *(uint2 *)(tn + uvr * CT_PLANE + (rr + 2) * 8) = own1; else if (is_pre) ((uint4 *)(s_preps + ((x + 1) & 1) * sizeof(DbPrep)))[lane - 40] = pre1; }
+      own1 = own2; pre1 = pre2;
     }
-    __syncthreads();
-    // last two rows of macroblock x: columns 0..3 are final (4..7 too when this is the last macroblock of the row)
+  }
+  __syncthreads();
+  if (!filter_wave) {
+    const uint8_t *tl = s_tiles + ((mb_w - 1) & 3) * CT_BYTES;
     if (has_down && lane >= 48 && lane < 56) {
       const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1, c4 = q & 1;
-      if (c4 == 0 || x == mb_w - 1)
-        put_granule(hand_me + (long)x * HAND_PER_MB + q, *((const uint32_t *)(s_tile + uv * 18 * CPB + (RH + r) * CPB + 8) + c4));
+      put_granule(hand_me + (long)(mb_w - 1) * HAND_PER_MB + q, *((const uint32_t *)(tl + uv * CT_PLANE + (RH + r) * 8) + c4));
     }
-    if (is_own) {
-      uint32_t *t = (uint32_t *)own_t;
-      uint8_t *g = (uint8_t *)own_p + 8 * x;
-      const uint32_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
-      if (store_own) {
-        if (x > 0) st8(g - 8, c0, c1);
-        if (x == mb_w - 1) st8(g, c2, c3);
-      }
-      t[0] = c2; t[1] = c3; t[2] = own1.x; t[3] = own1.y;
-    } else if (is_top) {
-      const uint32_t *t = (const uint32_t *)(top_t + 8);
-      st8(top_p + 8 * x, t[0], t[1]);
-    } else if (is_pre) ((uint4 *)s_prep)[lane - 40] = pre1;
-    own1 = own2; pre1 = pre2;
+    if (is_store) *(uint2 *)(store_p + 8 * (mb_w - 1)) = *(const uint2 *)(tl + suv * CT_PLANE + (srow + 2) * 8);
   }
 }
 
-__global__ __launch_bounds__(64) void k_deblock_rows(RowArgs A)
+__global__ __launch_bounds__(128) void k_deblock_rows(RowArgs A)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t s_tile[2 * 18 * CPB > 20 * YP ? 2 * 18 * CPB : 20 * YP];
-  __shared__ __attribute__((aligned(16))) uint8_t s_prep[sizeof(DbPrep)];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * (YT_BYTES > CT_BYTES ? YT_BYTES : CT_BYTES)];
+  __shared__ __attribute__((aligned(16))) uint8_t s_preps[2 * sizeof(DbPrep)];
   __shared__ unsigned s_ticket;
-  const int lane = threadIdx.x;
-  if (lane == 0) s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT);
-  for (int k = lane; k < (int)sizeof(s_tile) / 4; k += 64) ((uint32_t *)s_tile)[k] = 0;
+  __shared__ int s_abort;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT); s_abort = 0; }
+  for (int k = tid; k < (int)sizeof(s_tiles) / 4; k += 128) ((uint32_t *)s_tiles)[k] = 0;
   __syncthreads();
   const int t = (int)s_ticket, row = t / A.nkinds, kind = t - row * A.nkinds;
   if (row >= A.mb_h) return;
-  if (kind == 0) luma_row(A, row, s_tile, s_prep);
-  else chroma_row(A, row, s_tile, s_prep);
+  if (kind == 0) luma_row(A, row, s_tiles, s_preps, &s_abort);
+  else chroma_row(A, row, s_tiles, s_preps, &s_abort);
 }
 
 // prep + rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
@@ -466,6 +458,6 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
   RowArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
   A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;
-  hipLaunchKernelGGL(k_deblock_rows, dim3(nkinds * mb_h), dim3(64), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_deblock_rows, dim3(nkinds * mb_h), dim3(128), 0, ctx->stream, A);
   return JMHIP_OK;
 }
