@@ -201,47 +201,66 @@ __device__ __forceinline__ bool await_granules(const unsigned long long *g, bool
 // which THIS row stores.  Every image sample is stored by exactly one row.
 // A failed wait (timeout / pipeline error) raises s_abort; both waves leave at the next barrier.
 
-// ---- luma: tile rows -4..15 (index +4), 16 bytes per row
-#define YT_BYTES (20 * 16)
-__device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* 2 x sizeof(DbPrep) */, volatile int *s_abort)
+// ---- luma: FOUR macroblock rows per workgroup.  Only 16 lanes of the filter wave are busy with one row, and a VALU instruction
+// costs the same four cycles whatever the lane count, so the same instruction stream filters four rows at once: lanes
+// [16g, 16g+16) work on row g of the band, one macroblock behind row g-1 (step s: row g does macroblock s-g; H(x) of row g runs
+// in the step in which row g-1 runs V(x+1), exactly the order the 2:1 wavefront needs).  A ring slot is a tall tile: the four
+// rows' macroblock of one column stacked (4 + 64 rows x 16 bytes), so row g's "top rows" simply ARE row g-1's bottom rows: inside
+// a band nothing is handed over at all; granules connect the last row of a band to the first row of the next band only.
+#define LR 4                                   // rows per luma workgroup
+#define YT_BYTES ((4 + 16 * LR) * 16)          // one ring slot
+__device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* LR x 2 x sizeof(DbPrep) */, volatile int *s_abort)
 {
   const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w;
   const bool filter_wave = tid < 64;
   gu32 *err = (gu32 *)(A.sync + 1);
-  uint8_t *rowp = A.Y + (long)(16 * row) * A.pitchY;
-  const DbPrep *prow = A.prep + (long)row * mb_w;
-  const bool has_up = row > 0, has_down = row + 1 < A.mb_h;
+  const int row0 = band * LR, nrows = min(LR, A.mb_h - row0);                  // rows of this band
+  const bool has_up = row0 > 0, has_down = row0 + nrows < A.mb_h;
+  const int g = lane >> 4, l = lane & 15;                                     // row of the band, lane inside it
+  const bool row_ok = g < nrows;
+  uint8_t *band_p = A.Y + (long)(16 * row0) * A.pitchY;
   // mover roles
-  const bool is_own = lane < 16, is_gran = lane >= 16 && lane < 32 && has_up, is_pre = lane >= 32 && lane < 32 + PREP_VEC;
-  const uint8_t *own_p = rowp + (long)lane * A.pitchY;                        // is_own lanes: sample row `lane`
-  const unsigned long long *hand_up = A.hand + (long)(row - 1) * mb_w * HAND_PER_MB + (lane - 16);
-  unsigned long long *hand_me = A.hand + (long)row * mb_w * HAND_PER_MB;
-  const int own_rows = has_down ? 12 : 16;                                    // rows 12..15 are stored by the row below
-  const int srow = lane - 4;                                                  // store role: lanes 0..19 = picture rows -4..15
-  const bool is_store = lane < 20 && (srow >= 0 ? srow < own_rows : has_up);
+  const uint8_t *own_p = band_p + (long)lane * A.pitchY;                      // lane = sample row of the band (row g, line l)
+  const int pg = lane / PREP_VEC, pv = lane - pg * PREP_VEC;                  // record loads: lanes [0, LR*PREP_VEC): row pg, vector pv
+  const bool is_pre = lane < LR * PREP_VEC && pg < nrows;
+  const DbPrep *pre_p = A.prep + (long)(row0 + pg) * mb_w;
+  const bool is_gran = lane < 16 && has_up;                                   // granule `lane` = top row lane>>2, dword lane&3
+  const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * mb_w * HAND_PER_MB + lane;
+  unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * mb_w * HAND_PER_MB;
+  // image stores: lane L = tall-tile row L = picture row 16*row0 - 4 + L; row g's stores cover its rows -4..11 (the top neighbour's
+  // bottom rows it filtered, and its own rows it will not hand on); the frame's last four rows ride on lanes 0..3 of a second store
+  uint8_t *store_p = band_p + (long)(lane - 4) * A.pitchY;
+  const bool store_ok = row_ok && (lane >= 4 || has_up);
+  const bool tail_ok = !has_down && lane < 4;                                 // rows 12..15 of the last row of the frame
+  uint8_t *tail_p = band_p + (long)(16 * nrows - 4 + lane) * A.pitchY;
 
   uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1;
   unsigned long long gr = 0;
-  if (!filter_wave) {                                      // prologue: tile / record of macroblock 0, registers of macroblock 1
-    if (is_own) own1 = *(const uint4 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 32];
+  if (!filter_wave) {                                      // prologue: column 0 of every row, registers of column 1
+    if (row_ok) own1 = *(const uint4 *)own_p;
+    if (is_pre) pre1 = ((const uint4 *)pre_p)[pv];
     if (is_gran) gr = get_granule(hand_up);
-    if (is_own) *(uint4 *)(s_tiles + (lane + 4) * 16) = own1; else if (is_pre) ((uint4 *)s_preps)[lane - 32] = pre1;
-    if (mb_w > 1) { if (is_own) own1 = *(const uint4 *)(own_p + 16); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 32]; }
+    if (row_ok) *(uint4 *)(s_tiles + (4 + lane) * 16) = own1;
+    if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = pre1;
+    if (mb_w > 1) { if (row_ok) own1 = *(const uint4 *)(own_p + 16); if (is_pre) pre1 = ((const uint4 *)(pre_p + 1))[pv]; }
   }
 
-  for (int x = 0; x < mb_w; x++) {
-    uint8_t *tc = s_tiles + (x & 3) * YT_BYTES, *tp = s_tiles + ((x + 3) & 3) * YT_BYTES, *tn = s_tiles + ((x + 1) & 3) * YT_BYTES;
-    const DbPrep *P = (const DbPrep *)(s_preps + (x & 1) * sizeof(DbPrep));
-    __syncthreads();                                       // tile x (own rows) and record x are in place; H(x-1) is done
+  const int nsteps = mb_w + nrows - 1;
+  for (int s = 0; s < nsteps; s++) {
+    const int x = s - g;                                   // this lane group's macroblock (filter wave); row g is busy iff 0 <= x < mb_w
+    const bool busy = row_ok && x >= 0 && x < mb_w;
+    uint8_t *tc = s_tiles + (x & 3) * YT_BYTES, *tp = s_tiles + ((x + 3) & 3) * YT_BYTES;
+    const DbPrep *P = (const DbPrep *)(s_preps + (g * 2 + (x & 1)) * sizeof(DbPrep));
+    __syncthreads();                                       // columns s-g are in place for every row; the horizontal edges of step s-1 are done
     if (*s_abort) return;
     if (filter_wave) {
-      // ---- V(x): lane = sample row, columns -4..15 in registers (-4..-1 live in tile x-1)
-      if (lane < 16) {
-        const int seg = lane >> 2;
+      // ---- V(x): lane = sample row, columns -4..15 in registers (-4..-1 live in the slot of x-1)
+      if (busy) {
+        const int seg = l >> 2;
         const uint32_t bs = *(const uint32_t *)&P->bsY[0][seg][0];
         if (bs) {
-          uint32_t *tl = (uint32_t *)(tp + (lane + 4) * 16) + 3;
-          uint4 *tr = (uint4 *)(tc + (lane + 4) * 16);
+          uint32_t *tl = (uint32_t *)(tp + (4 + lane) * 16) + 3;
+          uint4 *tr = (uint4 *)(tc + (4 + lane) * 16);
           const uint32_t c0 = *(const uint32_t *)&P->c0Y[0][seg][0];
           const uint32_t abE = *(const uint16_t *)&P->ab[0][0][0], abI = *(const uint16_t *)&P->ab[0][2][0];
           const uint4 v = *tr;
@@ -258,28 +277,30 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x YT_B
         }
       }
     } else {
-      // ---- mover, while V(x) runs: bottom rows of x-1 (columns 0..11 are untouched by V(x)), the top rows of x, loads ahead
-      if (has_down && x > 0 && lane >= 48) {
+      // ---- mover, while the vertical edges run.  Its own view of the step: row r of the band works on column s - r.
+      const int xl = s - (nrows - 1);                      // column of the band's last row
+      if (has_down && xl >= 1 && xl <= mb_w && lane >= 48) {                  // its bottom rows of column xl-1: columns 0..11 (V(xl) leaves them alone)
         const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
-        if (c4 < 3) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + r * 4 + c4, ((const uint32_t *)(tp + (16 + r) * 16))[c4]);
+        if (c4 < 3) put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + r * 4 + c4, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + (16 * nrows + r) * 16))[c4]);
       }
-      if (has_up) {
-        if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
-        if (is_gran) { ((uint32_t *)(tc + ((lane - 16) >> 2) * 16))[(lane - 16) & 3] = (uint32_t)gr; if (x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB); }
+      if (has_up && s < mb_w) {                            // the first row's top rows of column s
+        if (!await_granules(hand_up + (long)s * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
+        if (is_gran) { ((uint32_t *)(s_tiles + (s & 3) * YT_BYTES + (lane >> 2) * 16))[lane & 3] = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
       }
-      if (x + 2 < mb_w) { if (is_own) own2 = *(const uint4 *)(own_p + 16 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 32]; }
+      { const int xo = s - g + 2; if (row_ok && xo >= 2 && xo < mb_w) own2 = *(const uint4 *)(own_p + 16 * xo); }
+      { const int xq = s - pg + 2; if (is_pre && xq >= 2 && xq < mb_w) pre2 = ((const uint4 *)(pre_p + xq))[pv]; }
     }
-    __syncthreads();                                       // V(x) done; the top rows of x are in the tile
+    __syncthreads();                                       // V done; the band's top rows are in the slot
     if (*s_abort) return;
     if (filter_wave) {
-      // ---- H(x): lane = sample column, rows -4..15 in registers
-      if (lane < 16) {
-        const int seg = lane >> 2;
+      // ---- H(x): lane = sample column; rows -4..15 of row g are tall-tile rows 16g .. 16g+19 of the slot of x
+      if (busy) {
+        const int seg = l >> 2;
         const uint32_t bs = *(const uint32_t *)&P->bsY[1][seg][0];
         if (bs) {
           const uint32_t c0 = *(const uint32_t *)&P->c0Y[1][seg][0];
           const uint32_t abE = *(const uint16_t *)&P->ab[0][1][0], abI = *(const uint16_t *)&P->ab[0][2][0];
-          uint8_t *c = tc + lane;
+          uint8_t *c = tc + (16 * g) * 16 + l;
           int p[20];
 #pragma unroll
           for (int k = 0; k < 20; k++) p[k] = c[k * 16];
@@ -292,20 +313,31 @@ __device__ void luma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x YT_B
         }
       }
     } else {
-      // ---- mover, while H(x) runs: macroblock x-1 is final (V(x) is through its last columns): hand over, store; fill tile x+1
-      if (x > 0) {
-        if (has_down && lane >= 48 && lane < 52) put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + (lane - 48) * 4 + 3, ((const uint32_t *)(tp + (16 + lane - 48) * 16))[3]);
-        if (is_store) *(uint4 *)(rowp + (long)srow * A.pitchY + 16 * (x - 1)) = *(const uint4 *)(tp + lane * 16);
+      // ---- mover, while the horizontal edges run: column s-g-1 of row g is final for this band (V(s-g) is through its last columns)
+      const int xl = s - (nrows - 1);
+      if (has_down && xl >= 1 && xl <= mb_w && lane >= 48 && lane < 52)
+        put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + (lane - 48) * 4 + 3, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + (16 * nrows + lane - 48) * 16))[3]);
+      {
+        const int xs = s - g - 1;                          // store: tall-tile rows 16g .. 16g+15 of the slot of xs = picture rows -4..11 of row g
+        if (store_ok && xs >= 0 && xs < mb_w) *(uint4 *)(store_p + 16 * xs) = *(const uint4 *)(s_tiles + (xs & 3) * YT_BYTES + lane * 16);
+        const int xt = s - (nrows - 1) - 1;                // the frame's very last rows
+        if (tail_ok && xt >= 0 && xt < mb_w) *(uint4 *)(tail_p + 16 * xt) = *(const uint4 *)(s_tiles + (xt & 3) * YT_BYTES + (16 * nrows + lane) * 16);
       }
-      if (x + 1 < mb_w) { if (is_own) *(uint4 *)(tn + (lane + 4) * 16) = own1; else if (is_pre) ((uint4 *)(s_preps + ((x + 1) & 1) * sizeof(DbPrep)))[lane - 32] = pre1; }
-      own1 = own2; pre1 = pre2;
+      { const int xo = s - g + 1; if (row_ok && xo >= 1 && xo < mb_w) *(uint4 *)(s_tiles + (xo & 3) * YT_BYTES + (4 + lane) * 16) = own1; }
+      { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; }
+      // the registers advance per row when that row has consumed them
+      { const int xo = s - g + 1; if (xo >= 1) own1 = own2; }
+      { const int xq = s - pg + 1; if (xq >= 1) pre1 = pre2; }
     }
   }
-  __syncthreads();                                         // H(mb_w-1) done
-  if (!filter_wave) {                                      // the last macroblock: all four column groups of its bottom rows, and the store
-    const uint8_t *tl = s_tiles + ((mb_w - 1) & 3) * YT_BYTES;
-    if (has_down && lane >= 48) put_granule(hand_me + (long)(mb_w - 1) * HAND_PER_MB + (lane - 48), ((const uint32_t *)(tl + (16 + ((lane - 48) >> 2)) * 16))[(lane - 48) & 3]);
-    if (is_store) *(uint4 *)(rowp + (long)srow * A.pitchY + 16 * (mb_w - 1)) = *(const uint4 *)(tl + lane * 16);
+  __syncthreads();                                         // the last horizontal edges are done
+  if (!filter_wave) {                                      // every row's last column; the last row's hand-over of it
+    const int xe = mb_w - 1;
+    const uint8_t *tl = s_tiles + (xe & 3) * YT_BYTES;
+    // rows 0..nrows-2 stored their last column in the loop (their step mb_w-1+g+1 <= nsteps-1) except the band's last row
+    if (has_down && lane >= 48) put_granule(hand_me + (long)xe * HAND_PER_MB + (lane - 48), ((const uint32_t *)(tl + (16 * nrows + ((lane - 48) >> 2)) * 16))[(lane - 48) & 3]);
+    if (store_ok && g == nrows - 1) *(uint4 *)(store_p + 16 * xe) = *(const uint4 *)(tl + lane * 16);
+    if (tail_ok) *(uint4 *)(tail_p + 16 * xe) = *(const uint4 *)(tl + (16 * nrows + lane) * 16);
   }
 }
 
@@ -434,17 +466,18 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x CT
 __global__ __launch_bounds__(128) void k_deblock_rows(RowArgs A)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * (YT_BYTES > CT_BYTES ? YT_BYTES : CT_BYTES)];
-  __shared__ __attribute__((aligned(16))) uint8_t s_preps[2 * sizeof(DbPrep)];
+  __shared__ __attribute__((aligned(16))) uint8_t s_preps[LR * 2 * sizeof(DbPrep)];
   __shared__ unsigned s_ticket;
   __shared__ int s_abort;
   const int tid = threadIdx.x;
   if (tid == 0) { s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT); s_abort = 0; }
   for (int k = tid; k < (int)sizeof(s_tiles) / 4; k += 128) ((uint32_t *)s_tiles)[k] = 0;
   __syncthreads();
-  const int t = (int)s_ticket, row = t / A.nkinds, kind = t - row * A.nkinds;
-  if (row >= A.mb_h) return;
-  if (kind == 0) luma_row(A, row, s_tiles, s_preps, &s_abort);
-  else chroma_row(A, row, s_tiles, s_preps, &s_abort);
+  // tickets: first the luma bands top to bottom, then the chroma rows top to bottom -- a workgroup only ever waits for one
+  // with a smaller ticket, i.e. one that has already started
+  const int t = (int)s_ticket, nbands = (A.mb_h + LR - 1) / LR;
+  if (t < nbands) luma_rows(A, t, s_tiles, s_preps, &s_abort);
+  else if (A.nkinds > 1 && t - nbands < A.mb_h) chroma_row(A, t - nbands, s_tiles, s_preps, &s_abort);
 }
 
 // prep + rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
@@ -458,6 +491,6 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
   RowArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
   A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;
-  hipLaunchKernelGGL(k_deblock_rows, dim3(nkinds * mb_h), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_deblock_rows, dim3((mb_h + LR - 1) / LR + (nkinds - 1) * mb_h), dim3(128), 0, ctx->stream, A);
   return JMHIP_OK;
 }
