@@ -341,55 +341,68 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
   }
 }
 
-// ---- chroma: both planes; per plane tile rows -2..RH-1 (index +2), 8 bytes per row, 18 rows
-#define CT_PLANE (18 * 8)
+// ---- chroma: both planes, the same band scheme: 64 / (2 RH) rows per workgroup (4 rows at 4:2:0, 2 at 4:2:2); per plane a tall
+// tile of 2 + RH * rows sample rows x 8 bytes
+#define CT_PLANE (34 * 8)
 #define CT_BYTES (2 * CT_PLANE)
-__device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x CT_BYTES */, uint8_t *s_preps, volatile int *s_abort)
+__device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x CT_BYTES */, uint8_t *s_preps, volatile int *s_abort)
 {
-  const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8;
+  const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8, CR = 32 / RH;
   const bool filter_wave = tid < 64;
   gu32 *err = (gu32 *)(A.sync + 1);
-  const DbPrep *prow = A.prep + (long)row * mb_w;
-  const bool has_up = row > 0, has_down = row + 1 < A.mb_h;
-  // filter roles: lanes [0, 2RH): (plane, sample row) for the vertical edges; lanes [0,16): (plane, column) for the horizontal edges
-  const bool is_vrow = lane < 2 * RH;
-  const int uvr = is_vrow ? lane / RH : 0, rr = lane - uvr * RH;
-  const int uvc = (lane >> 3) & 1, cc = lane & 7;
-  // mover roles: lanes [0, 2RH): own rows (loads); lanes [0, 2(RH+2)): store rows -2..RH-1 of a plane; lanes 40..51: the record;
-  // lanes 56..63: granule (lane-56) = plane (bit 2), top row (bit 1), dword (bit 0)
-  const bool is_own = is_vrow, is_pre = lane >= 40 && lane < 40 + PREP_VEC, is_gran = lane >= 56 && has_up;
-  const uint8_t *own_p = (uvr ? A.V : A.U) + (long)(RH * row + rr) * A.pitchC;
-  const int suv = lane / (RH + 2), srow = lane - suv * (RH + 2) - 2;          // store role
-  const bool is_store = lane < 2 * (RH + 2) && (srow >= 0 ? (has_down ? srow < RH - 2 : true) : has_up);
-  uint8_t *store_p = (suv ? A.V : A.U) + (long)(RH * row + srow) * A.pitchC;
+  const int row0 = band * CR, nrows = min(CR, A.mb_h - row0);
+  const bool has_up = row0 > 0, has_down = row0 + nrows < A.mb_h;
+  // vertical-edge / own-row lanes: lane -> (row gv of the band, plane uvr, sample row rr)
+  const int gv = lane / (2 * RH), uvr = (lane / RH) & 1, rr = lane % RH;
+  const bool vrow_ok = gv < nrows;
+  const int vt = 2 + RH * gv + rr;                                            // tall-tile row of that sample row
+  // horizontal-edge lanes: lane -> (row gh, plane uvc, column cc)
+  const int gh = lane >> 4, uvc = (lane >> 3) & 1, cc = lane & 7;
+  const bool hcol_ok = gh < nrows && gh < CR;
+  // mover roles
+  const uint8_t *own_p = (uvr ? A.V : A.U) + (long)(RH * (row0 + gv) + rr) * A.pitchC;
+  const int pg = lane / PREP_VEC, pv = lane - pg * PREP_VEC;
+  const bool is_pre = lane < CR * PREP_VEC && pg < nrows;
+  const DbPrep *pre_p = A.prep + (long)(row0 + pg) * mb_w;
+  const bool is_gran = lane >= 56 && has_up;                                  // granule (lane-56) = plane (bit 2), top row (bit 1), dword (bit 0)
   const int gq = lane - 56;
-  const int goff = ((gq >> 2) & 1) * CT_PLANE + ((gq >> 1) & 1) * 8 + (gq & 1) * 4;   // granule -> tile byte offset (rows -2 / -1)
-  const unsigned long long *hand_up = A.hand + (long)(row - 1) * mb_w * HAND_PER_MB + 16 + gq;
-  unsigned long long *hand_me = A.hand + (long)row * mb_w * HAND_PER_MB + 16;
+  const int goff = ((gq >> 2) & 1) * CT_PLANE + ((gq >> 1) & 1) * 8 + (gq & 1) * 4;
+  const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * mb_w * HAND_PER_MB + 16 + gq;
+  unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * mb_w * HAND_PER_MB + 16;
+  // image stores: lane -> plane su = lane >> 5, tall-tile row st = lane & 31 (row gs = st / RH stores its rows -2 .. RH-3)
+  const int su = lane >> 5, st = lane & 31, gs = st / RH;
+  const bool store_ok = gs < nrows && (st >= 2 || has_up);
+  uint8_t *store_p = (su ? A.V : A.U) + (long)(RH * row0 - 2 + st) * A.pitchC;
+  const bool tail_ok = !has_down && lane < 4;                                 // the frame's last two rows of each plane
+  uint8_t *tail_p = ((lane >> 1) ? A.V : A.U) + (long)(RH * (row0 + nrows) - 2 + (lane & 1)) * A.pitchC;
+  const int tail_off = (lane >> 1) * CT_PLANE + (RH * nrows + (lane & 1)) * 8;
 
   uint2 own1 = make_uint2(0, 0), own2 = own1;
   uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1;
   unsigned long long gr = 0;
   if (!filter_wave) {
-    if (is_own) own1 = *(const uint2 *)own_p; else if (is_pre) pre1 = ((const uint4 *)prow)[lane - 40];
+    if (vrow_ok) own1 = *(const uint2 *)own_p;
+    if (is_pre) pre1 = ((const uint4 *)pre_p)[pv];
     if (is_gran) gr = get_granule(hand_up);
-    if (is_own) *(uint2 *)(s_tiles + uvr * CT_PLANE + (rr + 2) * 8) = own1; else if (is_pre) ((uint4 *)s_preps)[lane - 40] = pre1;
-    if (mb_w > 1) { if (is_own) own1 = *(const uint2 *)(own_p + 8); else if (is_pre) pre1 = ((const uint4 *)(prow + 1))[lane - 40]; }
+    if (vrow_ok) *(uint2 *)(s_tiles + uvr * CT_PLANE + vt * 8) = own1;
+    if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = pre1;
+    if (mb_w > 1) { if (vrow_ok) own1 = *(const uint2 *)(own_p + 8); if (is_pre) pre1 = ((const uint4 *)(pre_p + 1))[pv]; }
   }
 
-  for (int x = 0; x < mb_w; x++) {
-    uint8_t *tc = s_tiles + (x & 3) * CT_BYTES, *tp = s_tiles + ((x + 3) & 3) * CT_BYTES, *tn = s_tiles + ((x + 1) & 3) * CT_BYTES;
-    const DbPrep *P = (const DbPrep *)(s_preps + (x & 1) * sizeof(DbPrep));
+  const int nsteps = mb_w + nrows - 1;
+  for (int s = 0; s < nsteps; s++) {
     __syncthreads();
     if (*s_abort) return;
     if (filter_wave) {
-      // ---- vertical edges (luma edges 0 and 2 -> chroma columns 0 and 4): lane = (plane, row), columns -4..7 (-4..-1 in tile x-1)
-      if (is_vrow) {
+      // ---- vertical edges (luma edges 0 and 2 -> chroma columns 0 and 4): lane = (row, plane, sample row), columns -4..7
+      const int x = s - gv;
+      if (vrow_ok && x >= 0 && x < mb_w) {
+        const DbPrep *P = (const DbPrep *)(s_preps + (gv * 2 + (x & 1)) * sizeof(DbPrep));
         const int seg = RH == 8 ? (rr >> 1) : (rr >> 2);
         const uint32_t bs = *(const uint32_t *)&P->bsC[0][seg][0] & 0x00ff00ffu;
         if (bs) {
-          uint32_t *tl = (uint32_t *)(tp + uvr * CT_PLANE + (rr + 2) * 8) + 1;
-          uint2 *tr = (uint2 *)(tc + uvr * CT_PLANE + (rr + 2) * 8);
+          uint32_t *tl = (uint32_t *)(s_tiles + ((x + 3) & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8) + 1;
+          uint2 *tr = (uint2 *)(s_tiles + (x & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8);
           const uint32_t c0 = *(const uint32_t *)&P->c0C[uvr][0][seg][0];
           const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvr][0][0], abI = *(const uint16_t *)&P->ab[1 + uvr][2][0];
           const uint2 v = *tr;
@@ -404,28 +417,31 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x CT
         }
       }
     } else {
-      // bottom two rows of x-1, columns 0..3 (untouched by V(x)); the top rows of x; loads ahead
-      if (has_down && x > 0 && lane >= 48 && lane < 56 && !(lane & 1)) {
+      const int xl = s - (nrows - 1);
+      if (has_down && xl >= 1 && xl <= mb_w && lane >= 48 && lane < 56 && !(lane & 1)) {          // last row's bottom two rows of column xl-1, columns 0..3
         const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1;
-        put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + q, *(const uint32_t *)(tp + uv * CT_PLANE + (RH + r) * 8));
+        put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + q, *(const uint32_t *)(s_tiles + ((xl - 1) & 3) * CT_BYTES + uv * CT_PLANE + (RH * nrows + r) * 8));
       }
-      if (has_up) {
-        if (!await_granules(hand_up + (long)x * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
-        if (is_gran) { *(uint32_t *)(tc + goff) = (uint32_t)gr; if (x + 1 < mb_w) gr = get_granule(hand_up + (long)(x + 1) * HAND_PER_MB); }
+      if (has_up && s < mb_w) {
+        if (!await_granules(hand_up + (long)s * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
+        if (is_gran) { *(uint32_t *)(s_tiles + (s & 3) * CT_BYTES + goff) = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
       }
-      if (x + 2 < mb_w) { if (is_own) own2 = *(const uint2 *)(own_p + 8 * (x + 2)); else if (is_pre) pre2 = ((const uint4 *)(prow + x + 2))[lane - 40]; }
+      { const int xo = s - gv + 2; if (vrow_ok && xo >= 2 && xo < mb_w) own2 = *(const uint2 *)(own_p + 8 * xo); }
+      { const int xq = s - pg + 2; if (is_pre && xq >= 2 && xq < mb_w) pre2 = ((const uint4 *)(pre_p + xq))[pv]; }
     }
     __syncthreads();
     if (*s_abort) return;
     if (filter_wave) {
-      // ---- horizontal edges: lane = (plane, column), rows -2..RH-1
-      if (lane < 16) {
+      // ---- horizontal edges: lane = (row, plane, column); rows -2..RH-1 of row gh are tall-tile rows RH*gh .. RH*gh+RH+1
+      const int x = s - gh;
+      if (hcol_ok && x >= 0 && x < mb_w) {
+        const DbPrep *P = (const DbPrep *)(s_preps + (gh * 2 + (x & 1)) * sizeof(DbPrep));
         const int seg = cc >> 1;
         const uint32_t bs = *(const uint32_t *)&P->bsC[1][seg][0];
         if (bs) {
           const uint32_t c0 = *(const uint32_t *)&P->c0C[uvc][1][seg][0];
           const uint32_t abE = *(const uint16_t *)&P->ab[1 + uvc][1][0], abI = *(const uint16_t *)&P->ab[1 + uvc][2][0];
-          uint8_t *c = tc + uvc * CT_PLANE + cc;
+          uint8_t *c = s_tiles + (x & 3) * CT_BYTES + uvc * CT_PLANE + (RH * gh) * 8 + cc;
           int p[18];
 #pragma unroll
           for (int k = 0; k < 18; k++) p[k] = (k < RH + 2) ? c[k * 8] : 0;
@@ -441,25 +457,31 @@ __device__ void chroma_row(const RowArgs &A, int row, uint8_t *s_tiles /* 4 x CT
         }
       }
     } else {
-      if (x > 0) {
-        if (has_down && lane >= 48 && lane < 56 && (lane & 1)) {
-          const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1;
-          put_granule(hand_me + (long)(x - 1) * HAND_PER_MB + q, *((const uint32_t *)(tp + uv * CT_PLANE + (RH + r) * 8) + 1));
-        }
-        if (is_store) *(uint2 *)(store_p + 8 * (x - 1)) = *(const uint2 *)(tp + suv * CT_PLANE + (srow + 2) * 8);
+      const int xl = s - (nrows - 1);
+      if (has_down && xl >= 1 && xl <= mb_w && lane >= 48 && lane < 56 && (lane & 1)) {           // columns 4..7 after V(xl)
+        const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1;
+        put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + q, *((const uint32_t *)(s_tiles + ((xl - 1) & 3) * CT_BYTES + uv * CT_PLANE + (RH * nrows + r) * 8) + 1));
       }
-      if (x + 1 < mb_w) { if (is_own) *(uint2 *)(tn + uvr * CT_PLANE + (rr + 2) * 8) = own1; else if (is_pre) ((uint4 *)(s_preps + ((x + 1) & 1) * sizeof(DbPrep)))[lane - 40] = pre1; }
-      own1 = own2; pre1 = pre2;
+      {
+        const int xs = s - gs - 1;
+        if (store_ok && xs >= 0 && xs < mb_w) *(uint2 *)(store_p + 8 * xs) = *(const uint2 *)(s_tiles + (xs & 3) * CT_BYTES + su * CT_PLANE + st * 8);
+        const int xt = s - (nrows - 1) - 1;
+        if (tail_ok && xt >= 0 && xt < mb_w) *(uint2 *)(tail_p + 8 * xt) = *(const uint2 *)(s_tiles + (xt & 3) * CT_BYTES + tail_off);
+      }
+      { const int xo = s - gv + 1; if (vrow_ok && xo >= 1 && xo < mb_w) *(uint2 *)(s_tiles + (xo & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8) = own1; if (xo >= 1) own1 = own2; }
+      { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; if (xq >= 1) pre1 = pre2; }
     }
   }
   __syncthreads();
   if (!filter_wave) {
-    const uint8_t *tl = s_tiles + ((mb_w - 1) & 3) * CT_BYTES;
+    const int xe = mb_w - 1;
+    const uint8_t *tl = s_tiles + (xe & 3) * CT_BYTES;
     if (has_down && lane >= 48 && lane < 56) {
       const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1, c4 = q & 1;
-      put_granule(hand_me + (long)(mb_w - 1) * HAND_PER_MB + q, *((const uint32_t *)(tl + uv * CT_PLANE + (RH + r) * 8) + c4));
+      put_granule(hand_me + (long)xe * HAND_PER_MB + q, *((const uint32_t *)(tl + uv * CT_PLANE + (RH * nrows + r) * 8) + c4));
     }
-    if (is_store) *(uint2 *)(store_p + 8 * (mb_w - 1)) = *(const uint2 *)(tl + suv * CT_PLANE + (srow + 2) * 8);
+    if (store_ok && gs == nrows - 1) *(uint2 *)(store_p + 8 * xe) = *(const uint2 *)(tl + su * CT_PLANE + st * 8);
+    if (tail_ok) *(uint2 *)(tail_p + 8 * xe) = *(const uint2 *)(tl + tail_off);
   }
 }
 
@@ -473,11 +495,15 @@ __global__ __launch_bounds__(128) void k_deblock_rows(RowArgs A)
   if (tid == 0) { s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT); s_abort = 0; }
   for (int k = tid; k < (int)sizeof(s_tiles) / 4; k += 128) ((uint32_t *)s_tiles)[k] = 0;
   __syncthreads();
-  // tickets: first the luma bands top to bottom, then the chroma rows top to bottom -- a workgroup only ever waits for one
-  // with a smaller ticket, i.e. one that has already started
-  const int t = (int)s_ticket, nbands = (A.mb_h + LR - 1) / LR;
-  if (t < nbands) luma_rows(A, t, s_tiles, s_preps, &s_abort);
-  else if (A.nkinds > 1 && t - nbands < A.mb_h) chroma_row(A, t - nbands, s_tiles, s_preps, &s_abort);
+  // tickets: luma and chroma bands alternate, top to bottom -- a workgroup only ever waits for one with a smaller ticket,
+  // i.e. one that has already started
+  const int t = (int)s_ticket, CR = A.fmt == 2 ? 2 : 4;
+  const int nl = (A.mb_h + LR - 1) / LR, nc = A.nkinds > 1 ? (A.mb_h + CR - 1) / CR : 0;
+  // order: l0 c0 l1 c1 ... while both last, then the rest of the longer list
+  const int both = min(nl, nc);
+  if (t < 2 * both) { if (t & 1) chroma_rows(A, t >> 1, s_tiles, s_preps, &s_abort); else luma_rows(A, t >> 1, s_tiles, s_preps, &s_abort); }
+  else if (nl > both) { if (t - both < nl) luma_rows(A, t - both, s_tiles, s_preps, &s_abort); }
+  else if (t - both < nc) chroma_rows(A, t - both, s_tiles, s_preps, &s_abort);
 }
 
 // prep + rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
@@ -491,6 +517,6 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
   RowArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
   A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;
-  hipLaunchKernelGGL(k_deblock_rows, dim3((mb_h + LR - 1) / LR + (nkinds - 1) * mb_h), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_deblock_rows, dim3((mb_h + LR - 1) / LR + (nkinds > 1 ? (mb_h + (fmt == 2 ? 2 : 4) - 1) / (fmt == 2 ? 2 : 4) : 0)), dim3(128), 0, ctx->stream, A);
   return JMHIP_OK;
 }
