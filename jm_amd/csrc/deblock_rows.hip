@@ -208,7 +208,10 @@ __device__ __forceinline__ bool await_granules(const unsigned long long *g, bool
 // rows' macroblock of one column stacked (4 + 64 rows x 16 bytes), so row g's "top rows" simply ARE row g-1's bottom rows: inside
 // a band nothing is handed over at all; granules connect the last row of a band to the first row of the next band only.
 #define LR 4                                   // rows per luma workgroup
-#define YT_BYTES ((4 + 16 * LR) * 16)          // one ring slot
+// tall-tile row R lives at YROW(R): 16 bytes per row plus 16 bytes of padding after every 16 rows, so that the four rows' lanes of a
+// column access (same k, rows 16 apart) fall into different LDS banks
+#define YROW(R) ((R) * 16 + ((R) >> 4) * 16)
+#define YT_BYTES (YROW(4 + 16 * LR) + 16)      // one ring slot
 __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* LR x 2 x sizeof(DbPrep) */, volatile int *s_abort)
 {
   const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w;
@@ -234,15 +237,18 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
   const bool tail_ok = !has_down && lane < 4;                                 // rows 12..15 of the last row of the frame
   uint8_t *tail_p = band_p + (long)(16 * nrows - 4 + lane) * A.pitchY;
 
-  uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1;
+  // the mover keeps the own samples / records of the next THREE columns in registers: a load issued in step s is first
+  // needed in step s+2, so it never stalls the mover (and through the barrier the filter wave)
+  uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1, own3 = own1, pre3 = own1;
   unsigned long long gr = 0;
-  if (!filter_wave) {                                      // prologue: column 0 of every row, registers of column 1
+  if (!filter_wave) {                                      // prologue: column 0 of every row, registers of columns 1 and 2
     if (row_ok) own1 = *(const uint4 *)own_p;
     if (is_pre) pre1 = ((const uint4 *)pre_p)[pv];
     if (is_gran) gr = get_granule(hand_up);
-    if (row_ok) *(uint4 *)(s_tiles + (4 + lane) * 16) = own1;
+    if (row_ok) *(uint4 *)(s_tiles + YROW(4 + lane)) = own1;
     if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = pre1;
     if (mb_w > 1) { if (row_ok) own1 = *(const uint4 *)(own_p + 16); if (is_pre) pre1 = ((const uint4 *)(pre_p + 1))[pv]; }
+    if (mb_w > 2) { if (row_ok) own2 = *(const uint4 *)(own_p + 32); if (is_pre) pre2 = ((const uint4 *)(pre_p + 2))[pv]; }
   }
 
   const int nsteps = mb_w + nrows - 1;
@@ -259,8 +265,8 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
         const int seg = l >> 2;
         const uint32_t bs = *(const uint32_t *)&P->bsY[0][seg][0];
         if (bs) {
-          uint32_t *tl = (uint32_t *)(tp + (4 + lane) * 16) + 3;
-          uint4 *tr = (uint4 *)(tc + (4 + lane) * 16);
+          uint32_t *tl = (uint32_t *)(tp + YROW(4 + lane)) + 3;
+          uint4 *tr = (uint4 *)(tc + YROW(4 + lane));
           const uint32_t c0 = *(const uint32_t *)&P->c0Y[0][seg][0];
           const uint32_t abE = *(const uint16_t *)&P->ab[0][0][0], abI = *(const uint16_t *)&P->ab[0][2][0];
           const uint4 v = *tr;
@@ -281,14 +287,14 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
       const int xl = s - (nrows - 1);                      // column of the band's last row
       if (has_down && xl >= 1 && xl <= mb_w && lane >= 48) {                  // its bottom rows of column xl-1: columns 0..11 (V(xl) leaves them alone)
         const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
-        if (c4 < 3) put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + r * 4 + c4, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + (16 * nrows + r) * 16))[c4]);
+        if (c4 < 3) put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + r * 4 + c4, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + YROW(16 * nrows + r)))[c4]);
       }
       if (has_up && s < mb_w) {                            // the first row's top rows of column s
         if (!await_granules(hand_up + (long)s * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
-        if (is_gran) { ((uint32_t *)(s_tiles + (s & 3) * YT_BYTES + (lane >> 2) * 16))[lane & 3] = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
+        if (is_gran) { ((uint32_t *)(s_tiles + (s & 3) * YT_BYTES + YROW(lane >> 2)))[lane & 3] = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
       }
-      { const int xo = s - g + 2; if (row_ok && xo >= 2 && xo < mb_w) own2 = *(const uint4 *)(own_p + 16 * xo); }
-      { const int xq = s - pg + 2; if (is_pre && xq >= 2 && xq < mb_w) pre2 = ((const uint4 *)(pre_p + xq))[pv]; }
+      { const int xo = s - g + 3; if (row_ok && xo >= 3 && xo < mb_w) own3 = *(const uint4 *)(own_p + 16 * xo); }
+      { const int xq = s - pg + 3; if (is_pre && xq >= 3 && xq < mb_w) pre3 = ((const uint4 *)(pre_p + xq))[pv]; }
     }
     __syncthreads();                                       // V done; the band's top rows are in the slot
     if (*s_abort) return;
@@ -300,34 +306,34 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
         if (bs) {
           const uint32_t c0 = *(const uint32_t *)&P->c0Y[1][seg][0];
           const uint32_t abE = *(const uint16_t *)&P->ab[0][1][0], abI = *(const uint16_t *)&P->ab[0][2][0];
-          uint8_t *c = tc + (16 * g) * 16 + l;
+          uint8_t *c = tc + g * (16 * 16 + 16) + l;          // YROW(16 g + k) = g * 272 + k * 16 + (k >> 4) * 16
           int p[20];
 #pragma unroll
-          for (int k = 0; k < 20; k++) p[k] = c[k * 16];
+          for (int k = 0; k < 20; k++) p[k] = c[k * 16 + (k >> 4) * 16];
 #define HEDGE(E) { const int bS = (bs >> (8 * (E))) & 255; const uint32_t ab = (E) ? abI : abE; \
                    if (__any(bS)) luma_edge<4 * (E), 20>(p, bS, ab & 255, ab >> 8, (c0 >> (8 * (E))) & 255, __any(bS == 4)); }
           HEDGE(0) HEDGE(1) HEDGE(2) HEDGE(3)
 #undef HEDGE
 #pragma unroll
-          for (int k = 1; k < 19; k++) c[k * 16] = (uint8_t)p[k];
+          for (int k = 1; k < 19; k++) c[k * 16 + (k >> 4) * 16] = (uint8_t)p[k];
         }
       }
     } else {
       // ---- mover, while the horizontal edges run: column s-g-1 of row g is final for this band (V(s-g) is through its last columns)
       const int xl = s - (nrows - 1);
       if (has_down && xl >= 1 && xl <= mb_w && lane >= 48 && lane < 52)
-        put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + (lane - 48) * 4 + 3, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + (16 * nrows + lane - 48) * 16))[3]);
+        put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + (lane - 48) * 4 + 3, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + YROW(16 * nrows + lane - 48)))[3]);
       {
         const int xs = s - g - 1;                          // store: tall-tile rows 16g .. 16g+15 of the slot of xs = picture rows -4..11 of row g
-        if (store_ok && xs >= 0 && xs < mb_w) *(uint4 *)(store_p + 16 * xs) = *(const uint4 *)(s_tiles + (xs & 3) * YT_BYTES + lane * 16);
+        if (store_ok && xs >= 0 && xs < mb_w) *(uint4 *)(store_p + 16 * xs) = *(const uint4 *)(s_tiles + (xs & 3) * YT_BYTES + YROW(lane));
         const int xt = s - (nrows - 1) - 1;                // the frame's very last rows
-        if (tail_ok && xt >= 0 && xt < mb_w) *(uint4 *)(tail_p + 16 * xt) = *(const uint4 *)(s_tiles + (xt & 3) * YT_BYTES + (16 * nrows + lane) * 16);
+        if (tail_ok && xt >= 0 && xt < mb_w) *(uint4 *)(tail_p + 16 * xt) = *(const uint4 *)(s_tiles + (xt & 3) * YT_BYTES + YROW(16 * nrows + lane));
       }
-      { const int xo = s - g + 1; if (row_ok && xo >= 1 && xo < mb_w) *(uint4 *)(s_tiles + (xo & 3) * YT_BYTES + (4 + lane) * 16) = own1; }
+      { const int xo = s - g + 1; if (row_ok && xo >= 1 && xo < mb_w) *(uint4 *)(s_tiles + (xo & 3) * YT_BYTES + YROW(4 + lane)) = own1; }
       { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; }
       // the registers advance per row when that row has consumed them
-      { const int xo = s - g + 1; if (xo >= 1) own1 = own2; }
-      { const int xq = s - pg + 1; if (xq >= 1) pre1 = pre2; }
+      { const int xo = s - g + 1; if (xo >= 1) { own1 = own2; own2 = own3; } }
+      { const int xq = s - pg + 1; if (xq >= 1) { pre1 = pre2; pre2 = pre3; } }
     }
   }
   __syncthreads();                                         // the last horizontal edges are done
@@ -335,9 +341,9 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
     const int xe = mb_w - 1;
     const uint8_t *tl = s_tiles + (xe & 3) * YT_BYTES;
     // rows 0..nrows-2 stored their last column in the loop (their step mb_w-1+g+1 <= nsteps-1) except the band's last row
-    if (has_down && lane >= 48) put_granule(hand_me + (long)xe * HAND_PER_MB + (lane - 48), ((const uint32_t *)(tl + (16 * nrows + ((lane - 48) >> 2)) * 16))[(lane - 48) & 3]);
-    if (store_ok && g == nrows - 1) *(uint4 *)(store_p + 16 * xe) = *(const uint4 *)(tl + lane * 16);
-    if (tail_ok) *(uint4 *)(tail_p + 16 * xe) = *(const uint4 *)(tl + (16 * nrows + lane) * 16);
+    if (has_down && lane >= 48) put_granule(hand_me + (long)xe * HAND_PER_MB + (lane - 48), ((const uint32_t *)(tl + YROW(16 * nrows + ((lane - 48) >> 2))))[(lane - 48) & 3]);
+    if (store_ok && g == nrows - 1) *(uint4 *)(store_p + 16 * xe) = *(const uint4 *)(tl + YROW(lane));
+    if (tail_ok) *(uint4 *)(tail_p + 16 * xe) = *(const uint4 *)(tl + YROW(16 * nrows + lane));
   }
 }
 
@@ -377,8 +383,8 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
   uint8_t *tail_p = ((lane >> 1) ? A.V : A.U) + (long)(RH * (row0 + nrows) - 2 + (lane & 1)) * A.pitchC;
   const int tail_off = (lane >> 1) * CT_PLANE + (RH * nrows + (lane & 1)) * 8;
 
-  uint2 own1 = make_uint2(0, 0), own2 = own1;
-  uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1;
+  uint2 own1 = make_uint2(0, 0), own2 = own1, own3 = own1;
+  uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1, pre3 = pre1;
   unsigned long long gr = 0;
   if (!filter_wave) {
     if (vrow_ok) own1 = *(const uint2 *)own_p;
@@ -387,6 +393,7 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
     if (vrow_ok) *(uint2 *)(s_tiles + uvr * CT_PLANE + vt * 8) = own1;
     if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = pre1;
     if (mb_w > 1) { if (vrow_ok) own1 = *(const uint2 *)(own_p + 8); if (is_pre) pre1 = ((const uint4 *)(pre_p + 1))[pv]; }
+    if (mb_w > 2) { if (vrow_ok) own2 = *(const uint2 *)(own_p + 16); if (is_pre) pre2 = ((const uint4 *)(pre_p + 2))[pv]; }
   }
 
   const int nsteps = mb_w + nrows - 1;
@@ -426,8 +433,8 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
         if (!await_granules(hand_up + (long)s * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
         if (is_gran) { *(uint32_t *)(s_tiles + (s & 3) * CT_BYTES + goff) = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
       }
-      { const int xo = s - gv + 2; if (vrow_ok && xo >= 2 && xo < mb_w) own2 = *(const uint2 *)(own_p + 8 * xo); }
-      { const int xq = s - pg + 2; if (is_pre && xq >= 2 && xq < mb_w) pre2 = ((const uint4 *)(pre_p + xq))[pv]; }
+      { const int xo = s - gv + 3; if (vrow_ok && xo >= 3 && xo < mb_w) own3 = *(const uint2 *)(own_p + 8 * xo); }
+      { const int xq = s - pg + 3; if (is_pre && xq >= 3 && xq < mb_w) pre3 = ((const uint4 *)(pre_p + xq))[pv]; }
     }
     __syncthreads();
     if (*s_abort) return;
@@ -468,8 +475,8 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
         const int xt = s - (nrows - 1) - 1;
         if (tail_ok && xt >= 0 && xt < mb_w) *(uint2 *)(tail_p + 8 * xt) = *(const uint2 *)(s_tiles + (xt & 3) * CT_BYTES + tail_off);
       }
-      { const int xo = s - gv + 1; if (vrow_ok && xo >= 1 && xo < mb_w) *(uint2 *)(s_tiles + (xo & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8) = own1; if (xo >= 1) own1 = own2; }
-      { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; if (xq >= 1) pre1 = pre2; }
+      { const int xo = s - gv + 1; if (vrow_ok && xo >= 1 && xo < mb_w) *(uint2 *)(s_tiles + (xo & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8) = own1; if (xo >= 1) { own1 = own2; own2 = own3; } }
+      { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; if (xq >= 1) { pre1 = pre2; pre2 = pre3; } }
     }
   }
   __syncthreads();
