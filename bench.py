@@ -159,6 +159,7 @@ def main():
     ctx.set_current_dev(d_cur.data_ptr(), W)
     gathered = torch.empty((N, H, W), dtype=torch.uint8, device=dev) if N > 1 else None
     local_ref = torch.empty((HL, W), dtype=torch.uint8, device=dev)
+    ref_rows_idx = shard.reference_rows(band, halo, N * H).to(dev) if N > 1 else None
 
     mbw, mbh = W // 16, H // 16
     nmb = mbw * mbh
@@ -213,10 +214,8 @@ def main():
 
     def step(i, timed):
         if N > 1:                                                       # reference-frame exchange over xGMI (RCCL): the one collective
-            shard.exchange_reference(ref_band, band, halo, N * H, gathered=gathered, out=local_ref)
-        else:
-            local_ref.copy_(ref_band)
-        ctx.set_reference_dev(0, local_ref.data_ptr(), W)               # K5
+            shard.exchange_reference(ref_band, band, halo, N * H, gathered=gathered, out=local_ref, idx=ref_rows_idx)
+        ctx.set_reference_dev(0, (local_ref if N > 1 else ref_band).data_ptr(), W)   # K5
         if timed:
             fs_events[i][0].record(stream)
         ctx.me_fullsearch_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr())           # K1-K3

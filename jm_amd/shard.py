@@ -58,13 +58,14 @@ def reference_rows(band, halo, pic_height):
     return idx.clamp_(0, pic_height - 1)
 
 
-def exchange_reference(own_band_rows, band, halo, pic_height, group=None, gathered=None, out=None):
+def exchange_reference(own_band_rows, band, halo, pic_height, group=None, gathered=None, out=None, idx=None):
     """All-gather the reconstructed bands and return this rank's local reference (band + halos).
 
     own_band_rows : (16 * rows_per_band, W) uint8 -- the rank's reconstructed band, padded with arbitrary rows when the
                     band is shorter than rows_per_band (all_gather needs equal shapes)
     returns       : (band.height + 2 * halo, W) uint8
-    The one collective of the path; `gathered` / `out` let the caller reuse buffers across pictures."""
+    The one collective of the path; `gathered` / `out` / `idx` (= reference_rows(...) already on the device) let the caller reuse
+    buffers across pictures, so that a step issues exactly one collective and one gather kernel and no host-to-device copy."""
     world = dist.get_world_size(group)
     rows, width = own_band_rows.shape
     assert rows == 16 * band.rows_per_band, (rows, band)
@@ -74,7 +75,8 @@ def exchange_reference(own_band_rows, band, halo, pic_height, group=None, gather
     # bands are laid out back to back with a stride of 16*rows_per_band rows; picture row y lives at the same index as long as
     # every band but the last is full, which is how band_of() partitions
     tall = gathered.view(world * rows, width)
-    idx = reference_rows(band, halo, pic_height).to(own_band_rows.device)
+    if idx is None:
+        idx = reference_rows(band, halo, pic_height).to(own_band_rows.device)
     if out is None:
         out = torch.empty((idx.numel(), width), dtype=own_band_rows.dtype, device=own_band_rows.device)
     torch.index_select(tall, 0, idx, out=out)
