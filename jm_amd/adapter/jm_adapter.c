@@ -13,13 +13,15 @@
  *   full_search_motion_estimation lencod/src/me_fullsearch.c:39    Macroblock.IntPelME  mv_search.c:139-175   jmhip_me_fullsearch (one window job)
  *   sub_pel_motion_estimation   lencod/src/me_fullsearch.c:186     Macroblock.SubPelME                 jmhip_me_subpel
  *   setup_fast_full_search      lencod/src/me_fullfast.c:269       Macroblock.p_SetupFastFullPelSearch jmhip_me_sad_tables (BlockSAD tables; JM keeps its argmin)
+ *   residual_transform_quant_luma_4x4 lencod/src/block.c:661       Macroblock.residual_transform_quant_luma_4x4   jmhip_tq_luma4x4 ("dct_4x4" + quant_4x4)
+ *   residual_transform_quant_luma_8x8 (+_cavlc) lencod/src/transform8x8.c:522 / :604   Macroblock.residual_transform_quant_luma_8x8   jmhip_tq_luma8x8
  *   DeblockFrame                lencod/src/loopFilter.c:63         image.c:236                         jmhip_deblock_frame
  *   encode_one_slice            lencod/src/slice.c:431             image.c:210                         (hook only: uploads the current picture, then calls JM's own)
  *
  * A call whose configuration the device path does not implement (weighted prediction, chroma ME, SSE metric,
  * RDOptimization=0's (0,0) bonus, field/MBAFF pictures, 4:4:4, bit depth > 8, search range > 64) is passed to JM's own
  * function (__real_*) and counted; the counters are printed at exit.  JMHIP_ADAPTER=off passes everything through;
- * JMHIP_ADAPTER_PARTS=interp,fs,subpel,ffs,deblock selects a subset.  There is no CPU restatement in here: either
+ * JMHIP_ADAPTER_PARTS=interp,fs,subpel,ffs,tq4,tq8,deblock selects a subset.  There is no CPU restatement in here: either
  * the GPU serves a call or JM's own code does.
  *
  * This is per-call, synchronous offload: it demonstrates the drop-in boundary and bit-exactness inside the real
@@ -39,6 +41,10 @@
 #include "me_fullfast.h"
 #include "loop_filter.h"
 #include "img_luma.h"
+#include "block.h"
+#include "transform8x8.h"
+#include "quant4x4.h"
+#include "quant8x8.h"
 #include "slice.h"
 #include "jmhip.h"
 
@@ -46,7 +52,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8;
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
   StorablePicture *slot_pic[MAX_SLOTS];
@@ -55,15 +61,16 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8;
 } G;
 
 static void adapter_report(void)
 {
   if (!G.init_done) return;
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
-                  "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls\n",
-          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed);
+                  "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
+                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -102,6 +109,7 @@ static int adapter_on(VideoParameters *p_Vid)
     atexit(adapter_report);
     G.part_interp = has_part(parts, "interp"); G.part_fs = has_part(parts, "fs"); G.part_subpel = has_part(parts, "subpel");
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
+    G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -382,4 +390,129 @@ void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
                            G.dbmb, G.dbmo, p_Vid->active_sps->direct_8x8_inference_flag);
   if (rc) adapter_die("jmhip_deblock_frame", rc);
   G.n_deblock++;
+}
+
+/* ------------------------------------------------------------------ K7/K8: luma residual transform + quantisation + reconstruction
+ * ("dct_4x4()/quant_4x4()" of the north star).  One block per call, as JM's RDO loop asks for them. */
+static void fill_tq_common(Macroblock *currMB, int *cavlc, int *around)
+{
+  *cavlc = currMB->p_Slice->symbol_mode == CAVLC;
+  *around = currMB->p_Vid->AdaptiveRounding != 0;
+}
+
+extern int __real_residual_transform_quant_luma_4x4(Macroblock *, ColorPlane, int, int, int *, int);
+int __wrap_residual_transform_quant_luma_4x4(Macroblock *currMB, ColorPlane pl, int block_x, int block_y, int *coeff_cost, int intra)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  const int pos_x = block_x >> BLOCK_SHIFT, pos_y = block_y >> BLOCK_SHIFT;
+  const int b8 = 2 * (pos_y >> 1) + (pos_x >> 1) + (pl << 2), b4 = 2 * (pos_y & 1) + (pos_x & 1);
+  imgpel **img_enc = p_Vid->enc_picture->p_curr_img, **mb_pred = currSlice->mb_pred[pl];
+  int **mb_ores = currSlice->mb_ores[pl];
+  jmhip_tq_params prm;
+  jmhip_tq_out out;
+  uint8_t orig[16], pred[16];
+  int j, i, k, rc, cavlc, around, qp;
+  LevelQuantParams **q;
+  if (!adapter_on(p_Vid) || !G.part_tq4 || pl != PLANE_Y || currMB->is_field_mode || currSlice->disthres != 0 ||
+      (currSlice->quant_4x4 != quant_4x4_normal && currSlice->quant_4x4 != quant_4x4_around)) {
+    G.n_passed++;
+    return __real_residual_transform_quant_luma_4x4(currMB, pl, block_x, block_y, coeff_cost, intra);
+  }
+  fill_tq_common(currMB, &cavlc, &around);
+  qp = currMB->qp_scaled[pl];
+  q = p_Vid->p_Quant->q_params_4x4[pl][intra][qp];
+  memset(&prm, 0, sizeof prm);
+  for (j = 0; j < 4; j++)
+    for (i = 0; i < 4; i++) {
+      prm.q[j * 4 + i].OffsetComp = q[j][i].OffsetComp; prm.q[j * 4 + i].ScaleComp = q[j][i].ScaleComp; prm.q[j * 4 + i].InvScaleComp = q[j][i].InvScaleComp;
+      pred[j * 4 + i] = (uint8_t)mb_pred[block_y + j][block_x + i];
+      orig[j * 4 + i] = (uint8_t)(mb_pred[block_y + j][block_x + i] + mb_ores[block_y + j][block_x + i]);   /* the source sample */
+    }
+  prm.qp_per = p_Vid->p_Quant->qp_per_matrix[qp]; prm.cavlc = cavlc; prm.adaptive_rounding = currSlice->quant_4x4 == quant_4x4_around;
+  prm.adapt_rnd_weight = p_Vid->AdaptRndWeight; prm.max_pel = p_Vid->max_imgpel_value;
+  if ((rc = jmhip_tq_luma4x4(G.ctx, &prm, orig, pred, 1, &out))) adapter_die("jmhip_tq_luma4x4", rc);
+  G.n_tq4++;
+  currMB->subblock_x = ((b8 & 1) == 0) ? (((b4 & 1) == 0) ? 0 : 4) : (((b4 & 1) == 0) ? 8 : 12);     /* block.c:693-694 */
+  currMB->subblock_y = (b8 < 2) ? ((b4 < 2) ? 0 : 4) : ((b4 < 2) ? 8 : 12);
+  for (k = 0; k < out.ncoef; k++) { currSlice->cofAC[b8][b4][0][k] = out.level[k]; currSlice->cofAC[b8][b4][1][k] = out.run[k]; }
+  currSlice->cofAC[b8][b4][0][out.ncoef] = 0;
+  *coeff_cost += out.coeff_cost;
+  if (out.any_residual && prm.adaptive_rounding) {
+    int **fadj = &p_Vid->ARCofAdj4x4[pl][currMB->ar_mode][block_y];
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) fadj[j][block_x + i] = out.fadjust[j * 4 + i];
+  }
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) img_enc[currMB->pix_y + block_y + j][currMB->pix_x + block_x + i] = out.rec[j * 4 + i];
+  return out.nonzero;
+}
+
+/* residual_transform_quant_luma_4x4 is stored into its slot by select_transform() in the SAME translation unit that defines it
+ * (block.c:2364-2432), so no link-time reference exists to wrap; the slot itself is rebound right after JM fills it. */
+extern void __real_select_transform(Macroblock *);
+void __wrap_select_transform(Macroblock *currMB)
+{
+  __real_select_transform(currMB);
+  if (currMB->residual_transform_quant_luma_4x4 == __real_residual_transform_quant_luma_4x4)
+    currMB->residual_transform_quant_luma_4x4 = __wrap_residual_transform_quant_luma_4x4;
+}
+
+static int tq8_common(Macroblock *currMB, ColorPlane pl, int b8, int *coeff_cost, int intra, int cavlc_variant,
+                      int (*real)(Macroblock *, ColorPlane, int, int *, int))
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  const int block_x = 8 * (b8 & 1), block_y = 8 * (b8 >> 1), pl_off = b8 + (pl << 2);
+  imgpel **img_enc = p_Vid->enc_picture->p_curr_img, **mb_pred = currSlice->mb_pred[pl];
+  int **mb_ores = currSlice->mb_ores[pl];
+  jmhip_tq8_params prm;
+  jmhip_tq8_out out;
+  uint8_t orig[64], pred[64];
+  int j, i, k, l, rc, qp, around;
+  LevelQuantParams **q;
+  if (cavlc_variant) around = currSlice->quant_8x8cavlc == quant_8x8cavlc_around;
+  else around = currSlice->quant_8x8 == quant_8x8_around;
+  if (!adapter_on(p_Vid) || !G.part_tq8 || pl != PLANE_Y || currMB->is_field_mode || currSlice->disthres != 0 ||
+      (cavlc_variant ? (currSlice->quant_8x8cavlc != quant_8x8cavlc_normal && !around) : (currSlice->quant_8x8 != quant_8x8_normal && !around))) {
+    G.n_passed++;
+    return real(currMB, pl, b8, coeff_cost, intra);
+  }
+  qp = currMB->qp_scaled[pl];
+  q = p_Vid->p_Quant->q_params_8x8[pl][intra][qp];
+  memset(&prm, 0, sizeof prm);
+  for (j = 0; j < 8; j++)
+    for (i = 0; i < 8; i++) {
+      prm.q[j * 8 + i].OffsetComp = q[j][i].OffsetComp; prm.q[j * 8 + i].ScaleComp = q[j][i].ScaleComp; prm.q[j * 8 + i].InvScaleComp = q[j][i].InvScaleComp;
+      pred[j * 8 + i] = (uint8_t)mb_pred[block_y + j][block_x + i];
+      orig[j * 8 + i] = (uint8_t)(mb_pred[block_y + j][block_x + i] + mb_ores[block_y + j][block_x + i]);
+    }
+  prm.qp_per = p_Vid->p_Quant->qp_per_matrix[qp]; prm.cavlc = cavlc_variant; prm.adaptive_rounding = around;
+  prm.adapt_rnd_weight = p_Vid->AdaptRndWeight; prm.max_pel = p_Vid->max_imgpel_value;
+  if ((rc = jmhip_tq_luma8x8(G.ctx, &prm, orig, pred, 1, &out))) adapter_die("jmhip_tq_luma8x8", rc);
+  G.n_tq8++;
+  if (cavlc_variant) {                                     /* four lists, cofAC[pl_off][k] (transform8x8.c:643) */
+    for (l = 0; l < 4; l++) {
+      for (k = 0; k < out.ncoef[l]; k++) { currSlice->cofAC[pl_off][l][0][k] = out.level[17 * l + k]; currSlice->cofAC[pl_off][l][1][k] = out.run[17 * l + k]; }
+      currSlice->cofAC[pl_off][l][0][out.ncoef[l]] = 0;
+    }
+  } else {
+    for (k = 0; k < out.ncoef[0]; k++) { currSlice->cofAC[pl_off][0][0][k] = out.level[k]; currSlice->cofAC[pl_off][0][1][k] = out.run[k]; }
+    currSlice->cofAC[pl_off][0][0][out.ncoef[0]] = 0;
+  }
+  *coeff_cost += out.coeff_cost;
+  if (around && (cavlc_variant || out.any_residual)) {
+    int **fadj = &p_Vid->ARCofAdj8x8[pl][currMB->ar_mode][block_y];
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) fadj[j][block_x + i] = out.fadjust[j * 8 + i];
+  }
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) img_enc[currMB->pix_y + block_y + j][currMB->pix_x + block_x + i] = out.rec[j * 8 + i];
+  return out.nonzero;
+}
+extern int __real_residual_transform_quant_luma_8x8(Macroblock *, ColorPlane, int, int *, int);
+int __wrap_residual_transform_quant_luma_8x8(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra)
+{
+  return tq8_common(m, pl, b8, cc, intra, 0, __real_residual_transform_quant_luma_8x8);
+}
+extern int __real_residual_transform_quant_luma_8x8_cavlc(Macroblock *, ColorPlane, int, int *, int);
+int __wrap_residual_transform_quant_luma_8x8_cavlc(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra)
+{
+  return tq8_common(m, pl, b8, cc, intra, 1, __real_residual_transform_quant_luma_8x8_cavlc);
 }
