@@ -250,6 +250,19 @@ def main():
             md5s[tag] = dict(cfg=cfg, overrides={k: str(v) for k, v in o.items()},
                              md5_264=md5(os.path.join(w, "o.264")), md5_recon=md5(os.path.join(w, "o_rec.yuv")),
                              bytes_264=os.path.getsize(os.path.join(w, "o.264")))
+        # ---- G2 = BASELINE.json configs[1] at full size: synthetic 1080p (SURVEY.md Appendix A clip as bench.write_yuv makes it),
+        #      Baseline IPPP, FullSearch SR=32, 1 reference, two frames (I + P)
+        sys.path.insert(0, ROOT)
+        import bench
+        w = os.path.join(tmp, "G2"); os.makedirs(w)
+        bench.write_yuv(os.path.join(w, "syn1080p.yuv"), 2)
+        o = dict(InputFile="syn1080p.yuv", SourceWidth=1920, SourceHeight=1080, OutputWidth=1920, OutputHeight=1080, FramesToBeEncoded=2,
+                 SearchMode=-1, SearchRange=32, NumberReferenceFrames=1, LevelIDC=51)
+        run(EXE, "encoder_baseline.cfg", o, w)
+        md5s["G2"] = dict(cfg="encoder_baseline.cfg", overrides={k: str(v) for k, v in o.items()},
+                          md5_264=md5(os.path.join(w, "o.264")), md5_recon=md5(os.path.join(w, "o_rec.yuv")),
+                          bytes_264=os.path.getsize(os.path.join(w, "o.264")),
+                          input="bench.write_yuv(path, 2): SURVEY.md Appendix A clip, first two frames")
         json.dump(md5s, open(os.path.join(OUT, "md5.json"), "w"), indent=1, sort_keys=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -73,6 +73,36 @@ def test_lencod_with_libjmhip_writes_jm_bitstream(tmp_path, tag, must_run):
     assert md5(rec) == MD5[tag]["md5_recon"], (tag, "reconstruction differs from CPU JM", c)
 
 
+@pytest.mark.gpu
+def test_lencod_configs1_full_size_1080p(tmp_path):
+    """BASELINE.json configs[1] end to end at full size: synthetic 1080p, Baseline IPPP, FullSearch SR=32, one reference, I + P.
+    334,560 BlockMotionSearch calls of the P frame go to the device one by one (integer search + sub-pel refinement), plus the
+    sub-pel planes and the deblocking of both frames; transform/quant stays with JM here (3.3 M synchronous single-block calls
+    would only measure PCIe latency -- the QCIF cases above cover it).  The bitstream must equal CPU JM's (md5 of SURVEY.md 8c, G2)."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    tmp = str(tmp_path)
+    bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), 2)
+    e = MD5["G2"]
+    args = [EXE, "-d", os.path.join(G, "jm_baseline.cfg")]
+    for k, v in dict(e["overrides"], OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
+        args += ["-p", f"{k}={v}"]
+    env = dict(os.environ, JMHIP_ADAPTER_PARTS="interp,fs,subpel,deblock")
+    r = subprocess.run(args, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
+    c = counters(err)
+    assert c["fs"] > 300000 and c["subpel"] > 300000 and c["interp"] == 2 and c["deblock"] == 2, c
+    assert md5(os.path.join(tmp, "o.264")) == e["md5_264"], ("bitstream differs from CPU JM", c)
+    assert md5(os.path.join(tmp, "o_rec.yuv")) == e["md5_recon"], ("reconstruction differs from CPU JM", c)
+    m = re.search(r"^\s*0*1\(\s*P\s*\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout.decode(errors="replace"), re.M)
+    if m:
+        print(f"P frame with the hot path on the device (per-call offload): {m.group(1)} ms total, {m.group(2)} ms ME")
+
+
 def test_adapter_fails_loudly_without_a_device(tmp_path):
     """not gpu: on a box without a HIP device the adapter must stop the encoder, not fall back to the CPU."""
     import torch
