@@ -150,11 +150,24 @@ extern "C" int jmhip_debug_read_db_sync(jmhip_ctx *ctx, void *out, size_t bytes)
   return JMHIP_OK;
 }
 
+// The deblocking row pipeline raises a device-side error word when a bounded wait runs out (it never hangs); it is read
+// back at the next synchronisation point of a context that has launched the pipeline.
+int jmhip_check_deblock_error(jmhip_ctx *ctx)
+{
+  if (!ctx->db_launched) return JMHIP_OK;
+  unsigned words[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(words, ctx->d_db_sync, sizeof words, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->db_launched = 0;
+  if (words[1] != 0) return jmhip_fail(ctx, JMHIP_EHIP, "deblocking row pipeline: a hand-over wait timed out (error word %u); the frame is incomplete", words[1]);
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
 {
   if (!ctx) return JMHIP_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return JMHIP_OK;
+  return jmhip_check_deblock_error(ctx);
 }
 
 extern "C" int jmhip_plane_geometry(const jmhip_ctx *ctx, int32_t *pitch, int32_t *rows, int64_t *plane_stride)

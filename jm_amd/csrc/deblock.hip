@@ -148,6 +148,7 @@ extern "C" int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pit
   jmhip_time_begin(ctx, 4);
   if (aligned && !ctx->force_db_diag) {
     jmhip_launch_deblock_rows(ctx, d_Y, pitchY, d_U, d_V, pitchC, d_mbs, d_motion, direct8x8);
+    ctx->db_launched = 1;
   } else {
     const int nwaves = A.mb_w + 2 * (A.mb_h - 1);
     for (int w = 0; w < nwaves; w++) {
@@ -193,6 +194,7 @@ extern "C" int jmhip_deblock_frame(jmhip_ctx *ctx, uint16_t *imgY, int32_t pitch
   if ((r = jmhip_deblock_frame_dev(ctx, dY, W, fmt ? dU : NULL, fmt ? dV : NULL, cw, dm, dmo, direct8x8))) return r;
   HIPCHK(ctx, hipMemcpyAsync(st, dpix, ybytes + 2 * cbytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if ((r = jmhip_check_deblock_error(ctx))) return r;
   for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) imgY[(size_t)y * pitchY + x] = st[(size_t)y * W + x];
   for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) {
     imgU[(size_t)y * pitchC + x] = st[ybytes + (size_t)y * cw + x];

@@ -29,6 +29,7 @@ struct jmhip_ctx {
   unsigned me_launches;
   void *d_db_prep;       // deblocking: 192-byte strength/parameter record per macroblock (k_deblock_prep)
   unsigned *d_db_sync;   // deblocking row pipeline: ticket, error
+  int db_launched;       // the row pipeline ran since its error word was last read
   void *d_db_hand;       // deblocking row pipeline: 24 8-byte hand-over granules per macroblock
   int force_db_diag;     // JMHIP_DEBLOCK_DIAG=1: one launch per diagonal instead of the row pipeline (A/B testing)
   int timing;
@@ -49,6 +50,7 @@ void jmhip_time_begin(jmhip_ctx *ctx, int kind);
 void jmhip_time_end(jmhip_ctx *ctx, int kind);
 
 // kernels' launchers (defined next to the kernels)
+int jmhip_check_deblock_error(jmhip_ctx *ctx);
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);
 int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8);

@@ -96,7 +96,8 @@ def test_fullsearch_golden_records(fs):
     ctx.close()
 
 
-@pytest.mark.parametrize("w,h,R,seed", [(176, 144, 16, 1), (320, 192, 32, 2), (64, 48, 8, 3)])
+@pytest.mark.parametrize("w,h,R,seed", [(176, 144, 16, 1), (320, 192, 32, 2), (64, 48, 8, 3), (208, 112, 1, 4), (16, 16, 3, 5),
+                                        (144, 96, 48, 6), (80, 64, 64, 7), (1920, 1088, 31, 8)])
 def test_fullsearch_all_partitions_vs_oracle(J, w, h, R, seed):
     """window jobs with all 41 partitions, random predictors and centres, windows hanging off every
     picture edge; FS semantics (max_mvd 0) and FFS semantics (max_mvd guard)."""
@@ -132,6 +133,62 @@ def test_fullsearch_all_partitions_vs_oracle(J, w, h, R, seed):
             got = res[i]["best"][p]
             assert (int(got["mv_x"]), int(got["mv_y"]), int(got["cost"])) == (mv[0], mv[1], cost), (i, p)
     ctx.close()
+
+
+def test_fullsearch_ties_resolve_in_spiral_order(J):
+    """flat reference and current: every position has the same SAD, so the winner is decided by the MV rate and, among equal
+    rates, by JM's spiral order (strict '<', mv_search.c:405-442) -- the tie path of the reduction."""
+    from jm_amd.lib import ME_JOB, PARTITIONS
+    for R in (7, 32, 40):
+        w, h = 96, 80
+        ref = np.full((h, w), 77, np.uint8); cur = np.full((h, w), 80, np.uint8)
+        cur[40:44, 48:52] = 78                                            # a little structure in one 4x4
+        ctx = make_ctx(w, h, R=R)
+        ctx.set_reference(0, ref); ctx.set_current(cur)
+        oref = J.RefPic(ref)
+        jobs = np.zeros(3, ME_JOB)
+        for i, (c, lam) in enumerate([((0, 0), 0), ((8, -4), 5), ((-12, 20), 187)]):
+            jobs[i]["mb_x"], jobs[i]["mb_y"], jobs[i]["center_x"], jobs[i]["center_y"] = 48, 32, c[0], c[1]
+            jobs[i]["search_range"], jobs[i]["lambda"], jobs[i]["part_mask"] = R, lam, np.uint64((1 << 41) - 1)
+            jobs[i]["pred"][:, 0], jobs[i]["pred"][:, 1] = c[0] + 4 * (i - 1), c[1] - 4 * i
+        res = ctx.me_fullsearch(0, jobs)
+        for i, j in enumerate(jobs):
+            c = (int(j["center_x"]), int(j["center_y"]))
+            for p, (bt, bx, by, bw, bh) in enumerate(PARTITIONS):
+                pred = (int(j["pred"][p][0]), int(j["pred"][p][1]))
+                mv, cost, _ = J.full_search(oref, cur, 48 + bx, 32 + by, bw, bh, pred, c, R, int(j["lambda"]))
+                got = res[i]["best"][p]
+                assert (int(got["mv_x"]), int(got["mv_y"]), int(got["cost"])) == (mv[0], mv[1], cost), (R, i, p)
+        ctx.close()
+
+
+def test_empty_batches_and_bad_arguments():
+    """n = 0 is a no-op for every batched entry point; bad arguments come back as JMHIP_EINVAL with a message, nothing exits."""
+    import ctypes as C
+    from jm_amd.lib import ME_JOB, ME_RESULT, SUBPEL_JOB, CAND, JmHipError
+    ctx = make_ctx(64, 48, R=8)
+    ctx.set_reference(0, np.zeros((48, 64), np.uint8)); ctx.set_current(np.zeros((48, 64), np.uint8))
+    assert len(ctx.me_fullsearch(0, np.zeros(0, ME_JOB))) == 0
+    assert len(ctx.me_subpel(0, np.zeros(0, SUBPEL_JOB))) == 0
+    assert len(ctx.me_eval(0, np.zeros(0, CAND))) == 0
+    assert len(ctx.tq_luma4x4(ctx.tq_params(np.ones((16, 3)), 4), np.zeros((0, 16), np.uint8), np.zeros((0, 16), np.uint8))) == 0
+    assert len(ctx.tq_luma8x8(ctx.tq8_params(np.ones((64, 3)), 4), np.zeros((0, 64), np.uint8), np.zeros((0, 64), np.uint8))) == 0
+    assert len(ctx.forward4x4(np.zeros((0, 16), np.int32))) == 0
+    bad = np.zeros(1, ME_JOB); bad["search_range"] = 9                      # larger than the context's
+    with pytest.raises(JmHipError, match="search_range"):
+        ctx.me_fullsearch(0, bad)
+    bad["search_range"], bad["mb_x"] = 8, 64                                # outside the picture
+    with pytest.raises(JmHipError, match="outside"):
+        ctx.me_fullsearch(0, bad)
+    with pytest.raises(JmHipError):
+        ctx.set_reference(3, np.zeros((48, 64), np.uint8))                  # no such slot
+    with pytest.raises(JmHipError, match="qp_per"):
+        ctx.tq_luma4x4(ctx.tq_params(np.ones((16, 3)), 9), np.zeros((1, 16), np.uint8), np.zeros((1, 16), np.uint8))
+    ctx.close()
+    with pytest.raises(JmHipError, match="multiples of 16"):
+        make_ctx(100, 48)
+    with pytest.raises(JmHipError, match="search_range"):
+        make_ctx(64, 48, R=65)
 
 
 def test_fullsearch_fractional_centre(J):
