@@ -137,12 +137,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    # JMHIP_BENCH_ONE_GPU=1 (debugging aid, never used for a reported number): all ranks share GPU 0 and the exchange goes through
+    # gloo on host copies, so the N > 1 code path can be exercised on a single-GPU box
+    one_gpu = os.environ.get("JMHIP_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from jm_amd import shard
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     N = world
     band = shard.band_of(rank, N, (H // 16) * N)        # one tall picture of N 1080p bands, one band (slice) per GPU
     halo = shard.halo_rows(R, MAX_VMV) if N > 1 else 0               # rows of neighbouring bands a band's search windows can read: 576
@@ -213,7 +221,9 @@ def main():
     fs_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i, timed):
-        if N > 1:                                                       # reference-frame exchange over xGMI (RCCL): the one collective
+        if N > 1 and one_gpu:                                           # debugging path: the same exchange on host copies over gloo
+            local_ref.copy_(shard.exchange_reference(ref_band.cpu(), band, halo, N * H))
+        elif N > 1:                                                     # reference-frame exchange over xGMI (RCCL): the one collective
             shard.exchange_reference(ref_band, band, halo, N * H, gathered=gathered, out=local_ref, idx=ref_rows_idx)
         ctx.set_reference_dev(0, (local_ref if N > 1 else ref_band).data_ptr(), W)   # K5
         if timed:
@@ -240,7 +250,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if N > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fs_ms = float(np.mean([a.elapsed_time(b) for a, b in fs_events]))
