@@ -91,4 +91,12 @@ __device__ __forceinline__ bool job_is_fast(const jmhip_me_job *__restrict__ job
   return true;
 }
 
+// Workgroup b runs on XCD b % 8 (observed placement, used for speed only): give every XCD a CONTIGUOUS run of jobs, so that jobs
+// whose search windows / candidate blocks share cache lines (horizontal neighbours) also share an L2.  A bijection of [0, n).
+__device__ __forceinline__ int xcd_job_index(int b, int n)
+{
+  const int k = b & 7, q = n >> 3, r = n & 7;
+  return k * q + (k < r ? k : r) + (b >> 3);
+}
+
 void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined);

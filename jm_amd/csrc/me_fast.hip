@@ -124,12 +124,13 @@ __device__ __forceinline__ double key_as_double(unsigned cost, unsigned idx)
 __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
-                                                       const int16_t *__restrict__ spiral, unsigned *__restrict__ declined)
+                                                       const int16_t *__restrict__ spiral, unsigned *__restrict__ declined, int njobs)
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[COPY_DWORDS > MERGE_DWORDS ? COPY_DWORDS : MERGE_DWORDS];   // window copies, later the wave-merge area
   __shared__ __attribute__((aligned(16))) uint32_t s_ry[65 * RYP];            // (lambda * mvbits(cand_y - pred_y[p])) << 7, [row][partition]
   __shared__ uint32_t s_rx64[RYP];                                              // x rate of column 64, per partition
-  const jmhip_me_job *__restrict__ job = jobs + blockIdx.x;
+  const int jb = xcd_job_index(blockIdx.x, njobs);
+  const jmhip_me_job *__restrict__ job = jobs + jb;
   if (!job_is_fast(job)) {                                  // left to k_me_fullsearch, which only does real work when this counter is non-zero
     if (threadIdx.x == 0) atomicAdd(declined, 1u);
     return;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
         jmhip_me_best b;
         b.mv_x = (int16_t)(cx + 4 * spiral[2 * idx]); b.mv_y = (int16_t)(cy + 4 * spiral[2 * idx + 1]);
         b.cost = (int32_t)cost;
-        results[blockIdx.x].best[p] = b;
+        results[jb].best[p] = b;
       }
     }
   }
@@ -351,5 +352,5 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
 void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined)
 {
   hipLaunchKernelGGL(k_me_fs_fast, dim3(njobs), dim3(NT), 0, ctx->stream, d_jobs, d_results, ctx->d_cur, ctx->cur_pitch,
-                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, d_declined);
+                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, d_declined, njobs);
 }

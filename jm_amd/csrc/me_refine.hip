@@ -15,6 +15,7 @@
 // sums are formed with LDS atomics.  41 lanes then replay JM's sequential strict-'<' scan over the 9 costs.
 // With the 8x8 transform (test8x8, block types 1-4) the unit is an 8x8 block (Hadamard 8x8), led by the lane of its top-left 4x4.
 #include "jmhip_internal.h"
+#include "me_common.h"
 
 struct PlaneSet2 { const uint8_t *base; int pitch; long plane_stride; int W, H; };
 
@@ -120,19 +121,20 @@ __device__ __forceinline__ int part_of(int t, int bx4, int by4)
 template <bool T8MODE>
 __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
                                                       jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
-                                                      PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch)
+                                                      PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch, int njobs)
 {
   __shared__ uint32_t s_cur[64];                  // the current macroblock, 16 rows x 4 dwords
   __shared__ int s_mv[JMHIP_NPART][2];            // per partition: the motion vector the running stage refines
   __shared__ int s_min[JMHIP_NPART];              // min_mcost carried between the stages
   __shared__ unsigned s_dist[JMHIP_NPART * 9];    // distortion of (partition, candidate), summed over its 4x4 / 8x8 blocks
   const int tid = threadIdx.x;
-  const jmhip_me_job *job = jobs + blockIdx.x;
+  const int jb = xcd_job_index(blockIdx.x, njobs);
+  const jmhip_me_job *job = jobs + jb;
   const uint64_t mask = job->part_mask;
   const int mb_x = job->mb_x, mb_y = job->mb_y;
   if (tid < 64) s_cur[tid] = *(const uint32_t *)(cur + (long)(mb_y + (tid >> 2)) * cur_pitch + mb_x + 4 * (tid & 3));
   if (tid < JMHIP_NPART) {
-    const jmhip_me_best ib = ires[blockIdx.x].best[tid];
+    const jmhip_me_best ib = ires[jb].best[tid];
     s_mv[tid][0] = ib.mv_x; s_mv[tid][1] = ib.mv_y;
     s_min[tid] = prm.start_hp ? ib.cost : COST_MAX;                              // mv_search.c:971-974
   }
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__rest
   if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
     jmhip_me_best b;
     b.mv_x = (int16_t)s_mv[tid][0]; b.mv_y = (int16_t)s_mv[tid][1]; b.cost = s_min[tid];
-    out[blockIdx.x].best[tid] = b;
+    out[jb].best[tid] = b;
   }
 }
 
@@ -214,7 +216,7 @@ void jmhip_launch_refine_mb(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs
 {
   PlaneSet2 ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H;
   if (prm->transform8x8_mode)
-    hipLaunchKernelGGL(k_me_refine_mb<true>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch);
+    hipLaunchKernelGGL(k_me_refine_mb<true>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
   else
-    hipLaunchKernelGGL(k_me_refine_mb<false>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch);
+    hipLaunchKernelGGL(k_me_refine_mb<false>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
 }
