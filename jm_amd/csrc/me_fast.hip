@@ -62,9 +62,14 @@ __device__ __forceinline__ void sad_pair(const uint2 *cp /* lane's copy + column
 #pragma unroll
   for (int k = 0; k < 16; k++) { sa[k] = 0; sb[k] = 0; }
   const uint2 *row = cp + wy * (CPITCH / 2);
+  // the two 8-byte halves are read by separate ds_read_b64: with the copy stride of 8 banks the 32 lanes of a half-wave cover all
+  // 64 banks exactly once per read, whereas one 16-byte read at 8-byte alignment makes neighbouring lanes' windows overlap by two
+  // banks (31 % of the LDS cycles were bank conflicts); hiding the adjacency keeps the compiler from merging them
+  const uint2 *rowh = row + 1;
+  asm volatile("" : "+v"(rowh));
 #pragma unroll
   for (int r = 0; r < (TWO ? 17 : 16); r++) {
-    const uint2 lo = row[0], hi = row[1];
+    const uint2 lo = row[0], hi = rowh[0];
     if (r < 16) {
       const int q = (r >> 2) * 4;
       sa[q + 0] = __builtin_amdgcn_sad_u8(lo.x, cw[r * 4 + 0], sa[q + 0]);
@@ -79,7 +84,7 @@ __device__ __forceinline__ void sad_pair(const uint2 *cp /* lane's copy + column
       sb[q + 2] = __builtin_amdgcn_sad_u8(hi.x, cw[(r - 1) * 4 + 2], sb[q + 2]);
       sb[q + 3] = __builtin_amdgcn_sad_u8(hi.y, cw[(r - 1) * 4 + 3], sb[q + 3]);
     }
-    row += CPITCH / 2;
+    row += CPITCH / 2; rowh += CPITCH / 2;
   }
 }
 
