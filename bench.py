@@ -32,8 +32,9 @@ sys.path.insert(0, ROOT)
 W, H_SRC, H = 1920, 1080, 1088
 R = 32
 QP = 28
-TRAFFIC_BYTES = 40283280   # HBM bytes per launch of k_me_fs_fast: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command,
-                           # corrected as MI355X_MICROARCH.md prescribes (profiles/r01_v4_kernel_stats.md); below the algorithmic 57.0 MB (L2 window overlap)
+TRAFFIC_BYTES = 12219816   # HBM bytes per launch of k_me_fs_fast: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command,
+                           # corrected as MI355X_MICROARCH.md prescribes (profiles/r01_v5_kernel_stats.md); far below the algorithmic 57.0 MB: neighbouring windows
+                           # overlap and, with the XCD-aware job order, meet in the same L2
 MAX_VMV = 512       # level-4/5.1 vertical MV limit in pels (lencod/src/conformance.c:604-631): a search centre can sit this far away
 
 
