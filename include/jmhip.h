@@ -230,6 +230,36 @@ typedef struct {
 int jmhip_tq_luma8x8(jmhip_ctx *ctx, const jmhip_tq8_params *prm, const uint8_t *orig, const uint8_t *pred, int32_t nblocks, jmhip_tq8_out *out);
 int jmhip_tq_luma8x8_dev(jmhip_ctx *ctx, const jmhip_tq8_params *prm, const uint8_t *d_orig, const uint8_t *d_pred, int32_t nblocks, jmhip_tq8_out *d_out);
 
+/* Chroma residual of one plane of a macroblock: residual_transform_quant_chroma_4x4 (lencod/src/block.c:954-1200, slot
+ * Macroblock.residual_transform_quant_chroma_4x4[uv], global.h:467) = forward4x4 per 4x4 block, the DC path (4:2:0: hadamard2x2 +
+ * quant_dc2x2 + ihadamard2x2; 4:2:2: hadamard4x2 + quant_dc4x2 at qp+3 + ihadamard4x2; lencod/src/quantChroma_normal.c:37 / :110),
+ * quant_ac4x4_normal / _around per block (quant4x4_normal.c:117 / quant4x4_around.c:129), the _CHROMA_COEFF_COST_ thresholding,
+ * inverse4x4 and reconstruction; cbp_blk / cr_cbp are updated exactly as JM updates Macroblock.cbp_blk and the returned cr_cbp
+ * (including the sign extension of JM's 32-bit DC mask for the V plane of 4:2:2).  Frame scan, disthres 0. */
+typedef struct {
+  jmhip_qparam q_ac[16];            /* p_Quant->q_params_4x4[uv+1][intra][cur_qp][j][i] at j*4+i */
+  jmhip_qparam q_dc;                /* 4:2:0: the [0][0] entry of the same table; 4:2:2: of the table at cur_qp + 3 */
+  int32_t qp_per_ac, qp_per_dc;     /* qp_per_matrix[cur_qp], qp_per_matrix[cur_qp (+3 for 4:2:2)] */
+  int32_t yuv_format;               /* 1 = 4:2:0 (8x8 samples per plane), 2 = 4:2:2 (8x16) */
+  int32_t cavlc, adaptive_rounding, adapt_rnd_weight, max_pel;
+  int32_t reserved_[2];
+} jmhip_tqc_params;                 /* 240 bytes; uniform per launch */
+typedef struct { int64_t cbp_blk; int32_t cr_cbp; int32_t uv; } jmhip_tqc_mb;      /* per item, in/out: Macroblock.cbp_blk, cr_cbp; plane 0 = U, 1 = V */
+typedef struct {
+  int16_t dc_level[9];              /* cofDC[uv+1][0], 0-terminated */
+  uint8_t dc_run[9];                /* cofDC[uv+1][1] */
+  uint8_t dc_nonzero;
+  int16_t ac_level[8][16];          /* cofAC[4 + b8 + uv_scale][b4][0], block k = 4*b8 + b4 = raster order of the plane's 4x4 blocks */
+  uint8_t ac_run[8][16];
+  uint8_t ac_ncoef[8];
+  uint8_t rec[128];                 /* reconstructed samples, rows of 8 (4:2:0: the first 64) */
+  int16_t fadjust[128];             /* ARCofAdj4x4 update (adaptive rounding; AC positions only, as in JM) */
+  uint8_t reserved_[4];
+} jmhip_tqc_out;                    /* 808 bytes */
+/* orig / pred: n items x 128 samples (rows of 8, uint8). */
+int jmhip_tq_chroma(jmhip_ctx *ctx, const jmhip_tqc_params *prm, jmhip_tqc_mb *mbs, const uint8_t *orig, const uint8_t *pred,
+                    int32_t nitems, jmhip_tqc_out *out);
+
 /* The DC transforms of lcommon/src/transform.c, batched over blocks of int32 (row-major):
  *   HADAMARD4x4 :121 / IHADAMARD4x4 :170   16 values (Intra16x16 luma DC)
  *   HADAMARD4x2 :220 / IHADAMARD4x2 :258   8 values, rows [2][4]; the inverse returns JM's transposed [4][2] layout (4:2:2 chroma DC)

@@ -15,13 +15,14 @@
  *   setup_fast_full_search      lencod/src/me_fullfast.c:269       Macroblock.p_SetupFastFullPelSearch jmhip_me_sad_tables (BlockSAD tables; JM keeps its argmin)
  *   residual_transform_quant_luma_4x4 lencod/src/block.c:661       Macroblock.residual_transform_quant_luma_4x4   jmhip_tq_luma4x4 ("dct_4x4" + quant_4x4)
  *   residual_transform_quant_luma_8x8 (+_cavlc) lencod/src/transform8x8.c:522 / :604   Macroblock.residual_transform_quant_luma_8x8   jmhip_tq_luma8x8
+ *   residual_transform_quant_chroma_4x4 lencod/src/block.c:954     Macroblock.residual_transform_quant_chroma_4x4[uv]   jmhip_tq_chroma
  *   DeblockFrame                lencod/src/loopFilter.c:63         image.c:236                         jmhip_deblock_frame
  *   encode_one_slice            lencod/src/slice.c:431             image.c:210                         (hook only: uploads the current picture, then calls JM's own)
  *
  * A call whose configuration the device path does not implement (weighted prediction, chroma ME, SSE metric,
  * RDOptimization=0's (0,0) bonus, field/MBAFF pictures, 4:4:4, bit depth > 8, search range > 64) is passed to JM's own
  * function (__real_*) and counted; the counters are printed at exit.  JMHIP_ADAPTER=off passes everything through;
- * JMHIP_ADAPTER_PARTS=interp,fs,subpel,ffs,tq4,tq8,deblock selects a subset.  There is no CPU restatement in here: either
+ * JMHIP_ADAPTER_PARTS=interp,fs,subpel,ffs,tq4,tq8,tqc,deblock selects a subset.  There is no CPU restatement in here: either
  * the GPU serves a call or JM's own code does.
  *
  * This is per-call, synchronous offload: it demonstrates the drop-in boundary and bit-exactness inside the real
@@ -52,7 +53,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc;
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
   StorablePicture *slot_pic[MAX_SLOTS];
@@ -61,7 +62,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc;
 } G;
 
 static void adapter_report(void)
@@ -69,8 +70,8 @@ static void adapter_report(void)
   if (!G.init_done) return;
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
-                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8\n",
-          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8);
+                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -109,7 +110,7 @@ static int adapter_on(VideoParameters *p_Vid)
     atexit(adapter_report);
     G.part_interp = has_part(parts, "interp"); G.part_fs = has_part(parts, "fs"); G.part_subpel = has_part(parts, "subpel");
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
-    G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8");
+    G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -448,12 +449,68 @@ int __wrap_residual_transform_quant_luma_4x4(Macroblock *currMB, ColorPlane pl, 
 
 /* residual_transform_quant_luma_4x4 is stored into its slot by select_transform() in the SAME translation unit that defines it
  * (block.c:2364-2432), so no link-time reference exists to wrap; the slot itself is rebound right after JM fills it. */
+/* residual_transform_quant_chroma_4x4 (block.c:954): one plane of the macroblock per call */
+extern int residual_transform_quant_chroma_4x4(Macroblock *, int, int);
+static int jmhip_rtq_chroma(Macroblock *currMB, int uv, int cr_cbp)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  const int yuv = p_Vid->yuv_format, H = p_Vid->mb_cr_size_y, intra = is_intra(currMB);
+  const int cur_qp = currMB->qpc[uv] + currSlice->bitdepth_chroma_qp_scale, qp_dc = yuv == YUV422 ? cur_qp + 3 : cur_qp;
+  const int uv_scale = uv * (p_Vid->num_blk8x8_uv >> 1), nblk = H / 2;
+  imgpel **mb_pred = currSlice->mb_pred[uv + 1];
+  int **mb_ores = currSlice->mb_ores[uv + 1];
+  jmhip_tqc_params prm;
+  jmhip_tqc_mb mb;
+  jmhip_tqc_out out;
+  uint8_t orig[128], pred[128];
+  LevelQuantParams **qa, *qd;
+  int j, i, k, c, rc, around;
+  if (!adapter_on(p_Vid) || !G.part_tqc || (yuv != YUV420 && yuv != YUV422) || currMB->is_field_mode || currSlice->disthres != 0 ||
+      p_Vid->mb_cr_size_x != 8 || (currSlice->quant_ac4x4cr != quant_ac4x4_normal && currSlice->quant_ac4x4cr != quant_ac4x4_around)) {
+    G.n_passed++;
+    return residual_transform_quant_chroma_4x4(currMB, uv, cr_cbp);
+  }
+  around = currSlice->quant_ac4x4cr == quant_ac4x4_around;
+  qa = p_Vid->p_Quant->q_params_4x4[uv + 1][intra][cur_qp];
+  qd = &p_Vid->p_Quant->q_params_4x4[uv + 1][intra][qp_dc][0][0];
+  memset(&prm, 0, sizeof prm); memset(orig, 0, sizeof orig); memset(pred, 0, sizeof pred);
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) {
+    prm.q_ac[j * 4 + i].OffsetComp = qa[j][i].OffsetComp; prm.q_ac[j * 4 + i].ScaleComp = qa[j][i].ScaleComp; prm.q_ac[j * 4 + i].InvScaleComp = qa[j][i].InvScaleComp;
+  }
+  prm.q_dc.OffsetComp = qd->OffsetComp; prm.q_dc.ScaleComp = qd->ScaleComp; prm.q_dc.InvScaleComp = qd->InvScaleComp;
+  prm.qp_per_ac = p_Vid->p_Quant->qp_per_matrix[cur_qp]; prm.qp_per_dc = p_Vid->p_Quant->qp_per_matrix[qp_dc];
+  prm.yuv_format = yuv; prm.cavlc = currSlice->symbol_mode == CAVLC; prm.adaptive_rounding = around;
+  prm.adapt_rnd_weight = p_Vid->AdaptRndWeight; prm.max_pel = p_Vid->max_pel_value_comp[uv + 1];
+  for (j = 0; j < H; j++) for (i = 0; i < 8; i++) { pred[j * 8 + i] = (uint8_t)mb_pred[j][i]; orig[j * 8 + i] = (uint8_t)(mb_pred[j][i] + mb_ores[j][i]); }
+  mb.cbp_blk = currMB->cbp_blk; mb.cr_cbp = cr_cbp; mb.uv = uv;
+  if ((rc = jmhip_tq_chroma(G.ctx, &prm, &mb, orig, pred, 1, &out))) adapter_die("jmhip_tq_chroma", rc);
+  G.n_tqc++;
+  p_Vid->is_v_block = uv;                                  /* block.c:1008 */
+  currMB->cbp_blk = mb.cbp_blk;
+  for (k = 0; k < 9; k++) { currSlice->cofDC[uv + 1][0][k] = out.dc_level[k]; currSlice->cofDC[uv + 1][1][k] = out.dc_run[k]; }
+  for (k = 0; k < nblk; k++) {
+    int *lev = currSlice->cofAC[4 + (k >> 2) + uv_scale][k & 3][0], *run = currSlice->cofAC[4 + (k >> 2) + uv_scale][k & 3][1];
+    for (c = 0; c < 16; c++) { lev[c] = out.ac_level[k][c]; run[c] = out.ac_run[k][c]; }
+  }
+  /* the last block's coeff_count context position, as JM leaves it (block.c:1108-1109) */
+  currMB->subblock_y = (short)(4 * ((nblk - 1) >> 1) & 0xf); currMB->subblock_x = (short)(4 * ((nblk - 1) & 1));
+  if (around) {
+    int **fadj = (currMB->mb_type == P8x8 && currMB->luma_transform_size_8x8_flag) ? p_Vid->ARCofAdj4x4[uv + 1][4] : p_Vid->ARCofAdj4x4[uv + 1][currMB->ar_mode];
+    for (j = 0; j < H; j++) for (i = 0; i < 8; i++) if ((j & 3) || (i & 3)) fadj[j][i] = out.fadjust[j * 8 + i];     /* AC positions only */
+  }
+  for (j = 0; j < H; j++) for (i = 0; i < 8; i++) p_Vid->enc_picture->imgUV[uv][currMB->pix_c_y + j][currMB->pix_c_x + i] = out.rec[j * 8 + i];
+  return mb.cr_cbp;
+}
+
 extern void __real_select_transform(Macroblock *);
 void __wrap_select_transform(Macroblock *currMB)
 {
   __real_select_transform(currMB);
   if (currMB->residual_transform_quant_luma_4x4 == __real_residual_transform_quant_luma_4x4)
     currMB->residual_transform_quant_luma_4x4 = __wrap_residual_transform_quant_luma_4x4;
+  if (currMB->residual_transform_quant_chroma_4x4[0] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[0] = jmhip_rtq_chroma;
+  if (currMB->residual_transform_quant_chroma_4x4[1] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[1] = jmhip_rtq_chroma;
 }
 
 static int tq8_common(Macroblock *currMB, ColorPlane pl, int b8, int *coeff_cost, int intra, int cavlc_variant,

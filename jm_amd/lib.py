@@ -43,6 +43,12 @@ TQ8_PARAMS = np.dtype([("q", "<i4", (64, 3)), ("qp_per", "<i4"), ("cavlc", "<i4"
                        ("adapt_rnd_weight", "<i4"), ("max_pel", "<i4"), ("reserved_", "<i4", (3,))])
 TQ8_OUT = np.dtype([("level", "<i2", (68,)), ("run", "u1", (68,)), ("coeff_cost", "<i4"), ("nonzero", "u1"), ("any_residual", "u1"),
                     ("ncoef", "u1", (4,)), ("reserved_", "u1", (2,)), ("rec", "u1", (64,)), ("fadjust", "<i2", (64,))])
+TQC_PARAMS = np.dtype([("q_ac", "<i4", (16, 3)), ("q_dc", "<i4", (3,)), ("qp_per_ac", "<i4"), ("qp_per_dc", "<i4"), ("yuv_format", "<i4"),
+                       ("cavlc", "<i4"), ("adaptive_rounding", "<i4"), ("adapt_rnd_weight", "<i4"), ("max_pel", "<i4"), ("reserved_", "<i4", (2,))])
+TQC_MB = np.dtype([("cbp_blk", "<i8"), ("cr_cbp", "<i4"), ("uv", "<i4")])
+TQC_OUT = np.dtype([("dc_level", "<i2", (9,)), ("dc_run", "u1", (9,)), ("dc_nonzero", "u1"), ("ac_level", "<i2", (8, 16)), ("ac_run", "u1", (8, 16)),
+                    ("ac_ncoef", "u1", (8,)), ("rec", "u1", (128,)), ("fadjust", "<i2", (128,)), ("reserved_", "u1", (4,))])
+assert TQC_PARAMS.itemsize == 240 and TQC_MB.itemsize == 16 and TQC_OUT.itemsize == 808
 DC_OUT = np.dtype([("level", "<i2", (17,)), ("run", "u1", (17,)), ("nonzero", "u1")])
 assert TQ8_PARAMS.itemsize == 800 and TQ8_OUT.itemsize == 408 and DC_OUT.itemsize == 52
 DC_KINDS = {"hadamard4x4": (0, 16), "ihadamard4x4": (1, 16), "hadamard4x2": (2, 8), "ihadamard4x2": (3, 8), "hadamard2x2": (4, 4), "ihadamard2x2": (5, 4)}
@@ -58,7 +64,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
-           "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4",
+           "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -273,6 +279,19 @@ class JmHip:
 
     def tq_luma8x8_dev(self, prm, d_orig, d_pred, n, d_out):
         self._ck(self.lib.jmhip_tq_luma8x8_dev(self.h, _vp(prm), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
+
+    def tq_chroma(self, yuv, q_ac, q_dc, qp_per_ac, qp_per_dc, cavlc, adaptive_rounding, adapt_rnd_weight, mbs, orig, pred, max_pel=255):
+        """residual_transform_quant_chroma_4x4 (lencod/src/block.c:954), batched over (macroblock, plane) items.
+        mbs: TQC_MB array (updated copy returned); orig / pred: (n, 128) uint8, rows of 8 samples."""
+        p = np.zeros(1, TQC_PARAMS)
+        p["q_ac"][0] = np.asarray(q_ac, np.int32).reshape(16, 3); p["q_dc"][0] = np.asarray(q_dc, np.int32).reshape(3)
+        p["qp_per_ac"], p["qp_per_dc"], p["yuv_format"], p["cavlc"] = qp_per_ac, qp_per_dc, yuv, cavlc
+        p["adaptive_rounding"], p["adapt_rnd_weight"], p["max_pel"] = adaptive_rounding, adapt_rnd_weight, max_pel
+        mbs = np.ascontiguousarray(mbs, TQC_MB).copy()
+        orig = np.ascontiguousarray(orig, np.uint8).reshape(-1, 128); pred = np.ascontiguousarray(pred, np.uint8).reshape(-1, 128)
+        out = np.zeros(len(mbs), TQC_OUT)
+        self._ck(self.lib.jmhip_tq_chroma(self.h, _vp(p), _vp(mbs), _vp(orig), _vp(pred), len(mbs), _vp(out)))
+        return mbs, out
 
     def dc_transform(self, name, x):
         """hadamard4x4 / ihadamard4x4 / hadamard4x2 / ihadamard4x2 / hadamard2x2 / ihadamard2x2 (lcommon/src/transform.c:121-330)."""

@@ -148,6 +148,11 @@ int jmo_quant_dc4x4_normal(int tblock[16], const jmo_qparam *q, int qp_per, int 
 int jmo_rtq_luma_8x8(const jmo_pel orig[64], const jmo_pel pred[64], const jmo_qparam q[64], int qp_per, int cavlc,
                      int adaptive_rounding, int adapt_rnd_weight, int max_pel, int level[68], int run[68], int *coeff_cost,
                      jmo_pel rec[64], int fadjust[64], int *any_residual);
+/* residual_transform_quant_chroma_4x4 block.c:954-1200, one plane of one macroblock (see jmo_tq.c) */
+int jmo_rtq_chroma(int yuv, int uv, int cr_cbp, int64_t *cbp_blk, const jmo_qparam q_ac[16], const jmo_qparam *q_dc,
+                   int qp_per_ac, int qp_per_dc, int cavlc, int adaptive_rounding, int adapt_rnd_weight, int max_pel,
+                   const jmo_pel *orig, const jmo_pel *pred, jmo_pel *rec, int dc_level[9], int dc_run[9],
+                   int ac_level[8][16], int ac_run[8][16], int fadjust[128]);
 extern const uint8_t JMO_SNGL_SCAN[16][2];       /* block.c:170 */
 extern const uint8_t JMO_SNGL_SCAN8x8[64][2];    /* transform8x8.c */
 extern const uint8_t JMO_COEFF_COST4x4[3][16];   /* block.c COEFF_COST4x4 */

@@ -399,3 +399,113 @@ int jmo_rtq_luma_4x4(const jmo_pel orig[16], const jmo_pel pred[16], int qp, int
   }
   return nonzero;
 }
+
+/* ---------------- chroma residual: residual_transform_quant_chroma_4x4 block.c:954-1200 ----------------
+ * One chroma plane (uv) of one macroblock, 4:2:0 (8x8 samples) or 4:2:2 (8x16), rows of 8 samples.
+ *   forward4x4 per 4x4 block (check_zero blocks stay zero)                         :1013-1029
+ *   DC: 4:2:0 hadamard2x2 + quant_dc2x2 (quantChroma_normal.c:37) + ihadamard2x2, >> 5       :1031-1055
+ *       4:2:2 hadamard4x2 on the transposed DCs + quant_dc4x2 (:110, qp + 3) + ihadamard4x2, (x + 32) >> 6   :1056-1093
+ *   AC: quant_ac4x4_normal / _around (quant4x4_normal.c:117 / quant4x4_around.c:129) per block in (b8, b4) = raster order   :1096-1137
+ *   thresholding: all AC levels dropped when their summed cost < _CHROMA_COEFF_COST_ = 4 (defines.h:115)      :1139-1171
+ *   inverse4x4 of every block with a DC or surviving AC, sample_reconstruct (DQ_BITS 6) / copy of the prediction   :1173-1199
+ * cbp_blk: the macroblock's coded-block bits, updated as JM does; returns cr_cbp.  Frame scan, disthres 0. */
+int jmo_rtq_chroma(int yuv, int uv, int cr_cbp, int64_t *cbp_blk, const jmo_qparam q_ac[16], const jmo_qparam *q_dc,
+                   int qp_per_ac, int qp_per_dc, int cavlc, int adaptive_rounding, int arw, int max_pel,
+                   const jmo_pel *orig, const jmo_pel *pred, jmo_pel *rec, int dc_level[9], int dc_run[9],
+                   int ac_level[8][16], int ac_run[8][16], int fadjust[128])
+{
+  const int H = yuv == 2 ? 16 : 8, nblk = H / 2, uv_scale = uv * (yuv == 2 ? 2 : 1);
+  static const uint8_t scan422[8][2] = {{0,0},{0,1},{1,0},{0,2},{0,3},{1,1},{1,2},{1,3}};       /* SCAN_YUV422 block.c:88 (j, i) */
+  int rres[16][8], nonzero[8] = {0}, k, j, i, coeff_cost = 0, cr_cbp_tmp = 0, dczero = 0, nonezero = 0, any = 0;
+  for (k = 0; k < nblk; k++) {
+    const int n1 = 4 * (k & 1), n2 = 4 * (k >> 1);
+    int in[16], out[16], z = 0;
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { in[4*j+i] = (int)orig[(n2+j)*8 + n1+i] - (int)pred[(n2+j)*8 + n1+i]; z |= in[4*j+i]; }
+    if (z) jmo_forward4x4(in, out); else memset(out, 0, sizeof out);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) rres[n2+j][n1+i] = out[4*j+i];
+  }
+  {                                                                            /* ---- DC ---- */
+    const int q_bits = 15 + qp_per_dc + 1, ndc = yuv == 2 ? 8 : 4;
+    int m[8], t[8], run = 0, n = 0;
+    if (yuv == 1) { int in[4] = {rres[0][0], rres[0][4], rres[4][0], rres[4][4]}; jmo_hadamard2x2(in, m); }
+    else {
+      int in[8];
+      for (j = 0; j < 4; j++) { in[j] = rres[4*j][0]; in[4 + j] = rres[4*j][4]; }   /* tblk4x4[i>>2][j>>2] = mb_rres[j][i]: rows = columns 0 / 4 */
+      jmo_hadamard4x2(in, m);
+    }
+    for (k = 0; k < ndc; k++) {
+      const int idx = yuv == 1 ? k : scan422[k][0] * 4 + scan422[k][1], c = m[idx];
+      if (c != 0) {
+        int lev = (iabs_(c) * q_dc->ScaleComp + (q_dc->OffsetComp << 1)) >> q_bits;
+        if (lev != 0) {
+          if (cavlc) lev = imin_(lev, 2063);
+          lev = c < 0 ? -lev : lev;
+          m[idx] = (lev * q_dc->InvScaleComp) << qp_per_dc;
+          dc_level[n] = lev; dc_run[n] = run; n++; run = 0; dczero = 1;
+        } else { run++; m[idx] = 0; }
+      } else run++;
+    }
+    dc_level[n] = 0;
+    /* JM forms these masks in 32-bit int arithmetic (block.c:1044 / :1080): 0xff0000 << 8 is negative and sign-extends into the
+       64-bit cbp_blk, setting every bit from 24 up for the V plane of 4:2:2 -- restated as is */
+    if (dczero) { *cbp_blk |= (int64_t)(int32_t)(yuv == 1 ? 0xf0000u << (uv << 2) : 0xff0000u << (uv << 3)); if (cr_cbp < 1) cr_cbp = 1; }
+    if (yuv == 1) {
+      jmo_ihadamard2x2(m, t);
+      rres[0][0] = t[0] >> 5; rres[0][4] = t[1] >> 5; rres[4][0] = t[2] >> 5; rres[4][4] = t[3] >> 5;
+    } else {
+      jmo_ihadamard4x2(m, t);                                                    /* t[j*2 + c]: row group j, column group c */
+      for (j = 0; j < 4; j++) { rres[4*j][0] = rshift_rnd_sf(t[2*j], 6); rres[4*j][4] = rshift_rnd_sf(t[2*j + 1], 6); }
+    }
+  }
+  for (k = 0; k < nblk; k++) {                                                 /* ---- AC ---- */
+    const int n1 = 4 * (k & 1), n2 = 4 * (k >> 1), q_bits = 15 + qp_per_ac;
+    int c, run = 0, n = 0, nz = 0;
+    for (c = 1; c < 16; c++) {
+      const int ii = JMO_SNGL_SCAN[c][0], jj = JMO_SNGL_SCAN[c][1], qi = jj * 4 + ii, v = rres[n2+jj][n1+ii];
+      int fadj = 0;
+      if (v != 0) {
+        const int scaled = iabs_(v) * q_ac[qi].ScaleComp;
+        int lev = (scaled + q_ac[qi].OffsetComp) >> q_bits;
+        if (lev != 0) {
+          if (cavlc) lev = imin_(lev, 2063);
+          if (adaptive_rounding) fadj = rshift_rnd_sf(arw * (scaled - (lev << q_bits)), q_bits + 1);
+          coeff_cost += (lev > 1) ? 999999 : JMO_COEFF_COST4x4[0][run];
+          lev = v < 0 ? -lev : lev;
+          rres[n2+jj][n1+ii] = rshift_rnd_sf((lev * q_ac[qi].InvScaleComp) << qp_per_ac, 4);
+          ac_level[k][n] = lev; ac_run[k][n] = run; n++; run = 0; nz = 1;
+        } else { rres[n2+jj][n1+ii] = 0; run++; }
+      } else run++;
+      if (adaptive_rounding) fadjust[(n2+jj)*8 + n1+ii] = fadj;
+    }
+    ac_level[k][n] = 0;
+    nonzero[k] = nz;
+    if (nz) { *cbp_blk |= (int64_t)1 << (16 + 4 * uv_scale + k); cr_cbp_tmp = 2; nonezero = 1; }
+  }
+  if (nonezero && coeff_cost < 4) {                                            /* ---- thresholding ---- */
+    const int64_t pat = yuv == 1 ? (int64_t)0xf0000 << (uv << 2) : (int64_t)0xff0000 << (uv << 3);
+    cr_cbp_tmp = 0;
+    for (k = 0; k < nblk; k++)
+      if (nonzero[k]) {
+        const int n1 = 4 * (k & 1), n2 = 4 * (k >> 1);
+        int c;
+        nonzero[k] = 0;
+        if (!dczero) *cbp_blk &= ~pat;
+        ac_level[k][0] = 0;
+        for (c = 1; c < 16; c++) { rres[n2 + JMO_SNGL_SCAN[c][1]][n1 + JMO_SNGL_SCAN[c][0]] = 0; ac_level[k][c] = 0; }
+      }
+  }
+  if (cr_cbp_tmp == 2) cr_cbp = 2;
+  for (k = 0; k < nblk; k++) {                                                 /* ---- inverse transform, reconstruction ---- */
+    const int n1 = 4 * (k & 1), n2 = 4 * (k >> 1);
+    if (rres[n2][n1] != 0 || nonzero[k]) {
+      int in[16], out[16];
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[4*j+i] = rres[n2+j][n1+i];
+      jmo_inverse4x4(in, out);
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) rres[n2+j][n1+i] = out[4*j+i];
+      any = 1;
+    }
+  }
+  for (j = 0; j < H; j++) for (i = 0; i < 8; i++)
+    rec[j*8+i] = any ? (jmo_pel)clip1(max_pel, rshift_rnd_sf(rres[j][i], 6) + (int)pred[j*8+i]) : pred[j*8+i];
+  return cr_cbp;
+}

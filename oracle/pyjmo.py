@@ -244,6 +244,19 @@ def rtq_luma_8x8(orig, pred, qparams, qp_per, cavlc, around, arw, max_pel=255):
     return nz, cost.value, rec, level, run, fadj, anyr.value
 
 
+def rtq_chroma(yuv, uv, cr_cbp, cbp_blk, q_ac, q_dc, qp_per_ac, qp_per_dc, cavlc, around, arw, max_pel, orig, pred):
+    """residual_transform_quant_chroma_4x4 for one plane of one macroblock; orig/pred: 128 samples (rows of 8).
+    Returns (cr_cbp, cbp_blk, rec[128], dc_level[9], dc_run[9], ac_level[8,16], ac_run[8,16], fadjust[128])."""
+    o = np.ascontiguousarray(orig, np.uint16); p_ = np.ascontiguousarray(pred, np.uint16)
+    qa = np.ascontiguousarray(q_ac, np.int32).reshape(16, 3); qd = np.ascontiguousarray(q_dc, np.int32).reshape(3)
+    cb = C.c_int64(int(cbp_blk)); rec = np.zeros(128, np.uint16)
+    dl = np.zeros(9, np.int32); dr = np.zeros(9, np.int32); al = np.zeros((8, 16), np.int32); ar = np.zeros((8, 16), np.int32)
+    fa = np.zeros(128, np.int32)
+    r = L.jmo_rtq_chroma(yuv, uv, cr_cbp, C.byref(cb), _p(qa), _p(qd), qp_per_ac, qp_per_dc, cavlc, around, arw, max_pel,
+                         _p(o), _p(p_), _p(rec), _p(dl), _p(dr), _p(al), _p(ar), _p(fa))
+    return r, cb.value, rec, dl, dr, al, ar, fa
+
+
 def qparams_4x4(qp, intra, offset):
     q = np.zeros((16, 3), np.int32)
     L.jmo_qparams_4x4(qp, intra, offset, _p(q))

@@ -535,3 +535,61 @@ extern int __real_residual_transform_quant_luma_8x8(Macroblock *, ColorPlane, in
 int __wrap_residual_transform_quant_luma_8x8(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra) { return tap_rtq8x8(0, m, pl, b8, cc, intra, __real_residual_transform_quant_luma_8x8); }
 extern int __real_residual_transform_quant_luma_8x8_cavlc(Macroblock *, ColorPlane, int, int *, int);
 int __wrap_residual_transform_quant_luma_8x8_cavlc(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra) { return tap_rtq8x8(1, m, pl, b8, cc, intra, __real_residual_transform_quant_luma_8x8_cavlc); }
+
+/* ================================================================== chroma residual: residual_transform_quant_chroma_4x4 (block.c:954)
+ * The slot Macroblock.residual_transform_quant_chroma_4x4[uv] is filled by select_transform() in the translation unit that also
+ * defines the function, so there is no link-time reference to wrap: select_transform is wrapped and the slot rebound to the tap.
+ * record: uv cr_cbp_in intra yuv cur_qp qp_per_ac qp_per_dc cavlc AdaptRndWeight AdaptiveRounding max_pel cbp_blk_in(lo,hi) |
+ *         16 x q_params AC | q_params DC | pred[128] | ores[128] | ret cbp_blk_out(lo,hi) | rec[128] | DC level[9] run[9] |
+ *         8 x (AC level[16], run[16]) | fadjust[128]                       (rows of 8 samples; 4:2:0 uses the first 64)      */
+extern int residual_transform_quant_chroma_4x4(Macroblock *, int, int);
+static int tap_rtq_chroma(Macroblock *currMB, int uv, int cr_cbp)
+{
+  static int n = 0;
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  const int yuv = p_Vid->yuv_format, H = p_Vid->mb_cr_size_y, intra = is_intra(currMB);
+  const int cur_qp = currMB->qpc[uv] + currSlice->bitdepth_chroma_qp_scale, qp_dc = yuv == YUV422 ? cur_qp + 3 : cur_qp;
+  const int uv_scale = uv * (p_Vid->num_blk8x8_uv >> 1);
+  int pred[128], ores[128], j, i, k, r;
+  int64 cbp_in = currMB->cbp_blk;
+  LevelQuantParams **qa = p_Vid->p_Quant->q_params_4x4[uv + 1][intra][cur_qp], *qd = &p_Vid->p_Quant->q_params_4x4[uv + 1][intra][qp_dc][0][0];
+  int **fadj = NULL;
+  if (yuv != YUV420 && yuv != YUV422) return residual_transform_quant_chroma_4x4(currMB, uv, cr_cbp);
+  memset(pred, 0, sizeof pred); memset(ores, 0, sizeof ores);
+  for (j = 0; j < H; j++) for (i = 0; i < 8; i++) { pred[j * 8 + i] = currSlice->mb_pred[uv + 1][j][i]; ores[j * 8 + i] = currSlice->mb_ores[uv + 1][j][i]; }
+  r = residual_transform_quant_chroma_4x4(currMB, uv, cr_cbp);
+  if (n < tap_max() / 2 && (n % 3) == 0) {
+    FILE *f = tap_open("rtq_chroma.bin");
+    put_i32(f, uv); put_i32(f, cr_cbp); put_i32(f, intra); put_i32(f, yuv); put_i32(f, cur_qp);
+    put_i32(f, p_Vid->p_Quant->qp_per_matrix[cur_qp]); put_i32(f, p_Vid->p_Quant->qp_per_matrix[qp_dc]);
+    put_i32(f, currSlice->symbol_mode == CAVLC); put_i32(f, p_Vid->AdaptRndWeight); put_i32(f, p_Vid->AdaptiveRounding); put_i32(f, p_Vid->max_pel_value_comp[uv + 1]);
+    put_i32(f, (int)(cbp_in & 0xffffffff)); put_i32(f, (int)(cbp_in >> 32));
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { put_i32(f, qa[j][i].OffsetComp); put_i32(f, qa[j][i].ScaleComp); put_i32(f, qa[j][i].InvScaleComp); }
+    put_i32(f, qd->OffsetComp); put_i32(f, qd->ScaleComp); put_i32(f, qd->InvScaleComp);
+    for (k = 0; k < 128; k++) put_i32(f, pred[k]);
+    for (k = 0; k < 128; k++) put_i32(f, ores[k]);
+    put_i32(f, r); put_i32(f, (int)(currMB->cbp_blk & 0xffffffff)); put_i32(f, (int)(currMB->cbp_blk >> 32));
+    for (j = 0; j < 16; j++) for (i = 0; i < 8; i++) put_i32(f, j < H ? p_Vid->enc_picture->imgUV[uv][currMB->pix_c_y + j][currMB->pix_c_x + i] : 0);
+    for (k = 0; k < 9; k++) put_i32(f, currSlice->cofDC[uv + 1][0][k]);
+    for (k = 0; k < 9; k++) put_i32(f, currSlice->cofDC[uv + 1][1][k]);
+    for (k = 0; k < 8; k++) {
+      const int b8 = k >> 2, b4 = k & 3, live = b8 < (p_Vid->num_blk8x8_uv >> 1);
+      for (j = 0; j < 16; j++) put_i32(f, live ? currSlice->cofAC[4 + b8 + uv_scale][b4][0][j] : 0);
+      for (j = 0; j < 16; j++) put_i32(f, live ? currSlice->cofAC[4 + b8 + uv_scale][b4][1][j] : 0);
+    }
+    if (p_Vid->AdaptiveRounding)
+      fadj = (currMB->mb_type == P8x8 && currMB->luma_transform_size_8x8_flag) ? p_Vid->ARCofAdj4x4[uv + 1][4] : p_Vid->ARCofAdj4x4[uv + 1][currMB->ar_mode];
+    for (j = 0; j < 16; j++) for (i = 0; i < 8; i++) put_i32(f, (fadj && j < H) ? fadj[j][i] : 0);
+    fclose(f);
+  }
+  n++;
+  return r;
+}
+extern void __real_select_transform(Macroblock *);
+void __wrap_select_transform(Macroblock *currMB)
+{
+  __real_select_transform(currMB);
+  if (currMB->residual_transform_quant_chroma_4x4[0] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[0] = tap_rtq_chroma;
+  if (currMB->residual_transform_quant_chroma_4x4[1] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[1] = tap_rtq_chroma;
+}

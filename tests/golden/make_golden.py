@@ -210,8 +210,9 @@ def main():
 
         # ---- D: 8x8 transform / quantisation and the DC transforms (High 4:2:2 CABAC + adaptive rounding; the same with CAVLC
         #         and plain rounding; High 4:2:0 CAVLC for the 2x2 chroma DC transform)
-        d, q8, r8 = {}, [], []
-        for name, cfg, o in [("D", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2)),
+        d, q8, r8, rc = {}, [], [], []
+        for name, cfg, o in [("D0", "encoder_baseline.cfg", dict(ov)),
+                             ("D", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2)),
                              ("D2", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2, SymbolMode=0, AdaptiveRounding=0)),
                              ("D3", "encoder_main.cfg", dict(FramesToBeEncoded=2, Transform8x8Mode=1, ProfileIDC=100, SymbolMode=0)),
                              ("D4", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2, AdaptiveRounding=0))]:
@@ -220,8 +221,14 @@ def main():
             q = read_i32_records(os.path.join(w, "quant8x8.bin"), 718)
             r = read_i32_records(os.path.join(w, "rtq8x8.bin"), 530)
             # keep the records that exercise something: at least one non-zero level, spread over the run
-            q = q[np.abs(q[:, 4 + 192 + 128 + 64 + 64 + 64:4 + 192 + 128 + 64 + 64 + 64 + 68]).sum(1) > 0]
-            q8.append(q[:: max(1, len(q) // 60)][:60]); r8.append(r[:: max(1, len(r) // 60)][:60])
+            if len(q):
+                q = q[np.abs(q[:, 4 + 192 + 128 + 64 + 64 + 64:4 + 192 + 128 + 64 + 64 + 64 + 68]).sum(1) > 0]
+            if len(q):
+                q8.append(q[:: max(1, len(q) // 60)][:60]); r8.append(r[:: max(1, len(r) // 60)][:60])
+            c = read_i32_records(os.path.join(w, "rtq_chroma.bin"), 853)
+            busy = c[np.abs(c[:, 451:460]).sum(1) + np.abs(c[:, 469:725]).sum(1) > 0]       # some DC or AC level survives
+            quiet = c[np.abs(c[:, 451:460]).sum(1) + np.abs(c[:, 469:725]).sum(1) == 0]
+            rc.append(busy[:: max(1, len(busy) // 45)][:45]); rc.append(quiet[:: max(1, len(quiet) // 10)][:10])
             for nm, wd in (("fwd8x8", 128), ("inv8x8", 128), ("hadamard4x4", 32), ("ihadamard4x4", 32), ("hadamard4x2", 16),
                            ("ihadamard4x2", 16), ("hadamard2x2", 8), ("ihadamard2x2", 8), ("quant_dc4x4", 73)):
                 a = read_i32_records(os.path.join(w, nm + ".bin"), wd)
@@ -232,6 +239,7 @@ def main():
         d = {k: np.concatenate(v) for k, v in d.items()}
         d["quant8x8"] = np.concatenate(q8)
         d["rtq8x8"] = np.concatenate(r8)
+        d["rtq_chroma"] = np.concatenate(rc)
         np.savez_compressed(os.path.join(OUT, "qcif_tq8.npz"), **d)
 
         # ---- md5 goldens of whole-encoder runs

@@ -30,6 +30,7 @@ def test_struct_sizes_match_the_header():
     assert L.ME_JOB.itemsize == 192 and L.ME_RESULT.itemsize == 328
     assert L.SUBPEL_JOB.itemsize == 36 and L.TQ_OUT.itemsize == 104
     assert L.DB_MB.itemsize == 28 and L.DB_MOTION.itemsize == 16
+    assert L.TQC_PARAMS.itemsize == 240 and L.TQC_MB.itemsize == 16 and L.TQC_OUT.itemsize == 808
     assert L.TQ8_PARAMS.itemsize == 800 and L.TQ8_OUT.itemsize == 408 and L.DC_OUT.itemsize == 52
 
 

@@ -501,6 +501,58 @@ def test_dc_transforms_and_dc_quant_golden_records(J, tq8):
     ctx.close()
 
 
+def test_tq_chroma_golden_records(tq8):
+    """residual_transform_quant_chroma_4x4 as the real encoder called it (4:2:0 / 4:2:2, CAVLC / CABAC, adaptive rounding on / off)."""
+    from jm_amd.lib import TQC_MB
+    from test_oracle_golden import unpack_chroma_record, check_chroma_lists
+    ctx = make_ctx(16, 16)
+    for r in tq8["rtq_chroma"]:
+        h = unpack_chroma_record(r)
+        rows = 64 if h["yuv"] == 1 else 128
+        mb = np.zeros(1, TQC_MB); mb["cbp_blk"], mb["cr_cbp"], mb["uv"] = h["cbp_in"], h["cr_cbp"], h["uv"]
+        mbo, out = ctx.tq_chroma(h["yuv"], h["q_ac"], h["q_dc"], h["qp_per_ac"], h["qp_per_dc"], h["cavlc"], h["around"], h["arw"], mb,
+                                 (h["pred"] + h["ores"]).astype(np.uint8), h["pred"].astype(np.uint8), h["max_pel"])
+        assert (int(mbo[0]["cr_cbp"]), int(mbo[0]["cbp_blk"])) == (h["ret"], h["cbp_out"])
+        assert out[0]["rec"][:rows].tolist() == h["rec"][:rows].tolist()
+        check_chroma_lists(h, out[0]["dc_level"], out[0]["dc_run"], out[0]["ac_level"], out[0]["ac_run"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("yuv,qp,cavlc,around,seed", [(1, 28, 1, 1, 1), (2, 28, 0, 1, 2), (1, 10, 0, 0, 3), (2, 45, 1, 0, 4), (1, 33, 1, 1, 5)])
+def test_tq_chroma_vs_oracle(J, yuv, qp, cavlc, around, seed):
+    from jm_amd.lib import TQC_MB
+    rng = np.random.default_rng(seed)
+    n = 900
+    rows = 64 if yuv == 1 else 128
+    pred = np.zeros((n, 128), np.uint8); orig = np.zeros((n, 128), np.uint8)
+    pred[:, :rows] = rng.integers(0, 256, (n, rows))
+    amp = rng.choice([0, 1, 1, 2, 3, 8, 40, 255], n)[:, None]
+    orig[:, :rows] = np.clip(pred[:, :rows].astype(np.int64) + rng.integers(-1, 2, (n, rows)) * rng.integers(0, 256, (n, rows)) * amp // 255
+                             + rng.integers(-1, 2, (n, 1)) * rng.integers(0, 6, (n, 1)), 0, 255)
+    q_ac = J.qparams_4x4(qp, 0, 342)
+    qdc = J.qparams_4x4(qp + (3 if yuv == 2 else 0), 0, 342)[0]
+    mbs = np.zeros(n, TQC_MB)
+    mbs["uv"] = rng.integers(0, 2, n); mbs["cr_cbp"] = rng.integers(0, 3, n); mbs["cbp_blk"] = rng.integers(0, 1 << 40, n) * rng.integers(0, 2, n)
+    ctx = make_ctx(16, 16)
+    mbo, out = ctx.tq_chroma(yuv, q_ac, qdc, qp // 6, (qp + (3 if yuv == 2 else 0)) // 6, cavlc, around, 4, mbs, orig, pred)
+    hit = set()
+    for i in range(n):
+        ret, cbp, rec, dl, dr, al, ar, fa = J.rtq_chroma(yuv, int(mbs[i]["uv"]), int(mbs[i]["cr_cbp"]), int(mbs[i]["cbp_blk"]), q_ac, qdc, qp // 6,
+                                                          (qp + (3 if yuv == 2 else 0)) // 6, cavlc, around, 4, 255, orig[i], pred[i])
+        assert (int(mbo[i]["cr_cbp"]), int(mbo[i]["cbp_blk"])) == (ret, cbp), i
+        assert out[i]["rec"][:rows].tolist() == rec[:rows].tolist(), i
+        nd = int(np.argmax(dl == 0)) + 1
+        assert out[i]["dc_level"][:nd].tolist() == dl[:nd].tolist() and out[i]["dc_run"][:nd - 1].tolist() == dr[:nd - 1].tolist(), i
+        for k in range(rows // 16):
+            na = int(np.argmax(al[k] == 0)) + 1
+            assert out[i]["ac_level"][k][:na].tolist() == al[k][:na].tolist() and out[i]["ac_run"][k][:na - 1].tolist() == ar[k][:na - 1].tolist(), (i, k)
+        if around:
+            assert out[i]["fadjust"][:rows].tolist() == fa[:rows].tolist(), i
+        hit.add(ret)
+    assert hit == {0, 1, 2}
+    ctx.close()
+
+
 # --------------------------------------------------------------------------- K9/K10 deblocking
 @pytest.mark.parametrize("name,frames,fmt", [("qcif_fs.npz", (0, 1), 1), ("qcif_422.npz", (0, 1), 2), ("qcif_main.npz", (0, 1, 2), 1)])
 def test_deblock_golden_frames(name, frames, fmt):

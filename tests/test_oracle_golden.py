@@ -169,6 +169,48 @@ def test_residual_transform_quant_luma_8x8_records(tq8):
     assert len(seen) >= 3, seen
 
 
+def unpack_chroma_record(r):
+    h = dict(zip(("uv", "cr_cbp", "intra", "yuv", "qp", "qp_per_ac", "qp_per_dc", "cavlc", "arw", "around", "max_pel"), (int(v) for v in r[:11])))
+    h["cbp_in"] = (int(r[11]) & 0xffffffff) | (int(r[12]) << 32)                 # signed 64-bit, as JM keeps it
+    h["q_ac"], h["q_dc"] = r[13:61].reshape(16, 3), r[61:64]
+    h["pred"], h["ores"] = r[64:192], r[192:320]
+    h["ret"] = int(r[320]); h["cbp_out"] = (int(r[321]) & 0xffffffff) | (int(r[322]) << 32)
+    h["rec"], h["dc_level"], h["dc_run"] = r[323:451], r[451:460], r[460:469]
+    ac = r[469:725].reshape(8, 2, 16)
+    h["ac_level"], h["ac_run"], h["fadjust"] = ac[:, 0], ac[:, 1], r[725:853]
+    return h
+
+
+def check_chroma_lists(h, dl, dr, al, ar):
+    n = int(np.argmax(h["dc_level"] == 0)) + 1
+    assert np.asarray(dl)[:n].tolist() == h["dc_level"][:n].tolist() and np.asarray(dr)[:n - 1].tolist() == h["dc_run"][:n - 1].tolist()
+    for k in range(4 if h["yuv"] == 1 else 8):
+        n = int(np.argmax(h["ac_level"][k] == 0)) + 1
+        assert np.asarray(al)[k][:n].tolist() == h["ac_level"][k][:n].tolist(), k
+        assert np.asarray(ar)[k][:n - 1].tolist() == h["ac_run"][k][:n - 1].tolist(), k
+
+
+def test_residual_transform_quant_chroma_records(tq8):
+    """residual_transform_quant_chroma_4x4 as the real encoder called it: 4:2:0 and 4:2:2, CAVLC and CABAC, with and without
+    adaptive rounding; DC path, AC quantisation, coefficient thresholding, cbp bits, reconstruction."""
+    recs = tq8["rtq_chroma"]
+    seen = set()
+    for r in recs:
+        h = unpack_chroma_record(r)
+        rows = 64 if h["yuv"] == 1 else 128
+        ret, cbp, rec, dl, dr, al, ar, fa = J.rtq_chroma(h["yuv"], h["uv"], h["cr_cbp"], h["cbp_in"], h["q_ac"], h["q_dc"], h["qp_per_ac"], h["qp_per_dc"],
+                                                          h["cavlc"], h["around"], h["arw"], h["max_pel"], h["pred"] + h["ores"], h["pred"])
+        assert (ret, cbp) == (h["ret"], h["cbp_out"])
+        assert rec[:rows].tolist() == h["rec"][:rows].tolist()
+        check_chroma_lists(h, dl, dr, al, ar)
+        if h["around"]:
+            # JM only writes the AC positions; the DC position of every 4x4 keeps whatever an earlier call left there
+            mask = np.ones(128, bool); mask[[(4 * (k >> 1)) * 8 + 4 * (k & 1) for k in range(8)]] = False
+            assert fa[:rows][mask[:rows]].tolist() == h["fadjust"][:rows][mask[:rows]].tolist()
+        seen.add((h["yuv"], h["cavlc"], h["around"], h["ret"]))
+    assert len({s[:3] for s in seen}) >= 3 and {s[3] for s in seen} == {0, 1, 2}, seen
+
+
 def test_reconstruct_records(fs):
     for r in fs["recon4x4"]:
         maxv, dq = int(r[0]), int(r[1])
