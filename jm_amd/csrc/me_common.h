@@ -73,12 +73,14 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 }
 
 // Which kernel owns a job: the tuned kernel (me_fast.hip) takes search ranges up to 32 whose 32-bit
-// (cost<<7 | rank) key cannot overflow and whose max_mvd guard (me_fullfast.c:638,671) cannot trigger
+// (cost << 11 | tag) key cannot overflow and whose max_mvd guard (me_fullfast.c:638,671) cannot trigger
 // anywhere in the window; everything else goes to the generic kernel.  Wave-uniform.
+// Key bound: an mv component difference is < 2^17, so mvbits <= 35 per component; lambda < 14000 keeps the rate below 2^20,
+// and with SAD << 5 <= 32640 * 32 (every partition but 16x16, which has one more bit) the cost stays below 2^21.
 __device__ __forceinline__ bool job_is_fast(const jmhip_me_job *__restrict__ job)
 {
   const int R = job->search_range;
-  if (R > 32 || R < 1 || job->lambda < 0 || job->lambda >= 65536) return false;
+  if (R > 32 || R < 1 || job->lambda < 0 || job->lambda >= 14000) return false;
   if (job->max_mvd != 0) {
     const int guard = job->max_mvd - 1;
     const uint64_t mask = job->part_mask;

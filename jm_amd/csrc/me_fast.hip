@@ -4,30 +4,33 @@
 // full_search_motion_estimation (lencod/src/me_fullsearch.c:39-103) /
 // fast_full_search_motion_estimation (lencod/src/me_fullfast.c:618-689) over the window, all 41 partitions --
 // but organised around what the MI355X VALU can issue (profiles/r01_valu_rates.txt):
-//   v_sad_u8        4 abs-diff+acc per lane-op at the full VOP3 rate (the SAD roofline: ~145 T abs-diff/s)
-//   v_add3_u32      1 op builds a packed (cost, tie-break) key
+//   v_sad_hi_u8     4 abs-diff per lane-op at the full VOP3 rate (the SAD roofline: ~148 T abs-diff/s), result added at bit 16
+//   v_add_u32       the fastest VALU op measured (87 lane-ops/clk/CU against 54-60 for the three-operand forms)
 //   v_min3_u32      1 op folds TWO candidate keys into the running minimum
 //   64-bit integer compare+select is 4.5x slower, v_alignbyte costs as much as the SAD it feeds.
 //
-// Mapping.  lane <-> window column (dx); a wave walks window rows two at a time; eight waves share one job (two jobs fit a CU's
-// LDS, so 4 waves per SIMD at <= 128 VGPRs):
-//   * the search window is staged in LDS as EIGHT byte-shifted copies, so the lane at column wx reads
-//     its 16 reference bytes of a row as two ALIGNED ds_read_b64 from copy (wx & 7): no v_alignbyte, and
-//     the copy stride (== 8 dwords mod 64) spreads the 32 lanes of a read over all 64 banks;
-//   * the current macroblock is fetched with scalar loads and stays in SGPRs: it is the scalar operand
-//     of v_sad_u8;
-//   * the 16 4x4 SADs are pre-shifted (<<12) once, the 25 aggregation adds then produce the 41
-//     partition SADs already in key position;
-//   * key = (SAD << 12) + (lambda*mvbits_y << 7) + rank, built by ONE v_add3_u32: the y rate is uniform
-//     per row (a per-job LDS table, read as a broadcast b128), the x rate is constant per lane and is
-//     added once at the end; rank (7 bits) orders the positions of one column exactly as JM's spiral
-//     does (mv_search.c:405-442), so the unsigned minimum reproduces "first spiral index wins";
+// Mapping.  lane <-> window column (dx); a wave walks window rows two at a time; four waves share one job and four jobs fit a
+// CU's LDS (37 KB each), so a CU holds 16 waves in four independent phases: one job's staging / merging overlaps the others'
+// VALU-bound main pass.
+//   * the search window is staged in LDS as FOUR byte-shifted copies, so the lane at column wx reads its 16 reference
+//     bytes of a row as four aligned dwords from copy (wx & 3): no v_alignbyte in the main pass, and the copy stride
+//     (== 16 dwords mod 64) spreads the 64 lanes of a read over all 64 banks;
+//   * the current macroblock is fetched with scalar loads and stays in SGPRs: it is the scalar operand of v_sad_hi_u8;
+//   * key layout.  The sixteen 4x4 accumulators START at rank (the position's order inside its column, below) and
+//     v_sad_hi_u8 adds SAD << 16 on top; the 25 aggregation adds then give, for a partition of n 4x4 blocks,
+//     (SAD << 16) + n * rank.  One v_add_u32 with the row constant (lambda * mvbits_y) << 11 makes it
+//     ((SAD << 5) + rate) << 11 + n * rank = (cost << 11) | tag: cost in JM's distblk units, tag < 2^11 ordering the rows
+//     of one column exactly as JM's spiral does (mv_search.c:405-442), so the unsigned minimum reproduces "first spiral
+//     index wins".  The 16x16 partition (SAD up to 65280) is shifted right by one first: (cost << 10) | 8 * rank.
+//     The y rate is uniform per row (a per-job LDS table, read as a broadcast b128), the x rate is constant per lane and
+//     is added once at the end;
 //   * two rows per step share a column, so one v_min3_u32 retires two candidates.
-// ~1.5 VALU ops per (position, partition) instead of ~12 in the generic kernel.
+// ~1.2 VALU ops per (position, partition) instead of ~12 in the generic kernel.
 //
-// The last window row (2R+1 is odd) is a single-row step; for R = 32 the 65th column is evaluated by
-// one wave with the generic per-position code.  Per-lane minima are merged across the waves
-// (same lane == same column, keys comparable), decoded to (cost, spiral index) and min-reduced.
+// 2R+1 rows are odd: the last step takes rows (2R-1, 2R), re-evaluating row 2R-1 (a duplicate key cannot change a minimum).
+// For R = 32 the 65th column is one more step of one wave: lane j evaluates rows (2j, 2j+1) of that column.
+// Per-lane minima are merged across the waves (same lane == same column, keys comparable); the final stage turns the
+// few candidates that attain the minimum cost into (cost, spiral index) pairs.
 // All 41 partitions are always evaluated (no branches in the hot loop); part_mask selects what is stored.
 //
 // Jobs this kernel cannot take (search_range > 32, a max_mvd guard that could trigger, lambda too large
@@ -38,14 +41,19 @@
 
 #define WROWS_MAX 80                        // 2*32 + 16
 #define CPITCH 20                           // dwords per row of one shifted copy (columns 0..64 + 15 -> 80 bytes)
-#define CSTRIDE (WROWS_MAX * CPITCH + 8)    // dwords between copies: == 8 (mod 64) banks
-#define NCOPY 8
-#define RYP 44                              // row pitch (dwords) of the y-rate table: 41 partitions padded to 11 x uint4
+#define NCOPY 4
+#define CSTRIDE (WROWS_MAX * CPITCH + 16)   // dwords between copies: == 16 (mod 64) banks
 #define COPY_DWORDS (NCOPY * CSTRIDE)
-#define NW 8                                 // waves per job: 2 jobs per CU (LDS) x 8 waves = 4 waves per SIMD (<= 128 VGPRs)
+#define RYP 44                              // row pitch (dwords) of the y-rate table: 41 partitions padded to 11 x uint4
+#define NW 4                                // waves per job
 #define NT (NW * 64)
-#define NWH (NW / 2)                         // the waves' minima are merged in two rounds so the merge area fits into the copy area
-#define MERGE_DWORDS (NWH * NP * 64 + NP * 66)
+#define NWH (NW / 2)                        // the waves' minima are merged in two rounds so the merge area fits into the copy area
+#define MPITCH 68                           // row pitch (dwords) of the published minima: == 4 (mod 64): 16 partitions x 4 threads hit 64 banks
+#define MERGE_DWORDS (NWH * NP * MPITCH)
+#define EXT_PITCH 34                        // 65th column: R + 1 row pairs per partition (overlays the y-rate table after the main pass)
+
+static_assert(MERGE_DWORDS <= COPY_DWORDS, "merge area must fit into the window copies");
+static_assert(NP * EXT_PITCH <= 65 * RYP, "65th-column keys must fit into the y-rate table");
 
 __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
 {
@@ -54,53 +62,34 @@ __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
   return r;
 }
 
-// 16 4x4 SADs for two vertically adjacent positions (rows wy, wy+1) of this lane's column
-template <bool TWO>
-__device__ __forceinline__ void sad_pair(const uint2 *cp /* lane's copy + column offset, 8-byte aligned */, int wy, const uint32_t (&cw)[64],
-                                         unsigned (&sa)[16], unsigned (&sb)[16])
+// key layout per partition: cost sits above COST_SHIFT(p), the tag below it is rank << TAG_SHIFT(p) (n = 1 << TAG_SHIFT blocks)
+__device__ __forceinline__ int cost_shift(int p) { return p == 0 ? 10 : 11; }
+__device__ __forceinline__ int tag_shift(int p) { return p < 5 ? 3 : (p < 9 ? 2 : (p < 25 ? 1 : 0)); }
+
+// 16 4x4 SADs (<< 16, on top of the initial values) for two vertically adjacent positions (rows wy, wy+1) of one column;
+// base = dword index of the column's first window dword in its shifted copy
+__device__ __forceinline__ void sad_pair(const uint32_t *s_mem, int base, int wy, const uint32_t (&cw)[64], unsigned (&sa)[16], unsigned (&sb)[16])
 {
+  int o = base + wy * CPITCH;
 #pragma unroll
-  for (int k = 0; k < 16; k++) { sa[k] = 0; sb[k] = 0; }
-  const uint2 *row = cp + wy * (CPITCH / 2);
-  // the two 8-byte halves are read by separate ds_read_b64: with the copy stride of 8 banks the 32 lanes of a half-wave cover all
-  // 64 banks exactly once per read, whereas one 16-byte read at 8-byte alignment makes neighbouring lanes' windows overlap by two
-  // banks (31 % of the LDS cycles were bank conflicts); hiding the adjacency keeps the compiler from merging them
-  const uint2 *rowh = row + 1;
-  asm volatile("" : "+v"(rowh));
-#pragma unroll
-  for (int r = 0; r < (TWO ? 17 : 16); r++) {
-    const uint2 lo = row[0], hi = rowh[0];
+  for (int r = 0; r < 17; r++) {
+    const uint32_t d0 = s_mem[o], d1 = s_mem[o + 1], d2 = s_mem[o + 2], d3 = s_mem[o + 3];
     if (r < 16) {
       const int q = (r >> 2) * 4;
-      sa[q + 0] = __builtin_amdgcn_sad_u8(lo.x, cw[r * 4 + 0], sa[q + 0]);
-      sa[q + 1] = __builtin_amdgcn_sad_u8(lo.y, cw[r * 4 + 1], sa[q + 1]);
-      sa[q + 2] = __builtin_amdgcn_sad_u8(hi.x, cw[r * 4 + 2], sa[q + 2]);
-      sa[q + 3] = __builtin_amdgcn_sad_u8(hi.y, cw[r * 4 + 3], sa[q + 3]);
+      sa[q + 0] = __builtin_amdgcn_sad_hi_u8(d0, cw[r * 4 + 0], sa[q + 0]);
+      sa[q + 1] = __builtin_amdgcn_sad_hi_u8(d1, cw[r * 4 + 1], sa[q + 1]);
+      sa[q + 2] = __builtin_amdgcn_sad_hi_u8(d2, cw[r * 4 + 2], sa[q + 2]);
+      sa[q + 3] = __builtin_amdgcn_sad_hi_u8(d3, cw[r * 4 + 3], sa[q + 3]);
     }
-    if (TWO && r >= 1) {
+    if (r >= 1) {
       const int q = ((r - 1) >> 2) * 4;
-      sb[q + 0] = __builtin_amdgcn_sad_u8(lo.x, cw[(r - 1) * 4 + 0], sb[q + 0]);
-      sb[q + 1] = __builtin_amdgcn_sad_u8(lo.y, cw[(r - 1) * 4 + 1], sb[q + 1]);
-      sb[q + 2] = __builtin_amdgcn_sad_u8(hi.x, cw[(r - 1) * 4 + 2], sb[q + 2]);
-      sb[q + 3] = __builtin_amdgcn_sad_u8(hi.y, cw[(r - 1) * 4 + 3], sb[q + 3]);
+      sb[q + 0] = __builtin_amdgcn_sad_hi_u8(d0, cw[(r - 1) * 4 + 0], sb[q + 0]);
+      sb[q + 1] = __builtin_amdgcn_sad_hi_u8(d1, cw[(r - 1) * 4 + 1], sb[q + 1]);
+      sb[q + 2] = __builtin_amdgcn_sad_hi_u8(d2, cw[(r - 1) * 4 + 2], sb[q + 2]);
+      sb[q + 3] = __builtin_amdgcn_sad_hi_u8(d3, cw[(r - 1) * 4 + 3], sb[q + 3]);
     }
-    row += CPITCH / 2; rowh += CPITCH / 2;
+    o += CPITCH;
   }
-}
-
-// 16 4x4 SADs -> 41 partition SADs, everything shifted left by 12 (ABI partition order, jmhip.h)
-__device__ __forceinline__ void aggregate41_shifted(const unsigned (&s7)[16], unsigned (&sp)[NP])
-{
-#pragma unroll
-  for (int k = 0; k < 16; k++) sp[25 + k] = s7[k] << 12;
-#pragma unroll
-  for (int by = 0; by < 4; by++) { sp[9 + by * 2] = sp[25 + by * 4] + sp[26 + by * 4]; sp[10 + by * 2] = sp[27 + by * 4] + sp[28 + by * 4]; }
-#pragma unroll
-  for (int bx = 0; bx < 4; bx++) { sp[17 + bx] = sp[25 + bx] + sp[29 + bx]; sp[21 + bx] = sp[33 + bx] + sp[37 + bx]; }
-  sp[5] = sp[9] + sp[11];  sp[6] = sp[10] + sp[12];  sp[7] = sp[13] + sp[15];  sp[8] = sp[14] + sp[16];
-  sp[1] = sp[5] + sp[6];   sp[2] = sp[7] + sp[8];
-  sp[3] = sp[5] + sp[7];   sp[4] = sp[6] + sp[8];
-  sp[0] = sp[1] + sp[2];
 }
 
 // rank of row dy inside column |dx| = a, in JM's spiral order: 0 .. 2R.
@@ -117,23 +106,49 @@ __device__ __forceinline__ int rank_to_dy(unsigned rank, int a)
   return (t & 1) ? u : -u;
 }
 
+// one step: rows (wy, wy+1) of the column whose window dwords start at `base`; keys folded into acc
+__device__ __forceinline__ void step_pair(const uint32_t *s_mem, const uint32_t *s_ry, int base, int wy, int R, int a, const uint32_t (&cw)[64], unsigned (&acc)[NP])
+{
+  unsigned sa[16], sb[16], pa[NP], pb[NP];
+  const unsigned rkA = col_rank(wy - R, a), rkB = col_rank(wy + 1 - R, a);
+#pragma unroll
+  for (int k = 0; k < 16; k++) { sa[k] = rkA; sb[k] = rkB; }
+  sad_pair(s_mem, base, wy, cw, sa, sb);
+  aggregate41(sa, pa);
+  aggregate41(sb, pb);
+  const uint4 *ryA = (const uint4 *)(s_ry + wy * RYP), *ryB = (const uint4 *)(s_ry + (wy + 1) * RYP);
+#pragma unroll
+  for (int g = 0; g < 11; g++) {
+    const uint4 ca = ryA[g], cb = ryB[g];                 // broadcast reads: 4 partitions' row constants
+    const unsigned cav[4] = {ca.x, ca.y, ca.z, ca.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int p = 4 * g + t;
+      if (p == 0) acc[p] = umin3(acc[p], (pa[p] >> 1) + cav[t], (pb[p] >> 1) + cbv[t]);
+      else if (p < NP) acc[p] = umin3(acc[p], pa[p] + cav[t], pb[p] + cbv[t]);
+    }
+  }
+}
+
 struct __attribute__((packed)) unaligned_u32 { uint32_t v; };
 
-// (cost, spiral index) as a positive normal double whose ordering equals the ordering of the pair:
-// v_min_f64 is a full-rate 64-bit minimum on gfx950, 64-bit integer compare+select is 4.5x slower
-__device__ __forceinline__ double key_as_double(unsigned cost, unsigned idx)
+// (cost, spiral index, dx, dy) of a key of partition p in column ddx (|ddx| = aa): ordered as JM orders candidates
+__device__ __forceinline__ unsigned long long full_key(unsigned kk, int p, int ddx, int aa)
 {
-  return __hiloint2double((int)(cost | 0x40000000u), (int)idx);
+  const unsigned cs = cost_shift(p);
+  const int ddy = rank_to_dy((kk & ((1u << cs) - 1u)) >> tag_shift(p), aa);
+  return ((unsigned long long)(kk >> cs) << 32) | ((unsigned)spiral_index(ddx, ddy) << 16) | ((unsigned)(ddx + 64) << 8) | (unsigned)(ddy + 64);
 }
 
 __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
-                                                       const int16_t *__restrict__ spiral, unsigned *__restrict__ declined, int njobs)
+                                                       unsigned *__restrict__ declined, int njobs)
 {
-  __shared__ __attribute__((aligned(16))) uint32_t s_mem[COPY_DWORDS > MERGE_DWORDS ? COPY_DWORDS : MERGE_DWORDS];   // window copies, later the wave-merge area
-  __shared__ __attribute__((aligned(16))) uint32_t s_ry[65 * RYP];            // (lambda * mvbits(cand_y - pred_y[p])) << 7, [row][partition]
+  __shared__ __attribute__((aligned(16))) uint32_t s_mem[COPY_DWORDS];        // window copies, later the wave-merge area
+  __shared__ __attribute__((aligned(16))) uint32_t s_ry[65 * RYP];            // (lambda * mvbits(cand_y - pred_y[p])) << cost_shift, [row][partition]; later the 65th column's keys
   __shared__ uint32_t s_rx64[RYP];                                              // x rate of column 64, per partition
+  __shared__ int s_px[RYP];                                                     // x predictor per partition (final stage)
   const int jb = xcd_job_index(blockIdx.x, njobs);
   const jmhip_me_job *__restrict__ job = jobs + jb;
   if (!job_is_fast(job)) {                                  // left to k_me_fullsearch, which only does real work when this counter is non-zero
@@ -144,31 +159,39 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = job->search_range, n1 = 2 * R + 1, wrows = 2 * R + 16;
   const int cx = job->center_x, cy = job->center_y, lambda = job->lambda;
+  const uint64_t mask = job->part_mask;
 
-  // ---- stage 1: the raw window (= copy 0), rows/cols clamped into the padded plane of the centre's phase
+  // ---- staging: four byte-shifted copies straight from the reference plane of the centre's phase (rows/cols clamped into the
+  //      padded plane): copy s, row r, dword k = window bytes 4k+s .. 4k+s+3
   {
     const int x0 = job->mb_x + (cx >> 2) - R, y0 = job->mb_y + (cy >> 2) - R;
     const uint8_t *plane = ref00 + ((cy & 3) * 4 + (cx & 3)) * plane_stride;
-    const bool inside = x0 >= -JMHIP_PAD_X && x0 + CPITCH * 4 + 8 <= W + JMHIP_PAD_X;      // no horizontal clamp needed
-    for (int k = tid; k < wrows * (CPITCH + 2); k += NT) {
-      const int r = k / (CPITCH + 2), c = k - r * (CPITCH + 2);                            // 22 dwords per row: bytes 0..87
+    const bool inside = x0 >= -JMHIP_PAD_X && x0 + CPITCH * 4 + 4 <= W + JMHIP_PAD_X;      // no horizontal clamp needed
+    const int total = wrows * CPITCH;
+    for (int k = tid; k < total; k += NT) {
+      const int r = k / CPITCH, c = k - r * CPITCH;
       const int yy = min(max(y0 + r, -JMHIP_PAD_Y), H + JMHIP_PAD_Y - 1) + JMHIP_PAD_Y;
       const uint8_t *prow = plane + (long)yy * pitch + JMHIP_PAD_X;
-      uint32_t v;
-      if (inside) v = ((const unaligned_u32 *)(prow + x0 + 4 * c))->v;
+      uint32_t d0, d1;
+      if (inside) { d0 = ((const unaligned_u32 *)(prow + x0 + 4 * c))->v; d1 = ((const unaligned_u32 *)(prow + x0 + 4 * c + 4))->v; }
       else {
-        v = 0;
+        d0 = 0; d1 = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) v |= (uint32_t)prow[min(max(x0 + 4 * c + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
+        for (int t = 0; t < 4; t++) {
+          d0 |= (uint32_t)prow[min(max(x0 + 4 * c + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
+          d1 |= (uint32_t)prow[min(max(x0 + 4 * c + 4 + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
+        }
       }
-      // raw rows are kept 22 dwords wide in the upper part of the copy area (copies 6,7 are built last from registers)
-      s_mem[(NCOPY - 2) * CSTRIDE + r * (CPITCH + 2) + c] = v;
+      s_mem[0 * CSTRIDE + k] = d0;
+      s_mem[1 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 1);
+      s_mem[2 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 2);
+      s_mem[3 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 3);
     }
-    if (tid < NP) s_rx64[tid] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - job->pred[tid][0])) << 7;
+    if (tid < NP) { s_rx64[tid] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - job->pred[tid][0])) << cost_shift(tid); s_px[tid] = job->pred[tid][0]; }
     // y-rate table
     for (int k = tid; k < n1 * NP; k += NT) {
       const int wy = k / NP, p = k - wy * NP;
-      s_ry[wy * RYP + p] = (uint32_t)(lambda * mvbits(cy + 4 * (wy - R) - job->pred[p][1])) << 7;
+      s_ry[wy * RYP + p] = (uint32_t)(lambda * mvbits(cy + 4 * (wy - R) - job->pred[p][1])) << cost_shift(p);
     }
   }
   // ---- current macroblock: uniform addresses -> scalar loads, stays in SGPRs
@@ -183,171 +206,106 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
     }
   }
   __syncthreads();
-  // ---- stage 2: eight byte-shifted copies: copy s, row r, dword k = window bytes 4k+s .. 4k+s+3
-  {
-    constexpr int NIT = (WROWS_MAX * CPITCH + NT - 1) / NT;
-    uint32_t d[NIT][3];                                     // this thread's items, read before anything is overwritten
-    const int total = wrows * CPITCH;
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int k = tid + NT * it;
-      if (k < total) {
-        const int r = k / CPITCH, c = k - r * CPITCH;
-        const uint32_t *raw = s_mem + (NCOPY - 2) * CSTRIDE + r * (CPITCH + 2) + c;
-        d[it][0] = raw[0]; d[it][1] = raw[1]; d[it][2] = raw[2];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int k = tid + NT * it;
-      if (k < total) {
-        const uint32_t d0 = d[it][0], d1 = d[it][1], d2 = d[it][2];
-        s_mem[0 * CSTRIDE + k] = d0;
-        s_mem[1 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 1);
-        s_mem[2 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 2);
-        s_mem[3 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 3);
-        s_mem[4 * CSTRIDE + k] = d1;
-        s_mem[5 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d2, d1, 1);
-        s_mem[6 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d2, d1, 2);
-        s_mem[7 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d2, d1, 3);
-      }
-    }
-  }
-  __syncthreads();
 
-  // ---- main pass: lane = column wx (0..63), wave w takes row pairs
+  // ---- main pass: lane = column wx (0..63), wave w takes every NW-th row pair
   const int wx = lane, dx = wx - R, a = dx < 0 ? -dx : dx;
   const bool col_ok = wx < n1;
-  const uint2 *cp = (const uint2 *)(s_mem + (wx & 7) * CSTRIDE + 2 * (wx >> 3));
   unsigned acc[NP];
 #pragma unroll
   for (int p = 0; p < NP; p++) acc[p] = 0xffffffffu;
-
-  const int npairs = R;                                  // rows 0 .. 2R-1
-  // pairs go round the waves; the two odd jobs (the last window row, the 65th column) go to the waves with the fewest pairs
+  {
+    const int base = (wx & 3) * CSTRIDE + (wx >> 2);
 #pragma unroll 1
-  for (int j = wave; j < npairs; j += NW) {
-    const int wy = 2 * j, dyA = wy - R;
-    unsigned sa[16], sb[16], pa[NP], pb[NP];
-    sad_pair<true>(cp, wy, cw, sa, sb);
-    aggregate41_shifted(sa, pa);
-    aggregate41_shifted(sb, pb);
-    const unsigned rkA = col_rank(dyA, a), rkB = col_rank(dyA + 1, a);
-    const uint4 *ryA = (const uint4 *)(s_ry + wy * RYP), *ryB = (const uint4 *)(s_ry + (wy + 1) * RYP);
-#pragma unroll
-    for (int g = 0; g < 11; g++) {
-      const uint4 ca = ryA[g], cb = ryB[g];                 // broadcast reads: 4 partitions' row constants
-      const unsigned cav[4] = {ca.x, ca.y, ca.z, ca.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int p = 4 * g + t;
-        if (p < NP) acc[p] = umin3(acc[p], pa[p] + cav[t] + rkA, pb[p] + cbv[t] + rkB);
-      }
-    }
+    for (int u = wave; u <= R; u += NW) step_pair(s_mem, s_ry, base, min(2 * u, 2 * R - 1), R, a, cw, acc);
   }
-  if (wave == NW - 4) {                                  // last row (2R): single-row step
-    const int wy = 2 * R;
-    unsigned sa[16], sb[16], pa[NP];
-    sad_pair<false>(cp, wy, cw, sa, sb);
-    aggregate41_shifted(sa, pa);
-    const unsigned rkA = col_rank(R, a);
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-      const unsigned k = pa[p] + s_ry[wy * RYP + p] + rkA;
-      acc[p] = k < acc[p] ? k : acc[p];
-    }
-  }
-  // The x rate is constant per (lane, partition): it commutes with the minimum over rows, so it is added once, after the
-  // four waves' minima have been merged (below), by the wave that owns the partition -- not by every wave.
 #pragma unroll
   for (int p = 0; p < NP; p++) acc[p] = col_ok ? acc[p] : 0xffffffffu;
 
-  // ---- 65th column (R = 32): its 65 positions are spread over waves 1..3 (generic per-position code on
-  //      copy 0, the plain window); keys use the same (cost << 7 | rank) form with a = 32.
+  // ---- 65th column (R = 32): lane j takes rows (2j, 2j+1), j <= R (the last pair overlaps as above); the wave with the fewest
+  //      row pairs does it.  Keys get the column's x rate here: they are compared across lanes in the final stage.
   unsigned ex[NP];
-  const int exq = (wave - (NW - 3)) + 3 * lane;          // position (row) index of this lane in column 64: the last three waves
-  const bool ex_live = n1 > 64 && wave >= NW - 3 && exq < n1;
-  if (n1 > 64 && wave >= NW - 3) {
+  const bool ex_wave = n1 > 64 && wave == NW - 1, ex_live = ex_wave && lane <= R;
+  if (ex_wave) {
 #pragma unroll
     for (int p = 0; p < NP; p++) ex[p] = 0xffffffffu;
-    if (ex_live) {                                       // wx = 64 is 8-byte aligned in copy 0: same aligned-read SAD code
-      const uint2 *cp64 = (const uint2 *)(s_mem + 2 * (64 >> 3));
-      unsigned sa[16], sb[16], pa[NP];
-      sad_pair<false>(cp64, exq, cw, sa, sb);
-      aggregate41_shifted(sa, pa);
-      const unsigned rk = col_rank(exq - R, 64 - R);
+    step_pair(s_mem, s_ry, 64 >> 2, min(2 * lane, 2 * R - 1), R, 64 - R, cw, ex);
 #pragma unroll
-      for (int p = 0; p < NP; p++) ex[p] = pa[p] + s_ry[exq * RYP + p] + s_rx64[p] + rk;
-    }
+    for (int p = 0; p < NP; p++) ex[p] += s_rx64[p];
   }
-  __syncthreads();                                       // every wave is done reading the window copies
+  __syncthreads();                                       // every wave is done reading the window copies and the y-rate table
   // ---- publish per-lane minima in two rounds (upper half of the waves, then the lower half merged with them):
-  //      s_mem[(w*NP + p)*64 + lane], w < NW/2; the 65th column's keys behind them
-  uint32_t *s_ext = s_mem + NWH * NP * 64;               // [NP][66]
+  //      s_mem[(w*NP + p)*MPITCH + lane], w < NW/2; the 65th column's keys go where the y-rate table was
+  uint32_t *s_ext = s_ry;                                // [NP][EXT_PITCH]
   if (wave >= NWH) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) s_mem[((wave - NWH) * NP + p) * 64 + lane] = acc[p];
+    for (int p = 0; p < NP; p++) s_mem[((wave - NWH) * NP + p) * MPITCH + lane] = acc[p];
   }
   if (ex_live) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) s_ext[p * 66 + exq] = ex[p];
+    for (int p = 0; p < NP; p++) s_ext[p * EXT_PITCH + lane] = ex[p];
   }
   __syncthreads();
   if (wave < NWH) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) acc[p] = min(acc[p], s_mem[(wave * NP + p) * 64 + lane]);
+    for (int p = 0; p < NP; p++) s_mem[(wave * NP + p) * MPITCH + lane] = min(acc[p], s_mem[(wave * NP + p) * MPITCH + lane]);
   }
   __syncthreads();
-  if (wave < NWH) {
-#pragma unroll
-    for (int p = 0; p < NP; p++) s_mem[(wave * NP + p) * 64 + lane] = acc[p];
-  }
-  __syncthreads();
-  // ---- final: wave w reduces partitions p = w, w+NW, ...  Lanes merge the waves (same column: keys comparable) and add the
-  //      column's x rate.  Across columns only the cost part of a key is comparable; ties between columns are decided by JM's
-  //      spiral index.  Ties are rare, so: wave-min of the 32-bit cost; if exactly one candidate attains it, that lane decodes
-  //      its position and stores -- otherwise (cost, spiral index) keys as order-preserving doubles are min-reduced.
+  // ---- final: four threads per partition, each takes 16 columns (+ 9 row pairs of the 65th column).  Within a column the tag
+  //      already orders the rows as JM's spiral does; across columns only the cost is comparable and ties go to the lower
+  //      spiral index.  So: minimum cost first (32-bit); a thread whose best candidate is alone at that cost turns just that one
+  //      into a (cost, spiral index, dx, dy) key; equal costs inside a thread (rare) take the path that converts all of them.
+  //      Two xor-shuffles inside the 4-lane group finish it.  No table look-up: the winner carries its own displacement.
   {
-    const uint64_t mask = job->part_mask;
-    const int dxe = 64 - R;
-#pragma unroll 1
-    for (int p = wave; p < NP; p += NW) {
-      unsigned kk = s_mem[p * 64 + lane];
+    const int p = tid >> 2, sub = tid & 3;
+    if (p < NP) {
+      const int px = s_px[p], cs = cost_shift(p), dxe = 64 - R;
+      unsigned kcol[16], kext[9];
+      unsigned m = 0xffffffffu, cnt = 0, bk = 0xffffffffu;
+      int bdx = 0, ba = 0;
 #pragma unroll
-      for (int w = 1; w < NWH; w++) kk = min(kk, s_mem[(w * NP + p) * 64 + lane]);
-      if (kk != 0xffffffffu) kk += (unsigned)(lambda * mvbits(cx + 4 * dx - job->pred[p][0])) << 7;
-      unsigned e = 0xffffffffu, e2 = 0xffffffffu;
-      if (n1 > 64) { e = s_ext[p * 66 + lane]; if (lane == 0) e2 = s_ext[p * 66 + 64]; }
-      const unsigned c = kk >> 7, ce = e >> 7, ce2 = e2 >> 7;             // 0x1ffffff for "no candidate"
-      unsigned m = umin3(c, ce, ce2);
+      for (int c = 0; c < 16; c++) {
+        const int col = c * 4 + sub, ddx = col - R;
+        unsigned kk = s_mem[p * MPITCH + col];
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-      const unsigned long long bc = __ballot(c == m), be = __ballot(ce == m), be2 = __ballot(ce2 == m);
-      unsigned idx, cost = m;
-      bool writer;
-      if (__popcll(bc) + __popcll(be) + __popcll(be2) == 1) {              // wave-uniform: a unique minimum
-        const bool mine = (c == m) | (ce == m) | (ce2 == m);
-        const unsigned key = c == m ? kk : (ce == m ? e : e2);
-        const int ddx = c == m ? dx : dxe, aa = c == m ? a : dxe;
-        idx = (unsigned)spiral_index(ddx, rank_to_dy(key & 127u, aa));
-        writer = mine;
-      } else {
-        double key = __longlong_as_double(0x7fe0000000000000LL);          // larger than any real key
-        if (kk != 0xffffffffu) key = key_as_double(kk >> 7, (unsigned)spiral_index(dx, rank_to_dy(kk & 127u, a)));
-        if (e != 0xffffffffu) key = fmin(key, key_as_double(e >> 7, (unsigned)spiral_index(dxe, rank_to_dy(e & 127u, dxe))));
-        if (e2 != 0xffffffffu) key = fmin(key, key_as_double(e2 >> 7, (unsigned)spiral_index(dxe, rank_to_dy(e2 & 127u, dxe))));
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) key = fmin(key, __shfl_xor(key, off, 64));
-        const unsigned long long kb = (unsigned long long)__double_as_longlong(key);
-        idx = (unsigned)(kb & 0xffffffffu);
-        cost = (unsigned)((kb >> 32) & 0x3fffffffu);
-        writer = lane == 0;
+        for (int w = 1; w < NWH; w++) kk = min(kk, s_mem[(w * NP + p) * MPITCH + col]);
+        if (kk != 0xffffffffu) kk += (unsigned)(lambda * mvbits(cx + 4 * ddx - px)) << cs;
+        kcol[c] = kk;
+        const unsigned cst = kk >> cs;                    // "no candidate" (0xffffffff) gives the largest value of the field
+        if (cst < m) { m = cst; cnt = 1; bk = kk; bdx = ddx; ba = ddx < 0 ? -ddx : ddx; }
+        else if (cst == m && kk != 0xffffffffu) cnt++;
       }
-      if (writer && ((mask >> p) & 1)) {
+#pragma unroll
+      for (int c = 0; c < 9; c++) {
+        const int q = c * 4 + sub;
+        unsigned e = 0xffffffffu;
+        if (n1 > 64 && q <= R) e = s_ext[p * EXT_PITCH + q];
+        kext[c] = e;
+        const unsigned cst = e >> cs;
+        if (cst < m) { m = cst; cnt = 1; bk = e; bdx = dxe; ba = dxe; }
+        else if (cst == m && e != 0xffffffffu) cnt++;
+      }
+      unsigned long long best = ~0ull;
+      if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
+        if (bk != 0xffffffffu) best = full_key(bk, p, bdx, ba);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          const int ddx = c * 4 + sub - R;
+          if (kcol[c] != 0xffffffffu && (kcol[c] >> cs) == m) { const unsigned long long key = full_key(kcol[c], p, ddx, ddx < 0 ? -ddx : ddx); best = key < best ? key : best; }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+          if (kext[c] != 0xffffffffu && (kext[c] >> cs) == m) { const unsigned long long key = full_key(kext[c], p, dxe, dxe); best = key < best ? key : best; }
+      }
+#pragma unroll
+      for (int off = 1; off <= 2; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+      }
+      if (sub == 0 && ((mask >> p) & 1)) {
         jmhip_me_best b;
-        b.mv_x = (int16_t)(cx + 4 * spiral[2 * idx]); b.mv_y = (int16_t)(cy + 4 * spiral[2 * idx + 1]);
-        b.cost = (int32_t)cost;
+        b.mv_x = (int16_t)(cx + 4 * ((int)((best >> 8) & 0xff) - 64)); b.mv_y = (int16_t)(cy + 4 * ((int)(best & 0xff) - 64));
+        b.cost = (int32_t)(best >> 32);
         results[jb].best[p] = b;
       }
     }
@@ -357,5 +315,5 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
 void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined)
 {
   hipLaunchKernelGGL(k_me_fs_fast, dim3(njobs), dim3(NT), 0, ctx->stream, d_jobs, d_results, ctx->d_cur, ctx->cur_pitch,
-                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, d_declined, njobs);
+                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, d_declined, njobs);
 }
