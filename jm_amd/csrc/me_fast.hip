@@ -39,6 +39,20 @@
 #include "jmhip_internal.h"
 #include "me_common.h"
 
+// Phase profiler (profiles/prof_me.py builds a library with -DME_PROF): lane 0 of every wave stores the s_memtime ticks it spent
+// in each phase; the time stamps sit after the scalar loads of the current macroblock (an earlier one would keep the compiler
+// from using scalar loads at all).  Not compiled into the product library.
+#ifdef ME_PROF
+#define PROF_JOBS 8192
+__device__ unsigned g_me_prof[PROF_JOBS * 8 * 8];
+#define PROF_START unsigned long long tprev = clock64()
+#define PROF(i) do { if (lane == 0) { const unsigned long long t_ = clock64(); g_me_prof[(blockIdx.x * 8 + wave) * 8 + (i)] = (unsigned)(t_ - tprev); tprev = t_; } } while (0)
+extern "C" void jmhip_debug_read_me_prof(unsigned *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(g_me_prof)); }
+#else
+#define PROF_START
+#define PROF(i)
+#endif
+
 #define WROWS_MAX 80                        // 2*32 + 16
 #define CPITCH 20                           // dwords per row of one shifted copy (columns 0..64 + 15 -> 80 bytes)
 #define NCOPY 4
@@ -59,6 +73,13 @@ __device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
 {
   unsigned r;
   asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ unsigned add_sat(unsigned a, unsigned b)
+{
+  unsigned r;
+  asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
@@ -167,31 +188,36 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
     const int x0 = job->mb_x + (cx >> 2) - R, y0 = job->mb_y + (cy >> 2) - R;
     const uint8_t *plane = ref00 + ((cy & 3) * 4 + (cx & 3)) * plane_stride;
     const bool inside = x0 >= -JMHIP_PAD_X && x0 + CPITCH * 4 + 4 <= W + JMHIP_PAD_X;      // no horizontal clamp needed
-    const int total = wrows * CPITCH;
-    for (int k = tid; k < total; k += NT) {
-      const int r = k / CPITCH, c = k - r * CPITCH;
-      const int yy = min(max(y0 + r, -JMHIP_PAD_Y), H + JMHIP_PAD_Y - 1) + JMHIP_PAD_Y;
-      const uint8_t *prow = plane + (long)yy * pitch + JMHIP_PAD_X;
-      uint32_t d0, d1;
-      if (inside) { d0 = ((const unaligned_u32 *)(prow + x0 + 4 * c))->v; d1 = ((const unaligned_u32 *)(prow + x0 + 4 * c + 4))->v; }
-      else {
-        d0 = 0; d1 = 0;
+    // thread <-> dword column c of the copies (20 of them), rows r0, r0 + 12, ...: no division, one address increment per step
+    if (tid < 12 * CPITCH) {
+      const int r0 = tid / CPITCH, c = tid - r0 * CPITCH;
+      const int xa = x0 + 4 * c;
+      for (int r = r0; r < wrows; r += 12) {
+        const int yy = min(max(y0 + r, -JMHIP_PAD_Y), H + JMHIP_PAD_Y - 1) + JMHIP_PAD_Y;
+        const uint8_t *prow = plane + (long)yy * pitch + JMHIP_PAD_X;
+        uint32_t d0, d1;
+        if (inside) { d0 = ((const unaligned_u32 *)(prow + xa))->v; d1 = ((const unaligned_u32 *)(prow + xa + 4))->v; }
+        else {
+          d0 = 0; d1 = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-          d0 |= (uint32_t)prow[min(max(x0 + 4 * c + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
-          d1 |= (uint32_t)prow[min(max(x0 + 4 * c + 4 + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
+          for (int t = 0; t < 4; t++) {
+            d0 |= (uint32_t)prow[min(max(xa + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
+            d1 |= (uint32_t)prow[min(max(xa + 4 + t, -JMHIP_PAD_X), W + JMHIP_PAD_X - 1)] << (8 * t);
+          }
         }
+        const int k = r * CPITCH + c;
+        s_mem[0 * CSTRIDE + k] = d0;
+        s_mem[1 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 1);
+        s_mem[2 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 2);
+        s_mem[3 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 3);
       }
-      s_mem[0 * CSTRIDE + k] = d0;
-      s_mem[1 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 1);
-      s_mem[2 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 2);
-      s_mem[3 * CSTRIDE + k] = __builtin_amdgcn_alignbyte(d1, d0, 3);
     }
-    if (tid < NP) { s_rx64[tid] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - job->pred[tid][0])) << cost_shift(tid); s_px[tid] = job->pred[tid][0]; }
-    // y-rate table
-    for (int k = tid; k < n1 * NP; k += NT) {
-      const int wy = k / NP, p = k - wy * NP;
-      s_ry[wy * RYP + p] = (uint32_t)(lambda * mvbits(cy + 4 * (wy - R) - job->pred[p][1])) << cost_shift(p);
+    // per-partition constants and the y-rate table: thread <-> partition p (6 threads each), rows g, g + 6, ...
+    if (tid < 6 * NP) {
+      const int g = tid / NP, p = tid - g * NP, cs = cost_shift(p);
+      const int py = job->pred[p][1];
+      if (g == 0) { const int px = job->pred[p][0]; s_rx64[p] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - px)) << cs; s_px[p] = px; }
+      for (int wy = g; wy < n1; wy += 6) s_ry[wy * RYP + p] = (uint32_t)(lambda * mvbits(cy + 4 * (wy - R) - py)) << cs;
     }
   }
   // ---- current macroblock: uniform addresses -> scalar loads, stays in SGPRs
@@ -205,7 +231,9 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
       for (int c = 0; c < 4; c++) cw[r * 4 + c] = cp[r * p4 + c];
     }
   }
+  PROF_START;
   __syncthreads();
+  PROF(0);
 
   // ---- main pass: lane = column wx (0..63), wave w takes every NW-th row pair
   const int wx = lane, dx = wx - R, a = dx < 0 ? -dx : dx;
@@ -221,6 +249,7 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
 #pragma unroll
   for (int p = 0; p < NP; p++) acc[p] = col_ok ? acc[p] : 0xffffffffu;
 
+  PROF(1);
   // ---- 65th column (R = 32): lane j takes rows (2j, 2j+1), j <= R (the last pair overlaps as above); the wave with the fewest
   //      row pairs does it.  Keys get the column's x rate here: they are compared across lanes in the final stage.
   unsigned ex[NP];
@@ -232,7 +261,9 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
 #pragma unroll
     for (int p = 0; p < NP; p++) ex[p] += s_rx64[p];
   }
+  PROF(2);
   __syncthreads();                                       // every wave is done reading the window copies and the y-rate table
+  PROF(3);
   // ---- publish per-lane minima in two rounds (upper half of the waves, then the lower half merged with them):
   //      s_mem[(w*NP + p)*MPITCH + lane], w < NW/2; the 65th column's keys go where the y-rate table was
   uint32_t *s_ext = s_ry;                                // [NP][EXT_PITCH]
@@ -250,6 +281,7 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
     for (int p = 0; p < NP; p++) s_mem[(wave * NP + p) * MPITCH + lane] = min(acc[p], s_mem[(wave * NP + p) * MPITCH + lane]);
   }
   __syncthreads();
+  PROF(4);
   // ---- final: four threads per partition, each takes 16 columns (+ 9 row pairs of the 65th column).  Within a column the tag
   //      already orders the rows as JM's spiral does; across columns only the cost is comparable and ties go to the lower
   //      spiral index.  So: minimum cost first (32-bit); a thread whose best candidate is alone at that cost turns just that one
@@ -260,19 +292,16 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
     if (p < NP) {
       const int px = s_px[p], cs = cost_shift(p), dxe = 64 - R;
       unsigned kcol[16], kext[9];
-      unsigned m = 0xffffffffu, cnt = 0, bk = 0xffffffffu;
-      int bdx = 0, ba = 0;
+      unsigned bk = 0xffffffffu;                          // minimum over the 32-bit keys: its cost field is this thread's minimal cost
 #pragma unroll
       for (int c = 0; c < 16; c++) {
-        const int col = c * 4 + sub, ddx = col - R;
+        const int col = c * 4 + sub;
         unsigned kk = s_mem[p * MPITCH + col];
 #pragma unroll
         for (int w = 1; w < NWH; w++) kk = min(kk, s_mem[(w * NP + p) * MPITCH + col]);
-        if (kk != 0xffffffffu) kk += (unsigned)(lambda * mvbits(cx + 4 * ddx - px)) << cs;
+        kk = add_sat(kk, (unsigned)(lambda * mvbits(cx + 4 * (col - R) - px)) << cs);     // "no candidate" stays 0xffffffff
         kcol[c] = kk;
-        const unsigned cst = kk >> cs;                    // "no candidate" (0xffffffff) gives the largest value of the field
-        if (cst < m) { m = cst; cnt = 1; bk = kk; bdx = ddx; ba = ddx < 0 ? -ddx : ddx; }
-        else if (cst == m && kk != 0xffffffffu) cnt++;
+        bk = min(bk, kk);
       }
 #pragma unroll
       for (int c = 0; c < 9; c++) {
@@ -280,14 +309,22 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
         unsigned e = 0xffffffffu;
         if (n1 > 64 && q <= R) e = s_ext[p * EXT_PITCH + q];
         kext[c] = e;
-        const unsigned cst = e >> cs;
-        if (cst < m) { m = cst; cnt = 1; bk = e; bdx = dxe; ba = dxe; }
-        else if (cst == m && e != 0xffffffffu) cnt++;
+        bk = min(bk, e);
       }
+      // how many of this thread's candidates share the minimal cost (x ^ bk has no bit at or above cs)
+      const unsigned lim = 1u << cs;
+      unsigned cnt = 0;
+      int bc = 0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) { cnt += (kcol[c] ^ bk) < lim; bc = kcol[c] == bk ? c : bc; }
+#pragma unroll
+      for (int c = 0; c < 9; c++) { cnt += (kext[c] ^ bk) < lim; bc = kext[c] == bk ? 16 + c : bc; }
       unsigned long long best = ~0ull;
-      if (__builtin_amdgcn_ballot_w64(cnt > 1) == 0) {
-        if (bk != 0xffffffffu) best = full_key(bk, p, bdx, ba);
+      if (__builtin_amdgcn_ballot_w64(cnt > 1 && bk != 0xffffffffu) == 0) {
+        const int ddx = bc < 16 ? bc * 4 + sub - R : dxe;
+        if (bk != 0xffffffffu) best = full_key(bk, p, ddx, ddx < 0 ? -ddx : ddx);
       } else {
+        const unsigned m = bk >> cs;
 #pragma unroll
         for (int c = 0; c < 16; c++) {
           const int ddx = c * 4 + sub - R;
@@ -310,6 +347,7 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
       }
     }
   }
+  PROF(5);
 }
 
 void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined)
