@@ -32,9 +32,10 @@ sys.path.insert(0, ROOT)
 W, H_SRC, H = 1920, 1080, 1088
 R = 32
 QP = 28
-TRAFFIC_BYTES = 12219816   # HBM bytes per launch of k_me_fs_fast: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command,
-                           # corrected as MI355X_MICROARCH.md prescribes (profiles/r01_v5_kernel_stats.md); far below the algorithmic 57.0 MB: neighbouring windows
-                           # overlap and, with the XCD-aware job order, meet in the same L2
+# HBM bytes per launch, per stage (K5, K1-K3, K4, K7/K8, K9/K10): 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
+# MI355X_MICROARCH.md prescribes (profiles/r01_v5_kernel_stats.md).  The full search moves far less than its algorithmic 57.0 MB: neighbouring windows overlap
+# and, with the XCD-aware job order, meet in the same L2
+TRAFFIC_BYTES = [42810000, 12219816, 45250000, 17940000, 16240000]
 MAX_VMV = 512       # level-4/5.1 vertical MV limit in pels (lencod/src/conformance.c:604-631): a search centre can sit this far away
 
 
@@ -126,6 +127,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deblock-load", choices=["real", "worst"], default="real",
+                    help="deblocking side information: the P picture of configs[1] as JM produced it (default) or an intra-heavy made-up mix")
     args = ap.parse_args()
 
     import torch
@@ -205,37 +208,59 @@ def main():
     pre_y = torch.from_numpy(frames[1]).to(dev)
     pre_c = torch.full((2, ch, cw), 128, dtype=torch.uint8, device=dev)
     work_y, work_c = torch.empty_like(pre_y), torch.empty_like(pre_c)
-    mbs = np.zeros(nmb, DB_MB)
-    mbs["mb_type"] = rng.choice([0, 1, 1, 2, 3, 8, 8, 9, 10], nmb)
-    mbs["qp"], mbs["qpc"] = QP, QP - 1
-    mbs["cbp_blk"] = rng.integers(0, 1 << 16, nmb) * (rng.integers(0, 3, nmb) > 0)
-    mbs["cbp"] = np.where(mbs["cbp_blk"] != 0, 15, 0)
+    # side information: what JM's DeblockFrame was given for the P picture of this very configuration (tests/golden/g2_sideinfo.npz,
+    # captured from the reference encoder by tests/golden/make_g2_sideinfo.py): 78 % skipped macroblocks, 8 % with coefficients,
+    # 0.2 % intra, 86 % of the 4x4 blocks on the clip's global motion vector.  --deblock-load worst swaps in a made-up intra-heavy mix.
+    from jm_amd.lib import db_arrays_from_tap
+    if args.deblock_load == "real":
+        g2 = np.load(os.path.join(ROOT, "tests", "golden", "g2_sideinfo.npz"))
+        mbs, mot = db_arrays_from_tap(g2["p_mbs"].astype(np.int32), g2["p_mot"].astype(np.int32))
+        mbs, mot = mbs.copy(), mot.reshape(-1).copy()
+    else:
+        mbs = np.zeros(nmb, DB_MB)
+        mbs["mb_type"] = rng.choice([0, 1, 1, 2, 3, 8, 8, 9, 10], nmb)
+        mbs["qp"], mbs["qpc"] = QP, QP - 1
+        mbs["cbp_blk"] = rng.integers(0, 1 << 16, nmb) * (rng.integers(0, 3, nmb) > 0)
+        mbs["cbp"] = np.where(mbs["cbp_blk"] != 0, 15, 0)
+        mot = np.zeros((H // 4) * (W // 4), DB_MOTION)
+        mot["mv"][:, 0, :] = np.array([12, 8], np.int16) + rng.integers(-5, 6, (len(mot), 2)).astype(np.int16)
+        mot["ref_id"][:, 0], mot["ref_id"][:, 1] = 0, -1
     mbs["df_disable_idc"] = 2 if N > 1 else 0
-    mot = np.zeros((H // 4) * (W // 4), DB_MOTION)
-    mot["mv"][:, 0, :] = np.array([12, 8], np.int16) + rng.integers(-5, 6, (len(mot), 2)).astype(np.int16)
-    mot["ref_id"][:, 0], mot["ref_id"][:, 1] = 0, -1
     d_mbs = torch.from_numpy(mbs.view(np.uint8).reshape(nmb, -1)).to(dev)
     d_mot = torch.from_numpy(mot.view(np.uint8).reshape(len(mot), -1)).to(dev)
     # deblock context works on the band itself (height H), not on the haloed reference
     dctx = ctx if halo == 0 else JmHip(W, H, search_range=R, num_ref_slots=1, yuv_format=1, device=local, stream=stream.cuda_stream)
 
-    fs_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream around every stage of every timed step: 6 marks per step
+    STAGES = ["k_subplanes (K5)", "k_me_fs_fast (K1-K3)", "k_me_refine_mb (K4)", "k_tq_luma4x4 (K7/K8)", "k_deblock_prep + k_deblock_rows (K9/K10)"]
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    SPANS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6)]                     # marks 4..5: the bench's own copy that restores the unfiltered picture
 
     def step(i, timed):
         if N > 1 and one_gpu:                                           # debugging path: the same exchange on host copies over gloo
             local_ref.copy_(shard.exchange_reference(ref_band.cpu(), band, halo, N * H))
         elif N > 1:                                                     # reference-frame exchange over xGMI (RCCL): the one collective
             shard.exchange_reference(ref_band, band, halo, N * H, gathered=gathered, out=local_ref, idx=ref_rows_idx)
+        if timed:
+            marks[i][0].record(stream)
         ctx.set_reference_dev(0, (local_ref if N > 1 else ref_band).data_ptr(), W)   # K5
         if timed:
-            fs_events[i][0].record(stream)
+            marks[i][1].record(stream)
         ctx.me_fullsearch_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr())           # K1-K3
         if timed:
-            fs_events[i][1].record(stream)
+            marks[i][2].record(stream)
         ctx.me_refine_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr(), rprm, d_fin.data_ptr())   # K4
+        if timed:
+            marks[i][3].record(stream)
         ctx.tq_luma4x4_dev(tqp, d_orig.data_ptr(), d_pred.data_ptr(), nblk, d_tq.data_ptr())     # K7/K8
+        if timed:
+            marks[i][4].record(stream)
         work_y.copy_(pre_y); work_c.copy_(pre_c)
+        if timed:
+            marks[i][5].record(stream)
         dctx.deblock_frame_dev(work_y.data_ptr(), W, work_c[0].data_ptr(), work_c[1].data_ptr(), cw, d_mbs.data_ptr(), d_mot.data_ptr(), 1)  # K9/K10
+        if timed:
+            marks[i][6].record(stream)
 
     def barrier():
         if N > 1:
@@ -254,7 +279,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    fs_ms = float(np.mean([a.elapsed_time(b) for a, b in fs_events]))
+    stage_ms = [float(np.mean([m[a].elapsed_time(m[b]) for m in marks])) for (a, b) in SPANS]
+    fs_ms = stage_ms[1]
 
     # sanity: the search found the clip's motion for the 16x16 partition of interior macroblocks
     res = d_fin.cpu().numpy().view(ME_RESULT).reshape(nmb)
@@ -264,7 +290,27 @@ def main():
 
     if rank == 0:
         total_mb = nmb * N * args.steps
-        alg_bytes = (256 + (2 * R + 16) ** 2 + 328) * nmb                # per MB-reference, R=32: 6656 in + 328 out
+        # algorithmic bytes per launch and HBM traffic per launch from the PMC passes (profiles/r01_v6_kernel_stats.md)
+        alg = [W * H + 16 * (W + 64) * (HL + 40),                               # K5: one plane in, 16 padded planes out
+               (256 + (2 * R + 16) ** 2 + 328) * nmb,                           # K1-K3: SURVEY.md 8d per MB-reference: 6656 in + 328 out at R=32
+               7 * 256 * 19 * nmb,                                              # K4: 18 candidate blocks + the current block, 7 block types
+               (32 + 104) * nblk,                                               # K7/K8: 32 B in, 104 B out per 4x4 block
+               int(1.5 * W * H * 2) + (192 + 28 + 16 * 16) * nmb]               # K9/K10: every sample once in, once out + records
+        kernels = [{"kernel": STAGES[k], "ms": round(stage_ms[k], 4), "algorithmic_bytes": alg[k], "hbm_traffic_bytes": TRAFFIC_BYTES[k],
+                    "hbm_frac": round(alg[k] / (stage_ms[k] * 1e-3) / 8e12, 5)} for k in range(len(STAGES))]
+        dom = int(np.argmax(stage_ms))
+        alg_bytes = alg[dom]
+        roof = {"kernel": STAGES[dom], "bound": "hbm", "achieved": round(alg_bytes / (stage_ms[dom] * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(alg_bytes / (stage_ms[dom] * 1e-3) / 8e12, 5), "traffic": TRAFFIC_BYTES[dom], "avg_kernel_ms": round(stage_ms[dom], 4),
+                "algorithmic_bytes_per_launch": alg_bytes}
+        sad_rate = nmb * (2 * R + 1) ** 2 * 256 / (fs_ms * 1e-3)
+        if dom == 1:
+            roof["valu_frac"] = round(sad_rate / 148.4e12, 4)
+            roof["note"] = ("VALU-bound, not HBM-bound (155 abs-diff per algorithmic byte): valu_frac = achieved abs-diff/s over the measured v_sad_hi_u8 "
+                            "peak of 148.4 T abs-diff/s (profiles/r01_valu_rates.txt); DESIGN.md section 3")
+        elif dom == 4:
+            roof["note"] = ("latency-bound by construction: JM's raster-order filter is a chain of (W/16 + H/16) macroblock steps of eight dependent edge "
+                            "filters each; DESIGN.md section 3 (K9/K10)")
         out = {
             "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
             "value": round(total_mb / dt, 1), "unit": "macroblocks/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -273,15 +319,13 @@ def main():
             "config": {"workload": "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP P-frame hot path, FullSearch SR=32, 1 ref, QP 28",
                        "macroblocks_per_step_per_gpu": nmb, "search_range": R, "partitions": NPART,
                        "parallelism": "1 GPU" if N == 1 else f"{N} slices (1080p bands) one per GPU, RCCL all-gather of reconstructed bands per step",
-                       "kernel_path_only": "MV predictors / prediction / deblock side info are synthetic inputs; mode decision and entropy coding stay on the host",
+                       "kernel_path_only": "MV predictors and the prediction fed to the transform are synthetic inputs; the deblocking side information is "
+                                           + ("the P picture's as JM produced it for this configuration" if args.deblock_load == "real" else "a made-up intra-heavy mix")
+                                           + "; mode decision and entropy coding stay on the host",
                        "motion_found_frac": round(motion_ok, 4)},
-            "roofline": {"kernel": "k_me_fs_fast (K1-K3 fused full search; + k_me_fullsearch for the jobs it declines)", "bound": "hbm",
-                         "achieved": round(alg_bytes / (fs_ms * 1e-3) / 1e9, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(alg_bytes / (fs_ms * 1e-3) / 8e12, 5), "traffic": TRAFFIC_BYTES,
-                         "avg_kernel_ms": round(fs_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_frac": round(nmb * (2 * R + 1) ** 2 * 256 / (fs_ms * 1e-3) / 144.8e12, 4),
-                         "valu_note": "the kernel is VALU-bound (155 abs-diff per algorithmic byte): valu_frac = achieved abs-diff/s over the "
-                                      "measured v_sad_u8 peak of 144.8 T abs-diff/s (profiles/r01_valu_rates.txt); DESIGN.md section 3"},
+            "roofline": roof,
+            "kernels": kernels,
+            "me_fullsearch": {"ms": round(fs_ms, 4), "abs_diff_per_s": round(sad_rate / 1e12, 2), "unit": "T abs-diff/s", "valu_frac": round(sad_rate / 148.4e12, 4)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

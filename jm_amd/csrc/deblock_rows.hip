@@ -212,10 +212,28 @@ __device__ __forceinline__ bool await_granules(const unsigned long long *g, bool
 // column access (same k, rows 16 apart) fall into different LDS banks
 #define YROW(R) ((R) * 16 + ((R) >> 4) * 16)
 #define YT_BYTES (YROW(4 + 16 * LR) + 16)      // one ring slot
+// Phase profiler (profiles/prof_deblock.py --phases; built with -DDB_PROF by profiles/build_dbprof.sh, not part of the product
+// library): per luma band and wave, the s_memtime ticks spent waiting at the two barriers of a step and working between them, and
+// four 100 MHz wall-clock stamps (loop entry, step 1, step 64, end) for the bands' time line.
+#ifdef DB_PROF
+__device__ unsigned long long g_db_prof[64 * 2 * 8];
+extern "C" void jmhip_debug_read_db_prof(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_db_prof), sizeof(g_db_prof)); }
+#define DBP_SLOT ((band * 2 + (threadIdx.x >> 6)) * 8)
+#define DBP_ON ((threadIdx.x & 63) == 0 && band < 64)
+#define DBP_DECL unsigned long long tp_ = clock64(), ta_[4] = {0, 0, 0, 0}; if (DBP_ON) g_db_prof[DBP_SLOT + 4] = wall_clock64()
+#define DBP_STEP(s_) do { if (DBP_ON && ((s_) == 1 || (s_) == 64)) g_db_prof[DBP_SLOT + ((s_) == 1 ? 5 : 6)] = wall_clock64(); } while (0)
+#define DBP(i) do { const unsigned long long t_ = clock64(); ta_[i] += t_ - tp_; tp_ = t_; } while (0)
+#define DBP_END do { if (DBP_ON) { for (int i_ = 0; i_ < 4; i_++) g_db_prof[DBP_SLOT + i_] = ta_[i_]; g_db_prof[DBP_SLOT + 7] = wall_clock64(); } } while (0)
+#else
+#define DBP_DECL
+#define DBP(i)
+#define DBP_STEP(s_)
+#define DBP_END
+#endif
 __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* LR x 2 x sizeof(DbPrep) */, volatile int *s_abort)
 {
   const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w;
-  const bool filter_wave = tid < 64;
+  const bool filter_wave = tid < 64, loader_wave = tid >= 128;
   gu32 *err = (gu32 *)(A.sync + 1);
   const int row0 = band * LR, nrows = min(LR, A.mb_h - row0);                  // rows of this band
   const bool has_up = row0 > 0, has_down = row0 + nrows < A.mb_h;
@@ -227,7 +245,8 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
   const int pg = lane / PREP_VEC, pv = lane - pg * PREP_VEC;                  // record loads: lanes [0, LR*PREP_VEC): row pg, vector pv
   const bool is_pre = lane < LR * PREP_VEC && pg < nrows;
   const DbPrep *pre_p = A.prep + (long)(row0 + pg) * mb_w;
-  const bool is_gran = lane < 16 && has_up;                                   // granule `lane` = top row lane>>2, dword lane&3
+  // polling the band above (loader wave): sixteen granules per column, granule `lane` = top row lane>>2, dword lane&3
+  const bool is_gran = lane < 16 && has_up;
   const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * mb_w * HAND_PER_MB + lane;
   unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * mb_w * HAND_PER_MB;
   // image stores: lane L = tall-tile row L = picture row 16*row0 - 4 + L; row g's stores cover its rows -4..11 (the top neighbour's
@@ -237,27 +256,67 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
   const bool tail_ok = !has_down && lane < 4;                                 // rows 12..15 of the last row of the frame
   uint8_t *tail_p = band_p + (long)(16 * nrows - 4 + lane) * A.pitchY;
 
-  // the mover keeps the own samples / records of the next THREE columns in registers: a load issued in step s is first
-  // needed in step s+2, so it never stalls the mover (and through the barrier the filter wave)
-  uint4 own1 = make_uint4(0, 0, 0, 0), pre1 = own1, own2 = own1, pre2 = own1, own3 = own1, pre3 = own1;
-  unsigned long long gr = 0;
-  if (!filter_wave) {                                      // prologue: column 0 of every row, registers of columns 1 and 2
-    if (row_ok) own1 = *(const uint4 *)own_p;
-    if (is_pre) pre1 = ((const uint4 *)pre_p)[pv];
-    if (is_gran) gr = get_granule(hand_up);
-    if (row_ok) *(uint4 *)(s_tiles + YROW(4 + lane)) = own1;
-    if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = pre1;
-    if (mb_w > 1) { if (row_ok) own1 = *(const uint4 *)(own_p + 16); if (is_pre) pre1 = ((const uint4 *)(pre_p + 1))[pv]; }
-    if (mb_w > 2) { if (row_ok) own2 = *(const uint4 *)(own_p + 32); if (is_pre) pre2 = ((const uint4 *)(pre_p + 2))[pv]; }
-  }
-
   const int nsteps = mb_w + nrows - 1;
+  // ---- the LOADER wave: own samples and strength records, global -> registers -> tile ring, two columns ahead.  It has its own loop,
+  // unrolled by two so that the two register sets alternate by NAME: a register is written to LDS two steps after its load was issued
+  // and is never copied -- a copy (or a rotation through a third register) would make the wave wait for a load it issued the step
+  // before, and with nothing to filter that wait (the L2/HBM latency) was the length of a step.  Same barriers as the other two waves.
+  if (loader_wave) {
+    uint4 ownA = make_uint4(0, 0, 0, 0), ownB = ownA, preA = ownA, preB = ownA;
+    if (row_ok) *(uint4 *)(s_tiles + YROW(4 + lane)) = *(const uint4 *)own_p;               // column 0 of every row
+    if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = ((const uint4 *)pre_p)[pv];
+    // column c >= 1 of row g is consumed in step c + g - 1, by the register set of that step's parity
+    { const int ca = (g & 1) ? 2 : 1, cb = 3 - ca;
+      if (row_ok && ca < mb_w) ownA = *(const uint4 *)(own_p + 16 * ca);
+      if (row_ok && cb < mb_w) ownB = *(const uint4 *)(own_p + 16 * cb); }
+    { const int ca = (pg & 1) ? 2 : 1, cb = 3 - ca;
+      if (is_pre && ca < mb_w) preA = ((const uint4 *)(pre_p + ca))[pv];
+      if (is_pre && cb < mb_w) preB = ((const uint4 *)(pre_p + cb))[pv]; }
+    // the band above is polled here too: this wave issues loads only, so a wait for an old load never waits for a store (the wave
+    // that stores would sit out the write acknowledge of its previous step on every poll).  Four granule registers, re-armed right
+    // after use, i.e. four steps before they are needed again; the first look at a register is outside the re-poll loop so that the
+    // compiler's wait counts stay exact (inside the loop it must assume the register was just re-loaded)
+    unsigned long long gr0 = 0, gr1 = 0, gr2 = 0, gr3 = 0;
+    if (is_gran) {
+      gr0 = get_granule(hand_up);
+      if (mb_w > 1) gr1 = get_granule(hand_up + 1 * HAND_PER_MB);
+      if (mb_w > 2) gr2 = get_granule(hand_up + 2 * HAND_PER_MB);
+      if (mb_w > 3) gr3 = get_granule(hand_up + 3 * HAND_PER_MB);
+    }
+#define LSTEP(S, OWN, PRE, GR) { \
+    __syncthreads(); if (*s_abort) return; \
+    if (has_up && (S) < mb_w) {                              /* the first row's top rows of column S */ \
+      if (!__all(!is_gran || (GR >> 32) != 0)) { if (!await_granules(hand_up + (long)(S) * HAND_PER_MB, is_gran, GR, err)) *s_abort = 1; } \
+      if (is_gran) { ((uint32_t *)(s_tiles + ((S) & 3) * YT_BYTES + YROW(lane >> 2)))[lane & 3] = (uint32_t)GR; \
+                     if ((S) + 4 < mb_w) GR = get_granule(hand_up + (long)((S) + 4) * HAND_PER_MB); } \
+    } \
+    __syncthreads(); if (*s_abort) return; \
+    { const int xo = (S) - g + 1; \
+      if (row_ok && xo >= 1 && xo < mb_w) *(uint4 *)(s_tiles + (xo & 3) * YT_BYTES + YROW(4 + lane)) = OWN; \
+      if (row_ok && xo >= 1 && xo + 2 < mb_w) OWN = *(const uint4 *)(own_p + 16 * (xo + 2)); } \
+    { const int xq = (S) - pg + 1; \
+      if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = PRE; \
+      if (is_pre && xq >= 1 && xq + 2 < mb_w) PRE = ((const uint4 *)(pre_p + xq + 2))[pv]; } }
+    for (int s = 0; s < nsteps; s += 4) {
+      LSTEP(s, ownA, preA, gr0)
+      if (s + 1 < nsteps) LSTEP(s + 1, ownB, preB, gr1)
+      if (s + 2 < nsteps) LSTEP(s + 2, ownA, preA, gr2)
+      if (s + 3 < nsteps) LSTEP(s + 3, ownB, preB, gr3)
+    }
+#undef LSTEP
+    __syncthreads();
+    return;
+  }
+  DBP_DECL;
   for (int s = 0; s < nsteps; s++) {
     const int x = s - g;                                   // this lane group's macroblock (filter wave); row g is busy iff 0 <= x < mb_w
     const bool busy = row_ok && x >= 0 && x < mb_w;
     uint8_t *tc = s_tiles + (x & 3) * YT_BYTES, *tp = s_tiles + ((x + 3) & 3) * YT_BYTES;
     const DbPrep *P = (const DbPrep *)(s_preps + (g * 2 + (x & 1)) * sizeof(DbPrep));
+    DBP(3);
+    DBP_STEP(s);
     __syncthreads();                                       // columns s-g are in place for every row; the horizontal edges of step s-1 are done
+    DBP(0);
     if (*s_abort) return;
     if (filter_wave) {
       // ---- V(x): lane = sample row, columns -4..15 in registers (-4..-1 live in the slot of x-1)
@@ -289,14 +348,10 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
         const int r = (lane - 48) >> 2, c4 = (lane - 48) & 3;
         if (c4 < 3) put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + r * 4 + c4, ((const uint32_t *)(s_tiles + ((xl - 1) & 3) * YT_BYTES + YROW(16 * nrows + r)))[c4]);
       }
-      if (has_up && s < mb_w) {                            // the first row's top rows of column s
-        if (!await_granules(hand_up + (long)s * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
-        if (is_gran) { ((uint32_t *)(s_tiles + (s & 3) * YT_BYTES + YROW(lane >> 2)))[lane & 3] = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
-      }
-      { const int xo = s - g + 3; if (row_ok && xo >= 3 && xo < mb_w) own3 = *(const uint4 *)(own_p + 16 * xo); }
-      { const int xq = s - pg + 3; if (is_pre && xq >= 3 && xq < mb_w) pre3 = ((const uint4 *)(pre_p + xq))[pv]; }
     }
+    DBP(1);
     __syncthreads();                                       // V done; the band's top rows are in the slot
+    DBP(2);
     if (*s_abort) return;
     if (filter_wave) {
       // ---- H(x): lane = sample column; rows -4..15 of row g are tall-tile rows 16g .. 16g+19 of the slot of x
@@ -329,13 +384,9 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
         const int xt = s - (nrows - 1) - 1;                // the frame's very last rows
         if (tail_ok && xt >= 0 && xt < mb_w) *(uint4 *)(tail_p + 16 * xt) = *(const uint4 *)(s_tiles + (xt & 3) * YT_BYTES + YROW(16 * nrows + lane));
       }
-      { const int xo = s - g + 1; if (row_ok && xo >= 1 && xo < mb_w) *(uint4 *)(s_tiles + (xo & 3) * YT_BYTES + YROW(4 + lane)) = own1; }
-      { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; }
-      // the registers advance per row when that row has consumed them
-      { const int xo = s - g + 1; if (xo >= 1) { own1 = own2; own2 = own3; } }
-      { const int xq = s - pg + 1; if (xq >= 1) { pre1 = pre2; pre2 = pre3; } }
     }
   }
+  DBP_END;
   __syncthreads();                                         // the last horizontal edges are done
   if (!filter_wave) {                                      // every row's last column; the last row's hand-over of it
     const int xe = mb_w - 1;
@@ -370,8 +421,9 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
   const int pg = lane / PREP_VEC, pv = lane - pg * PREP_VEC;
   const bool is_pre = lane < CR * PREP_VEC && pg < nrows;
   const DbPrep *pre_p = A.prep + (long)(row0 + pg) * mb_w;
-  const bool is_gran = lane >= 56 && has_up;                                  // granule (lane-56) = plane (bit 2), top row (bit 1), dword (bit 0)
-  const int gq = lane - 56;
+  // polling the band above (loader wave, as in luma_rows): eight granules per column, granule gq = plane (bit 2), top row (bit 1), dword (bit 0)
+  const int gq = lane & 7;
+  const bool is_gran = lane < 8 && has_up;
   const int goff = ((gq >> 2) & 1) * CT_PLANE + ((gq >> 1) & 1) * 8 + (gq & 1) * 4;
   const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * mb_w * HAND_PER_MB + 16 + gq;
   unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * mb_w * HAND_PER_MB + 16;
@@ -383,20 +435,50 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
   uint8_t *tail_p = ((lane >> 1) ? A.V : A.U) + (long)(RH * (row0 + nrows) - 2 + (lane & 1)) * A.pitchC;
   const int tail_off = (lane >> 1) * CT_PLANE + (RH * nrows + (lane & 1)) * 8;
 
-  uint2 own1 = make_uint2(0, 0), own2 = own1, own3 = own1;
-  uint4 pre1 = make_uint4(0, 0, 0, 0), pre2 = pre1, pre3 = pre1;
-  unsigned long long gr = 0;
-  if (!filter_wave) {
-    if (vrow_ok) own1 = *(const uint2 *)own_p;
-    if (is_pre) pre1 = ((const uint4 *)pre_p)[pv];
-    if (is_gran) gr = get_granule(hand_up);
-    if (vrow_ok) *(uint2 *)(s_tiles + uvr * CT_PLANE + vt * 8) = own1;
-    if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = pre1;
-    if (mb_w > 1) { if (vrow_ok) own1 = *(const uint2 *)(own_p + 8); if (is_pre) pre1 = ((const uint4 *)(pre_p + 1))[pv]; }
-    if (mb_w > 2) { if (vrow_ok) own2 = *(const uint2 *)(own_p + 16); if (is_pre) pre2 = ((const uint4 *)(pre_p + 2))[pv]; }
-  }
-
   const int nsteps = mb_w + nrows - 1;
+  // ---- the LOADER wave (see luma_rows): own samples of both planes and the strength records, two columns ahead, two register sets
+  if (tid >= 128) {
+    uint2 ownA = make_uint2(0, 0), ownB = ownA;
+    uint4 preA = make_uint4(0, 0, 0, 0), preB = preA;
+    if (vrow_ok) *(uint2 *)(s_tiles + uvr * CT_PLANE + vt * 8) = *(const uint2 *)own_p;
+    if (is_pre) ((uint4 *)(s_preps + pg * 2 * sizeof(DbPrep)))[pv] = ((const uint4 *)pre_p)[pv];
+    { const int ca = (gv & 1) ? 2 : 1, cb = 3 - ca;
+      if (vrow_ok && ca < mb_w) ownA = *(const uint2 *)(own_p + 8 * ca);
+      if (vrow_ok && cb < mb_w) ownB = *(const uint2 *)(own_p + 8 * cb); }
+    { const int ca = (pg & 1) ? 2 : 1, cb = 3 - ca;
+      if (is_pre && ca < mb_w) preA = ((const uint4 *)(pre_p + ca))[pv];
+      if (is_pre && cb < mb_w) preB = ((const uint4 *)(pre_p + cb))[pv]; }
+    unsigned long long gr0 = 0, gr1 = 0, gr2 = 0, gr3 = 0;
+    if (is_gran) {
+      gr0 = get_granule(hand_up);
+      if (mb_w > 1) gr1 = get_granule(hand_up + 1 * HAND_PER_MB);
+      if (mb_w > 2) gr2 = get_granule(hand_up + 2 * HAND_PER_MB);
+      if (mb_w > 3) gr3 = get_granule(hand_up + 3 * HAND_PER_MB);
+    }
+#define LSTEP(S, OWN, PRE, GR) { \
+    __syncthreads(); if (*s_abort) return; \
+    if (has_up && (S) < mb_w) { \
+      if (!__all(!is_gran || (GR >> 32) != 0)) { if (!await_granules(hand_up + (long)(S) * HAND_PER_MB, is_gran, GR, err)) *s_abort = 1; } \
+      if (is_gran) { *(uint32_t *)(s_tiles + ((S) & 3) * CT_BYTES + goff) = (uint32_t)GR; \
+                     if ((S) + 4 < mb_w) GR = get_granule(hand_up + (long)((S) + 4) * HAND_PER_MB); } \
+    } \
+    __syncthreads(); if (*s_abort) return; \
+    { const int xo = (S) - gv + 1; \
+      if (vrow_ok && xo >= 1 && xo < mb_w) *(uint2 *)(s_tiles + (xo & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8) = OWN; \
+      if (vrow_ok && xo >= 1 && xo + 2 < mb_w) OWN = *(const uint2 *)(own_p + 8 * (xo + 2)); } \
+    { const int xq = (S) - pg + 1; \
+      if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = PRE; \
+      if (is_pre && xq >= 1 && xq + 2 < mb_w) PRE = ((const uint4 *)(pre_p + xq + 2))[pv]; } }
+    for (int s = 0; s < nsteps; s += 4) {
+      LSTEP(s, ownA, preA, gr0)
+      if (s + 1 < nsteps) LSTEP(s + 1, ownB, preB, gr1)
+      if (s + 2 < nsteps) LSTEP(s + 2, ownA, preA, gr2)
+      if (s + 3 < nsteps) LSTEP(s + 3, ownB, preB, gr3)
+    }
+#undef LSTEP
+    __syncthreads();
+    return;
+  }
   for (int s = 0; s < nsteps; s++) {
     __syncthreads();
     if (*s_abort) return;
@@ -429,12 +511,6 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
         const int q = lane - 48, uv = q >> 2, r = (q >> 1) & 1;
         put_granule(hand_me + (long)(xl - 1) * HAND_PER_MB + q, *(const uint32_t *)(s_tiles + ((xl - 1) & 3) * CT_BYTES + uv * CT_PLANE + (RH * nrows + r) * 8));
       }
-      if (has_up && s < mb_w) {
-        if (!await_granules(hand_up + (long)s * HAND_PER_MB, is_gran, gr, err)) *s_abort = 1;
-        if (is_gran) { *(uint32_t *)(s_tiles + (s & 3) * CT_BYTES + goff) = (uint32_t)gr; if (s + 1 < mb_w) gr = get_granule(hand_up + (long)(s + 1) * HAND_PER_MB); }
-      }
-      { const int xo = s - gv + 3; if (vrow_ok && xo >= 3 && xo < mb_w) own3 = *(const uint2 *)(own_p + 8 * xo); }
-      { const int xq = s - pg + 3; if (is_pre && xq >= 3 && xq < mb_w) pre3 = ((const uint4 *)(pre_p + xq))[pv]; }
     }
     __syncthreads();
     if (*s_abort) return;
@@ -475,8 +551,6 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
         const int xt = s - (nrows - 1) - 1;
         if (tail_ok && xt >= 0 && xt < mb_w) *(uint2 *)(tail_p + 8 * xt) = *(const uint2 *)(s_tiles + (xt & 3) * CT_BYTES + tail_off);
       }
-      { const int xo = s - gv + 1; if (vrow_ok && xo >= 1 && xo < mb_w) *(uint2 *)(s_tiles + (xo & 3) * CT_BYTES + uvr * CT_PLANE + vt * 8) = own1; if (xo >= 1) { own1 = own2; own2 = own3; } }
-      { const int xq = s - pg + 1; if (is_pre && xq >= 1 && xq < mb_w) ((uint4 *)(s_preps + (pg * 2 + (xq & 1)) * sizeof(DbPrep)))[pv] = pre1; if (xq >= 1) { pre1 = pre2; pre2 = pre3; } }
     }
   }
   __syncthreads();
@@ -492,7 +566,7 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
   }
 }
 
-__global__ __launch_bounds__(128) void k_deblock_rows(RowArgs A)
+__global__ __launch_bounds__(192) void k_deblock_rows(RowArgs A)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * (YT_BYTES > CT_BYTES ? YT_BYTES : CT_BYTES)];
   __shared__ __attribute__((aligned(16))) uint8_t s_preps[LR * 2 * sizeof(DbPrep)];
@@ -500,7 +574,7 @@ __global__ __launch_bounds__(128) void k_deblock_rows(RowArgs A)
   __shared__ int s_abort;
   const int tid = threadIdx.x;
   if (tid == 0) { s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT); s_abort = 0; }
-  for (int k = tid; k < (int)sizeof(s_tiles) / 4; k += 128) ((uint32_t *)s_tiles)[k] = 0;
+  for (int k = tid; k < (int)sizeof(s_tiles) / 4; k += 192) ((uint32_t *)s_tiles)[k] = 0;
   __syncthreads();
   // tickets: luma and chroma bands alternate, top to bottom -- a workgroup only ever waits for one with a smaller ticket,
   // i.e. one that has already started
@@ -524,6 +598,6 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
   RowArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
   A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;
-  hipLaunchKernelGGL(k_deblock_rows, dim3((mb_h + LR - 1) / LR + (nkinds > 1 ? (mb_h + (fmt == 2 ? 2 : 4) - 1) / (fmt == 2 ? 2 : 4) : 0)), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_deblock_rows, dim3((mb_h + LR - 1) / LR + (nkinds > 1 ? (mb_h + (fmt == 2 ? 2 : 4) - 1) / (fmt == 2 ? 2 : 4) : 0)), dim3(192), 0, ctx->stream, A);
   return JMHIP_OK;
 }
