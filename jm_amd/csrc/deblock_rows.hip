@@ -126,19 +126,23 @@ __device__ __forceinline__ void luma_edge(int (&p)[N], int bS, int alpha, int be
   const int tc = c0 + (int)apb + (int)aqb;
   const int dif = med3i(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
   int nL2 = L2, nR2 = R2;
-  int nL1 = apb ? L1 + med3i(-c0, c0, (L2 + RL0 - (L1 << 1)) >> 1) : L1;
-  int nR1 = aqb ? R1 + med3i(-c0, c0, (R2 + RL0 - (R1 << 1)) >> 1) : R1;
+  // both arms of every selection are computed and pinned (FORCE): left alone the compiler turns "cond ? five instructions : x" into an
+  // exec-mask branch, which costs this single wave more issue slots (s_and_saveexec, s_cbranch, s_or, a copy) than the arm itself
+#define FORCE(v) asm volatile("" : "+v"(v))
+  int tL1 = L1 + med3i(-c0, c0, (L2 + RL0 - (L1 << 1)) >> 1), tR1 = R1 + med3i(-c0, c0, (R2 + RL0 - (R1 << 1)) >> 1);
+  FORCE(tL1); FORCE(tR1);
+  int nL1 = apb ? tL1 : L1, nR1 = aqb ? tR1 : R1;
   int nL0 = med3i(0, 255, L0 + dif), nR0 = med3i(0, 255, R0 - dif);
   if (any_strong) {                                                           // bS == 4 somewhere in the wave
     const bool st = bS == 4, sg = ad < ((alpha >> 2) + 2);
     const bool ap = apb && sg, aq = aqb && sg;
     const int S = L0 + R0;
-    const int sL0 = ap ? (R1 + ((L1 + S) << 1) + L2 + 4) >> 3 : ((L1 << 1) + L0 + R1 + 2) >> 2;
-    const int sL1 = ap ? (L2 + L1 + S + 2) >> 2 : L1;
-    const int sL2 = ap ? (((L3 + L2) << 1) + L2 + L1 + S + 4) >> 3 : L2;
-    const int sR0 = aq ? (L1 + ((R1 + S) << 1) + R2 + 4) >> 3 : ((R1 << 1) + R0 + L1 + 2) >> 2;
-    const int sR1 = aq ? (R2 + R0 + L0 + R1 + 2) >> 2 : R1;
-    const int sR2 = aq ? (((R3 + R2) << 1) + R2 + R1 + S + 4) >> 3 : R2;
+    int aL0 = (R1 + ((L1 + S) << 1) + L2 + 4) >> 3, bL0 = ((L1 << 1) + L0 + R1 + 2) >> 2, aL1 = (L2 + L1 + S + 2) >> 2, aL2 = (((L3 + L2) << 1) + L2 + L1 + S + 4) >> 3;
+    int aR0 = (L1 + ((R1 + S) << 1) + R2 + 4) >> 3, bR0 = ((R1 << 1) + R0 + L1 + 2) >> 2, aR1 = (R2 + R0 + L0 + R1 + 2) >> 2, aR2 = (((R3 + R2) << 1) + R2 + R1 + S + 4) >> 3;
+    FORCE(aL0); FORCE(bL0); FORCE(aL1); FORCE(aL2); FORCE(aR0); FORCE(bR0); FORCE(aR1); FORCE(aR2);
+    const int sL0 = ap ? aL0 : bL0, sL1 = ap ? aL1 : L1, sL2 = ap ? aL2 : L2;
+    const int sR0 = aq ? aR0 : bR0, sR1 = aq ? aR1 : R1, sR2 = aq ? aR2 : R2;
+#undef FORCE
     nL0 = st ? sL0 : nL0; nL1 = st ? sL1 : nL1; nL2 = st ? sL2 : nL2;
     nR0 = st ? sR0 : nR0; nR1 = st ? sR1 : nR1; nR2 = st ? sR2 : nR2;
     p[O + 1] = on ? nL2 : L2; p[O + 6] = on ? nR2 : R2;
