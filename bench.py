@@ -33,9 +33,9 @@ W, H_SRC, H = 1920, 1080, 1088
 R = 32
 QP = 28
 # HBM bytes per launch, per stage (K5, K1-K3, K4, K7/K8, K9/K10): 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
-# MI355X_MICROARCH.md prescribes (profiles/r01_v5_kernel_stats.md).  The full search moves far less than its algorithmic 57.0 MB: neighbouring windows overlap
+# MI355X_MICROARCH.md prescribes (profiles/r01_v6_kernel_stats.md).  The full search moves far less than its algorithmic 57.0 MB: neighbouring windows overlap
 # and, with the XCD-aware job order, meet in the same L2
-TRAFFIC_BYTES = [42810000, 12219816, 45250000, 17940000, 16240000]
+TRAFFIC_BYTES = [42809088, 12333600, 45246336, 17939968, 17047488]
 MAX_VMV = 512       # level-4/5.1 vertical MV limit in pels (lencod/src/conformance.c:604-631): a search centre can sit this far away
 
 

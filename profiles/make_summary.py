@@ -10,8 +10,8 @@ out = [f"# {title} -- rocprofv3 --kernel-trace --stats", "",
 for r in rows:
     out.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.3f} | {float(r['Percentage']):.2f} |")
 b, bb = json.load(open(f"{O}/bench_prof.json")), json.load(open(f"{O}/bench.json"))
-out += ["", f"bench line of the profiled run: ms_per_step {b['ms_per_step']}, full search (k_me_fs_fast + k_me_fullsearch) by HIP events {b['roofline']['avg_kernel_ms']} ms",
-        f"bench line without the profiler (profiles/{tag}_bench.json): {bb['value']} MB/s, ms_per_step {bb['ms_per_step']}, full search {bb['roofline']['avg_kernel_ms']} ms",
+out += ["", f"bench line of the profiled run: ms_per_step {b['ms_per_step']}, stages by HIP events (ms): {[k['ms'] for k in b['kernels']]}",
+        f"bench line without the profiler (profiles/{tag}_bench.json): {bb['value']} MB/s, ms_per_step {bb['ms_per_step']}, stages (ms): {[k['ms'] for k in bb['kernels']]}",
         "", "## HBM traffic from PMC counters (separate passes, `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, bench.py --steps 3 --warmup 1)", "",
         "Unit KB per launch; FETCH_SIZE x 2 on gfx950 (calibration: profiles/r01_v3_kernel_stats.md, profiles/microbench/fetch_calib.hip).", "",
         "| kernel | FETCH_SIZE KB | x2 = read MB | WRITE_SIZE KB | traffic MB | algorithmic MB |", "|---|---|---|---|---|---|"]
@@ -27,8 +27,9 @@ alg = {"k_me_fs_fast": 56.99, "k_subplanes": 2.09 + 35.81, "k_tq_luma4x4": 13056
 for k in ("k_me_fs_fast", "k_me_refine_mb", "k_subplanes", "k_tq_luma4x4", "k_deblock_prep", "k_deblock_rows"):
     f, w = acc[k].get("FETCH_SIZE", 0), acc[k].get("WRITE_SIZE", 0)
     out.append(f"| `{k}` | {f:.0f} | {2*f*1024/1e6:.2f} | {w:.0f} | {(2*f+w)*1024/1e6:.2f} | {round(alg[k],2) if k in alg else ''} |")
-    if k == "k_me_fs_fast":
-        print("k_me_fs_fast traffic bytes:", round((2 * f + w) * 1024))
+tb = lambda k: (2 * acc[k].get("FETCH_SIZE", 0) + acc[k].get("WRITE_SIZE", 0)) * 1024
+print("TRAFFIC_BYTES =", [round(tb("k_subplanes")), round(tb("k_me_fs_fast") + tb("k_me_fullsearch")), round(tb("k_me_refine_mb")), round(tb("k_tq_luma4x4")),
+                          round(tb("k_deblock_prep") + tb("k_deblock_rows"))])
 open(f"profiles/{tag}_kernel_stats.md", "w").write("\n".join(out) + "\n")
 shutil.copy(f"{O}/bench.json", f"profiles/{tag}_bench.json")
 shutil.copy(f"{O}/stats/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
