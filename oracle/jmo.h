@@ -169,6 +169,11 @@ int jmo_rtq_luma_4x4(const jmo_pel orig[16], const jmo_pel pred[16], int qp, int
 /* ---- sub-pel plane generation: getSubImagesLuma lencod/src/img_luma.c:611-679 ----
  * src: W x H luma (pitch src_pitch).  dst: 16 planes, plane (j,i) at dst + (j*4+i)*plane_stride,
  * each (H+2*PAD_Y) rows x pitch samples, picture origin at row PAD_Y, col PAD_X. */
+/* ---- motion-compensated prediction, un-weighted (lencod/src/mc_prediction.c; see jmo_mc.c) ---- */
+void jmo_luma_pred(const jmo_refpic *r0, const jmo_refpic *r1, int p_dir, int x, int y, int bsx, int bsy, jmo_mv mv0, jmo_mv mv1, jmo_pel *out);
+void jmo_chroma_pred4x4(const jmo_pel *p0, const jmo_pel *p1, int pitch, int W, int H, int yuv, int p_dir, int xc, int yc,
+                        const jmo_mv mv0[4][2], const jmo_mv mv1[4][2], jmo_pel out[16]);
+
 void jmo_sub_images_luma(const jmo_pel *src, int src_pitch, int width, int height,
                          int max_pel, jmo_pel *dst, int pitch, long plane_stride);
 

@@ -74,6 +74,8 @@ L.jmo_compute_satd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int
 L.jmo_sub_images_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_long]
 L.jmo_ffs_search.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, MV, MV, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]
 L.jmo_ffs_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, MV, C.c_int, C.c_void_p]
+L.jmo_luma_pred.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, MV, MV, C.c_void_p]
+L.jmo_chroma_pred4x4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
 def _p(a):
@@ -284,3 +286,27 @@ def deblock_frame(y, u, v, fmt, mbs, mot, maxy=255, maxc=255, d8=1):
     L.jmo_deblock_frame(_p(Y), w, _p(U) if U is not None else None, _p(V) if V is not None else None,
                         U.shape[1] if U is not None else 0, w, h, fmt, arr, _p(mo_bytes), maxy, maxc, d8)
     return Y, U, V
+
+
+# ---- motion-compensated prediction (jmo_mc.c)
+def luma_pred(r0, r1, p_dir, x, y, bsx, bsy, mv0, mv1):
+    """luma_prediction, un-weighted: r0 / r1 RefPic of list 0 / 1 (either may be None when unused); returns (bsy, bsx) uint8"""
+    out = np.zeros(bsx * bsy, np.uint16)
+    any_ref = r0 if r0 is not None else r1
+    L.jmo_luma_pred((r0 or any_ref).ptr(), (r1 or any_ref).ptr(), int(p_dir), int(x), int(y), int(bsx), int(bsy),
+                    MV(int(mv0[0]), int(mv0[1])), MV(int(mv1[0]), int(mv1[1])), _p(out))
+    return out.reshape(bsy, bsx).astype(np.uint8)
+
+
+def chroma_pred4x4(p0, p1, yuv, p_dir, xc, yc, mv0, mv1):
+    """chroma_prediction_4x4 (ChromaMCBuffer = 1), un-weighted: p0 / p1 integer chroma planes (H, W) of list 0 / 1;
+    mv0 / mv1: (4, 2, 2) vectors per sample row and sample pair; returns (4, 4) uint8"""
+    anyp = p0 if p0 is not None else p1
+    a = np.ascontiguousarray(p0 if p0 is not None else anyp, np.uint16)
+    b = np.ascontiguousarray(p1 if p1 is not None else anyp, np.uint16)
+    h, w = a.shape
+    m0 = np.ascontiguousarray(mv0, np.int16).reshape(4, 2, 2)
+    m1 = np.ascontiguousarray(mv1, np.int16).reshape(4, 2, 2)
+    out = np.zeros(16, np.uint16)
+    L.jmo_chroma_pred4x4(_p(a), _p(b), w, w, h, int(yuv), int(p_dir), int(xc), int(yc), _p(m0), _p(m1), _p(out))
+    return out.reshape(4, 4).astype(np.uint8)

@@ -55,6 +55,13 @@ static void put_plane(FILE *f, imgpel **rows, int y0, int x0, int h, int w)
 }
 
 static int g_refs_made = 0;        /* number of getSubImagesLuma calls so far = reference pictures produced */
+static StorablePicture *g_ref_ptr[64];   /* reference picture made by call number k (mod 64): identity for the prediction taps */
+static int ref_index_of(StorablePicture *s)
+{
+  int k;
+  for (k = g_refs_made - 1; k >= 0 && k >= g_refs_made - 64; k--) if (g_ref_ptr[k & 63] == s) return k;
+  return -1;
+}
 static int g_cur_dumped = -1;
 
 static void dump_cur_frame(VideoParameters *p_Vid)
@@ -186,8 +193,85 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
       for (i = 0; i < 4; i++)
         put_plane(f, s->p_curr_img_sub[j][i], -IMG_PAD_SIZE_Y, -IMG_PAD_SIZE_X, s->size_y_padded, s->size_x_padded);
     fclose(f);
+    if (p_Vid->yuv_format != YUV400) {           /* the integer chroma planes of the same picture (chroma prediction) */
+      f = tap_open("refchroma.bin");
+      put_i32(f, g_refs_made); put_i32(f, p_Vid->yuv_format);
+      put_plane(f, s->imgUV[0], 0, 0, s->size_y_cr, s->size_x_cr);
+      put_plane(f, s->imgUV[1], 0, 0, s->size_y_cr, s->size_x_cr);
+      fclose(f);
+    }
   }
+  g_ref_ptr[g_refs_made & 63] = s;
   g_refs_made++;
+}
+
+/* ------------------------------------------------------------------ motion-compensated prediction
+ *   luma_prediction          lencod/src/mc_prediction.c:144   (bound to p_Dpb->pf_luma_prediction in lencod.c:367)
+ *   chroma_prediction_4x4    lencod/src/mc_prediction.c:568
+ * Records: the block, the direction, per list {reference picture made by getSubImagesLuma call k, motion vector(s)} exactly as the
+ * function resolves them, and the samples it left in currSlice->mb_pred. */
+static MotionVector *****mc_mv_array(Macroblock *currMB, int p_dir, int m0, int m1, int r0, int r1, short bipred_me)
+{
+  Slice *sl = currMB->p_Slice;
+  if (bipred_me && r0 == 0 && r1 == 0 && p_dir == 2 && is_bipred_enabled(currMB->p_Vid, m0) && is_bipred_enabled(currMB->p_Vid, m1))
+    return sl->bipred_mv[bipred_me - 1];
+  return sl->all_mv;
+}
+extern void __real_luma_prediction(Macroblock *, int, int, int, int, int, int *, char *, short);
+void __wrap_luma_prediction(Macroblock *currMB, int block_x, int block_y, int bsx, int bsy, int p_dir, int list_mode[2], char *ref_idx, short bipred_me)
+{
+  static int n = 0, calls = 0;
+  __real_luma_prediction(currMB, block_x, block_y, bsx, bsy, p_dir, list_mode, ref_idx, bipred_me);
+  if (calls++ % 16 == 0 && n < tap_max() / 4 && g_refs_made <= 4) {      /* every 16th call: the sample reaches the later pictures */
+    Slice *sl = currMB->p_Slice;
+    MotionVector *****mva = mc_mv_array(currMB, p_dir, list_mode[0], list_mode[1], ref_idx[0], ref_idx[1], bipred_me);
+    int wp = (sl->weighted_prediction == 1) || (sl->weighted_prediction == 2 && p_dir == 2);
+    int l, j;
+    FILE *f = tap_open("mc_luma.bin");
+    put_i32(f, g_refs_made); put_i32(f, currMB->pix_x + block_x); put_i32(f, currMB->opix_y + block_y);
+    put_i32(f, bsx); put_i32(f, bsy); put_i32(f, p_dir); put_i32(f, wp);
+    for (l = 0; l < 2; l++) {
+      if (p_dir == l || p_dir == 2) {
+        MotionVector *mv = &mva[l][(short)ref_idx[l]][list_mode[l]][block_y >> 2][block_x >> 2];
+        put_i32(f, ref_index_of(sl->listX[l + currMB->list_offset][(short)ref_idx[l]])); put_i32(f, mv->mv_x); put_i32(f, mv->mv_y);
+      } else { put_i32(f, -1); put_i32(f, 0); put_i32(f, 0); }
+    }
+    for (j = 0; j < bsy; j++) fwrite(&sl->mb_pred[0][block_y + j][block_x], sizeof(imgpel), (size_t)bsx, f);
+    fclose(f); n++;
+  }
+}
+extern void __real_chroma_prediction_4x4(Macroblock *, int, int, int, int, int, int, short, short, short);
+void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int block_y, int p_dir, int l0_mode, int l1_mode,
+                                  short l0_ref_idx, short l1_ref_idx, short bipred_me)
+{
+  static int n = 0, calls = 0;
+  __real_chroma_prediction_4x4(currMB, uv, block_x, block_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx, bipred_me);
+  if (calls++ % 32 == 0 && n < tap_max() / 2 && g_refs_made <= 4) {
+    VideoParameters *p_Vid = currMB->p_Vid;
+    Slice *sl = currMB->p_Slice;
+    MotionVector *****mva = mc_mv_array(currMB, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx, bipred_me);
+    int wp = (sl->weighted_prediction == 1) || (sl->weighted_prediction == 2 && p_dir == 2);
+    int rsx = 4 - p_Vid->chroma_shift_x, rsy = 4 - p_Vid->chroma_shift_y;      /* chroma sample -> luma 4x4 block index, as the function does */
+    int mode[2] = {l0_mode, l1_mode}, ref[2] = {l0_ref_idx, l1_ref_idx};
+    int l, j;
+    FILE *f = tap_open("mc_chroma.bin");
+    put_i32(f, g_refs_made); put_i32(f, p_Vid->yuv_format); put_i32(f, uv);
+    put_i32(f, currMB->pix_c_x + block_x); put_i32(f, currMB->opix_c_y + block_y); put_i32(f, p_dir); put_i32(f, wp);
+    put_i32(f, p_Vid->p_Inp->ChromaMCBuffer);
+    for (l = 0; l < 2; l++) {
+      if (p_dir == l || p_dir == 2) {
+        StorablePicture *pic = sl->listX[l + currMB->list_offset][ref[l]];
+        MotionVector **mv = mva[l][ref[l]][mode[l]];
+        put_i32(f, ref_index_of(pic)); put_i32(f, pic->chroma_vector_adjustment);
+        for (j = block_y; j < block_y + 4; j++) {          /* the two vectors each sample row uses (left / right sample pair) */
+          MotionVector *a = &mv[j >> rsy][block_x >> rsx], *b = &mv[j >> rsy][(block_x + 2) >> rsx];
+          put_i32(f, a->mv_x); put_i32(f, a->mv_y); put_i32(f, b->mv_x); put_i32(f, b->mv_y);
+        }
+      } else { int k; put_i32(f, -1); put_i32(f, 0); for (k = 0; k < 16; k++) put_i32(f, 0); }
+    }
+    for (j = 0; j < 4; j++) fwrite(&sl->mb_pred[uv + 1][block_y + j][block_x], sizeof(imgpel), 4, f);
+    fclose(f); n++;
+  }
 }
 
 /* ------------------------------------------------------------------ deblocking */

@@ -12,6 +12,7 @@ stores what the reference's hot-path functions were given and what they returned
   tests/golden/qcif_ffs.npz   FastFullSearch SR=16: BlockSAD tables + argmin records
   tests/golden/qcif_422.npz   High 4:2:2, 8x8 transform, CABAC: deblock in/out (intra + inter)
   tests/golden/qcif_main.npz  Main profile with a B frame: deblock in/out (two-list strengths)
+  tests/golden/qcif_mc.npz    luma_prediction / chroma_prediction_4x4 records (4:2:0 P, 4:2:2 P, B picture) + the reference planes they read
   tests/golden/md5.json       .264 / recon md5 of the BASELINE.json configurations at QCIF
 
 Fixtures are data only (inputs and expected outputs); no reference source is stored.
@@ -102,6 +103,48 @@ def read_subimages(path):
                         sha=[hashlib.sha256(p.astype(np.uint8).tobytes()).hexdigest() for p in planes],
                         planes=planes))
     return out
+
+
+def read_mc(path, luma):
+    """mc_luma.bin: 13 ints + bsx*bsy samples;  mc_chroma.bin: 44 ints + 16 samples (oracle/ref_tap.c)"""
+    r, hdr, pix = Reader(path), [], []
+    while not r.eof():
+        h = r.i32(13 if luma else 44).copy()
+        n = int(h[3]) * int(h[4]) if luma else 16
+        px = np.frombuffer(r.b, np.uint16, n, r.o).astype(np.uint8); r.o += 2 * n
+        full = np.zeros(256 if luma else 16, np.uint8); full[:n] = px
+        hdr.append(h); pix.append(full)
+    return (np.array(hdr, np.int32).reshape(-1, 13 if luma else 44), np.array(pix, np.uint8).reshape(-1, 256 if luma else 16))
+
+
+def read_refchroma(path):
+    r, out = Reader(path), {}
+    while not r.eof():
+        idx, fmt = r.i32(), r.i32()
+        out[int(idx)] = (r.plane().astype(np.uint8), r.plane().astype(np.uint8))
+    return out
+
+
+def mc_arrays(tag, workdir, d, n_luma=260, n_chroma=420):
+    """prediction records of one tapped run: a spread sample, every record whose vector leaves the picture far enough to hit the
+    origin clamps, and the reference pictures (luma source + integer chroma planes) they read"""
+    lh, lp = read_mc(os.path.join(workdir, "mc_luma.bin"), True)
+    ch, cp = read_mc(os.path.join(workdir, "mc_chroma.bin"), False)
+    def pick(h, n, far):
+        keep = np.zeros(len(h), bool); keep[:: max(1, len(h) // n)] = True; keep |= far
+        return np.flatnonzero(keep)[: 2 * n]
+    mv = np.abs(lh[:, [8, 9, 11, 12]]).max(1)
+    il = pick(lh, n_luma, (mv > 40) | (lh[:, 5] == 2))
+    mvc = np.abs(ch[:, 10:26]).max(1)
+    ic = pick(ch, n_chroma, (mvc > 40) | (ch[:, 5] == 2))
+    d[tag + "_mcl_hdr"], d[tag + "_mcl_pix"] = lh[il], lp[il]
+    d[tag + "_mcc_hdr"], d[tag + "_mcc_pix"] = ch[ic], cp[ic]
+    used = set(lh[il][:, 7].tolist()) | set(lh[il][:, 10].tolist()) | set(ch[ic][:, 8].tolist()) | set(ch[ic][:, 26].tolist())
+    subs = {s_["idx"]: s_ for s_ in read_subimages(os.path.join(workdir, "subimages.bin"))}
+    rc = read_refchroma(os.path.join(workdir, "refchroma.bin"))
+    for k in sorted(u for u in used if u >= 0):
+        d[f"{tag}_ref{k}_y"] = subs[k]["src"]
+        d[f"{tag}_ref{k}_u"], d[f"{tag}_ref{k}_v"] = rc[k]
 
 
 def read_deblock(path):
@@ -207,6 +250,11 @@ def main():
         d = {}
         deblock_arrays("db", read_deblock(os.path.join(we, "deblock.bin")), d)
         np.savez_compressed(os.path.join(OUT, "qcif_main.npz"), **d)
+
+        # ---- motion-compensated prediction (luma_prediction / chroma_prediction_4x4) of runs A (4:2:0 P), C (4:2:2 P), E (B picture)
+        d = {}
+        mc_arrays("a", wa, d); mc_arrays("c", wc, d); mc_arrays("e", we, d)
+        np.savez_compressed(os.path.join(OUT, "qcif_mc.npz"), **d)
 
         # ---- D: 8x8 transform / quantisation and the DC transforms (High 4:2:2 CABAC + adaptive rounding; the same with CAVLC
         #         and plain rounding; High 4:2:0 CAVLC for the 2x2 chroma DC transform)
