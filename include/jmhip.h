@@ -277,6 +277,42 @@ typedef struct { int16_t level[17]; uint8_t run[17]; uint8_t nonzero; } jmhip_dc
 int jmhip_quant_dc4x4(jmhip_ctx *ctx, const jmhip_qparam *q, int32_t qp_per, int32_t cavlc, int32_t *blocks, int32_t nblocks, jmhip_dc_out *out);
 
 /* ------------------------------------------------------------------------------------------
+ * Motion-compensated prediction, un-weighted, frame pictures
+ *
+ * luma:   luma_prediction (lencod/src/mc_prediction.c:144-236; bound to p_Dpb->pf_luma_prediction, lencod.c:367):
+ *         OneComponentLumaPrediction :122-136 copies block_size_y rows of block_size_x samples from the quarter-pel plane
+ *         the vector's phase selects, from ONE UMVLine4X origin (refbuf.h:22-26); two lists: (a + b + 1) >> 1 (:82-93).
+ * chroma: chroma_prediction_4x4 (:568-650) with ChromaMCBuffer = 1 (OneComponentChromaPrediction4x4_retrieve :361-411):
+ *         per sample row and sample pair the vector of the luma 4x4 block above them, two samples from the chroma sub-image
+ *         of the vector's phase (getSubImagesChroma, lencod/src/img_chroma.c:338-437) through UMVLine8X_chroma (refbuf.h:61-65).
+ *         The device interpolates from the integer chroma planes on the fly -- the same values, without 64 (4:2:0) / 32 (4:2:2)
+ *         stored sub-images per plane.
+ * A reference slot's chroma planes are set with jmhip_set_reference_chroma (the luma sub-planes with jmhip_set_reference).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int16_t x, y;              /* block position in the picture, luma samples (currMB->pix_x + block_x, opix_y + block_y) */
+  uint8_t w, h;              /* block size: 4, 8 or 16 each */
+  uint8_t dir;               /* p_dir: 0 = list 0, 1 = list 1, 2 = both */
+  uint8_t reserved_;
+  int8_t  slot[2];           /* reference slot of list 0 / list 1 (ignored for an unused list) */
+  int16_t mv[2][2];          /* [list][x, y], quarter-pel */
+  int16_t reserved2_;
+} jmhip_mc_luma_blk;         /* 20 bytes */
+typedef struct {
+  int16_t x, y;              /* 4x4 block position in the picture, chroma samples (pix_c_x + block_x, opix_c_y + block_y) */
+  uint8_t dir, plane;        /* p_dir; 0 = U, 1 = V */
+  int8_t  slot[2];
+  int16_t mv[2][4][2][2];    /* [list][sample row][sample pair (0,1) / (2,3)][x, y]: the vectors the reference reads from all_mv */
+} jmhip_mc_chroma_blk;       /* 72 bytes */
+/* out: luma n x 256 bytes (the w x h samples row-major at the start of each record); chroma n x 16 bytes */
+int jmhip_set_reference_chroma(jmhip_ctx *ctx, int32_t slot, const uint16_t *u, const uint16_t *v, int32_t pitch_samples);
+int jmhip_set_reference_chroma_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_u, const uint8_t *d_v, int32_t pitch_bytes);
+int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, int32_t n, uint8_t *out);
+int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t n, uint8_t *d_out);
+int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out);
+int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int32_t n, uint8_t *d_out);
+
+/* ------------------------------------------------------------------------------------------
  * In-loop deblocking of a whole frame
  *
  * DeblockFrame(p_Vid, imgY, imgUV) (lencod/src/loopFilter.c:63-71; DeblockMb :120-297, strengths and

@@ -95,6 +95,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { jmhip_fail(NULL, JMHIP_EHIP, "%s: %s", #call, hipGetErrorString(e_)); jmhip_destroy(c); return JMHIP_EHIP; } } while (0)
   CK(hipMalloc((void **)&c->d_cur, (size_t)c->cur_pitch * c->H));
   c->d_sub = (uint8_t **)calloc(cfg->num_ref_slots, sizeof(uint8_t *));
+  c->d_refc = (uint8_t **)calloc(cfg->num_ref_slots, sizeof(uint8_t *));
   for (int s = 0; s < cfg->num_ref_slots; s++) {
     CK(hipMalloc((void **)&c->d_sub[s], (size_t)c->plane_stride * 16));
     CK(hipMemsetAsync(c->d_sub[s], 0, (size_t)c->plane_stride * 16, c->stream));
@@ -128,6 +129,7 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   (void)hipStreamSynchronize(c->stream);
   if (c->d_cur) (void)hipFree(c->d_cur);
   if (c->d_sub) { for (int s = 0; s < c->cfg.num_ref_slots; s++) if (c->d_sub[s]) (void)hipFree(c->d_sub[s]); free(c->d_sub); }
+  if (c->d_refc) { for (int s = 0; s < c->cfg.num_ref_slots; s++) if (c->d_refc[s]) (void)hipFree(c->d_refc[s]); free(c->d_refc); }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -241,6 +243,35 @@ extern "C" int jmhip_set_reference(jmhip_ctx *ctx, int32_t slot, const uint16_t 
   if (r) return r;
   r = jmhip_launch_subplanes(ctx, ctx->d_stage, ctx->cur_pitch, ctx->d_sub[slot]);
   if (r) return r;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+static int refc_slot(jmhip_ctx *ctx, int slot)
+{
+  if (!ctx->d_refc[slot]) HIPCHK(ctx, hipMalloc((void **)&ctx->d_refc[slot], (size_t)2 * ctx->cw * ctx->ch));
+  return JMHIP_OK;
+}
+extern "C" int jmhip_set_reference_chroma_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_u, const uint8_t *d_v, int32_t pitch_bytes)
+{
+  if (!ctx || !d_u || !d_v || slot < 0 || slot >= ctx->cfg.num_ref_slots || ctx->cfg.yuv_format == 0 || pitch_bytes < ctx->cw)
+    return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_chroma_dev: bad argument") : JMHIP_EINVAL;
+  int r = refc_slot(ctx, slot);
+  if (r) return r;
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_refc[slot], ctx->cw, d_u, pitch_bytes, ctx->cw, ctx->ch, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_refc[slot] + (size_t)ctx->cw * ctx->ch, ctx->cw, d_v, pitch_bytes, ctx->cw, ctx->ch, hipMemcpyDeviceToDevice, ctx->stream));
+  return JMHIP_OK;
+}
+extern "C" int jmhip_set_reference_chroma(jmhip_ctx *ctx, int32_t slot, const uint16_t *u, const uint16_t *v, int32_t pitch_samples)
+{
+  if (!ctx || !u || !v || slot < 0 || slot >= ctx->cfg.num_ref_slots || ctx->cfg.yuv_format == 0 || pitch_samples < ctx->cw)
+    return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_chroma: bad argument") : JMHIP_EINVAL;
+  int r = refc_slot(ctx, slot);
+  if (r) return r;
+  for (int k = 0; k < 2; k++) {
+    r = upload_u16_as_u8(ctx, k ? v : u, pitch_samples, ctx->cw, ctx->ch, ctx->d_refc[slot] + (size_t)k * ctx->cw * ctx->ch, ctx->cw);
+    if (r) return r;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;
 }

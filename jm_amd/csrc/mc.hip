@@ -1,0 +1,143 @@
+// mc.hip -- motion-compensated prediction of block lists, un-weighted, frame pictures (gfx950).  SURVEY.md 8f row 2.
+//
+// Same samples, bit for bit, as
+//   luma_prediction         lencod/src/mc_prediction.c:144-236  (OneComponentLumaPrediction :122-136, mc_prediction :100-110,
+//                           bi_prediction :82-93) reading the sixteen quarter-pel planes k_subplanes made, and
+//   chroma_prediction_4x4   :568-650 with OneComponentChromaPrediction4x4_retrieve :361-411 (ChromaMCBuffer = 1).
+// The reference keeps 64 (4:2:0) / 32 (4:2:2) pre-interpolated chroma sub-images per plane (getSubImagesChroma,
+// lencod/src/img_chroma.c:338-437) and reads two samples per (row, pair) through UMVLine8X_chroma (refbuf.h:61-65); every
+// such sample is (w00 S[Y][X] + w01 S[Y][X+1] + w10 S[Y+1][X] + w11 S[Y+1][X+1] + 32) >> 6 of the integer plane S with all
+// coordinates clamped into the picture, so the kernel interpolates on the fly from the integer planes: 4 byte gathers per
+// sample from an L2-resident plane instead of 32-64x the plane in HBM.
+//
+// Both kernels are gathers: algorithmic bytes = w*h in per list + w*h out (luma), 16 out + 4..36 in (chroma); HBM/L2-bound.
+#include "jmhip_internal.h"
+
+struct McSlots { const uint8_t *p[32]; };
+
+struct __attribute__((packed)) u32un { uint32_t v; };
+__device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const u32un *)p)->v; }
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+
+// 64 lanes per block: lane -> (row, group of four samples)
+__global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__restrict__ blocks, int n, McSlots slots, int nslots,
+                                                 int pitch, long plane_stride, int W, int H, uint8_t *__restrict__ out)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 6, l = t & 63, row = l >> 2, c4 = l & 3;
+  if (b >= n) return;
+  const jmhip_mc_luma_blk q = blocks[b];
+  if (row >= q.h || 4 * c4 >= q.w || q.dir > 2) return;
+  uint32_t v[2] = {0, 0};
+#pragma unroll
+  for (int list = 0; list < 2; list++) {
+    if (q.dir != list && q.dir != 2) continue;
+    const int s = q.slot[list];
+    if (s < 0 || s >= nslots) return;
+    const int qx = (q.x << 2) + q.mv[list][0], qy = (q.y << 2) + q.mv[list][1];
+    const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), W + 15);     // UMVLine4X: one origin per block
+    v[list] = ld4u(slots.p[s] + ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y + row) * pitch + xx + JMHIP_PAD_X + 4 * c4);
+  }
+  const uint32_t r = q.dir == 0 ? v[0] : (q.dir == 1 ? v[1] : avg4(v[0], v[1]));
+  *(uint32_t *)(out + (long)b * 256 + row * q.w + 4 * c4) = r;
+}
+
+// 16 lanes per block: lane -> sample (row j, column i); the sample pair i >> 1 shares a vector
+__global__ __launch_bounds__(256) void k_mc_chroma(const jmhip_mc_chroma_blk *__restrict__ blocks, int n, McSlots slots, int nslots,
+                                                   int cw, int ch, int yuv, uint8_t *__restrict__ out)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 4, smp = t & 15, j = smp >> 2, i = smp & 3, hp = i >> 1, o = i & 1;
+  if (b >= n) return;
+  const jmhip_mc_chroma_blk *q = blocks + b;
+  const int dir = q->dir, plane = q->plane;
+  if (dir > 2 || plane > 1) return;
+  const int sy = yuv == 2 ? 2 : 3, my = yuv == 2 ? 3 : 7, ky = yuv == 2 ? 2 : 1;      // chroma_shift_y, chroma_mask_mv_y (lencod.c:2366-2380), eighths per phase
+  const int pad_x = JMHIP_PAD_X >> 1, pad_y = yuv == 2 ? JMHIP_PAD_Y : JMHIP_PAD_Y >> 1;
+  const int max_x = cw - 1 + pad_x - 8, max_y = ch - 1 + pad_y - (yuv == 2 ? 16 : 8);  // size_x_cr_pad, size_y_cr_pad (mbuffer.c:568-569)
+  int v[2] = {0, 0};
+#pragma unroll
+  for (int list = 0; list < 2; list++) {
+    if (dir != list && dir != 2) continue;
+    const int s = q->slot[list];
+    if (s < 0 || s >= nslots || !slots.p[s]) return;
+    const uint8_t *pl = slots.p[s] + (long)plane * cw * ch;
+    const int ii = ((q->x + 2 * hp) << 3) + q->mv[list][j][hp][0], jj = ((q->y + j) << sy) + q->mv[list][j][hp][1];
+    const int X = min(max(ii >> 3, -pad_x), max_x) + o, Y = min(max(jj >> sy, -pad_y), max_y);
+    const int lx = ii & 7, k = (jj & my) * ky, m = 8 - k;
+    const int w01 = m * lx, w00 = (m << 3) - w01, w11 = k * lx, w10 = (k << 3) - w11;
+    const int y0 = min(max(Y, 0), ch - 1), y1 = min(max(Y + 1, 0), ch - 1), x0 = min(max(X, 0), cw - 1), x1 = min(max(X + 1, 0), cw - 1);
+    v[list] = (w00 * pl[y0 * cw + x0] + w01 * pl[y0 * cw + x1] + w10 * pl[y1 * cw + x0] + w11 * pl[y1 * cw + x1] + 32) >> 6;
+  }
+  out[(long)b * 16 + smp] = (uint8_t)(dir == 0 ? v[0] : (dir == 1 ? v[1] : (v[0] + v[1] + 1) >> 1));
+}
+
+static McSlots luma_slots(jmhip_ctx *ctx) { McSlots s; for (int k = 0; k < 32; k++) s.p[k] = k < ctx->cfg.num_ref_slots ? ctx->d_sub[k] : nullptr; return s; }
+static McSlots chroma_slots(jmhip_ctx *ctx) { McSlots s; for (int k = 0; k < 32; k++) s.p[k] = k < ctx->cfg.num_ref_slots ? ctx->d_refc[k] : nullptr; return s; }
+
+extern "C" int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t n, uint8_t *d_out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!d_blocks || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma_dev: bad argument");
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_mc_luma, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, d_blocks, n, luma_slots(ctx), ctx->cfg.num_ref_slots,
+                     ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, int32_t n, uint8_t *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!blocks || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma: bad argument");
+  for (int i = 0; i < n; i++) {
+    const jmhip_mc_luma_blk *q = blocks + i;
+    const bool size_ok = (q->w == 4 || q->w == 8 || q->w == 16) && (q->h == 4 || q->h == 8 || q->h == 16);
+    if (!size_ok || q->dir > 2) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma: block %d: size %dx%d, direction %d", i, q->w, q->h, q->dir);
+    for (int l = 0; l < 2; l++)
+      if ((q->dir == l || q->dir == 2) && (q->slot[l] < 0 || q->slot[l] >= ctx->cfg.num_ref_slots))
+        return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma: block %d: list %d reference slot %d", i, l, q->slot[l]);
+  }
+  if (n == 0) return JMHIP_OK;
+  int r; void *din, *dout;
+  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_mc_luma_blk), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 1, (size_t)n * 256, &dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(din, blocks, (size_t)n * sizeof(jmhip_mc_luma_blk), hipMemcpyHostToDevice, ctx->stream));
+  if ((r = jmhip_mc_luma_dev(ctx, (const jmhip_mc_luma_blk *)din, n, (uint8_t *)dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int32_t n, uint8_t *d_out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!d_blocks || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_chroma_dev: bad argument");
+  if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_mc_chroma: yuv_format %d (4:2:0 and 4:2:2 only)", ctx->cfg.yuv_format);
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_mc_chroma, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_blocks, n, chroma_slots(ctx), ctx->cfg.num_ref_slots,
+                     ctx->cw, ctx->ch, ctx->cfg.yuv_format, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!blocks || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_chroma: bad argument");
+  if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_mc_chroma: yuv_format %d (4:2:0 and 4:2:2 only)", ctx->cfg.yuv_format);
+  for (int i = 0; i < n; i++) {
+    const jmhip_mc_chroma_blk *q = blocks + i;
+    if (q->dir > 2 || q->plane > 1) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_chroma: block %d: direction %d, plane %d", i, q->dir, q->plane);
+    for (int l = 0; l < 2; l++)
+      if ((q->dir == l || q->dir == 2) && (q->slot[l] < 0 || q->slot[l] >= ctx->cfg.num_ref_slots || !ctx->d_refc[q->slot[l]]))
+        return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_chroma: block %d: list %d reference slot %d has no chroma planes", i, l, q->slot[l]);
+  }
+  if (n == 0) return JMHIP_OK;
+  int r; void *din, *dout;
+  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_mc_chroma_blk), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 1, (size_t)n * 16, &dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(din, blocks, (size_t)n * sizeof(jmhip_mc_chroma_blk), hipMemcpyHostToDevice, ctx->stream));
+  if ((r = jmhip_mc_chroma_dev(ctx, (const jmhip_mc_chroma_blk *)din, n, (uint8_t *)dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}

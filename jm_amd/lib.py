@@ -56,6 +56,10 @@ DB_MB = np.dtype([("mb_type", "<i2"), ("slice_type", "<i2"), ("qp", "<i2"), ("qp
                   ("slice_nr", "<i2"), ("df_disable_idc", "<i2"), ("df_alpha_c0", "<i2"), ("df_beta", "<i2"), ("transform8x8", "<i2"),
                   ("reserved_", "<i2")])
 DB_MOTION = np.dtype([("mv", "<i2", (2, 2)), ("ref_id", "<i4", (2,))])
+MC_LUMA_BLK = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("reserved_", "u1"), ("slot", "i1", (2,)),
+                        ("mv", "<i2", (2, 2)), ("reserved2_", "<i2")])
+MC_CHROMA_BLK = np.dtype([("x", "<i2"), ("y", "<i2"), ("dir", "u1"), ("plane", "u1"), ("slot", "i1", (2,)), ("mv", "<i2", (2, 4, 2, 2))])
+assert MC_LUMA_BLK.itemsize == 20 and MC_CHROMA_BLK.itemsize == 72
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16
 
@@ -65,6 +69,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -308,6 +313,36 @@ class JmHip:
         out = np.zeros(len(b), DC_OUT)
         self._ck(self.lib.jmhip_quant_dc4x4(self.h, _vp(q), qp_per, cavlc, _vp(b), len(b), _vp(out)))
         return b, out
+
+    # ---- motion-compensated prediction
+    def set_reference_chroma(self, slot, u, v):
+        """the integer chroma planes of the reference picture in `slot` (StorablePicture.imgUV)"""
+        U = np.ascontiguousarray(u, np.uint16); V = np.ascontiguousarray(v, np.uint16)
+        assert U.shape == V.shape
+        self._ck(self.lib.jmhip_set_reference_chroma(self.h, slot, _vp(U), _vp(V), U.shape[1]))
+
+    def set_reference_chroma_dev(self, slot, d_u, d_v, pitch):
+        self._ck(self.lib.jmhip_set_reference_chroma_dev(self.h, slot, _vp(d_u), _vp(d_v), pitch))
+
+    def mc_luma(self, blocks):
+        """luma_prediction (lencod/src/mc_prediction.c:144), un-weighted; blocks: MC_LUMA_BLK array -> (n, 256) uint8, w*h samples first"""
+        b = np.ascontiguousarray(blocks, MC_LUMA_BLK)
+        out = np.zeros((len(b), 256), np.uint8)
+        self._ck(self.lib.jmhip_mc_luma(self.h, _vp(b), len(b), _vp(out)))
+        return out
+
+    def mc_luma_dev(self, d_blocks, n, d_out):
+        self._ck(self.lib.jmhip_mc_luma_dev(self.h, _vp(d_blocks), n, _vp(d_out)))
+
+    def mc_chroma(self, blocks):
+        """chroma_prediction_4x4 (lencod/src/mc_prediction.c:568, ChromaMCBuffer = 1), un-weighted; MC_CHROMA_BLK array -> (n, 16) uint8"""
+        b = np.ascontiguousarray(blocks, MC_CHROMA_BLK)
+        out = np.zeros((len(b), 16), np.uint8)
+        self._ck(self.lib.jmhip_mc_chroma(self.h, _vp(b), len(b), _vp(out)))
+        return out
+
+    def mc_chroma_dev(self, d_blocks, n, d_out):
+        self._ck(self.lib.jmhip_mc_chroma_dev(self.h, _vp(d_blocks), n, _vp(d_out)))
 
     # ---- deblocking
     def deblock_frame(self, y, u, v, mbs, motion, direct8x8=1):

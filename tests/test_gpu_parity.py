@@ -646,3 +646,117 @@ def test_fullsize_translation_property():
     ok = (b["mv_x"] == 4 * dx) & (b["mv_y"] == 4 * dy) & (b["cost"] == 187 * (bits(4 * dx) + bits(4 * dy)))
     assert ok.mean() > 0.99
     ctx.close()
+
+
+# ---------------------------------------------------------------- motion-compensated prediction
+@pytest.fixture(scope="module")
+def mcg():
+    return np.load(os.path.join(G, "qcif_mc.npz"))
+
+
+def _mc_ctx(mcg, tag):
+    """a context holding every reference picture the records of run `tag` read, one per slot"""
+    fmt = 2 if tag == "c" else 1
+    refs = sorted(int(k[len(tag) + 4:-2]) for k in mcg.files if k.startswith(tag + "_ref") and k.endswith("_y"))
+    ctx = make_ctx(176, 144, slots=max(refs) + 1, fmt=fmt)
+    for r in refs:
+        ctx.set_reference(r, mcg[f"{tag}_ref{r}_y"])
+        ctx.set_reference_chroma(r, mcg[f"{tag}_ref{r}_u"], mcg[f"{tag}_ref{r}_v"])
+    return ctx
+
+
+@pytest.mark.parametrize("tag", ["a", "c", "e"])
+def test_mc_luma_golden_records(mcg, tag):
+    """k_mc_luma == luma_prediction on the real encoder's calls (4:2:0 P, 4:2:2 P, B picture with bi-prediction)"""
+    from jm_amd.lib import MC_LUMA_BLK
+    hdr, pix = mcg[tag + "_mcl_hdr"], mcg[tag + "_mcl_pix"]
+    keep = hdr[:, 6] == 0                                    # un-weighted
+    hdr, pix = hdr[keep], pix[keep]
+    b = np.zeros(len(hdr), MC_LUMA_BLK)
+    b["x"], b["y"], b["w"], b["h"], b["dir"] = hdr[:, 1], hdr[:, 2], hdr[:, 3], hdr[:, 4], hdr[:, 5]
+    b["slot"][:, 0], b["slot"][:, 1] = np.maximum(hdr[:, 7], 0), np.maximum(hdr[:, 10], 0)
+    b["mv"][:, 0, 0], b["mv"][:, 0, 1], b["mv"][:, 1, 0], b["mv"][:, 1, 1] = hdr[:, 8], hdr[:, 9], hdr[:, 11], hdr[:, 12]
+    ctx = _mc_ctx(mcg, tag)
+    out = ctx.mc_luma(b)
+    n = hdr[:, 3] * hdr[:, 4]
+    for i in range(len(hdr)):
+        assert np.array_equal(out[i, :n[i]], pix[i, :n[i]]), (tag, i, hdr[i].tolist())
+    assert len(hdr) > 300
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["a", "c", "e"])
+def test_mc_chroma_golden_records(mcg, tag):
+    """k_mc_chroma == chroma_prediction_4x4 (buffered chroma sub-images) on the real encoder's calls"""
+    from jm_amd.lib import MC_CHROMA_BLK
+    hdr, pix = mcg[tag + "_mcc_hdr"], mcg[tag + "_mcc_pix"]
+    keep = (hdr[:, 6] == 0) & (hdr[:, 7] == 1)
+    hdr, pix = hdr[keep], pix[keep]
+    b = np.zeros(len(hdr), MC_CHROMA_BLK)
+    b["x"], b["y"], b["dir"], b["plane"] = hdr[:, 3], hdr[:, 4], hdr[:, 5], hdr[:, 2]
+    b["slot"][:, 0], b["slot"][:, 1] = np.maximum(hdr[:, 8], 0), np.maximum(hdr[:, 26], 0)
+    b["mv"][:, 0] = hdr[:, 10:26].reshape(-1, 4, 2, 2)
+    b["mv"][:, 1] = hdr[:, 28:44].reshape(-1, 4, 2, 2)
+    ctx = _mc_ctx(mcg, tag)
+    out = ctx.mc_chroma(b)
+    bad = np.flatnonzero((out != pix).any(1))
+    assert len(bad) == 0, (tag, bad[:5].tolist(), hdr[bad[0]].tolist(), out[bad[0]].tolist(), pix[bad[0]].tolist())
+    assert len(hdr) > 100
+    ctx.close()
+
+
+@pytest.mark.parametrize("fmt,w,h,seed", [(1, 176, 144, 1), (2, 176, 144, 2), (1, 1920, 1088, 3)])
+def test_mc_random_blocks_vs_oracle(J, fmt, w, h, seed):
+    """random blocks, vectors far outside the picture included (origin clamps of UMVLine4X / UMVLine8X_chroma), both lists"""
+    from jm_amd.lib import MC_LUMA_BLK, MC_CHROMA_BLK
+    rng = np.random.default_rng(seed)
+    ys = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(2)]
+    ch = h if fmt == 2 else h // 2
+    cs = [rng.integers(0, 256, (2, ch, w // 2)).astype(np.uint8) for _ in range(2)]
+    ctx = make_ctx(w, h, slots=2, fmt=fmt)
+    refs = [J.RefPic(y) for y in ys]
+    for s in range(2):
+        ctx.set_reference(s, ys[s]); ctx.set_reference_chroma(s, cs[s][0], cs[s][1])
+    n = 400 if w < 1000 else 150
+    b = np.zeros(n, MC_LUMA_BLK)
+    b["w"], b["h"] = rng.choice([4, 8, 16], n), rng.choice([4, 8, 16], n)
+    b["x"], b["y"] = rng.integers(0, w // 4, n) * 4, rng.integers(0, h // 4, n) * 4
+    b["x"], b["y"] = np.minimum(b["x"], w - b["w"].astype(np.int32)), np.minimum(b["y"], h - b["h"].astype(np.int32))
+    b["dir"] = rng.integers(0, 3, n)
+    b["slot"] = rng.integers(0, 2, (n, 2))
+    b["mv"] = rng.integers(-60, 61, (n, 2, 2))
+    far = rng.random(n) < 0.3
+    b["mv"][far] = rng.integers(-4 * (w + 80), 4 * (w + 80), (int(far.sum()), 2, 2))
+    out = ctx.mc_luma(b)
+    for i in range(n):
+        q = b[i]
+        want = J.luma_pred(refs[q["slot"][0]], refs[q["slot"][1]], int(q["dir"]), int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"]), q["mv"][0], q["mv"][1])
+        assert np.array_equal(out[i, : int(q["w"]) * int(q["h"])].reshape(int(q["h"]), int(q["w"])), want), (i, q)
+    c = np.zeros(n, MC_CHROMA_BLK)
+    c["x"], c["y"] = rng.integers(0, w // 8, n) * 4, rng.integers(0, ch // 4, n) * 4
+    c["dir"], c["plane"] = rng.integers(0, 3, n), rng.integers(0, 2, n)
+    c["slot"] = rng.integers(0, 2, (n, 2))
+    c["mv"] = rng.integers(-60, 61, (n, 2, 4, 2, 2))
+    c["mv"][far] = rng.integers(-4 * (w + 80), 4 * (w + 80), (int(far.sum()), 2, 4, 2, 2))
+    outc = ctx.mc_chroma(c)
+    for i in range(n):
+        q = c[i]
+        want = J.chroma_pred4x4(cs[q["slot"][0]][q["plane"]], cs[q["slot"][1]][q["plane"]], fmt, int(q["dir"]), int(q["x"]), int(q["y"]), q["mv"][0], q["mv"][1])
+        assert np.array_equal(outc[i].reshape(4, 4), want), (i, q)
+    ctx.close()
+
+
+def test_mc_bad_arguments():
+    from jm_amd.lib import MC_LUMA_BLK, MC_CHROMA_BLK, JmHipError
+    ctx = make_ctx(64, 48, slots=2, fmt=1)
+    assert ctx.mc_luma(np.zeros(0, MC_LUMA_BLK)).shape == (0, 256)
+    b = np.zeros(1, MC_LUMA_BLK); b["w"], b["h"] = 5, 4
+    with pytest.raises(JmHipError):
+        ctx.mc_luma(b)
+    b["w"], b["slot"] = 4, 7
+    with pytest.raises(JmHipError):
+        ctx.mc_luma(b)
+    c = np.zeros(1, MC_CHROMA_BLK)                            # slot 0 has no chroma planes yet
+    with pytest.raises(JmHipError):
+        ctx.mc_chroma(c)
+    ctx.close()
