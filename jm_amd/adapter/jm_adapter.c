@@ -53,16 +53,17 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_mcl, part_mcc;
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
   StorablePicture *slot_pic[MAX_SLOTS];
   unsigned    slot_tick[MAX_SLOTS], tick;
+  int         slot_chroma[MAX_SLOTS]; /* the slot's integer chroma planes are on the device (jmhip_set_reference_chroma) */
   uint16_t   *planes;                 /* 16 x (H+40) x (W+64) imgpel, jmhip_get_subplanes output */
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_mcl, n_mcc;
 } G;
 
 static void adapter_report(void)
@@ -70,8 +71,8 @@ static void adapter_report(void)
   if (!G.init_done) return;
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
-                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes\n",
-          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc);
+                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -111,6 +112,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_interp = has_part(parts, "interp"); G.part_fs = has_part(parts, "fs"); G.part_subpel = has_part(parts, "subpel");
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
+    G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -154,7 +156,7 @@ static int slot_take(StorablePicture *s)
     if (!G.slot_pic[k]) { best = k; break; }
     if (G.slot_tick[k] < G.slot_tick[best]) best = k;
   }
-  G.slot_pic[best] = s; G.slot_tick[best] = ++G.tick;
+  G.slot_pic[best] = s; G.slot_tick[best] = ++G.tick; G.slot_chroma[best] = 0;
   return best;
 }
 /* slot holding the sub-pel planes of `s`; a picture the slot ring has dropped is rebuilt from its luma */
@@ -184,6 +186,7 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
     return;
   }
   k = slot_take(s);
+  G.slot_chroma[k] = 0;                                     /* the picture's samples are new: its chroma planes go up again when first needed */
   if ((rc = jmhip_set_reference(G.ctx, k, s->imgY[0], (int)(s->imgY[1] - s->imgY[0])))) adapter_die("jmhip_set_reference", rc);
   if ((rc = jmhip_get_subplanes(G.ctx, k, G.planes))) adapter_die("jmhip_get_subplanes", rc);
   for (j = 0; j < 4; j++)                                   /* JM's host-side MC / RDO keep reading p_curr_img_sub */
@@ -348,6 +351,105 @@ void __wrap_setup_fast_full_search(Macroblock *currMB, MEBlock *mv_block, int li
     }
   ff->search_setup_done[list][ref] = 1;
   G.n_ffs++;
+}
+
+/* ------------------------------------------------------------------ motion-compensated prediction
+ * luma_prediction (lencod/src/mc_prediction.c:144; bound to p_Dpb->pf_luma_prediction in lencod.c:367) and chroma_prediction_4x4
+ * (:568), un-weighted, frame macroblocks; everything else (weighted prediction, field / MBAFF, ChromaMCBuffer = 0) goes to JM. */
+static MotionVector *****mc_vectors(Macroblock *currMB, int p_dir, int m0, int m1, int r0, int r1, short bipred_me)
+{
+  Slice *sl = currMB->p_Slice;
+  if (bipred_me && r0 == 0 && r1 == 0 && p_dir == 2 && is_bipred_enabled(currMB->p_Vid, m0) && is_bipred_enabled(currMB->p_Vid, m1))
+    return sl->bipred_mv[bipred_me - 1];
+  return sl->all_mv;
+}
+static int mc_common_ok(Macroblock *currMB, int p_dir)
+{
+  Slice *sl = currMB->p_Slice;
+  if (!adapter_on(currMB->p_Vid) || p_dir < 0 || p_dir > 2 || currMB->list_offset != 0) return 0;
+  if (sl->weighted_prediction == 1 || (sl->weighted_prediction == 2 && p_dir == 2)) return 0;
+  return 1;
+}
+static int slot_with_chroma(StorablePicture *s)
+{
+  int k = slot_of_reference(s);
+  if (!G.slot_chroma[k]) {
+    int rc = jmhip_set_reference_chroma(G.ctx, k, s->imgUV[0][0], s->imgUV[1][0], (int)(s->imgUV[0][1] - s->imgUV[0][0]));
+    if (rc) adapter_die("jmhip_set_reference_chroma", rc);
+    G.slot_chroma[k] = 1;
+  }
+  return k;
+}
+extern void __real_luma_prediction(Macroblock *, int, int, int, int, int, int *, char *, short);
+void __wrap_luma_prediction(Macroblock *currMB, int block_x, int block_y, int bsx, int bsy, int p_dir, int list_mode[2], char *ref_idx, short bipred_me)
+{
+  Slice *sl = currMB->p_Slice;
+  jmhip_mc_luma_blk b;
+  uint8_t out[256];
+  int l, j, i, rc, ok = mc_common_ok(currMB, p_dir) && G.part_mcl && (bsx == 4 || bsx == 8 || bsx == 16) && (bsy == 4 || bsy == 8 || bsy == 16);
+  memset(&b, 0, sizeof b);
+  for (l = 0; ok && l < 2; l++)
+    if (p_dir == l || p_dir == 2) {
+      StorablePicture *pic = sl->listX[l][(short)ref_idx[l]];
+      if (!pic || pic->size_x != G.W || pic->size_y != G.H) ok = 0;
+    }
+  if (!ok) { G.n_passed++; __real_luma_prediction(currMB, block_x, block_y, bsx, bsy, p_dir, list_mode, ref_idx, bipred_me); return; }
+  {
+    MotionVector *****mva = mc_vectors(currMB, p_dir, list_mode[0], list_mode[1], ref_idx[0], ref_idx[1], bipred_me);
+    b.x = (int16_t)(currMB->pix_x + block_x); b.y = (int16_t)(currMB->opix_y + block_y);
+    b.w = (uint8_t)bsx; b.h = (uint8_t)bsy; b.dir = (uint8_t)p_dir;
+    for (l = 0; l < 2; l++)
+      if (p_dir == l || p_dir == 2) {
+        MotionVector *mv = &mva[l][(short)ref_idx[l]][list_mode[l]][block_y >> 2][block_x >> 2];
+        b.slot[l] = (int8_t)slot_of_reference(sl->listX[l][(short)ref_idx[l]]);
+        b.mv[l][0] = mv->mv_x; b.mv[l][1] = mv->mv_y;
+      }
+  }
+  if (p_dir == 2 && G.slot_pic[b.slot[0]] != sl->listX[0][(short)ref_idx[0]]) b.slot[0] = (int8_t)slot_of_reference(sl->listX[0][(short)ref_idx[0]]);  /* list 1 may have evicted it */
+  if ((rc = jmhip_mc_luma(G.ctx, &b, 1, out))) adapter_die("jmhip_mc_luma", rc);
+  for (j = 0; j < bsy; j++)
+    for (i = 0; i < bsx; i++) sl->mb_pred[0][block_y + j][block_x + i] = out[j * bsx + i];
+  G.n_mcl++;
+}
+extern void __real_chroma_prediction_4x4(Macroblock *, int, int, int, int, int, int, short, short, short);
+void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int block_y, int p_dir, int l0_mode, int l1_mode,
+                                  short l0_ref_idx, short l1_ref_idx, short bipred_me)
+{
+  VideoParameters *p_Vid = currMB->p_Vid;
+  Slice *sl = currMB->p_Slice;
+  jmhip_mc_chroma_blk b;
+  uint8_t out[16];
+  int mode[2] = {l0_mode, l1_mode}, ref[2] = {l0_ref_idx, l1_ref_idx};
+  int l, j, rc, ok = mc_common_ok(currMB, p_dir) && G.part_mcc && p_Vid->p_Inp->ChromaMCBuffer && (uv == 0 || uv == 1);
+  memset(&b, 0, sizeof b);
+  for (l = 0; ok && l < 2; l++)
+    if (p_dir == l || p_dir == 2) {
+      StorablePicture *pic = sl->listX[l][ref[l]];
+      if (!pic || pic->size_x != G.W || pic->size_y != G.H || pic->chroma_vector_adjustment != 0) ok = 0;
+    }
+  if (!ok) { G.n_passed++; __real_chroma_prediction_4x4(currMB, uv, block_x, block_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx, bipred_me); return; }
+  {
+    MotionVector *****mva = mc_vectors(currMB, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx, bipred_me);
+    const int rsx = 4 - p_Vid->chroma_shift_x, rsy = 4 - p_Vid->chroma_shift_y;     /* chroma sample -> luma 4x4 block, as JM does it */
+    b.x = (int16_t)(currMB->pix_c_x + block_x); b.y = (int16_t)(currMB->opix_c_y + block_y);
+    b.dir = (uint8_t)p_dir; b.plane = (uint8_t)uv;
+    for (l = 0; l < 2; l++)
+      if (p_dir == l || p_dir == 2) {
+        MotionVector **mv = mva[l][ref[l]][mode[l]];
+        b.slot[l] = (int8_t)slot_with_chroma(sl->listX[l][ref[l]]);
+        for (j = 0; j < 4; j++) {
+          const MotionVector *a = &mv[(block_y + j) >> rsy][block_x >> rsx], *c = &mv[(block_y + j) >> rsy][(block_x + 2) >> rsx];
+          b.mv[l][j][0][0] = a->mv_x; b.mv[l][j][0][1] = a->mv_y; b.mv[l][j][1][0] = c->mv_x; b.mv[l][j][1][1] = c->mv_y;
+        }
+      }
+  }
+  if (p_dir == 2 && (G.slot_pic[b.slot[0]] != sl->listX[0][ref[0]] || !G.slot_chroma[b.slot[0]])) b.slot[0] = (int8_t)slot_with_chroma(sl->listX[0][ref[0]]);
+  if ((rc = jmhip_mc_chroma(G.ctx, &b, 1, out))) adapter_die("jmhip_mc_chroma", rc);
+  for (j = 0; j < 4; j++) {
+    imgpel *row = &sl->mb_pred[uv + 1][block_y + j][block_x];
+    row[0] = out[j * 4]; row[1] = out[j * 4 + 1]; row[2] = out[j * 4 + 2]; row[3] = out[j * 4 + 3];
+  }
+  G.n_mcc++;
 }
 
 /* ------------------------------------------------------------------ K9/K10: deblocking */
