@@ -135,6 +135,34 @@ def test_fullsearch_all_partitions_vs_oracle(J, w, h, R, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("lam", [13999, 14000, 60000])
+def test_fullsearch_key_limits(J, lam):
+    """the widest keys the tuned kernel accepts (lambda just below its bound, every SAD at its maximum: white reference, black
+    current, predictors as far away as int16 allows) and the first lambdas it must leave to the generic kernel"""
+    from jm_amd.lib import ME_JOB, PARTITIONS
+    w, h, R = 96, 80, 32
+    ref, cur = np.full((h, w), 255, np.uint8), np.zeros((h, w), np.uint8)
+    cur[40:44, 40:60] = 3                                    # a little structure so that not every cost is equal
+    ctx = make_ctx(w, h, R=R)
+    ctx.set_reference(0, ref); ctx.set_current(cur)
+    oref = J.RefPic(ref)
+    jobs = np.zeros(2, ME_JOB)
+    for i, (pred, c) in enumerate((((-32000, 31000), (0, 0)), ((20, -8), (16, -8)))):
+        j = jobs[i]
+        j["mb_x"], j["mb_y"], j["center_x"], j["center_y"] = 32, 32, c[0], c[1]
+        j["search_range"], j["lambda"], j["part_mask"] = R, lam, np.uint64((1 << 41) - 1)
+        j["pred"] = np.array(pred)
+    res = ctx.me_fullsearch(0, jobs)
+    for i, j in enumerate(jobs):
+        c = (int(j["center_x"]), int(j["center_y"]))
+        for p, (bt, bx, by, bw, bh) in enumerate(PARTITIONS):
+            pred = (int(j["pred"][p][0]), int(j["pred"][p][1]))
+            mv, cost, _ = J.full_search(oref, cur, 32 + bx, 32 + by, bw, bh, pred, c, R, lam)
+            got = res[i]["best"][p]
+            assert (int(got["mv_x"]), int(got["mv_y"]), int(got["cost"])) == (mv[0], mv[1], min(cost, 0x7fffffff)), (lam, i, p)
+    ctx.close()
+
+
 def test_fullsearch_ties_resolve_in_spiral_order(J):
     """flat reference and current: every position has the same SAD, so the winner is decided by the MV rate and, among equal
     rates, by JM's spiral order (strict '<', mv_search.c:405-442) -- the tie path of the reduction."""
