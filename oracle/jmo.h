@@ -148,6 +148,10 @@ int jmo_quant_dc4x4_normal(int tblock[16], const jmo_qparam *q, int qp_per, int 
 int jmo_rtq_luma_8x8(const jmo_pel orig[64], const jmo_pel pred[64], const jmo_qparam q[64], int qp_per, int cavlc,
                      int adaptive_rounding, int adapt_rnd_weight, int max_pel, int level[68], int run[68], int *coeff_cost,
                      jmo_pel rec[64], int fadjust[64], int *any_residual);
+/* residual_transform_quant_luma_16x16 block.c:208-349, one macroblock (see jmo_tq.c) */
+int jmo_rtq_luma_16x16(const jmo_pel orig[256], const jmo_pel pred[256], const jmo_qparam q[16], int qp_per, int cavlc,
+                       int adaptive_rounding, int arw, int max_pel, int dc_level[17], int dc_run[17],
+                       int ac_level[16][16], int ac_run[16][16], jmo_pel rec[256], int fadjust[64]);
 /* residual_transform_quant_chroma_4x4 block.c:954-1200, one plane of one macroblock (see jmo_tq.c) */
 int jmo_rtq_chroma(int yuv, int uv, int cr_cbp, int64_t *cbp_blk, const jmo_qparam q_ac[16], const jmo_qparam *q_dc,
                    int qp_per_ac, int qp_per_dc, int cavlc, int adaptive_rounding, int adapt_rnd_weight, int max_pel,

@@ -509,3 +509,65 @@ int jmo_rtq_chroma(int yuv, int uv, int cr_cbp, int64_t *cbp_blk, const jmo_qpar
     rec[j*8+i] = any ? (jmo_pel)clip1(max_pel, rshift_rnd_sf(rres[j][i], 6) + (int)pred[j*8+i]) : pred[j*8+i];
   return cr_cbp;
 }
+
+/* residual_transform_quant_luma_16x16 block.c:208-349 (Intra16x16 luma of one macroblock, frame scan): sixteen forward4x4, the DC
+ * coefficients through hadamard4x4 -> quant_dc4x4_normal (quant4x4_normal.c:200; also bound when AdaptiveRounding is on, quant4x4.c:56)
+ * -> ihadamard4x4 -> rshift_rnd_sf((dc * InvScaleComp[0][0]) << qp_per, 6), the AC coefficients of every block through
+ * quant_ac4x4_normal :117 / quant_ac4x4_around (quant4x4_around.c:129), inverse4x4 where the block has a DC or an AC level, and
+ * sample_reconstruct with DQ_BITS = 6.  ac_level / ac_run are indexed b8 * 4 + b4 as JM's cofAC.  Returns ac_coef (15 or 0).
+ * fadjust: JM hands quant_ac4x4_around the array ARCofAdj4x4[pl][I16MB] WITHOUT the block's row offset (block.c:247), so every block
+ * row writes rows 0..3 and the last one wins; restated as is: fadjust[4][16], AC positions only (the DC positions are never written). */
+int jmo_rtq_luma_16x16(const jmo_pel orig[256], const jmo_pel pred[256], const jmo_qparam q[16], int qp_per, int cavlc,
+                       int adaptive_rounding, int arw, int max_pel, int dc_level[17], int dc_run[17],
+                       int ac_level[16][16], int ac_run[16][16], jmo_pel rec[256], int fadjust[64])
+{
+  int t[16][16], dc[16], hd[16], j, i, jj, ii, c, ac_coef = 0, dc_nonzero;
+  const int q_bits = 15 + qp_per;
+  for (jj = 0; jj < 4; jj++)
+    for (ii = 0; ii < 4; ii++) {
+      int in[16], out[16];
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[4*j+i] = (int)orig[(4*jj+j)*16 + 4*ii+i] - (int)pred[(4*jj+j)*16 + 4*ii+i];
+      jmo_forward4x4(in, out);
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) t[4*jj+j][4*ii+i] = out[4*j+i];
+      dc[jj*4+ii] = out[0];
+    }
+  jmo_hadamard4x4(dc, hd);
+  dc_nonzero = jmo_quant_dc4x4_normal(hd, &q[0], qp_per, cavlc, dc_level, dc_run);
+  if (dc_nonzero) {
+    int ih[16];
+    jmo_ihadamard4x4(hd, ih);
+    for (jj = 0; jj < 4; jj++) for (ii = 0; ii < 4; ii++) t[4*jj][4*ii] = rshift_rnd_sf((ih[jj*4+ii] * q[0].InvScaleComp) << qp_per, 6);
+  } else
+    for (jj = 0; jj < 4; jj++) for (ii = 0; ii < 4; ii++) t[4*jj][4*ii] = 0;
+  for (jj = 0; jj < 4; jj++)
+    for (ii = 0; ii < 4; ii++) {
+      const int b = (2 * (jj >> 1) + (ii >> 1)) * 4 + 2 * (jj & 1) + (ii & 1);
+      int run = 0, n = 0, nz = 0;
+      for (c = 1; c < 16; c++) {
+        const int si = JMO_SNGL_SCAN[c][0], sj = JMO_SNGL_SCAN[c][1], qi = sj * 4 + si, v = t[4*jj+sj][4*ii+si];
+        int fadj = 0;
+        if (v != 0) {
+          const int scaled = iabs_(v) * q[qi].ScaleComp;
+          int lev = (scaled + q[qi].OffsetComp) >> q_bits;
+          if (lev != 0) {
+            if (cavlc) lev = imin_(lev, 2063);
+            if (adaptive_rounding) fadj = rshift_rnd_sf(arw * (scaled - (lev << q_bits)), q_bits + 1);
+            lev = v < 0 ? -lev : lev;
+            t[4*jj+sj][4*ii+si] = rshift_rnd_sf((lev * q[qi].InvScaleComp) << qp_per, 4);
+            ac_level[b][n] = lev; ac_run[b][n] = run; n++; run = 0; nz = 1;
+          } else { t[4*jj+sj][4*ii+si] = 0; run++; }
+        } else run++;
+        if (adaptive_rounding) fadjust[sj * 16 + 4*ii + si] = fadj;              /* row sj of the array, whatever the block row */
+      }
+      ac_level[b][n] = 0;
+      if (nz) ac_coef = 15;
+      if (t[4*jj][4*ii] != 0 || nz) {
+        int in[16], out[16];
+        for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[4*j+i] = t[4*jj+j][4*ii+i];
+        jmo_inverse4x4(in, out);
+        for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) t[4*jj+j][4*ii+i] = out[4*j+i];
+      }
+    }
+  for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) rec[j*16+i] = (jmo_pel)clip1(max_pel, rshift_rnd_sf(t[j][i], 6) + (int)pred[j*16+i]);
+  return ac_coef;
+}

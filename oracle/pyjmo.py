@@ -310,3 +310,16 @@ def chroma_pred4x4(p0, p1, yuv, p_dir, xc, yc, mv0, mv1):
     out = np.zeros(16, np.uint16)
     L.jmo_chroma_pred4x4(_p(a), _p(b), w, w, h, int(yuv), int(p_dir), int(xc), int(yc), _p(m0), _p(m1), _p(out))
     return out.reshape(4, 4).astype(np.uint8)
+
+
+def rtq_luma_16x16(orig, pred, qparams, qp_per, cavlc, around, arw, max_pel=255):
+    """residual_transform_quant_luma_16x16 (block.c:208): returns (ac_coef, dc_level[17], dc_run[17], ac_level[16][16], ac_run[16][16],
+    rec (16, 16) uint8, fadjust (4, 16) with the AC positions JM writes)"""
+    o = np.ascontiguousarray(orig, np.uint16).reshape(256); p = np.ascontiguousarray(pred, np.uint16).reshape(256)
+    q = np.ascontiguousarray(qparams, np.int32).reshape(16, 3)
+    dl, dr = np.zeros(17, np.int32), np.zeros(17, np.int32)
+    al, ar = np.zeros((16, 16), np.int32), np.zeros((16, 16), np.int32)
+    rec, fadj = np.zeros(256, np.uint16), np.zeros(64, np.int32)
+    r = L.jmo_rtq_luma_16x16(_p(o), _p(p), _p(q), int(qp_per), int(cavlc), int(around), int(arw), int(max_pel),
+                             _p(dl), _p(dr), _p(al), _p(ar), _p(rec), _p(fadj))
+    return r, dl, dr, al, ar, rec.reshape(16, 16).astype(np.uint8), fadj.reshape(4, 16)

@@ -670,10 +670,51 @@ static int tap_rtq_chroma(Macroblock *currMB, int uv, int cr_cbp)
   n++;
   return r;
 }
+/* ================================================================== Intra16x16 luma: residual_transform_quant_luma_16x16 (block.c:208)
+ * (slot rebound through select_transform, as above)
+ * record: pl qp qp_per cavlc AdaptiveRounding AdaptRndWeight max_pel i16mode | 16 x q_params (intra) | orig[256] | pred[256] |
+ *         ret | DC level[17] run[17] | 16 x (AC level[16], run[16]) in (b8, b4) order | rec[256] | fadjust rows 0..3 [4][16] after the call */
+extern int residual_transform_quant_luma_16x16(Macroblock *, ColorPlane);
+static int tap_rtq_luma_16x16(Macroblock *currMB, ColorPlane pl)
+{
+  static int n = 0;
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  int orig[256], pred[256], j, i, k, b, r;
+  const int mode = currMB->i16mode, qp = currMB->qp_scaled[pl];
+  if (pl != PLANE_Y || p_Vid->yuv_format == YUV444) return residual_transform_quant_luma_16x16(currMB, pl);
+  for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) {
+    orig[j * 16 + i] = p_Vid->pCurImg[currMB->opix_y + j][currMB->pix_x + i];
+    pred[j * 16 + i] = currSlice->mpr_16x16[pl][mode][j][i];
+  }
+  r = residual_transform_quant_luma_16x16(currMB, pl);
+  if (n < tap_max() / 8 && (n % 2) == 0) {
+    LevelQuantParams **q = p_Vid->p_Quant->q_params_4x4[pl][1][qp];
+    FILE *f = tap_open("rtq16x16.bin");
+    put_i32(f, pl); put_i32(f, qp); put_i32(f, p_Vid->p_Quant->qp_per_matrix[qp]); put_i32(f, currSlice->symbol_mode == CAVLC);
+    put_i32(f, p_Vid->AdaptiveRounding); put_i32(f, p_Vid->AdaptRndWeight); put_i32(f, p_Vid->max_imgpel_value); put_i32(f, mode);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { put_i32(f, q[j][i].OffsetComp); put_i32(f, q[j][i].ScaleComp); put_i32(f, q[j][i].InvScaleComp); }
+    for (k = 0; k < 256; k++) put_i32(f, orig[k]);
+    for (k = 0; k < 256; k++) put_i32(f, pred[k]);
+    put_i32(f, r);
+    for (k = 0; k < 17; k++) put_i32(f, currSlice->cofDC[pl][0][k]);
+    for (k = 0; k < 17; k++) put_i32(f, currSlice->cofDC[pl][1][k]);
+    for (b = 0; b < 16; b++) {
+      for (k = 0; k < 16; k++) put_i32(f, currSlice->cofAC[(pl << 2) + (b >> 2)][b & 3][0][k]);
+      for (k = 0; k < 16; k++) put_i32(f, currSlice->cofAC[(pl << 2) + (b >> 2)][b & 3][1][k]);
+    }
+    for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) put_i32(f, p_Vid->enc_picture->p_curr_img[currMB->pix_y + j][currMB->pix_x + i]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 16; i++) put_i32(f, p_Vid->AdaptiveRounding ? p_Vid->ARCofAdj4x4[pl][I16MB][j][i] : 0);
+    fclose(f);
+  }
+  n++;
+  return r;
+}
 extern void __real_select_transform(Macroblock *);
 void __wrap_select_transform(Macroblock *currMB)
 {
   __real_select_transform(currMB);
+  if (currMB->residual_transform_quant_luma_16x16 == residual_transform_quant_luma_16x16) currMB->residual_transform_quant_luma_16x16 = tap_rtq_luma_16x16;
   if (currMB->residual_transform_quant_chroma_4x4[0] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[0] = tap_rtq_chroma;
   if (currMB->residual_transform_quant_chroma_4x4[1] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[1] = tap_rtq_chroma;
 }

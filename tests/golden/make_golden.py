@@ -258,7 +258,7 @@ def main():
 
         # ---- D: 8x8 transform / quantisation and the DC transforms (High 4:2:2 CABAC + adaptive rounding; the same with CAVLC
         #         and plain rounding; High 4:2:0 CAVLC for the 2x2 chroma DC transform)
-        d, q8, r8, rc = {}, [], [], []
+        d, q8, r8, rc, r16 = {}, [], [], [], []
         for name, cfg, o in [("D0", "encoder_baseline.cfg", dict(ov)),
                              ("D", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2)),
                              ("D2", "encoder_yuv422.cfg", dict(NumberBFrames=0, FramesToBeEncoded=2, SymbolMode=0, AdaptiveRounding=0)),
@@ -273,6 +273,10 @@ def main():
                 q = q[np.abs(q[:, 4 + 192 + 128 + 64 + 64 + 64:4 + 192 + 128 + 64 + 64 + 64 + 68]).sum(1) > 0]
             if len(q):
                 q8.append(q[:: max(1, len(q) // 60)][:60]); r8.append(r[:: max(1, len(r) // 60)][:60])
+            i16 = read_i32_records(os.path.join(w, "rtq16x16.bin"), 1435)
+            if len(i16):                                            # Intra16x16 luma: a spread sample, the few all-zero-AC records included
+                quiet = i16[i16[:, 568] == 0]
+                r16.append(i16[:: max(1, len(i16) // 18)][:18]); r16.append(quiet[:3])
             c = read_i32_records(os.path.join(w, "rtq_chroma.bin"), 853)
             busy = c[np.abs(c[:, 451:460]).sum(1) + np.abs(c[:, 469:725]).sum(1) > 0]       # some DC or AC level survives
             quiet = c[np.abs(c[:, 451:460]).sum(1) + np.abs(c[:, 469:725]).sum(1) == 0]
@@ -288,6 +292,7 @@ def main():
         d["quant8x8"] = np.concatenate(q8)
         d["rtq8x8"] = np.concatenate(r8)
         d["rtq_chroma"] = np.concatenate(rc)
+        d["rtq16x16"] = np.concatenate(r16)
         np.savez_compressed(os.path.join(OUT, "qcif_tq8.npz"), **d)
 
         # ---- md5 goldens of whole-encoder runs

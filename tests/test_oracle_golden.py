@@ -339,3 +339,45 @@ def test_oracle_chroma_prediction_matches_the_reference(tag):
         assert np.array_equal(got, want), (tag, yuv, uv, xc, yc, p_dir, mv0.tolist(), mv1.tolist(), got.tolist(), want.tolist())
         n += 1
     assert n > 100
+
+
+# ---------------------------------------------------------------- Intra16x16 luma: residual_transform_quant_luma_16x16
+def unpack_i16_record(r):
+    """fields of one rtq16x16 record (oracle/ref_tap.c)"""
+    d = dict(qp=int(r[1]), qp_per=int(r[2]), cavlc=int(r[3]), around=int(r[4]), arw=int(r[5]), max_pel=int(r[6]), mode=int(r[7]))
+    d["q"], d["orig"], d["pred"] = r[8:56].reshape(16, 3), r[56:312].reshape(16, 16), r[312:568].reshape(16, 16)
+    d["ret"], d["dc_level"], d["dc_run"] = int(r[568]), r[569:586], r[586:603]
+    ac = r[603:1115].reshape(16, 2, 16)
+    d["ac_level"], d["ac_run"] = ac[:, 0], ac[:, 1]
+    d["rec"], d["fadjust"] = r[1115:1371].reshape(16, 16), r[1371:1435].reshape(4, 16)
+    return d
+
+
+def check_level_lists(want_level, want_run, got_level, got_run, what):
+    """JM's lists end at the first zero level; entries behind it are stale"""
+    n = 0
+    while want_level[n] != 0:
+        n += 1
+    assert np.array_equal(np.asarray(got_level)[: n + 1], want_level[: n + 1]), (what, "levels")
+    assert np.array_equal(np.asarray(got_run)[:n], want_run[:n]), (what, "runs")
+
+
+I16_AC_MASK = np.ones((4, 16), bool)
+I16_AC_MASK[0, ::4] = False                      # the DC position of each block is never written by quant_ac4x4
+
+
+def test_oracle_rtq_luma_16x16_matches_the_reference(tq8):
+    """jmo_rtq_luma_16x16 == residual_transform_quant_luma_16x16 (block.c:208) on the real encoder's calls: CAVLC / CABAC, with and
+    without adaptive rounding (incl. JM's un-offset fadjust rows), macroblocks with and without AC levels"""
+    recs = tq8["rtq16x16"]
+    assert len(recs) > 80
+    for k, r in enumerate(recs):
+        d = unpack_i16_record(r)
+        ret, dl, dr, al, ar, rec, fadj = J.rtq_luma_16x16(d["orig"], d["pred"], d["q"], d["qp_per"], d["cavlc"], d["around"], d["arw"], d["max_pel"])
+        assert ret == d["ret"], k
+        check_level_lists(d["dc_level"], d["dc_run"], dl, dr, (k, "dc"))
+        for b in range(16):
+            check_level_lists(d["ac_level"][b], d["ac_run"][b], al[b], ar[b], (k, "ac", b))
+        assert np.array_equal(rec, d["rec"]), k
+        if d["around"]:
+            assert np.array_equal(fadj[I16_AC_MASK], d["fadjust"][I16_AC_MASK]), k
