@@ -260,6 +260,28 @@ typedef struct {
 int jmhip_tq_chroma(jmhip_ctx *ctx, const jmhip_tqc_params *prm, jmhip_tqc_mb *mbs, const uint8_t *orig, const uint8_t *pred,
                     int32_t nitems, jmhip_tqc_out *out);
 
+/* Intra16x16 luma of whole macroblocks: Macroblock.residual_transform_quant_luma_16x16 (global.h:467) = residual_transform_quant_luma_16x16
+ * (lencod/src/block.c:208-349): sixteen forward4x4, the DC coefficients through hadamard4x4 -> Slice.quant_dc4x4 (quant_dc4x4_normal,
+ * quant4x4_normal.c:200) -> ihadamard4x4 -> their own dequantisation (block.c:294), the AC coefficients through Slice.quant_ac4x4
+ * (quant_ac4x4_normal quant4x4_normal.c:117 / quant_ac4x4_around quant4x4_around.c:129), inverse4x4, sample_reconstruct.
+ * prm: jmhip_tq_params with the INTRA quantiser of the macroblock's qp; orig / pred: n x 256 samples row-major (pred = mpr_16x16[i16mode]). */
+typedef struct {
+  uint8_t rec[256];                 /* reconstructed macroblock, rows of 16 */
+  int16_t fadjust[4][16];           /* what JM's call leaves in rows 0..3 of ARCofAdj4x4[pl][I16MB] (adaptive rounding): it passes the array
+                                       without the block's row offset (block.c:247), so these are block row 3's values; the DC position of
+                                       each block ([0][0], [0][4], ...) is never written by JM -- ignore it */
+  int16_t ac_level[16][16];         /* cofAC[b8][b4][0] at index b8 * 4 + b4, 0-terminated when fewer than 15 */
+  int16_t dc_level[17];             /* cofDC[pl][0], 0-terminated */
+  uint8_t ac_run[16][16];           /* cofAC[b8][b4][1] */
+  uint8_t ac_ncoef[16];
+  uint8_t dc_run[17];               /* cofDC[pl][1] */
+  uint8_t dc_nonzero;
+  uint8_t ac_coef;                  /* return value: 15 when any block has an AC level, else 0 */
+  uint8_t reserved_[3];
+} jmhip_tq16_out;                   /* 1224 bytes */
+int jmhip_tq_luma16x16(jmhip_ctx *ctx, const jmhip_tq_params *prm, const uint8_t *orig, const uint8_t *pred, int32_t nmbs, jmhip_tq16_out *out);
+int jmhip_tq_luma16x16_dev(jmhip_ctx *ctx, const jmhip_tq_params *prm, const uint8_t *d_orig, const uint8_t *d_pred, int32_t nmbs, jmhip_tq16_out *d_out);
+
 /* The DC transforms of lcommon/src/transform.c, batched over blocks of int32 (row-major):
  *   HADAMARD4x4 :121 / IHADAMARD4x4 :170   16 values (Intra16x16 luma DC)
  *   HADAMARD4x2 :220 / IHADAMARD4x2 :258   8 values, rows [2][4]; the inverse returns JM's transposed [4][2] layout (4:2:2 chroma DC)

@@ -50,6 +50,9 @@ TQC_OUT = np.dtype([("dc_level", "<i2", (9,)), ("dc_run", "u1", (9,)), ("dc_nonz
                     ("ac_ncoef", "u1", (8,)), ("rec", "u1", (128,)), ("fadjust", "<i2", (128,)), ("reserved_", "u1", (4,))])
 assert TQC_PARAMS.itemsize == 240 and TQC_MB.itemsize == 16 and TQC_OUT.itemsize == 808
 DC_OUT = np.dtype([("level", "<i2", (17,)), ("run", "u1", (17,)), ("nonzero", "u1")])
+TQ16_OUT = np.dtype([("rec", "u1", (256,)), ("fadjust", "<i2", (4, 16)), ("ac_level", "<i2", (16, 16)), ("dc_level", "<i2", (17,)), ("ac_run", "u1", (16, 16)),
+                     ("ac_ncoef", "u1", (16,)), ("dc_run", "u1", (17,)), ("dc_nonzero", "u1"), ("ac_coef", "u1"), ("reserved_", "u1", (3,))])
+assert TQ16_OUT.itemsize == 1224
 assert TQ8_PARAMS.itemsize == 800 and TQ8_OUT.itemsize == 408 and DC_OUT.itemsize == 52
 DC_KINDS = {"hadamard4x4": (0, 16), "ihadamard4x4": (1, 16), "hadamard4x2": (2, 8), "ihadamard4x2": (3, 8), "hadamard2x2": (4, 4), "ihadamard2x2": (5, 4)}
 DB_MB = np.dtype([("mb_type", "<i2"), ("slice_type", "<i2"), ("qp", "<i2"), ("qpc", "<i2", (2,)), ("cbp", "<i2"), ("cbp_blk", "<u4"),
@@ -68,7 +71,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
-           "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
+           "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
@@ -284,6 +287,17 @@ class JmHip:
 
     def tq_luma8x8_dev(self, prm, d_orig, d_pred, n, d_out):
         self._ck(self.lib.jmhip_tq_luma8x8_dev(self.h, _vp(prm), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
+
+    def tq_luma16x16(self, prm, orig, pred):
+        """residual_transform_quant_luma_16x16 (lencod/src/block.c:208) of whole macroblocks; prm from tq_params() with the intra
+        quantiser; orig / pred: (n, 256) uint8"""
+        o = np.ascontiguousarray(orig, np.uint8).reshape(-1, 256); p = np.ascontiguousarray(pred, np.uint8).reshape(-1, 256)
+        out = np.zeros(len(o), TQ16_OUT)
+        self._ck(self.lib.jmhip_tq_luma16x16(self.h, _vp(prm), _vp(o), _vp(p), len(o), _vp(out)))
+        return out
+
+    def tq_luma16x16_dev(self, prm, d_orig, d_pred, n, d_out):
+        self._ck(self.lib.jmhip_tq_luma16x16_dev(self.h, _vp(prm), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
 
     def tq_chroma(self, yuv, q_ac, q_dc, qp_per_ac, qp_per_dc, cavlc, adaptive_rounding, adapt_rnd_weight, mbs, orig, pred, max_pel=255):
         """residual_transform_quant_chroma_4x4 (lencod/src/block.c:954), batched over (macroblock, plane) items.

@@ -788,3 +788,53 @@ def test_mc_bad_arguments():
     with pytest.raises(JmHipError):
         ctx.mc_chroma(c)
     ctx.close()
+
+
+# ---------------------------------------------------------------- Intra16x16 luma: residual_transform_quant_luma_16x16
+def _check_i16(out, want_ret, want_dl, want_dr, want_al, want_ar, want_rec, want_fadj, around, what):
+    from test_oracle_golden import check_level_lists, I16_AC_MASK
+    assert int(out["ac_coef"]) == want_ret, what
+    check_level_lists(np.asarray(want_dl), np.asarray(want_dr), out["dc_level"], out["dc_run"], (what, "dc"))
+    for b in range(16):
+        check_level_lists(np.asarray(want_al[b]), np.asarray(want_ar[b]), out["ac_level"][b], out["ac_run"][b], (what, "ac", b))
+    assert np.array_equal(out["rec"].reshape(16, 16), want_rec), what
+    if around:
+        assert np.array_equal(out["fadjust"][I16_AC_MASK], np.asarray(want_fadj)[I16_AC_MASK]), what
+
+
+def test_tq_luma16x16_golden_records(tq8):
+    """k_tq_luma16x16 == residual_transform_quant_luma_16x16 (block.c:208) on the real encoder's calls"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_oracle_golden import unpack_i16_record
+    ctx = make_ctx(64, 48)
+    recs = tq8["rtq16x16"]
+    for k, r in enumerate(recs):
+        d = unpack_i16_record(r)
+        prm = ctx.tq_params(d["q"], d["qp_per"], cavlc=d["cavlc"], adaptive_rounding=d["around"], adapt_rnd_weight=d["arw"], max_pel=d["max_pel"])
+        out = ctx.tq_luma16x16(prm, d["orig"].astype(np.uint8), d["pred"].astype(np.uint8))[0]
+        _check_i16(out, d["ret"], d["dc_level"], d["dc_run"], d["ac_level"], d["ac_run"], d["rec"], d["fadjust"], d["around"], k)
+    assert len(recs) > 80
+    ctx.close()
+
+
+@pytest.mark.parametrize("qp,cavlc,around", [(28, 1, 1), (28, 0, 0), (0, 1, 0), (51, 0, 1), (12, 1, 1), (40, 0, 1)])
+def test_tq_luma16x16_vs_oracle(J, qp, cavlc, around):
+    """batches of random macroblocks: flat, textured, extreme residuals, prediction == original (everything zero)"""
+    rng = np.random.default_rng(qp * 7 + cavlc * 3 + around)
+    n = 200
+    orig = rng.integers(0, 256, (n, 16, 16)).astype(np.uint8)
+    pred = np.clip(orig.astype(np.int32) + rng.integers(-40, 41, (n, 16, 16)), 0, 255).astype(np.uint8)
+    pred[:20] = orig[:20]                                    # no residual at all
+    pred[20:40] = np.clip(orig[20:40].astype(np.int32) + rng.integers(-2, 3, (20, 16, 16)), 0, 255)   # tiny residuals: DC only or nothing
+    orig[40:50], pred[40:50] = 255, 0                        # the largest DC
+    orig[50:60] = rng.integers(0, 2, (10, 16, 16)) * 255; pred[50:60] = 255 - orig[50:60]             # the largest AC
+    q = J.qparams_4x4(qp, 1, 682)
+    ctx = make_ctx(64, 48)
+    prm = ctx.tq_params(q, qp // 6, cavlc=cavlc, adaptive_rounding=around, adapt_rnd_weight=4)
+    out = ctx.tq_luma16x16(prm, orig, pred)
+    for k in range(n):
+        ret, dl, dr, al, ar, rec, fadj = J.rtq_luma_16x16(orig[k], pred[k], q, qp // 6, cavlc, around, 4)
+        _check_i16(out[k], ret, dl, dr, al, ar, rec, fadj, around, (qp, k))
+    assert len(ctx.tq_luma16x16(prm, orig[:0], pred[:0])) == 0
+    ctx.close()
