@@ -53,7 +53,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_mcl, part_mcc;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc;
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
   StorablePicture *slot_pic[MAX_SLOTS];
@@ -63,7 +63,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_mcl, n_mcc;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc;
 } G;
 
 static void adapter_report(void)
@@ -71,8 +71,9 @@ static void adapter_report(void)
   if (!G.init_done) return;
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
-                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma\n",
-          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc);
+                  "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
+                  "Intra16x16 macroblocks on the MI355X: %ld\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -112,7 +113,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_interp = has_part(parts, "interp"); G.part_fs = has_part(parts, "fs"); G.part_subpel = has_part(parts, "subpel");
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
-    G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc");
+    G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -606,9 +607,57 @@ static int jmhip_rtq_chroma(Macroblock *currMB, int uv, int cr_cbp)
 }
 
 extern void __real_select_transform(Macroblock *);
+/* residual_transform_quant_luma_16x16 (block.c:208): the Intra16x16 luma of one macroblock */
+extern int residual_transform_quant_luma_16x16(Macroblock *, ColorPlane);
+static int jmhip_rtq_luma_16x16(Macroblock *currMB, ColorPlane pl)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currSlice->p_Vid;
+  jmhip_tq_params prm;
+  static jmhip_tq16_out out;
+  uint8_t orig[256], pred[256];
+  int j, i, k, b, rc, cavlc, around, qp;
+  LevelQuantParams **q;
+  if (!adapter_on(p_Vid) || !G.part_tq16 || pl != PLANE_Y || p_Vid->yuv_format == YUV444 || currMB->is_field_mode ||
+      currSlice->slice_type == SP_SLICE || currSlice->slice_type == SI_SLICE || currSlice->quant_dc4x4 != quant_dc4x4_normal ||
+      (currSlice->quant_ac4x4 != quant_ac4x4_normal && currSlice->quant_ac4x4 != quant_ac4x4_around)) {
+    G.n_passed++;
+    return residual_transform_quant_luma_16x16(currMB, pl);
+  }
+  fill_tq_common(currMB, &cavlc, &around);
+  qp = currMB->qp_scaled[pl];
+  q = p_Vid->p_Quant->q_params_4x4[pl][1][qp];
+  memset(&prm, 0, sizeof prm);
+  for (j = 0; j < 4; j++)
+    for (i = 0; i < 4; i++) { prm.q[j * 4 + i].OffsetComp = q[j][i].OffsetComp; prm.q[j * 4 + i].ScaleComp = q[j][i].ScaleComp; prm.q[j * 4 + i].InvScaleComp = q[j][i].InvScaleComp; }
+  prm.qp_per = p_Vid->p_Quant->qp_per_matrix[qp]; prm.cavlc = cavlc; prm.adaptive_rounding = currSlice->quant_ac4x4 == quant_ac4x4_around;
+  prm.adapt_rnd_weight = p_Vid->AdaptRndWeight; prm.max_pel = p_Vid->max_imgpel_value;
+  for (j = 0; j < 16; j++)
+    for (i = 0; i < 16; i++) {
+      orig[j * 16 + i] = (uint8_t)p_Vid->pCurImg[currMB->opix_y + j][currMB->pix_x + i];
+      pred[j * 16 + i] = (uint8_t)currSlice->mpr_16x16[pl][currMB->i16mode][j][i];
+    }
+  if ((rc = jmhip_tq_luma16x16(G.ctx, &prm, orig, pred, 1, &out))) adapter_die("jmhip_tq_luma16x16", rc);
+  G.n_tq16++;
+  currMB->subblock_x = 12; currMB->subblock_y = 12;                          /* what the loop of block.c:310-336 leaves behind */
+  for (k = 0; k < 17; k++) { currSlice->cofDC[pl][0][k] = out.dc_level[k]; currSlice->cofDC[pl][1][k] = out.dc_run[k]; }
+  for (b = 0; b < 16; b++) {
+    int *lev = currSlice->cofAC[(pl << 2) + (b >> 2)][b & 3][0], *run = currSlice->cofAC[(pl << 2) + (b >> 2)][b & 3][1];
+    for (k = 0; k < out.ac_ncoef[b]; k++) { lev[k] = out.ac_level[b][k]; run[k] = out.ac_run[b][k]; }
+    lev[out.ac_ncoef[b]] = 0;
+  }
+  if (prm.adaptive_rounding) {                                                /* rows 0..3 only, the DC positions untouched: as JM's call does */
+    int **fadj = p_Vid->ARCofAdj4x4[pl][I16MB];
+    for (j = 0; j < 4; j++) for (i = 0; i < 16; i++) if (j || (i & 3)) fadj[j][i] = out.fadjust[j][i];
+  }
+  for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) p_Vid->enc_picture->p_curr_img[currMB->pix_y + j][currMB->pix_x + i] = out.rec[j * 16 + i];
+  return out.ac_coef;
+}
+
 void __wrap_select_transform(Macroblock *currMB)
 {
   __real_select_transform(currMB);
+  if (currMB->residual_transform_quant_luma_16x16 == residual_transform_quant_luma_16x16) currMB->residual_transform_quant_luma_16x16 = jmhip_rtq_luma_16x16;
   if (currMB->residual_transform_quant_luma_4x4 == __real_residual_transform_quant_luma_4x4)
     currMB->residual_transform_quant_luma_4x4 = __wrap_residual_transform_quant_luma_4x4;
   if (currMB->residual_transform_quant_chroma_4x4[0] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[0] = jmhip_rtq_chroma;
