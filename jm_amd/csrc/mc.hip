@@ -19,15 +19,15 @@ struct __attribute__((packed)) u32un { uint32_t v; };
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const u32un *)p)->v; }
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
 
-// 64 lanes per block: lane -> (row, group of four samples)
+// 16 lanes per block; a lane copies every 16th group of four samples (one group for 4x4 .. 8x8, four for 16x16)
 __global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__restrict__ blocks, int n, McSlots slots, int nslots,
                                                  int pitch, long plane_stride, int W, int H, uint8_t *__restrict__ out)
 {
-  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 6, l = t & 63, row = l >> 2, c4 = l & 3;
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 4, l = t & 15;
   if (b >= n) return;
   const jmhip_mc_luma_blk q = blocks[b];
-  if (row >= q.h || 4 * c4 >= q.w || q.dir > 2) return;
-  uint32_t v[2] = {0, 0};
+  if (q.dir > 2) return;
+  const uint8_t *src[2] = {nullptr, nullptr};
 #pragma unroll
   for (int list = 0; list < 2; list++) {
     if (q.dir != list && q.dir != 2) continue;
@@ -35,10 +35,15 @@ __global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__rest
     if (s < 0 || s >= nslots) return;
     const int qx = (q.x << 2) + q.mv[list][0], qy = (q.y << 2) + q.mv[list][1];
     const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), W + 15);     // UMVLine4X: one origin per block
-    v[list] = ld4u(slots.p[s] + ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y + row) * pitch + xx + JMHIP_PAD_X + 4 * c4);
+    src[list] = slots.p[s] + ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y) * pitch + xx + JMHIP_PAD_X;
   }
-  const uint32_t r = q.dir == 0 ? v[0] : (q.dir == 1 ? v[1] : avg4(v[0], v[1]));
-  *(uint32_t *)(out + (long)b * 256 + row * q.w + 4 * c4) = r;
+  const int w4 = q.w >> 2, groups = w4 * q.h;
+  for (int g = l; g < groups; g += 16) {
+    const int row = g / w4, c4 = g - row * w4;
+    const long off = (long)row * pitch + 4 * c4;
+    const uint32_t a = q.dir != 1 ? ld4u(src[0] + off) : 0u, c = q.dir != 0 ? ld4u(src[1] + off) : 0u;
+    *(uint32_t *)(out + (long)b * 256 + row * q.w + 4 * c4) = q.dir == 0 ? a : (q.dir == 1 ? c : avg4(a, c));
+  }
 }
 
 // 16 lanes per block: lane -> sample (row j, column i); the sample pair i >> 1 shares a vector
@@ -78,7 +83,7 @@ extern "C" int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_bloc
   if (!ctx) return JMHIP_EINVAL;
   if (n < 0 || (n > 0 && (!d_blocks || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma_dev: bad argument");
   if (n == 0) return JMHIP_OK;
-  hipLaunchKernelGGL(k_mc_luma, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, d_blocks, n, luma_slots(ctx), ctx->cfg.num_ref_slots,
+  hipLaunchKernelGGL(k_mc_luma, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_blocks, n, luma_slots(ctx), ctx->cfg.num_ref_slots,
                      ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, d_out);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
