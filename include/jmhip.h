@@ -129,6 +129,7 @@ int jmhip_me_sad_tables(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *jobs, 
  * Candidate-list distortion and sub-pel refinement
  * ------------------------------------------------------------------------------------------ */
 #define JMHIP_METRIC_SAD  0          /* ERROR_SAD  */
+#define JMHIP_METRIC_SSE  1          /* ERROR_SSE: jmhip_distortion only */
 #define JMHIP_METRIC_SATD 2          /* ERROR_SATD (Hadamard) */
 
 /* computeSAD / computeSATD (me_distortion.c:349-426 / :745-825; MEBlock.computePred{F,H,Q}Pel,
@@ -297,6 +298,12 @@ int jmhip_dc_transform(jmhip_ctx *ctx, int32_t kind, const int32_t *in, int32_t 
  * transformed DC coefficients on entry and the quantised LEVELS on return, as JM leaves them for ihadamard4x4. */
 typedef struct { int16_t level[17]; uint8_t run[17]; uint8_t nonzero; } jmhip_dc_out;   /* 52 bytes */
 int jmhip_quant_dc4x4(jmhip_ctx *ctx, const jmhip_qparam *q, int32_t qp_per, int32_t cavlc, int32_t *blocks, int32_t nblocks, jmhip_dc_out *out);
+
+/* The block distortions of JM's mode decision, batched: VideoParameters.distortion4x4 / distortion8x8 (lencod/inc/global.h:1470-1471,
+ * bound in lencod/src/me_distortion.c:148-166) = distortion{4x4,8x8}{SAD,SSE,SATD} (:38-146; HadamardSAD4x4 :175, HadamardSAD8x8 :266).
+ * diff: n blocks of size*size int16 differences, row-major; out[i] = dist_scale(value) = value << 5.  (distortion8x8SADthres, the
+ * early-exit variant, returns a partial sum when it exits and is not provided.) */
+int jmhip_distortion(jmhip_ctx *ctx, int32_t metric, int32_t size, const int16_t *diff, int32_t nblocks, int64_t *out);
 
 /* ------------------------------------------------------------------------------------------
  * Motion-compensated prediction, un-weighted, frame pictures

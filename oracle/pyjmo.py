@@ -323,3 +323,9 @@ def rtq_luma_16x16(orig, pred, qparams, qp_per, cavlc, around, arw, max_pel=255)
     r = L.jmo_rtq_luma_16x16(_p(o), _p(p), _p(q), int(qp_per), int(cavlc), int(around), int(arw), int(max_pel),
                              _p(dl), _p(dr), _p(al), _p(ar), _p(rec), _p(fadj))
     return r, dl, dr, al, ar, rec.reshape(16, 16).astype(np.uint8), fadj.reshape(4, 16)
+
+
+def hadamard_sad(diff):
+    """HadamardSAD4x4 / HadamardSAD8x8 (me_distortion.c:175 / :266) of one int16 difference block (16 or 64 values)"""
+    d = np.ascontiguousarray(diff, np.int16).reshape(-1)
+    return int(L.jmo_hadamard_sad4x4(_p(d)) if d.size == 16 else L.jmo_hadamard_sad8x8(_p(d)))

@@ -838,3 +838,20 @@ def test_tq_luma16x16_vs_oracle(J, qp, cavlc, around):
         _check_i16(out[k], ret, dl, dr, al, ar, rec, fadj, around, (qp, k))
     assert len(ctx.tq_luma16x16(prm, orig[:0], pred[:0])) == 0
     ctx.close()
+
+
+# ---------------------------------------------------------------- distortion4x4 / distortion8x8 (mode decision)
+def test_distortion_blocks(J):
+    """SURVEY.md Appendix C known answers (JM's own functions) and random blocks against the oracle"""
+    ctx = make_ctx(64, 48)
+    d4 = np.array([207, 244, -28, 186, -3, 239, -62, 77, -223, 111, -232, 166, -139, 132, 163, -190], np.int16)
+    assert int(ctx.distortion(2, 4, d4)[0]) == 4516 << 5 and int(ctx.distortion(0, 4, d4)[0]) == 76864
+    rng = np.random.default_rng(11)
+    for size in (4, 8):
+        d = rng.integers(-255, 256, (500, size * size)).astype(np.int16)
+        d[:3] = [[255] * (size * size), [-255] * (size * size), [0] * (size * size)]
+        assert np.array_equal(ctx.distortion(0, size, d), np.abs(d.astype(np.int64)).sum(1) << 5)
+        assert np.array_equal(ctx.distortion(1, size, d), (d.astype(np.int64) ** 2).sum(1) << 5)
+        assert np.array_equal(ctx.distortion(2, size, d), np.array([J.hadamard_sad(b) for b in d], np.int64) << 5)
+    assert len(ctx.distortion(2, 4, np.zeros((0, 16), np.int16))) == 0
+    ctx.close()
