@@ -37,6 +37,8 @@
 
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(3))) int lds_int;   // the abort flag is polled twice per step: through a generic pointer that is a flat load plus a wait for every
+                                                         // outstanding memory operation of the wave; through an LDS pointer it is a ds_read
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 struct __attribute__((aligned(16))) DbPrep {
@@ -234,7 +236,7 @@ extern "C" void jmhip_debug_read_db_prof(unsigned long long *out) { (void)hipMem
 #define DBP_STEP(s_)
 #define DBP_END
 #endif
-__device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* LR x 2 x sizeof(DbPrep) */, volatile int *s_abort)
+__device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT_BYTES */, uint8_t *s_preps /* LR x 2 x sizeof(DbPrep) */, volatile lds_int *s_abort)
 {
   const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w;
   const bool filter_wave = tid < 64, loader_wave = tid >= 128;
@@ -406,7 +408,7 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
 // tile of 2 + RH * rows sample rows x 8 bytes
 #define CT_PLANE (34 * 8)
 #define CT_BYTES (2 * CT_PLANE)
-__device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x CT_BYTES */, uint8_t *s_preps, volatile int *s_abort)
+__device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x CT_BYTES */, uint8_t *s_preps, volatile lds_int *s_abort)
 {
   const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8, CR = 32 / RH;
   const bool filter_wave = tid < 64;
@@ -586,9 +588,9 @@ __global__ __launch_bounds__(192) void k_deblock_rows(RowArgs A)
   const int nl = (A.mb_h + LR - 1) / LR, nc = A.nkinds > 1 ? (A.mb_h + CR - 1) / CR : 0;
   // order: l0 c0 l1 c1 ... while both last, then the rest of the longer list
   const int both = min(nl, nc);
-  if (t < 2 * both) { if (t & 1) chroma_rows(A, t >> 1, s_tiles, s_preps, &s_abort); else luma_rows(A, t >> 1, s_tiles, s_preps, &s_abort); }
-  else if (nl > both) { if (t - both < nl) luma_rows(A, t - both, s_tiles, s_preps, &s_abort); }
-  else if (t - both < nc) chroma_rows(A, t - both, s_tiles, s_preps, &s_abort);
+  if (t < 2 * both) { if (t & 1) chroma_rows(A, t >> 1, s_tiles, s_preps, (lds_int *)&s_abort); else luma_rows(A, t >> 1, s_tiles, s_preps, (lds_int *)&s_abort); }
+  else if (nl > both) { if (t - both < nl) luma_rows(A, t - both, s_tiles, s_preps, (lds_int *)&s_abort); }
+  else if (t - both < nc) chroma_rows(A, t - both, s_tiles, s_preps, (lds_int *)&s_abort);
 }
 
 // prep + rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
