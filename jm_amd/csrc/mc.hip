@@ -27,21 +27,25 @@ __global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__rest
   if (b >= n) return;
   const jmhip_mc_luma_blk q = blocks[b];
   if (q.dir > 2) return;
-  const uint8_t *src[2] = {nullptr, nullptr};
+  // the origin of each list: UMVLine4X clamps the block's origin once (refbuf.h:22-26)
+  long o0 = 0, o1 = 0;
+  int s0 = 0, s1 = 0;
 #pragma unroll
   for (int list = 0; list < 2; list++) {
     if (q.dir != list && q.dir != 2) continue;
     const int s = q.slot[list];
     if (s < 0 || s >= nslots) return;
     const int qx = (q.x << 2) + q.mv[list][0], qy = (q.y << 2) + q.mv[list][1];
-    const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), W + 15);     // UMVLine4X: one origin per block
-    src[list] = slots.p[s] + ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y) * pitch + xx + JMHIP_PAD_X;
+    const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), W + 15);
+    const long o = ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y) * pitch + xx + JMHIP_PAD_X;
+    if (list == 0) { o0 = o; s0 = s; } else { o1 = o; s1 = s; }
   }
+  const uint8_t *__restrict__ src0 = slots.p[s0] + o0, *__restrict__ src1 = slots.p[s1] + o1;
   const int w4 = q.w >> 2, groups = w4 * q.h;
   for (int g = l; g < groups; g += 16) {
     const int row = g / w4, c4 = g - row * w4;
     const long off = (long)row * pitch + 4 * c4;
-    const uint32_t a = q.dir != 1 ? ld4u(src[0] + off) : 0u, c = q.dir != 0 ? ld4u(src[1] + off) : 0u;
+    const uint32_t a = q.dir != 1 ? ld4u(src0 + off) : 0u, c = q.dir != 0 ? ld4u(src1 + off) : 0u;
     *(uint32_t *)(out + (long)b * 256 + row * q.w + 4 * c4) = q.dir == 0 ? a : (q.dir == 1 ? c : avg4(a, c));
   }
 }
