@@ -53,7 +53,8 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval;
+  int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
   StorablePicture *slot_pic[MAX_SLOTS];
@@ -63,7 +64,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval;
 } G;
 
 static void adapter_report(void)
@@ -72,8 +73,8 @@ static void adapter_report(void)
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
-                  "Intra16x16 macroblocks on the MI355X: %ld\n",
-          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16);
+                  "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -114,6 +115,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
+    G.part_eval = has_part(parts, "eval");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -250,7 +252,7 @@ distblk __wrap_full_search_motion_estimation(Macroblock *currMB, MotionVector *p
       R < 1 || R > G.R || lambda_factor < 0 || mv_block->pos_x != currMB->pix_x + 4 * mv_block->block_x ||
       mv_block->pos_y != currMB->opix_y + 4 * mv_block->block_y) {
     G.n_passed++;
-    return __real_full_search_motion_estimation(currMB, pred_mv, mv_block, min_mcost, lambda_factor);
+    { distblk r_; G.in_real_me++; r_ = __real_full_search_motion_estimation(currMB, pred_mv, mv_block, min_mcost, lambda_factor); G.in_real_me--; return r_; }
   }
   slot = slot_of_reference(currSlice->listX[list + currMB->list_offset][(int)mv_block->ref_idx]);
   memset(&job, 0, sizeof job);
@@ -286,7 +288,7 @@ distblk __wrap_sub_pel_motion_estimation(Macroblock *currMB, MotionVector *pred,
       !((mq == ERROR_SAD && mv_block->computePredQPel == computeSAD) || (mq == ERROR_SATD && mv_block->computePredQPel == computeSATD)) ||
       lambda[H_PEL] < 0 || lambda[Q_PEL] < 0) {
     G.n_passed++;
-    return __real_sub_pel_motion_estimation(currMB, pred, mv_block, min_mcost, lambda);
+    { distblk r_; G.in_real_me++; r_ = __real_sub_pel_motion_estimation(currMB, pred, mv_block, min_mcost, lambda); G.in_real_me--; return r_; }
   }
   slot = slot_of_reference(currSlice->listX[list + currMB->list_offset][(int)mv_block->ref_idx]);
   memset(&job, 0, sizeof job);
@@ -321,7 +323,7 @@ void __wrap_setup_fast_full_search(Macroblock *currMB, MEBlock *mv_block, int li
   int rc, slot, t, k, pos;
   if (!me_common_ok(currMB, mv_block) || !G.part_ffs || wp || p_Inp->MEErrorMetric[F_PEL] != ERROR_SAD || R < 1 || R > G.R) {
     G.n_passed++;
-    __real_setup_fast_full_search(currMB, mv_block, list);
+    G.in_real_me++; __real_setup_fast_full_search(currMB, mv_block, list); G.in_real_me--;
     return;
   }
   /* search centre = the 16x16 predictor rounded to full-pel and kept inside the level's MV range (me_fullfast.c:307-327) */
@@ -352,6 +354,44 @@ void __wrap_setup_fast_full_search(Macroblock *currMB, MEBlock *mv_block, int li
     }
   ff->search_setup_done[list][ref] = 1;
   G.n_ffs++;
+}
+
+/* ------------------------------------------------------------------ candidate distortions: MEBlock.computePred{F,H,Q}Pel
+ * computeSAD (lencod/src/me_distortion.c:349) / computeSATD (:745), reached through p_Dpb->pf_computeSAD / pf_computeSATD (lencod.c:355-357)
+ * by the searches that stay on the host: EPZS's predictor and pattern walk (me_epzs*.c) evaluates its candidates one by one.
+ * JM's early exit returns min_mcost itself as soon as a partial sum exceeds min_mcost >> 5 (dist_scale_f, mv_search.h:20), and the
+ * last check covers the whole block: the result is min_mcost when the full distortion exceeds that bound, else distortion << 5. */
+static distblk eval_candidate(StorablePicture *ref1, MEBlock *mv_block, distblk min_mcost, MotionVector *cand, int metric,
+                              distblk (*real)(StorablePicture *, MEBlock *, distblk, MotionVector *))
+{
+  VideoParameters *p_Vid = mv_block->p_Vid;
+  jmhip_cand c;
+  int32_t dist;
+  int rc;
+  const int bsx = mv_block->blocksize_x, bsy = mv_block->blocksize_y;
+  const int rx = cand->mv_x - (mv_block->pos_x << 2), ry = cand->mv_y - (mv_block->pos_y << 2);
+  if (G.in_real_me || !adapter_on(p_Vid) || !G.part_eval || G.n_cur == 0 || p_Vid->structure != FRAME || mv_block->ChromaMEEnable ||
+      !ref1 || ref1->size_x != G.W || ref1->size_y != G.H || (bsx != 4 && bsx != 8 && bsx != 16) || (bsy != 4 && bsy != 8 && bsy != 16) ||
+      rx < -32768 || rx > 32767 || ry < -32768 || ry > 32767 || (metric == JMHIP_METRIC_SATD && mv_block->test8x8 && (bsx < 8 || bsy < 8))) {
+    G.n_passed++;
+    return real(ref1, mv_block, min_mcost, cand);
+  }
+  memset(&c, 0, sizeof c);
+  c.pos_x = mv_block->pos_x; c.pos_y = mv_block->pos_y; c.bsx = (int16_t)bsx; c.bsy = (int16_t)bsy;
+  c.cand_x = (int16_t)rx; c.cand_y = (int16_t)ry; c.metric = (int16_t)metric; c.test8x8 = (int16_t)(mv_block->test8x8 != 0);
+  if ((rc = jmhip_me_eval(G.ctx, slot_of_reference(ref1), &c, 1, &dist))) adapter_die("jmhip_me_eval", rc);
+  G.n_eval++;
+  return ((distblk)dist >> 5) > (min_mcost >> 5) ? min_mcost : (distblk)dist;
+}
+extern distblk __real_computeSAD(StorablePicture *, MEBlock *, distblk, MotionVector *);
+distblk __wrap_computeSAD(StorablePicture *ref1, MEBlock *mv_block, distblk min_mcost, MotionVector *cand)
+{
+  return eval_candidate(ref1, mv_block, min_mcost, cand, JMHIP_METRIC_SAD, __real_computeSAD);
+}
+extern distblk __real_computeSATD(StorablePicture *, MEBlock *, distblk, MotionVector *);
+distblk __wrap_computeSATD(StorablePicture *ref1, MEBlock *mv_block, distblk min_mcost, MotionVector *cand)
+{
+  return eval_candidate(ref1, mv_block, min_mcost, cand, JMHIP_METRIC_SATD, __real_computeSATD);
 }
 
 /* ------------------------------------------------------------------ motion-compensated prediction
