@@ -5,10 +5,14 @@ One "step" = one pass of the hot path over one P frame whose inputs are already 
   K5  sub-pel planes of the reference      (getSubImagesLuma)
   K1-3 full search, SR=32, 41 partitions    (full_search_motion_estimation, one window job per macroblock)
   K4  9+9 sub-pel refinement, SATD          (sub_pel_motion_estimation)
-  K7/8 4x4 transform/quant/reconstruct      (residual_transform_quant_luma_4x4, 16 luma blocks per macroblock)
-  K9/10 deblocking of the frame             (DeblockFrame)
-The MV predictors, the prediction fed to the transform and the deblocking side information are synthetic
-inputs (the sequential mode decision that produces them in JM stays on the host: SURVEY.md 8b/8f).
+  MC  luma prediction of every macroblock with its refined 16x16 vector (luma_prediction), device resident
+  K7/8 4x4 transform/quant/reconstruct      (residual_transform_quant_luma_4x4, 16 luma blocks per macroblock) on source - prediction,
+       the reconstructed blocks assembled into the picture
+  K9/10 deblocking of that reconstructed picture (DeblockFrame)
+Data flows from stage to stage on the device as it does in the encoder (reference -> search -> refinement -> prediction -> residual
+-> reconstruction -> loop filter).  What stays synthetic: the MV predictors (the sequential mode decision that produces them in JM
+stays on the host), the choice "every macroblock is P16x16", and the chroma planes; the deblocking side
+information is the P picture's of this very configuration as JM produced it (tests/golden/g2_sideinfo.npz).
 
 python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, one rank per GPU)
 N > 1 shards one tall frame of N 1080p bands (slices) one band per GPU; each step all-gathers the
@@ -192,7 +196,6 @@ def main():
     def blocks_of(img):
         return np.ascontiguousarray(img.reshape(H // 4, 4, W // 4, 4).transpose(0, 2, 1, 3).reshape(-1, 16))
     d_orig = torch.from_numpy(blocks_of(frames[1])).to(dev)
-    d_pred = torch.from_numpy(blocks_of(frames[0])).to(dev)
     nblk = d_orig.shape[0]
     d_tq = torch.zeros((nblk, TQ_OUT.itemsize), dtype=torch.uint8, device=dev)
     q = np.zeros((16, 3), np.int32)
@@ -232,9 +235,11 @@ def main():
     dctx = ctx if halo == 0 else JmHip(W, H, search_range=R, num_ref_slots=1, yuv_format=1, device=local, stream=stream.cuda_stream)
 
     # HIP events on the launch stream around every stage of every timed step: 6 marks per step
-    STAGES = ["k_subplanes (K5)", "k_me_fs_fast (K1-K3)", "k_me_refine_mb (K4)", "k_tq_luma4x4 (K7/K8)", "k_deblock_prep + k_deblock_rows (K9/K10)"]
+    STAGES = ["k_subplanes (K5)", "k_me_fs_fast (K1-K3)", "k_me_refine_mb (K4)", "k_mc_mb16 + k_tq_luma4x4 + k_tq_rec_to_plane (MC, K7/K8)",
+              "k_deblock_prep + k_deblock_rows (K9/K10)"]
     marks = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
-    SPANS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6)]                     # marks 4..5: the bench's own copy that restores the unfiltered picture
+    SPANS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6)]                     # marks 4..5: the bench's own copy that resets the chroma planes
+    d_predb = torch.zeros((nblk, 16), dtype=torch.uint8, device=dev)      # prediction in 4x4-block order, written by the MC stage
 
     def step(i, timed):
         if N > 1 and one_gpu:                                           # debugging path: the same exchange on host copies over gloo
@@ -252,10 +257,14 @@ def main():
         ctx.me_refine_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr(), rprm, d_fin.data_ptr())   # K4
         if timed:
             marks[i][3].record(stream)
-        ctx.tq_luma4x4_dev(tqp, d_orig.data_ptr(), d_pred.data_ptr(), nblk, d_tq.data_ptr())     # K7/K8
+        # P16x16 reconstruction path, device resident: prediction with each macroblock's refined 16x16 vector, residual transform /
+        # quantisation / reconstruction of the sixteen 4x4 blocks, reconstructed blocks assembled into the picture the deblocking reads
+        ctx.mc_mb16_dev(0, d_jobs.data_ptr(), d_fin.data_ptr(), nmb, halo, W // 4, d_predb.data_ptr())
+        ctx.tq_luma4x4_dev(tqp, d_orig.data_ptr(), d_predb.data_ptr(), nblk, d_tq.data_ptr())    # K7/K8
+        ctx.tq_rec_to_plane_dev(d_tq.data_ptr(), nblk, W // 4, work_y.data_ptr(), W)
         if timed:
             marks[i][4].record(stream)
-        work_y.copy_(pre_y); work_c.copy_(pre_c)
+        work_c.copy_(pre_c)
         if timed:
             marks[i][5].record(stream)
         dctx.deblock_frame_dev(work_y.data_ptr(), W, work_c[0].data_ptr(), work_c[1].data_ptr(), cw, d_mbs.data_ptr(), d_mot.data_ptr(), 1)  # K9/K10
@@ -294,7 +303,7 @@ def main():
         alg = [W * H + 16 * (W + 64) * (HL + 40),                               # K5: one plane in, 16 padded planes out
                (256 + (2 * R + 16) ** 2 + 328) * nmb,                           # K1-K3: SURVEY.md 8d per MB-reference: 6656 in + 328 out at R=32
                7 * 256 * 19 * nmb,                                              # K4: 18 candidate blocks + the current block, 7 block types
-               (32 + 104) * nblk,                                               # K7/K8: 32 B in, 104 B out per 4x4 block
+               (16 + 32 + 104 + 16) * nblk,                                     # MC + K7/K8: 16 B reference in; 32 B in, 104 B out per 4x4 block; 16 B picture out
                int(1.5 * W * H * 2) + (192 + 28 + 16 * 16) * nmb]               # K9/K10: every sample once in, once out + records
         kernels = [{"kernel": STAGES[k], "ms": round(stage_ms[k], 4), "algorithmic_bytes": alg[k], "hbm_traffic_bytes": TRAFFIC_BYTES[k],
                     "hbm_frac": round(alg[k] / (stage_ms[k] * 1e-3) / 8e12, 5)} for k in range(len(STAGES))]
@@ -319,7 +328,7 @@ def main():
             "config": {"workload": "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP P-frame hot path, FullSearch SR=32, 1 ref, QP 28",
                        "macroblocks_per_step_per_gpu": nmb, "search_range": R, "partitions": NPART,
                        "parallelism": "1 GPU" if N == 1 else f"{N} slices (1080p bands) one per GPU, RCCL all-gather of reconstructed bands per step",
-                       "kernel_path_only": "MV predictors and the prediction fed to the transform are synthetic inputs; the deblocking side information is "
+                       "kernel_path_only": "MV predictors are synthetic inputs and every macroblock is reconstructed as P16x16 from its refined vector; the deblocking side information is "
                                            + ("the P picture's as JM produced it for this configuration" if args.deblock_load == "real" else "a made-up intra-heavy mix")
                                            + "; mode decision and entropy coding stay on the host",
                        "motion_found_frac": round(motion_ok, 4)},

@@ -341,6 +341,16 @@ int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t
 int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out);
 int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int32_t n, uint8_t *d_out);
 
+/* Device-resident glue between the stages of a P picture coded as 16x16 macroblocks (no host round trip):
+ * jmhip_mc_mb16_dev   luma_prediction of every window job's 16x16 partition with the vector the refinement left in
+ *                     results[job].best[0], written as sixteen 4x4 blocks of 16 samples each in picture block-raster order
+ *                     (block (by, bx) at index by * blocks_per_row + bx): the layout jmhip_tq_luma4x4_dev reads.  job.mb_y - y_offset
+ *                     is the macroblock's row in that block array (y_offset: rows of halo above a band, else 0).
+ * jmhip_tq_rec_to_plane_dev  the reconstructed samples of jmhip_tq_out records (same block order) assembled into a plane. */
+int jmhip_mc_mb16_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t njobs,
+                      int32_t y_offset, int32_t blocks_per_row, uint8_t *d_pred_blocks);
+int jmhip_tq_rec_to_plane_dev(jmhip_ctx *ctx, const jmhip_tq_out *d_out, int32_t nblocks, int32_t blocks_per_row, uint8_t *d_plane, int32_t pitch_bytes);
+
 /* ------------------------------------------------------------------------------------------
  * In-loop deblocking of a whole frame
  *

@@ -150,3 +150,53 @@ extern "C" int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;
 }
+
+
+// ---- frame-level glue for P pictures coded as 16x16 macroblocks: prediction straight from the refinement's results into the
+//      block order the transform/quant kernel reads; 64 lanes per macroblock, lane -> (row, four samples)
+__global__ __launch_bounds__(256) void k_mc_mb16(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ results, int n,
+                                                 const uint8_t *__restrict__ planes, int pitch, long plane_stride, int W, int H,
+                                                 int y_offset, int blocks_per_row, uint8_t *__restrict__ pred)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 6, l = t & 63, row = l >> 2, c4 = l & 3;
+  if (b >= n) return;
+  const int mb_x = jobs[b].mb_x, mb_y = jobs[b].mb_y;
+  const jmhip_me_best mv = results[b].best[0];
+  const int qx = (mb_x << 2) + mv.mv_x, qy = (mb_y << 2) + mv.mv_y;
+  const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), W + 15);
+  const uint32_t v = ld4u(planes + ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y + row) * pitch + xx + JMHIP_PAD_X + 4 * c4);
+  const long blk = (long)(((mb_y - y_offset) >> 2) + (row >> 2)) * blocks_per_row + (mb_x >> 2) + c4;
+  *(uint32_t *)(pred + blk * 16 + (row & 3) * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void k_tq_rec_to_plane(const jmhip_tq_out *__restrict__ out, int n, int blocks_per_row, uint8_t *__restrict__ plane, int pitch)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 2, r = t & 3;
+  if (b >= n) return;
+  const int by = b / blocks_per_row, bx = b - by * blocks_per_row;
+  *(uint32_t *)(plane + (long)(4 * by + r) * pitch + 4 * bx) = *(const uint32_t *)(out[b].rec + 4 * r);
+}
+
+extern "C" int jmhip_mc_mb16_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t n,
+                                 int32_t y_offset, int32_t blocks_per_row, uint8_t *d_pred)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots || blocks_per_row < 4 || (n > 0 && (!d_jobs || !d_results || !d_pred)))
+    return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_mb16_dev: bad argument");
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_mc_mb16, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, d_jobs, d_results, n, (const uint8_t *)ctx->d_sub[slot], ctx->pitch,
+                     (long)ctx->plane_stride, ctx->W, ctx->H, y_offset, blocks_per_row, d_pred);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_tq_rec_to_plane_dev(jmhip_ctx *ctx, const jmhip_tq_out *d_out, int32_t n, int32_t blocks_per_row, uint8_t *d_plane, int32_t pitch)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || blocks_per_row < 1 || pitch < 4 * blocks_per_row || (pitch & 3) || (n > 0 && (!d_out || !d_plane)))
+    return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_tq_rec_to_plane_dev: bad argument");
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_tq_rec_to_plane, dim3((n + 63) / 64), dim3(256), 0, ctx->stream, d_out, n, blocks_per_row, d_plane, pitch);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}

@@ -72,7 +72,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -357,6 +357,12 @@ class JmHip:
 
     def mc_chroma_dev(self, d_blocks, n, d_out):
         self._ck(self.lib.jmhip_mc_chroma_dev(self.h, _vp(d_blocks), n, _vp(d_out)))
+
+    def mc_mb16_dev(self, slot, d_jobs, d_results, n, y_offset, blocks_per_row, d_pred):
+        self._ck(self.lib.jmhip_mc_mb16_dev(self.h, slot, _vp(d_jobs), _vp(d_results), n, y_offset, blocks_per_row, _vp(d_pred)))
+
+    def tq_rec_to_plane_dev(self, d_out, n, blocks_per_row, d_plane, pitch):
+        self._ck(self.lib.jmhip_tq_rec_to_plane_dev(self.h, _vp(d_out), n, blocks_per_row, _vp(d_plane), pitch))
 
     def distortion(self, metric, size, diff):
         """distortion4x4 / distortion8x8 {SAD 0, SSE 1, SATD 2} (lencod/src/me_distortion.c:38-146) of int16 difference blocks -> int64 << 5"""

@@ -855,3 +855,49 @@ def test_distortion_blocks(J):
         assert np.array_equal(ctx.distortion(2, size, d), np.array([J.hadamard_sad(b) for b in d], np.int64) << 5)
     assert len(ctx.distortion(2, 4, np.zeros((0, 16), np.int16))) == 0
     ctx.close()
+
+
+# ---------------------------------------------------------------- device-resident glue: prediction from results, reconstruction to a plane
+def test_mc_mb16_and_rec_to_plane_vs_oracle(J):
+    """jmhip_mc_mb16_dev == luma_prediction of every macroblock's 16x16 vector, delivered in the 4x4-block order the transform kernel
+    reads; jmhip_tq_rec_to_plane_dev puts the transform kernel's reconstructed blocks back into picture order"""
+    import torch
+    from jm_amd.lib import ME_JOB, ME_RESULT, TQ_OUT
+    w, h = 96, 64
+    rng = np.random.default_rng(5)
+    ref = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    cur = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    ctx = make_ctx(w, h)
+    ctx.set_reference(0, ref)
+    oref = J.RefPic(ref)
+    nmb = (w // 16) * (h // 16)
+    jobs = np.zeros(nmb, ME_JOB)
+    jobs["mb_x"] = np.tile(np.arange(w // 16) * 16, h // 16); jobs["mb_y"] = np.repeat(np.arange(h // 16) * 16, w // 16)
+    res = np.zeros(nmb, ME_RESULT)
+    res["best"]["mv_x"][:, 0] = rng.integers(-300, 301, nmb); res["best"]["mv_y"][:, 0] = rng.integers(-300, 301, nmb)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(nmb, -1)).to(dev)
+    d_res = torch.from_numpy(res.view(np.uint8).reshape(nmb, -1)).to(dev)
+    nblk = (w // 4) * (h // 4)
+    d_pred = torch.zeros((nblk, 16), dtype=torch.uint8, device=dev)
+    ctx.mc_mb16_dev(0, d_jobs.data_ptr(), d_res.data_ptr(), nmb, 0, w // 4, d_pred.data_ptr())
+    ctx.synchronize()
+    pred = d_pred.cpu().numpy().reshape(h // 4, w // 4, 4, 4).transpose(0, 2, 1, 3).reshape(h, w)
+    for k in range(nmb):
+        x, y = int(jobs["mb_x"][k]), int(jobs["mb_y"][k])
+        mv = (int(res["best"]["mv_x"][k, 0]), int(res["best"]["mv_y"][k, 0]))
+        assert np.array_equal(pred[y:y + 16, x:x + 16], J.luma_pred(oref, None, 0, x, y, 16, 16, mv, (0, 0))), k
+    # transform/quant on (cur, pred) blocks, then the reconstructed blocks back into a plane
+    blocks = lambda img: np.ascontiguousarray(img.reshape(h // 4, 4, w // 4, 4).transpose(0, 2, 1, 3).reshape(-1, 16))
+    q = J.qparams_4x4(28, 0, 342)
+    prm = ctx.tq_params(q, 4, cavlc=1, adaptive_rounding=0)
+    d_orig = torch.from_numpy(blocks(cur)).to(dev)
+    d_out = torch.zeros((nblk, TQ_OUT.itemsize), dtype=torch.uint8, device=dev)
+    ctx.tq_luma4x4_dev(prm, d_orig.data_ptr(), d_pred.data_ptr(), nblk, d_out.data_ptr())
+    d_plane = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+    ctx.tq_rec_to_plane_dev(d_out.data_ptr(), nblk, w // 4, d_plane.data_ptr(), w)
+    ctx.synchronize()
+    out = d_out.cpu().numpy().view(TQ_OUT).reshape(nblk)
+    want = out["rec"].reshape(h // 4, w // 4, 4, 4).transpose(0, 2, 1, 3).reshape(h, w)
+    assert np.array_equal(d_plane.cpu().numpy(), want)
+    ctx.close()
