@@ -8,15 +8,16 @@ One "step" = one pass of the hot path over one P frame whose inputs are already 
   MC  luma prediction of every macroblock with its refined 16x16 vector (luma_prediction), device resident
   K7/8 4x4 transform/quant/reconstruct      (residual_transform_quant_luma_4x4, 16 luma blocks per macroblock) on source - prediction,
        the reconstructed blocks assembled into the picture
-  K9/10 deblocking of that reconstructed picture (DeblockFrame)
+  the same for both chroma planes           (chroma_prediction_4x4, residual_transform_quant_chroma_4x4)
+  K9/10 deblocking of that reconstructed picture, luma and chroma (DeblockFrame)
 Data flows from stage to stage on the device as it does in the encoder (reference -> search -> refinement -> prediction -> residual
 -> reconstruction -> loop filter).  What stays synthetic: the MV predictors (the sequential mode decision that produces them in JM
-stays on the host), the choice "every macroblock is P16x16", and the chroma planes; the deblocking side
+stays on the host) and the choice "every macroblock is P16x16"; the deblocking side
 information is the P picture's of this very configuration as JM produced it (tests/golden/g2_sideinfo.npz).
 
 python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, one rank per GPU)
 N > 1 shards one tall frame of N 1080p bands (slices) one band per GPU; each step all-gathers the
-reconstructed bands over RCCL (the reference-frame exchange of SURVEY.md 8e) -- weak scaling.
+reconstructed bands (luma + chroma, one collective) over RCCL (the reference-picture exchange of SURVEY.md 8e) -- weak scaling.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -169,13 +170,20 @@ def main():
 
     # ---------------- synthetic inputs, resident in HBM before the timed region
     frames = synth_luma(2, seed=1234 + rank)
-    ref_band = torch.from_numpy(frames[0]).to(dev)                      # this band's reconstructed reference luma
+    def chroma_of(y):                                                   # U = 128 + (Y/2 - 128)/4, V = 128 - (Y/2 - 128)/4
+        d = 0.25 * (y[::2, ::2].astype(np.float32) - 128)
+        return np.clip(np.rint(128 + d), 0, 255).astype(np.uint8), np.clip(np.rint(128 - d), 0, 255).astype(np.uint8)
+    ref_u, ref_v = chroma_of(frames[0])
+    cur_u, cur_v = chroma_of(frames[1])
+    ref_band = torch.from_numpy(frames[0]).to(dev)                      # this band's reconstructed reference: luma ...
+    ref_band_u, ref_band_v = torch.from_numpy(ref_u).to(dev), torch.from_numpy(ref_v).to(dev)   # ... and 4:2:0 chroma
+    ref_packed = shard.packed_band(ref_band, ref_band_u, ref_band_v) if N > 1 else None
+    yuv_exchange = shard.YuvExchange(band, halo, N * H, W, N, "cpu" if one_gpu else dev) if N > 1 else None
     cur_local = np.zeros((HL, W), np.uint8); cur_local[halo:halo + H] = frames[1]
     d_cur = torch.from_numpy(cur_local).to(dev)
     ctx.set_current_dev(d_cur.data_ptr(), W)
-    gathered = torch.empty((N, H, W), dtype=torch.uint8, device=dev) if N > 1 else None
     local_ref = torch.empty((HL, W), dtype=torch.uint8, device=dev)
-    ref_rows_idx = shard.reference_rows(band, halo, N * H).to(dev) if N > 1 else None
+    local_ref_c = torch.empty((HL // 2, W), dtype=torch.uint8, device=dev)      # U | V side by side, as the exchange delivers them
 
     mbw, mbh = W // 16, H // 16
     nmb = mbw * mbh
@@ -205,12 +213,24 @@ def main():
             c = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 and j % 2) else 2)
             q[j * 4 + i] = (342 << (15 + QP // 6 - 11), sc[c], ds[c] << 4)
     tqp = ctx.tq_params(q, QP // 6, cavlc=1, adaptive_rounding=1, adapt_rnd_weight=4)
+    # chroma: both planes of every macroblock as items (2 * macroblock + plane) of 8x8 samples in rows of 8 (jmhip_tq_chroma_dev's layout)
+    from jm_amd.lib import TQC_MB, TQC_OUT
+    def items_of(u, v):
+        a = np.zeros((nmb, 2, 16, 8), np.uint8)
+        for p, pl in enumerate((u, v)):
+            a[:, p, :8] = pl.reshape(mbh, 8, mbw, 8).transpose(0, 2, 1, 3).reshape(nmb, 8, 8)
+        return a.reshape(2 * nmb, 128)
+    d_origc = torch.from_numpy(items_of(cur_u, cur_v)).to(dev)
+    d_predc = torch.zeros((2 * nmb, 128), dtype=torch.uint8, device=dev)
+    cmbs = np.zeros(2 * nmb, TQC_MB); cmbs["uv"] = np.arange(2 * nmb) % 2
+    d_cmbs = torch.from_numpy(cmbs.view(np.uint8).reshape(2 * nmb, -1)).to(dev)
+    d_tqc = torch.zeros((2 * nmb, TQC_OUT.itemsize), dtype=torch.uint8, device=dev)
+    tqcp = ctx.tqc_params(1, q, q[0], QP // 6, QP // 6, cavlc=1, adaptive_rounding=1, adapt_rnd_weight=4)   # chroma qp 28 for luma qp 28 (QP_SCALE_CR)
 
     # deblocking input: pre-filter reconstruction (the current frame stands in for it) + synthetic side information
     ch, cw = H // 2, W // 2
     pre_y = torch.from_numpy(frames[1]).to(dev)
-    pre_c = torch.full((2, ch, cw), 128, dtype=torch.uint8, device=dev)
-    work_y, work_c = torch.empty_like(pre_y), torch.empty_like(pre_c)
+    work_y, work_c = torch.empty_like(pre_y), torch.empty((2, ch, cw), dtype=torch.uint8, device=dev)
     # side information: what JM's DeblockFrame was given for the P picture of this very configuration (tests/golden/g2_sideinfo.npz,
     # captured from the reference encoder by tests/golden/make_g2_sideinfo.py): 78 % skipped macroblocks, 8 % with coefficients,
     # 0.2 % intra, 86 % of the 4x4 blocks on the clip's global motion vector.  --deblock-load worst swaps in a made-up intra-heavy mix.
@@ -235,20 +255,28 @@ def main():
     dctx = ctx if halo == 0 else JmHip(W, H, search_range=R, num_ref_slots=1, yuv_format=1, device=local, stream=stream.cuda_stream)
 
     # HIP events on the launch stream around every stage of every timed step: 6 marks per step
-    STAGES = ["k_subplanes (K5)", "k_me_fs_fast (K1-K3)", "k_me_refine_mb (K4)", "k_mc_mb16 + k_tq_luma4x4 + k_tq_rec_to_plane (MC, K7/K8)",
+    STAGES = ["k_subplanes (K5)", "k_me_fs_fast (K1-K3)", "k_me_refine_mb (K4)", "prediction + transform/quant + reconstruction, luma and chroma (MC, K7/K8)",
               "k_deblock_prep + k_deblock_rows (K9/K10)"]
     marks = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
-    SPANS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6)]                     # marks 4..5: the bench's own copy that resets the chroma planes
+    SPANS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6)]
     d_predb = torch.zeros((nblk, 16), dtype=torch.uint8, device=dev)      # prediction in 4x4-block order, written by the MC stage
 
     def step(i, timed):
         if N > 1 and one_gpu:                                           # debugging path: the same exchange on host copies over gloo
-            local_ref.copy_(shard.exchange_reference(ref_band.cpu(), band, halo, N * H))
-        elif N > 1:                                                     # reference-frame exchange over xGMI (RCCL): the one collective
-            shard.exchange_reference(ref_band, band, halo, N * H, gathered=gathered, out=local_ref, idx=ref_rows_idx)
+            ly, lu, lv = yuv_exchange(ref_packed.cpu())
+            local_ref.copy_(ly); local_ref_c[:, :W // 2].copy_(lu); local_ref_c[:, W // 2:].copy_(lv)
+        elif N > 1:                                                     # reference-picture exchange over xGMI (RCCL): the one collective (luma + chroma)
+            ly, lu, lv = yuv_exchange(ref_packed)
+        if N > 1 and one_gpu:
+            ly, lu, lv = local_ref, local_ref_c[:, :W // 2], local_ref_c[:, W // 2:]
         if timed:
             marks[i][0].record(stream)
-        ctx.set_reference_dev(0, (local_ref if N > 1 else ref_band).data_ptr(), W)   # K5
+        if N > 1:
+            ctx.set_reference_dev(0, ly.data_ptr(), W)                                   # K5
+            ctx.set_reference_chroma_dev(0, lu.data_ptr(), lv.data_ptr(), W)
+        else:
+            ctx.set_reference_dev(0, ref_band.data_ptr(), W)                             # K5
+            ctx.set_reference_chroma_dev(0, ref_band_u.data_ptr(), ref_band_v.data_ptr(), W // 2)
         if timed:
             marks[i][1].record(stream)
         ctx.me_fullsearch_dev(0, d_jobs.data_ptr(), nmb, d_int.data_ptr())           # K1-K3
@@ -262,9 +290,12 @@ def main():
         ctx.mc_mb16_dev(0, d_jobs.data_ptr(), d_fin.data_ptr(), nmb, halo, W // 4, d_predb.data_ptr())
         ctx.tq_luma4x4_dev(tqp, d_orig.data_ptr(), d_predb.data_ptr(), nblk, d_tq.data_ptr())    # K7/K8
         ctx.tq_rec_to_plane_dev(d_tq.data_ptr(), nblk, W // 4, work_y.data_ptr(), W)
+        # the same for both chroma planes (chroma_prediction_4x4, residual_transform_quant_chroma_4x4)
+        ctx.mc_mb16_chroma_dev(0, d_jobs.data_ptr(), d_fin.data_ptr(), nmb, d_predc.data_ptr())
+        ctx.tq_chroma_dev(tqcp, d_cmbs.data_ptr(), d_origc.data_ptr(), d_predc.data_ptr(), 2 * nmb, d_tqc.data_ptr())
+        ctx.tqc_rec_to_planes_dev(d_jobs.data_ptr(), d_tqc.data_ptr(), nmb, halo, work_c[0].data_ptr(), work_c[1].data_ptr(), cw)
         if timed:
             marks[i][4].record(stream)
-        work_c.copy_(pre_c)
         if timed:
             marks[i][5].record(stream)
         dctx.deblock_frame_dev(work_y.data_ptr(), W, work_c[0].data_ptr(), work_c[1].data_ptr(), cw, d_mbs.data_ptr(), d_mot.data_ptr(), 1)  # K9/K10
@@ -296,6 +327,12 @@ def main():
     interior = (jobs["mb_x"] > 64) & (jobs["mb_x"] < W - 80) & (jobs["mb_y"] - halo > 64) & (jobs["mb_y"] - halo < H_SRC - 80)
     mv16 = res["best"][interior, 0]
     motion_ok = float(np.mean((np.abs(mv16["mv_x"] - 12) <= 2) & (np.abs(mv16["mv_y"] - 8) <= 2)))
+    # sanity: the filtered reconstruction at the end of the chain is a faithful picture of the source (QP 28)
+    def psnr(a, b):
+        mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+        return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    psnr_y = psnr(work_y.cpu().numpy(), frames[1])
+    psnr_u = psnr(work_c[0].cpu().numpy(), cur_u)
 
     if rank == 0:
         total_mb = nmb * N * args.steps
@@ -303,7 +340,8 @@ def main():
         alg = [W * H + 16 * (W + 64) * (HL + 40),                               # K5: one plane in, 16 padded planes out
                (256 + (2 * R + 16) ** 2 + 328) * nmb,                           # K1-K3: SURVEY.md 8d per MB-reference: 6656 in + 328 out at R=32
                7 * 256 * 19 * nmb,                                              # K4: 18 candidate blocks + the current block, 7 block types
-               (16 + 32 + 104 + 16) * nblk,                                     # MC + K7/K8: 16 B reference in; 32 B in, 104 B out per 4x4 block; 16 B picture out
+               (16 + 32 + 104 + 16) * nblk + (64 + 128 + 808 + 64) * 2 * nmb,   # MC + K7/K8: per luma 4x4 block 16 B reference, 32 B in, 104 B out, 16 B picture;
+                                                                                # per chroma plane of a macroblock 64 B reference, 128 B in, 808 B out, 64 B picture
                int(1.5 * W * H * 2) + (192 + 28 + 16 * 16) * nmb]               # K9/K10: every sample once in, once out + records
         kernels = [{"kernel": STAGES[k], "ms": round(stage_ms[k], 4), "algorithmic_bytes": alg[k], "hbm_traffic_bytes": TRAFFIC_BYTES[k],
                     "hbm_frac": round(alg[k] / (stage_ms[k] * 1e-3) / 8e12, 5)} for k in range(len(STAGES))]
@@ -331,7 +369,7 @@ def main():
                        "kernel_path_only": "MV predictors are synthetic inputs and every macroblock is reconstructed as P16x16 from its refined vector; the deblocking side information is "
                                            + ("the P picture's as JM produced it for this configuration" if args.deblock_load == "real" else "a made-up intra-heavy mix")
                                            + "; mode decision and entropy coding stay on the host",
-                       "motion_found_frac": round(motion_ok, 4)},
+                       "motion_found_frac": round(motion_ok, 4), "recon_psnr_y_db": round(psnr_y, 2), "recon_psnr_u_db": round(psnr_u, 2)},
             "roofline": roof,
             "kernels": kernels,
             "me_fullsearch": {"ms": round(fs_ms, 4), "abs_diff_per_s": round(sad_rate / 1e12, 2), "unit": "T abs-diff/s", "valu_frac": round(sad_rate / 148.4e12, 4)},

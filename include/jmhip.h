@@ -260,6 +260,8 @@ typedef struct {
 /* orig / pred: n items x 128 samples (rows of 8, uint8). */
 int jmhip_tq_chroma(jmhip_ctx *ctx, const jmhip_tqc_params *prm, jmhip_tqc_mb *mbs, const uint8_t *orig, const uint8_t *pred,
                     int32_t nitems, jmhip_tqc_out *out);
+int jmhip_tq_chroma_dev(jmhip_ctx *ctx, const jmhip_tqc_params *prm, jmhip_tqc_mb *d_mbs, const uint8_t *d_orig, const uint8_t *d_pred,
+                        int32_t nitems, jmhip_tqc_out *d_out);
 
 /* Intra16x16 luma of whole macroblocks: Macroblock.residual_transform_quant_luma_16x16 (global.h:467) = residual_transform_quant_luma_16x16
  * (lencod/src/block.c:208-349): sixteen forward4x4, the DC coefficients through hadamard4x4 -> Slice.quant_dc4x4 (quant_dc4x4_normal,
@@ -346,10 +348,16 @@ int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int
  *                     results[job].best[0], written as sixteen 4x4 blocks of 16 samples each in picture block-raster order
  *                     (block (by, bx) at index by * blocks_per_row + bx): the layout jmhip_tq_luma4x4_dev reads.  job.mb_y - y_offset
  *                     is the macroblock's row in that block array (y_offset: rows of halo above a band, else 0).
- * jmhip_tq_rec_to_plane_dev  the reconstructed samples of jmhip_tq_out records (same block order) assembled into a plane. */
+ * jmhip_tq_rec_to_plane_dev  the reconstructed samples of jmhip_tq_out records (same block order) assembled into a plane.
+ * jmhip_mc_mb16_chroma_dev   chroma_prediction_4x4 of both planes of every job's macroblock with the same vector, written as items
+ *                     2 * job + plane of 128 samples (rows of 8; 4:2:0 uses the first 64): the layout jmhip_tq_chroma_dev reads.
+ * jmhip_tqc_rec_to_planes_dev  the reconstructed samples of those items' jmhip_tqc_out records put into the U and V planes. */
 int jmhip_mc_mb16_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t njobs,
                       int32_t y_offset, int32_t blocks_per_row, uint8_t *d_pred_blocks);
 int jmhip_tq_rec_to_plane_dev(jmhip_ctx *ctx, const jmhip_tq_out *d_out, int32_t nblocks, int32_t blocks_per_row, uint8_t *d_plane, int32_t pitch_bytes);
+int jmhip_mc_mb16_chroma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t njobs, uint8_t *d_pred_items);
+int jmhip_tqc_rec_to_planes_dev(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, const jmhip_tqc_out *d_out, int32_t njobs, int32_t y_offset,
+                                uint8_t *d_u, uint8_t *d_v, int32_t pitch_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * In-loop deblocking of a whole frame

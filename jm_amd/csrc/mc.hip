@@ -200,3 +200,76 @@ extern "C" int jmhip_tq_rec_to_plane_dev(jmhip_ctx *ctx, const jmhip_tq_out *d_o
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
 }
+
+// chroma of the same macroblocks: 2 planes x (8 x RH) samples per job, one lane per sample pair row segment of four samples:
+// lane -> (plane, row, half); every sample of the macroblock uses the job's 16x16 vector (chroma_prediction_4x4's per-pair vectors coincide)
+__global__ __launch_bounds__(256) void k_mc_mb16_chroma(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ results, int n,
+                                                        const uint8_t *__restrict__ planes, int cw, int ch, int yuv, uint8_t *__restrict__ pred)
+{
+  const int RH = yuv == 2 ? 16 : 8, per = 2 * RH * 2;                        // lanes per job: plane x row x half row
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t / per, l = t - b * per;
+  if (b >= n) return;
+  const int plane = l / (RH * 2), row = (l >> 1) % RH, half = l & 1;
+  const int mb_cx = jobs[b].mb_x >> 1, mb_cy = yuv == 2 ? jobs[b].mb_y : jobs[b].mb_y >> 1;
+  const jmhip_me_best mv = results[b].best[0];
+  const int sy = yuv == 2 ? 2 : 3, my = yuv == 2 ? 3 : 7, ky = yuv == 2 ? 2 : 1;
+  const int pad_x = JMHIP_PAD_X >> 1, pad_y = yuv == 2 ? JMHIP_PAD_Y : JMHIP_PAD_Y >> 1;
+  const int max_x = cw - 1 + pad_x - 8, max_y = ch - 1 + pad_y - (yuv == 2 ? 16 : 8);
+  const uint8_t *pl = planes + (long)plane * cw * ch;
+  uint32_t w = 0;
+#pragma unroll
+  for (int hp = 0; hp < 2; hp++) {                                           // the two sample pairs of this half row
+    const int ii = ((mb_cx + 4 * half + 2 * hp) << 3) + mv.mv_x, jj = ((mb_cy + row) << sy) + mv.mv_y;
+    const int X0 = min(max(ii >> 3, -pad_x), max_x), Y = min(max(jj >> sy, -pad_y), max_y);
+    const int lx = ii & 7, k = (jj & my) * ky, m = 8 - k;
+    const int w01 = m * lx, w00 = (m << 3) - w01, w11 = k * lx, w10 = (k << 3) - w11;
+    const int y0 = min(max(Y, 0), ch - 1), y1 = min(max(Y + 1, 0), ch - 1);
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+      const int x0 = min(max(X0 + o, 0), cw - 1), x1 = min(max(X0 + o + 1, 0), cw - 1);
+      const int v = (w00 * pl[y0 * cw + x0] + w01 * pl[y0 * cw + x1] + w10 * pl[y1 * cw + x0] + w11 * pl[y1 * cw + x1] + 32) >> 6;
+      w |= (uint32_t)v << (8 * (2 * hp + o));
+    }
+  }
+  *(uint32_t *)(pred + ((long)b * 2 + plane) * 128 + row * 8 + 4 * half) = w;
+}
+
+__global__ __launch_bounds__(256) void k_tqc_rec_to_planes(const jmhip_me_job *__restrict__ jobs, const jmhip_tqc_out *__restrict__ out, int n, int yuv,
+                                                           int y_offset, uint8_t *__restrict__ u, uint8_t *__restrict__ v, int pitch)
+{
+  const int RH = yuv == 2 ? 16 : 8, per = 2 * RH * 2;
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t / per, l = t - b * per;
+  if (b >= n) return;
+  const int plane = l / (RH * 2), row = (l >> 1) % RH, half = l & 1;
+  const int cx = jobs[b].mb_x >> 1, cy = yuv == 2 ? jobs[b].mb_y - y_offset : (jobs[b].mb_y - y_offset) >> 1;
+  *(uint32_t *)((plane ? v : u) + (long)(cy + row) * pitch + cx + 4 * half) = *(const uint32_t *)(out[(long)b * 2 + plane].rec + row * 8 + 4 * half);
+}
+
+extern "C" int jmhip_mc_mb16_chroma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t n, uint8_t *d_pred)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots || (n > 0 && (!d_jobs || !d_results || !d_pred)))
+    return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_mb16_chroma_dev: bad argument");
+  if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_mc_mb16_chroma_dev: yuv_format %d", ctx->cfg.yuv_format);
+  if (!ctx->d_refc[slot]) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_mb16_chroma_dev: reference slot %d has no chroma planes", slot);
+  if (n == 0) return JMHIP_OK;
+  const int per = (ctx->cfg.yuv_format == 2 ? 16 : 8) * 4;
+  hipLaunchKernelGGL(k_mc_mb16_chroma, dim3(((long)n * per + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, d_results, n, (const uint8_t *)ctx->d_refc[slot],
+                     ctx->cw, ctx->ch, ctx->cfg.yuv_format, d_pred);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_tqc_rec_to_planes_dev(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, const jmhip_tqc_out *d_out, int32_t n, int32_t y_offset,
+                                           uint8_t *d_u, uint8_t *d_v, int32_t pitch)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || pitch < ctx->cw || (pitch & 3) || (n > 0 && (!d_jobs || !d_out || !d_u || !d_v)))
+    return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_tqc_rec_to_planes_dev: bad argument");
+  if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_tqc_rec_to_planes_dev: yuv_format %d", ctx->cfg.yuv_format);
+  if (n == 0) return JMHIP_OK;
+  const int per = (ctx->cfg.yuv_format == 2 ? 16 : 8) * 4;
+  hipLaunchKernelGGL(k_tqc_rec_to_planes, dim3(((long)n * per + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, d_out, n, ctx->cfg.yuv_format, y_offset, d_u, d_v, pitch);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}

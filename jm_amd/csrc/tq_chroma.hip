@@ -228,6 +228,19 @@ __global__ __launch_bounds__(256) void k_tq_chroma(jmhip_tqc_params prm, jmhip_t
   }
 }
 
+extern "C" int jmhip_tq_chroma_dev(jmhip_ctx *ctx, const jmhip_tqc_params *prm, jmhip_tqc_mb *d_mbs, const uint8_t *d_orig, const uint8_t *d_pred,
+                                   int32_t n, jmhip_tqc_out *d_out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!prm || n < 0 || (n > 0 && (!d_mbs || !d_orig || !d_pred || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_tq_chroma_dev: bad argument");
+  if (prm->yuv_format != 1 && prm->yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_tq_chroma_dev: yuv_format %d (4:2:0 and 4:2:2 only)", prm->yuv_format);
+  if (prm->qp_per_ac < 0 || prm->qp_per_ac > 8 || prm->qp_per_dc < 0 || prm->qp_per_dc > 9) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_tq_chroma_dev: qp_per outside range");
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_tq_chroma, dim3((n + 31) / 32), dim3(256), 0, ctx->stream, *prm, d_mbs, d_orig, d_pred, n, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_tq_chroma(jmhip_ctx *ctx, const jmhip_tqc_params *prm, jmhip_tqc_mb *mbs, const uint8_t *orig, const uint8_t *pred,
                                int32_t n, jmhip_tqc_out *out)
 {

@@ -72,7 +72,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -363,6 +363,23 @@ class JmHip:
 
     def tq_rec_to_plane_dev(self, d_out, n, blocks_per_row, d_plane, pitch):
         self._ck(self.lib.jmhip_tq_rec_to_plane_dev(self.h, _vp(d_out), n, blocks_per_row, _vp(d_plane), pitch))
+
+    def mc_mb16_chroma_dev(self, slot, d_jobs, d_results, n, d_pred):
+        self._ck(self.lib.jmhip_mc_mb16_chroma_dev(self.h, slot, _vp(d_jobs), _vp(d_results), n, _vp(d_pred)))
+
+    def tqc_rec_to_planes_dev(self, d_jobs, d_out, n, y_offset, d_u, d_v, pitch):
+        self._ck(self.lib.jmhip_tqc_rec_to_planes_dev(self.h, _vp(d_jobs), _vp(d_out), n, y_offset, _vp(d_u), _vp(d_v), pitch))
+
+    @staticmethod
+    def tqc_params(yuv, q_ac, q_dc, qp_per_ac, qp_per_dc, cavlc=1, adaptive_rounding=0, adapt_rnd_weight=0, max_pel=255):
+        p = np.zeros(1, TQC_PARAMS)
+        p["q_ac"][0] = np.asarray(q_ac, np.int32).reshape(16, 3); p["q_dc"][0] = np.asarray(q_dc, np.int32).reshape(3)
+        p["qp_per_ac"], p["qp_per_dc"], p["yuv_format"], p["cavlc"] = qp_per_ac, qp_per_dc, yuv, cavlc
+        p["adaptive_rounding"], p["adapt_rnd_weight"], p["max_pel"] = adaptive_rounding, adapt_rnd_weight, max_pel
+        return p
+
+    def tq_chroma_dev(self, prm, d_mbs, d_orig, d_pred, n, d_out):
+        self._ck(self.lib.jmhip_tq_chroma_dev(self.h, _vp(prm), _vp(d_mbs), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
 
     def distortion(self, metric, size, diff):
         """distortion4x4 / distortion8x8 {SAD 0, SSE 1, SATD 2} (lencod/src/me_distortion.c:38-146) of int16 difference blocks -> int64 << 5"""

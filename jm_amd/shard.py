@@ -81,3 +81,36 @@ def exchange_reference(own_band_rows, band, halo, pic_height, group=None, gather
         out = torch.empty((idx.numel(), width), dtype=own_band_rows.dtype, device=own_band_rows.device)
     torch.index_select(tall, 0, idx, out=out)
     return out
+
+
+def packed_band(luma_rows, u_rows, v_rows):
+    """One band's reconstruction as ONE (rows + rows/2, W) uint8 tensor for the exchange: the luma rows, then the 4:2:0 chroma rows with
+    U in the left half and V in the right half of each row (16 * rows_per_band luma rows -> 8 * rows_per_band chroma rows)."""
+    return torch.cat([luma_rows, torch.cat([u_rows, v_rows], dim=1)], dim=0)
+
+
+class YuvExchange:
+    """The one collective of the path for 4:2:0 pictures: all-gather of the packed bands (luma + chroma: 1.5 bytes per sample position),
+    then one gather kernel per plane kind cutting out this rank's local reference: luma rows [y0 - halo, y0 + height + halo) and chroma
+    rows [(y0 - halo) / 2, (y0 + height + halo) / 2), clamped into the picture.  Buffers and index tensors are built once."""
+
+    def __init__(self, band, halo, pic_height, width, world, device):
+        self.band, self.world, self.width = band, world, width
+        self.rows = 16 * band.rows_per_band                  # luma rows per (padded) band
+        self.per_rank = self.rows + self.rows // 2           # rows of one packed band
+        y = reference_rows(band, halo, pic_height)           # picture rows of the local luma reference
+        c = torch.arange((band.y0 - halo) // 2, (band.y0 + band.height + halo) // 2).clamp_(0, pic_height // 2 - 1)
+        # picture row -> (rank that owns it, row inside that rank's packed band); every band but the last is full
+        self.idx_y = ((y // self.rows) * self.per_rank + y % self.rows).to(device)
+        self.idx_c = ((c // (self.rows // 2)) * self.per_rank + self.rows + c % (self.rows // 2)).to(device)
+        self.gathered = torch.empty((world * self.per_rank, width), dtype=torch.uint8, device=device)
+        self.out_y = torch.empty((len(y), width), dtype=torch.uint8, device=device)
+        self.out_c = torch.empty((len(c), width), dtype=torch.uint8, device=device)
+
+    def __call__(self, packed, group=None):
+        """packed: packed_band(...) of this rank, (per_rank, W); returns (local luma reference, local U, local V)"""
+        assert packed.shape == (self.per_rank, self.width), (packed.shape, self.per_rank, self.width)
+        dist.all_gather_into_tensor(self.gathered.view(-1), packed.contiguous().view(-1), group=group)
+        torch.index_select(self.gathered, 0, self.idx_y, out=self.out_y)
+        torch.index_select(self.gathered, 0, self.idx_c, out=self.out_c)
+        return self.out_y, self.out_c[:, : self.width // 2], self.out_c[:, self.width // 2:]

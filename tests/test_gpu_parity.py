@@ -901,3 +901,61 @@ def test_mc_mb16_and_rec_to_plane_vs_oracle(J):
     want = out["rec"].reshape(h // 4, w // 4, 4, 4).transpose(0, 2, 1, 3).reshape(h, w)
     assert np.array_equal(d_plane.cpu().numpy(), want)
     ctx.close()
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_mc_mb16_chroma_and_planes_vs_oracle(J, fmt):
+    """jmhip_mc_mb16_chroma_dev == chroma_prediction_4x4 of every 4x4 block of both planes with the macroblock's vector, in the item
+    layout jmhip_tq_chroma_dev reads; jmhip_tqc_rec_to_planes_dev puts that kernel's reconstructions into the planes"""
+    import torch
+    from jm_amd.lib import ME_JOB, ME_RESULT, TQC_MB, TQC_OUT
+    w, h = 96, 64
+    ch = h if fmt == 2 else h // 2
+    RH = 16 if fmt == 2 else 8
+    rng = np.random.default_rng(9 + fmt)
+    ref = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    cu = rng.integers(0, 256, (2, ch, w // 2)).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    ctx = make_ctx(w, h, fmt=fmt)
+    ctx.set_reference(0, ref); ctx.set_reference_chroma(0, cu[0], cu[1])
+    nmb = (w // 16) * (h // 16)
+    jobs = np.zeros(nmb, ME_JOB)
+    jobs["mb_x"] = np.tile(np.arange(w // 16) * 16, h // 16); jobs["mb_y"] = np.repeat(np.arange(h // 16) * 16, w // 16)
+    res = np.zeros(nmb, ME_RESULT)
+    res["best"]["mv_x"][:, 0] = rng.integers(-200, 201, nmb); res["best"]["mv_y"][:, 0] = rng.integers(-200, 201, nmb)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(nmb, -1)).to(dev)
+    d_res = torch.from_numpy(res.view(np.uint8).reshape(nmb, -1)).to(dev)
+    d_pred = torch.zeros((nmb * 2, 128), dtype=torch.uint8, device=dev)
+    ctx.mc_mb16_chroma_dev(0, d_jobs.data_ptr(), d_res.data_ptr(), nmb, d_pred.data_ptr())
+    ctx.synchronize()
+    pred = d_pred.cpu().numpy().reshape(nmb, 2, 16, 8)
+    for k in range(nmb):
+        cx, cy = int(jobs["mb_x"][k]) // 2, int(jobs["mb_y"][k]) // (1 if fmt == 2 else 2)
+        mv = np.tile(np.array([res["best"]["mv_x"][k, 0], res["best"]["mv_y"][k, 0]]), (4, 2, 1))
+        for plane in range(2):
+            for by in range(0, RH, 4):
+                for bx in (0, 4):
+                    want = J.chroma_pred4x4(cu[plane], None, fmt, 0, cx + bx, cy + by, mv, mv)
+                    assert np.array_equal(pred[k, plane, by:by + 4, bx:bx + 4], want), (k, plane, by, bx)
+    # chroma transform/quant on the device-resident items, reconstructions into the planes
+    orig = rng.integers(0, 256, (nmb * 2, 128)).astype(np.uint8)
+    q = J.qparams_4x4(27, 0, 342)
+    prm = ctx.tqc_params(fmt, q, q[0] if fmt == 1 else J.qparams_4x4(30, 0, 342)[0], 27 // 6, (27 // 6) if fmt == 1 else 30 // 6)
+    mbs = np.zeros(nmb * 2, TQC_MB); mbs["uv"] = np.arange(nmb * 2) % 2
+    d_mbs = torch.from_numpy(mbs.view(np.uint8).reshape(nmb * 2, -1)).to(dev)
+    d_orig = torch.from_numpy(orig).to(dev)
+    d_out = torch.zeros((nmb * 2, TQC_OUT.itemsize), dtype=torch.uint8, device=dev)
+    ctx.tq_chroma_dev(prm, d_mbs.data_ptr(), d_orig.data_ptr(), d_pred.data_ptr(), nmb * 2, d_out.data_ptr())
+    d_u = torch.zeros((ch, w // 2), dtype=torch.uint8, device=dev); d_v = torch.zeros_like(d_u)
+    ctx.tqc_rec_to_planes_dev(d_jobs.data_ptr(), d_out.data_ptr(), nmb, 0, d_u.data_ptr(), d_v.data_ptr(), w // 2)
+    ctx.synchronize()
+    # the same items through the host entry point (already pinned to the reference by the golden records)
+    _, want = ctx.tq_chroma(fmt, q, prm["q_dc"][0], int(prm["qp_per_ac"][0]), int(prm["qp_per_dc"][0]), 1, 0, 0, mbs, orig, d_pred.cpu().numpy())
+    out = d_out.cpu().numpy().view(TQC_OUT).reshape(nmb * 2)
+    assert np.array_equal(out["rec"], want["rec"]) and np.array_equal(out["ac_level"], want["ac_level"]) and np.array_equal(out["dc_level"], want["dc_level"])
+    planes = [d_u.cpu().numpy(), d_v.cpu().numpy()]
+    for k in range(nmb):
+        cx, cy = int(jobs["mb_x"][k]) // 2, int(jobs["mb_y"][k]) // (1 if fmt == 2 else 2)
+        for plane in range(2):
+            assert np.array_equal(planes[plane][cy:cy + RH, cx:cx + 8], out["rec"][2 * k + plane].reshape(16, 8)[:RH]), (k, plane)
+    ctx.close()

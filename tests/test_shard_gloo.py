@@ -74,6 +74,46 @@ def test_band_exchange_gloo(world, h_mbs):
     assert [r[3] for r in res] == [min(i * -(-h_mbs // world), h_mbs) for i in range(world)]
 
 
+def _worker_yuv(rank, world, port, h_mbs, w, halo, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H = 16 * h_mbs
+        rng = np.random.default_rng(23)
+        Y, U, V = rng.integers(0, 256, (H, w)).astype(np.uint8), rng.integers(0, 256, (H // 2, w // 2)).astype(np.uint8), rng.integers(0, 256, (H // 2, w // 2)).astype(np.uint8)
+        band = shard.band_of(rank, world, h_mbs)
+        rows = 16 * band.rows_per_band
+        oy, ou, ov = np.zeros((rows, w), np.uint8), np.zeros((rows // 2, w // 2), np.uint8), np.zeros((rows // 2, w // 2), np.uint8)
+        oy[:band.height] = Y[band.y0:band.y0 + band.height]
+        ou[:band.height // 2] = U[band.y0 // 2:(band.y0 + band.height) // 2]; ov[:band.height // 2] = V[band.y0 // 2:(band.y0 + band.height) // 2]
+        ex = shard.YuvExchange(band, halo, H, w, world, "cpu")
+        ok = True
+        for rep in range(2):
+            ly, lu, lv = ex(shard.packed_band(torch.from_numpy(oy), torch.from_numpy(ou), torch.from_numpy(ov)))
+            wy = Y[np.clip(np.arange(band.y0 - halo, band.y0 + band.height + halo), 0, H - 1)]
+            cr = np.clip(np.arange((band.y0 - halo) // 2, (band.y0 + band.height + halo) // 2), 0, H // 2 - 1)
+            ok &= bool((ly.numpy() == wy).all()) and bool((lu.numpy() == U[cr]).all()) and bool((lv.numpy() == V[cr]).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h_mbs", [(2, 8), (3, 8), (2, 5)])
+def test_packed_yuv_exchange_gloo(world, h_mbs):
+    """luma and 4:2:0 chroma of the reconstructed bands in ONE all-gather; every rank ends up with its band + halo of all three planes"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_yuv, args=(r, world, port, h_mbs, 64, 32, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
 def test_slice_argument_matches_jm_config():
     # configs[3]: 2160p = 240 x 135 macroblocks, 8 slices -> SliceArgument 4080 (17 rows each, the last band 16)
     assert shard.slice_argument(135, 240, 8) == 4080
