@@ -92,7 +92,11 @@ __device__ int hadamard8_lds(const uint32_t *s_cur, int by, int bx4, const uint8
   return (s + 2) >> 2;
 }
 
-__device__ __constant__ int8_t c_sp9b[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};   // mv_search.c:405-442, R = 1
+// the nine positions of JM's spiral with R = 1 (mv_search.c:405-442): {0,0} {0,-1} {0,1} {-1,-1} {1,-1} {-1,0} {1,0} {-1,1} {1,1}, two bits per
+// coordinate (value + 1) in a constant: the candidate index differs per lane, and a table look-up would be a global load on the path
+// from the motion vector to the reference address
+__device__ __forceinline__ int sp9_dx(int c) { return (int)((0x22215u >> (2 * c)) & 3u) - 1; }
+__device__ __forceinline__ int sp9_dy(int c) { return (int)((0x29421u >> (2 * c)) & 3u) - 1; }
 __device__ __constant__ uint8_t c_geom[JMHIP_NPART][4] = {           // x, y, w, h of the 41 partitions (ABI order, jmhip.h)
   {0,0,16,16}, {0,0,16,8},{0,8,16,8}, {0,0,8,16},{8,0,8,16}, {0,0,8,8},{8,0,8,8},{0,8,8,8},{8,8,8,8},
   {0,0,8,4},{8,0,8,4},{0,4,8,4},{8,4,8,4},{0,8,8,4},{8,8,8,4},{0,12,8,4},{8,12,8,4},
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__rest
         const int t = item / 144, rem = item - t * 144, cand = rem >> 4, b4 = rem & 15;
         const int bx4 = b4 & 3, by4 = b4 >> 2, p = part_of(t, bx4, by4);
         if (((mask >> p) & 1) && cand >= start) {
-          const int cx = s_mv[p][0] + c_sp9b[cand][0] * step, cy = s_mv[p][1] + c_sp9b[cand][1] * step;
+          const int cx = s_mv[p][0] + sp9_dx(cand) * step, cy = s_mv[p][1] + sp9_dy(cand) * step;
           const bool t8 = T8MODE && p <= 8 && metric != JMHIP_METRIC_SAD;                          // mv_search.c:1630 / :1770
           const uint8_t *r;
           if (metric == JMHIP_METRIC_SAD) {
@@ -194,12 +198,12 @@ __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__rest
         int cost;
         if (l < start) cost = l == 0 ? carried : COST_MAX;                      // position 0 keeps the carried-in cost
         else {
-          const int cx = mvx + c_sp9b[l][0] * step, cy = mvy + c_sp9b[l][1] * step;
+          const int cx = mvx + sp9_dx(l) * step, cy = mvy + sp9_dy(l) * step;
           cost = lambda * (mvbits2(cx - pred_x) + mvbits2(cy - pred_y)) + (int)(s_dist[p * 9 + l] << 5);
         }
         if (cost < min_mcost) { min_mcost = cost; best = l; }
       }
-      s_mv[p][0] = mvx + c_sp9b[best][0] * step; s_mv[p][1] = mvy + c_sp9b[best][1] * step;
+      s_mv[p][0] = mvx + sp9_dx(best) * step; s_mv[p][1] = mvy + sp9_dy(best) * step;
       s_min[p] = min_mcost;
     }
     __syncthreads();

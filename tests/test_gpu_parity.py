@@ -959,3 +959,27 @@ def test_mc_mb16_chroma_and_planes_vs_oracle(J, fmt):
         for plane in range(2):
             assert np.array_equal(planes[plane][cy:cy + RH, cx:cx + 8], out["rec"][2 * k + plane].reshape(16, 8)[:RH]), (k, plane)
     ctx.close()
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """the widened entry points fail with a message instead of launching on nonsense"""
+    from jm_amd.lib import JmHipError, TQ16_OUT
+    ctx = make_ctx(64, 48, fmt=1)
+    q = np.zeros((16, 3), np.int32)
+    with pytest.raises(JmHipError):
+        ctx.tq_luma16x16(ctx.tq_params(q, 9), np.zeros((1, 256), np.uint8), np.zeros((1, 256), np.uint8))      # qp_per outside 0..8
+    with pytest.raises(JmHipError):
+        ctx.distortion(2, 5, np.zeros((1, 25), np.int16))                                                     # block size 5
+    with pytest.raises(JmHipError):
+        ctx.distortion(3, 4, np.zeros((1, 16), np.int16))                                                     # unknown metric
+    with pytest.raises(JmHipError):
+        ctx.mc_mb16_dev(3, 1, 1, 1, 0, 16, 1)                                                                 # slot outside the context
+    with pytest.raises(JmHipError):
+        ctx.mc_mb16_chroma_dev(0, 1, 1, 1, 1)                                                                 # no chroma planes in the slot yet
+    with pytest.raises(JmHipError):
+        ctx.tq_rec_to_plane_dev(1, 4, 16, 1, 30)                                                              # pitch smaller than the row
+    ctx.close()
+    mono = make_ctx(64, 48, fmt=0)
+    with pytest.raises(JmHipError):
+        mono.set_reference_chroma(0, np.zeros((24, 32), np.uint16), np.zeros((24, 32), np.uint16))            # 4:0:0 has no chroma
+    mono.close()
