@@ -173,6 +173,13 @@ int jmo_rtq_luma_4x4(const jmo_pel orig[16], const jmo_pel pred[16], int qp, int
 /* ---- sub-pel plane generation: getSubImagesLuma lencod/src/img_luma.c:611-679 ----
  * src: W x H luma (pitch src_pitch).  dst: 16 planes, plane (j,i) at dst + (j*4+i)*plane_stride,
  * each (H+2*PAD_Y) rows x pitch samples, picture origin at row PAD_Y, col PAD_X. */
+/* ---- luma intra prediction and the Intra16x16 mode search (lencod/src/intra4x4.c, intra16x16.c; see jmo_intra.c) ---- */
+void jmo_intrapred_4x4(const jmo_pel e[13], int mode, int left_available, int up_available, jmo_pel out[16]);
+void jmo_intrapred_16x16(const jmo_pel e[33], int mode, int left_available, int up_available, int max_pel, jmo_pel out[256]);
+jmo_dist jmo_dist_i16x16(const jmo_pel orig[256], const jmo_pel pred[256], int metric);
+jmo_dist jmo_intra16_search(const jmo_pel e[33], int left_available, int up_available, int mode_mask, int metric, int max_pel,
+                            const jmo_pel orig[256], jmo_pel pred4[4][256], int *best_mode);
+
 /* ---- motion-compensated prediction, un-weighted (lencod/src/mc_prediction.c; see jmo_mc.c) ---- */
 void jmo_luma_pred(const jmo_refpic *r0, const jmo_refpic *r1, int p_dir, int x, int y, int bsx, int bsy, jmo_mv mv0, jmo_mv mv1, jmo_pel *out);
 void jmo_chroma_pred4x4(const jmo_pel *p0, const jmo_pel *p1, int pitch, int W, int H, int yuv, int p_dir, int xc, int yc,

@@ -1,0 +1,138 @@
+/* jmo_intra.c -- TEST INFRASTRUCTURE (oracle): plain-C restatement of JM 19.0's luma intra prediction and of its Intra16x16 mode search.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ *   get_intrapred_4x4      lencod/src/intra4x4.c:521-561 (nine modes :72-308) over the predictor samples set_intrapred_4x4 :421-519 gathers:
+ *                          e[0] = X (above left), e[1..8] = A..H (above, above right), e[9..12] = I..L (left)
+ *   get_intrapred_16x16    lencod/src/intra16x16.c:307-328 (four modes :28-146): e[0] = above left, e[1..16] above, e[17..32] left
+ *   find_sad_16x16_JM      :463-517 with distI16x16_sad / _sse / _satd :331-452
+ * Written from the prediction formulas of H.264 8.3.1.2 / 8.3.3 (which JM's per-sample assignments implement); pinned by the records of
+ * the real encoder's calls in tests/golden/qcif_intra.npz. */
+#include "jmo.h"
+
+static int top4(const jmo_pel *e, int x) { return x < 0 ? e[0] : e[1 + x]; }       /* p[x, -1], x = -1 .. 7 */
+static int left4(const jmo_pel *e, int y) { return y < 0 ? e[0] : e[9 + y]; }      /* p[-1, y], y = -1 .. 3 */
+
+void jmo_intrapred_4x4(const jmo_pel e[13], int mode, int left_available, int up_available, jmo_pel out[16])
+{
+  int x, y;
+  for (y = 0; y < 4; y++)
+    for (x = 0; x < 4; x++) {
+      int v = 0;
+      switch (mode) {
+      case 0: v = top4(e, x); break;                                                /* vertical */
+      case 1: v = left4(e, y); break;                                               /* horizontal */
+      case 2:                                                                       /* DC */
+        if (up_available && left_available) v = (e[1] + e[2] + e[3] + e[4] + e[9] + e[10] + e[11] + e[12] + 4) >> 3;
+        else if (left_available) v = (e[9] + e[10] + e[11] + e[12] + 2) >> 2;
+        else if (up_available) v = (e[1] + e[2] + e[3] + e[4] + 2) >> 2;
+        else v = e[1];                                                              /* already the DC value (set_intrapred_4x4) */
+        break;
+      case 3:                                                                       /* diagonal down left */
+        v = (x == 3 && y == 3) ? (top4(e, 6) + 3 * top4(e, 7) + 2) >> 2 : (top4(e, x + y) + 2 * top4(e, x + y + 1) + top4(e, x + y + 2) + 2) >> 2;
+        break;
+      case 4:                                                                       /* diagonal down right */
+        if (x > y) v = (top4(e, x - y - 2) + 2 * top4(e, x - y - 1) + top4(e, x - y) + 2) >> 2;
+        else if (x < y) v = (left4(e, y - x - 2) + 2 * left4(e, y - x - 1) + left4(e, y - x) + 2) >> 2;
+        else v = (top4(e, 0) + 2 * e[0] + left4(e, 0) + 2) >> 2;
+        break;
+      case 5: {                                                                     /* vertical right */
+        const int z = 2 * x - y, k = x - (y >> 1);
+        if (z >= 0 && !(z & 1)) v = (top4(e, k - 1) + top4(e, k) + 1) >> 1;
+        else if (z > 0) v = (top4(e, k - 2) + 2 * top4(e, k - 1) + top4(e, k) + 2) >> 2;
+        else if (z == -1) v = (left4(e, 0) + 2 * e[0] + top4(e, 0) + 2) >> 2;
+        else v = (left4(e, y - 1) + 2 * left4(e, y - 2) + left4(e, y - 3) + 2) >> 2;
+        break; }
+      case 6: {                                                                     /* horizontal down */
+        const int z = 2 * y - x, k = y - (x >> 1);
+        if (z >= 0 && !(z & 1)) v = (left4(e, k - 1) + left4(e, k) + 1) >> 1;
+        else if (z > 0) v = (left4(e, k - 2) + 2 * left4(e, k - 1) + left4(e, k) + 2) >> 2;
+        else if (z == -1) v = (left4(e, 0) + 2 * e[0] + top4(e, 0) + 2) >> 2;
+        else v = (top4(e, x - 1) + 2 * top4(e, x - 2) + top4(e, x - 3) + 2) >> 2;
+        break; }
+      case 7: {                                                                     /* vertical left */
+        const int k = x + (y >> 1);
+        v = (y & 1) ? (top4(e, k) + 2 * top4(e, k + 1) + top4(e, k + 2) + 2) >> 2 : (top4(e, k) + top4(e, k + 1) + 1) >> 1;
+        break; }
+      default: {                                                                    /* 8: horizontal up */
+        const int z = x + 2 * y, k = y + (x >> 1);
+        if (z > 5) v = left4(e, 3);
+        else if (z == 5) v = (left4(e, 2) + 3 * left4(e, 3) + 2) >> 2;
+        else if (z & 1) v = (left4(e, k) + 2 * left4(e, k + 1) + left4(e, k + 2) + 2) >> 2;
+        else v = (left4(e, k) + left4(e, k + 1) + 1) >> 1;
+        break; }
+      }
+      out[4 * y + x] = (jmo_pel)v;
+    }
+}
+
+void jmo_intrapred_16x16(const jmo_pel e[33], int mode, int left_available, int up_available, int max_pel, jmo_pel out[256])
+{
+  int x, y, dc = 0, a = 0, b = 0, c = 0;
+  if (mode == 2) {
+    int s1 = 0, s2 = 0;
+    for (x = 0; x < 16; x++) { s1 += e[1 + x]; s2 += e[17 + x]; }
+    if (up_available && left_available) dc = (s1 + s2 + 16) >> 5;
+    else if (up_available) dc = (s1 + 8) >> 4;
+    else if (left_available) dc = (s2 + 8) >> 4;
+    else dc = e[1];
+  } else if (mode == 3) {
+    int H = 0, V = 0;
+    for (x = 0; x < 8; x++) {                                                       /* p[-1, -1] stands in for index -1 */
+      H += (x + 1) * (e[1 + 8 + x] - (x == 7 ? e[0] : e[1 + 6 - x]));
+      V += (x + 1) * (e[17 + 8 + x] - (x == 7 ? e[0] : e[17 + 6 - x]));
+    }
+    b = (5 * H + 32) >> 6; c = (5 * V + 32) >> 6; a = 16 * (e[16] + e[32]);
+  }
+  for (y = 0; y < 16; y++)
+    for (x = 0; x < 16; x++) {
+      int v;
+      if (mode == 0) v = e[1 + x];
+      else if (mode == 1) v = e[17 + y];
+      else if (mode == 2) v = dc;
+      else { v = (a + b * (x - 7) + c * (y - 7) + 16) >> 5; v = v < 0 ? 0 : (v > max_pel ? max_pel : v); }
+      out[16 * y + x] = (jmo_pel)v;
+    }
+}
+
+/* Slice.distI16x16 of a 16x16 prediction: metric 0 SAD, 1 SSE, 2 (and anything else) SATD; the value JM reaches without early exit, << 5 */
+jmo_dist jmo_dist_i16x16(const jmo_pel orig[256], const jmo_pel pred[256], int metric)
+{
+  int64_t cost = 0;
+  int j, i, jj, ii;
+  if (metric == 0 || metric == 1) {
+    for (j = 0; j < 256; j++) { const int d = (int)orig[j] - (int)pred[j]; cost += metric == 0 ? (d < 0 ? -d : d) : d * d; }
+    return cost << 5;
+  }
+  {
+    int dc[16], hd[16];
+    for (jj = 0; jj < 4; jj++)
+      for (ii = 0; ii < 4; ii++) {
+        int in[16], out[16];
+        for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) in[4*j+i] = (int)orig[(4*jj+j)*16 + 4*ii+i] - (int)pred[(4*jj+j)*16 + 4*ii+i];
+        jmo_hadamard4x4(in, out);                                                   /* JM's hadamard4x4: second pass >> 1 */
+        for (j = 1; j < 16; j++) cost += out[j] < 0 ? -out[j] : out[j];
+        dc[jj * 4 + ii] = out[0] >> 1;
+      }
+    jmo_hadamard4x4(dc, hd);
+    for (j = 0; j < 16; j++) cost += hd[j] < 0 ? -hd[j] : hd[j];
+  }
+  return cost << 5;
+}
+
+/* find_sad_16x16_JM: modes of mode_mask in ascending order, strict '<' against the running best (DISTBLK_MAX first); pred4 receives the
+ * predictions of the evaluated modes.  Returns the best cost, *best_mode as JM leaves currMB->i16mode (DC when nothing was evaluated). */
+jmo_dist jmo_intra16_search(const jmo_pel e[33], int left_available, int up_available, int mode_mask, int metric, int max_pel,
+                            const jmo_pel orig[256], jmo_pel pred4[4][256], int *best_mode)
+{
+  jmo_dist best = JMO_DIST_MAX;
+  int k;
+  *best_mode = 2;
+  for (k = 0; k < 4; k++)
+    if ((mode_mask >> k) & 1) {
+      jmo_dist c;
+      jmo_intrapred_16x16(e, k, left_available, up_available, max_pel, pred4[k]);
+      c = jmo_dist_i16x16(orig, pred4[k], metric);
+      if (c < best) { best = c; *best_mode = k; }
+    }
+  return best;
+}

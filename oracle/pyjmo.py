@@ -329,3 +329,28 @@ def hadamard_sad(diff):
     """HadamardSAD4x4 / HadamardSAD8x8 (me_distortion.c:175 / :266) of one int16 difference block (16 or 64 values)"""
     d = np.ascontiguousarray(diff, np.int16).reshape(-1)
     return int(L.jmo_hadamard_sad4x4(_p(d)) if d.size == 16 else L.jmo_hadamard_sad8x8(_p(d)))
+
+
+# ---- intra prediction (jmo_intra.c)
+L.jmo_intra16_search.restype = C.c_int64
+L.jmo_dist_i16x16.restype = C.c_int64
+
+
+def intrapred_4x4(edge, mode, left, up):
+    e = np.ascontiguousarray(edge, np.uint16).reshape(13); out = np.zeros(16, np.uint16)
+    L.jmo_intrapred_4x4(_p(e), int(mode), int(left), int(up), _p(out))
+    return out.reshape(4, 4).astype(np.uint8)
+
+
+def intrapred_16x16(edge, mode, left, up, max_pel=255):
+    e = np.ascontiguousarray(edge, np.uint16).reshape(33); out = np.zeros(256, np.uint16)
+    L.jmo_intrapred_16x16(_p(e), int(mode), int(left), int(up), int(max_pel), _p(out))
+    return out.reshape(16, 16).astype(np.uint8)
+
+
+def intra16_search(edge, left, up, mode_mask, metric, orig, max_pel=255):
+    """find_sad_16x16_JM: returns (best cost, best mode, predictions (4, 16, 16) of the evaluated modes)"""
+    e = np.ascontiguousarray(edge, np.uint16).reshape(33); o = np.ascontiguousarray(orig, np.uint16).reshape(256)
+    pred = np.zeros((4, 256), np.uint16); best = C.c_int(0)
+    c = L.jmo_intra16_search(_p(e), int(left), int(up), int(mode_mask), int(metric), int(max_pel), _p(o), _p(pred), C.byref(best))
+    return int(c), best.value, pred.reshape(4, 16, 16).astype(np.uint8)

@@ -274,6 +274,56 @@ void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int b
   }
 }
 
+/* ------------------------------------------------------------------ intra prediction
+ *   get_intrapred_4x4     lencod/src/intra4x4.c:521     (predictor samples currMB->intra4x4_pred[pl][0..12]: X, A..H, I..L)
+ *   get_intrapred_16x16   lencod/src/intra16x16.c:307   (currMB->intra16x16_pred[pl][0..32]: corner, 16 above, 16 left)
+ * record: mode left up max_pel | predictor samples | the prediction left in mpr_4x4[pl][mode] / mpr_16x16[pl][mode] */
+extern void __real_get_intrapred_4x4(Macroblock *, ColorPlane, int, int, int, int, int);
+void __wrap_get_intrapred_4x4(Macroblock *currMB, ColorPlane pl, int mode, int img_x, int img_y, int left, int up)
+{
+  static int n = 0, calls = 0;
+  __real_get_intrapred_4x4(currMB, pl, mode, img_x, img_y, left, up);
+  if (pl == PLANE_Y && calls++ % 23 == 0 && n < tap_max() / 4) {
+    int j, i;
+    FILE *f = tap_open("intra4x4.bin");
+    put_i32(f, mode); put_i32(f, left); put_i32(f, up); put_i32(f, currMB->p_Vid->max_imgpel_value);
+    for (i = 0; i < 13; i++) put_i32(f, currMB->intra4x4_pred[pl][i]);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, currMB->p_Slice->mpr_4x4[pl][mode][j][i]);
+    fclose(f); n++;
+  }
+}
+/* find_sad_16x16_JM (lencod/src/intra16x16.c:463, Slice.find_sad_16x16): the Intra16x16 mode search -- predictor samples, the four
+ * predictions (get_intrapred_16x16 is called from inside the same translation unit, so the search is tapped as a whole), the mode cost
+ * Slice.distI16x16 and the strict-'<' choice.
+ * record: left up upleft mode_mask metric max_pel | predictor samples[33] | source 16x16 | ret(lo,hi) i16mode | 4 x prediction 16x16 */
+extern distblk __real_find_sad_16x16_JM(Macroblock *);
+distblk __wrap_find_sad_16x16_JM(Macroblock *currMB)
+{
+  static int n = 0, calls = 0;
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  InputParameters *p_Inp = currMB->p_Inp;
+  distblk r = __real_find_sad_16x16_JM(currMB);
+  if (!currSlice->P444_joined && calls++ % 3 == 0 && n < tap_max() / 16) {
+    int left, up, all, k, j, i, mask = 0;
+    FILE *f = tap_open("intra16_search.bin");
+    currSlice->set_intrapred_16x16(currMB, PLANE_Y, &left, &up, &all);            /* a pure function of the picture: the flags the search used */
+    for (k = 0; k < 4; k++) {                                                     /* the modes the search evaluated (intra16x16.c:483-494) */
+      int off = 0;
+      if (p_Inp->IntraDisableInterOnly == 0 || (currSlice->slice_type != I_SLICE && currSlice->slice_type != SI_SLICE))
+        off = (p_Inp->Intra16x16ParDisable && (k == VERT_PRED_16 || k == HOR_PRED_16)) || (p_Inp->Intra16x16PlaneDisable && k == PLANE_16);
+      if (!off && !((k == VERT_PRED_16 && !up) || (k == HOR_PRED_16 && !left) || (k == PLANE_16 && (!left || !up || !all)))) mask |= 1 << k;
+    }
+    put_i32(f, left); put_i32(f, up); put_i32(f, all); put_i32(f, mask); put_i32(f, p_Inp->ModeDecisionMetric); put_i32(f, p_Vid->max_imgpel_value);
+    for (i = 0; i < 33; i++) put_i32(f, currMB->intra16x16_pred[0][i]);
+    for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) put_i32(f, p_Vid->pCurImg[currMB->opix_y + j][currMB->pix_x + i]);
+    put_i32(f, (int)(r & 0xffffffff)); put_i32(f, (int)(r >> 32)); put_i32(f, currMB->i16mode);
+    for (k = 0; k < 4; k++) for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) put_i32(f, (mask >> k) & 1 ? currSlice->mpr_16x16[0][k][j][i] : 0);
+    fclose(f); n++;
+  }
+  return r;
+}
+
 /* ------------------------------------------------------------------ deblocking */
 extern void __real_DeblockFrame(VideoParameters *, imgpel **, imgpel ***);
 void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)

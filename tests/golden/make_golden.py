@@ -13,6 +13,7 @@ stores what the reference's hot-path functions were given and what they returned
   tests/golden/qcif_422.npz   High 4:2:2, 8x8 transform, CABAC: deblock in/out (intra + inter)
   tests/golden/qcif_main.npz  Main profile with a B frame: deblock in/out (two-list strengths)
   tests/golden/qcif_mc.npz    luma_prediction / chroma_prediction_4x4 records (4:2:0 P, 4:2:2 P, B picture) + the reference planes they read
+  tests/golden/qcif_intra.npz get_intrapred_4x4 records and find_sad_16x16_JM (Intra16x16 mode search) records of the same three runs
   tests/golden/md5.json       .264 / recon md5 of the BASELINE.json configurations at QCIF
 
 Fixtures are data only (inputs and expected outputs); no reference source is stored.
@@ -147,6 +148,22 @@ def mc_arrays(tag, workdir, d, n_luma=260, n_chroma=420):
         d[f"{tag}_ref{k}_u"], d[f"{tag}_ref{k}_v"] = rc[k]
 
 
+def intra_arrays(tag, workdir, d, n4=450, n16=40):
+    """get_intrapred_4x4 records (mode left up max_pel | 13 predictor samples | 16 predicted) and find_sad_16x16_JM records
+    (left up upleft mode_mask metric max_pel | 33 predictor samples | source 16x16 | cost lo hi, i16mode | 4 predictions) of one tapped run"""
+    a = read_i32_records(os.path.join(workdir, "intra4x4.bin"), 33)
+    a = np.unique(a, axis=0)
+    d[tag + "_i4"] = a[:: max(1, -(-len(a) // n4))].astype(np.int16)          # sorted by mode: an even stride keeps all nine
+    b = read_i32_records(os.path.join(workdir, "intra16_search.bin"), 6 + 33 + 256 + 3 + 1024)
+    b = b[:: max(1, -(-len(b) // n16))]
+    d[tag + "_i16_hdr"] = b[:, :6].astype(np.int16)
+    d[tag + "_i16_edge"] = b[:, 6:39].astype(np.uint8)
+    d[tag + "_i16_orig"] = b[:, 39:295].astype(np.uint8)
+    d[tag + "_i16_cost"] = (b[:, 295].astype(np.int64) & 0xffffffff) | (b[:, 296].astype(np.int64) << 32)
+    d[tag + "_i16_mode"] = b[:, 297].astype(np.int16)
+    d[tag + "_i16_pred"] = b[:, 298:].reshape(-1, 4, 256).astype(np.uint8)
+
+
 def read_deblock(path):
     r, out = Reader(path), []
     while not r.eof():
@@ -255,6 +272,11 @@ def main():
         d = {}
         mc_arrays("a", wa, d); mc_arrays("c", wc, d); mc_arrays("e", we, d)
         np.savez_compressed(os.path.join(OUT, "qcif_mc.npz"), **d)
+
+        # ---- luma intra prediction (get_intrapred_4x4) and the Intra16x16 mode search (find_sad_16x16_JM) of the same runs
+        d = {}
+        intra_arrays("a", wa, d); intra_arrays("c", wc, d); intra_arrays("e", we, d)
+        np.savez_compressed(os.path.join(OUT, "qcif_intra.npz"), **d)
 
         # ---- D: 8x8 transform / quantisation and the DC transforms (High 4:2:2 CABAC + adaptive rounding; the same with CAVLC
         #         and plain rounding; High 4:2:0 CAVLC for the 2x2 chroma DC transform)

@@ -381,3 +381,28 @@ def test_oracle_rtq_luma_16x16_matches_the_reference(tq8):
         assert np.array_equal(rec, d["rec"]), k
         if d["around"]:
             assert np.array_equal(fadj[I16_AC_MASK], d["fadjust"][I16_AC_MASK]), k
+
+
+# ---------------------------------------------------------------- luma intra prediction, Intra16x16 mode search (tests/golden/qcif_intra.npz)
+def intra_golden():
+    return np.load(os.path.join(G, "qcif_intra.npz"))
+
+
+@pytest.mark.parametrize("tag", ["a", "c", "e"])
+def test_oracle_intra_prediction_matches_the_reference(tag):
+    """jmo_intrapred_4x4 == get_intrapred_4x4 (intra4x4.c:521, all nine modes, every availability case) and jmo_intra16_search ==
+    find_sad_16x16_JM (intra16x16.c:463: the four predictions, the SATD mode cost, the chosen mode) on the real encoder's calls"""
+    g = intra_golden()
+    i4 = g[tag + "_i4"]
+    assert len(i4) > 300 and set(np.unique(i4[:, 0])) == set(range(9))
+    for r in i4:
+        assert np.array_equal(J.intrapred_4x4(r[4:17], r[0], r[1], r[2]).reshape(-1), r[17:33]), r.tolist()
+    hdr = g[tag + "_i16_hdr"]
+    for k in range(len(hdr)):
+        left, up, allav, mask, metric, maxp = [int(v) for v in hdr[k]]
+        cost, mode, pred = J.intra16_search(g[tag + "_i16_edge"][k], left, up, mask, metric, g[tag + "_i16_orig"][k], maxp)
+        assert cost == int(g[tag + "_i16_cost"][k]) and mode == int(g[tag + "_i16_mode"][k]), k
+        for m in range(4):
+            if (mask >> m) & 1:
+                assert np.array_equal(pred[m].reshape(-1), g[tag + "_i16_pred"][k, m]), (k, m)
+    assert len(hdr) >= 20
