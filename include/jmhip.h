@@ -308,6 +308,29 @@ int jmhip_quant_dc4x4(jmhip_ctx *ctx, const jmhip_qparam *q, int32_t qp_per, int
 int jmhip_distortion(jmhip_ctx *ctx, int32_t metric, int32_t size, const int16_t *diff, int32_t nblocks, int64_t *out);
 
 /* ------------------------------------------------------------------------------------------
+ * Luma intra prediction and the Intra16x16 mode search
+ *
+ * jmhip_intrapred4x4: get_intrapred_4x4 (lencod/src/intra4x4.c:521-561; modes 0..8 = VERT, HOR, DC, DIAG_DOWN_LEFT, DIAG_DOWN_RIGHT,
+ *   VERT_RIGHT, HOR_DOWN, VERT_LEFT, HOR_UP) over the predictor samples set_intrapred_4x4 (:421) leaves in currMB->intra4x4_pred[pl]:
+ *   edge[0] = above left, edge[1..8] = above and above right, edge[9..12] = left.  left / up: the availability flags the DC mode takes.
+ * jmhip_intra16_search: find_sad_16x16_JM (lencod/src/intra16x16.c:463-517; Slice.find_sad_16x16, bound in rdopt.c:301): the predictions
+ *   of the modes in mode_mask (bit k = VERT_PRED_16, HOR_PRED_16, DC_PRED_16, PLANE_16; get_intrapred_16x16 :307) over
+ *   currMB->intra16x16_pred[pl] (edge[0] = above left, [1..16] above, [17..32] left), their cost Slice.distI16x16 (metric: JMHIP_METRIC_*;
+ *   distI16x16_sad / _sse / _satd :331-452) and the choice by strict '<' in ascending mode order.  8-bit samples.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint8_t edge[13]; uint8_t mode, left, up; } jmhip_ip4_blk;                    /* 16 bytes */
+typedef struct { uint8_t edge[33]; uint8_t left, up, mode_mask, metric; uint8_t reserved_[3]; } jmhip_i16_mb;   /* 40 bytes */
+typedef struct {
+  int64_t cost;                     /* best cost (distblk, << 5); DISTBLK_MAX when mode_mask is empty */
+  int32_t mode;                     /* what JM leaves in currMB->i16mode (DC_PRED_16 when nothing was evaluated) */
+  int32_t reserved_;
+  uint8_t pred[4][256];             /* mpr_16x16[pl][k] of the evaluated modes, rows of 16 */
+} jmhip_i16_out;                    /* 1040 bytes */
+int jmhip_intrapred4x4(jmhip_ctx *ctx, const jmhip_ip4_blk *blocks, int32_t n, uint8_t *out /* n x 16 */);
+int jmhip_intra16_search(jmhip_ctx *ctx, const jmhip_i16_mb *mbs, const uint8_t *orig /* n x 256 */, int32_t n, jmhip_i16_out *out);
+int jmhip_intra16_search_dev(jmhip_ctx *ctx, const jmhip_i16_mb *d_mbs, const uint8_t *d_orig, int32_t n, jmhip_i16_out *d_out);
+
+/* ------------------------------------------------------------------------------------------
  * Motion-compensated prediction, un-weighted, frame pictures
  *
  * luma:   luma_prediction (lencod/src/mc_prediction.c:144-236; bound to p_Dpb->pf_luma_prediction, lencod.c:367):

@@ -1,0 +1,221 @@
+// intra.hip -- luma intra prediction of 4x4 blocks and the Intra16x16 mode search of whole macroblocks (gfx950).  SURVEY.md 8f row 1.
+//
+// Same values, bit for bit, as
+//   get_intrapred_4x4      lencod/src/intra4x4.c:521-561 (the nine modes :72-308) over the predictor samples set_intrapred_4x4 :421 gathers
+//                          (edge[0] = above left, [1..8] = above and above right, [9..12] = left), and
+//   find_sad_16x16_JM      lencod/src/intra16x16.c:463-517: the four predictions of get_intrapred_16x16 :307 (:28-146; edge[0] = above left,
+//                          [1..16] above, [17..32] left), the mode cost Slice.distI16x16 (distI16x16_sad / _sse / _satd :331-452; the SATD
+//                          form sums the AC terms of hadamard4x4 of every 4x4 difference block and the hadamard4x4 of the halved DC terms),
+//                          and the choice by strict '<' in ascending mode order.
+// The formulas are those of H.264 8.3.1.2 / 8.3.3, which JM's per-sample assignments implement.
+// k_intrapred4x4: 16 lanes per block, one sample each.  k_intra16_search: 16 lanes per macroblock, lane = 4x4 block: prediction,
+// difference and Hadamard in registers, the sixteen DC terms by wave shuffles, the cost by a group reduction.
+#include "jmhip_internal.h"
+static_assert(sizeof(jmhip_ip4_blk) == 16 && sizeof(jmhip_i16_mb) == 40 && sizeof(jmhip_i16_out) == 1040, "intra records");
+
+__device__ __forceinline__ int e4t(const uint8_t *e, int x) { return x < 0 ? e[0] : e[1 + x]; }     // p[x, -1], x = -1 .. 7
+__device__ __forceinline__ int e4l(const uint8_t *e, int y) { return y < 0 ? e[0] : e[9 + y]; }     // p[-1, y], y = -1 .. 3
+
+__global__ __launch_bounds__(256) void k_intrapred4x4(const jmhip_ip4_blk *__restrict__ blks, int n, uint8_t *__restrict__ out)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 4, x = t & 3, y = (t >> 2) & 3;
+  if (b >= n) return;
+  const uint8_t *e = blks[b].edge;
+  const int mode = blks[b].mode, left = blks[b].left, up = blks[b].up;
+  int v;
+  switch (mode) {
+  case 0: v = e4t(e, x); break;
+  case 1: v = e4l(e, y); break;
+  case 2:
+    if (up && left) v = (e[1] + e[2] + e[3] + e[4] + e[9] + e[10] + e[11] + e[12] + 4) >> 3;
+    else if (left) v = (e[9] + e[10] + e[11] + e[12] + 2) >> 2;
+    else if (up) v = (e[1] + e[2] + e[3] + e[4] + 2) >> 2;
+    else v = e[1];
+    break;
+  case 3: v = (x == 3 && y == 3) ? (e4t(e, 6) + 3 * e4t(e, 7) + 2) >> 2 : (e4t(e, x + y) + 2 * e4t(e, x + y + 1) + e4t(e, x + y + 2) + 2) >> 2; break;
+  case 4:
+    if (x > y) v = (e4t(e, x - y - 2) + 2 * e4t(e, x - y - 1) + e4t(e, x - y) + 2) >> 2;
+    else if (x < y) v = (e4l(e, y - x - 2) + 2 * e4l(e, y - x - 1) + e4l(e, y - x) + 2) >> 2;
+    else v = (e4t(e, 0) + 2 * e[0] + e4l(e, 0) + 2) >> 2;
+    break;
+  case 5: {
+    const int z = 2 * x - y, k = x - (y >> 1);
+    if (z >= 0 && !(z & 1)) v = (e4t(e, k - 1) + e4t(e, k) + 1) >> 1;
+    else if (z > 0) v = (e4t(e, k - 2) + 2 * e4t(e, k - 1) + e4t(e, k) + 2) >> 2;
+    else if (z == -1) v = (e4l(e, 0) + 2 * e[0] + e4t(e, 0) + 2) >> 2;
+    else v = (e4l(e, y - 1) + 2 * e4l(e, y - 2) + e4l(e, y - 3) + 2) >> 2;
+    break; }
+  case 6: {
+    const int z = 2 * y - x, k = y - (x >> 1);
+    if (z >= 0 && !(z & 1)) v = (e4l(e, k - 1) + e4l(e, k) + 1) >> 1;
+    else if (z > 0) v = (e4l(e, k - 2) + 2 * e4l(e, k - 1) + e4l(e, k) + 2) >> 2;
+    else if (z == -1) v = (e4l(e, 0) + 2 * e[0] + e4t(e, 0) + 2) >> 2;
+    else v = (e4t(e, x - 1) + 2 * e4t(e, x - 2) + e4t(e, x - 3) + 2) >> 2;
+    break; }
+  case 7: {
+    const int k = x + (y >> 1);
+    v = (y & 1) ? (e4t(e, k) + 2 * e4t(e, k + 1) + e4t(e, k + 2) + 2) >> 2 : (e4t(e, k) + e4t(e, k + 1) + 1) >> 1;
+    break; }
+  default: {
+    const int z = x + 2 * y, k = y + (x >> 1);
+    if (z > 5) v = e4l(e, 3);
+    else if (z == 5) v = (e4l(e, 2) + 3 * e4l(e, 3) + 2) >> 2;
+    else if (z & 1) v = (e4l(e, k) + 2 * e4l(e, k + 1) + e4l(e, k + 2) + 2) >> 2;
+    else v = (e4l(e, k) + e4l(e, k + 1) + 1) >> 1;
+    break; }
+  }
+  out[(long)b * 16 + 4 * y + x] = (uint8_t)v;
+}
+
+__device__ __forceinline__ int iabsi_(int v) { return v < 0 ? -v : v; }
+// JM's hadamard4x4 (transform.c:121-168): rows, then columns with >> 1; in place on a row-major 4x4
+__device__ __forceinline__ void hadamard4x4_jm(int (&m)[16])
+{
+  int u[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int e0 = m[4 * i] + m[4 * i + 3], e1 = m[4 * i + 1] + m[4 * i + 2], o0 = m[4 * i + 1] - m[4 * i + 2], o1 = m[4 * i] - m[4 * i + 3];
+    u[4 * i] = e0 + e1; u[4 * i + 1] = o1 + o0; u[4 * i + 2] = e0 - e1; u[4 * i + 3] = o1 - o0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int e0 = u[i] + u[12 + i], e1 = u[4 + i] + u[8 + i], o0 = u[4 + i] - u[8 + i], o1 = u[i] - u[12 + i];
+    m[i] = (e0 + e1) >> 1; m[4 + i] = (o0 + o1) >> 1; m[8 + i] = (e0 - e1) >> 1; m[12 + i] = (o1 - o0) >> 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_intra16_search(const jmhip_i16_mb *__restrict__ mbs, const uint8_t *__restrict__ orig, int n, int max_pel,
+                                                        jmhip_i16_out *__restrict__ out)
+{
+  const int lane = threadIdx.x & 63, b = lane & 15, gb = lane & ~15;
+  const int item = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = item < n;
+  const int it = live ? item : 0;
+  const jmhip_i16_mb *mb = mbs + it;
+  const uint8_t *e = mb->edge;
+  const int jj = b >> 2, ii = b & 3, left = mb->left, up = mb->up, mask = mb->mode_mask, metric = mb->metric;
+  // the block's source samples
+  int src[16];
+  {
+    const uint8_t *po = orig + (long)it * 256 + (4 * jj) * 16 + 4 * ii;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t w = *(const uint32_t *)(po + 16 * j);
+#pragma unroll
+      for (int i = 0; i < 4; i++) src[4 * j + i] = (w >> (8 * i)) & 255;
+    }
+  }
+  // uniform parameters of the DC and plane modes
+  int dc, pa, pb, pc;
+  {
+    int s1 = 0, s2 = 0, H = 0, V = 0;
+#pragma unroll
+    for (int x = 0; x < 16; x++) { s1 += e[1 + x]; s2 += e[17 + x]; }
+    dc = (up && left) ? (s1 + s2 + 16) >> 5 : (up ? (s1 + 8) >> 4 : (left ? (s2 + 8) >> 4 : e[1]));
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+      H += (x + 1) * ((int)e[9 + x] - (int)(x == 7 ? e[0] : e[7 - x]));
+      V += (x + 1) * ((int)e[25 + x] - (int)(x == 7 ? e[0] : e[23 - x]));
+    }
+    pb = (5 * H + 32) >> 6; pc = (5 * V + 32) >> 6; pa = 16 * (e[16] + e[32]);
+  }
+  long long best = 0x7fffffffLL << 5;                       // DISTBLK_MAX
+  int best_mode = 2;
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    if (!((mask >> k) & 1)) continue;                       // uniform inside the 16-lane group, and the shuffles below stay inside it
+    int m[16];
+    uint32_t pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      pw[j] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int x = 4 * ii + i, y = 4 * jj + j;
+        int v;
+        if (k == 0) v = e[1 + x];
+        else if (k == 1) v = e[17 + y];
+        else if (k == 2) v = dc;
+        else { v = (pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5; v = v < 0 ? 0 : (v > max_pel ? max_pel : v); }
+        pw[j] |= (uint32_t)v << (8 * i);
+        m[4 * j + i] = src[4 * j + i] - v;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) *(uint32_t *)(out[it].pred[k] + (4 * jj + j) * 16 + 4 * ii) = pw[j];
+    }
+    long long part = 0;
+    if (metric == JMHIP_METRIC_SAD) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) part += iabsi_(m[c]);
+    } else if (metric == JMHIP_METRIC_SSE) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) part += m[c] * m[c];
+    } else {
+      hadamard4x4_jm(m);
+#pragma unroll
+      for (int c = 1; c < 16; c++) part += iabsi_(m[c]);
+      int t[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) t[q] = __shfl(m[0] >> 1, gb + q, 64);
+      hadamard4x4_jm(t);
+      int v = 0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) v = (w == b) ? t[w] : v;      // each lane adds one term of the DC transform
+      part += iabsi_(v);
+    }
+    int lo = (int)part;                                    // a block's share stays far below 2^31 (SSE: 16 * 255^2)
+    lo += __shfl_xor(lo, 1, 64); lo += __shfl_xor(lo, 2, 64); lo += __shfl_xor(lo, 4, 64); lo += __shfl_xor(lo, 8, 64);
+    const long long cost = (long long)lo << 5;
+    if (cost < best) { best = cost; best_mode = k; }
+  }
+  if (live && b == 0) { out[it].cost = best; out[it].mode = best_mode; out[it].reserved_ = 0; }
+}
+
+extern "C" int jmhip_intrapred4x4(jmhip_ctx *ctx, const jmhip_ip4_blk *blks, int32_t n, uint8_t *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!blks || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intrapred4x4: bad argument");
+  for (int i = 0; i < n; i++) if (blks[i].mode > 8) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intrapred4x4: block %d: mode %d", i, blks[i].mode);
+  if (n == 0) return JMHIP_OK;
+  int r; void *din, *dout;
+  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_ip4_blk), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 1, (size_t)n * 16, &dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(din, blks, (size_t)n * sizeof(jmhip_ip4_blk), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_intrapred4x4, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, (const jmhip_ip4_blk *)din, n, (uint8_t *)dout);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_intra16_search_dev(jmhip_ctx *ctx, const jmhip_i16_mb *d_mbs, const uint8_t *d_orig, int32_t n, jmhip_i16_out *d_out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!d_mbs || !d_orig || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intra16_search_dev: bad argument");
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_intra16_search, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_mbs, d_orig, n, 255, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_intra16_search(jmhip_ctx *ctx, const jmhip_i16_mb *mbs, const uint8_t *orig, int32_t n, jmhip_i16_out *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!mbs || !orig || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intra16_search: bad argument");
+  for (int i = 0; i < n; i++)
+    if (mbs[i].mode_mask > 15 || mbs[i].metric > 2) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intra16_search: macroblock %d: mode mask %d, metric %d", i, mbs[i].mode_mask, mbs[i].metric);
+  if (n == 0) return JMHIP_OK;
+  int r; void *din, *dout;
+  if ((r = jmhip_scratch(ctx, 0, (size_t)n * (sizeof(jmhip_i16_mb) + 256) + 64, &din))) return r;
+  if ((r = jmhip_scratch(ctx, 1, (size_t)n * sizeof(jmhip_i16_out), &dout))) return r;
+  uint8_t *d_orig = (uint8_t *)din;
+  jmhip_i16_mb *d_mbs = (jmhip_i16_mb *)(d_orig + (size_t)n * 256);
+  HIPCHK(ctx, hipMemcpyAsync(d_orig, orig, (size_t)n * 256, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_mbs, mbs, (size_t)n * sizeof(jmhip_i16_mb), hipMemcpyHostToDevice, ctx->stream));
+  if ((r = jmhip_intra16_search_dev(ctx, d_mbs, d_orig, n, (jmhip_i16_out *)dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * sizeof(jmhip_i16_out), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}

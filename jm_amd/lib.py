@@ -63,6 +63,10 @@ MC_LUMA_BLK = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("
                         ("mv", "<i2", (2, 2)), ("reserved2_", "<i2")])
 MC_CHROMA_BLK = np.dtype([("x", "<i2"), ("y", "<i2"), ("dir", "u1"), ("plane", "u1"), ("slot", "i1", (2,)), ("mv", "<i2", (2, 4, 2, 2))])
 assert MC_LUMA_BLK.itemsize == 20 and MC_CHROMA_BLK.itemsize == 72
+IP4_BLK = np.dtype([("edge", "u1", (13,)), ("mode", "u1"), ("left", "u1"), ("up", "u1")])
+I16_MB = np.dtype([("edge", "u1", (33,)), ("left", "u1"), ("up", "u1"), ("mode_mask", "u1"), ("metric", "u1"), ("reserved_", "u1", (3,))])
+I16_OUT = np.dtype([("cost", "<i8"), ("mode", "<i4"), ("reserved_", "<i4"), ("pred", "u1", (4, 256))])
+assert IP4_BLK.itemsize == 16 and I16_MB.itemsize == 40 and I16_OUT.itemsize == 1040
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16
 
@@ -72,7 +76,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -380,6 +384,20 @@ class JmHip:
 
     def tq_chroma_dev(self, prm, d_mbs, d_orig, d_pred, n, d_out):
         self._ck(self.lib.jmhip_tq_chroma_dev(self.h, _vp(prm), _vp(d_mbs), _vp(d_orig), _vp(d_pred), n, _vp(d_out)))
+
+    def intrapred4x4(self, blocks):
+        """get_intrapred_4x4 (lencod/src/intra4x4.c:521): IP4_BLK array -> (n, 16) uint8"""
+        b = np.ascontiguousarray(blocks, IP4_BLK)
+        out = np.zeros((len(b), 16), np.uint8)
+        self._ck(self.lib.jmhip_intrapred4x4(self.h, _vp(b), len(b), _vp(out)))
+        return out
+
+    def intra16_search(self, mbs, orig):
+        """find_sad_16x16_JM (lencod/src/intra16x16.c:463): I16_MB array, orig (n, 256) uint8 -> I16_OUT array"""
+        m = np.ascontiguousarray(mbs, I16_MB); o = np.ascontiguousarray(orig, np.uint8).reshape(-1, 256)
+        out = np.zeros(len(m), I16_OUT)
+        self._ck(self.lib.jmhip_intra16_search(self.h, _vp(m), _vp(o), len(m), _vp(out)))
+        return out
 
     def distortion(self, metric, size, diff):
         """distortion4x4 / distortion8x8 {SAD 0, SSE 1, SATD 2} (lencod/src/me_distortion.c:38-146) of int16 difference blocks -> int64 << 5"""

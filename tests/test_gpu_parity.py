@@ -983,3 +983,58 @@ def test_new_entry_points_reject_bad_arguments():
     with pytest.raises(JmHipError):
         mono.set_reference_chroma(0, np.zeros((24, 32), np.uint16), np.zeros((24, 32), np.uint16))            # 4:0:0 has no chroma
     mono.close()
+
+
+# ---------------------------------------------------------------- luma intra prediction, Intra16x16 mode search
+@pytest.mark.parametrize("tag", ["a", "c", "e"])
+def test_intra_golden_records(tag):
+    """k_intrapred4x4 == get_intrapred_4x4 and k_intra16_search == find_sad_16x16_JM on the real encoder's calls"""
+    from jm_amd.lib import IP4_BLK, I16_MB
+    g = np.load(os.path.join(G, "qcif_intra.npz"))
+    ctx = make_ctx(64, 48)
+    i4 = g[tag + "_i4"]
+    b = np.zeros(len(i4), IP4_BLK)
+    b["mode"], b["left"], b["up"], b["edge"] = i4[:, 0], i4[:, 1], i4[:, 2], i4[:, 4:17]
+    assert np.array_equal(ctx.intrapred4x4(b), i4[:, 17:33].astype(np.uint8))
+    hdr = g[tag + "_i16_hdr"]
+    m = np.zeros(len(hdr), I16_MB)
+    m["left"], m["up"], m["mode_mask"], m["metric"], m["edge"] = hdr[:, 0], hdr[:, 1], hdr[:, 3], hdr[:, 4], g[tag + "_i16_edge"]
+    out = ctx.intra16_search(m, g[tag + "_i16_orig"])
+    assert np.array_equal(out["cost"], g[tag + "_i16_cost"]) and np.array_equal(out["mode"], g[tag + "_i16_mode"])
+    for k in range(len(hdr)):
+        for mode in range(4):
+            if (int(hdr[k, 3]) >> mode) & 1:
+                assert np.array_equal(out["pred"][k, mode], g[tag + "_i16_pred"][k, mode]), (k, mode)
+    ctx.close()
+
+
+def test_intra_random_vs_oracle(J):
+    """random predictor samples: every 4x4 mode with every availability combination; Intra16x16 searches with every mode mask and metric"""
+    from jm_amd.lib import IP4_BLK, I16_MB
+    rng = np.random.default_rng(17)
+    ctx = make_ctx(64, 48)
+    n = 9 * 4 * 12
+    b = np.zeros(n, IP4_BLK)
+    b["mode"], b["left"], b["up"] = np.arange(n) % 9, (np.arange(n) // 9) % 2, (np.arange(n) // 18) % 2
+    b["edge"] = rng.integers(0, 256, (n, 13))
+    b["edge"][:40] = rng.choice([0, 255], (40, 13))
+    out = ctx.intrapred4x4(b)
+    for k in range(n):
+        assert np.array_equal(out[k].reshape(4, 4), J.intrapred_4x4(b["edge"][k], b["mode"][k], b["left"][k], b["up"][k])), b[k]
+    n = 16 * 3 * 4
+    m = np.zeros(n, I16_MB)
+    m["mode_mask"], m["metric"] = np.arange(n) % 16, (np.arange(n) // 16) % 3
+    m["left"], m["up"] = rng.integers(0, 2, n), rng.integers(0, 2, n)
+    m["edge"] = rng.integers(0, 256, (n, 33))
+    m["edge"][:30] = rng.choice([0, 255], (30, 33))                # plane predictions that need the clip
+    orig = rng.integers(0, 256, (n, 256)).astype(np.uint8)
+    orig[:10] = 0; orig[10:20] = 255
+    out = ctx.intra16_search(m, orig)
+    for k in range(n):
+        cost, mode, pred = J.intra16_search(m["edge"][k], m["left"][k], m["up"][k], m["mode_mask"][k], m["metric"][k], orig[k])
+        assert (int(out["cost"][k]), int(out["mode"][k])) == (cost, mode), (k, m[k])
+        for md in range(4):
+            if (int(m["mode_mask"][k]) >> md) & 1:
+                assert np.array_equal(out["pred"][k, md].reshape(16, 16), pred[md]), (k, md)
+    assert len(ctx.intrapred4x4(b[:0])) == 0 and len(ctx.intra16_search(m[:0], orig[:0])) == 0
+    ctx.close()
