@@ -47,13 +47,15 @@
 #include "quant4x4.h"
 #include "quant8x8.h"
 #include "slice.h"
+#include "intra16x16.h"
+#include "intra4x4.h"
 #include "jmhip.h"
 
 #define MAX_SLOTS 20
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -64,7 +66,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16;
 } G;
 
 static void adapter_report(void)
@@ -73,8 +75,10 @@ static void adapter_report(void)
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
-                  "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld\n",
-          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval);
+                  "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld; "
+                  "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches\n",
+          G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
+          G.n_ip4, G.n_i16);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -115,7 +119,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
-    G.part_eval = has_part(parts, "eval");
+    G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -392,6 +396,62 @@ extern distblk __real_computeSATD(StorablePicture *, MEBlock *, distblk, MotionV
 distblk __wrap_computeSATD(StorablePicture *ref1, MEBlock *mv_block, distblk min_mcost, MotionVector *cand)
 {
   return eval_candidate(ref1, mv_block, min_mcost, cand, JMHIP_METRIC_SATD, __real_computeSATD);
+}
+
+/* ------------------------------------------------------------------ luma intra prediction
+ * get_intrapred_4x4 (lencod/src/intra4x4.c:521) and the Intra16x16 mode search find_sad_16x16_JM (intra16x16.c:463; Slice.find_sad_16x16,
+ * rdopt.c:301).  JM keeps gathering the predictor samples (set_intrapred_4x4 / set_intrapred_16x16: neighbour availability, constrained
+ * intra prediction); the predictions, the mode cost and the mode choice come from the device. */
+extern void __real_get_intrapred_4x4(Macroblock *, ColorPlane, int, int, int, int, int);
+void __wrap_get_intrapred_4x4(Macroblock *currMB, ColorPlane pl, int mode, int img_x, int img_y, int left, int up)
+{
+  jmhip_ip4_blk b;
+  uint8_t out[16];
+  int i, j, rc;
+  if (!adapter_on(currMB->p_Vid) || !G.part_ip4 || pl != PLANE_Y || mode < 0 || mode > 8) {
+    G.n_passed++;
+    __real_get_intrapred_4x4(currMB, pl, mode, img_x, img_y, left, up);
+    return;
+  }
+  for (i = 0; i < 13; i++) b.edge[i] = (uint8_t)currMB->intra4x4_pred[pl][i];
+  b.mode = (uint8_t)mode; b.left = (uint8_t)(left != 0); b.up = (uint8_t)(up != 0);
+  if ((rc = jmhip_intrapred4x4(G.ctx, &b, 1, out))) adapter_die("jmhip_intrapred4x4", rc);
+  for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) currMB->p_Slice->mpr_4x4[pl][mode][j][i] = out[4 * j + i];
+  G.n_ip4++;
+}
+extern distblk __real_find_sad_16x16_JM(Macroblock *);
+distblk __wrap_find_sad_16x16_JM(Macroblock *currMB)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  InputParameters *p_Inp = currMB->p_Inp;
+  jmhip_i16_mb m;
+  static jmhip_i16_out out;
+  uint8_t orig[256];
+  int left, up, all, k, j, i, rc;
+  if (!adapter_on(p_Vid) || !G.part_i16 || currSlice->P444_joined || currSlice->set_intrapred_16x16 != set_intrapred_16x16) {
+    G.n_passed++;
+    return __real_find_sad_16x16_JM(currMB);
+  }
+  memset(&m, 0, sizeof m);
+  currSlice->set_intrapred_16x16(currMB, PLANE_Y, &left, &up, &all);
+  for (k = 0; k < 4; k++) {                                                   /* the modes JM's loop evaluates (intra16x16.c:483-494) */
+    int off = 0;
+    if (p_Inp->IntraDisableInterOnly == 0 || (currSlice->slice_type != I_SLICE && currSlice->slice_type != SI_SLICE))
+      off = (p_Inp->Intra16x16ParDisable && (k == VERT_PRED_16 || k == HOR_PRED_16)) || (p_Inp->Intra16x16PlaneDisable && k == PLANE_16);
+    if (!off && !((k == VERT_PRED_16 && !up) || (k == HOR_PRED_16 && !left) || (k == PLANE_16 && (!left || !up || !all)))) m.mode_mask |= (uint8_t)(1 << k);
+  }
+  for (i = 0; i < 33; i++) m.edge[i] = (uint8_t)currMB->intra16x16_pred[0][i];
+  m.left = (uint8_t)(left != 0); m.up = (uint8_t)(up != 0);
+  m.metric = (uint8_t)(p_Inp->ModeDecisionMetric == ERROR_SAD ? JMHIP_METRIC_SAD : (p_Inp->ModeDecisionMetric == ERROR_SSE ? JMHIP_METRIC_SSE : JMHIP_METRIC_SATD));
+  for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) orig[j * 16 + i] = (uint8_t)p_Vid->pCurImg[currMB->opix_y + j][currMB->pix_x + i];
+  if ((rc = jmhip_intra16_search(G.ctx, &m, orig, 1, &out))) adapter_die("jmhip_intra16_search", rc);
+  for (k = 0; k < 4; k++)
+    if ((m.mode_mask >> k) & 1)
+      for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) currSlice->mpr_16x16[0][k][j][i] = out.pred[k][j * 16 + i];
+  currMB->i16mode = (char)out.mode;
+  G.n_i16++;
+  return (distblk)out.cost;
 }
 
 /* ------------------------------------------------------------------ motion-compensated prediction
