@@ -70,3 +70,19 @@ void jmo_chroma_pred4x4(const jmo_pel *p0, const jmo_pel *p1, int pitch, int W, 
   if (p_dir != 0) one_chroma(p1, pitch, W, H, yuv, xc, yc, mv1, b);
   for (k = 0; k < 16; k++) out[k] = p_dir == 0 ? a[k] : (p_dir == 1 ? b[k] : (jmo_pel)((a[k] + b[k] + 1) >> 1));
 }
+
+/* getSubImagesChroma (lencod/src/img_chroma.c:338-437) of one plane: every sub-image with its padding.
+ * dst: [suby][subx][H + 2 pad_y][W + 2 pad_x], suby < 8 (4:2:0) or 4 (4:2:2), subx < 8; pads (IMG_PAD_SIZE >> 1 each at 4:2:0,
+ * IMG_PAD_SIZE_Y rows at 4:2:2; lencod.c:2366-2376). */
+void jmo_sub_images_chroma(const jmo_pel *src, int pitch, int W, int H, int yuv, jmo_pel *dst)
+{
+  const int ny = yuv == 2 ? 4 : 8, pad_x = JMO_PAD_X >> 1, pad_y = yuv == 2 ? JMO_PAD_Y : JMO_PAD_Y >> 1;
+  const int Wp = W + 2 * pad_x, Hp = H + 2 * pad_y;
+  int sy, sx, Y, X;
+  for (sy = 0; sy < ny; sy++)
+    for (sx = 0; sx < 8; sx++) {
+      jmo_pel *d = dst + (long)(sy * 8 + sx) * Wp * Hp;
+      for (Y = -pad_y; Y < H + pad_y; Y++)
+        for (X = -pad_x; X < W + pad_x; X++) d[(long)(Y + pad_y) * Wp + X + pad_x] = (jmo_pel)chroma_sub(src, pitch, W, H, yuv, sy, sx, Y, X);
+    }
+}

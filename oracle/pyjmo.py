@@ -354,3 +354,12 @@ def intra16_search(edge, left, up, mode_mask, metric, orig, max_pel=255):
     pred = np.zeros((4, 256), np.uint16); best = C.c_int(0)
     c = L.jmo_intra16_search(_p(e), int(left), int(up), int(mode_mask), int(metric), int(max_pel), _p(o), _p(pred), C.byref(best))
     return int(c), best.value, pred.reshape(4, 16, 16).astype(np.uint8)
+
+
+def sub_images_chroma(plane, yuv):
+    """getSubImagesChroma of one plane: (ny, 8, H + 2 pad_y, W + 2 pad_x) uint8, ny = 8 (4:2:0) or 4 (4:2:2)"""
+    p = np.ascontiguousarray(plane, np.uint16); h, w = p.shape
+    ny, pad_x, pad_y = (4 if yuv == 2 else 8), PAD_X // 2, (PAD_Y if yuv == 2 else PAD_Y // 2)
+    out = np.zeros((ny, 8, h + 2 * pad_y, w + 2 * pad_x), np.uint16)
+    L.jmo_sub_images_chroma(_p(p), w, w, h, int(yuv), _p(out))
+    return out.astype(np.uint8)

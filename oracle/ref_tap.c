@@ -205,6 +205,28 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
   g_refs_made++;
 }
 
+/* ------------------------------------------------------------------ chroma sub-images (K6)
+ * getSubImagesChroma (lencod/src/img_chroma.c:338; called by UnifiedOneForthPix, image.c:2205, when ChromaMCBuffer = 1): for the first
+ * reference pictures, every sub-image of both planes with its padding.
+ * record: picture index, yuv_format, subimages_y, subimages_x, pad_y, pad_x | per plane, per (suby, subx): the padded plane */
+extern void __real_getSubImagesChroma(VideoParameters *, StorablePicture *);
+void __wrap_getSubImagesChroma(VideoParameters *p_Vid, StorablePicture *s)
+{
+  static int n = 0;
+  __real_getSubImagesChroma(p_Vid, s);
+  if (n < 2 && (p_Vid->yuv_format == YUV420 || p_Vid->yuv_format == YUV422) && !p_Vid->p_Inp->OnTheFlyFractMCP) {
+    const int ny = p_Vid->yuv_format == YUV420 ? 8 : 4, nx = 8, py = p_Vid->pad_size_uv_y, px = p_Vid->pad_size_uv_x;
+    int uv, j, i;
+    FILE *f = tap_open("chromasub.bin");
+    put_i32(f, g_refs_made - 1); put_i32(f, p_Vid->yuv_format); put_i32(f, ny); put_i32(f, nx); put_i32(f, py); put_i32(f, px);
+    for (uv = 0; uv < 2; uv++)
+      for (j = 0; j < ny; j++)
+        for (i = 0; i < nx; i++) put_plane(f, s->p_img_sub[uv + 1][j][i], -py, -px, s->size_y_cr + 2 * py, s->size_x_cr + 2 * px);
+    fclose(f);
+  }
+  n++;
+}
+
 /* ------------------------------------------------------------------ motion-compensated prediction
  *   luma_prediction          lencod/src/mc_prediction.c:144   (bound to p_Dpb->pf_luma_prediction in lencod.c:367)
  *   chroma_prediction_4x4    lencod/src/mc_prediction.c:568

@@ -146,6 +146,14 @@ def mc_arrays(tag, workdir, d, n_luma=260, n_chroma=420):
     for k in sorted(u for u in used if u >= 0):
         d[f"{tag}_ref{k}_y"] = subs[k]["src"]
         d[f"{tag}_ref{k}_u"], d[f"{tag}_ref{k}_v"] = rc[k]
+    # getSubImagesChroma of the first reference picture: a digest of every sub-image of both planes, and every 13th row of the U planes
+    r = Reader(os.path.join(workdir, "chromasub.bin"))
+    idx, fmt, ny, nx, py, px = [r.i32() for _ in range(6)]
+    planes = [[r.plane().astype(np.uint8) for _ in range(ny * nx)] for _ in range(2)]
+    assert idx == 0, idx
+    d[tag + "_csub_hdr"] = np.array([idx, fmt, ny, nx, py, px], np.int32)
+    d[tag + "_csub_sha"] = np.array([[hashlib.sha256(p.tobytes()).hexdigest() for p in pl] for pl in planes])
+    d[tag + "_csub_u_rows"] = np.stack([p[::13] for p in planes[0]])
 
 
 def intra_arrays(tag, workdir, d, n4=450, n16=40):

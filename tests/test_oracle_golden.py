@@ -406,3 +406,16 @@ def test_oracle_intra_prediction_matches_the_reference(tag):
             if (mask >> m) & 1:
                 assert np.array_equal(pred[m].reshape(-1), g[tag + "_i16_pred"][k, m]), (k, m)
     assert len(hdr) >= 20
+
+
+@pytest.mark.parametrize("tag,fmt", [("a", 1), ("c", 2), ("e", 1)])
+def test_oracle_chroma_subimages_match_the_reference(tag, fmt):
+    """jmo_sub_images_chroma == getSubImagesChroma (img_chroma.c:338): every sub-image of both planes of the first reference picture,
+    padding included (digests), and every 13th row of the U sub-images sample by sample"""
+    g = mc_golden()
+    for pl, name in enumerate("uv"):
+        sub = J.sub_images_chroma(g[f"{tag}_ref0_{name}"], fmt)
+        sha = [hashlib.sha256(sub[j, i].tobytes()).hexdigest() for j in range(sub.shape[0]) for i in range(8)]
+        assert sha == list(g[tag + "_csub_sha"][pl]), (tag, name)
+        if pl == 0:
+            assert np.array_equal(sub.reshape(-1, *sub.shape[2:])[:, ::13], g[tag + "_csub_u_rows"])
