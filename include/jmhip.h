@@ -361,6 +361,10 @@ typedef struct {
 /* out: luma n x 256 bytes (the w x h samples row-major at the start of each record); chroma n x 16 bytes */
 int jmhip_set_reference_chroma(jmhip_ctx *ctx, int32_t slot, const uint16_t *u, const uint16_t *v, int32_t pitch_samples);
 int jmhip_set_reference_chroma_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_u, const uint8_t *d_v, int32_t pitch_bytes);
+/* K6: getSubImagesChroma (lencod/src/img_chroma.c:338-437) of plane 0 = U / 1 = V of the reference in `slot`, for callers that keep JM's
+ * host-side chroma prediction: out[suby][subx][ch + 2 pad_y][cw + 2 pad_x] imgpel, suby < 8 (4:2:0) / 4 (4:2:2), subx < 8,
+ * pad_x = 16, pad_y = 10 (4:2:0) / 20 (4:2:2)  (lencod.c:2366-2376). */
+int jmhip_get_chroma_subplanes(jmhip_ctx *ctx, int32_t slot, int32_t plane, uint16_t *out);
 int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, int32_t n, uint8_t *out);
 int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t n, uint8_t *d_out);
 int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out);

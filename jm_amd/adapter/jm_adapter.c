@@ -55,7 +55,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -63,10 +63,11 @@ static struct {
   unsigned    slot_tick[MAX_SLOTS], tick;
   int         slot_chroma[MAX_SLOTS]; /* the slot's integer chroma planes are on the device (jmhip_set_reference_chroma) */
   uint16_t   *planes;                 /* 16 x (H+40) x (W+64) imgpel, jmhip_get_subplanes output */
+  uint16_t   *cplanes;                /* chroma sub-images of one plane, jmhip_get_chroma_subplanes output (allocated on first use) */
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc;
 } G;
 
 static void adapter_report(void)
@@ -76,9 +77,9 @@ static void adapter_report(void)
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
                   "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld; "
-                  "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches\n",
+                  "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches; getSubImagesChroma on the MI355X: %ld\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
-          G.n_ip4, G.n_i16);
+          G.n_ip4, G.n_i16, G.n_interpc);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -120,6 +121,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
+    G.part_interpc = has_part(parts, "interpc");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -203,6 +205,35 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
       for (y = 0; y < Hp; y++) memcpy(&dst[y - JMHIP_PAD_Y][-JMHIP_PAD_X], src + (size_t)y * Wp, (size_t)Wp * sizeof(imgpel));
     }
   G.n_interp++;
+}
+
+/* ------------------------------------------------------------------ K6: chroma sub-images
+ * getSubImagesChroma (lencod/src/img_chroma.c:338; UnifiedOneForthPix calls it right after getSubImagesLuma when ChromaMCBuffer = 1). */
+static int slot_with_chroma(StorablePicture *s);
+extern void __real_getSubImagesChroma(VideoParameters *, StorablePicture *);
+void __wrap_getSubImagesChroma(VideoParameters *p_Vid, StorablePicture *s)
+{
+  const int fmt = p_Vid->yuv_format, ny = fmt == YUV422 ? 4 : 8, py = p_Vid->pad_size_uv_y, px = p_Vid->pad_size_uv_x;
+  const int Wp = s->size_x_cr + 2 * px, Hp = s->size_y_cr + 2 * py;
+  int uv, j, i, y, k, rc;
+  if (!adapter_on(p_Vid) || !G.part_interpc || (fmt != YUV420 && fmt != YUV422) || p_Vid->p_Inp->OnTheFlyFractMCP ||
+      s->size_x != G.W || s->size_y != G.H || px != (JMHIP_PAD_X >> 1) || py != (fmt == YUV422 ? JMHIP_PAD_Y : JMHIP_PAD_Y >> 1)) {
+    G.n_passed++;
+    __real_getSubImagesChroma(p_Vid, s);
+    return;
+  }
+  if (!G.cplanes && !(G.cplanes = (uint16_t *)malloc((size_t)ny * 8 * Wp * Hp * sizeof(uint16_t)))) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+  k = slot_with_chroma(s);
+  for (uv = 0; uv < 2; uv++) {
+    if ((rc = jmhip_get_chroma_subplanes(G.ctx, k, uv, G.cplanes))) adapter_die("jmhip_get_chroma_subplanes", rc);
+    for (j = 0; j < ny; j++)
+      for (i = 0; i < 8; i++) {
+        const uint16_t *src = G.cplanes + (size_t)(j * 8 + i) * Wp * Hp;
+        imgpel **dst = s->p_img_sub[uv + 1][j][i];
+        for (y = 0; y < Hp; y++) memcpy(&dst[y - py][-px], src + (size_t)y * Wp, (size_t)Wp * sizeof(imgpel));
+      }
+  }
+  G.n_interpc++;
 }
 
 /* ------------------------------------------------------------------ current picture: uploaded once per coded picture */

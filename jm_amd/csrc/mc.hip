@@ -273,3 +273,53 @@ extern "C" int jmhip_tqc_rec_to_planes_dev(jmhip_ctx *ctx, const jmhip_me_job *d
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
 }
+
+// ---- K6: the chroma sub-images themselves (getSubImagesChroma, lencod/src/img_chroma.c:338-437), for callers that keep JM's host-side
+//      chroma prediction: sub-image (sy, sx) of a plane = the clamped bilinear blend above at every position of the padded plane.
+//      One thread per four horizontally adjacent samples; the integer plane (one per launch) stays in L2, the 64 (4:2:0) / 32 (4:2:2)
+//      output planes are a stream: HBM-bound on the stores.
+__global__ __launch_bounds__(256) void k_chroma_subplanes(const uint8_t *__restrict__ pl, int cw, int ch, int yuv, uint8_t *__restrict__ out)
+{
+  const int pad_x = JMHIP_PAD_X >> 1, pad_y = yuv == 2 ? JMHIP_PAD_Y : JMHIP_PAD_Y >> 1, ky = yuv == 2 ? 2 : 1;
+  const int Wp = cw + 2 * pad_x, Hp = ch + 2 * pad_y, W4 = Wp >> 2;                  // Wp is a multiple of 4 (cw is a multiple of 8)
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int x4 = (int)(t % W4), row = (int)((t / W4) % Hp), sub = (int)(t / ((long)W4 * Hp));
+  if (sub >= (yuv == 2 ? 32 : 64)) return;
+  const int sy = sub >> 3, sx = sub & 7, k = sy * ky, m = 8 - k;
+  const int w01 = m * sx, w00 = (m << 3) - w01, w11 = k * sx, w10 = (k << 3) - w11;
+  const int Y = row - pad_y, y0 = min(max(Y, 0), ch - 1), y1 = min(max(Y + 1, 0), ch - 1);
+  uint32_t w = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int X = 4 * x4 + i - pad_x, x0 = min(max(X, 0), cw - 1), x1 = min(max(X + 1, 0), cw - 1);
+    const int v = (w00 * pl[y0 * cw + x0] + w01 * pl[y0 * cw + x1] + w10 * pl[y1 * cw + x0] + w11 * pl[y1 * cw + x1] + 32) >> 6;
+    w |= (uint32_t)v << (8 * i);
+  }
+  *(uint32_t *)(out + ((long)sub * Hp + row) * Wp + 4 * x4) = w;
+}
+
+extern "C" int jmhip_get_chroma_subplanes(jmhip_ctx *ctx, int32_t slot, int32_t plane, uint16_t *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!out || slot < 0 || slot >= ctx->cfg.num_ref_slots || plane < 0 || plane > 1) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_get_chroma_subplanes: bad argument");
+  const int yuv = ctx->cfg.yuv_format;
+  if (yuv != 1 && yuv != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_get_chroma_subplanes: yuv_format %d (4:2:0 and 4:2:2 only)", yuv);
+  if (!ctx->d_refc[slot]) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_get_chroma_subplanes: reference slot %d has no chroma planes", slot);
+  const int pad_x = JMHIP_PAD_X >> 1, pad_y = yuv == 2 ? JMHIP_PAD_Y : JMHIP_PAD_Y >> 1, nsub = yuv == 2 ? 32 : 64;
+  const int Wp = ctx->cw + 2 * pad_x, Hp = ctx->ch + 2 * pad_y;
+  const size_t plane_px = (size_t)Wp * Hp;
+  if (plane_px > ctx->h_stage_bytes) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_get_chroma_subplanes: plane larger than staging");
+  void *dout; int r;
+  if ((r = jmhip_scratch(ctx, 1, plane_px * nsub, &dout))) return r;
+  const long threads = (long)(Wp >> 2) * Hp * nsub;
+  hipLaunchKernelGGL(k_chroma_subplanes, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint8_t *)ctx->d_refc[slot] + (size_t)plane * ctx->cw * ctx->ch, ctx->cw, ctx->ch, yuv, (uint8_t *)dout);
+  HIPCHK(ctx, hipGetLastError());
+  for (int k = 0; k < nsub; k++) {                         // back through the pinned staging area as u8, widened to imgpel on the host
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, (const uint8_t *)dout + (size_t)k * plane_px, plane_px, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint16_t *o = out + (size_t)k * plane_px;
+    for (size_t i = 0; i < plane_px; i++) o[i] = ctx->h_stage[i];
+  }
+  return JMHIP_OK;
+}

@@ -76,7 +76,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -136,7 +136,7 @@ class JmHip:
         rc = self.lib.jmhip_create(C.byref(self.h), C.byref(self.cfg))
         if rc != 0:
             raise JmHipError(f"jmhip_create failed ({rc}): {self.lib.jmhip_last_error(None).decode()}")
-        self.W, self.H, self.R = width, height, search_range
+        self.W, self.H, self.R, self.yuv_format = width, height, search_range, yuv_format
         p, r, s = C.c_int32(), C.c_int32(), C.c_int64()
         self._ck(self.lib.jmhip_plane_geometry(self.h, C.byref(p), C.byref(r), C.byref(s)))
         self.pitch, self.rows, self.plane_stride = p.value, r.value, s.value
@@ -341,6 +341,15 @@ class JmHip:
 
     def set_reference_chroma_dev(self, slot, d_u, d_v, pitch):
         self._ck(self.lib.jmhip_set_reference_chroma_dev(self.h, slot, _vp(d_u), _vp(d_v), pitch))
+
+    def get_chroma_subplanes(self, slot, plane):
+        """getSubImagesChroma (lencod/src/img_chroma.c:338) of plane 0 = U / 1 = V: (ny, 8, ch + 2 pad_y, cw + 2 pad_x) uint16"""
+        fmt = self.yuv_format
+        ny, pad_y = (4, 20) if fmt == 2 else (8, 10)
+        ch = self.H if fmt == 2 else self.H // 2
+        out = np.zeros((ny, 8, ch + 2 * pad_y, self.W // 2 + 32), np.uint16)
+        self._ck(self.lib.jmhip_get_chroma_subplanes(self.h, slot, plane, _vp(out)))
+        return out
 
     def mc_luma(self, blocks):
         """luma_prediction (lencod/src/mc_prediction.c:144), un-weighted; blocks: MC_LUMA_BLK array -> (n, 256) uint8, w*h samples first"""

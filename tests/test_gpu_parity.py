@@ -1038,3 +1038,31 @@ def test_intra_random_vs_oracle(J):
                 assert np.array_equal(out["pred"][k, md].reshape(16, 16), pred[md]), (k, md)
     assert len(ctx.intrapred4x4(b[:0])) == 0 and len(ctx.intra16_search(m[:0], orig[:0])) == 0
     ctx.close()
+
+
+# ---------------------------------------------------------------- K6: chroma sub-images
+@pytest.mark.parametrize("tag,fmt", [("a", 1), ("c", 2), ("e", 1)])
+def test_chroma_subplanes_golden_and_oracle(J, mcg, tag, fmt):
+    """k_chroma_subplanes == getSubImagesChroma: digests of every sub-image of the reference encoder's first reference picture, and the
+    oracle sample by sample"""
+    import hashlib
+    ctx = make_ctx(176, 144, fmt=fmt)
+    ctx.set_reference(0, mcg[f"{tag}_ref0_y"])
+    ctx.set_reference_chroma(0, mcg[f"{tag}_ref0_u"], mcg[f"{tag}_ref0_v"])
+    for pl, name in enumerate("uv"):
+        sub = ctx.get_chroma_subplanes(0, pl).astype(np.uint8)
+        sha = [hashlib.sha256(sub[j, i].tobytes()).hexdigest() for j in range(sub.shape[0]) for i in range(8)]
+        assert sha == list(mcg[tag + "_csub_sha"][pl]), (tag, name)
+        assert np.array_equal(sub, J.sub_images_chroma(mcg[f"{tag}_ref0_{name}"], fmt))
+    ctx.close()
+
+
+def test_chroma_subplanes_1080p_vs_oracle(J):
+    rng = np.random.default_rng(4)
+    w, h = 1920, 1088
+    ctx = make_ctx(w, h, fmt=1)
+    u, v = rng.integers(0, 256, (h // 2, w // 2)).astype(np.uint8), rng.integers(0, 256, (h // 2, w // 2)).astype(np.uint8)
+    ctx.set_reference(0, np.zeros((h, w), np.uint8)); ctx.set_reference_chroma(0, u, v)
+    got = ctx.get_chroma_subplanes(0, 1).astype(np.uint8)
+    assert np.array_equal(got, J.sub_images_chroma(v, 1))
+    ctx.close()
