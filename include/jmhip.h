@@ -142,6 +142,34 @@ typedef struct {
 } jmhip_cand;
 int jmhip_me_eval(jmhip_ctx *ctx, int32_t slot, const jmhip_cand *cands, int32_t n, int32_t *dist);
 
+/* The weighted and bi-predictive candidate distortions (me_distortion.c; MEBlock.computeBiPred{F,H,Q}Pel, lencod/inc/global.h:319-321,
+ * and MEBlock.computePred{F,H,Q}Pel when MEBlock.apply_weights, mv_search.c:741-768), full distortion << 5 without the early exit:
+ *   JMHIP_PRED_AVG     computeBiPred{SAD,SSE,SATD}1  :525 / :1353 / :943    p = (r1 + r2 + 1) >> 1
+ *   JMHIP_PRED_BI_WP   computeBiPred{SAD,SSE,SATD}2  :624 / :1438 / :1038   p = clip1(((w1*r1 + w2*r2 + round) >> shift) + offset)
+ *                      round = 2 * Slice.wp_luma_round, shift = Slice.luma_log_weight_denom + 1, weights = MEBlock.weight1 / weight2 / offsetBi
+ *   JMHIP_PRED_UNI_WP  compute{SAD,SSE,SATD}WP       :434 / :1261 / :833    p = clip1(((w1*r1 + round) >> shift) + offset)
+ *                      round = Slice.wp_luma_round, shift = Slice.luma_log_weight_denom, weights = MEBlock.weight_luma / offset_luma
+ *   JMHIP_PRED_UNI     compute{SAD,SSE,SATD}         :349 / :1190 / :745    p = r1
+ * All three metrics.  Luma only (MEBlock.ChromaMEEnable == 0).  computeBiPredSATD2's 8x8 path is reproduced with the source-pointer slip
+ * of me_distortion.c:1167 (every further row of an 8x8 sub-block starts one source sample earlier), because the reference's results carry it. */
+#define JMHIP_PRED_AVG    0
+#define JMHIP_PRED_BI_WP  1
+#define JMHIP_PRED_UNI_WP 2
+#define JMHIP_PRED_UNI    3
+typedef struct {
+  int16_t pos_x, pos_y;             /* block position, luma samples */
+  int16_t bsx, bsy;
+  int16_t cand_x[2], cand_y[2];     /* candidate MV per reference, relative to the block, quarter-pel ([1] unused for the UNI kinds) */
+  int8_t  slot[2];                  /* reference slot per list ([1] unused for the UNI kinds) */
+  int8_t  metric, test8x8;          /* JMHIP_METRIC_*; test8x8: 8x8 Hadamard sub-blocks */
+  int8_t  pred;                     /* JMHIP_PRED_* */
+  int8_t  shift;                    /* 0..8 */
+  int16_t weight[2], offset, round;
+  int16_t reserved_;
+} jmhip_pred_cand;                  /* 32 bytes */
+int jmhip_me_eval_pred(jmhip_ctx *ctx, const jmhip_pred_cand *cands, int32_t n, int32_t *dist);
+int jmhip_me_eval_pred_dev(jmhip_ctx *ctx, const jmhip_pred_cand *d_cands, int32_t n, int32_t *d_dist);
+
 /* sub_pel_motion_estimation (me_fullsearch.c:186-289, Macroblock.SubPelME) for RDOptimization != 0:
  * up to 9 half-pel then 9 quarter-pel candidates around `mv`. */
 typedef struct {

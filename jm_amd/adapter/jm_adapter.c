@@ -55,7 +55,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -67,7 +67,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp;
 } G;
 
 static void adapter_report(void)
@@ -77,9 +77,10 @@ static void adapter_report(void)
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
                   "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld; "
-                  "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches; getSubImagesChroma on the MI355X: %ld\n",
+                  "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches; getSubImagesChroma on the MI355X: %ld; "
+                  "weighted / bi-predictive candidate distortions on the MI355X: %ld\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
-          G.n_ip4, G.n_i16, G.n_interpc);
+          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -121,7 +122,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
-    G.part_interpc = has_part(parts, "interpc");
+    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -428,6 +429,76 @@ distblk __wrap_computeSATD(StorablePicture *ref1, MEBlock *mv_block, distblk min
 {
   return eval_candidate(ref1, mv_block, min_mcost, cand, JMHIP_METRIC_SATD, __real_computeSATD);
 }
+
+/* ------------------------------------------------------------------ weighted / bi-predictive candidate distortions
+ * compute{SAD,SATD,SSE}WP (me_distortion.c:434 / :833 / :1261; MEBlock.computePred{F,H,Q}Pel when MEBlock.apply_weights), computeSSE (:1190) and
+ * computeBiPred{SAD,SATD,SSE}1 / 2 (:525 / :943 / :1353 un-weighted, :624 / :1038 / :1438 weighted; MEBlock.computeBiPred{F,H,Q}Pel), reached
+ * through p_Dpb->pf_compute* (lencod.c:355-366) by JM's bi-predictive searches and by every search of a weighted slice.  The weights are read
+ * where the reference's functions read them: MEBlock.weight_luma / offset_luma, MEBlock.weight1 / weight2 / offsetBi, Slice.wp_luma_round and
+ * Slice.luma_log_weight_denom.  Same early-exit rule as eval_candidate. */
+static int pred_candidate_ok(StorablePicture *ref, MEBlock *mv_block, int metric)
+{
+  VideoParameters *p_Vid = mv_block->p_Vid;
+  const int bsx = mv_block->blocksize_x, bsy = mv_block->blocksize_y;
+  return !G.in_real_me && adapter_on(p_Vid) && G.part_evalp && G.n_cur != 0 && p_Vid->structure == FRAME && !mv_block->ChromaMEEnable &&
+         ref && ref->size_x == G.W && ref->size_y == G.H && (bsx == 4 || bsx == 8 || bsx == 16) && (bsy == 4 || bsy == 8 || bsy == 16) &&
+         !(metric == JMHIP_METRIC_SATD && mv_block->test8x8 && (bsx < 8 || bsy < 8));
+}
+static int rel_mv(MEBlock *mv_block, MotionVector *cand, int16_t *rx, int16_t *ry)
+{
+  const int x = cand->mv_x - (mv_block->pos_x << 2), y = cand->mv_y - (mv_block->pos_y << 2);
+  if (x < -32768 || x > 32767 || y < -32768 || y > 32767) return 0;
+  *rx = (int16_t)x; *ry = (int16_t)y;
+  return 1;
+}
+static distblk eval_pred_candidate(StorablePicture *ref1, StorablePicture *ref2, MEBlock *mv_block, distblk min_mcost, MotionVector *cand1,
+                                   MotionVector *cand2, int metric, int pred, int *handled)
+{
+  Slice *currSlice = mv_block->p_Slice;
+  jmhip_pred_cand c;
+  int32_t dist;
+  int rc;
+  const int two = pred == JMHIP_PRED_AVG || pred == JMHIP_PRED_BI_WP;
+  *handled = 0;
+  memset(&c, 0, sizeof c);
+  if (!pred_candidate_ok(ref1, mv_block, metric) || (two && !pred_candidate_ok(ref2, mv_block, metric)) ||
+      !rel_mv(mv_block, cand1, &c.cand_x[0], &c.cand_y[0]) || (two && !rel_mv(mv_block, cand2, &c.cand_x[1], &c.cand_y[1])) ||
+      currSlice->luma_log_weight_denom < 0 || currSlice->luma_log_weight_denom > 7) {
+    G.n_passed++;
+    return 0;
+  }
+  c.pos_x = mv_block->pos_x; c.pos_y = mv_block->pos_y; c.bsx = mv_block->blocksize_x; c.bsy = mv_block->blocksize_y;
+  c.metric = (int8_t)metric; c.test8x8 = (int8_t)(mv_block->test8x8 != 0); c.pred = (int8_t)pred;
+  c.slot[0] = (int8_t)slot_of_reference(ref1);
+  if (two) c.slot[1] = (int8_t)slot_of_reference(ref2);
+  if (pred == JMHIP_PRED_BI_WP) {
+    c.weight[0] = mv_block->weight1; c.weight[1] = mv_block->weight2; c.offset = mv_block->offsetBi;
+    c.round = (int16_t)(2 * currSlice->wp_luma_round); c.shift = (int8_t)(currSlice->luma_log_weight_denom + 1);
+  } else if (pred == JMHIP_PRED_UNI_WP) {
+    c.weight[0] = mv_block->weight_luma; c.offset = mv_block->offset_luma;
+    c.round = (int16_t)currSlice->wp_luma_round; c.shift = (int8_t)currSlice->luma_log_weight_denom;
+  }
+  if ((rc = jmhip_me_eval_pred(G.ctx, &c, 1, &dist))) adapter_die("jmhip_me_eval_pred", rc);
+  G.n_evalp++;
+  *handled = 1;
+  return ((distblk)dist >> 5) > (min_mcost >> 5) ? min_mcost : (distblk)dist;
+}
+#define WRAP_UNI(fn, metric, pred) \
+  extern distblk __real_##fn(StorablePicture *, MEBlock *, distblk, MotionVector *); \
+  distblk __wrap_##fn(StorablePicture *ref1, MEBlock *mv_block, distblk min_mcost, MotionVector *cand) \
+  { int done; distblk d = eval_pred_candidate(ref1, NULL, mv_block, min_mcost, cand, NULL, metric, pred, &done); \
+    return done ? d : __real_##fn(ref1, mv_block, min_mcost, cand); }
+#define WRAP_BI(fn, metric, pred) \
+  extern distblk __real_##fn(StorablePicture *, StorablePicture *, MEBlock *, distblk, MotionVector *, MotionVector *); \
+  distblk __wrap_##fn(StorablePicture *ref1, StorablePicture *ref2, MEBlock *mv_block, distblk min_mcost, MotionVector *cand1, MotionVector *cand2) \
+  { int done; distblk d = eval_pred_candidate(ref1, ref2, mv_block, min_mcost, cand1, cand2, metric, pred, &done); \
+    return done ? d : __real_##fn(ref1, ref2, mv_block, min_mcost, cand1, cand2); }
+WRAP_UNI(computeSADWP, JMHIP_METRIC_SAD, JMHIP_PRED_UNI_WP) WRAP_UNI(computeSATDWP, JMHIP_METRIC_SATD, JMHIP_PRED_UNI_WP)
+WRAP_UNI(computeSSEWP, JMHIP_METRIC_SSE, JMHIP_PRED_UNI_WP) WRAP_UNI(computeSSE, JMHIP_METRIC_SSE, JMHIP_PRED_UNI)
+WRAP_BI(computeBiPredSAD1, JMHIP_METRIC_SAD, JMHIP_PRED_AVG) WRAP_BI(computeBiPredSATD1, JMHIP_METRIC_SATD, JMHIP_PRED_AVG)
+WRAP_BI(computeBiPredSSE1, JMHIP_METRIC_SSE, JMHIP_PRED_AVG)
+WRAP_BI(computeBiPredSAD2, JMHIP_METRIC_SAD, JMHIP_PRED_BI_WP) WRAP_BI(computeBiPredSATD2, JMHIP_METRIC_SATD, JMHIP_PRED_BI_WP)
+WRAP_BI(computeBiPredSSE2, JMHIP_METRIC_SSE, JMHIP_PRED_BI_WP)
 
 /* ------------------------------------------------------------------ luma intra prediction
  * get_intrapred_4x4 (lencod/src/intra4x4.c:521) and the Intra16x16 mode search find_sad_16x16_JM (intra16x16.c:463; Slice.find_sad_16x16,

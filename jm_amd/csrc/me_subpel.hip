@@ -120,6 +120,98 @@ __global__ __launch_bounds__(256) void k_me_eval(const jmhip_cand *__restrict__ 
   dist[i] = d << 5;
 }
 
+// ---- weighted / bi-predictive candidates: compute{SAD,SSE,SATD}WP, computeBiPred{SAD,SSE,SATD}1 / 2 (me_distortion.c:434-1530)
+// One 16-lane group per candidate.  SAD / SSE: lane l sums sample row l (one UMVLine4X origin per reference for the whole block);
+// SATD: lane l takes sub-block l (its own origin per reference per sub-block, as the reference fetches them); the group adds up.
+struct SlotBases { const uint8_t *p[32]; };
+static_assert(sizeof(jmhip_pred_cand) == 32, "jmhip_pred_cand is 32 bytes in include/jmhip.h");
+
+struct PredSrc { const uint8_t *r1, *r2; int pitch, kind, w1, w2, off, rnd, sh; };
+__device__ __forceinline__ int pred_at(const PredSrc &p, int j, int i)
+{
+  const int a = p.r1[(long)j * p.pitch + i];
+  if (p.kind == JMHIP_PRED_UNI) return a;
+  if (p.kind == JMHIP_PRED_UNI_WP) return min(max(((p.w1 * a + p.rnd) >> p.sh) + p.off, 0), 255);
+  const int b = p.r2[(long)j * p.pitch + i];
+  if (p.kind == JMHIP_PRED_AVG) return (a + b + 1) >> 1;
+  return min(max(((p.w1 * a + p.w2 * b + p.rnd) >> p.sh) + p.off, 0), 255);
+}
+
+__global__ __launch_bounds__(64) void k_me_eval_pred(const jmhip_pred_cand *__restrict__ cands, int n, int32_t *__restrict__ dist, SlotBases slots, int nslots,
+                                                     PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
+{
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const bool live = g < n;
+  const jmhip_pred_cand c = cands[live ? g : 0];
+  const bool two = c.pred == JMHIP_PRED_AVG || c.pred == JMHIP_PRED_BI_WP;
+  const int s1 = c.slot[0], s2 = two ? c.slot[1] : c.slot[0];
+  const bool ok = live && s1 >= 0 && s1 < nslots && s2 >= 0 && s2 < nslots;
+  PlaneSet pa = ps, pb = ps;
+  pa.base = slots.p[ok ? s1 : 0]; pb.base = slots.p[ok ? s2 : 0];
+  PredSrc p; p.pitch = ps.pitch; p.kind = c.pred; p.w1 = c.weight[0]; p.w2 = c.weight[1]; p.off = c.offset; p.rnd = c.round; p.sh = c.shift;
+  const uint8_t *cu = cur + (long)c.pos_y * cur_pitch + c.pos_x;
+  const int q1x = (c.pos_x << 2) + c.cand_x[0], q1y = (c.pos_y << 2) + c.cand_y[0];
+  const int q2x = two ? (c.pos_x << 2) + c.cand_x[1] : q1x, q2y = two ? (c.pos_y << 2) + c.cand_y[1] : q1y;
+  int acc = 0;
+  if (c.metric != JMHIP_METRIC_SATD) {
+    if (l < c.bsy) {
+      p.r1 = umv_line(pa, q1y, q1x); p.r2 = umv_line(pb, q2y, q2x);
+      for (int x = 0; x < c.bsx; x++) {
+        const int d = (int)cu[l * cur_pitch + x] - pred_at(p, l, x);
+        acc += c.metric == JMHIP_METRIC_SAD ? iabs_(d) : d * d;
+      }
+    }
+  } else if (!c.test8x8) {
+    const int nbx = c.bsx >> 2;
+    if (l < nbx * (c.bsy >> 2)) {
+      const int y = (l / nbx) * 4, x = (l % nbx) * 4;
+      p.r1 = umv_line(pa, q1y + 4 * y, q1x + 4 * x); p.r2 = umv_line(pb, q2y + 4 * y, q2x + 4 * x);
+      int d[16];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[4 * j + i] = (int)cu[(y + j) * cur_pitch + x + i] - pred_at(p, j, i);
+      acc = hadamard4(d);
+    }
+  } else {
+    const int nbx = c.bsx >> 3;
+    if (l < nbx * (c.bsy >> 3)) {
+      const int y = (l / nbx) * 8, x = (l % nbx) * 8;
+      p.r1 = umv_line(pa, q1y + 4 * y, q1x + 4 * x); p.r2 = umv_line(pb, q2y + 4 * y, q2x + 4 * x);
+      // me_distortion.c:1167: computeBiPredSATD2 reads the eighth source sample of a row without advancing, so row j of the sub-block is
+      // read j samples early in the block's row-major copy (bsx samples per row): sample k = (y + j) * bsx + x + i - j
+      const int slip = c.pred == JMHIP_PRED_BI_WP, lg = c.bsx == 16 ? 4 : 3;
+      int m[8][8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int k = ((y + j) << lg) + x + i - slip * j;
+          v[i] = (int)cu[(k >> lg) * cur_pitch + (k & (c.bsx - 1))] - pred_at(p, j, i);
+        }
+        had8_1d(v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[j][i] = v[i];
+      }
+      int s = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = m[j][i];
+        had8_1d(v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += iabs_(v[j]);
+      }
+      acc = (s + 2) >> 2;
+    }
+  }
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
+  if (live && l == 0) dist[g] = ok ? acc << 5 : -1;
+}
+
 // JM's 3x3 spiral (mv_search.c:405-442 with search_range 1): position index -> (dx,dy)
 __device__ __constant__ int8_t c_sp9[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
 
@@ -277,6 +369,50 @@ extern "C" int jmhip_me_eval(jmhip_ctx *ctx, int32_t slot, const jmhip_cand *can
   HIPCHK(ctx, hipMemcpyAsync(dc, cands, sizeof(jmhip_cand) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_me_eval, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const jmhip_cand *)dc, n, (int32_t *)dd, planes_of(ctx, slot), ctx->d_cur, ctx->cur_pitch);
   HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(dist, dd, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+static int launch_eval_pred(jmhip_ctx *ctx, const jmhip_pred_cand *d_cands, int n, int32_t *d_dist)
+{
+  SlotBases sb;
+  for (int k = 0; k < 32; k++) sb.p[k] = k < ctx->cfg.num_ref_slots ? ctx->d_sub[k] : nullptr;
+  hipLaunchKernelGGL(k_me_eval_pred, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, d_cands, n, d_dist, sb, (int)ctx->cfg.num_ref_slots,
+                     planes_of(ctx, 0), ctx->d_cur, ctx->cur_pitch);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+// d_cands are not validated (device memory): a slot outside the context yields dist = -1 for that candidate
+extern "C" int jmhip_me_eval_pred_dev(jmhip_ctx *ctx, const jmhip_pred_cand *d_cands, int32_t n, int32_t *d_dist)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!d_cands || !d_dist || n < 0) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_eval_pred_dev: bad argument");
+  if (n == 0) return JMHIP_OK;
+  return launch_eval_pred(ctx, d_cands, n, d_dist);
+}
+
+extern "C" int jmhip_me_eval_pred(jmhip_ctx *ctx, const jmhip_pred_cand *cands, int32_t n, int32_t *dist)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!cands || !dist || n < 0) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_eval_pred: bad argument");
+  if (n == 0) return JMHIP_OK;
+  int r;
+  for (int i = 0; i < n; i++) {
+    const jmhip_pred_cand &c = cands[i];
+    if ((r = check_block(ctx, i, c.pos_x, c.pos_y, c.bsx, c.bsy))) return r;
+    const bool two = c.pred == JMHIP_PRED_AVG || c.pred == JMHIP_PRED_BI_WP;
+    if (c.pred < 0 || c.pred > JMHIP_PRED_UNI || (c.metric != JMHIP_METRIC_SAD && c.metric != JMHIP_METRIC_SSE && c.metric != JMHIP_METRIC_SATD) ||
+        c.shift < 0 || c.shift > 8 || c.slot[0] < 0 || c.slot[0] >= ctx->cfg.num_ref_slots || (two && (c.slot[1] < 0 || c.slot[1] >= ctx->cfg.num_ref_slots)) ||
+        (c.metric == JMHIP_METRIC_SATD && c.test8x8 && ((c.bsx & 7) || (c.bsy & 7))))
+      return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_eval_pred: candidate %d: bad prediction kind, metric, shift, slot or 8x8 sub-blocks on a block that is not a multiple of 8", i);
+  }
+  void *dc, *dd;
+  if ((r = jmhip_scratch(ctx, 0, sizeof(jmhip_pred_cand) * (size_t)n, &dc))) return r;
+  if ((r = jmhip_scratch(ctx, 1, sizeof(int32_t) * (size_t)n, &dd))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(dc, cands, sizeof(jmhip_pred_cand) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if ((r = launch_eval_pred(ctx, (const jmhip_pred_cand *)dc, n, (int32_t *)dd))) return r;
   HIPCHK(ctx, hipMemcpyAsync(dist, dd, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;

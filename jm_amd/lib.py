@@ -29,6 +29,10 @@ ME_BEST = np.dtype([("mv_x", "<i2"), ("mv_y", "<i2"), ("cost", "<i4")])
 ME_RESULT = np.dtype([("best", ME_BEST, (NPART,))])
 CAND = np.dtype([("pos_x", "<i2"), ("pos_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"), ("cand_x", "<i2"), ("cand_y", "<i2"),
                  ("metric", "<i2"), ("test8x8", "<i2")])
+PRED_CAND = np.dtype([("pos_x", "<i2"), ("pos_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"), ("cand_x", "<i2", (2,)), ("cand_y", "<i2", (2,)),
+                      ("slot", "i1", (2,)), ("metric", "i1"), ("test8x8", "i1"), ("pred", "i1"), ("shift", "i1"),
+                      ("weight", "<i2", (2,)), ("offset", "<i2"), ("round", "<i2"), ("reserved_", "<i2")])
+PRED_AVG, PRED_BI_WP, PRED_UNI_WP, PRED_UNI = 0, 1, 2, 3
 SUBPEL_JOB = np.dtype([("pos_x", "<i2"), ("pos_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"), ("pred_x", "<i2"), ("pred_y", "<i2"),
                        ("mv_x", "<i2"), ("mv_y", "<i2"), ("lambda_h", "<i4"), ("lambda_q", "<i4"), ("metric_h", "i1"),
                        ("metric_q", "i1"), ("start_hp", "i1"), ("start_qp", "i1"), ("test8x8", "i1"), ("reserved_", "i1", (3,)),
@@ -68,12 +72,12 @@ I16_MB = np.dtype([("edge", "u1", (33,)), ("left", "u1"), ("up", "u1"), ("mode_m
 I16_OUT = np.dtype([("cost", "<i8"), ("mode", "<i4"), ("reserved_", "<i4"), ("pred", "u1", (4, 256))])
 assert IP4_BLK.itemsize == 16 and I16_MB.itemsize == 40 and I16_OUT.itemsize == 1040
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
-assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16
+assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
 EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_plane_geometry",
            "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_reference", "jmhip_set_reference_dev",
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
-           "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
+           "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
@@ -216,6 +220,16 @@ class JmHip:
         out = np.zeros(len(cands), np.int32)
         self._ck(self.lib.jmhip_me_eval(self.h, slot, _vp(cands), len(cands), _vp(out)))
         return out
+
+    def me_eval_pred(self, cands):
+        """weighted / bi-predictive candidate distortions (compute*WP, computeBiPred*1 / *2): PRED_CAND records -> distortion << 5"""
+        cands = np.ascontiguousarray(cands, PRED_CAND)
+        out = np.zeros(len(cands), np.int32)
+        self._ck(self.lib.jmhip_me_eval_pred(self.h, _vp(cands), len(cands), _vp(out)))
+        return out
+
+    def me_eval_pred_dev(self, d_cands, n, d_out):
+        self._ck(self.lib.jmhip_me_eval_pred_dev(self.h, C.c_void_p(d_cands), n, C.c_void_p(d_out)))
 
     def me_subpel(self, slot, jobs):
         jobs = np.ascontiguousarray(jobs, SUBPEL_JOB)

@@ -61,6 +61,13 @@ jmo_dist jmo_compute_sad (const jmo_refpic *ref, const jmo_pel *orig, int bsx, i
 jmo_dist jmo_compute_satd(const jmo_refpic *ref, const jmo_pel *orig, int bsx, int bsy,
                           int test8x8, jmo_dist min_mcost, int cand_x, int cand_y);
 
+/* weighted / bi-predictive candidate distortions, me_distortion.c:434-740, :833-1180, :1261-1530 (luma only).
+ * pred: 0 = BiPred*1 (average), 1 = BiPred*2 (weighted), 2 = *WP (one weighted reference), 3 = plain; metric: 0 SAD, 1 SSE, 2 SATD */
+typedef struct { int weight[2], offset, round, shift; } jmo_wp;
+jmo_dist jmo_compute_pred_dist(const jmo_refpic *ref1, const jmo_refpic *ref2, const jmo_pel *orig, int bsx, int bsy, int test8x8,
+                               int metric, int pred, const jmo_wp *wp, int max_pel, jmo_dist min_mcost,
+                               int cand1_x, int cand1_y, int cand2_x, int cand2_y);
+
 /* ---- integer-pel search ---- */
 typedef struct {
   int pos_x, pos_y;          /* block position in the picture, full-pel (MEBlock.pos_x/pos_y) */

@@ -142,6 +142,68 @@ jmo_dist jmo_compute_satd(const jmo_refpic *ref, const jmo_pel *orig, int bsx, i
   return ((jmo_dist)mcost) << JMO_LAMBDA_BITS;
 }
 
+/* The weighted / bi-predictive candidate distortions of lencod/src/me_distortion.c (luma only: ChromaMEEnable = 0):
+ *   pred 0  computeBiPred{SAD,SATD,SSE}1  :525 / :943 / :1353   p = (r1 + r2 + 1) >> 1
+ *   pred 1  computeBiPred{SAD,SATD,SSE}2  :624 / :1038 / :1438  p = clip1(((w1*r1 + w2*r2 + round) >> shift) + offset),
+ *                                                              round = 2*wp_luma_round, shift = luma_log_weight_denom + 1
+ *   pred 2  compute{SAD,SATD,SSE}WP       :434 / :833 / :1261   p = clip1(((w1*r1 + round) >> shift) + offset),
+ *                                                              round = wp_luma_round, shift = luma_log_weight_denom
+ *   pred 3  compute{SAD,SATD,SSE}         :349 / :745 / :1190   p = r1
+ * metric 0 = SAD, 1 = SSE, 2 = SATD.  SAD / SSE: one UMVLine4X origin per reference and an early exit per sample row; SATD: one origin
+ * per reference per 4x4 (8x8 when test8x8) sub-block and an early exit per sub-block.  The early exits return min_mcost itself. */
+static inline int pred_sample(int pred, int r1, int r2, const jmo_wp *wp, int max_pel)
+{
+  int v;
+  switch (pred) {
+  case 0: return (r1 + r2 + 1) >> 1;
+  case 1: v = ((wp->weight[0] * r1 + wp->weight[1] * r2 + wp->round) >> wp->shift) + wp->offset; break;
+  case 2: v = ((wp->weight[0] * r1 + wp->round) >> wp->shift) + wp->offset; break;
+  default: return r1;
+  }
+  return v < 0 ? 0 : (v > max_pel ? max_pel : v);
+}
+
+jmo_dist jmo_compute_pred_dist(const jmo_refpic *ref1, const jmo_refpic *ref2, const jmo_pel *orig, int bsx, int bsy, int test8x8,
+                               int metric, int pred, const jmo_wp *wp, int max_pel, jmo_dist min_mcost,
+                               int cand1_x, int cand1_y, int cand2_x, int cand2_y)
+{
+  const int imin_cost = (int)(min_mcost >> JMO_LAMBDA_BITS);
+  const int two = pred < 2;
+  int mcost = 0, x, y, i, j;
+  if (metric != 2) {
+    const jmo_pel *r1 = umv_line4x(ref1, cand1_y, cand1_x);
+    const jmo_pel *r2 = two ? umv_line4x(ref2, cand2_y, cand2_x) : r1;
+    const long p2 = two ? ref2->pitch : ref1->pitch;
+    for (y = 0; y < bsy; y++) {
+      for (x = 0; x < bsx; x++) {
+        int d = (int)orig[y * bsx + x] - pred_sample(pred, r1[(long)y * ref1->pitch + x], r2[y * p2 + x], wp, max_pel);
+        mcost += metric == 0 ? iabs_(d) : d * d;
+      }
+      if (mcost > imin_cost) return min_mcost;
+    }
+  } else {
+    const int bs = test8x8 ? 8 : 4;
+    int16_t diff[64];
+    for (y = 0; y < bsy; y += bs)
+      for (x = 0; x < bsx; x += bs) {
+        const jmo_pel *r1 = umv_line4x(ref1, cand1_y + (y << 2), cand1_x + (x << 2));
+        const jmo_pel *r2 = two ? umv_line4x(ref2, cand2_y + (y << 2), cand2_x + (x << 2)) : r1;
+        const long p2 = two ? ref2->pitch : ref1->pitch;
+        const jmo_pel *sl = orig + y * bsx + x;
+        /* computeBiPredSATD2's 8x8 path reads the eighth source sample of a row without advancing the pointer (me_distortion.c:1167,
+         * `*src_line` where the other seven have `*src_line++`), so every further row of the sub-block starts one source sample earlier:
+         * row j is read from sl + j*(bsx - 1).  The reference's results -- and so the bitstream -- carry that; it is restated as is. */
+        const int src_pitch = (pred == 1 && test8x8) ? bsx - 1 : bsx;
+        for (j = 0; j < bs; j++)
+          for (i = 0; i < bs; i++)
+            diff[j * bs + i] = (int16_t)((int)sl[j * src_pitch + i] - pred_sample(pred, r1[(long)j * ref1->pitch + i], r2[j * p2 + i], wp, max_pel));
+        mcost += test8x8 ? jmo_hadamard_sad8x8(diff) : jmo_hadamard_sad4x4(diff);
+        if (mcost > imin_cost) return min_mcost;
+      }
+  }
+  return ((jmo_dist)mcost) << JMO_LAMBDA_BITS;
+}
+
 /* mv_cost, lencod/inc/mv_search.h:100-112 (JCOST_CALC_SCALEUP) */
 static inline jmo_dist mv_cost(int lambda, int cx, int cy, int px, int py)
 {

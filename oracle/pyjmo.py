@@ -64,6 +64,13 @@ class DbMotion(C.Structure):
     _fields_ = [("mv", (C.c_int16 * 2) * 2), ("ref_id", C.c_int32 * 2)]
 
 
+class WP(C.Structure):
+    _fields_ = [("weight", C.c_int * 2), ("offset", C.c_int), ("round", C.c_int), ("shift", C.c_int)]
+
+
+L.jmo_compute_pred_dist.restype = C.c_int64
+L.jmo_compute_pred_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
 L.jmo_full_search.restype = C.c_int64
 L.jmo_compute_sad.restype = C.c_int64
 L.jmo_compute_satd.restype = C.c_int64
@@ -286,6 +293,18 @@ def deblock_frame(y, u, v, fmt, mbs, mot, maxy=255, maxc=255, d8=1):
     L.jmo_deblock_frame(_p(Y), w, _p(U) if U is not None else None, _p(V) if V is not None else None,
                         U.shape[1] if U is not None else 0, w, h, fmt, arr, _p(mo_bytes), maxy, maxc, d8)
     return Y, U, V
+
+
+PRED_AVG, PRED_BI_WP, PRED_UNI_WP, PRED_UNI = 0, 1, 2, 3
+
+
+def pred_dist(ref1, ref2, orig, bsx, bsy, test8x8, metric, pred, weights, min_mcost, cand1, cand2, max_pel=255):
+    """computeBiPred{SAD,SSE,SATD}1 / 2, compute{SAD,SSE,SATD}WP, compute{SAD,SSE,SATD} (me_distortion.c) for one candidate (pair).
+    weights = (w1, w2, offset, round, shift) exactly as the formula uses them; cand* absolute quarter-pel positions."""
+    wp = WP((C.c_int * 2)(int(weights[0]), int(weights[1])), int(weights[2]), int(weights[3]), int(weights[4]))
+    orig = np.ascontiguousarray(orig, np.uint16)
+    return int(L.jmo_compute_pred_dist(ref1.ptr(), (ref2 or ref1).ptr(), _p(orig), int(bsx), int(bsy), int(test8x8), int(metric), int(pred),
+                                       C.byref(wp), int(max_pel), int(min_mcost), int(cand1[0]), int(cand1[1]), int(cand2[0]), int(cand2[1])))
 
 
 # ---- motion-compensated prediction (jmo_mc.c)

@@ -790,3 +790,44 @@ void __wrap_select_transform(Macroblock *currMB)
   if (currMB->residual_transform_quant_chroma_4x4[0] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[0] = tap_rtq_chroma;
   if (currMB->residual_transform_quant_chroma_4x4[1] == residual_transform_quant_chroma_4x4) currMB->residual_transform_quant_chroma_4x4[1] = tap_rtq_chroma;
 }
+
+/* ------------------------------------------------------------------ weighted / bi-predictive candidate distortions: call counts
+ *   compute{SAD,SATD,SSE}WP, computeBiPred{SAD,SATD,SSE}1 / 2     lencod/src/me_distortion.c:434-1530
+ * Which of them a configuration reaches, and with which weights (the distinct (w1, w2, offset, denominator) tuples, first 64), written
+ * to dist_calls.txt at exit.  Their arithmetic is pinned by direct calls (oracle/ref_call.c); this tap tells which configurations are
+ * worth running end to end. */
+#include "me_distortion.h"
+static long g_dist_calls[9];
+static int g_wp_seen[64][5], g_wp_n;
+static void dist_report(void)
+{
+  static const char *nm[9] = {"computeSADWP", "computeSATDWP", "computeSSEWP", "computeBiPredSAD1", "computeBiPredSATD1", "computeBiPredSSE1",
+                              "computeBiPredSAD2", "computeBiPredSATD2", "computeBiPredSSE2"};
+  FILE *f = tap_open("dist_calls.txt");
+  int k;
+  for (k = 0; k < 9; k++) fprintf(f, "%s %ld\n", nm[k], g_dist_calls[k]);
+  for (k = 0; k < g_wp_n; k++) fprintf(f, "weights kind=%d w1=%d w2=%d offset=%d log_denom=%d\n", g_wp_seen[k][0], g_wp_seen[k][1], g_wp_seen[k][2], g_wp_seen[k][3], g_wp_seen[k][4]);
+  fclose(f);
+}
+static void dist_count(int which, MEBlock *mb, int bi)
+{
+  static int hooked = 0;
+  int t[5], k;
+  if (!hooked) { hooked = 1; atexit(dist_report); }
+  g_dist_calls[which]++;
+  t[0] = bi; t[1] = bi ? mb->weight1 : mb->weight_luma; t[2] = bi ? mb->weight2 : 0; t[3] = bi ? mb->offsetBi : mb->offset_luma;
+  t[4] = mb->p_Slice->luma_log_weight_denom;
+  if (bi == 2) return;                                                        /* the un-weighted average reads no weights */
+  for (k = 0; k < g_wp_n; k++) if (!memcmp(g_wp_seen[k], t, sizeof t)) return;
+  if (g_wp_n < 64) memcpy(g_wp_seen[g_wp_n++], t, sizeof t);
+}
+#define TAP_UNI(fn, idx) \
+  extern distblk __real_##fn(StorablePicture *, MEBlock *, distblk, MotionVector *); \
+  distblk __wrap_##fn(StorablePicture *r, MEBlock *mb, distblk m, MotionVector *c) { dist_count(idx, mb, 0); return __real_##fn(r, mb, m, c); }
+#define TAP_BI(fn, idx, kind) \
+  extern distblk __real_##fn(StorablePicture *, StorablePicture *, MEBlock *, distblk, MotionVector *, MotionVector *); \
+  distblk __wrap_##fn(StorablePicture *r1, StorablePicture *r2, MEBlock *mb, distblk m, MotionVector *c1, MotionVector *c2) \
+  { dist_count(idx, mb, kind); return __real_##fn(r1, r2, mb, m, c1, c2); }
+TAP_UNI(computeSADWP, 0) TAP_UNI(computeSATDWP, 1) TAP_UNI(computeSSEWP, 2)
+TAP_BI(computeBiPredSAD1, 3, 2) TAP_BI(computeBiPredSATD1, 4, 2) TAP_BI(computeBiPredSSE1, 5, 2)
+TAP_BI(computeBiPredSAD2, 6, 1) TAP_BI(computeBiPredSATD2, 7, 1) TAP_BI(computeBiPredSSE2, 8, 1)

@@ -334,6 +334,10 @@ def main():
             "G3b": ("encoder_main.cfg", dict(SearchMode=3, Transform8x8Mode=1, ProfileIDC=100)),
             "G4q": ("encoder_baseline.cfg", dict(SearchMode=-1, SearchRange=16, SliceMode=1, SliceArgument=33, AdaptiveRounding=0)),
             "G5": ("encoder_yuv422.cfg", dict(NumberBFrames=0)),
+            # explicit weighted prediction in P and B pictures: compute*WP and computeBiPred*2 with the weights JM estimates (33 / -5, 33+32 / -2);
+            # with the 8x8 transform computeBiPredSATD2 takes its 8x8 path (me_distortion.c:1113-1175)
+            "G3w": ("encoder_main.cfg", dict(SearchMode=3, WeightedPrediction=1, WeightedBiprediction=1)),
+            "G3wb": ("encoder_main.cfg", dict(SearchMode=3, WeightedPrediction=1, WeightedBiprediction=1, Transform8x8Mode=1, ProfileIDC=100)),
         }
         for tag, (cfg, o) in runs.items():
             w = os.path.join(tmp, tag); os.makedirs(w)

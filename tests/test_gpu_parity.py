@@ -1066,3 +1066,97 @@ def test_chroma_subplanes_1080p_vs_oracle(J):
     got = ctx.get_chroma_subplanes(0, 1).astype(np.uint8)
     assert np.array_equal(got, J.sub_images_chroma(v, 1))
     ctx.close()
+
+
+# ---------------------------------------------------------------- weighted / bi-predictive candidate distortions
+def pred_cands_from_records(recs):
+    """tests/golden/pred_dist.npz rows -> PRED_CAND records (slot 0 = ref1, slot 1 = ref2); (round, shift) as the reference derives them"""
+    from jm_amd.lib import PRED_CAND, PRED_BI_WP
+    c = np.zeros(len(recs), PRED_CAND)
+    for k, r in enumerate(recs):
+        bi = r["pred"] == PRED_BI_WP
+        c[k]["pos_x"], c[k]["pos_y"], c[k]["bsx"], c[k]["bsy"] = r["pos_x"], r["pos_y"], r["bsx"], r["bsy"]
+        c[k]["cand_x"], c[k]["cand_y"] = (r["c1x"], r["c2x"]), (r["c1y"], r["c2y"])
+        c[k]["slot"] = (0, 1)
+        c[k]["metric"], c[k]["test8x8"], c[k]["pred"] = r["metric"], r["test8x8"], r["pred"]
+        c[k]["weight"], c[k]["offset"] = (r["w1"], r["w2"]), r["offset"]
+        c[k]["round"], c[k]["shift"] = (2 * r["wp_round"], r["log_denom"] + 1) if bi else (r["wp_round"], r["log_denom"])
+    return c
+
+
+def test_eval_pred_matches_the_reference_records():
+    """k_me_eval_pred against the values the REAL reference's compute*WP / computeBiPred*1 / *2 / compute* returned
+    (tests/golden/pred_dist.npz, made by make_pred_dist.py through oracle/ref_call.c): all 16 kinds x metrics, 900 candidates,
+    computeBiPredSATD2's 8x8 source-pointer slip included."""
+    g = np.load(os.path.join(G, "pred_dist.npz"))
+    cols = [str(c) for c in g["columns"]]
+    recs = [dict(zip(cols, (int(v) for v in r))) for r in g["records"]]
+    h, w = g["cur"].shape
+    ctx = make_ctx(w, h, R=8, slots=2)
+    ctx.set_reference(0, g["ref1"]); ctx.set_reference(1, g["ref2"]); ctx.set_current(g["cur"])
+    got = ctx.me_eval_pred(pred_cands_from_records(recs))
+    want = np.array([r["full_result"] for r in recs], np.int64)
+    bad = np.flatnonzero(got.astype(np.int64) != want)
+    assert len(bad) == 0, (bad[:10], [recs[b] for b in bad[:3]], got[bad[:10]], want[bad[:10]])
+    # the early-exit rule applied on the host side reproduces the thresholded results too
+    thr = np.array([r["min_mcost"] for r in recs], np.int64)
+    host = np.where((got.astype(np.int64) >> 5) > (thr >> 5), thr, got.astype(np.int64))
+    assert np.array_equal(host, np.array([r["result"] for r in recs], np.int64))
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_eval_pred_vs_oracle_and_plain_eval(J, seed):
+    """random candidates on a larger picture (device-resident variant as well); the plain kind equals jmhip_me_eval"""
+    import torch
+    from jm_amd.lib import PRED_CAND, CAND, PARTITIONS, PRED_UNI, PRED_BI_WP, PRED_AVG
+    w, h = 320, 192
+    ref1, cur = synth_pair(w, h, 40 + seed)
+    ref2, _ = synth_pair(w, h, 50 + seed, shift=(5, 1))
+    rng = np.random.default_rng(seed)
+    ctx = make_ctx(w, h, R=8, slots=3)
+    ctx.set_reference(0, ref1); ctx.set_reference(2, ref2); ctx.set_current(cur)
+    o = {0: J.RefPic(ref1), 2: J.RefPic(ref2)}
+    n = 700
+    c = np.zeros(n, PRED_CAND)
+    for k in range(n):
+        bt, bx, by, bw, bh = PARTITIONS[int(rng.integers(0, 41))]
+        metric = int(rng.choice([0, 1, 2]))
+        c[k]["pos_x"], c[k]["pos_y"] = int(rng.integers(0, w // 16)) * 16 + bx, int(rng.integers(0, h // 16)) * 16 + by
+        c[k]["bsx"], c[k]["bsy"] = bw, bh
+        c[k]["cand_x"], c[k]["cand_y"] = rng.integers(-300, 301, 2), rng.integers(-300, 301, 2)
+        c[k]["slot"] = rng.choice([0, 2], 2)
+        c[k]["metric"], c[k]["test8x8"] = metric, int(metric == 2 and bw >= 8 and bh >= 8 and rng.integers(0, 2))
+        c[k]["pred"] = int(rng.integers(0, 4))
+        c[k]["shift"] = int(rng.integers(0, 9))
+        c[k]["weight"], c[k]["offset"], c[k]["round"] = rng.integers(-128, 128, 2), int(rng.integers(-128, 128)), int(rng.integers(0, 129))
+    got = ctx.me_eval_pred(c)
+    d_c = torch.from_numpy(c.view(np.uint8)).cuda()
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.me_eval_pred_dev(d_c.data_ptr(), n, d_out.data_ptr()); ctx.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), got)
+    for k in range(n):
+        r = c[k]
+        px, py, bw, bh = int(r["pos_x"]), int(r["pos_y"]), int(r["bsx"]), int(r["bsy"])
+        want = J.pred_dist(o[int(r["slot"][0])], o[int(r["slot"][1])], cur[py:py + bh, px:px + bw], bw, bh, int(r["test8x8"]), int(r["metric"]),
+                           int(r["pred"]), (int(r["weight"][0]), int(r["weight"][1]), int(r["offset"]), int(r["round"]), int(r["shift"])), J.DIST_MAX,
+                           (4 * px + int(r["cand_x"][0]), 4 * py + int(r["cand_y"][0])), (4 * px + int(r["cand_x"][1]), 4 * py + int(r["cand_y"][1])))
+        assert int(got[k]) == want, (k, r)
+    # JMHIP_PRED_UNI with SAD / SATD is jmhip_me_eval
+    uni = np.flatnonzero((c["pred"] == PRED_UNI) & (c["metric"] != 1) & (c["slot"][:, 0] == 0))
+    plain = np.zeros(len(uni), CAND)
+    for f in ("pos_x", "pos_y", "bsx", "bsy", "metric", "test8x8"):
+        plain[f] = c[uni][f]
+    plain["cand_x"], plain["cand_y"] = c[uni]["cand_x"][:, 0], c[uni]["cand_y"][:, 0]
+    assert len(uni) > 20 and np.array_equal(ctx.me_eval(0, plain), got[uni])
+    # bad arguments fail with a message; an empty batch is fine
+    from jm_amd.lib import JmHipError
+    assert len(ctx.me_eval_pred(c[:0])) == 0
+    for field, value in (("pred", 4), ("metric", 3), ("shift", 9), ("slot", (0, 3)), ("bsx", 6)):
+        b = c[:1].copy(); b["pred"] = PRED_AVG; b[field] = value
+        with pytest.raises(JmHipError):
+            ctx.me_eval_pred(b)
+    b = c[:1].copy(); b["pred"], b["metric"], b["test8x8"], b["bsx"], b["bsy"], b["pos_x"], b["pos_y"] = PRED_BI_WP, 2, 1, 4, 8, 0, 0
+    with pytest.raises(JmHipError):
+        ctx.me_eval_pred(b)
+    ctx.close()

@@ -419,3 +419,44 @@ def test_oracle_chroma_subimages_match_the_reference(tag, fmt):
         assert sha == list(g[tag + "_csub_sha"][pl]), (tag, name)
         if pl == 0:
             assert np.array_equal(sub.reshape(-1, *sub.shape[2:])[:, ::13], g[tag + "_csub_u_rows"])
+
+
+def pred_dist_golden():
+    """tests/golden/pred_dist.npz (make_pred_dist.py): the REAL reference's compute{,BiPred}{SAD,SSE,SATD}{,WP,1,2} called on seeded
+    blocks / candidates / weights.  Returns (cur, ref1, ref2, records as dict rows)."""
+    g = np.load(os.path.join(G, "pred_dist.npz"))
+    cols = [str(c) for c in g["columns"]]
+    return g["cur"], g["ref1"], g["ref2"], [dict(zip(cols, (int(v) for v in r))) for r in g["records"]]
+
+
+def pred_dist_weights(r):
+    """(w1, w2, offset, round, shift) as the reference's formula uses them: BiPred*2 doubles wp_luma_round and adds 1 to the
+    denominator (me_distortion.c:636-637), *WP takes them as they are (:452-455)"""
+    if r["pred"] == J.PRED_BI_WP:
+        return (r["w1"], r["w2"], r["offset"], 2 * r["wp_round"], r["log_denom"] + 1)
+    return (r["w1"], 0, r["offset"], r["wp_round"], r["log_denom"])
+
+
+def test_oracle_weighted_and_bipred_distortions_match_the_reference():
+    cur, r1, r2, recs = pred_dist_golden()
+    p1, p2 = J.RefPic(r1), J.RefPic(r2)
+    seen = set()
+    for k, r in enumerate(recs):
+        orig = cur[r["pos_y"]:r["pos_y"] + r["bsy"], r["pos_x"]:r["pos_x"] + r["bsx"]]
+        c1 = (4 * r["pos_x"] + r["c1x"], 4 * r["pos_y"] + r["c1y"])
+        c2 = (4 * r["pos_x"] + r["c2x"], 4 * r["pos_y"] + r["c2y"])
+        for thr, want in ((r["min_mcost"], r["result"]), (J.DIST_MAX, r["full_result"])):
+            got = J.pred_dist(p1, p2, orig, r["bsx"], r["bsy"], r["test8x8"], r["metric"], r["pred"], pred_dist_weights(r), thr, c1, c2)
+            assert got == want, (k, r, got)
+        seen.add((r["pred"], r["metric"], r["test8x8"]))
+    assert len(seen) == 16                      # 4 prediction kinds x {SAD, SSE, SATD 4x4, SATD 8x8}
+    # the plain kind agrees with the functions the rest of the oracle uses
+    for r in recs:
+        if r["pred"] == J.PRED_UNI and r["metric"] != 1:
+            orig = np.ascontiguousarray(cur[r["pos_y"]:r["pos_y"] + r["bsy"], r["pos_x"]:r["pos_x"] + r["bsx"]], np.uint16)
+            c1 = (4 * r["pos_x"] + r["c1x"], 4 * r["pos_y"] + r["c1y"])
+            if r["metric"] == 0:
+                got = J.L.jmo_compute_sad(p1.ptr(), J._p(orig), r["bsx"], r["bsy"], r["min_mcost"], c1[0], c1[1])
+            else:
+                got = J.L.jmo_compute_satd(p1.ptr(), J._p(orig), r["bsx"], r["bsy"], r["test8x8"], r["min_mcost"], c1[0], c1[1])
+            assert got == r["result"], r
