@@ -386,6 +386,20 @@ typedef struct {
   int8_t  slot[2];
   int16_t mv[2][4][2][2];    /* [list][sample row][sample pair (0,1) / (2,3)][x, y]: the vectors the reference reads from all_mv */
 } jmhip_mc_chroma_blk;       /* 72 bytes */
+/* Weighted sample prediction (weighted_mc_prediction / weighted_bi_prediction, mc_prediction.c:38-73; luma_prediction :203-228,
+ * chroma_prediction_4x4 :615-640), one record per block, same for luma and chroma:
+ *   one list (dir 0 / 1):  clip1(((weight[dir] * p + round) >> shift) + offset)
+ *                          weight = Slice.wp_weight[dir][ref][comp], offset = wp_offset[dir][ref][comp], round = wp_luma_round / wp_chroma_round,
+ *                          shift = luma_log_weight_denom / chroma_log_weight_denom
+ *   both lists (dir 2):    clip1(((weight[0] * p0 + weight[1] * p1 + round) >> shift) + offset)
+ *                          weight[l] = Slice.wbp_weight[l][ref0][ref1][comp], offset = (wp_offset[0][ref0][comp] + wp_offset[1][ref1][comp] + 1) >> 1,
+ *                          round = 2 * wp_*_round, shift = *_log_weight_denom + 1 */
+typedef struct {
+  int16_t weight[2];
+  int16_t offset, round;
+  int8_t  shift;             /* 0..8 */
+  int8_t  reserved_[3];
+} jmhip_mc_weights;          /* 12 bytes */
 /* out: luma n x 256 bytes (the w x h samples row-major at the start of each record); chroma n x 16 bytes */
 int jmhip_set_reference_chroma(jmhip_ctx *ctx, int32_t slot, const uint16_t *u, const uint16_t *v, int32_t pitch_samples);
 int jmhip_set_reference_chroma_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_u, const uint8_t *d_v, int32_t pitch_bytes);
@@ -397,6 +411,11 @@ int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, int32_t n, ui
 int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t n, uint8_t *d_out);
 int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out);
 int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int32_t n, uint8_t *d_out);
+/* the same with weighted prediction: weights[i] belongs to blocks[i]; weights == NULL is the un-weighted call */
+int jmhip_mc_luma_wp(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, const jmhip_mc_weights *weights, int32_t n, uint8_t *out);
+int jmhip_mc_luma_wp_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, const jmhip_mc_weights *d_weights, int32_t n, uint8_t *d_out);
+int jmhip_mc_chroma_wp(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, const jmhip_mc_weights *weights, int32_t n, uint8_t *out);
+int jmhip_mc_chroma_wp_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, const jmhip_mc_weights *d_weights, int32_t n, uint8_t *d_out);
 
 /* Device-resident glue between the stages of a P picture coded as 16x16 macroblocks (no host round trip):
  * jmhip_mc_mb16_dev   luma_prediction of every window job's 16x16 partition with the vector the refinement left in

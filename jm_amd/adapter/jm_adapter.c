@@ -558,7 +558,8 @@ distblk __wrap_find_sad_16x16_JM(Macroblock *currMB)
 
 /* ------------------------------------------------------------------ motion-compensated prediction
  * luma_prediction (lencod/src/mc_prediction.c:144; bound to p_Dpb->pf_luma_prediction in lencod.c:367) and chroma_prediction_4x4
- * (:568), un-weighted, frame macroblocks; everything else (weighted prediction, field / MBAFF, ChromaMCBuffer = 0) goes to JM. */
+ * (:568), frame macroblocks, un-weighted and weighted (weighted_mc_prediction / weighted_bi_prediction :38-73 with the parameters the two
+ * functions hand over, :203-228 and :615-640); field / MBAFF and ChromaMCBuffer = 0 go to JM. */
 static MotionVector *****mc_vectors(Macroblock *currMB, int p_dir, int m0, int m1, int r0, int r1, short bipred_me)
 {
   Slice *sl = currMB->p_Slice;
@@ -570,7 +571,24 @@ static int mc_common_ok(Macroblock *currMB, int p_dir)
 {
   Slice *sl = currMB->p_Slice;
   if (!adapter_on(currMB->p_Vid) || p_dir < 0 || p_dir > 2 || currMB->list_offset != 0) return 0;
-  if (sl->weighted_prediction == 1 || (sl->weighted_prediction == 2 && p_dir == 2)) return 0;
+  if (sl->luma_log_weight_denom < 0 || sl->luma_log_weight_denom > 7 || sl->chroma_log_weight_denom < 0 || sl->chroma_log_weight_denom > 7) return 0;
+  return 1;
+}
+/* apply_weights of luma_prediction / chroma_prediction_4x4 and, when set, the parameters they pass on; comp 0 = luma, 1 / 2 = U / V */
+static int mc_weights(Slice *sl, int p_dir, int r0, int r1, int comp, jmhip_mc_weights *w)
+{
+  const int round_ = comp ? sl->wp_chroma_round : sl->wp_luma_round, denom = comp ? sl->chroma_log_weight_denom : sl->luma_log_weight_denom;
+  memset(w, 0, sizeof *w);
+  if (!(sl->weighted_prediction == 1 || (sl->weighted_prediction == 2 && p_dir == 2))) return 0;
+  if (p_dir == 2) {
+    w->weight[0] = sl->wbp_weight[0][r0][r1][comp]; w->weight[1] = sl->wbp_weight[1][r0][r1][comp];
+    w->offset = (int16_t)((sl->wp_offset[0][r0][comp] + sl->wp_offset[1][r1][comp] + 1) >> 1);
+    w->round = (int16_t)(round_ << 1); w->shift = (int8_t)(denom + 1);
+  } else {
+    const int r = p_dir ? r1 : r0;
+    w->weight[p_dir] = sl->wp_weight[p_dir][r][comp]; w->offset = sl->wp_offset[p_dir][r][comp];
+    w->round = (int16_t)round_; w->shift = (int8_t)denom;
+  }
   return 1;
 }
 static int slot_with_chroma(StorablePicture *s)
@@ -588,6 +606,7 @@ void __wrap_luma_prediction(Macroblock *currMB, int block_x, int block_y, int bs
 {
   Slice *sl = currMB->p_Slice;
   jmhip_mc_luma_blk b;
+  jmhip_mc_weights w;
   uint8_t out[256];
   int l, j, i, rc, ok = mc_common_ok(currMB, p_dir) && G.part_mcl && (bsx == 4 || bsx == 8 || bsx == 16) && (bsy == 4 || bsy == 8 || bsy == 16);
   memset(&b, 0, sizeof b);
@@ -609,7 +628,7 @@ void __wrap_luma_prediction(Macroblock *currMB, int block_x, int block_y, int bs
       }
   }
   if (p_dir == 2 && G.slot_pic[b.slot[0]] != sl->listX[0][(short)ref_idx[0]]) b.slot[0] = (int8_t)slot_of_reference(sl->listX[0][(short)ref_idx[0]]);  /* list 1 may have evicted it */
-  if ((rc = jmhip_mc_luma(G.ctx, &b, 1, out))) adapter_die("jmhip_mc_luma", rc);
+  if ((rc = jmhip_mc_luma_wp(G.ctx, &b, mc_weights(sl, p_dir, (short)ref_idx[0], (short)ref_idx[1], 0, &w) ? &w : NULL, 1, out))) adapter_die("jmhip_mc_luma_wp", rc);
   for (j = 0; j < bsy; j++)
     for (i = 0; i < bsx; i++) sl->mb_pred[0][block_y + j][block_x + i] = out[j * bsx + i];
   G.n_mcl++;
@@ -621,6 +640,7 @@ void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int b
   VideoParameters *p_Vid = currMB->p_Vid;
   Slice *sl = currMB->p_Slice;
   jmhip_mc_chroma_blk b;
+  jmhip_mc_weights w;
   uint8_t out[16];
   int mode[2] = {l0_mode, l1_mode}, ref[2] = {l0_ref_idx, l1_ref_idx};
   int l, j, rc, ok = mc_common_ok(currMB, p_dir) && G.part_mcc && p_Vid->p_Inp->ChromaMCBuffer && (uv == 0 || uv == 1);
@@ -647,7 +667,7 @@ void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int b
       }
   }
   if (p_dir == 2 && (G.slot_pic[b.slot[0]] != sl->listX[0][ref[0]] || !G.slot_chroma[b.slot[0]])) b.slot[0] = (int8_t)slot_with_chroma(sl->listX[0][ref[0]]);
-  if ((rc = jmhip_mc_chroma(G.ctx, &b, 1, out))) adapter_die("jmhip_mc_chroma", rc);
+  if ((rc = jmhip_mc_chroma_wp(G.ctx, &b, mc_weights(sl, p_dir, l0_ref_idx, l1_ref_idx, uv + 1, &w) ? &w : NULL, 1, out))) adapter_die("jmhip_mc_chroma_wp", rc);
   for (j = 0; j < 4; j++) {
     imgpel *row = &sl->mb_pred[uv + 1][block_y + j][block_x];
     row[0] = out[j * 4]; row[1] = out[j * 4 + 1]; row[2] = out[j * 4 + 2]; row[3] = out[j * 4 + 3];

@@ -14,14 +14,30 @@
 #include "jmhip_internal.h"
 
 struct McSlots { const uint8_t *p[32]; };
+static_assert(sizeof(jmhip_mc_weights) == 12, "jmhip_mc_weights is 12 bytes in include/jmhip.h");
 
 struct __attribute__((packed)) u32un { uint32_t v; };
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const u32un *)p)->v; }
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
 
 // 16 lanes per block; a lane copies every 16th group of four samples (one group for 4x4 .. 8x8, four for 16x16)
-__global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__restrict__ blocks, int n, McSlots slots, int nslots,
-                                                 int pitch, long plane_stride, int W, int H, uint8_t *__restrict__ out)
+// weighted sample prediction (mc_prediction.c:38-73): one list clip1(((w * p + round) >> shift) + offset), both lists
+// clip1(((w0 * p0 + w1 * p1 + round) >> shift) + offset); four samples of a 32-bit word at a time
+__device__ __forceinline__ int wp1(int p, const jmhip_mc_weights &w, int list) { return min(max(((w.weight[list] * p + w.round) >> w.shift) + w.offset, 0), 255); }
+__device__ __forceinline__ int wp2(int p0, int p1, const jmhip_mc_weights &w) { return min(max(((w.weight[0] * p0 + w.weight[1] * p1 + w.round) >> w.shift) + w.offset, 0), 255); }
+__device__ __forceinline__ uint32_t wp_word(uint32_t a, uint32_t c, int dir, const jmhip_mc_weights &w)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int p0 = (a >> (8 * k)) & 255, p1 = (c >> (8 * k)) & 255;
+    r |= (uint32_t)(dir == 2 ? wp2(p0, p1, w) : (dir == 0 ? wp1(p0, w, 0) : wp1(p1, w, 1))) << (8 * k);
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__restrict__ blocks, const jmhip_mc_weights *__restrict__ weights, int n,
+                                                 McSlots slots, int nslots, int pitch, long plane_stride, int W, int H, uint8_t *__restrict__ out)
 {
   const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 4, l = t & 15;
   if (b >= n) return;
@@ -41,18 +57,20 @@ __global__ __launch_bounds__(256) void k_mc_luma(const jmhip_mc_luma_blk *__rest
     if (list == 0) { o0 = o; s0 = s; } else { o1 = o; s1 = s; }
   }
   const uint8_t *__restrict__ src0 = slots.p[s0] + o0, *__restrict__ src1 = slots.p[s1] + o1;
+  jmhip_mc_weights wt = {};
+  if (weights) wt = weights[b];
   const int w4 = q.w >> 2, groups = w4 * q.h;
   for (int g = l; g < groups; g += 16) {
     const int row = g / w4, c4 = g - row * w4;
     const long off = (long)row * pitch + 4 * c4;
     const uint32_t a = q.dir != 1 ? ld4u(src0 + off) : 0u, c = q.dir != 0 ? ld4u(src1 + off) : 0u;
-    *(uint32_t *)(out + (long)b * 256 + row * q.w + 4 * c4) = q.dir == 0 ? a : (q.dir == 1 ? c : avg4(a, c));
+    *(uint32_t *)(out + (long)b * 256 + row * q.w + 4 * c4) = weights ? wp_word(a, c, q.dir, wt) : (q.dir == 0 ? a : (q.dir == 1 ? c : avg4(a, c)));
   }
 }
 
 // 16 lanes per block: lane -> sample (row j, column i); the sample pair i >> 1 shares a vector
-__global__ __launch_bounds__(256) void k_mc_chroma(const jmhip_mc_chroma_blk *__restrict__ blocks, int n, McSlots slots, int nslots,
-                                                   int cw, int ch, int yuv, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_mc_chroma(const jmhip_mc_chroma_blk *__restrict__ blocks, const jmhip_mc_weights *__restrict__ weights, int n,
+                                                   McSlots slots, int nslots, int cw, int ch, int yuv, uint8_t *__restrict__ out)
 {
   const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 4, smp = t & 15, j = smp >> 2, i = smp & 3, hp = i >> 1, o = i & 1;
   if (b >= n) return;
@@ -76,27 +94,54 @@ __global__ __launch_bounds__(256) void k_mc_chroma(const jmhip_mc_chroma_blk *__
     const int y0 = min(max(Y, 0), ch - 1), y1 = min(max(Y + 1, 0), ch - 1), x0 = min(max(X, 0), cw - 1), x1 = min(max(X + 1, 0), cw - 1);
     v[list] = (w00 * pl[y0 * cw + x0] + w01 * pl[y0 * cw + x1] + w10 * pl[y1 * cw + x0] + w11 * pl[y1 * cw + x1] + 32) >> 6;
   }
-  out[(long)b * 16 + smp] = (uint8_t)(dir == 0 ? v[0] : (dir == 1 ? v[1] : (v[0] + v[1] + 1) >> 1));
+  if (weights) {
+    const jmhip_mc_weights wt = weights[b];
+    out[(long)b * 16 + smp] = (uint8_t)(dir == 2 ? wp2(v[0], v[1], wt) : wp1(v[dir], wt, dir));
+  } else out[(long)b * 16 + smp] = (uint8_t)(dir == 0 ? v[0] : (dir == 1 ? v[1] : (v[0] + v[1] + 1) >> 1));
 }
 
 static McSlots luma_slots(jmhip_ctx *ctx) { McSlots s; for (int k = 0; k < 32; k++) s.p[k] = k < ctx->cfg.num_ref_slots ? ctx->d_sub[k] : nullptr; return s; }
 static McSlots chroma_slots(jmhip_ctx *ctx) { McSlots s; for (int k = 0; k < 32; k++) s.p[k] = k < ctx->cfg.num_ref_slots ? ctx->d_refc[k] : nullptr; return s; }
 
-extern "C" int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t n, uint8_t *d_out)
+extern "C" int jmhip_mc_luma_wp_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, const jmhip_mc_weights *d_weights, int32_t n, uint8_t *d_out)
 {
   if (!ctx) return JMHIP_EINVAL;
   if (n < 0 || (n > 0 && (!d_blocks || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma_dev: bad argument");
   if (n == 0) return JMHIP_OK;
-  hipLaunchKernelGGL(k_mc_luma, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_blocks, n, luma_slots(ctx), ctx->cfg.num_ref_slots,
+  hipLaunchKernelGGL(k_mc_luma, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_blocks, d_weights, n, luma_slots(ctx), ctx->cfg.num_ref_slots,
                      ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, d_out);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
 }
+extern "C" int jmhip_mc_luma_dev(jmhip_ctx *ctx, const jmhip_mc_luma_blk *d_blocks, int32_t n, uint8_t *d_out)
+{
+  return jmhip_mc_luma_wp_dev(ctx, d_blocks, nullptr, n, d_out);
+}
 
-extern "C" int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, int32_t n, uint8_t *out)
+// the weights of a host batch: shift 0..8 (log_weight_denom 0..7, + 1 for two lists)
+static int check_weights(jmhip_ctx *ctx, const char *who, const jmhip_mc_weights *weights, int n)
+{
+  for (int i = 0; weights && i < n; i++)
+    if (weights[i].shift < 0 || weights[i].shift > 8) return jmhip_fail(ctx, JMHIP_EINVAL, "%s: block %d: weight shift %d outside 0..8", who, i, weights[i].shift);
+  return JMHIP_OK;
+}
+// weights (may be NULL) -> a device copy behind the block records in scratch buffer 0 (`din`, sized by blocks_bytes())
+static size_t blocks_bytes(size_t n, size_t rec, bool with_weights) { return ((n * rec + 15) & ~(size_t)15) + (with_weights ? n * sizeof(jmhip_mc_weights) : 0); }
+static int stage_weights(jmhip_ctx *ctx, const jmhip_mc_weights *weights, int n, void *din, size_t rec, const jmhip_mc_weights **d_weights)
+{
+  *d_weights = nullptr;
+  if (!weights) return JMHIP_OK;
+  void *dw = (char *)din + (((size_t)n * rec + 15) & ~(size_t)15);
+  HIPCHK(ctx, hipMemcpyAsync(dw, weights, (size_t)n * sizeof(jmhip_mc_weights), hipMemcpyHostToDevice, ctx->stream));
+  *d_weights = (const jmhip_mc_weights *)dw;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_mc_luma_wp(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, const jmhip_mc_weights *weights, int32_t n, uint8_t *out)
 {
   if (!ctx) return JMHIP_EINVAL;
   if (n < 0 || (n > 0 && (!blocks || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_luma: bad argument");
+  { int r_ = check_weights(ctx, "jmhip_mc_luma_wp", weights, n); if (r_) return r_; }
   for (int i = 0; i < n; i++) {
     const jmhip_mc_luma_blk *q = blocks + i;
     const bool size_ok = (q->w == 4 || q->w == 8 || q->w == 16) && (q->h == 4 || q->h == 8 || q->h == 16);
@@ -107,30 +152,41 @@ extern "C" int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, in
   }
   if (n == 0) return JMHIP_OK;
   int r; void *din, *dout;
-  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_mc_luma_blk), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 0, blocks_bytes((size_t)n, sizeof(jmhip_mc_luma_blk), weights != nullptr), &din))) return r;
   if ((r = jmhip_scratch(ctx, 1, (size_t)n * 256, &dout))) return r;
   HIPCHK(ctx, hipMemcpyAsync(din, blocks, (size_t)n * sizeof(jmhip_mc_luma_blk), hipMemcpyHostToDevice, ctx->stream));
-  if ((r = jmhip_mc_luma_dev(ctx, (const jmhip_mc_luma_blk *)din, n, (uint8_t *)dout))) return r;
+  const jmhip_mc_weights *dw;
+  if ((r = stage_weights(ctx, weights, n, din, sizeof(jmhip_mc_luma_blk), &dw))) return r;
+  if ((r = jmhip_mc_luma_wp_dev(ctx, (const jmhip_mc_luma_blk *)din, dw, n, (uint8_t *)dout))) return r;
   HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;
 }
+extern "C" int jmhip_mc_luma(jmhip_ctx *ctx, const jmhip_mc_luma_blk *blocks, int32_t n, uint8_t *out)
+{
+  return jmhip_mc_luma_wp(ctx, blocks, nullptr, n, out);
+}
 
-extern "C" int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int32_t n, uint8_t *d_out)
+extern "C" int jmhip_mc_chroma_wp_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, const jmhip_mc_weights *d_weights, int32_t n, uint8_t *d_out)
 {
   if (!ctx) return JMHIP_EINVAL;
   if (n < 0 || (n > 0 && (!d_blocks || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_chroma_dev: bad argument");
   if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_mc_chroma: yuv_format %d (4:2:0 and 4:2:2 only)", ctx->cfg.yuv_format);
   if (n == 0) return JMHIP_OK;
-  hipLaunchKernelGGL(k_mc_chroma, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_blocks, n, chroma_slots(ctx), ctx->cfg.num_ref_slots,
+  hipLaunchKernelGGL(k_mc_chroma, dim3((n + 15) / 16), dim3(256), 0, ctx->stream, d_blocks, d_weights, n, chroma_slots(ctx), ctx->cfg.num_ref_slots,
                      ctx->cw, ctx->ch, ctx->cfg.yuv_format, d_out);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
 }
+extern "C" int jmhip_mc_chroma_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, int32_t n, uint8_t *d_out)
+{
+  return jmhip_mc_chroma_wp_dev(ctx, d_blocks, nullptr, n, d_out);
+}
 
-extern "C" int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out)
+extern "C" int jmhip_mc_chroma_wp(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, const jmhip_mc_weights *weights, int32_t n, uint8_t *out)
 {
   if (!ctx) return JMHIP_EINVAL;
+  { int r_ = check_weights(ctx, "jmhip_mc_chroma_wp", weights, n); if (r_) return r_; }
   if (n < 0 || (n > 0 && (!blocks || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mc_chroma: bad argument");
   if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_mc_chroma: yuv_format %d (4:2:0 and 4:2:2 only)", ctx->cfg.yuv_format);
   for (int i = 0; i < n; i++) {
@@ -142,13 +198,19 @@ extern "C" int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks
   }
   if (n == 0) return JMHIP_OK;
   int r; void *din, *dout;
-  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_mc_chroma_blk), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 0, blocks_bytes((size_t)n, sizeof(jmhip_mc_chroma_blk), weights != nullptr), &din))) return r;
   if ((r = jmhip_scratch(ctx, 1, (size_t)n * 16, &dout))) return r;
   HIPCHK(ctx, hipMemcpyAsync(din, blocks, (size_t)n * sizeof(jmhip_mc_chroma_blk), hipMemcpyHostToDevice, ctx->stream));
-  if ((r = jmhip_mc_chroma_dev(ctx, (const jmhip_mc_chroma_blk *)din, n, (uint8_t *)dout))) return r;
+  const jmhip_mc_weights *dw;
+  if ((r = stage_weights(ctx, weights, n, din, sizeof(jmhip_mc_chroma_blk), &dw))) return r;
+  if ((r = jmhip_mc_chroma_wp_dev(ctx, (const jmhip_mc_chroma_blk *)din, dw, n, (uint8_t *)dout))) return r;
   HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;
+}
+extern "C" int jmhip_mc_chroma(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *blocks, int32_t n, uint8_t *out)
+{
+  return jmhip_mc_chroma_wp(ctx, blocks, nullptr, n, out);
 }
 
 

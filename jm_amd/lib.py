@@ -66,7 +66,8 @@ DB_MOTION = np.dtype([("mv", "<i2", (2, 2)), ("ref_id", "<i4", (2,))])
 MC_LUMA_BLK = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("reserved_", "u1"), ("slot", "i1", (2,)),
                         ("mv", "<i2", (2, 2)), ("reserved2_", "<i2")])
 MC_CHROMA_BLK = np.dtype([("x", "<i2"), ("y", "<i2"), ("dir", "u1"), ("plane", "u1"), ("slot", "i1", (2,)), ("mv", "<i2", (2, 4, 2, 2))])
-assert MC_LUMA_BLK.itemsize == 20 and MC_CHROMA_BLK.itemsize == 72
+MC_WEIGHTS = np.dtype([("weight", "<i2", (2,)), ("offset", "<i2"), ("round", "<i2"), ("shift", "i1"), ("reserved_", "i1", (3,))])
+assert MC_LUMA_BLK.itemsize == 20 and MC_CHROMA_BLK.itemsize == 72 and MC_WEIGHTS.itemsize == 12
 IP4_BLK = np.dtype([("edge", "u1", (13,)), ("mode", "u1"), ("left", "u1"), ("up", "u1")])
 I16_MB = np.dtype([("edge", "u1", (33,)), ("left", "u1"), ("up", "u1"), ("mode_mask", "u1"), ("metric", "u1"), ("reserved_", "u1", (3,))])
 I16_OUT = np.dtype([("cost", "<i8"), ("mode", "<i4"), ("reserved_", "<i4"), ("pred", "u1", (4, 256))])
@@ -80,7 +81,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -374,6 +375,27 @@ class JmHip:
 
     def mc_luma_dev(self, d_blocks, n, d_out):
         self._ck(self.lib.jmhip_mc_luma_dev(self.h, _vp(d_blocks), n, _vp(d_out)))
+
+    def mc_luma_wp(self, blocks, weights):
+        """luma_prediction with weighted prediction (weighted_mc_prediction / weighted_bi_prediction): weights[i] (MC_WEIGHTS) for blocks[i]"""
+        b, w = np.ascontiguousarray(blocks, MC_LUMA_BLK), np.ascontiguousarray(weights, MC_WEIGHTS)
+        assert len(b) == len(w)
+        out = np.zeros((len(b), 256), np.uint8)
+        self._ck(self.lib.jmhip_mc_luma_wp(self.h, _vp(b), _vp(w), len(b), _vp(out)))
+        return out
+
+    def mc_luma_wp_dev(self, d_blocks, d_weights, n, d_out):
+        self._ck(self.lib.jmhip_mc_luma_wp_dev(self.h, _vp(d_blocks), _vp(d_weights), n, _vp(d_out)))
+
+    def mc_chroma_wp(self, blocks, weights):
+        b, w = np.ascontiguousarray(blocks, MC_CHROMA_BLK), np.ascontiguousarray(weights, MC_WEIGHTS)
+        assert len(b) == len(w)
+        out = np.zeros((len(b), 16), np.uint8)
+        self._ck(self.lib.jmhip_mc_chroma_wp(self.h, _vp(b), _vp(w), len(b), _vp(out)))
+        return out
+
+    def mc_chroma_wp_dev(self, d_blocks, d_weights, n, d_out):
+        self._ck(self.lib.jmhip_mc_chroma_wp_dev(self.h, _vp(d_blocks), _vp(d_weights), n, _vp(d_out)))
 
     def mc_chroma(self, blocks):
         """chroma_prediction_4x4 (lencod/src/mc_prediction.c:568, ChromaMCBuffer = 1), un-weighted; MC_CHROMA_BLK array -> (n, 16) uint8"""

@@ -192,6 +192,9 @@ void jmo_luma_pred(const jmo_refpic *r0, const jmo_refpic *r1, int p_dir, int x,
 void jmo_chroma_pred4x4(const jmo_pel *p0, const jmo_pel *p1, int pitch, int W, int H, int yuv, int p_dir, int xc, int yc,
                         const jmo_mv mv0[4][2], const jmo_mv mv1[4][2], jmo_pel out[16]);
 
+/* weighted sample prediction of per-list predictions, mc_prediction.c:38-73 (jmo_wp: weight[list], offset, round, shift as the formula uses them) */
+void jmo_weighted_samples(const jmo_pel *p0, const jmo_pel *p1, int n, int p_dir, const jmo_wp *wp, int max_pel, jmo_pel *out);
+
 void jmo_sub_images_chroma(const jmo_pel *src, int pitch, int W, int H, int yuv, jmo_pel *dst);   /* img_chroma.c:338-437, see jmo_mc.c */
 void jmo_sub_images_luma(const jmo_pel *src, int src_pitch, int width, int height,
                          int max_pel, jmo_pel *dst, int pitch, long plane_stride);

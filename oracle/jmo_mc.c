@@ -86,3 +86,17 @@ void jmo_sub_images_chroma(const jmo_pel *src, int pitch, int W, int H, int yuv,
         for (X = -pad_x; X < W + pad_x; X++) d[(long)(Y + pad_y) * Wp + X + pad_x] = (jmo_pel)chroma_sub(src, pitch, W, H, yuv, sy, sx, Y, X);
     }
 }
+
+/* weighted_mc_prediction / weighted_bi_prediction, lencod/src/mc_prediction.c:38-73, applied to the per-list predictions p0 / p1 of n samples
+ * (luma_prediction :203-228 and chroma_prediction_4x4 :615-640 hand them over with the parameters documented at jmo_wp):
+ *   p_dir 0 / 1  clip1(((weight[p_dir] * p + round) >> shift) + offset)        p_dir 2  clip1(((w0 * p0 + w1 * p1 + round) >> shift) + offset) */
+void jmo_weighted_samples(const jmo_pel *p0, const jmo_pel *p1, int n, int p_dir, const jmo_wp *wp, int max_pel, jmo_pel *out)
+{
+  int i;
+  for (i = 0; i < n; i++) {
+    int v;
+    if (p_dir == 2) v = ((wp->weight[0] * p0[i] + wp->weight[1] * p1[i] + wp->round) >> wp->shift) + wp->offset;
+    else v = ((wp->weight[p_dir] * (p_dir ? p1[i] : p0[i]) + wp->round) >> wp->shift) + wp->offset;
+    out[i] = (jmo_pel)(v < 0 ? 0 : (v > max_pel ? max_pel : v));
+  }
+}

@@ -71,6 +71,7 @@ class WP(C.Structure):
 L.jmo_compute_pred_dist.restype = C.c_int64
 L.jmo_compute_pred_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+L.jmo_weighted_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 L.jmo_full_search.restype = C.c_int64
 L.jmo_compute_sad.restype = C.c_int64
 L.jmo_compute_satd.restype = C.c_int64
@@ -315,6 +316,29 @@ def luma_pred(r0, r1, p_dir, x, y, bsx, bsy, mv0, mv1):
     L.jmo_luma_pred((r0 or any_ref).ptr(), (r1 or any_ref).ptr(), int(p_dir), int(x), int(y), int(bsx), int(bsy),
                     MV(int(mv0[0]), int(mv0[1])), MV(int(mv1[0]), int(mv1[1])), _p(out))
     return out.reshape(bsy, bsx).astype(np.uint8)
+
+
+def weighted_samples(p0, p1, p_dir, weights, max_pel=255):
+    """weighted_mc_prediction / weighted_bi_prediction on per-list predictions (arrays of equal shape); weights = (w0, w1, offset, round, shift)"""
+    a = np.ascontiguousarray(p0 if p0 is not None else p1, np.uint16)
+    b = np.ascontiguousarray(p1 if p1 is not None else p0, np.uint16)
+    wp = WP((C.c_int * 2)(int(weights[0]), int(weights[1])), int(weights[2]), int(weights[3]), int(weights[4]))
+    out = np.zeros(a.size, np.uint16)
+    L.jmo_weighted_samples(_p(a), _p(b), a.size, int(p_dir), C.byref(wp), int(max_pel), _p(out))
+    return out.reshape(a.shape).astype(np.uint8)
+
+
+def luma_pred_wp(r0, r1, p_dir, x, y, bsx, bsy, mv0, mv1, weights):
+    """luma_prediction with weighted prediction: the per-list predictions, then weighted_samples"""
+    a = luma_pred(r0, r1, 0, x, y, bsx, bsy, mv0, mv1) if p_dir != 1 else None
+    b = luma_pred(r0, r1, 1, x, y, bsx, bsy, mv0, mv1) if p_dir != 0 else None
+    return weighted_samples(a, b, p_dir, weights)
+
+
+def chroma_pred4x4_wp(p0, p1, yuv, p_dir, xc, yc, mv0, mv1, weights):
+    a = chroma_pred4x4(p0, p1, yuv, 0, xc, yc, mv0, mv1) if p_dir != 1 else None
+    b = chroma_pred4x4(p0, p1, yuv, 1, xc, yc, mv0, mv1) if p_dir != 0 else None
+    return weighted_samples(a, b, p_dir, weights)
 
 
 def chroma_pred4x4(p0, p1, yuv, p_dir, xc, yc, mv0, mv1):

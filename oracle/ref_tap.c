@@ -232,6 +232,21 @@ void __wrap_getSubImagesChroma(VideoParameters *p_Vid, StorablePicture *s)
  *   chroma_prediction_4x4    lencod/src/mc_prediction.c:568
  * Records: the block, the direction, per list {reference picture made by getSubImagesLuma call k, motion vector(s)} exactly as the
  * function resolves them, and the samples it left in currSlice->mb_pred. */
+/* the weighted-prediction parameters exactly as luma_prediction (:203-228) / chroma_prediction_4x4 (:615-640) hand them to
+ * weighted_mc_prediction / weighted_bi_prediction: weight[list], offset, round, shift (zeros when the call is un-weighted) */
+static void put_mc_weights(FILE *f, Slice *sl, int wp, int p_dir, int r0, int r1, int comp)
+{
+  int w[2] = {0, 0}, off = 0, rnd = 0, sh = 0;
+  const int round_ = comp ? sl->wp_chroma_round : sl->wp_luma_round, denom = comp ? sl->chroma_log_weight_denom : sl->luma_log_weight_denom;
+  if (wp && p_dir == 2) {
+    w[0] = sl->wbp_weight[0][r0][r1][comp]; w[1] = sl->wbp_weight[1][r0][r1][comp];
+    off = (sl->wp_offset[0][r0][comp] + sl->wp_offset[1][r1][comp] + 1) >> 1; rnd = round_ << 1; sh = denom + 1;
+  } else if (wp) {
+    const int r = p_dir ? r1 : r0;
+    w[p_dir] = sl->wp_weight[p_dir][r][comp]; off = sl->wp_offset[p_dir][r][comp]; rnd = round_; sh = denom;
+  }
+  put_i32(f, w[0]); put_i32(f, w[1]); put_i32(f, off); put_i32(f, rnd); put_i32(f, sh);
+}
 static MotionVector *****mc_mv_array(Macroblock *currMB, int p_dir, int m0, int m1, int r0, int r1, short bipred_me)
 {
   Slice *sl = currMB->p_Slice;
@@ -258,6 +273,7 @@ void __wrap_luma_prediction(Macroblock *currMB, int block_x, int block_y, int bs
         put_i32(f, ref_index_of(sl->listX[l + currMB->list_offset][(short)ref_idx[l]])); put_i32(f, mv->mv_x); put_i32(f, mv->mv_y);
       } else { put_i32(f, -1); put_i32(f, 0); put_i32(f, 0); }
     }
+    put_mc_weights(f, sl, wp, p_dir, (short)ref_idx[0], (short)ref_idx[1], 0);
     for (j = 0; j < bsy; j++) fwrite(&sl->mb_pred[0][block_y + j][block_x], sizeof(imgpel), (size_t)bsx, f);
     fclose(f); n++;
   }
@@ -291,6 +307,7 @@ void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int b
         }
       } else { int k; put_i32(f, -1); put_i32(f, 0); for (k = 0; k < 16; k++) put_i32(f, 0); }
     }
+    put_mc_weights(f, sl, wp, p_dir, l0_ref_idx, l1_ref_idx, uv + 1);
     for (j = 0; j < 4; j++) fwrite(&sl->mb_pred[uv + 1][block_y + j][block_x], sizeof(imgpel), 4, f);
     fclose(f); n++;
   }

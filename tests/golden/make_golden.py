@@ -107,15 +107,15 @@ def read_subimages(path):
 
 
 def read_mc(path, luma):
-    """mc_luma.bin: 13 ints + bsx*bsy samples;  mc_chroma.bin: 44 ints + 16 samples (oracle/ref_tap.c)"""
+    """mc_luma.bin: 13 ints + 5 weight ints + bsx*bsy samples;  mc_chroma.bin: 44 ints + 5 weight ints + 16 samples (oracle/ref_tap.c)"""
     r, hdr, pix = Reader(path), [], []
     while not r.eof():
-        h = r.i32(13 if luma else 44).copy()
+        h = r.i32(18 if luma else 49).copy()
         n = int(h[3]) * int(h[4]) if luma else 16
         px = np.frombuffer(r.b, np.uint16, n, r.o).astype(np.uint8); r.o += 2 * n
         full = np.zeros(256 if luma else 16, np.uint8); full[:n] = px
         hdr.append(h); pix.append(full)
-    return (np.array(hdr, np.int32).reshape(-1, 13 if luma else 44), np.array(pix, np.uint8).reshape(-1, 256 if luma else 16))
+    return (np.array(hdr, np.int32).reshape(-1, 18 if luma else 49), np.array(pix, np.uint8).reshape(-1, 256 if luma else 16))
 
 
 def read_refchroma(path):
@@ -279,6 +279,10 @@ def main():
         # ---- motion-compensated prediction (luma_prediction / chroma_prediction_4x4) of runs A (4:2:0 P), C (4:2:2 P), E (B picture)
         d = {}
         mc_arrays("a", wa, d); mc_arrays("c", wc, d); mc_arrays("e", we, d)
+        # explicit weighted prediction in P and B pictures (the G3w configuration): weighted_mc_prediction / weighted_bi_prediction
+        ww = os.path.join(tmp, "W"); os.makedirs(ww)
+        run(TAP, "encoder_main.cfg", dict(SearchMode=3, WeightedPrediction=1, WeightedBiprediction=1), ww, tap=True)
+        mc_arrays("w", ww, d)
         np.savez_compressed(os.path.join(OUT, "qcif_mc.npz"), **d)
 
         # ---- luma intra prediction (get_intrapred_4x4) and the Intra16x16 mode search (find_sad_16x16_JM) of the same runs

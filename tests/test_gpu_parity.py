@@ -693,19 +693,33 @@ def _mc_ctx(mcg, tag):
     return ctx
 
 
-@pytest.mark.parametrize("tag", ["a", "c", "e"])
+def _mc_weights(hdr, wp_col, first):
+    """MC_WEIGHTS for golden records: the five ints the reference handed to weighted_*_prediction, or -- for an un-weighted record inside a
+    weighted batch -- the identity (one list: w = 1; both: (p0 + p1 + 1) >> 1 = weights (1, 1), round 1, shift 1)"""
+    from jm_amd.lib import MC_WEIGHTS
+    w = np.zeros(len(hdr), MC_WEIGHTS)
+    for i, h in enumerate(hdr):
+        if h[wp_col]:
+            w[i]["weight"], w[i]["offset"], w[i]["round"], w[i]["shift"] = (h[first], h[first + 1]), h[first + 2], h[first + 3], h[first + 4]
+        else:
+            w[i]["weight"], w[i]["round"], w[i]["shift"] = (1, 1), int(h[5] == 2), int(h[5] == 2)
+    return w
+
+
+@pytest.mark.parametrize("tag", ["a", "c", "e", "w"])
 def test_mc_luma_golden_records(mcg, tag):
-    """k_mc_luma == luma_prediction on the real encoder's calls (4:2:0 P, 4:2:2 P, B picture with bi-prediction)"""
+    """k_mc_luma == luma_prediction on the real encoder's calls (4:2:0 P, 4:2:2 P, B picture with bi-prediction; run w: explicit weighted
+    prediction in P and B pictures)"""
     from jm_amd.lib import MC_LUMA_BLK
     hdr, pix = mcg[tag + "_mcl_hdr"], mcg[tag + "_mcl_pix"]
-    keep = hdr[:, 6] == 0                                    # un-weighted
-    hdr, pix = hdr[keep], pix[keep]
     b = np.zeros(len(hdr), MC_LUMA_BLK)
     b["x"], b["y"], b["w"], b["h"], b["dir"] = hdr[:, 1], hdr[:, 2], hdr[:, 3], hdr[:, 4], hdr[:, 5]
     b["slot"][:, 0], b["slot"][:, 1] = np.maximum(hdr[:, 7], 0), np.maximum(hdr[:, 10], 0)
     b["mv"][:, 0, 0], b["mv"][:, 0, 1], b["mv"][:, 1, 0], b["mv"][:, 1, 1] = hdr[:, 8], hdr[:, 9], hdr[:, 11], hdr[:, 12]
     ctx = _mc_ctx(mcg, tag)
-    out = ctx.mc_luma(b)
+    weighted = bool(hdr[:, 6].any())
+    assert weighted == (tag == "w")
+    out = ctx.mc_luma_wp(b, _mc_weights(hdr, 6, 13)) if weighted else ctx.mc_luma(b)
     n = hdr[:, 3] * hdr[:, 4]
     for i in range(len(hdr)):
         assert np.array_equal(out[i, :n[i]], pix[i, :n[i]]), (tag, i, hdr[i].tolist())
@@ -713,12 +727,12 @@ def test_mc_luma_golden_records(mcg, tag):
     ctx.close()
 
 
-@pytest.mark.parametrize("tag", ["a", "c", "e"])
+@pytest.mark.parametrize("tag", ["a", "c", "e", "w"])
 def test_mc_chroma_golden_records(mcg, tag):
     """k_mc_chroma == chroma_prediction_4x4 (buffered chroma sub-images) on the real encoder's calls"""
     from jm_amd.lib import MC_CHROMA_BLK
     hdr, pix = mcg[tag + "_mcc_hdr"], mcg[tag + "_mcc_pix"]
-    keep = (hdr[:, 6] == 0) & (hdr[:, 7] == 1)
+    keep = hdr[:, 7] == 1
     hdr, pix = hdr[keep], pix[keep]
     b = np.zeros(len(hdr), MC_CHROMA_BLK)
     b["x"], b["y"], b["dir"], b["plane"] = hdr[:, 3], hdr[:, 4], hdr[:, 5], hdr[:, 2]
@@ -726,10 +740,60 @@ def test_mc_chroma_golden_records(mcg, tag):
     b["mv"][:, 0] = hdr[:, 10:26].reshape(-1, 4, 2, 2)
     b["mv"][:, 1] = hdr[:, 28:44].reshape(-1, 4, 2, 2)
     ctx = _mc_ctx(mcg, tag)
-    out = ctx.mc_chroma(b)
+    weighted = bool(hdr[:, 6].any())
+    out = ctx.mc_chroma_wp(b, _mc_weights(hdr, 6, 44)) if weighted else ctx.mc_chroma(b)
     bad = np.flatnonzero((out != pix).any(1))
     assert len(bad) == 0, (tag, bad[:5].tolist(), hdr[bad[0]].tolist(), out[bad[0]].tolist(), pix[bad[0]].tolist())
     assert len(hdr) > 100
+    ctx.close()
+
+
+def test_mc_weighted_random_blocks_vs_oracle(J):
+    """weighted prediction with arbitrary weights, offsets, rounds and shifts (the encoder's own runs only reach 31..33 / -5..5): luma and
+    chroma, one list and both, device-resident variant included"""
+    import torch
+    from jm_amd.lib import MC_LUMA_BLK, MC_CHROMA_BLK, MC_WEIGHTS, JmHipError
+    rng = np.random.default_rng(11)
+    w, h, fmt, n = 176, 144, 1, 500
+    ys = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(2)]
+    cs = [rng.integers(0, 256, (2, h // 2, w // 2)).astype(np.uint8) for _ in range(2)]
+    ctx = make_ctx(w, h, slots=2, fmt=fmt)
+    refs = [J.RefPic(y) for y in ys]
+    for s in range(2):
+        ctx.set_reference(s, ys[s]); ctx.set_reference_chroma(s, cs[s][0], cs[s][1])
+    wt = np.zeros(n, MC_WEIGHTS)
+    wt["weight"], wt["offset"] = rng.integers(-128, 128, (n, 2)), rng.integers(-128, 128, n)
+    wt["shift"] = rng.integers(0, 9, n)
+    wt["round"] = np.where(rng.random(n) < 0.7, (1 << wt["shift"].astype(np.int32)) >> 1, rng.integers(0, 200, n))
+    tup = lambda q: (int(q["weight"][0]), int(q["weight"][1]), int(q["offset"]), int(q["round"]), int(q["shift"]))
+    b = np.zeros(n, MC_LUMA_BLK)
+    b["w"], b["h"] = rng.choice([4, 8, 16], n), rng.choice([4, 8, 16], n)
+    b["x"], b["y"] = rng.integers(0, (w - 16) // 4, n) * 4, rng.integers(0, (h - 16) // 4, n) * 4
+    b["dir"], b["slot"], b["mv"] = rng.integers(0, 3, n), rng.integers(0, 2, (n, 2)), rng.integers(-90, 91, (n, 2, 2))
+    out = ctx.mc_luma_wp(b, wt)
+    d_b, d_w = torch.from_numpy(b.view(np.uint8)).cuda(), torch.from_numpy(wt.view(np.uint8)).cuda()
+    d_o = torch.zeros((n, 256), dtype=torch.uint8, device="cuda")
+    ctx.mc_luma_wp_dev(d_b.data_ptr(), d_w.data_ptr(), n, d_o.data_ptr()); ctx.synchronize()
+    for i in range(n):
+        q = b[i]
+        want = J.luma_pred_wp(refs[q["slot"][0]], refs[q["slot"][1]], int(q["dir"]), int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"]), q["mv"][0], q["mv"][1], tup(wt[i]))
+        k = int(q["w"]) * int(q["h"])
+        assert np.array_equal(out[i, :k].reshape(int(q["h"]), int(q["w"])), want), (i, q, wt[i])
+        assert np.array_equal(d_o[i, :k].cpu().numpy(), out[i, :k])
+    c = np.zeros(n, MC_CHROMA_BLK)
+    c["x"], c["y"] = rng.integers(0, w // 8, n) * 4, rng.integers(0, h // 8, n) * 4
+    c["dir"], c["plane"], c["slot"] = rng.integers(0, 3, n), rng.integers(0, 2, n), rng.integers(0, 2, (n, 2))
+    c["mv"] = rng.integers(-90, 91, (n, 2, 4, 2, 2))
+    outc = ctx.mc_chroma_wp(c, wt)
+    for i in range(n):
+        q = c[i]
+        want = J.chroma_pred4x4_wp(cs[q["slot"][0]][q["plane"]], cs[q["slot"][1]][q["plane"]], fmt, int(q["dir"]), int(q["x"]), int(q["y"]), q["mv"][0], q["mv"][1], tup(wt[i]))
+        assert np.array_equal(outc[i].reshape(4, 4), want), (i, q, wt[i])
+    bad = wt[:1].copy(); bad["shift"] = 9
+    with pytest.raises(JmHipError):
+        ctx.mc_luma_wp(b[:1], bad)
+    with pytest.raises(JmHipError):
+        ctx.mc_chroma_wp(c[:1], bad)
     ctx.close()
 
 

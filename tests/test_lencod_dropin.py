@@ -58,8 +58,8 @@ CASES = [
     ("G3a", ("interp", "eval", "evalp", "tq4", "tqc", "mcl", "mcc", "deblock")),              # Main, CABAC, B frame; EPZS: JM's own walk (me_epzs*.c), every candidate's distortion on the device
     ("G3b", ("interp", "eval", "evalp", "tq4", "tq8", "tqc", "mcl", "mcc", "deblock")),               # + 8x8 transform (High, CABAC): residual_transform_quant_luma_8x8
     # explicit weighted prediction (P and B): JM's searches call compute*WP / computeBiPred*2 with the weights it estimated (33 / -5, 33 + 32 / -2)
-    ("G3w", ("interp", "evalp", "tq4", "tqc", "deblock")),
-    ("G3wb", ("interp", "evalp", "tq4", "tq8", "tqc", "deblock")),           # + 8x8 transform: computeBiPredSATD2's 8x8 path (me_distortion.c:1113-1175)
+    ("G3w", ("interp", "evalp", "tq4", "tqc", "mcl", "mcc", "deblock")),
+    ("G3wb", ("interp", "evalp", "tq4", "tq8", "tqc", "mcl", "mcc", "deblock")),           # + 8x8 transform: computeBiPredSATD2's 8x8 path (me_distortion.c:1113-1175)
     ("G5", ("interp", "interpc", "ffs", "subpel", "tq4", "tq8", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),  # configs[4]: High 4:2:2, FFS, 5 refs, 8x8 transform
 ]
 
@@ -73,6 +73,7 @@ def test_lencod_with_libjmhip_writes_jm_bitstream(tmp_path, tag, must_run):
     err = r.stderr.decode(errors="replace")
     assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
     c = counters(err)
+    print(f"{tag}: calls on the device / passed to JM: {c}")
     for k in must_run:
         assert c[k] > 0, (tag, k, c)
     assert md5(out264) == MD5[tag]["md5_264"], (tag, "bitstream differs from CPU JM", c)

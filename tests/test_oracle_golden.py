@@ -292,53 +292,62 @@ def mc_golden():
 
 
 def mc_luma_records(g, tag):
-    """(x, y, bsx, bsy, p_dir, ref0, mv0, ref1, mv1, expected (bsy, bsx)) of the un-weighted luma_prediction records"""
+    """(x, y, bsx, bsy, p_dir, ref0, mv0, ref1, mv1, weights or None, expected (bsy, bsx)) of the luma_prediction records;
+    weights = (w0, w1, offset, round, shift) as the reference handed them to weighted_mc_prediction / weighted_bi_prediction"""
     for h, px in zip(g[tag + "_mcl_hdr"], g[tag + "_mcl_pix"]):
-        frame, x, y, bsx, bsy, p_dir, wp, r0, m0x, m0y, r1, m1x, m1y = [int(v) for v in h]
-        if wp:
-            continue
-        yield x, y, bsx, bsy, p_dir, r0, (m0x, m0y), r1, (m1x, m1y), px[: bsx * bsy].reshape(bsy, bsx)
+        frame, x, y, bsx, bsy, p_dir, wp, r0, m0x, m0y, r1, m1x, m1y = [int(v) for v in h[:13]]
+        yield x, y, bsx, bsy, p_dir, r0, (m0x, m0y), r1, (m1x, m1y), tuple(int(v) for v in h[13:18]) if wp else None, px[: bsx * bsy].reshape(bsy, bsx)
 
 
 def mc_chroma_records(g, tag):
     for h, px in zip(g[tag + "_mcc_hdr"], g[tag + "_mcc_pix"]):
         frame, yuv, uv, xc, yc, p_dir, wp, buffered = [int(v) for v in h[:8]]
-        if wp or not buffered:
+        if not buffered:
             continue
         r0, r1 = int(h[8]), int(h[26])
         mv0, mv1 = h[10:26].reshape(4, 2, 2), h[28:44].reshape(4, 2, 2)
-        yield yuv, uv, xc, yc, p_dir, r0, mv0, r1, mv1, px.reshape(4, 4)
+        yield yuv, uv, xc, yc, p_dir, r0, mv0, r1, mv1, tuple(int(v) for v in h[44:49]) if wp else None, px.reshape(4, 4)
 
 
-@pytest.mark.parametrize("tag", ["a", "c", "e"])
+@pytest.mark.parametrize("tag", ["a", "c", "e", "w"])
 def test_oracle_luma_prediction_matches_the_reference(tag):
-    """jmo_luma_pred == luma_prediction (mc_prediction.c:144) on the real encoder's calls: 4:2:0 P, 4:2:2 P, B picture (bi-prediction)"""
+    """jmo_luma_pred (+ jmo_weighted_samples) == luma_prediction (mc_prediction.c:144) on the real encoder's calls: 4:2:0 P, 4:2:2 P,
+    B picture (bi-prediction), and explicit weighted prediction in P and B pictures (run w)"""
     g = mc_golden()
     refs = {}
-    n = 0
-    for x, y, bsx, bsy, p_dir, r0, mv0, r1, mv1, want in mc_luma_records(g, tag):
+    n = nw = 0
+    for x, y, bsx, bsy, p_dir, r0, mv0, r1, mv1, wts, want in mc_luma_records(g, tag):
         for r in (r0, r1):
             if r >= 0 and r not in refs:
                 refs[r] = J.RefPic(g[f"{tag}_ref{r}_y"])
-        got = J.luma_pred(refs.get(r0), refs.get(r1), p_dir, x, y, bsx, bsy, mv0, mv1)
-        assert np.array_equal(got, want), (tag, x, y, bsx, bsy, p_dir, mv0, mv1)
+        if wts is None:
+            got = J.luma_pred(refs.get(r0), refs.get(r1), p_dir, x, y, bsx, bsy, mv0, mv1)
+        else:
+            got = J.luma_pred_wp(refs.get(r0), refs.get(r1), p_dir, x, y, bsx, bsy, mv0, mv1, wts)
+            nw += 1
+        assert np.array_equal(got, want), (tag, x, y, bsx, bsy, p_dir, mv0, mv1, wts)
         n += 1
-    assert n > 300
+    assert n > 300 and (nw > 300) == (tag == "w")
 
 
-@pytest.mark.parametrize("tag", ["a", "c", "e"])
+@pytest.mark.parametrize("tag", ["a", "c", "e", "w"])
 def test_oracle_chroma_prediction_matches_the_reference(tag):
-    """jmo_chroma_pred4x4 == chroma_prediction_4x4 (mc_prediction.c:568, buffered chroma sub-images) on the real encoder's calls"""
+    """jmo_chroma_pred4x4 (+ jmo_weighted_samples) == chroma_prediction_4x4 (mc_prediction.c:568, buffered chroma sub-images) on the
+    real encoder's calls"""
     g = mc_golden()
-    n = 0
-    for yuv, uv, xc, yc, p_dir, r0, mv0, r1, mv1, want in mc_chroma_records(g, tag):
+    n = nw = 0
+    for yuv, uv, xc, yc, p_dir, r0, mv0, r1, mv1, wts, want in mc_chroma_records(g, tag):
         pl = "uv"[uv]
         p0 = g[f"{tag}_ref{r0}_{pl}"] if r0 >= 0 else None
         p1 = g[f"{tag}_ref{r1}_{pl}"] if r1 >= 0 else None
-        got = J.chroma_pred4x4(p0, p1, yuv, p_dir, xc, yc, mv0, mv1)
-        assert np.array_equal(got, want), (tag, yuv, uv, xc, yc, p_dir, mv0.tolist(), mv1.tolist(), got.tolist(), want.tolist())
+        if wts is None:
+            got = J.chroma_pred4x4(p0, p1, yuv, p_dir, xc, yc, mv0, mv1)
+        else:
+            got = J.chroma_pred4x4_wp(p0, p1, yuv, p_dir, xc, yc, mv0, mv1, wts)
+            nw += 1
+        assert np.array_equal(got, want), (tag, yuv, uv, xc, yc, p_dir, mv0.tolist(), mv1.tolist(), wts, got.tolist(), want.tolist())
         n += 1
-    assert n > 100
+    assert n > 100 and (nw > 100) == (tag == "w")
 
 
 # ---------------------------------------------------------------- Intra16x16 luma: residual_transform_quant_luma_16x16
