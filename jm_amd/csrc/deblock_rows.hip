@@ -53,7 +53,9 @@ struct __attribute__((aligned(16))) DbPrep {
 
 __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restrict__ mbs, const jmhip_db_motion *__restrict__ motion,
                                                       int mb_w, int mb_h, int fmt, int direct8x8, DbPrep *__restrict__ prep,
-                                                      unsigned *__restrict__ sync, int nsync, unsigned long long *__restrict__ hand)
+                                                      unsigned *__restrict__ sync, int nsync, unsigned long long *__restrict__ hand,
+                                                      const uint8_t *__restrict__ Y, int pitchY, const uint8_t *__restrict__ U,
+                                                      const uint8_t *__restrict__ V, int pitchC, int lr, int cr)
 {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) for (int k = tid; k < nsync; k += 256) sync[k] = 0;
@@ -96,10 +98,36 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restr
     else o->c0C[comp - 1][dir][idx][edge] = c_tc0[iA][sc];
     if (idx == 0 && edge < 2) { o->ab[comp][which][0] = c_alpha[iA]; o->ab[comp][which][1] = c_beta[iB]; }
   }
-  o->bsY[dir][idx][edge] = (uint8_t)(non8x8 ? S : 0);
-  o->bsC[dir][idx][edge] = (uint8_t)(ecr >= 0 ? S : 0);
+  const int vY = non8x8 ? S : 0, vC = ecr >= 0 ? S : 0;
+  o->bsY[dir][idx][edge] = (uint8_t)vY;
+  o->bsC[dir][idx][edge] = (uint8_t)vC;
   if (l < 14) o->pad_[l] = 0;
-  if (l < 24) hand[(long)addr * 24 + l] = 0;        // hand-over granules of this macroblock: tag 0 = not there yet
+  // Hand-over granules of this macroblock (its bottom rows, for the band below): tag 0 = not there yet.  Where the band that owns the
+  // macroblock cannot change those rows -- no edge segment of the macroblock is active and neither is the left edge of its right
+  // neighbour, which would reach into its last three columns -- they are what the picture holds now, so the granule is issued right
+  // here and the band below does not wait for the band above at this column.  In a P picture of mostly skipped macroblocks that
+  // removes the wavefront start-up between bands; an intra picture (every edge active) is untouched.  Conservative: an active
+  // segment need not change a sample (alpha / beta tests), and only segments covering the bottom rows could.
+  int S2 = 0;                                          // left edge of the right neighbour, segment idx (lanes l < 4: dir 0, edge 0)
+  if (l < 4 && mbx + 1 < mb_w) {
+    const jmhip_db_mb *q2 = q + 1;
+    const bool left_ok2 = q2->df_disable_idc == 2 ? q2->slice_nr == q->slice_nr : true;
+    if (q2->df_disable_idc != 1 && left_ok2) S2 = strength_of(0, 0, idx, addr + 1, mb_w, mbs, motion);
+  }
+  const int half = (tid >> 5) & 1;
+  const unsigned anyY = (unsigned)(__ballot(vY != 0 || S2 != 0) >> (32 * half)), anyC = (unsigned)(__ballot(vC != 0 || S2 != 0) >> (32 * half));
+  if (l < 16) {
+    const bool pre = lr > 0 && mby % lr == lr - 1 && mby + 1 < mb_h && anyY == 0;
+    unsigned long long v = 0;
+    if (pre) v = (1ull << 32) | *(const uint32_t *)(Y + (long)(16 * mby + 12 + (l >> 2)) * pitchY + 16 * mbx + 4 * (l & 3));
+    hand[(long)addr * 24 + l] = v;
+  } else if (l < 24) {
+    const int qg = l - 16, RH = fmt == 2 ? 16 : 8;
+    const bool pre = cr > 0 && (fmt == 1 || fmt == 2) && mby % cr == cr - 1 && mby + 1 < mb_h && anyC == 0;
+    unsigned long long v = 0;
+    if (pre) v = (1ull << 32) | *(const uint32_t *)(((qg >> 2) ? V : U) + (long)(RH * mby + RH - 2 + ((qg >> 1) & 1)) * pitchC + 8 * mbx + 4 * (qg & 1));
+    hand[(long)addr * 24 + l] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -599,8 +627,10 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
 {
   const int mb_w = ctx->W / 16, mb_h = ctx->H / 16, nmb = mb_w * mb_h, fmt = ctx->cfg.yuv_format;
   const int nkinds = fmt ? 2 : 1, nsync = 2;
+  const int no_prefill = getenv("JMHIP_DEBLOCK_NO_PREFILL") != nullptr;              // A/B switch for profiling and tests
   hipLaunchKernelGGL(k_deblock_prep, dim3((nmb + 7) / 8), dim3(256), 0, ctx->stream, d_mbs, d_motion, mb_w, mb_h, fmt, direct8x8,
-                     (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync, (unsigned long long *)ctx->d_db_hand);
+                     (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync, (unsigned long long *)ctx->d_db_hand,
+                     (const uint8_t *)d_Y, pitchY, (const uint8_t *)d_U, (const uint8_t *)d_V, pitchC, no_prefill ? 0 : LR, no_prefill ? 0 : (fmt == 2 ? 2 : 4));
   RowArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
   A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;

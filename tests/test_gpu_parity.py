@@ -647,6 +647,60 @@ def test_deblock_random_side_info_vs_oracle(J, w, h, fmt, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("w,h,fmt,density,seed", [(1920, 1088, 1, 0.0, 1), (1920, 1088, 1, 0.03, 2), (1920, 1088, 1, 0.3, 3), (704, 576, 2, 0.05, 4),
+                                                 (320, 192, 1, 0.1, 5), (3840, 2160, 1, 0.02, 6), (64, 208, 1, 0.2, 7)])
+def test_deblock_sparse_side_info_vs_oracle(J, w, h, fmt, density, seed):
+    """P-picture-like side information: most macroblocks skipped with one common vector (no active edge segment: their hand-over granules
+    are issued by k_deblock_prep and the bands run ahead of each other), a fraction `density` of macroblocks with random type /
+    coefficients / motion, plus one fully active macroblock row and column.  Repeated: the bands' relative timing must not matter."""
+    from jm_amd.lib import db_arrays_from_tap
+    rng = np.random.default_rng(seed)
+    mw, mh = w // 16, h // 16
+    nmb = mw * mh
+    y = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    y = (y // 8 + np.kron(rng.integers(40, 200, (h // 4, w // 4)), np.ones((4, 4), np.int64))).clip(0, 255).astype(np.uint8)
+    ch, cw = (h // 2 if fmt == 1 else h), w // 2
+    u, v = rng.integers(90, 150, (ch, cw)).astype(np.uint8), rng.integers(90, 150, (ch, cw)).astype(np.uint8)
+    act = rng.random((mh, mw)) < density
+    act[mh - 1, :] = True                                  # the padded last row of a 1080p picture looks like this
+    act[:, int(rng.integers(0, mw))] = True
+    if mh > 5:
+        act[int(rng.integers(1, mh - 1)), : mw // 2] = True
+    a = act.ravel()
+    m12 = np.zeros((nmb, 12), np.int32)
+    m12[:, 0] = np.where(a, rng.choice([1, 2, 3, 8, 9, 10], nmb), 0)
+    m12[:, 2] = 28; m12[:, 3] = 27; m12[:, 4] = 27
+    m12[:, 2] += np.where(a, rng.integers(-4, 9, nmb), 0)
+    m12[:, 6] = np.where(a, rng.integers(0, 1 << 16, nmb) * rng.integers(0, 2, nmb), 0)
+    m12[:, 5] = np.where(m12[:, 6] != 0, 15, 0)
+    m12[:, 7] = 0
+    m12[:, 9] = rng.integers(-2, 3); m12[:, 10] = rng.integers(-2, 3)
+    mot = np.zeros((h // 4, w // 4, 2, 3), np.int32)
+    mot[:, :, 0, 0], mot[:, :, 0, 1] = 12, -8
+    a4 = np.kron(act, np.ones((4, 4), bool))
+    rnd = rng.integers(-9, 10, (h // 4, w // 4, 2))
+    mot[:, :, 0, 0:2] = np.where(a4[:, :, None], rnd, mot[:, :, 0, 0:2])
+    mot[:, :, 1, 2] = -1
+    oy, ou, ov = J.deblock_frame(y, u, v, fmt, m12, mot, 255, 255, 1)
+    changed = float((oy != y).mean())
+    assert changed > 0 and (density >= 0.3 or changed < 0.25)
+    mbs, mo = db_arrays_from_tap(m12, mot)
+    ctx = make_ctx(w, h, fmt=fmt)
+    for rep in range(4):
+        gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, 1)
+        assert (gy == oy).all(), (rep, np.argwhere(gy != oy)[:5])
+        assert (gu == ou).all() and (gv == ov).all(), rep
+    ctx.close()
+    os.environ["JMHIP_DEBLOCK_NO_PREFILL"] = "1"            # and the same frame with every granule coming from the band above
+    try:
+        ctx = make_ctx(w, h, fmt=fmt)
+        gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, 1)
+    finally:
+        del os.environ["JMHIP_DEBLOCK_NO_PREFILL"]
+    assert (gy == oy).all() and (gu == ou).all() and (gv == ov).all()
+    ctx.close()
+
+
 # --------------------------------------------------------------------------- full-size properties
 def test_fullsize_translation_property():
     """1080p, SR=32: when the current frame is an exact translation of the reference, every partition of
