@@ -68,6 +68,17 @@ int         jmhip_plane_geometry(const jmhip_ctx *ctx, int32_t *pitch, int32_t *
 int jmhip_set_current(jmhip_ctx *ctx, const uint16_t *luma, int32_t pitch_samples);
 int jmhip_set_current_dev(jmhip_ctx *ctx, const uint8_t *d_luma, int32_t pitch_bytes);
 
+/* The source picture straight from the file's bytes: read_one_frame's buf2img (lcommon/src/input.c:792-868, buf2img_basic :552-600; 8-bit,
+ * source size == output size) followed by pad_borders (:880-925; image.c:1243-1244) -- `raw` is one frame as it lies in the YUV file, planar
+ * Y then U then V at src_w x src_h (chroma sub-sampled per the context's yuv_format); the coded-size planes (every sample right of / below
+ * the picture repeats its left / upper neighbour) stay on the device: the luma plane becomes the current picture of the motion search
+ * (as after jmhip_set_current), jmhip_current_planes_dev hands all three to the transform / quantisation stage as the originals, and
+ * jmhip_get_current_planes copies them out as imgpel (tight pitches W and W / 2: what p_Vid->pImgOrg[0..2] hold). */
+int jmhip_set_current_frame(jmhip_ctx *ctx, const uint8_t *raw, int32_t src_w, int32_t src_h);
+int jmhip_set_current_frame_dev(jmhip_ctx *ctx, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
+int jmhip_current_planes_dev(jmhip_ctx *ctx, const uint8_t **d_y, int32_t *pitch_y, const uint8_t **d_u, const uint8_t **d_v, int32_t *pitch_c);
+int jmhip_get_current_planes(jmhip_ctx *ctx, uint16_t *y, uint16_t *u, uint16_t *v);
+
 /* Reference picture `slot` := reconstructed luma; builds the 16 quarter-pel planes on the device.
  * Replaces getSubImagesLuma(p_Vid, s) (lencod/src/img_luma.c:611-679), reached from
  * UnifiedOneForthPix (lencod/src/image.c:2187) when a picture enters the DPB (mbuffer.c:2313). */

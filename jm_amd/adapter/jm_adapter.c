@@ -55,7 +55,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -67,7 +67,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load;
 } G;
 
 static void adapter_report(void)
@@ -78,9 +78,9 @@ static void adapter_report(void)
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
                   "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld; "
                   "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches; getSubImagesChroma on the MI355X: %ld; "
-                  "weighted / bi-predictive candidate distortions on the MI355X: %ld\n",
+                  "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
-          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp);
+          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -122,7 +122,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
-    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp");
+    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -673,6 +673,48 @@ void __wrap_chroma_prediction_4x4(Macroblock *currMB, int uv, int block_x, int b
     row[0] = out[j * 4]; row[1] = out[j * 4 + 1]; row[2] = out[j * 4 + 2]; row[3] = out[j * 4 + 3];
   }
   G.n_mcc++;
+}
+
+/* ------------------------------------------------------------------ the source picture: pad_borders (lcommon/src/input.c:880; image.c:1244)
+ * JM has just read the picture (read_one_frame: buf2img into the top-left output.width x output.height of each plane); the device takes
+ * those samples as the file laid them out, builds the coded-size planes (k_load_frame: the copy + both borders) and keeps them as the
+ * current picture; the padded planes come back into JM's arrays. */
+extern void __real_pad_borders(FrameFormat, int, int, int, int, imgpel **[3]);
+void __wrap_pad_borders(FrameFormat output, int img_size_x, int img_size_y, int img_size_x_cr, int img_size_y_cr, imgpel **pImage[3])
+{
+  VideoParameters *p_Vid = p_Enc ? p_Enc->p_Vid : NULL;
+  const int sw = output.width[0], sh = output.height[0], fmt = (int)output.yuv_format;
+  const int scw = fmt ? output.width[1] : 0, sch = fmt ? output.height[1] : 0;
+  uint8_t *raw;
+  uint16_t *planes;
+  int k, x, y, rc;
+  size_t n = 0;
+  if (!p_Vid || !adapter_on(p_Vid) || !G.part_load || fmt != G.fmt || img_size_x != G.W || img_size_y != G.H || sw > G.W || sh > G.H ||
+      G.W - sw >= 16 || G.H - sh >= 16 || output.bit_depth[0] != 8 || (fmt && (output.bit_depth[1] != 8 || scw != sw / 2 || (sw & 1))) ||
+      (fmt == 1 && (sch != sh / 2 || (sh & 1))) || (fmt == 2 && sch != sh) || (fmt && (img_size_x_cr != G.W / 2 || img_size_y_cr != (fmt == 1 ? G.H / 2 : G.H)))) {
+    G.n_passed++;
+    __real_pad_borders(output, img_size_x, img_size_y, img_size_x_cr, img_size_y_cr, pImage);
+    return;
+  }
+  raw = (uint8_t *)malloc((size_t)sw * sh + (size_t)2 * scw * sch);
+  planes = (uint16_t *)malloc(((size_t)G.W * G.H + (size_t)2 * img_size_x_cr * img_size_y_cr + 1) * sizeof(uint16_t));
+  if (!raw || !planes) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+  for (k = 0; k < (fmt ? 3 : 1); k++) {
+    const int w = k ? scw : sw, h = k ? sch : sh;
+    for (y = 0; y < h; y++) for (x = 0; x < w; x++) raw[n++] = (uint8_t)pImage[k][y][x];
+  }
+  if ((rc = jmhip_set_current_frame(G.ctx, raw, sw, sh))) adapter_die("jmhip_set_current_frame", rc);
+  {
+    uint16_t *py = planes, *pu = fmt ? planes + (size_t)G.W * G.H : NULL, *pv = fmt ? pu + (size_t)img_size_x_cr * img_size_y_cr : NULL;
+    if ((rc = jmhip_get_current_planes(G.ctx, py, pu, pv))) adapter_die("jmhip_get_current_planes", rc);
+    for (y = 0; y < G.H; y++) for (x = 0; x < G.W; x++) pImage[0][y][x] = py[(size_t)y * G.W + x];
+    for (k = 1; k < (fmt ? 3 : 1); k++) {
+      const uint16_t *pc = k == 1 ? pu : pv;
+      for (y = 0; y < img_size_y_cr; y++) for (x = 0; x < img_size_x_cr; x++) pImage[k][y][x] = pc[(size_t)y * img_size_x_cr + x];
+    }
+  }
+  free(raw); free(planes);
+  G.n_load++;
 }
 
 /* ------------------------------------------------------------------ K9/K10: deblocking */

@@ -128,6 +128,7 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
   if (c->d_cur) (void)hipFree(c->d_cur);
+  if (c->d_cur_c) (void)hipFree(c->d_cur_c);
   if (c->d_sub) { for (int s = 0; s < c->cfg.num_ref_slots; s++) if (c->d_sub[s]) (void)hipFree(c->d_sub[s]); free(c->d_sub); }
   if (c->d_refc) { for (int s = 0; s < c->cfg.num_ref_slots; s++) if (c->d_refc[s]) (void)hipFree(c->d_refc[s]); free(c->d_refc); }
   if (c->h_stage) (void)hipHostFree(c->h_stage);

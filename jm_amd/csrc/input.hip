@@ -1,0 +1,98 @@
+// input.hip -- the source picture: a frame as it lies in the file -> the coded-size planes on the device (gfx950).
+//
+// Device counterpart of (reference):
+//   read_one_frame   lcommon/src/input.c:792-868   hands the Y, U, V parts of the file buffer to buf2img
+//   buf2img_basic    lcommon/src/input.c:552-600   one byte per sample, source size == output size: a straight copy
+//   pad_borders      lcommon/src/input.c:880-925   coded size > picture size (not a multiple of 16): every sample right of the picture
+//                                                  repeats its left neighbour, every row below it repeats the row above
+// which together are out[y][x] = src[min(y, src_h - 1)][min(x, src_w - 1)] per plane.  A copy: HBM-bound, 1.5 bytes read and written per
+// luma sample position (4.7 MB + 4.7 MB at 1080p 4:2:0); a thread writes four samples of one row.
+#include "jmhip_internal.h"
+
+__global__ __launch_bounds__(256) void k_load_frame(const uint8_t *__restrict__ raw, int sw, int sh, int scw, int sch,
+                                                    uint8_t *__restrict__ y, int pitch_y, int W, int H,
+                                                    uint8_t *__restrict__ u, uint8_t *__restrict__ v, int pitch_c, int cw, int ch)
+{
+  int row = blockIdx.y;                                  // rows of Y, then U, then V
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const uint8_t *src; uint8_t *dst; int w, srcw, srch, dpitch;
+  if (row < H) { src = raw; dst = y; w = W; srcw = sw; srch = sh; dpitch = pitch_y; }
+  else {
+    row -= H;
+    const int pl = row >= ch;
+    if (pl) row -= ch;
+    src = raw + (long)sw * sh + (long)pl * scw * sch; dst = pl ? v : u; w = cw; srcw = scw; srch = sch; dpitch = pitch_c;
+  }
+  if (x4 >= w) return;
+  const uint8_t *s = src + (long)min(row, srch - 1) * srcw;
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) o |= (uint32_t)s[min(x4 + k, srcw - 1)] << (8 * k);
+  *(uint32_t *)(dst + (long)row * dpitch + x4) = o;
+}
+
+static int check_source(jmhip_ctx *ctx, const char *who, const void *raw, int src_w, int src_h)
+{
+  const int fmt = ctx->cfg.yuv_format;
+  if (!raw || src_w <= 0 || src_h <= 0 || src_w > ctx->W || src_h > ctx->H || ctx->W - src_w >= 16 || ctx->H - src_h >= 16 ||
+      (fmt && (src_w & 1)) || (fmt == 1 && (src_h & 1)))
+    return jmhip_fail(ctx, JMHIP_EINVAL, "%s: source %dx%d does not pad to the coded %dx%d (less than one macroblock of padding, even size for sub-sampled chroma)",
+                      who, src_w, src_h, ctx->W, ctx->H);
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_set_current_frame_dev(jmhip_ctx *ctx, const uint8_t *d_raw, int32_t src_w, int32_t src_h)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  int r = check_source(ctx, "jmhip_set_current_frame_dev", d_raw, src_w, src_h);
+  if (r) return r;
+  const int fmt = ctx->cfg.yuv_format;
+  if (fmt && !ctx->d_cur_c) HIPCHK(ctx, hipMalloc((void **)&ctx->d_cur_c, (size_t)2 * ctx->cw * ctx->ch));
+  const int scw = fmt ? src_w / 2 : 0, sch = fmt == 1 ? src_h / 2 : (fmt == 2 ? src_h : 0);
+  hipLaunchKernelGGL(k_load_frame, dim3((ctx->W / 4 + 255) / 256, ctx->H + 2 * ctx->ch), dim3(256), 0, ctx->stream, d_raw, src_w, src_h, scw, sch,
+                     ctx->d_cur, ctx->cur_pitch, ctx->W, ctx->H, ctx->d_cur_c, ctx->d_cur_c ? ctx->d_cur_c + (size_t)ctx->cw * ctx->ch : nullptr, ctx->cw, ctx->cw, ctx->ch);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_set_current_frame(jmhip_ctx *ctx, const uint8_t *raw, int32_t src_w, int32_t src_h)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  int r = check_source(ctx, "jmhip_set_current_frame", raw, src_w, src_h);
+  if (r) return r;
+  const int fmt = ctx->cfg.yuv_format;
+  const size_t bytes = (size_t)src_w * src_h + (fmt ? (size_t)2 * (src_w / 2) * (fmt == 1 ? src_h / 2 : src_h) : 0);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, raw, bytes, hipMemcpyHostToDevice, ctx->stream));      // d_stage holds 3 x W x H bytes
+  if ((r = jmhip_set_current_frame_dev(ctx, ctx->d_stage, src_w, src_h))) return r;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_current_planes_dev(jmhip_ctx *ctx, const uint8_t **d_y, int32_t *pitch_y, const uint8_t **d_u, const uint8_t **d_v, int32_t *pitch_c)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!d_y || !pitch_y) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_current_planes_dev: bad argument");
+  *d_y = ctx->d_cur; *pitch_y = ctx->cur_pitch;
+  if (d_u) *d_u = ctx->d_cur_c;
+  if (d_v) *d_v = ctx->d_cur_c ? ctx->d_cur_c + (size_t)ctx->cw * ctx->ch : nullptr;
+  if (pitch_c) *pitch_c = ctx->cw;
+  return JMHIP_OK;
+}
+
+// host copies as imgpel, tight pitches (W, W/2): what p_Vid->pImgOrg[0..2] hold
+extern "C" int jmhip_get_current_planes(jmhip_ctx *ctx, uint16_t *y, uint16_t *u, uint16_t *v)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!y) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_get_current_planes: bad argument");
+  if ((u || v) && !ctx->d_cur_c) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_get_current_planes: no chroma planes (jmhip_set_current_frame has not run)");
+  uint8_t *st = ctx->h_stage;
+  const size_t ny = (size_t)ctx->W * ctx->H, nc = (size_t)ctx->cw * ctx->ch;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy2DAsync(st, ctx->W, ctx->d_cur, ctx->cur_pitch, ctx->W, ctx->H, hipMemcpyDeviceToHost, ctx->stream));
+  if (u || v) HIPCHK(ctx, hipMemcpyAsync(st + ny, ctx->d_cur_c, 2 * nc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ny; i++) y[i] = st[i];
+  if (u) for (size_t i = 0; i < nc; i++) u[i] = st[ny + i];
+  if (v) for (size_t i = 0; i < nc; i++) v[i] = st[ny + nc + i];
+  return JMHIP_OK;
+}

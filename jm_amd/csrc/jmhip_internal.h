@@ -18,6 +18,7 @@ struct jmhip_ctx {
   int cw, ch;            // chroma plane size
   uint8_t *d_cur;        // W x H current luma, pitch cur_pitch
   int cur_pitch;
+  uint8_t *d_cur_c;      // current chroma U then V, cw x ch bytes each (allocated by jmhip_set_current_frame)
   uint8_t **d_sub;       // [num_ref_slots] -> 16 planes
   uint8_t **d_refc;      // [num_ref_slots] -> integer chroma planes U then V, cw x ch bytes each (allocated on first use)
   uint8_t *d_stage;      // staging for host uploads (W x H luma, u8)

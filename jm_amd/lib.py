@@ -76,7 +76,7 @@ assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.items
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
 EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_plane_geometry",
-           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_reference", "jmhip_set_reference_dev",
+           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_current_frame", "jmhip_set_current_frame_dev", "jmhip_current_planes_dev", "jmhip_get_current_planes", "jmhip_set_reference", "jmhip_set_reference_dev",
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
@@ -181,6 +181,33 @@ class JmHip:
 
     def set_current_dev(self, dptr, pitch):
         self._ck(self.lib.jmhip_set_current_dev(self.h, _vp(dptr), pitch))
+
+    def set_current_frame(self, raw, src_w, src_h):
+        """read_one_frame + pad_borders: one frame's bytes as they lie in the YUV file (planar Y, U, V at src_w x src_h) -> the coded-size
+        planes on the device; the luma plane becomes the current picture"""
+        a = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
+        cw, chh = src_w // 2, (src_h // 2 if self.yuv_format == 1 else src_h)
+        assert a.size == src_w * src_h + (2 * cw * chh if self.yuv_format else 0), (a.size, src_w, src_h)
+        self._ck(self.lib.jmhip_set_current_frame(self.h, _vp(a), src_w, src_h))
+
+    def set_current_frame_dev(self, d_raw, src_w, src_h):
+        self._ck(self.lib.jmhip_set_current_frame_dev(self.h, _vp(d_raw), src_w, src_h))
+
+    def get_current_planes(self):
+        """(y, u, v) uint8 planes of the coded size as jmhip_set_current_frame left them (u, v None at 4:0:0)"""
+        cw, chh = self.W // 2, (self.H // 2 if self.yuv_format == 1 else self.H)
+        y = np.zeros((self.H, self.W), np.uint16)
+        u = np.zeros((chh, cw), np.uint16) if self.yuv_format else None
+        v = np.zeros((chh, cw), np.uint16) if self.yuv_format else None
+        self._ck(self.lib.jmhip_get_current_planes(self.h, _vp(y), _vp(u), _vp(v)))
+        return y.astype(np.uint8), (u.astype(np.uint8) if u is not None else None), (v.astype(np.uint8) if v is not None else None)
+
+    def current_planes_dev(self):
+        """device pointers (y, pitch_y, u, v, pitch_c) of the current picture's planes"""
+        py, pu, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self.lib.jmhip_current_planes_dev(self.h, C.byref(py), C.byref(a), C.byref(pu), C.byref(pv), C.byref(b)))
+        return py.value, a.value, pu.value, pv.value, b.value
 
     def set_reference(self, slot, luma):
         """getSubImagesLuma for reference `slot` (lencod/src/img_luma.c:611)."""

@@ -187,6 +187,9 @@ jmo_dist jmo_dist_i16x16(const jmo_pel orig[256], const jmo_pel pred[256], int m
 jmo_dist jmo_intra16_search(const jmo_pel e[33], int left_available, int up_available, int mode_mask, int metric, int max_pel,
                             const jmo_pel orig[256], jmo_pel pred4[4][256], int *best_mode);
 
+/* ---- source frame -> coded-size planes: buf2img_basic + pad_borders, lcommon/src/input.c:552-600, :880-925 (see jmo_interp.c) ---- */
+void jmo_load_frame(const uint8_t *raw, int src_w, int src_h, int W, int H, int yuv, jmo_pel *y, jmo_pel *u, jmo_pel *v);
+
 /* ---- motion-compensated prediction, un-weighted (lencod/src/mc_prediction.c; see jmo_mc.c) ---- */
 void jmo_luma_pred(const jmo_refpic *r0, const jmo_refpic *r1, int p_dir, int x, int y, int bsx, int bsy, jmo_mv mv0, jmo_mv mv1, jmo_pel *out);
 void jmo_chroma_pred4x4(const jmo_pel *p0, const jmo_pel *p1, int pitch, int W, int H, int yuv, int p_dir, int xc, int yc,

@@ -81,3 +81,26 @@ void jmo_sub_images_luma(const jmo_pel *src, int src_pitch, int W, int H, int ma
 #undef P
   free(tmp);
 }
+
+/* A frame as it lies in the source file (planar Y, U, V, 8-bit, source size == output size) -> the coded-size planes:
+ *   buf2img_basic    lcommon/src/input.c:552-600  one byte per sample widened to imgpel, straight copy when the sizes agree
+ *   pad_borders      lcommon/src/input.c:880-925  right border: every sample repeats its left neighbour; bottom border: every row repeats the row above
+ * (read_one_frame :792-868 hands the three planes of p_Vid->buf to buf2img; image.c:1243-1244 pads).  yuv: 0 4:0:0, 1 4:2:0, 2 4:2:2. */
+static void load_plane(const uint8_t *raw, int sw, int sh, int W, int H, jmo_pel *out)
+{
+  int x, y;
+  for (y = 0; y < sh; y++) {
+    for (x = 0; x < sw; x++) out[(long)y * W + x] = raw[(long)y * sw + x];
+    for (x = sw; x < W; x++) out[(long)y * W + x] = out[(long)y * W + x - 1];
+  }
+  for (y = sh; y < H; y++) for (x = 0; x < W; x++) out[(long)y * W + x] = out[(long)(y - 1) * W + x];
+}
+void jmo_load_frame(const uint8_t *raw, int src_w, int src_h, int W, int H, int yuv, jmo_pel *y, jmo_pel *u, jmo_pel *v)
+{
+  const int scw = src_w >> 1, sch = yuv == 1 ? src_h >> 1 : src_h, cw = W >> 1, ch = yuv == 1 ? H >> 1 : H;
+  load_plane(raw, src_w, src_h, W, H, y);
+  if (yuv == 1 || yuv == 2) {
+    load_plane(raw + (long)src_w * src_h, scw, sch, cw, ch, u);
+    load_plane(raw + (long)src_w * src_h + (long)scw * sch, scw, sch, cw, ch, v);
+  }
+}

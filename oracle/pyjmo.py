@@ -72,6 +72,7 @@ L.jmo_compute_pred_dist.restype = C.c_int64
 L.jmo_compute_pred_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
 L.jmo_weighted_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+L.jmo_load_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 L.jmo_full_search.restype = C.c_int64
 L.jmo_compute_sad.restype = C.c_int64
 L.jmo_compute_satd.restype = C.c_int64
@@ -306,6 +307,15 @@ def pred_dist(ref1, ref2, orig, bsx, bsy, test8x8, metric, pred, weights, min_mc
     orig = np.ascontiguousarray(orig, np.uint16)
     return int(L.jmo_compute_pred_dist(ref1.ptr(), (ref2 or ref1).ptr(), _p(orig), int(bsx), int(bsy), int(test8x8), int(metric), int(pred),
                                        C.byref(wp), int(max_pel), int(min_mcost), int(cand1[0]), int(cand1[1]), int(cand2[0]), int(cand2[1])))
+
+
+def load_frame(raw, src_w, src_h, w, h, yuv):
+    """read_one_frame's buf2img + pad_borders: raw planar 8-bit frame bytes -> (y, u, v) uint8 planes of the coded size (u, v None at 4:0:0)"""
+    raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
+    cw, ch = w // 2, (h // 2 if yuv == 1 else h)
+    y = np.zeros((h, w), np.uint16); u = np.zeros((ch, cw), np.uint16); v = np.zeros((ch, cw), np.uint16)
+    L.jmo_load_frame(_p(raw), int(src_w), int(src_h), int(w), int(h), int(yuv), _p(y), _p(u), _p(v))
+    return y.astype(np.uint8), (u.astype(np.uint8) if yuv else None), (v.astype(np.uint8) if yuv else None)
 
 
 # ---- motion-compensated prediction (jmo_mc.c)

@@ -71,6 +71,15 @@ static void dump_cur_frame(VideoParameters *p_Vid)
     put_i32(f, g_refs_made);
     put_plane(f, p_Vid->pCurImg, 0, 0, p_Vid->height, p_Vid->width);
     fclose(f);
+    /* the whole source picture as read_one_frame + pad_borders left it (lcommon/src/input.c:792, :880): Y, U, V at the coded size */
+    f = tap_open("cur_yuv.bin");
+    put_i32(f, g_refs_made); put_i32(f, p_Vid->yuv_format);
+    put_plane(f, p_Vid->pImgOrg[0], 0, 0, p_Vid->height, p_Vid->width);
+    if (p_Vid->yuv_format != YUV400) {
+      put_plane(f, p_Vid->pImgOrg[1], 0, 0, p_Vid->height_cr, p_Vid->width_cr);
+      put_plane(f, p_Vid->pImgOrg[2], 0, 0, p_Vid->height_cr, p_Vid->width_cr);
+    }
+    fclose(f);
     g_cur_dumped = g_refs_made;
   }
 }

@@ -34,6 +34,12 @@ def main():
             d[tag + "_mot"] = r["mot"].astype(np.int16)
             d[tag + "_d8"] = np.int32(r["d8"])
             d[tag + "_sha_pre_post"] = np.array([hashlib.sha256(p.tobytes()).hexdigest() for p in r["pre"] + r["post"]])
+        # the P picture's source as JM holds it after read_one_frame + pad_borders (1080 -> 1088 rows; dumped when its first motion search
+        # starts: clip frame 1): sha256 of Y, U, V
+        r = G.Reader(os.path.join(tmp, "cur_yuv.bin"))
+        idx, fmt = r.i32(), r.i32()
+        assert (idx, fmt) == (1, 1) and r.b[r.o:r.o + 8] == np.array([1088, 1920], np.int32).tobytes()
+        d["p_cur_yuv_sha"] = np.array([hashlib.sha256(r.plane().astype(np.uint8).tobytes()).hexdigest() for _ in range(3)])
         np.savez_compressed(os.path.join(HERE, "g2_sideinfo.npz"), **d)
         print("wrote", os.path.join(HERE, "g2_sideinfo.npz"), os.path.getsize(os.path.join(HERE, "g2_sideinfo.npz")), "bytes")
 

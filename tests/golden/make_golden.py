@@ -14,6 +14,7 @@ stores what the reference's hot-path functions were given and what they returned
   tests/golden/qcif_main.npz  Main profile with a B frame: deblock in/out (two-list strengths)
   tests/golden/qcif_mc.npz    luma_prediction / chroma_prediction_4x4 records (4:2:0 P, 4:2:2 P, B picture) + the reference planes they read
   tests/golden/qcif_intra.npz get_intrapred_4x4 records and find_sad_16x16_JM (Intra16x16 mode search) records of the same three runs
+  tests/golden/qcif_pad.npz   digests of the source picture after read_one_frame + pad_borders for a 168x136 source (coded 176x144)
   tests/golden/md5.json       .264 / recon md5 of the BASELINE.json configurations at QCIF
 
 Fixtures are data only (inputs and expected outputs); no reference source is stored.
@@ -328,6 +329,17 @@ def main():
         d["rtq_chroma"] = np.concatenate(rc)
         d["rtq16x16"] = np.concatenate(r16)
         np.savez_compressed(os.path.join(OUT, "qcif_tq8.npz"), **d)
+
+        # ---- P: a source size that is not a multiple of 16 (168x136 read from the QCIF clip's bytes): read_one_frame + pad_borders fill the
+        #         right 8 columns and the bottom 8 rows of the coded 176x144 picture; digests of the P picture's planes (clip frame 1)
+        wp = os.path.join(tmp, "P"); os.makedirs(wp)
+        run(TAP, "encoder_baseline.cfg", dict(ov, SourceWidth=168, SourceHeight=136, OutputWidth=168, OutputHeight=136), wp, tap=True)
+        r = Reader(os.path.join(wp, "cur_yuv.bin"))
+        idx, fmt = int(r.i32()), int(r.i32())
+        planes = [r.plane().astype(np.uint8) for _ in range(3)]
+        assert idx == 1 and planes[0].shape == (144, 176) and planes[1].shape == (72, 88)
+        np.savez_compressed(os.path.join(OUT, "qcif_pad.npz"), geometry=np.array([168, 136, 176, 144, fmt, idx], np.int32),
+                            sha=np.array([hashlib.sha256(p_.tobytes()).hexdigest() for p_ in planes]), y_tail=planes[0][130:, 160:], u_tail=planes[1][64:, 80:])
 
         # ---- md5 goldens of whole-encoder runs
         runs = {

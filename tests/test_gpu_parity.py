@@ -1278,3 +1278,54 @@ def test_eval_pred_vs_oracle_and_plain_eval(J, seed):
     with pytest.raises(JmHipError):
         ctx.me_eval_pred(b)
     ctx.close()
+
+
+# ---------------------------------------------------------------- the source picture: file bytes -> coded-size planes
+@pytest.mark.parametrize("sw,sh,fmt", [(168, 136, 1), (176, 144, 1), (170, 130, 2), (1920, 1080, 1), (1906, 1074, 0), (162, 144, 2)])
+def test_set_current_frame_vs_oracle_and_reference_digests(J, sw, sh, fmt):
+    """k_load_frame == read_one_frame + pad_borders: against the oracle for several geometries, against the reference encoder's own digests
+    where a fixture holds them (168x136 of the QCIF clip; the 1080p clip of configs[1]); the luma plane is the current picture afterwards"""
+    import hashlib
+    import torch
+    W, H = -(-sw // 16) * 16, -(-sh // 16) * 16
+    rng = np.random.default_rng(sw + sh)
+    n = sw * sh + (2 * (sw // 2) * (sh // 2 if fmt == 1 else sh) if fmt else 0)
+    want_sha = None
+    if (sw, sh, fmt) == (168, 136, 1):
+        g = np.load(os.path.join(G, "qcif_pad.npz"))
+        raw = np.frombuffer(open(os.path.join(G, "foreman_part_qcif.yuv"), "rb").read(), np.uint8)[n:2 * n].copy()
+        want_sha = [str(s_) for s_ in g["sha"]]
+    elif (sw, sh, fmt) == (1920, 1080, 1):
+        import tempfile
+        import bench
+        with tempfile.TemporaryDirectory() as t:
+            bench.write_yuv(os.path.join(t, "c.yuv"), 2)
+            raw = np.frombuffer(open(os.path.join(t, "c.yuv"), "rb").read(), np.uint8)[n:2 * n].copy()
+        want_sha = [str(s_) for s_ in np.load(os.path.join(G, "g2_sideinfo.npz"))["p_cur_yuv_sha"]]
+    else:
+        raw = rng.integers(0, 256, n).astype(np.uint8)
+    ctx = make_ctx(W, H, fmt=fmt)
+    ctx.set_current_frame(raw, sw, sh)
+    y, u, v = ctx.get_current_planes()
+    oy, ou, ov = J.load_frame(raw, sw, sh, W, H, fmt)
+    assert np.array_equal(y, oy)
+    if fmt:
+        assert np.array_equal(u, ou) and np.array_equal(v, ov)
+    if want_sha:
+        assert [hashlib.sha256(p.tobytes()).hexdigest() for p in (y, u, v)] == want_sha
+    # device-resident variant, and the planes' device pointers
+    d_raw = torch.from_numpy(raw).cuda()
+    ctx.set_current_frame_dev(d_raw.data_ptr(), sw, sh); ctx.synchronize()
+    y2, _, _ = ctx.get_current_planes()
+    assert np.array_equal(y2, oy)
+    py, pitch_y, pu, pv, pitch_c = ctx.current_planes_dev()
+    assert py and pitch_y >= W and (not fmt or (pu and pv and pitch_c == W // 2))
+    # the motion search sees that luma plane: a zero-motion candidate against a reference made of the same picture costs nothing
+    from jm_amd.lib import CAND
+    ctx.set_reference(0, oy)
+    c = np.zeros(1, CAND); c["pos_x"], c["pos_y"], c["bsx"], c["bsy"] = W - 16, H - 16, 16, 16
+    assert int(ctx.me_eval(0, c)[0]) == 0
+    from jm_amd.lib import JmHipError
+    with pytest.raises(JmHipError):
+        ctx.set_current_frame(np.zeros((W - 16) * H * 2, np.uint8)[: (W - 16) * sh + (2 * ((W - 16) // 2) * (sh // 2 if fmt == 1 else sh) if fmt else 0)], W - 16, sh)   # a whole macroblock of padding
+    ctx.close()

@@ -44,14 +44,14 @@ def counters(stderr):
                   r"transform/quant blocks on the MI355X: (\d+) 4x4, (\d+) 8x8, (\d+) chroma planes; prediction blocks on the MI355X: (\d+) luma, (\d+) chroma; "
                   r"Intra16x16 macroblocks on the MI355X: (\d+); candidate distortions \(computeSAD / computeSATD\) on the MI355X: (\d+); "
                   r"intra predictions on the MI355X: (\d+) 4x4 blocks, (\d+) Intra16x16 mode searches; getSubImagesChroma on the MI355X: (\d+); "
-                  r"weighted / bi-predictive candidate distortions on the MI355X: (\d+)", stderr)
+                  r"weighted / bi-predictive candidate distortions on the MI355X: (\d+); source pictures padded on the MI355X: (\d+)", stderr)
     assert m, stderr[-2000:]
-    return dict(zip(("interp", "fs", "subpel", "ffs", "deblock", "cur", "passed", "tq4", "tq8", "tqc", "mcl", "mcc", "tq16", "eval", "ip4", "i16", "interpc", "evalp"), (int(x) for x in m.groups())))
+    return dict(zip(("interp", "fs", "subpel", "ffs", "deblock", "cur", "passed", "tq4", "tq8", "tqc", "mcl", "mcc", "tq16", "eval", "ip4", "i16", "interpc", "evalp", "load"), (int(x) for x in m.groups())))
 
 
 # tag -> which adapter counters must be non-zero (what that configuration exercises on the device)
 CASES = [
-    ("G1", ("interp", "interpc", "fs", "subpel", "tq4", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),       # BASELINE configs[0]: FullSearch SR=16, 5 refs, RDO, CAVLC
+    ("G1", ("load", "interp", "interpc", "fs", "subpel", "tq4", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),       # BASELINE configs[0]: FullSearch SR=16, 5 refs, RDO, CAVLC
     ("G0", ("interp", "ffs", "subpel", "tq4", "tqc", "mcl", "mcc", "deblock")),      # encoder_baseline.cfg as shipped: FastFullSearch SR=32
     ("G1_1ref_2frames", ("interp", "fs", "subpel", "tq4", "tqc", "deblock")),
     ("G4q", ("interp", "fs", "subpel", "tq4", "tqc", "deblock")),      # configs[3] shape: 3 slices, AdaptiveRounding off (quant_4x4_normal)
@@ -60,7 +60,7 @@ CASES = [
     # explicit weighted prediction (P and B): JM's searches call compute*WP / computeBiPred*2 with the weights it estimated (33 / -5, 33 + 32 / -2)
     ("G3w", ("interp", "evalp", "tq4", "tqc", "mcl", "mcc", "deblock")),
     ("G3wb", ("interp", "evalp", "tq4", "tq8", "tqc", "mcl", "mcc", "deblock")),           # + 8x8 transform: computeBiPredSATD2's 8x8 path (me_distortion.c:1113-1175)
-    ("G5", ("interp", "interpc", "ffs", "subpel", "tq4", "tq8", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),  # configs[4]: High 4:2:2, FFS, 5 refs, 8x8 transform
+    ("G5", ("load", "interp", "interpc", "ffs", "subpel", "tq4", "tq8", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),  # configs[4]: High 4:2:2, FFS, 5 refs, 8x8 transform
 ]
 
 
@@ -97,12 +97,12 @@ def test_lencod_configs1_full_size_1080p(tmp_path):
     args = [EXE, "-d", os.path.join(G, "jm_baseline.cfg")]
     for k, v in dict(e["overrides"], OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
         args += ["-p", f"{k}={v}"]
-    env = dict(os.environ, JMHIP_ADAPTER_PARTS="interp,fs,subpel,deblock")
+    env = dict(os.environ, JMHIP_ADAPTER_PARTS="load,interp,fs,subpel,deblock")
     r = subprocess.run(args, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     err = r.stderr.decode(errors="replace")
     assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
     c = counters(err)
-    assert c["fs"] > 300000 and c["subpel"] > 300000 and c["interp"] == 2 and c["deblock"] == 2, c
+    assert c["fs"] > 300000 and c["subpel"] > 300000 and c["interp"] == 2 and c["deblock"] == 2 and c["load"] >= 2, c    # load: 1080 -> 1088 rows on the device
     assert md5(os.path.join(tmp, "o.264")) == e["md5_264"], ("bitstream differs from CPU JM", c)
     assert md5(os.path.join(tmp, "o_rec.yuv")) == e["md5_recon"], ("reconstruction differs from CPU JM", c)
     m = re.search(r"^\s*0*1\(\s*P\s*\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout.decode(errors="replace"), re.M)

@@ -469,3 +469,26 @@ def test_oracle_weighted_and_bipred_distortions_match_the_reference():
             else:
                 got = J.L.jmo_compute_satd(p1.ptr(), J._p(orig), r["bsx"], r["bsy"], r["test8x8"], r["min_mcost"], c1[0], c1[1])
             assert got == r["result"], r
+
+
+def test_oracle_source_frame_padding_matches_the_reference():
+    """jmo_load_frame == read_one_frame + pad_borders (lcommon/src/input.c:792, :880): digests of the planes the reference encoder held for
+    a 168x136 source coded as 176x144 (right and bottom padding; tests/golden/qcif_pad.npz) and for the 1080p clip of configs[1] coded as
+    1920x1088 (bottom padding; tests/golden/g2_sideinfo.npz, clip regenerated by bench.write_yuv)"""
+    g = np.load(os.path.join(G, "qcif_pad.npz"))
+    sw, sh, W, H, fmt, idx = (int(v) for v in g["geometry"])
+    raw = open(os.path.join(G, "foreman_part_qcif.yuv"), "rb").read()
+    fs = sw * sh * 3 // 2
+    y, u, v = J.load_frame(raw[idx * fs:(idx + 1) * fs], sw, sh, W, H, fmt)
+    assert [hashlib.sha256(p.tobytes()).hexdigest() for p in (y, u, v)] == [str(s_) for s_ in g["sha"]]
+    assert np.array_equal(y[130:, 160:], g["y_tail"]) and np.array_equal(u[64:, 80:], g["u_tail"])
+    assert (y[:, 168:] == y[:, 167:168]).all() and (y[136:] == y[135]).all()
+    import tempfile
+    import bench
+    with tempfile.TemporaryDirectory() as t:
+        bench.write_yuv(os.path.join(t, "c.yuv"), 2)
+        raw = open(os.path.join(t, "c.yuv"), "rb").read()
+    fs = 1920 * 1080 * 3 // 2
+    y, u, v = J.load_frame(raw[fs:2 * fs], 1920, 1080, 1920, 1088, 1)
+    want = np.load(os.path.join(G, "g2_sideinfo.npz"))["p_cur_yuv_sha"]
+    assert [hashlib.sha256(p.tobytes()).hexdigest() for p in (y, u, v)] == [str(s_) for s_ in want]
