@@ -444,6 +444,23 @@ int jmhip_mc_mb16_chroma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d
 int jmhip_tqc_rec_to_planes_dev(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, const jmhip_tqc_out *d_out, int32_t njobs, int32_t y_offset,
                                 uint8_t *d_u, uint8_t *d_v, int32_t pitch_bytes);
 
+/* Chroma intra prediction: intra_chroma_prediction (lencod/src/intra_chroma.c:530-778; Slice.intra_chroma_prediction, bound in slice.c:1135),
+ * frame macroblocks, 4:2:0 (8x8) and 4:2:2 (8x16): the DC (per 4x4 block, :590-686), horizontal, vertical and plane (:718-747) predictions of
+ * both planes.  The caller gathers the neighbour samples the way the function does (getNeighbour + UseConstrainedIntraPred, :556-574):
+ *   up[plane][i]   = imgUV[plane][pix_c.pos_y][pix_c.pos_x + i], i < 8       left[plane][j] = imgUV[plane][pix_a.pos_y + j][pix_a.pos_x], j < 8 / 16
+ *   corner[plane]  = imgUV[plane][pix_d.pos_y][pix_d.pos_x]
+ * out: n x 1024 bytes = [mode DC_PRED_8 0 / HOR_PRED_8 1 / VERT_PRED_8 2 / PLANE_8 3][plane][16 rows x 8]; a mode whose neighbours are missing
+ * (the reference leaves Slice.mpr_16x16 alone then) is zeros.  rdo_low_intra_chroma_decision (RDOptimization = 0) stays with the host. */
+typedef struct {
+  uint8_t up[2][8];
+  uint8_t left[2][16];
+  uint8_t corner[2];
+  uint8_t up_avail, left_avail, upleft_avail;
+  uint8_t reserved_[3];
+} jmhip_ic_mb;               /* 56 bytes */
+int jmhip_intra_chroma(jmhip_ctx *ctx, const jmhip_ic_mb *mbs, int32_t n, uint8_t *out);
+int jmhip_intra_chroma_dev(jmhip_ctx *ctx, const jmhip_ic_mb *d_mbs, int32_t n, uint8_t *d_out);
+
 /* ------------------------------------------------------------------------------------------
  * In-loop deblocking of a whole frame
  *

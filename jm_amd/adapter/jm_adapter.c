@@ -55,7 +55,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -67,7 +67,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load, n_ic;
 } G;
 
 static void adapter_report(void)
@@ -78,9 +78,9 @@ static void adapter_report(void)
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
                   "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld; "
                   "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches; getSubImagesChroma on the MI355X: %ld; "
-                  "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld\n",
+                  "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld; chroma intra predictions on the MI355X: %ld macroblocks\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
-          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load);
+          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load, G.n_ic);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -122,7 +122,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
-    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load");
+    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -554,6 +554,56 @@ distblk __wrap_find_sad_16x16_JM(Macroblock *currMB)
   currMB->i16mode = (char)out.mode;
   G.n_i16++;
   return (distblk)out.cost;
+}
+
+/* ------------------------------------------------------------------ chroma intra prediction
+ * intra_chroma_prediction (lencod/src/intra_chroma.c:530; Slice.intra_chroma_prediction, slice.c:1135): JM's neighbour logic (getNeighbour,
+ * constrained intra prediction) stays here, the four predictions of both planes come from the device, and with RDOptimization = 0 JM's own
+ * rdo_low_intra_chroma_decision runs on them as before (:774-777). */
+extern void __real_intra_chroma_prediction(Macroblock *, int *, int *, int *);
+void __wrap_intra_chroma_prediction(Macroblock *currMB, int *mb_up, int *mb_left, int *mb_up_left)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  InputParameters *p_Inp = currMB->p_Inp;
+  PixelPos a, c, d;
+  jmhip_ic_mb m;
+  static uint8_t out[1024];
+  int up, left[2], ul, uv, k, j, i, rc;
+  const int ch = p_Vid->mb_cr_size_y;
+  if (!adapter_on(p_Vid) || !G.part_ic || (p_Vid->yuv_format != YUV420 && p_Vid->yuv_format != YUV422) || p_Vid->mb_cr_size_x != 8 || currMB->mb_field) {
+    G.n_passed++;
+    __real_intra_chroma_prediction(currMB, mb_up, mb_left, mb_up_left);
+    return;
+  }
+  p_Vid->getNeighbour(currMB, -1, -1, p_Vid->mb_size[IS_CHROMA], &d);
+  p_Vid->getNeighbour(currMB, -1,  0, p_Vid->mb_size[IS_CHROMA], &a);
+  p_Vid->getNeighbour(currMB,  0, -1, p_Vid->mb_size[IS_CHROMA], &c);
+  up = c.available; ul = d.available; left[0] = left[1] = a.available;
+  if (p_Inp->UseConstrainedIntraPred) {
+    up = c.available ? p_Vid->intra_block[c.mb_addr] : 0;
+    left[0] = left[1] = a.available ? p_Vid->intra_block[a.mb_addr] : 0;
+    ul = d.available ? p_Vid->intra_block[d.mb_addr] : 0;
+  }
+  if (mb_up) *mb_up = up;
+  if (mb_left) *mb_left = left[0];
+  if (mb_up_left) *mb_up_left = ul;
+  memset(&m, 0, sizeof m);
+  m.up_avail = (uint8_t)(up != 0); m.left_avail = (uint8_t)(left[0] != 0); m.upleft_avail = (uint8_t)(ul != 0);
+  for (uv = 0; uv < 2; uv++) {
+    imgpel **img = p_Vid->enc_picture->imgUV[uv];
+    if (up) for (i = 0; i < 8; i++) m.up[uv][i] = (uint8_t)img[c.pos_y][c.pos_x + i];
+    if (left[0]) for (j = 0; j < ch; j++) m.left[uv][j] = (uint8_t)img[a.pos_y + j][a.pos_x];
+    if (ul) m.corner[uv] = (uint8_t)img[d.pos_y][d.pos_x];
+  }
+  if ((rc = jmhip_intra_chroma(G.ctx, &m, 1, out))) adapter_die("jmhip_intra_chroma", rc);
+  for (uv = 0; uv < 2; uv++)
+    for (k = 0; k < 4; k++) {
+      if (!(k == DC_PRED_8 || (k == VERT_PRED_8 && up) || (k == HOR_PRED_8 && left[0]) || (k == PLANE_8 && up && left[0] && ul))) continue;
+      for (j = 0; j < ch; j++) for (i = 0; i < 8; i++) currSlice->mpr_16x16[uv + 1][k][j][i] = out[k * 256 + uv * 128 + j * 8 + i];
+    }
+  G.n_ic++;
+  if (!p_Inp->rdopt) currSlice->rdo_low_intra_chroma_decision(currMB, up, left, ul);
 }
 
 /* ------------------------------------------------------------------ motion-compensated prediction

@@ -219,3 +219,80 @@ extern "C" int jmhip_intra16_search(jmhip_ctx *ctx, const jmhip_i16_mb *mbs, con
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;
 }
+
+
+// ---- chroma: intra_chroma_prediction (lencod/src/intra_chroma.c:530-778, frame macroblocks), all four modes of both planes of a macroblock.
+// 64 lanes per macroblock: lane -> (plane, sample row j < 16, half row of four samples); a lane writes its four samples of every mode.
+// DC per 4x4 block by the block's place (:590-686): top-left and bottom-right use both neighbour sums, top-right prefers the samples above,
+// bottom-left the samples to the left; 128 without neighbours.  Modes whose neighbours are missing are written as zeros (the reference
+// leaves them alone).
+static_assert(sizeof(jmhip_ic_mb) == 56, "jmhip_ic_mb is 56 bytes in include/jmhip.h");
+__global__ __launch_bounds__(256) void k_intra_chroma(const jmhip_ic_mb *__restrict__ mbs, int n, int ch, uint8_t *__restrict__ out)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 6, l = t & 63, uv = l >> 5, j = (l >> 1) & 15, bx = (l & 1) * 4;
+  if (b >= n) return;
+  const jmhip_ic_mb *q = mbs + b;
+  const uint8_t *up = q->up[uv], *left = q->left[uv];
+  const int ua = q->up_avail, la = q->left_avail, da = q->upleft_avail, corner = q->corner[uv];
+  uint8_t *o = out + (long)b * 1024 + uv * 128 + j * 8 + bx;                 // out[b][mode][plane][16 x 8]
+  uint32_t dc = 0, hor = 0, ver = 0, pl = 0;
+  if (j < ch) {
+    const int by = j & ~3;
+    int su = 0, sl = 0, s = 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { su += up[bx + i]; sl += left[by + i]; }
+    if ((by == 0) == (bx == 0)) s = (ua && la) ? (su + sl + 4) >> 3 : (ua ? (su + 2) >> 2 : (la ? (sl + 2) >> 2 : 128));
+    else if (by == 0) s = ua ? (su + 2) >> 2 : (la ? (sl + 2) >> 2 : 128);
+    else s = la ? (sl + 2) >> 2 : (ua ? (su + 2) >> 2 : 128);
+    dc = 0x01010101u * (uint32_t)s;
+    if (la) hor = 0x01010101u * (uint32_t)left[j];
+    if (ua) ver = (uint32_t)up[bx] | ((uint32_t)up[bx + 1] << 8) | ((uint32_t)up[bx + 2] << 16) | ((uint32_t)up[bx + 3] << 24);
+    if (ua && la && da) {
+      const int cr_y = ch >> 1;
+      int ih = 4 * ((int)up[7] - corner), iv = cr_y * ((int)left[ch - 1] - corner);
+#pragma unroll
+      for (int i = 0; i < 3; i++) ih += (i + 1) * ((int)up[4 + i] - (int)up[2 - i]);
+      for (int i = 0; i < cr_y - 1; i++) iv += (i + 1) * ((int)left[cr_y + i] - (int)left[cr_y - 2 - i]);
+      const int ib = (17 * ih + 16) >> 5, ic = ch == 8 ? (17 * iv + 16) >> 5 : (5 * iv + 32) >> 6;
+      const int iaa = 16 * ((int)up[7] + (int)left[ch - 1]) - 3 * ib + (1 - cr_y) * ic;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        // the shifted value is pinned before the clamp: left alone, hipcc (ROCm 7.2) fuses the first two "clamp(x >> 5, 0, 255)" into one
+        // v_ashr_pk_u8_i32 and ORs the other two bytes into bits 16..31 of its result -- which the instruction does not clear on the
+        // MI355X (it keeps what the destination register held: here the first source, 0xffff.... when that was negative), so samples
+        // 2 and 3 came out as 255 (profiles/microbench/ashr_pk_u8.hip).  The only place in the library where the pattern occurs.
+        int v = (iaa + (bx + i) * ib + j * ic + 16) >> 5;
+        asm volatile("" : "+v"(v));
+        pl |= (uint32_t)min(max(v, 0), 255) << (8 * i);
+      }
+    }
+  }
+  *(uint32_t *)(o + 0 * 256) = dc; *(uint32_t *)(o + 1 * 256) = hor; *(uint32_t *)(o + 2 * 256) = ver; *(uint32_t *)(o + 3 * 256) = pl;
+}
+
+extern "C" int jmhip_intra_chroma_dev(jmhip_ctx *ctx, const jmhip_ic_mb *d_mbs, int32_t n, uint8_t *d_out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!d_mbs || !d_out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intra_chroma_dev: bad argument");
+  if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_intra_chroma: yuv_format %d (4:2:0 and 4:2:2 only)", ctx->cfg.yuv_format);
+  if (n == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_intra_chroma, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, d_mbs, n, ctx->cfg.yuv_format == 2 ? 16 : 8, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_intra_chroma(jmhip_ctx *ctx, const jmhip_ic_mb *mbs, int32_t n, uint8_t *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!mbs || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intra_chroma: bad argument");
+  if (ctx->cfg.yuv_format != 1 && ctx->cfg.yuv_format != 2) return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "jmhip_intra_chroma: yuv_format %d (4:2:0 and 4:2:2 only)", ctx->cfg.yuv_format);
+  if (n == 0) return JMHIP_OK;
+  int r; void *din, *dout;
+  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_ic_mb), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 1, (size_t)n * 1024, &dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(din, mbs, (size_t)n * sizeof(jmhip_ic_mb), hipMemcpyHostToDevice, ctx->stream));
+  if ((r = jmhip_intra_chroma_dev(ctx, (const jmhip_ic_mb *)din, n, (uint8_t *)dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 1024, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}

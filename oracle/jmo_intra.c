@@ -7,6 +7,7 @@
  *   find_sad_16x16_JM      :463-517 with distI16x16_sad / _sse / _satd :331-452
  * Written from the prediction formulas of H.264 8.3.1.2 / 8.3.3 (which JM's per-sample assignments implement); pinned by the records of
  * the real encoder's calls in tests/golden/qcif_intra.npz. */
+#include <string.h>
 #include "jmo.h"
 
 static int top4(const jmo_pel *e, int x) { return x < 0 ? e[0] : e[1 + x]; }       /* p[x, -1], x = -1 .. 7 */
@@ -135,4 +136,53 @@ jmo_dist jmo_intra16_search(const jmo_pel e[33], int left_available, int up_avai
       if (c < best) { best = c; *best_mode = k; }
     }
   return best;
+}
+
+/* intra_chroma_prediction, lencod/src/intra_chroma.c:530-778 (frame macroblocks): the four chroma prediction modes of one plane.
+ *   up[cw] = image[pix_c.pos_y][pix_c.pos_x ...], left[ch] = image[pix_a.pos_y ...][pix_a.pos_x], corner = image[pix_d.pos_y][pix_d.pos_x]
+ *   cw = 8, ch = 8 (4:2:0) or 16 (4:2:2);  pred[mode][j * 8 + i], modes DC_PRED_8 0, HOR_PRED_8 1, VERT_PRED_8 2, PLANE_8 3 (defines.h:280-283)
+ * DC: per 4x4 block, by the block's place (:590-686): top-left both sums, top-right the upper sum first, bottom-left the left sum first,
+ * bottom-right both; 128 (dc_pred_value) without neighbours.  Vertical / horizontal only with their neighbour, plane only with all three
+ * (:690-747; the modes without their neighbours are left alone: zeros here).  Returns the mask of the modes written. */
+int jmo_intra_chroma_pred(const jmo_pel *up, const jmo_pel *left, int corner, int up_avail, int left_avail, int upleft_avail,
+                          int ch, int max_pel, jmo_pel pred[4][128])
+{
+  const int cw = 8;
+  int bx, by, i, j, mask = 1;
+  memset(pred, 0, 4 * 128 * sizeof(jmo_pel));
+  for (by = 0; by < ch; by += 4)
+    for (bx = 0; bx < cw; bx += 4) {
+      int su = 0, sl = 0, s = (max_pel + 1) >> 1;
+      for (i = 0; i < 4; i++) { su += up_avail ? up[bx + i] : 0; sl += left_avail ? left[by + i] : 0; }
+      if ((by == 0) == (bx == 0)) {                                 /* top-left, bottom-right: both sums when both are there */
+        if (up_avail && left_avail) s = (su + sl + 4) >> 3;
+        else if (up_avail) s = (su + 2) >> 2;
+        else if (left_avail) s = (sl + 2) >> 2;
+      } else if (by == 0) {                                         /* top-right: the samples above first */
+        if (up_avail) s = (su + 2) >> 2;
+        else if (left_avail) s = (sl + 2) >> 2;
+      } else {                                                      /* bottom-left: the samples to the left first */
+        if (left_avail) s = (sl + 2) >> 2;
+        else if (up_avail) s = (su + 2) >> 2;
+      }
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) pred[0][(by + j) * 8 + bx + i] = (jmo_pel)s;
+    }
+  if (up_avail) { mask |= 4; for (j = 0; j < ch; j++) for (i = 0; i < cw; i++) pred[2][j * 8 + i] = up[i]; }
+  if (left_avail) { mask |= 2; for (j = 0; j < ch; j++) for (i = 0; i < cw; i++) pred[1][j * 8 + i] = left[j]; }
+  if (left_avail && up_avail && upleft_avail) {
+    const int cr_x = cw >> 1, cr_y = ch >> 1;
+    int ih = cr_x * ((int)up[cw - 1] - corner), iv = cr_y * ((int)left[ch - 1] - corner), ib, ic, iaa;
+    for (i = 0; i < cr_x - 1; i++) ih += (i + 1) * ((int)up[cr_x + i] - (int)up[cr_x - 2 - i]);
+    for (i = 0; i < cr_y - 1; i++) iv += (i + 1) * ((int)left[cr_y + i] - (int)left[cr_y - 2 - i]);
+    ib = (17 * ih + 2 * cw) >> 5;                                   /* cr_MB_x == 8 */
+    ic = ch == 8 ? (17 * iv + 2 * ch) >> 5 : (5 * iv + 2 * ch) >> 6;
+    iaa = 16 * ((int)up[cw - 1] + (int)left[ch - 1]) + (1 - cr_x) * ib + (1 - cr_y) * ic;
+    for (j = 0; j < ch; j++)
+      for (i = 0; i < cw; i++) {
+        int v = (iaa + i * ib + j * ic + 16) >> 5;
+        pred[3][j * 8 + i] = (jmo_pel)(v < 0 ? 0 : (v > max_pel ? max_pel : v));
+      }
+    mask |= 8;
+  }
+  return mask;
 }

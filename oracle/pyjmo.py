@@ -409,6 +409,14 @@ def intra16_search(edge, left, up, mode_mask, metric, orig, max_pel=255):
     return int(c), best.value, pred.reshape(4, 16, 16).astype(np.uint8)
 
 
+def intra_chroma_pred(up, left, corner, up_avail, left_avail, upleft_avail, ch, max_pel=255):
+    """intra_chroma_prediction for one plane: returns (mask of modes written, predictions (4, ch, 8) uint8; modes DC, horizontal, vertical, plane)"""
+    u = np.ascontiguousarray(up, np.uint16); l = np.ascontiguousarray(left, np.uint16)
+    out = np.zeros((4, 128), np.uint16)
+    m = L.jmo_intra_chroma_pred(_p(u), _p(l), int(corner), int(up_avail), int(left_avail), int(upleft_avail), int(ch), int(max_pel), _p(out))
+    return int(m), out.reshape(4, 16, 8)[:, :ch].astype(np.uint8)
+
+
 def sub_images_chroma(plane, yuv):
     """getSubImagesChroma of one plane: (ny, 8, H + 2 pad_y, W + 2 pad_x) uint8, ny = 8 (4:2:0) or 4 (4:2:2)"""
     p = np.ascontiguousarray(plane, np.uint16); h, w = p.shape

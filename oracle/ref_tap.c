@@ -372,6 +372,44 @@ distblk __wrap_find_sad_16x16_JM(Macroblock *currMB)
   return r;
 }
 
+/* intra_chroma_prediction (lencod/src/intra_chroma.c:530, Slice.intra_chroma_prediction bound in slice.c:1135): the four chroma intra
+ * predictions of both planes.  record: yuv_format up left upleft | per plane: up[8] left[16] corner | per plane, per mode: 8 x ch samples
+ * (zeros for a mode the function did not write).  The neighbour flags and samples are re-derived the way the function derives them. */
+extern void __real_intra_chroma_prediction(Macroblock *, int *, int *, int *);
+void __wrap_intra_chroma_prediction(Macroblock *currMB, int *mb_up, int *mb_left, int *mb_up_left)
+{
+  static int n = 0, calls = 0;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  Slice *sl = currMB->p_Slice;
+  __real_intra_chroma_prediction(currMB, mb_up, mb_left, mb_up_left);
+  if (calls++ % 5 == 0 && n < tap_max() / 8 && (p_Vid->yuv_format == YUV420 || p_Vid->yuv_format == YUV422)) {
+    PixelPos a, c, d;
+    int up, left, ul, uv, k, j, i;
+    const int ch = p_Vid->mb_cr_size_y;
+    FILE *f = tap_open("intra_chroma.bin");
+    p_Vid->getNeighbour(currMB, -1, -1, p_Vid->mb_size[IS_CHROMA], &d);
+    p_Vid->getNeighbour(currMB, -1,  0, p_Vid->mb_size[IS_CHROMA], &a);
+    p_Vid->getNeighbour(currMB,  0, -1, p_Vid->mb_size[IS_CHROMA], &c);
+    up = c.available; left = a.available; ul = d.available;
+    if (p_Vid->p_Inp->UseConstrainedIntraPred) {
+      up = c.available ? p_Vid->intra_block[c.mb_addr] : 0; left = a.available ? p_Vid->intra_block[a.mb_addr] : 0; ul = d.available ? p_Vid->intra_block[d.mb_addr] : 0;
+    }
+    put_i32(f, p_Vid->yuv_format); put_i32(f, up); put_i32(f, left); put_i32(f, ul);
+    for (uv = 0; uv < 2; uv++) {
+      imgpel **img = p_Vid->enc_picture->imgUV[uv];
+      for (i = 0; i < 8; i++) put_i32(f, up ? img[c.pos_y][c.pos_x + i] : 0);
+      for (j = 0; j < 16; j++) put_i32(f, left && j < ch ? img[a.pos_y + j][a.pos_x] : 0);
+      put_i32(f, ul ? img[d.pos_y][d.pos_x] : 0);
+    }
+    for (uv = 0; uv < 2; uv++)
+      for (k = 0; k < 4; k++) {
+        const int written = k == DC_PRED_8 || (k == VERT_PRED_8 && up) || (k == HOR_PRED_8 && left) || (k == PLANE_8 && up && left && ul);
+        for (j = 0; j < 16; j++) for (i = 0; i < 8; i++) put_i32(f, written && j < ch ? sl->mpr_16x16[uv + 1][k][j][i] : 0);
+      }
+    fclose(f); n++;
+  }
+}
+
 /* ------------------------------------------------------------------ deblocking */
 extern void __real_DeblockFrame(VideoParameters *, imgpel **, imgpel ***);
 void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)

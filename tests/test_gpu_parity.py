@@ -1329,3 +1329,36 @@ def test_set_current_frame_vs_oracle_and_reference_digests(J, sw, sh, fmt):
     with pytest.raises(JmHipError):
         ctx.set_current_frame(np.zeros((W - 16) * H * 2, np.uint8)[: (W - 16) * sh + (2 * ((W - 16) // 2) * (sh // 2 if fmt == 1 else sh) if fmt else 0)], W - 16, sh)   # a whole macroblock of padding
     ctx.close()
+
+
+# ---------------------------------------------------------------- chroma intra prediction
+@pytest.mark.parametrize("tag,fmt", [("a", 1), ("c", 2), ("e", 1)])
+def test_intra_chroma_golden_and_random(J, tag, fmt):
+    """k_intra_chroma == intra_chroma_prediction: the reference encoder's records (tests/golden/qcif_intra.npz), then random neighbour samples
+    under every availability combination against the oracle"""
+    from jm_amd.lib import IC_MB
+    g = np.load(os.path.join(G, "qcif_intra.npz"))
+    hdr, edge, pred = g[tag + "_ic_hdr"], g[tag + "_ic_edge"], g[tag + "_ic_pred"]
+    ch = 8 if fmt == 1 else 16
+    assert (hdr[:, 0] == fmt).all()
+    m = np.zeros(len(hdr), IC_MB)
+    m["up"], m["left"], m["corner"] = edge[:, :, :8], edge[:, :, 8:24], edge[:, :, 24]
+    m["up_avail"], m["left_avail"], m["upleft_avail"] = hdr[:, 1], hdr[:, 2], hdr[:, 3]
+    ctx = make_ctx(64, 48, fmt=fmt)
+    out = ctx.intra_chroma(m)                                   # (n, mode, plane, 16, 8)
+    want = pred.transpose(0, 2, 1, 3, 4)                         # golden is (n, plane, mode, 16, 8)
+    assert np.array_equal(out[:, :, :, :ch], want[:, :, :, :ch])
+    rng = np.random.default_rng(17 + fmt)
+    n = 400
+    r = np.zeros(n, IC_MB)
+    r["up"], r["left"], r["corner"] = rng.integers(0, 256, (n, 2, 8)), rng.integers(0, 256, (n, 2, 16)), rng.integers(0, 256, (n, 2))
+    r["up_avail"], r["left_avail"], r["upleft_avail"] = rng.integers(0, 2, n), rng.integers(0, 2, n), rng.integers(0, 2, n)
+    r["up"][:40], r["left"][:40], r["corner"][:40] = rng.choice([0, 255], (40, 2, 8)), rng.choice([0, 255], (40, 2, 16)), rng.choice([0, 255], (40, 2))   # plane clipping
+    r["up_avail"][:40] = r["left_avail"][:40] = r["upleft_avail"][:40] = 1
+    got = ctx.intra_chroma(r)
+    for i in range(n):
+        for uv in range(2):
+            _, w = J.intra_chroma_pred(r[i]["up"][uv], r[i]["left"][uv], int(r[i]["corner"][uv]), int(r[i]["up_avail"]), int(r[i]["left_avail"]), int(r[i]["upleft_avail"]), ch)
+            assert np.array_equal(got[i, :, uv, :ch], w), (i, uv, r[i])
+    assert len(ctx.intra_chroma(r[:0])) == 0
+    ctx.close()

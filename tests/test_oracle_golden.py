@@ -492,3 +492,21 @@ def test_oracle_source_frame_padding_matches_the_reference():
     y, u, v = J.load_frame(raw[fs:2 * fs], 1920, 1080, 1920, 1088, 1)
     want = np.load(os.path.join(G, "g2_sideinfo.npz"))["p_cur_yuv_sha"]
     assert [hashlib.sha256(p.tobytes()).hexdigest() for p in (y, u, v)] == [str(s_) for s_ in want]
+
+
+@pytest.mark.parametrize("tag", ["a", "c", "e"])
+def test_oracle_intra_chroma_prediction_matches_the_reference(tag):
+    """jmo_intra_chroma_pred == intra_chroma_prediction (intra_chroma.c:530): DC / horizontal / vertical / plane of both planes on the
+    real encoder's calls, 4:2:0 (8x8) and 4:2:2 (8x16), every neighbour-availability combination the runs reach"""
+    g = np.load(os.path.join(G, "qcif_intra.npz"))
+    hdr, edge, pred = g[tag + "_ic_hdr"], g[tag + "_ic_edge"], g[tag + "_ic_pred"]
+    combos = set()
+    for h, e, p in zip(hdr, edge, pred):
+        yuv, up, left, ul = (int(v) for v in h)
+        ch = 8 if yuv == 1 else 16
+        for uv in range(2):
+            mask, got = J.intra_chroma_pred(e[uv][:8], e[uv][8:24], e[uv][24], up, left, ul, ch)
+            assert mask == (1 | (2 if left else 0) | (4 if up else 0) | (8 if (up and left and ul) else 0))
+            assert np.array_equal(got, p[uv][:, :ch]), (tag, h.tolist(), uv)
+        combos.add((up, left, ul))
+    assert len(hdr) > 30 and len(combos) >= 4
