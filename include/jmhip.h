@@ -444,6 +444,16 @@ int jmhip_mc_mb16_chroma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d
 int jmhip_tqc_rec_to_planes_dev(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, const jmhip_tqc_out *d_out, int32_t njobs, int32_t y_offset,
                                 uint8_t *d_u, uint8_t *d_v, int32_t pitch_bytes);
 
+/* Intra8x8 luma prediction: get_intrapred_8x8 (lencod/src/intra8x8.c:716-760; the nine modes :148-495).  edge = currMB->intra8x8_pred[pl][0..24]
+ * = Z, A..P (16 samples above and above-right), Q..X (8 samples left) as set_intrapred_8x8 (:497-601) leaves them, i.e. after
+ * LowPassForIntra8x8Pred (:85-140); mode 0..8 (VERT_PRED .. HOR_UP_PRED); left / up = the availability flags get_intrapred_8x8 is given
+ * (only the DC mode reads them).  out: n x 64 samples, row-major 8x8: Slice.mpr_8x8[pl][mode]. */
+typedef struct {
+  uint8_t edge[25];
+  uint8_t mode, left, up;
+} jmhip_ip8_blk;             /* 28 bytes */
+int jmhip_intrapred8x8(jmhip_ctx *ctx, const jmhip_ip8_blk *blks, int32_t n, uint8_t *out);
+
 /* Chroma intra prediction: intra_chroma_prediction (lencod/src/intra_chroma.c:530-778; Slice.intra_chroma_prediction, bound in slice.c:1135),
  * frame macroblocks, 4:2:0 (8x8) and 4:2:2 (8x16): the DC (per 4x4 block, :590-686), horizontal, vertical and plane (:718-747) predictions of
  * both planes.  The caller gathers the neighbour samples the way the function does (getNeighbour + UseConstrainedIntraPred, :556-574):

@@ -49,13 +49,14 @@
 #include "slice.h"
 #include "intra16x16.h"
 #include "intra4x4.h"
+#include "intra8x8.h"
 #include "jmhip.h"
 
 #define MAX_SLOTS 20
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic, part_ip8;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -67,7 +68,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load, n_ic;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load, n_ic, n_ip8;
 } G;
 
 static void adapter_report(void)
@@ -78,9 +79,9 @@ static void adapter_report(void)
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
                   "Intra16x16 macroblocks on the MI355X: %ld; candidate distortions (computeSAD / computeSATD) on the MI355X: %ld; "
                   "intra predictions on the MI355X: %ld 4x4 blocks, %ld Intra16x16 mode searches; getSubImagesChroma on the MI355X: %ld; "
-                  "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld; chroma intra predictions on the MI355X: %ld macroblocks\n",
+                  "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld; chroma intra predictions on the MI355X: %ld macroblocks; Intra8x8 predictions on the MI355X: %ld blocks\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
-          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load, G.n_ic);
+          G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load, G.n_ic, G.n_ip8);
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -122,7 +123,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
-    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic");
+    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic"); G.part_ip8 = has_part(parts, "ip8");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -520,6 +521,25 @@ void __wrap_get_intrapred_4x4(Macroblock *currMB, ColorPlane pl, int mode, int i
   if ((rc = jmhip_intrapred4x4(G.ctx, &b, 1, out))) adapter_die("jmhip_intrapred4x4", rc);
   for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) currMB->p_Slice->mpr_4x4[pl][mode][j][i] = out[4 * j + i];
   G.n_ip4++;
+}
+/* get_intrapred_8x8 (lencod/src/intra8x8.c:716, called from rd_intra_jm.c:291 / rd_intra_jm_low.c:226): set_intrapred_8x8 (neighbours,
+ * LowPassForIntra8x8Pred) stays with JM; the mode's prediction comes from the device */
+extern void __real_get_intrapred_8x8(Macroblock *, ColorPlane, int, int, int);
+void __wrap_get_intrapred_8x8(Macroblock *currMB, ColorPlane pl, int mode, int left, int up)
+{
+  jmhip_ip8_blk b;
+  uint8_t out[64];
+  int i, j, rc;
+  if (!adapter_on(currMB->p_Vid) || !G.part_ip8 || pl != PLANE_Y || mode < 0 || mode > 8) {
+    G.n_passed++;
+    __real_get_intrapred_8x8(currMB, pl, mode, left, up);
+    return;
+  }
+  for (i = 0; i < 25; i++) b.edge[i] = (uint8_t)currMB->intra8x8_pred[pl][i];
+  b.mode = (uint8_t)mode; b.left = (uint8_t)(left != 0); b.up = (uint8_t)(up != 0);
+  if ((rc = jmhip_intrapred8x8(G.ctx, &b, 1, out))) adapter_die("jmhip_intrapred8x8", rc);
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) currMB->p_Slice->mpr_8x8[pl][mode][j][i] = out[8 * j + i];
+  G.n_ip8++;
 }
 extern distblk __real_find_sad_16x16_JM(Macroblock *);
 distblk __wrap_find_sad_16x16_JM(Macroblock *currMB)

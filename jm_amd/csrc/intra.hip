@@ -296,3 +296,78 @@ extern "C" int jmhip_intra_chroma(jmhip_ctx *ctx, const jmhip_ic_mb *mbs, int32_
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JMHIP_OK;
 }
+
+
+// ---- Intra8x8: get_intrapred_8x8 (lencod/src/intra8x8.c:716-760, the nine modes :148-495) from the 25 low-pass filtered predictor samples
+// (Z, A..P, Q..X: LowPassForIntra8x8Pred :85-140 is applied by set_intrapred_8x8, which stays with the caller).  64 lanes per block, one
+// sample each; H.264 8.3.2.2.2 - 8.3.2.2.10 with p'[x,-1] = e8t(x), p'[-1,y] = e8l(y).
+static_assert(sizeof(jmhip_ip8_blk) == 28, "jmhip_ip8_blk is 28 bytes in include/jmhip.h");
+__device__ __forceinline__ int e8t(const uint8_t *e, int x) { return x < 0 ? e[0] : e[1 + x]; }      // x = -1 .. 15
+__device__ __forceinline__ int e8l(const uint8_t *e, int y) { return y < 0 ? e[0] : e[17 + y]; }     // y = -1 .. 7
+__global__ __launch_bounds__(256) void k_intrapred8x8(const jmhip_ip8_blk *__restrict__ blks, int n, uint8_t *__restrict__ out)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 6, x = t & 7, y = (t >> 3) & 7;
+  if (b >= n) return;
+  const uint8_t *e = blks[b].edge;
+  const int mode = blks[b].mode, left = blks[b].left, up = blks[b].up;
+  int v;
+  switch (mode) {
+  case 0: v = e8t(e, x); break;
+  case 1: v = e8l(e, y); break;
+  case 2: {
+    int su = 0, sl = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { su += e[1 + i]; sl += e[17 + i]; }
+    v = (up && left) ? (su + sl + 8) >> 4 : (left ? (sl + 4) >> 3 : (up ? (su + 4) >> 3 : e[1]));
+    break; }
+  case 3: v = (x == 7 && y == 7) ? (e8t(e, 14) + 3 * e8t(e, 15) + 2) >> 2 : (e8t(e, x + y) + 2 * e8t(e, x + y + 1) + e8t(e, x + y + 2) + 2) >> 2; break;
+  case 4:
+    if (x > y) v = (e8t(e, x - y - 2) + 2 * e8t(e, x - y - 1) + e8t(e, x - y) + 2) >> 2;
+    else if (x < y) v = (e8l(e, y - x - 2) + 2 * e8l(e, y - x - 1) + e8l(e, y - x) + 2) >> 2;
+    else v = (e8t(e, 0) + 2 * e[0] + e8l(e, 0) + 2) >> 2;
+    break;
+  case 5: {
+    const int z = 2 * x - y, k = x - (y >> 1);
+    if (z >= 0 && !(z & 1)) v = (e8t(e, k - 1) + e8t(e, k) + 1) >> 1;
+    else if (z > 0) v = (e8t(e, k - 2) + 2 * e8t(e, k - 1) + e8t(e, k) + 2) >> 2;
+    else if (z == -1) v = (e8l(e, 0) + 2 * e[0] + e8t(e, 0) + 2) >> 2;
+    else v = (e8l(e, y - 2 * x - 1) + 2 * e8l(e, y - 2 * x - 2) + e8l(e, y - 2 * x - 3) + 2) >> 2;
+    break; }
+  case 6: {
+    const int z = 2 * y - x, k = y - (x >> 1);
+    if (z >= 0 && !(z & 1)) v = (e8l(e, k - 1) + e8l(e, k) + 1) >> 1;
+    else if (z > 0) v = (e8l(e, k - 2) + 2 * e8l(e, k - 1) + e8l(e, k) + 2) >> 2;
+    else if (z == -1) v = (e8l(e, 0) + 2 * e[0] + e8t(e, 0) + 2) >> 2;
+    else v = (e8t(e, x - 2 * y - 1) + 2 * e8t(e, x - 2 * y - 2) + e8t(e, x - 2 * y - 3) + 2) >> 2;
+    break; }
+  case 7: {
+    const int k = x + (y >> 1);
+    v = (y & 1) ? (e8t(e, k) + 2 * e8t(e, k + 1) + e8t(e, k + 2) + 2) >> 2 : (e8t(e, k) + e8t(e, k + 1) + 1) >> 1;
+    break; }
+  default: {
+    const int z = x + 2 * y, k = y + (x >> 1);
+    if (z > 13) v = e8l(e, 7);
+    else if (z == 13) v = (e8l(e, 6) + 3 * e8l(e, 7) + 2) >> 2;
+    else if (z & 1) v = (e8l(e, k) + 2 * e8l(e, k + 1) + e8l(e, k + 2) + 2) >> 2;
+    else v = (e8l(e, k) + e8l(e, k + 1) + 1) >> 1;
+    break; }
+  }
+  out[(long)b * 64 + y * 8 + x] = (uint8_t)v;
+}
+
+extern "C" int jmhip_intrapred8x8(jmhip_ctx *ctx, const jmhip_ip8_blk *blks, int32_t n, uint8_t *out)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (n < 0 || (n > 0 && (!blks || !out))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intrapred8x8: bad argument");
+  for (int i = 0; i < n; i++) if (blks[i].mode > 8) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_intrapred8x8: block %d: mode %d", i, blks[i].mode);
+  if (n == 0) return JMHIP_OK;
+  int r; void *din, *dout;
+  if ((r = jmhip_scratch(ctx, 0, (size_t)n * sizeof(jmhip_ip8_blk), &din))) return r;
+  if ((r = jmhip_scratch(ctx, 1, (size_t)n * 64, &dout))) return r;
+  HIPCHK(ctx, hipMemcpyAsync(din, blks, (size_t)n * sizeof(jmhip_ip8_blk), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_intrapred8x8, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, (const jmhip_ip8_blk *)din, n, (uint8_t *)dout);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, (size_t)n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JMHIP_OK;
+}

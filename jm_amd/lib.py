@@ -71,6 +71,8 @@ assert MC_LUMA_BLK.itemsize == 20 and MC_CHROMA_BLK.itemsize == 72 and MC_WEIGHT
 IP4_BLK = np.dtype([("edge", "u1", (13,)), ("mode", "u1"), ("left", "u1"), ("up", "u1")])
 I16_MB = np.dtype([("edge", "u1", (33,)), ("left", "u1"), ("up", "u1"), ("mode_mask", "u1"), ("metric", "u1"), ("reserved_", "u1", (3,))])
 I16_OUT = np.dtype([("cost", "<i8"), ("mode", "<i4"), ("reserved_", "<i4"), ("pred", "u1", (4, 256))])
+IP8_BLK = np.dtype([("edge", "u1", (25,)), ("mode", "u1"), ("left", "u1"), ("up", "u1")])
+assert IP8_BLK.itemsize == 28
 IC_MB = np.dtype([("up", "u1", (2, 8)), ("left", "u1", (2, 16)), ("corner", "u1", (2,)), ("up_avail", "u1"), ("left_avail", "u1"), ("upleft_avail", "u1"),
                   ("reserved_", "u1", (3,))])
 assert IP4_BLK.itemsize == 16 and I16_MB.itemsize == 40 and I16_OUT.itemsize == 1040 and IC_MB.itemsize == 56
@@ -83,7 +85,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -393,6 +395,13 @@ class JmHip:
         ch = self.H if fmt == 2 else self.H // 2
         out = np.zeros((ny, 8, ch + 2 * pad_y, self.W // 2 + 32), np.uint16)
         self._ck(self.lib.jmhip_get_chroma_subplanes(self.h, slot, plane, _vp(out)))
+        return out
+
+    def intrapred8x8(self, blks):
+        """get_intrapred_8x8: IP8_BLK records (25 filtered predictor samples, mode, left, up) -> (n, 64) uint8"""
+        b = np.ascontiguousarray(blks, IP8_BLK)
+        out = np.zeros((len(b), 64), np.uint8)
+        self._ck(self.lib.jmhip_intrapred8x8(self.h, _vp(b), len(b), _vp(out)))
         return out
 
     def intra_chroma(self, mbs):

@@ -187,6 +187,8 @@ jmo_dist jmo_dist_i16x16(const jmo_pel orig[256], const jmo_pel pred[256], int m
 jmo_dist jmo_intra16_search(const jmo_pel e[33], int left_available, int up_available, int mode_mask, int metric, int max_pel,
                             const jmo_pel orig[256], jmo_pel pred4[4][256], int *best_mode);
 
+/* get_intrapred_8x8 intra8x8.c:716 (nine modes :148-495) on the low-pass filtered predictor samples Z, A..P, Q..X */
+void jmo_intrapred_8x8(const jmo_pel e[25], int mode, int left_available, int up_available, jmo_pel out[64]);
 /* intra_chroma_prediction intra_chroma.c:530-778: DC / horizontal / vertical / plane of one chroma plane (8 wide, ch = 8 or 16 rows) */
 int jmo_intra_chroma_pred(const jmo_pel *up, const jmo_pel *left, int corner, int up_avail, int left_avail, int upleft_avail,
                           int ch, int max_pel, jmo_pel pred[4][128]);

@@ -186,3 +186,61 @@ int jmo_intra_chroma_pred(const jmo_pel *up, const jmo_pel *left, int corner, in
   }
   return mask;
 }
+
+/* get_intrapred_8x8, lencod/src/intra8x8.c:716-760 (the nine modes :148-495): 8x8 luma intra prediction from the 25 predictor samples
+ * currMB->intra8x8_pred[pl] = Z, A..P (16 above incl. above-right), Q..X (8 left) AFTER LowPassForIntra8x8Pred (:85-140, applied by
+ * set_intrapred_8x8 :497-601).  H.264 8.3.2.2.2-8.3.2.2.10 with p'[x,-1] = top8(x), p'[-1,y] = left8(y); JM's per-sample assignments implement them. */
+static int top8(const jmo_pel *e, int x) { return x < 0 ? e[0] : e[1 + x]; }        /* p'[x, -1], x = -1 .. 15 */
+static int left8(const jmo_pel *e, int y) { return y < 0 ? e[0] : e[17 + y]; }      /* p'[-1, y], y = -1 .. 7 */
+void jmo_intrapred_8x8(const jmo_pel e[25], int mode, int left_available, int up_available, jmo_pel out[64])
+{
+  int x, y, i;
+  for (y = 0; y < 8; y++)
+    for (x = 0; x < 8; x++) {
+      int v = 0;
+      switch (mode) {
+      case 0: v = top8(e, x); break;
+      case 1: v = left8(e, y); break;
+      case 2: {
+        int su = 0, sl = 0;
+        for (i = 0; i < 8; i++) { su += e[1 + i]; sl += e[17 + i]; }
+        if (up_available && left_available) v = (su + sl + 8) >> 4;
+        else if (left_available) v = (sl + 4) >> 3;
+        else if (up_available) v = (su + 4) >> 3;
+        else v = e[1];                                                              /* P_A: holds dc_pred_value then (:216) */
+        break; }
+      case 3: v = (x == 7 && y == 7) ? (top8(e, 14) + 3 * top8(e, 15) + 2) >> 2 : (top8(e, x + y) + 2 * top8(e, x + y + 1) + top8(e, x + y + 2) + 2) >> 2; break;
+      case 4:
+        if (x > y) v = (top8(e, x - y - 2) + 2 * top8(e, x - y - 1) + top8(e, x - y) + 2) >> 2;
+        else if (x < y) v = (left8(e, y - x - 2) + 2 * left8(e, y - x - 1) + left8(e, y - x) + 2) >> 2;
+        else v = (top8(e, 0) + 2 * e[0] + left8(e, 0) + 2) >> 2;
+        break;
+      case 5: {
+        const int z = 2 * x - y, k = x - (y >> 1);
+        if (z >= 0 && !(z & 1)) v = (top8(e, k - 1) + top8(e, k) + 1) >> 1;
+        else if (z > 0) v = (top8(e, k - 2) + 2 * top8(e, k - 1) + top8(e, k) + 2) >> 2;
+        else if (z == -1) v = (left8(e, 0) + 2 * e[0] + top8(e, 0) + 2) >> 2;
+        else v = (left8(e, y - 2 * x - 1) + 2 * left8(e, y - 2 * x - 2) + left8(e, y - 2 * x - 3) + 2) >> 2;
+        break; }
+      case 6: {
+        const int z = 2 * y - x, k = y - (x >> 1);
+        if (z >= 0 && !(z & 1)) v = (left8(e, k - 1) + left8(e, k) + 1) >> 1;
+        else if (z > 0) v = (left8(e, k - 2) + 2 * left8(e, k - 1) + left8(e, k) + 2) >> 2;
+        else if (z == -1) v = (left8(e, 0) + 2 * e[0] + top8(e, 0) + 2) >> 2;
+        else v = (top8(e, x - 2 * y - 1) + 2 * top8(e, x - 2 * y - 2) + top8(e, x - 2 * y - 3) + 2) >> 2;
+        break; }
+      case 7: {
+        const int k = x + (y >> 1);
+        v = (y & 1) ? (top8(e, k) + 2 * top8(e, k + 1) + top8(e, k + 2) + 2) >> 2 : (top8(e, k) + top8(e, k + 1) + 1) >> 1;
+        break; }
+      default: {
+        const int z = x + 2 * y, k = y + (x >> 1);
+        if (z > 13) v = left8(e, 7);
+        else if (z == 13) v = (left8(e, 6) + 3 * left8(e, 7) + 2) >> 2;
+        else if (z & 1) v = (left8(e, k) + 2 * left8(e, k + 1) + left8(e, k + 2) + 2) >> 2;
+        else v = (left8(e, k) + left8(e, k + 1) + 1) >> 1;
+        break; }
+      }
+      out[y * 8 + x] = (jmo_pel)v;
+    }
+}

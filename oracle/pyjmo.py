@@ -395,6 +395,12 @@ def intrapred_4x4(edge, mode, left, up):
     return out.reshape(4, 4).astype(np.uint8)
 
 
+def intrapred_8x8(edge, mode, left, up):
+    e = np.ascontiguousarray(edge, np.uint16).reshape(25); out = np.zeros(64, np.uint16)
+    L.jmo_intrapred_8x8(_p(e), int(mode), int(left), int(up), _p(out))
+    return out.reshape(8, 8).astype(np.uint8)
+
+
 def intrapred_16x16(edge, mode, left, up, max_pel=255):
     e = np.ascontiguousarray(edge, np.uint16).reshape(33); out = np.zeros(256, np.uint16)
     L.jmo_intrapred_16x16(_p(e), int(mode), int(left), int(up), int(max_pel), _p(out))

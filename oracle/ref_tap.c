@@ -36,6 +36,7 @@
 #include "blk_prediction.h"
 #include "loop_filter.h"
 #include "img_luma.h"
+#include "intra8x8.h"
 
 static FILE *tap_open(const char *name)
 {
@@ -337,6 +338,21 @@ void __wrap_get_intrapred_4x4(Macroblock *currMB, ColorPlane pl, int mode, int i
     put_i32(f, mode); put_i32(f, left); put_i32(f, up); put_i32(f, currMB->p_Vid->max_imgpel_value);
     for (i = 0; i < 13; i++) put_i32(f, currMB->intra4x4_pred[pl][i]);
     for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) put_i32(f, currMB->p_Slice->mpr_4x4[pl][mode][j][i]);
+    fclose(f); n++;
+  }
+}
+/* get_intrapred_8x8 (lencod/src/intra8x8.c:716): record mode left up | the 25 filtered predictor samples | the 8x8 prediction */
+extern void __real_get_intrapred_8x8(Macroblock *, ColorPlane, int, int, int);
+void __wrap_get_intrapred_8x8(Macroblock *currMB, ColorPlane pl, int mode, int left, int up)
+{
+  static int n = 0, calls = 0;
+  __real_get_intrapred_8x8(currMB, pl, mode, left, up);
+  if (pl == PLANE_Y && calls++ % 7 == 0 && n < tap_max() / 4) {
+    int j, i;
+    FILE *f = tap_open("intra8x8.bin");
+    put_i32(f, mode); put_i32(f, left); put_i32(f, up);
+    for (i = 0; i < 25; i++) put_i32(f, currMB->intra8x8_pred[pl][i]);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) put_i32(f, currMB->p_Slice->mpr_8x8[pl][mode][j][i]);
     fclose(f); n++;
   }
 }

@@ -157,7 +157,7 @@ def mc_arrays(tag, workdir, d, n_luma=260, n_chroma=420):
     d[tag + "_csub_u_rows"] = np.stack([p[::13] for p in planes[0]])
 
 
-def intra_arrays(tag, workdir, d, n4=450, n16=40, nc=120):
+def intra_arrays(tag, workdir, d, n4=450, n16=40, nc=120, n8=400):
     """get_intrapred_4x4 records (mode left up max_pel | 13 predictor samples | 16 predicted) and find_sad_16x16_JM records
     (left up upleft mode_mask metric max_pel | 33 predictor samples | source 16x16 | cost lo hi, i16mode | 4 predictions) of one tapped run"""
     a = read_i32_records(os.path.join(workdir, "intra4x4.bin"), 33)
@@ -174,6 +174,10 @@ def intra_arrays(tag, workdir, d, n4=450, n16=40, nc=120):
     # intra_chroma_prediction records: yuv up left upleft | per plane up[8] left[16] corner | per plane per mode 16 rows x 8 (distinct ones, spread)
     c = np.unique(read_i32_records(os.path.join(workdir, "intra_chroma.bin"), 4 + 2 * 25 + 2 * 4 * 128), axis=0)
     c = c[:: max(1, -(-len(c) // nc))]
+    p8 = os.path.join(workdir, "intra8x8.bin")
+    if os.path.exists(p8):                                  # get_intrapred_8x8 records (8x8 transform runs): mode left up | 25 samples | 64 predicted
+        e = np.unique(read_i32_records(p8, 3 + 25 + 64), axis=0)
+        d[tag + "_i8"] = e[:: max(1, -(-len(e) // n8))].astype(np.int16)
     d[tag + "_ic_hdr"] = c[:, :4].astype(np.int16)
     d[tag + "_ic_edge"] = c[:, 4:54].reshape(-1, 2, 25).astype(np.uint8)
     d[tag + "_ic_pred"] = c[:, 54:].reshape(-1, 2, 4, 16, 8).astype(np.uint8)

@@ -34,7 +34,7 @@ def test_struct_sizes_match_the_header():
     assert L.TQ8_PARAMS.itemsize == 800 and L.TQ8_OUT.itemsize == 408 and L.DC_OUT.itemsize == 52
     assert L.MC_LUMA_BLK.itemsize == 20 and L.MC_CHROMA_BLK.itemsize == 72 and L.TQ16_OUT.itemsize == 1224
     assert L.IP4_BLK.itemsize == 16 and L.I16_MB.itemsize == 40 and L.I16_OUT.itemsize == 1040
-    assert L.CAND.itemsize == 16 and L.PRED_CAND.itemsize == 32 and L.MC_WEIGHTS.itemsize == 12 and L.IC_MB.itemsize == 56
+    assert L.CAND.itemsize == 16 and L.PRED_CAND.itemsize == 32 and L.MC_WEIGHTS.itemsize == 12 and L.IC_MB.itemsize == 56 and L.IP8_BLK.itemsize == 28
 
 
 def test_partition_table_is_the_abi_order():

@@ -1362,3 +1362,26 @@ def test_intra_chroma_golden_and_random(J, tag, fmt):
             assert np.array_equal(got[i, :, uv, :ch], w), (i, uv, r[i])
     assert len(ctx.intra_chroma(r[:0])) == 0
     ctx.close()
+
+
+def test_intrapred8x8_golden_and_random(J):
+    """k_intrapred8x8 == get_intrapred_8x8: the reference encoder's records (all nine modes), then random predictor samples against the oracle"""
+    from jm_amd.lib import IP8_BLK, JmHipError
+    rec = np.load(os.path.join(G, "qcif_intra.npz"))["c_i8"]
+    b = np.zeros(len(rec), IP8_BLK)
+    b["mode"], b["left"], b["up"], b["edge"] = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3:28]
+    ctx = make_ctx(64, 48)
+    assert np.array_equal(ctx.intrapred8x8(b), rec[:, 28:].astype(np.uint8))
+    rng = np.random.default_rng(88)
+    n = 900
+    r = np.zeros(n, IP8_BLK)
+    r["edge"], r["mode"], r["left"], r["up"] = rng.integers(0, 256, (n, 25)), np.arange(n) % 9, rng.integers(0, 2, n), rng.integers(0, 2, n)
+    r["edge"][:90] = rng.choice([0, 255], (90, 25))
+    got = ctx.intrapred8x8(r)
+    for i in range(n):
+        assert np.array_equal(got[i].reshape(8, 8), J.intrapred_8x8(r[i]["edge"], int(r[i]["mode"]), int(r[i]["left"]), int(r[i]["up"]))), (i, r[i])
+    assert len(ctx.intrapred8x8(r[:0])) == 0
+    bad = r[:1].copy(); bad["mode"] = 9
+    with pytest.raises(JmHipError):
+        ctx.intrapred8x8(bad)
+    ctx.close()

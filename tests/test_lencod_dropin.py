@@ -44,9 +44,9 @@ def counters(stderr):
                   r"transform/quant blocks on the MI355X: (\d+) 4x4, (\d+) 8x8, (\d+) chroma planes; prediction blocks on the MI355X: (\d+) luma, (\d+) chroma; "
                   r"Intra16x16 macroblocks on the MI355X: (\d+); candidate distortions \(computeSAD / computeSATD\) on the MI355X: (\d+); "
                   r"intra predictions on the MI355X: (\d+) 4x4 blocks, (\d+) Intra16x16 mode searches; getSubImagesChroma on the MI355X: (\d+); "
-                  r"weighted / bi-predictive candidate distortions on the MI355X: (\d+); source pictures padded on the MI355X: (\d+); chroma intra predictions on the MI355X: (\d+) macroblocks", stderr)
+                  r"weighted / bi-predictive candidate distortions on the MI355X: (\d+); source pictures padded on the MI355X: (\d+); chroma intra predictions on the MI355X: (\d+) macroblocks; Intra8x8 predictions on the MI355X: (\d+) blocks", stderr)
     assert m, stderr[-2000:]
-    return dict(zip(("interp", "fs", "subpel", "ffs", "deblock", "cur", "passed", "tq4", "tq8", "tqc", "mcl", "mcc", "tq16", "eval", "ip4", "i16", "interpc", "evalp", "load", "ic"), (int(x) for x in m.groups())))
+    return dict(zip(("interp", "fs", "subpel", "ffs", "deblock", "cur", "passed", "tq4", "tq8", "tqc", "mcl", "mcc", "tq16", "eval", "ip4", "i16", "interpc", "evalp", "load", "ic", "ip8"), (int(x) for x in m.groups())))
 
 
 # tag -> which adapter counters must be non-zero (what that configuration exercises on the device)
@@ -56,11 +56,11 @@ CASES = [
     ("G1_1ref_2frames", ("interp", "fs", "subpel", "tq4", "tqc", "deblock")),
     ("G4q", ("interp", "fs", "subpel", "tq4", "tqc", "deblock")),      # configs[3] shape: 3 slices, AdaptiveRounding off (quant_4x4_normal)
     ("G3a", ("ic", "interp", "eval", "evalp", "tq4", "tqc", "mcl", "mcc", "deblock")),              # Main, CABAC, B frame; EPZS: JM's own walk (me_epzs*.c), every candidate's distortion on the device
-    ("G3b", ("interp", "eval", "evalp", "tq4", "tq8", "tqc", "mcl", "mcc", "deblock")),               # + 8x8 transform (High, CABAC): residual_transform_quant_luma_8x8
+    ("G3b", ("ip8", "interp", "eval", "evalp", "tq4", "tq8", "tqc", "mcl", "mcc", "deblock")),               # + 8x8 transform (High, CABAC): residual_transform_quant_luma_8x8
     # explicit weighted prediction (P and B): JM's searches call compute*WP / computeBiPred*2 with the weights it estimated (33 / -5, 33 + 32 / -2)
     ("G3w", ("interp", "evalp", "tq4", "tqc", "mcl", "mcc", "deblock")),
     ("G3wb", ("interp", "evalp", "tq4", "tq8", "tqc", "mcl", "mcc", "deblock")),           # + 8x8 transform: computeBiPredSATD2's 8x8 path (me_distortion.c:1113-1175)
-    ("G5", ("load", "ic", "interp", "interpc", "ffs", "subpel", "tq4", "tq8", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),  # configs[4]: High 4:2:2, FFS, 5 refs, 8x8 transform
+    ("G5", ("load", "ic", "ip8", "interp", "interpc", "ffs", "subpel", "tq4", "tq8", "tqc", "tq16", "mcl", "mcc", "ip4", "i16", "deblock")),  # configs[4]: High 4:2:2, FFS, 5 refs, 8x8 transform
 ]
 
 

@@ -510,3 +510,13 @@ def test_oracle_intra_chroma_prediction_matches_the_reference(tag):
             assert np.array_equal(got, p[uv][:, :ch]), (tag, h.tolist(), uv)
         combos.add((up, left, ul))
     assert len(hdr) > 30 and len(combos) >= 4
+
+
+def test_oracle_intra8x8_prediction_matches_the_reference():
+    """jmo_intrapred_8x8 == get_intrapred_8x8 (intra8x8.c:716) on the real encoder's calls (High 4:2:2 run with the 8x8 transform): all nine modes"""
+    g = np.load(os.path.join(G, "qcif_intra.npz"))
+    rec = g["c_i8"]
+    for r in rec:
+        mode, left, up = (int(v) for v in r[:3])
+        assert np.array_equal(J.intrapred_8x8(r[3:28], mode, left, up), r[28:].reshape(8, 8).astype(np.uint8)), (mode, left, up, r[3:28].tolist())
+    assert set(rec[:, 0].tolist()) == set(range(9)) and len(rec) > 300
