@@ -60,6 +60,11 @@ int         jmhip_synchronize(jmhip_ctx *ctx);           /* wait for the context
 /* geometry of the resident padded planes: pitch (bytes), rows, bytes between the 16 sub-planes */
 int         jmhip_plane_geometry(const jmhip_ctx *ctx, int32_t *pitch, int32_t *rows, int64_t *plane_stride);
 
+/* The HIP stream every later call of this context launches on (hipStream_t; NULL = the default stream).  The context itself keeps no
+ * work in flight across the switch: ordering between the old and the new stream is the caller's (events), which is what lets independent
+ * stages of one picture -- e.g. the chroma and the luma residual paths -- run side by side.  One host thread per context, as before. */
+int jmhip_set_stream(jmhip_ctx *ctx, void *hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * Frames
  * ------------------------------------------------------------------------------------------ */

@@ -166,6 +166,13 @@ int jmhip_check_deblock_error(jmhip_ctx *ctx)
   return JMHIP_OK;
 }
 
+extern "C" int jmhip_set_stream(jmhip_ctx *ctx, void *hip_stream)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  ctx->stream = (hipStream_t)hip_stream;
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
 {
   if (!ctx) return JMHIP_EINVAL;

@@ -79,7 +79,7 @@ assert IP4_BLK.itemsize == 16 and I16_MB.itemsize == 40 and I16_OUT.itemsize == 
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
-EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_plane_geometry",
+EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_set_stream", "jmhip_plane_geometry",
            "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_current_frame", "jmhip_set_current_frame_dev", "jmhip_current_planes_dev", "jmhip_get_current_planes", "jmhip_set_reference", "jmhip_set_reference_dev",
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
@@ -177,6 +177,10 @@ class JmHip:
         return ms.value
 
     # ---- frames
+    def set_stream(self, hip_stream):
+        """launch every later call on this HIP stream (an int handle, e.g. torch.cuda.Stream.cuda_stream); ordering is the caller's"""
+        self._ck(self.lib.jmhip_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
     def set_current(self, luma):
         """p_Vid->pCurImg := luma (H x W, any integer dtype, values 0..255)."""
         a = np.ascontiguousarray(luma, np.uint16)

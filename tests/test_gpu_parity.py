@@ -1385,3 +1385,27 @@ def test_intrapred8x8_golden_and_random(J):
     with pytest.raises(JmHipError):
         ctx.intrapred8x8(bad)
     ctx.close()
+
+
+def test_set_stream_moves_the_launches(J):
+    """jmhip_set_stream: the same device-resident call on a second HIP stream gives the same result (ordering by the caller's events)"""
+    import torch
+    from jm_amd.lib import PRED_CAND
+    w, h = 128, 96
+    ref, cur = synth_pair(w, h, 3)
+    ctx = make_ctx(w, h, R=8)
+    ctx.set_reference(0, ref); ctx.set_current(cur)
+    c = np.zeros(64, PRED_CAND)
+    c["pos_x"], c["pos_y"], c["bsx"], c["bsy"], c["pred"] = (np.arange(64) % 7) * 16, (np.arange(64) // 7 % 5) * 16, 16, 16, 3
+    c["cand_x"][:, 0], c["cand_y"][:, 0] = np.arange(64) - 32, 5
+    want = ctx.me_eval_pred(c)
+    d_c = torch.from_numpy(c.view(np.uint8)).cuda()
+    d_o = torch.zeros(64, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream()); side.wait_event(ev)
+    ctx.set_stream(side.cuda_stream)
+    ctx.me_eval_pred_dev(d_c.data_ptr(), 64, d_o.data_ptr())
+    side.synchronize()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_o.cpu().numpy(), want)
+    ctx.close()
