@@ -29,24 +29,38 @@ __device__ __forceinline__ const uint8_t *umv_line2(const PlaneSet2 &ps, int qy,
 struct __attribute__((packed)) u32u { uint32_t v; };
 __device__ __forceinline__ uint32_t ld4(const uint8_t *p) { return ((const u32u *)p)->v; }
 
-// sum |H d H^T| of a 4x4 block given as four packed rows of the current and the reference samples
+// (sum |H d H^T| + 1) >> 1 of a 4x4 block given as four packed rows of the current and the reference samples: HadamardSAD4x4.
+// Packed 16-bit arithmetic, two sample rows per instruction (every intermediate fits: |row pass| <= 1020, |column pass| <= 4080):
+//   v_perm_b32 lifts column k of two rows into the halves of a register (4 + 4 per row pair), v_pk_sub_i16 forms the differences,
+//   the row butterflies are 8 v_pk_add/sub per row pair; in the column pass P = rows (0,1), Q = rows (2,3) of one column give
+//   [s0, s1] = P + swap(Q) and [s3, s2] = P - swap(Q), and since |x + y| + |x - y| = 2 max(|x|, |y|) the four outputs of the column
+//   add up to 2 max(|s0|, |s1|) + 2 max(|s2|, |s3|): no last butterfly, and the final (sum + 1) >> 1 is just the sum of the maxima.
+// About half the instructions of the scalar form (this kernel is bound by VALU issue).
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v colpair(uint32_t row_lo, uint32_t row_hi, int k)
+{
+  return __builtin_bit_cast(s2v, __builtin_amdgcn_perm(row_hi, row_lo, 0x0c040c00u + (uint32_t)k * 0x00010001u));   // [row_lo.byte k, row_hi.byte k], zero extended
+}
+__device__ __forceinline__ s2v swap2(s2v v) { return __builtin_shufflevector(v, v, 1, 0); }
+__device__ __forceinline__ s2v abs2(s2v v) { return __builtin_elementwise_max(v, (s2v)(-v)); }
 __device__ __forceinline__ int hadamard4_rows(const uint32_t c[4], const uint32_t r[4])
 {
-  int m[16], s = 0;
+  s2v m[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int a = (int)(c[i] & 255) - (int)(r[i] & 255), b = (int)((c[i] >> 8) & 255) - (int)((r[i] >> 8) & 255);
-    const int cc = (int)((c[i] >> 16) & 255) - (int)((r[i] >> 16) & 255), e = (int)(c[i] >> 24) - (int)(r[i] >> 24);
-    const int s0 = a + e, s1 = b + cc, s2 = b - cc, s3 = a - e;
-    m[4 * i] = s0 + s1; m[4 * i + 1] = s0 - s1; m[4 * i + 2] = s2 + s3; m[4 * i + 3] = s3 - s2;
+  for (int q = 0; q < 2; q++) {
+    const s2v a = colpair(c[2 * q], c[2 * q + 1], 0) - colpair(r[2 * q], r[2 * q + 1], 0), b = colpair(c[2 * q], c[2 * q + 1], 1) - colpair(r[2 * q], r[2 * q + 1], 1);
+    const s2v cc = colpair(c[2 * q], c[2 * q + 1], 2) - colpair(r[2 * q], r[2 * q + 1], 2), e = colpair(c[2 * q], c[2 * q + 1], 3) - colpair(r[2 * q], r[2 * q + 1], 3);
+    const s2v s0 = a + e, s1 = b + cc, s2 = b - cc, s3 = a - e;
+    m[q][0] = s0 + s1; m[q][1] = s0 - s1; m[q][2] = s2 + s3; m[q][3] = s3 - s2;
   }
+  s2v acc = {0, 0};
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int a = m[i], b = m[4 + i], cc = m[8 + i], e = m[12 + i];
-    const int s0 = a + e, s1 = b + cc, s2 = b - cc, s3 = a - e;
-    s += iabs2_(s0 + s1) + iabs2_(s0 - s1) + iabs2_(s2 + s3) + iabs2_(s3 - s2);
+  for (int j = 0; j < 4; j++) {
+    const s2v qs = swap2(m[1][j]);
+    const s2v x = abs2(m[0][j] + qs), y = abs2(m[0][j] - qs);                  // |s0|, |s1| and |s3|, |s2|
+    acc += __builtin_elementwise_max(x, swap2(x)) + __builtin_elementwise_max(y, swap2(y));
   }
-  return (s + 1) >> 1;
+  return (int)(unsigned short)acc.x;
 }
 __device__ __forceinline__ int sad4_rows(const uint32_t c[4], const uint32_t r[4])
 {
