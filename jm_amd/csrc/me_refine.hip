@@ -7,11 +7,11 @@
 //   computeSATD             me_distortion.c:745-825   (per 4x4 -- or per 8x8 when test8x8 -- sub-block origin through UMVLine4X)
 //   HadamardSAD4x4 / 8x8    me_distortion.c:175-258 / :266-341
 //
-// Mapping.  One workgroup = one window job = one macroblock.  Whatever the block type, a macroblock is sixteen 4x4 blocks, so
+// Mapping.  One workgroup (two waves) = one window job = one macroblock.  Whatever the block type, a macroblock is sixteen 4x4 blocks, so
 // one refinement stage (9 candidates) of all 7 block types is 7 x 16 x 9 = 1008 equal work items "SAD / Hadamard-SATD of 4x4 block
-// b at candidate c of the partition of type t that contains b"; 256 lanes take four each, with no divergence between
-// block sizes and no idle candidate lanes.  An item reads its four reference rows as (unaligned) dwords straight from the
-// plane its candidate's quarter-pel phase selects, the current macroblock sits in LDS, and the per-(partition, candidate)
+// b at candidate c of the partition of type t that contains b"; a lane owns one of the 112 (t, b) pairs and walks its nine candidates,
+// with no divergence between block sizes.  A candidate reads its four reference rows as (unaligned) dwords straight from the
+// plane its quarter-pel phase selects, the current macroblock sits in LDS, and the per-(partition, candidate)
 // sums are formed with LDS atomics.  41 lanes then replay JM's sequential strict-'<' scan over the 9 costs.
 // With the 8x8 transform (test8x8, block types 1-4) the unit is an 8x8 block (Hadamard 8x8), led by the lane of its top-left 4x4.
 #include "jmhip_internal.h"
@@ -21,13 +21,19 @@ struct PlaneSet2 { const uint8_t *base; int pitch; long plane_stride; int W, H; 
 
 __device__ __forceinline__ int iabs2_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int mvbits2(int d) { int a = iabs2_(d); return a == 0 ? 1 : 2 * (31 - __clz(a)) + 3; }
-__device__ __forceinline__ const uint8_t *umv_line2(const PlaneSet2 &ps, int qy, int qx)
+// Byte offset, from the first plane, of the sample UMVLine4X (refbuf.h:22-26) yields for quarter-pel position (qx, qy): the plane the two low
+// bits select, the ORIGIN clamped.  32-bit throughout (16 planes of an 8K picture are 0.5 GB) and with 24-bit multiplies -- v_mul_u32_u24 runs
+// at full rate, a 64-bit multiply-add at a quarter of it, and with a uniform base the loads take the offset as it is (saddr addressing), so
+// no 64-bit address arithmetic is left in the kernel.  plane_stride is a multiple of 256 (jmhip_create), pitch and row numbers are < 2^24.
+__device__ __forceinline__ uint32_t umv_off2(const PlaneSet2 &ps, int qy, int qx)
 {
   const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), ps.H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), ps.W + 15);
-  return ps.base + ((qy & 3) * 4 + (qx & 3)) * ps.plane_stride + (long)(yy + JMHIP_PAD_Y) * ps.pitch + xx + JMHIP_PAD_X;
+  return (__umul24((uint32_t)((qy & 3) * 4 + (qx & 3)), (uint32_t)(ps.plane_stride >> 8)) << 8) + __umul24((uint32_t)(yy + JMHIP_PAD_Y), (uint32_t)ps.pitch) +
+         (uint32_t)(xx + JMHIP_PAD_X);
 }
 struct __attribute__((packed)) u32u { uint32_t v; };
 __device__ __forceinline__ uint32_t ld4(const uint8_t *p) { return ((const u32u *)p)->v; }
+__device__ __forceinline__ uint32_t ld4o(const uint8_t *base, uint32_t off) { return ((const u32u *)(base + (size_t)off))->v; }
 
 // (sum |H d H^T| + 1) >> 1 of a 4x4 block given as four packed rows of the current and the reference samples: HadamardSAD4x4.
 // Packed 16-bit arithmetic, two sample rows per instruction (every intermediate fits: |row pass| <= 1020, |column pass| <= 4080):
@@ -132,14 +138,15 @@ __device__ __forceinline__ int part_of(int t, int bx4, int by4)
   }
 }
 
-#define NITEMS (7 * 16 * 9)
+#define NPAIRS (7 * 16)                             // (block type, 4x4 block) pairs of a macroblock
+#define REFINE_THREADS 128
 #define COST_MAX 0x7fffffff
 
 // T8MODE: prm.transform8x8_mode != 0 (the Hadamard 8x8 path costs ~64 VGPRs; without it the kernel runs at full occupancy)
 template <bool T8MODE>
-__global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
-                                                      jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
-                                                      PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch, int njobs)
+__global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
+                                                                 jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
+                                                                 PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch, int njobs)
 {
   __shared__ uint32_t s_cur[64];                  // the current macroblock, 16 rows x 4 dwords
   __shared__ int s_mv[JMHIP_NPART][2];            // per partition: the motion vector the running stage refines
@@ -156,49 +163,46 @@ __global__ __launch_bounds__(256) void k_me_refine_mb(const jmhip_me_job *__rest
     s_mv[tid][0] = ib.mv_x; s_mv[tid][1] = ib.mv_y;
     s_min[tid] = prm.start_hp ? ib.cost : COST_MAX;                              // mv_search.c:971-974
   }
+  // A lane owns one (block type, 4x4 block) pair for the whole kernel and walks its nine candidates: which partition the block belongs to,
+  // where it lies, its current samples and (for SAD) its offset inside the partition are worked out once instead of once per item, and a
+  // candidate costs its clamped origin, four loads and the distortion.  112 of the 128 lanes are busy; a lane's nine candidates are
+  // independent, so all their reference rows are requested before the first distortion is computed (one memory latency per stage).
+  const int pair = tid, t = pair >> 4, b4 = pair & 15, bx4 = b4 & 3, by4 = b4 >> 2;
+  const int p = pair < NPAIRS ? part_of(t, bx4, by4) : 0;
+  const bool act = pair < NPAIRS && ((mask >> p) & 1);
+  const int gx = c_geom[p][0], gy = c_geom[p][1];
 #pragma unroll 1
   for (int stage = 0; stage < 2; stage++) {
     const int step = stage == 0 ? 2 : 1, start = stage == 0 ? prm.start_hp : prm.start_qp;
     const int lambda = stage == 0 ? prm.lambda_h : prm.lambda_q, metric = stage == 0 ? prm.metric_h : prm.metric_q;
-    for (int k = tid; k < JMHIP_NPART * 9; k += 256) s_dist[k] = 0;
+    for (int k = tid; k < JMHIP_NPART * 9; k += REFINE_THREADS) s_dist[k] = 0;
     __syncthreads();
-    // Two passes over this lane's four items: first every item's reference rows are requested (the planes are far larger than
-    // L2, a load is a trip to the Infinity Cache / HBM), then the distortions are computed -- one memory latency per stage
-    // instead of one per item.
-    uint32_t rr[4][4];
-    int meta[4];                                             // p * 16 + cand, or -1: nothing to do; bit 30: 8x8 leader (loads itself)
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int item = tid + 256 * it;
-      meta[it] = -1;
-      if (item < NITEMS) {
-        const int t = item / 144, rem = item - t * 144, cand = rem >> 4, b4 = rem & 15;
-        const int bx4 = b4 & 3, by4 = b4 >> 2, p = part_of(t, bx4, by4);
-        if (((mask >> p) & 1) && cand >= start) {
-          const int cx = s_mv[p][0] + sp9_dx(cand) * step, cy = s_mv[p][1] + sp9_dy(cand) * step;
-          const bool t8 = T8MODE && p <= 8 && metric != JMHIP_METRIC_SAD;                          // mv_search.c:1630 / :1770
-          const uint8_t *r;
-          if (metric == JMHIP_METRIC_SAD) {
-            // the whole block hangs off ONE clamped origin (computeSAD): offset of this 4x4 inside its partition
-            const int px = mb_x + c_geom[p][0], py = mb_y + c_geom[p][1];
-            r = umv_line2(ps, (py << 2) + cy, (px << 2) + cx) + (long)(4 * by4 - c_geom[p][1]) * ps.pitch + (4 * bx4 - c_geom[p][0]);
-          } else r = umv_line2(ps, ((mb_y + 4 * by4) << 2) + cy, ((mb_x + 4 * bx4) << 2) + cx);
-          if (!t8) {
-            meta[it] = p * 16 + cand;
-            rr[it][0] = ld4(r); rr[it][1] = ld4(r + ps.pitch); rr[it][2] = ld4(r + 2L * ps.pitch); rr[it][3] = ld4(r + 3L * ps.pitch);
-          } else if (T8MODE && !((bx4 | by4) & 1)) {         // the top-left 4x4 leads its 8x8 block (loads in place)
-            atomicAdd(&s_dist[p * 9 + cand], (unsigned)hadamard8_lds(s_cur, 4 * by4, bx4, r, ps.pitch));
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      if (meta[it] >= 0) {
-        const int item = tid + 256 * it, b4 = item & 15, bx4 = b4 & 3, by4 = b4 >> 2;          // 144 = 9 * 16: b4 = item mod 16
+    if (act) {
+      const bool sad = metric == JMHIP_METRIC_SAD;
+      const bool t8 = T8MODE && p <= 8 && !sad;                                                      // mv_search.c:1630 / :1770
+      const int mvx = s_mv[p][0], mvy = s_mv[p][1];
+      // SAD: the whole partition hangs off ONE clamped origin (computeSAD), this block sits at a fixed offset from it;
+      // SATD: every 4x4 (8x8) sub-block has its own clamped origin (computeSATD)
+      const int qx0 = ((sad ? mb_x + gx : mb_x + 4 * bx4) << 2) + mvx, qy0 = ((sad ? mb_y + gy : mb_y + 4 * by4) << 2) + mvy;
+      const uint32_t inner = sad ? (uint32_t)(__mul24(4 * by4 - gy, ps.pitch) + (4 * bx4 - gx)) : 0u, pw = (uint32_t)ps.pitch;
+      if (!t8) {
         const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
-        const int d = metric == JMHIP_METRIC_SAD ? sad4_rows(c, rr[it]) : hadamard4_rows(c, rr[it]);
-        atomicAdd(&s_dist[(meta[it] >> 4) * 9 + (meta[it] & 15)], (unsigned)d);
+        uint32_t rr[9][4];
+#pragma unroll
+        for (int cand = 0; cand < 9; cand++)
+          if (cand >= start) {
+            const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
+            rr[cand][0] = ld4o(ps.base, r); rr[cand][1] = ld4o(ps.base, r + pw); rr[cand][2] = ld4o(ps.base, r + 2 * pw); rr[cand][3] = ld4o(ps.base, r + 3 * pw);
+          }
+#pragma unroll
+        for (int cand = 0; cand < 9; cand++)
+          if (cand >= start) atomicAdd(&s_dist[p * 9 + cand], (unsigned)(sad ? sad4_rows(c, rr[cand]) : hadamard4_rows(c, rr[cand])));
+      } else if (T8MODE && !((bx4 | by4) & 1)) {             // the top-left 4x4 leads its 8x8 block
+#pragma unroll 1
+        for (int cand = start; cand < 9; cand++) {
+          const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step);
+          atomicAdd(&s_dist[p * 9 + cand], (unsigned)hadamard8_lds(s_cur, 4 * by4, bx4, ps.base + (size_t)r, ps.pitch));
+        }
       }
     }
     __syncthreads();
@@ -234,7 +238,7 @@ void jmhip_launch_refine_mb(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs
 {
   PlaneSet2 ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H;
   if (prm->transform8x8_mode)
-    hipLaunchKernelGGL(k_me_refine_mb<true>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
+    hipLaunchKernelGGL(k_me_refine_mb<true>, dim3(njobs), dim3(REFINE_THREADS), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
   else
-    hipLaunchKernelGGL(k_me_refine_mb<false>, dim3(njobs), dim3(256), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
+    hipLaunchKernelGGL(k_me_refine_mb<false>, dim3(njobs), dim3(REFINE_THREADS), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
 }
