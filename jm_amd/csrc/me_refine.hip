@@ -152,6 +152,7 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
   __shared__ int s_mv[JMHIP_NPART][2];            // per partition: the motion vector the running stage refines
   __shared__ int s_min[JMHIP_NPART];              // min_mcost carried between the stages
   __shared__ unsigned s_dist[JMHIP_NPART * 9];    // distortion of (partition, candidate), summed over its 4x4 / 8x8 blocks
+  __shared__ uint16_t s_val[NPAIRS * 9];          // distortion of (block type, 4x4 block, candidate) as its lane computed it, for lanes with the same vector
   const int tid = threadIdx.x;
   const int jb = xcd_job_index(blockIdx.x, njobs);
   const jmhip_me_job *job = jobs + jb;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
     const int lambda = stage == 0 ? prm.lambda_h : prm.lambda_q, metric = stage == 0 ? prm.metric_h : prm.metric_q;
     for (int k = tid; k < JMHIP_NPART * 9; k += REFINE_THREADS) s_dist[k] = 0;
     __syncthreads();
+    int leader = -1;
     if (act) {
       const bool sad = metric == JMHIP_METRIC_SAD;
       const bool t8 = T8MODE && p <= 8 && !sad;                                                      // mv_search.c:1630 / :1770
@@ -185,18 +187,34 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
       // SATD: every 4x4 (8x8) sub-block has its own clamped origin (computeSATD)
       const int qx0 = ((sad ? mb_x + gx : mb_x + 4 * bx4) << 2) + mvx, qy0 = ((sad ? mb_y + gy : mb_y + 4 * by4) << 2) + mvy;
       const uint32_t inner = sad ? (uint32_t)(__mul24(4 * by4 - gy, ps.pitch) + (4 * bx4 - gx)) : 0u, pw = (uint32_t)ps.pitch;
+      // Hadamard SATD takes every 4x4 sub-block from its own clamped origin (computeSATD), so the distortion of 4x4 block b at a candidate
+      // depends on the block and the vector only, not on the partition it is counted for: when partitions of several block types carry the
+      // same vector -- the common case, one motion per macroblock -- the lane of the smallest such type computes, the others pick the nine
+      // values up from LDS.  (SAD hangs a partition off one clamped origin, so it is left alone; so are the 8x8-Hadamard types.)
+      leader = t;
+      if (!sad && !t8)
+        for (int t2 = t - 1; t2 >= 0; t2--) {
+          const int p2 = part_of(t2, bx4, by4);
+          if (((mask >> p2) & 1) && !(T8MODE && p2 <= 8) && s_mv[p2][0] == mvx && s_mv[p2][1] == mvy) leader = t2;
+        }
       if (!t8) {
-        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
-        uint32_t rr[9][4];
+        if (leader == t) {
+          const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
+          uint32_t rr[9][4];
 #pragma unroll
-        for (int cand = 0; cand < 9; cand++)
-          if (cand >= start) {
-            const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
-            rr[cand][0] = ld4o(ps.base, r); rr[cand][1] = ld4o(ps.base, r + pw); rr[cand][2] = ld4o(ps.base, r + 2 * pw); rr[cand][3] = ld4o(ps.base, r + 3 * pw);
-          }
+          for (int cand = 0; cand < 9; cand++)
+            if (cand >= start) {
+              const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
+              rr[cand][0] = ld4o(ps.base, r); rr[cand][1] = ld4o(ps.base, r + pw); rr[cand][2] = ld4o(ps.base, r + 2 * pw); rr[cand][3] = ld4o(ps.base, r + 3 * pw);
+            }
 #pragma unroll
-        for (int cand = 0; cand < 9; cand++)
-          if (cand >= start) atomicAdd(&s_dist[p * 9 + cand], (unsigned)(sad ? sad4_rows(c, rr[cand]) : hadamard4_rows(c, rr[cand])));
+          for (int cand = 0; cand < 9; cand++)
+            if (cand >= start) {
+              const unsigned d = (unsigned)(sad ? sad4_rows(c, rr[cand]) : hadamard4_rows(c, rr[cand]));
+              s_val[pair * 9 + cand] = (uint16_t)d;
+              atomicAdd(&s_dist[p * 9 + cand], d);
+            }
+        }
       } else if (T8MODE && !((bx4 | by4) & 1)) {             // the top-left 4x4 leads its 8x8 block
 #pragma unroll 1
         for (int cand = start; cand < 9; cand++) {
@@ -205,7 +223,11 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
         }
       }
     }
-    __syncthreads();
+    if (__syncthreads_or(leader >= 0 && leader != t)) {     // some lane waits for another lane's values (workgroup-uniform)
+      if (leader >= 0 && leader != t)
+        for (int cand = start; cand < 9; cand++) atomicAdd(&s_dist[p * 9 + cand], (unsigned)s_val[(leader * 16 + b4) * 9 + cand]);
+      __syncthreads();
+    }
     if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
       const int p = tid, mvx = s_mv[p][0], mvy = s_mv[p][1], pred_x = job->pred[p][0], pred_y = job->pred[p][1];
       int min_mcost = (stage == 1 && !prm.start_qp) ? COST_MAX : s_min[p];     // me_fullsearch.c:252-253

@@ -348,11 +348,14 @@ def test_subpel_and_eval_vs_oracle(J, metric, test8x8, start):
     ctx.close()
 
 
-@pytest.mark.parametrize("metric,t8mode,start,seed", [(2, 0, 0, 1), (0, 0, 1, 2), (2, 1, 0, 3), (0, 0, 0, 4), (2, 0, 1, 5)])
-def test_refine_dev_vs_oracle(J, metric, t8mode, start, seed):
+@pytest.mark.parametrize("metric,t8mode,start,seed,pool", [(2, 0, 0, 1, 0), (0, 0, 1, 2, 0), (2, 1, 0, 3, 0), (0, 0, 0, 4, 0), (2, 0, 1, 5, 0),
+                                                          (2, 0, 0, 6, 1), (2, 0, 0, 7, 3), (2, 1, 0, 8, 2), (2, 0, 1, 9, 2), (0, 0, 0, 10, 2)])
+def test_refine_dev_vs_oracle(J, metric, t8mode, start, seed, pool):
     """jmhip_me_refine_dev (BlockMotionSearch's IntPelME -> SubPelME hand-over, all partitions of every window job, device
     resident) against the oracle's sub_pel_motion_estimation: random integer MVs (incl. far outside the picture), random
-    predictors, partial partition masks, several jobs per macroblock."""
+    predictors, partial partition masks, several jobs per macroblock.  pool > 0: a macroblock's partitions draw their vectors from
+    `pool` values only (one motion per macroblock and the like), the case in which the kernel computes a 4x4 block's Hadamard
+    distortions once for all block types that carry the same vector."""
     import torch
     from jm_amd.lib import ME_JOB, ME_RESULT, PARTITIONS, NPART
     w, h = 160, 96
@@ -373,6 +376,11 @@ def test_refine_dev_vs_oracle(J, metric, t8mode, start, seed):
         jobs[i]["pred"] = rng.integers(-40, 41, (41, 2))
         ires[i]["best"]["mv_x"] = 4 * rng.integers(-50 if far else -10, 51 if far else 11, 41)
         ires[i]["best"]["mv_y"] = 4 * rng.integers(-40 if far else -8, 41 if far else 9, 41)
+        if pool:
+            pick = rng.integers(0, pool, 41)
+            ires[i]["best"]["mv_x"], ires[i]["best"]["mv_y"] = ires[i]["best"]["mv_x"][pick], ires[i]["best"]["mv_y"][pick]
+            if i % 3 == 0:
+                jobs[i]["pred"] = jobs[i]["pred"][0]                 # one predictor as well: the second stage keeps the vectors together
         for p, (bt, bx, by, bw, bh) in enumerate(PARTITIONS):       # the cost the integer search would have returned (used when start != 0)
             mv = (int(ires[i]["best"][p]["mv_x"]), int(ires[i]["best"][p]["mv_y"]))
             pred = jobs[i]["pred"][p]
