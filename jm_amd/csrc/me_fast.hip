@@ -216,8 +216,8 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
     if (tid < 6 * NP) {
       const int g = tid / NP, p = tid - g * NP, cs = cost_shift(p);
       const int py = job->pred[p][1];
-      if (g == 0) { const int px = job->pred[p][0]; s_rx64[p] = (uint32_t)(lambda * mvbits(cx + 4 * (64 - R) - px)) << cs; s_px[p] = px; }
-      for (int wy = g; wy < n1; wy += 6) s_ry[wy * RYP + p] = (uint32_t)(lambda * mvbits(cy + 4 * (wy - R) - py)) << cs;
+      if (g == 0) { const int px = job->pred[p][0]; s_rx64[p] = (uint32_t)__umul24((unsigned)lambda, (unsigned)mvbits(cx + 4 * (64 - R) - px)) << cs; s_px[p] = px; }
+      for (int wy = g; wy < n1; wy += 6) s_ry[wy * RYP + p] = (uint32_t)__umul24((unsigned)lambda, (unsigned)mvbits(cy + 4 * (wy - R) - py)) << cs;
     }
   }
   // ---- current macroblock: uniform addresses -> scalar loads, stays in SGPRs
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
         unsigned kk = s_mem[p * MPITCH + col];
 #pragma unroll
         for (int w = 1; w < NWH; w++) kk = min(kk, s_mem[(w * NP + p) * MPITCH + col]);
-        kk = add_sat(kk, (unsigned)(lambda * mvbits(cx + 4 * (col - R) - px)) << cs);     // "no candidate" stays 0xffffffff
+        kk = add_sat(kk, __umul24((unsigned)lambda, (unsigned)mvbits(cx + 4 * (col - R) - px)) << cs);     // "no candidate" stays 0xffffffff
         kcol[c] = kk;
         bk = min(bk, kk);
       }
