@@ -709,6 +709,37 @@ def test_deblock_sparse_side_info_vs_oracle(J, w, h, fmt, density, seed):
     ctx.close()
 
 
+def test_deblock_real_p_picture_side_info_1080p(J):
+    """The deblocking stage exactly as bench.py runs it: the side information JM's DeblockFrame was given for the P picture of
+    BASELINE.json configs[1] (tests/golden/g2_sideinfo.npz: 78 % skipped macroblocks, the padded last macroblock row all P8x8 / intra)
+    on a 1080p picture of the synthetic clip -- the device against the oracle, repeated, and with the pre-issued hand-over granules off."""
+    import bench
+    from jm_amd.lib import db_arrays_from_tap
+    g2 = np.load(os.path.join(G, "g2_sideinfo.npz"))
+    m12, mot = g2["p_mbs"].astype(np.int32), g2["p_mot"].astype(np.int32)
+    y = bench.synth_luma(2)[1]
+    h, w = y.shape
+    assert (h, w) == (1088, 1920)
+    u = np.clip(np.rint(128 + 0.25 * (y[::2, ::2].astype(np.float32) - 128)), 0, 255).astype(np.uint8)
+    v = np.clip(np.rint(128 - 0.25 * (y[::2, ::2].astype(np.float32) - 128)), 0, 255).astype(np.uint8)
+    oy, ou, ov = J.deblock_frame(y, u, v, 1, m12, mot, 255, 255, int(g2["p_d8"]))
+    assert 0 < float((oy != y).mean()) < 0.05
+    mbs, mo = db_arrays_from_tap(m12, mot)
+    ctx = make_ctx(w, h, fmt=1)
+    for rep in range(3):
+        gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, int(g2["p_d8"]))
+        assert (gy == oy).all() and (gu == ou).all() and (gv == ov).all(), rep
+    ctx.close()
+    os.environ["JMHIP_DEBLOCK_NO_PREFILL"] = "1"
+    try:
+        ctx = make_ctx(w, h, fmt=1)
+        gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, int(g2["p_d8"]))
+    finally:
+        del os.environ["JMHIP_DEBLOCK_NO_PREFILL"]
+    assert (gy == oy).all() and (gu == ou).all() and (gv == ov).all()
+    ctx.close()
+
+
 # --------------------------------------------------------------------------- full-size properties
 def test_fullsize_translation_property():
     """1080p, SR=32: when the current frame is an exact translation of the reference, every partition of
