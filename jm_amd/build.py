@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libjmhip.so")
-SOURCES = ["ctx.hip", "input.hip", "interp.hip", "me_fullsearch.hip", "me_fast.hip", "me_subpel.hip", "me_refine.hip", "tq.hip", "tq8.hip", "tq16.hip", "tq_chroma.hip", "mc.hip", "intra.hip", "distortion.hip", "deblock.hip", "deblock_rows.hip"]
+SOURCES = ["ctx.hip", "input.hip", "interp.hip", "me_fullsearch.hip", "me_fast.hip", "me_subpel.hip", "me_refine.hip", "tq.hip", "tq8.hip", "tq16.hip", "tq_chroma.hip", "mc.hip", "intra.hip", "distortion.hip", "deblock.hip", "deblock_rows.hip", "deblock_sparse.hip"]
 
 
 def hipcc():

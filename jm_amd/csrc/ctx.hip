@@ -116,6 +116,8 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   CK(hipMalloc(&c->d_db_prep, (size_t)(c->W / 16) * (c->H / 16) * 192));
   CK(hipMalloc((void **)&c->d_db_sync, 64 + (size_t)(c->H / 16) * 2 * 6 * 8));
   CK(hipMalloc(&c->d_db_hand, (size_t)(c->W / 16) * (c->H / 16) * 192));
+  CK(hipMalloc((void **)&c->d_db_flags, (size_t)(c->W / 16) * (c->H / 16) * 2 + 16));
+  CK(hipMalloc(&c->d_db_tasks, 1024 * 8));
   for (int k = 0; k < JMHIP_NKINDS; k++) { CK(hipEventCreate(&c->ev0[k])); CK(hipEventCreate(&c->ev1[k])); }
   CK(hipStreamSynchronize(c->stream));
 #undef CK
@@ -140,6 +142,8 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   if (c->d_me_declined) (void)hipFree(c->d_me_declined);
   if (c->d_db_sync) (void)hipFree(c->d_db_sync);
   if (c->d_db_hand) (void)hipFree(c->d_db_hand);
+  if (c->d_db_flags) (void)hipFree(c->d_db_flags);
+  if (c->d_db_tasks) (void)hipFree(c->d_db_tasks);
   for (int k = 0; k < JMHIP_NKINDS; k++) { if (c->ev0[k]) (void)hipEventDestroy(c->ev0[k]); if (c->ev1[k]) (void)hipEventDestroy(c->ev1[k]); }
   free(c);
 }

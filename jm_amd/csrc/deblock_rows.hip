@@ -51,11 +51,12 @@ struct __attribute__((aligned(16))) DbPrep {
 };                           // 192 bytes = 12 x 16
 #define PREP_VEC 12
 
+#ifndef DB_SPARSE
 __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restrict__ mbs, const jmhip_db_motion *__restrict__ motion,
                                                       int mb_w, int mb_h, int fmt, int direct8x8, DbPrep *__restrict__ prep,
                                                       unsigned *__restrict__ sync, int nsync, unsigned long long *__restrict__ hand,
                                                       const uint8_t *__restrict__ Y, int pitchY, const uint8_t *__restrict__ U,
-                                                      const uint8_t *__restrict__ V, int pitchC, int lr, int cr)
+                                                      const uint8_t *__restrict__ V, int pitchC, int lr, int cr, uint8_t *__restrict__ flags)
 {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) for (int k = tid; k < nsync; k += 256) sync[k] = 0;
@@ -115,7 +116,11 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restr
     if (q2->df_disable_idc != 1 && left_ok2) S2 = strength_of(0, 0, idx, addr + 1, mb_w, mbs, motion);
   }
   const int half = (tid >> 5) & 1;
-  const unsigned anyY = (unsigned)(__ballot(vY != 0 || S2 != 0) >> (32 * half)), anyC = (unsigned)(__ballot(vC != 0 || S2 != 0) >> (32 * half));
+  const unsigned ownY = (unsigned)(__ballot(vY != 0) >> (32 * half)), ownC = (unsigned)(__ballot(vC != 0) >> (32 * half)), nbr = (unsigned)(__ballot(S2 != 0) >> (32 * half));
+  const unsigned anyY = ownY | nbr, anyC = ownC | nbr;
+  // for the segment walks (deblock_sparse.hip): bit 0 = some segment of this macroblock is active, bit 1 = its left edge is (luma or chroma:
+  // lanes 0..3 hold dir 0, edge 0) -- where it is not, nothing connects this macroblock to its left neighbour and a row can be cut
+  if (flags && l == 0) flags[addr] = (uint8_t)(((ownY | ownC) != 0) | ((((ownY | ownC) & 0xfu) != 0) << 1));
   if (l < 16) {
     const bool pre = lr > 0 && mby % lr == lr - 1 && mby + 1 < mb_h && anyY == 0;
     unsigned long long v = 0;
@@ -129,6 +134,8 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const jmhip_db_mb *__restr
     hand[(long)addr * 24 + l] = v;
   }
 }
+
+#endif  // !DB_SPARSE
 
 // ---------------------------------------------------------------------------------------------------
 // Edge filters on registers, branch-free: a step of the pipeline is a chain of eight dependent edge filters executed by a
@@ -196,6 +203,10 @@ struct RowArgs {
   const DbPrep *prep; unsigned *sync;          // sync[0] ticket, sync[1] error
   unsigned long long *hand;                    // hand-over granules: per macroblock 16 luma + 8 chroma, zeroed by k_deblock_prep
   int mb_w, mb_h, fmt, nkinds;
+  int stride;                                  // macroblocks per picture row: row stride of prep / hand / store_bottom (mb_w is the width of the walk)
+  const uint8_t *store_bottom;                 // segment walks (deblock_sparse.hip): per macroblock, nobody below will store its bottom rows; NULL otherwise
+  unsigned *ctl;                               // ctl[0] mode (1 = segment walks do the frame), ctl[1] number of segment tasks, ctl[2] their ticket
+  const int2 *tasks;                           // segment tasks {row, first column | end column << 16}
 };
 #define HAND_PER_MB 24                         // 8-byte granules per macroblock: [0,16) luma rows 12..15 x 4 dwords, [16,24) chroma
 
@@ -241,7 +252,9 @@ __device__ __forceinline__ bool await_granules(const unsigned long long *g, bool
 // in the step in which row g-1 runs V(x+1), exactly the order the 2:1 wavefront needs).  A ring slot is a tall tile: the four
 // rows' macroblock of one column stacked (4 + 64 rows x 16 bytes), so row g's "top rows" simply ARE row g-1's bottom rows: inside
 // a band nothing is handed over at all; granules connect the last row of a band to the first row of the next band only.
-#define LR 4                                   // rows per luma workgroup
+#ifndef LR
+#define LR 4                                   // rows per luma workgroup (deblock_sparse.hip compiles this file with LR = 1)
+#endif
 // tall-tile row R lives at YROW(R): 16 bytes per row plus 16 bytes of padding after every 16 rows, so that the four rows' lanes of a
 // column access (same k, rows 16 apart) fall into different LDS banks
 #define YROW(R) ((R) * 16 + ((R) >> 4) * 16)
@@ -278,16 +291,20 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
   const uint8_t *own_p = band_p + (long)lane * A.pitchY;                      // lane = sample row of the band (row g, line l)
   const int pg = lane / PREP_VEC, pv = lane - pg * PREP_VEC;                  // record loads: lanes [0, LR*PREP_VEC): row pg, vector pv
   const bool is_pre = lane < LR * PREP_VEC && pg < nrows;
-  const DbPrep *pre_p = A.prep + (long)(row0 + pg) * mb_w;
+  const DbPrep *pre_p = A.prep + (long)(row0 + pg) * A.stride;
   // polling the band above (loader wave): sixteen granules per column, granule `lane` = top row lane>>2, dword lane&3
   const bool is_gran = lane < 16 && has_up;
-  const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * mb_w * HAND_PER_MB + lane;
-  unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * mb_w * HAND_PER_MB;
+  const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * A.stride * HAND_PER_MB + lane;
+  unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * A.stride * HAND_PER_MB;
   // image stores: lane L = tall-tile row L = picture row 16*row0 - 4 + L; row g's stores cover its rows -4..11 (the top neighbour's
   // bottom rows it filtered, and its own rows it will not hand on); the frame's last four rows ride on lanes 0..3 of a second store
   uint8_t *store_p = band_p + (long)(lane - 4) * A.pitchY;
   const bool store_ok = row_ok && (lane >= 4 || has_up);
-  const bool tail_ok = !has_down && lane < 4;                                 // rows 12..15 of the last row of the frame
+  // rows 12..15 of the band's last row: stored here when no row below will (the frame's last row; in a segment walk the columns whose
+  // lower neighbour no walk covers)
+  const bool tail_lane = lane < 4 && (!has_down || A.store_bottom);
+  const uint8_t *sb_p = (has_down && A.store_bottom) ? A.store_bottom + (long)(row0 + nrows - 1) * A.stride : nullptr;
+#define TAIL_OK(X) (tail_lane && (!sb_p || sb_p[X]))
   uint8_t *tail_p = band_p + (long)(16 * nrows - 4 + lane) * A.pitchY;
 
   const int nsteps = mb_w + nrows - 1;
@@ -416,7 +433,7 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
         const int xs = s - g - 1;                          // store: tall-tile rows 16g .. 16g+15 of the slot of xs = picture rows -4..11 of row g
         if (store_ok && xs >= 0 && xs < mb_w) *(uint4 *)(store_p + 16 * xs) = *(const uint4 *)(s_tiles + (xs & 3) * YT_BYTES + YROW(lane));
         const int xt = s - (nrows - 1) - 1;                // the frame's very last rows
-        if (tail_ok && xt >= 0 && xt < mb_w) *(uint4 *)(tail_p + 16 * xt) = *(const uint4 *)(s_tiles + (xt & 3) * YT_BYTES + YROW(16 * nrows + lane));
+        if (xt >= 0 && xt < mb_w && TAIL_OK(xt)) *(uint4 *)(tail_p + 16 * xt) = *(const uint4 *)(s_tiles + (xt & 3) * YT_BYTES + YROW(16 * nrows + lane));
       }
     }
   }
@@ -428,8 +445,9 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
     // rows 0..nrows-2 stored their last column in the loop (their step mb_w-1+g+1 <= nsteps-1) except the band's last row
     if (has_down && lane >= 48) put_granule(hand_me + (long)xe * HAND_PER_MB + (lane - 48), ((const uint32_t *)(tl + YROW(16 * nrows + ((lane - 48) >> 2))))[(lane - 48) & 3]);
     if (store_ok && g == nrows - 1) *(uint4 *)(store_p + 16 * xe) = *(const uint4 *)(tl + YROW(lane));
-    if (tail_ok) *(uint4 *)(tail_p + 16 * xe) = *(const uint4 *)(tl + YROW(16 * nrows + lane));
+    if (TAIL_OK(xe)) *(uint4 *)(tail_p + 16 * xe) = *(const uint4 *)(tl + YROW(16 * nrows + lane));
   }
+#undef TAIL_OK
 }
 
 // ---- chroma: both planes, the same band scheme: 64 / (2 RH) rows per workgroup (4 rows at 4:2:0, 2 at 4:2:2); per plane a tall
@@ -438,7 +456,7 @@ __device__ void luma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x YT
 #define CT_BYTES (2 * CT_PLANE)
 __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x CT_BYTES */, uint8_t *s_preps, volatile lds_int *s_abort)
 {
-  const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8, CR = 32 / RH;
+  const int tid = threadIdx.x, lane = tid & 63, mb_w = A.mb_w, fmt = A.fmt, RH = fmt == 2 ? 16 : 8, CR = LR == 1 ? 1 : 32 / RH;
   const bool filter_wave = tid < 64;
   gu32 *err = (gu32 *)(A.sync + 1);
   const int row0 = band * CR, nrows = min(CR, A.mb_h - row0);
@@ -454,18 +472,20 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
   const uint8_t *own_p = (uvr ? A.V : A.U) + (long)(RH * (row0 + gv) + rr) * A.pitchC;
   const int pg = lane / PREP_VEC, pv = lane - pg * PREP_VEC;
   const bool is_pre = lane < CR * PREP_VEC && pg < nrows;
-  const DbPrep *pre_p = A.prep + (long)(row0 + pg) * mb_w;
+  const DbPrep *pre_p = A.prep + (long)(row0 + pg) * A.stride;
   // polling the band above (loader wave, as in luma_rows): eight granules per column, granule gq = plane (bit 2), top row (bit 1), dword (bit 0)
   const int gq = lane & 7;
   const bool is_gran = lane < 8 && has_up;
   const int goff = ((gq >> 2) & 1) * CT_PLANE + ((gq >> 1) & 1) * 8 + (gq & 1) * 4;
-  const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * mb_w * HAND_PER_MB + 16 + gq;
-  unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * mb_w * HAND_PER_MB + 16;
+  const unsigned long long *hand_up = A.hand + (long)(row0 - 1) * A.stride * HAND_PER_MB + 16 + gq;
+  unsigned long long *hand_me = A.hand + (long)(row0 + nrows - 1) * A.stride * HAND_PER_MB + 16;
   // image stores: lane -> plane su = lane >> 5, tall-tile row st = lane & 31 (row gs = st / RH stores its rows -2 .. RH-3)
   const int su = lane >> 5, st = lane & 31, gs = st / RH;
   const bool store_ok = gs < nrows && (st >= 2 || has_up);
   uint8_t *store_p = (su ? A.V : A.U) + (long)(RH * row0 - 2 + st) * A.pitchC;
-  const bool tail_ok = !has_down && lane < 4;                                 // the frame's last two rows of each plane
+  const bool tail_lane = lane < 4 && (!has_down || A.store_bottom);          // the last two rows of each plane of the band's last row (see luma_rows)
+  const uint8_t *sb_p = (has_down && A.store_bottom) ? A.store_bottom + (long)(row0 + nrows - 1) * A.stride : nullptr;
+#define TAIL_OK(X) (tail_lane && (!sb_p || sb_p[X]))
   uint8_t *tail_p = ((lane >> 1) ? A.V : A.U) + (long)(RH * (row0 + nrows) - 2 + (lane & 1)) * A.pitchC;
   const int tail_off = (lane >> 1) * CT_PLANE + (RH * nrows + (lane & 1)) * 8;
 
@@ -583,7 +603,7 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
         const int xs = s - gs - 1;
         if (store_ok && xs >= 0 && xs < mb_w) *(uint2 *)(store_p + 8 * xs) = *(const uint2 *)(s_tiles + (xs & 3) * CT_BYTES + su * CT_PLANE + st * 8);
         const int xt = s - (nrows - 1) - 1;
-        if (tail_ok && xt >= 0 && xt < mb_w) *(uint2 *)(tail_p + 8 * xt) = *(const uint2 *)(s_tiles + (xt & 3) * CT_BYTES + tail_off);
+        if (xt >= 0 && xt < mb_w && TAIL_OK(xt)) *(uint2 *)(tail_p + 8 * xt) = *(const uint2 *)(s_tiles + (xt & 3) * CT_BYTES + tail_off);
       }
     }
   }
@@ -596,10 +616,12 @@ __device__ void chroma_rows(const RowArgs &A, int band, uint8_t *s_tiles /* 4 x 
       put_granule(hand_me + (long)xe * HAND_PER_MB + q, *((const uint32_t *)(tl + uv * CT_PLANE + (RH * nrows + r) * 8) + c4));
     }
     if (store_ok && gs == nrows - 1) *(uint2 *)(store_p + 8 * xe) = *(const uint2 *)(tl + su * CT_PLANE + st * 8);
-    if (tail_ok) *(uint2 *)(tail_p + 8 * xe) = *(const uint2 *)(tl + tail_off);
+    if (TAIL_OK(xe)) *(uint2 *)(tail_p + 8 * xe) = *(const uint2 *)(tl + tail_off);
   }
+#undef TAIL_OK
 }
 
+#ifndef DB_SPARSE
 __global__ __launch_bounds__(192) void k_deblock_rows(RowArgs A)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * (YT_BYTES > CT_BYTES ? YT_BYTES : CT_BYTES)];
@@ -607,6 +629,7 @@ __global__ __launch_bounds__(192) void k_deblock_rows(RowArgs A)
   __shared__ unsigned s_ticket;
   __shared__ int s_abort;
   const int tid = threadIdx.x;
+  if (A.ctl && A.ctl[0] == 1u) return;               // the segment walks (deblock_sparse.hip) do this frame
   if (tid == 0) { s_ticket = __hip_atomic_fetch_add((gu32 *)A.sync, 1u, RLX_AGENT); s_abort = 0; }
   for (int k = tid; k < (int)sizeof(s_tiles) / 4; k += 192) ((uint32_t *)s_tiles)[k] = 0;
   __syncthreads();
@@ -621,19 +644,33 @@ __global__ __launch_bounds__(192) void k_deblock_rows(RowArgs A)
   else if (t - both < nc) chroma_rows(A, t - both, s_tiles, s_preps, (lds_int *)&s_abort);
 }
 
-// prep + rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
+int jmhip_launch_deblock_sparse(jmhip_ctx *ctx, const RowArgs &A, const uint8_t *d_flags, int max_active_pct);      // deblock_sparse.hip
+
+// prep + segment walks / rows on the context's stream; the caller has checked alignment (8-byte planes and pitches)
 int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8)
 {
   const int mb_w = ctx->W / 16, mb_h = ctx->H / 16, nmb = mb_w * mb_h, fmt = ctx->cfg.yuv_format;
-  const int nkinds = fmt ? 2 : 1, nsync = 2;
-  const int no_prefill = getenv("JMHIP_DEBLOCK_NO_PREFILL") != nullptr;              // A/B switch for profiling and tests
+  const int nkinds = fmt ? 2 : 1, nsync = 5;                                         // ticket, error | mode, tasks, task ticket
+  const int no_prefill = getenv("JMHIP_DEBLOCK_NO_PREFILL") != nullptr;              // A/B switches for profiling and tests
+  // segment walks (deblock_sparse.hip) for pictures with few active macroblocks; the decision is taken on the device, per frame
+  const char *pct = getenv("JMHIP_DEBLOCK_SPARSE_PCT");
+  const int max_active_pct = pct ? atoi(pct) : 40;
+  const bool sparse_on = !no_prefill && max_active_pct > 0 && ctx->d_db_tasks && mb_w <= 256 && mb_h <= 256;
+  const int lr = no_prefill ? 0 : (sparse_on ? 1 : LR), cr = no_prefill ? 0 : (sparse_on ? 1 : (fmt == 2 ? 2 : 4));
   hipLaunchKernelGGL(k_deblock_prep, dim3((nmb + 7) / 8), dim3(256), 0, ctx->stream, d_mbs, d_motion, mb_w, mb_h, fmt, direct8x8,
                      (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync, (unsigned long long *)ctx->d_db_hand,
-                     (const uint8_t *)d_Y, pitchY, (const uint8_t *)d_U, (const uint8_t *)d_V, pitchC, no_prefill ? 0 : LR, no_prefill ? 0 : (fmt == 2 ? 2 : 4));
+                     (const uint8_t *)d_Y, pitchY, (const uint8_t *)d_U, (const uint8_t *)d_V, pitchC, lr, cr, sparse_on ? ctx->d_db_flags : nullptr);
   RowArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.prep = (const DbPrep *)ctx->d_db_prep; A.sync = ctx->d_db_sync; A.hand = (unsigned long long *)ctx->d_db_hand;
-  A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds;
+  A.mb_w = mb_w; A.mb_h = mb_h; A.fmt = fmt; A.nkinds = nkinds; A.stride = mb_w;
+  A.store_bottom = nullptr; A.ctl = sparse_on ? ctx->d_db_sync + 2 : nullptr; A.tasks = (const int2 *)ctx->d_db_tasks;
+  if (sparse_on) {
+    RowArgs S = A;
+    S.store_bottom = ctx->d_db_flags + nmb;
+    jmhip_launch_deblock_sparse(ctx, S, ctx->d_db_flags, max_active_pct);
+  }
   hipLaunchKernelGGL(k_deblock_rows, dim3((mb_h + LR - 1) / LR + (nkinds > 1 ? (mb_h + (fmt == 2 ? 2 : 4) - 1) / (fmt == 2 ? 2 : 4) : 0)), dim3(192), 0, ctx->stream, A);
   return JMHIP_OK;
 }
+#endif  // !DB_SPARSE

@@ -33,6 +33,8 @@ struct jmhip_ctx {
   unsigned *d_db_sync;   // deblocking row pipeline: ticket, error
   int db_launched;       // the row pipeline ran since its error word was last read
   void *d_db_hand;       // deblocking row pipeline: 24 8-byte hand-over granules per macroblock
+  uint8_t *d_db_flags;   // deblocking segment walks: per macroblock flags (nmb bytes), then store_bottom (nmb bytes)
+  void *d_db_tasks;      // deblocking segment walks: task list (1024 x int2)
   int force_db_diag;     // JMHIP_DEBLOCK_DIAG=1: one launch per diagonal instead of the row pipeline (A/B testing)
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
