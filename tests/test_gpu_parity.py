@@ -656,11 +656,14 @@ def test_deblock_random_side_info_vs_oracle(J, w, h, fmt, seed):
 
 
 @pytest.mark.parametrize("w,h,fmt,density,seed", [(1920, 1088, 1, 0.0, 1), (1920, 1088, 1, 0.03, 2), (1920, 1088, 1, 0.3, 3), (704, 576, 2, 0.05, 4),
-                                                 (320, 192, 1, 0.1, 5), (3840, 2160, 1, 0.02, 6), (64, 208, 1, 0.2, 7)])
+                                                 (320, 192, 1, 0.1, 5), (3840, 2160, 1, 0.02, 6), (64, 208, 1, 0.2, 7), (320, 192, 0, 0.1, 8),
+                                                 (4096, 64, 1, 0.15, 9), (1920, 1088, 1, 0.45, 10)])
 def test_deblock_sparse_side_info_vs_oracle(J, w, h, fmt, density, seed):
     """P-picture-like side information: most macroblocks skipped with one common vector (no active edge segment: their hand-over granules
-    are issued by k_deblock_prep and the bands run ahead of each other), a fraction `density` of macroblocks with random type /
-    coefficients / motion, plus one fully active macroblock row and column.  Repeated: the bands' relative timing must not matter."""
+    are issued by k_deblock_prep), a fraction `density` of macroblocks with random type / coefficients / motion, plus one fully active
+    macroblock row and column.  Below 40 % active macroblocks the frame is done by segment walks (deblock_sparse.hip: rows cut where a
+    left edge is inactive, one walker per run with work), above by the band pipeline with bands running ahead of each other where they
+    can.  Repeated: the walkers' relative timing must not matter; and once more with each mechanism switched off."""
     from jm_amd.lib import db_arrays_from_tap
     rng = np.random.default_rng(seed)
     mw, mh = w // 16, h // 16
@@ -668,7 +671,8 @@ def test_deblock_sparse_side_info_vs_oracle(J, w, h, fmt, density, seed):
     y = rng.integers(0, 256, (h, w)).astype(np.uint8)
     y = (y // 8 + np.kron(rng.integers(40, 200, (h // 4, w // 4)), np.ones((4, 4), np.int64))).clip(0, 255).astype(np.uint8)
     ch, cw = (h // 2 if fmt == 1 else h), w // 2
-    u, v = rng.integers(90, 150, (ch, cw)).astype(np.uint8), rng.integers(90, 150, (ch, cw)).astype(np.uint8)
+    u = rng.integers(90, 150, (ch, cw)).astype(np.uint8) if fmt else None
+    v = rng.integers(90, 150, (ch, cw)).astype(np.uint8) if fmt else None
     act = rng.random((mh, mw)) < density
     act[mh - 1, :] = True                                  # the padded last row of a 1080p picture looks like this
     act[:, int(rng.integers(0, mw))] = True
@@ -694,19 +698,24 @@ def test_deblock_sparse_side_info_vs_oracle(J, w, h, fmt, density, seed):
     assert changed > 0 and (density >= 0.3 or changed < 0.25)
     mbs, mo = db_arrays_from_tap(m12, mot)
     ctx = make_ctx(w, h, fmt=fmt)
+    def same(g, o):
+        return (g is None and o is None) or (g == o).all()
     for rep in range(4):
         gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, 1)
         assert (gy == oy).all(), (rep, np.argwhere(gy != oy)[:5])
-        assert (gu == ou).all() and (gv == ov).all(), rep
+        assert same(gu, ou) and same(gv, ov), rep
     ctx.close()
-    os.environ["JMHIP_DEBLOCK_NO_PREFILL"] = "1"            # and the same frame with every granule coming from the band above
-    try:
-        ctx = make_ctx(w, h, fmt=fmt)
-        gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, 1)
-    finally:
-        del os.environ["JMHIP_DEBLOCK_NO_PREFILL"]
-    assert (gy == oy).all() and (gu == ou).all() and (gv == ov).all()
-    ctx.close()
+    for switch, value in (("JMHIP_DEBLOCK_SPARSE_PCT", "0"),     # no segment walks: the band pipeline with pre-issued granules
+                          ("JMHIP_DEBLOCK_SPARSE_PCT", "100"),   # segment walks whatever the density (unless the task list is too long)
+                          ("JMHIP_DEBLOCK_NO_PREFILL", "1")):    # every granule from the band above
+        os.environ[switch] = value
+        try:
+            ctx = make_ctx(w, h, fmt=fmt)
+            gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, 1)
+        finally:
+            del os.environ[switch]
+        assert (gy == oy).all() and same(gu, ou) and same(gv, ov), (switch, value)
+        ctx.close()
 
 
 def test_deblock_real_p_picture_side_info_1080p(J):
