@@ -656,7 +656,7 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
   // segment walks (deblock_sparse.hip) for pictures with few active macroblocks; the decision is taken on the device, per frame
   const char *pct = getenv("JMHIP_DEBLOCK_SPARSE_PCT");
   const int max_active_pct = pct ? atoi(pct) : 40;
-  const bool sparse_on = !no_prefill && max_active_pct > 0 && ctx->d_db_tasks && mb_w <= 256 && mb_h <= 256;
+  const bool sparse_on = !no_prefill && max_active_pct > 0 && ctx->d_db_tasks && mb_w <= 256 && mb_h <= 256 && nmb <= 40960;
   const int lr = no_prefill ? 0 : (sparse_on ? 1 : LR), cr = no_prefill ? 0 : (sparse_on ? 1 : (fmt == 2 ? 2 : 4));
   hipLaunchKernelGGL(k_deblock_prep, dim3((nmb + 7) / 8), dim3(256), 0, ctx->stream, d_mbs, d_motion, mb_w, mb_h, fmt, direct8x8,
                      (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync, (unsigned long long *)ctx->d_db_hand,

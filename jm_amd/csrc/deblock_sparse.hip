@@ -24,73 +24,85 @@
 
 #define DB_MAX_TASKS 1024
 #define DB_MAX_ROWS 256                            // macroblock rows (and, for the four-word masks, columns) the task builder takes
+#define DB_MAX_LDS_MBS 40960                       // macroblocks whose flags it stages in LDS
 
 // Bit masks of one macroblock row (up to 256 macroblocks = four 64-bit words), uniform across the wave that handles the row.
 struct RowMask { unsigned long long w[4]; };
+// (every loop over the four words is unrolled with the word index as a constant: a run-time index would put the masks in scratch memory,
+// and each look at them would be a memory round trip)
 __device__ __forceinline__ int mask_prev_set(const RowMask &m, int x)            // highest set bit <= x (bit 0 is always set for a cut mask)
 {
-  for (int k = x >> 6; k >= 0; k--) {
-    const unsigned long long v = m.w[k] & (k == (x >> 6) ? (~0ull >> (63 - (x & 63))) : ~0ull);
-    if (v) return k * 64 + 63 - __clzll((long long)v);
+  int res = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    unsigned long long v = m.w[k];
+    if (k == (x >> 6)) v &= ~0ull >> (63 - (x & 63)); else if (k > (x >> 6)) v = 0;
+    if (v) res = k * 64 + 63 - __clzll((long long)v);
   }
-  return 0;
+  return res;
 }
 __device__ __forceinline__ int mask_next_set(const RowMask &m, int x, int n)     // lowest set bit > x, or n
 {
-  for (int k = x >> 6; k < 4; k++) {
-    const unsigned long long v = m.w[k] & (k == (x >> 6) ? ((x & 63) == 63 ? 0ull : (~0ull << ((x & 63) + 1))) : ~0ull);
-    if (v) return min(n, k * 64 + __ffsll((long long)v) - 1);
-  }
-  return n;
-}
-__device__ __forceinline__ bool mask_any(const RowMask &m, int s, int e)         // any set bit in [s, e)
-{
-  for (int k = s >> 6; k <= (e - 1) >> 6; k++) {
+  int res = n;
+#pragma unroll
+  for (int k = 3; k >= 0; k--) {
     unsigned long long v = m.w[k];
-    if (k == (s >> 6)) v &= ~0ull << (s & 63);
-    if (k == ((e - 1) >> 6)) v &= ~0ull >> (63 - ((e - 1) & 63));
-    if (v) return true;
+    if (k == (x >> 6)) v &= (x & 63) == 63 ? 0ull : (~0ull << ((x & 63) + 1)); else if (k < (x >> 6)) v = 0;
+    if (v) res = min(n, k * 64 + __ffsll((long long)v) - 1);
   }
-  return false;
+  return res;
+}
+__device__ __forceinline__ bool mask_any(const RowMask &m, int s, int e)         // any set bit in [s, e), s < e
+{
+  bool r = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    unsigned long long v = m.w[k];
+    const int lo = k * 64, hi = lo + 64;
+    if (e <= lo || s >= hi) v = 0;
+    else { if (s > lo) v &= ~0ull << (s - lo); if (e < hi) v &= ~0ull >> (hi - e); }
+    r |= v != 0;
+  }
+  return r;
 }
 
 // One workgroup of sixteen waves; a wave takes every sixteenth row, a lane a macroblock of the row's 64-wide chunks.  Pass 1: per row the mask of macroblocks
 // that belong to a run with work (s_proc) and the number of such runs; a scan over the rows gives every row's place in the task list;
 // pass 2 writes the tasks and, with the mask of the row below, who stores whose bottom rows.
 #define TASK_WAVES 16
-#define TASK_RPW (DB_MAX_ROWS / TASK_WAVES)         // rows per wave
 __global__ __launch_bounds__(64 * TASK_WAVES) void k_deblock_tasks(const uint8_t *__restrict__ flags, int mb_w, int mb_h, int2 *__restrict__ tasks,
                                                        uint8_t *__restrict__ store_bottom, unsigned *__restrict__ ctl, int max_active_pct)
 {
   __shared__ unsigned long long s_proc[DB_MAX_ROWS + 1][4];
   __shared__ int s_cnt[DB_MAX_ROWS], s_off[DB_MAX_ROWS], s_act[DB_MAX_ROWS], s_wsum[4], s_asum[4];
-  // every flag this lane will look at, requested before the first is used: the kernel is one memory latency long, not one per row
-  int fl[TASK_RPW][4];
-#pragma unroll
-  for (int i = 0; i < TASK_RPW; i++)
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int r = (int)(threadIdx.x >> 6) + TASK_WAVES * i, x = c * 64 + (int)(threadIdx.x & 63);
-      fl[i][c] = (r < mb_h && x < mb_w) ? flags[r * mb_w + x] : 0;
-    }
+  // the flags go through LDS: every lane fetches its share with a few wide loads that are all in flight together (the buffer is padded
+  // to a multiple of 16), so the kernel is one memory latency long however many rows a wave takes
+  __shared__ __attribute__((aligned(16))) uint8_t s_f[DB_MAX_LDS_MBS + 16];
+  {
+    const int nvec = (mb_w * mb_h + 15) >> 4, i0 = threadIdx.x, i1 = i0 + 64 * TASK_WAVES, i2 = i1 + 64 * TASK_WAVES;   // 3 x 1024 x 16 >= DB_MAX_LDS_MBS
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 v0 = i0 < nvec ? ((const uint4 *)flags)[i0] : z, v1 = i1 < nvec ? ((const uint4 *)flags)[i1] : z, v2 = i2 < nvec ? ((const uint4 *)flags)[i2] : z;
+    if (i0 < nvec) ((uint4 *)s_f)[i0] = v0;
+    if (i1 < nvec) ((uint4 *)s_f)[i1] = v1;
+    if (i2 < nvec) ((uint4 *)s_f)[i2] = v2;
+  }
+  __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nmb = mb_w * mb_h, nch = (mb_w + 63) >> 6;
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
-#pragma unroll
-    for (int i = 0; i < TASK_RPW; i++) {
-      const int r = wave + TASK_WAVES * i;
-      if (r >= mb_h) break;
+#pragma unroll 1
+    for (int r = wave; r < mb_h; r += TASK_WAVES) {
       RowMask cut = {{0, 0, 0, 0}}, act = {{0, 0, 0, 0}};
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        if (c >= nch) break;
+      for (int c = 0; c < 4; c++) {                                              // (no early exit: the word index must stay a constant)
         const int x = c * 64 + lane;
-        const int f = fl[i][c];
+        const int f = x < mb_w ? s_f[r * mb_w + x] : 0;
         cut.w[c] = __ballot(x < mb_w && (x == 0 || !(f & 2)));                  // a cut before x: nothing connects x to x - 1
         act.w[c] = __ballot(f & 1);
       }
       int cnt = 0, nact = 0, base = pass ? s_off[r] : 0;
-      for (int c = 0; c < nch; c++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
         const int x = c * 64 + lane;
         bool proc = false, start = false;
         int e = 0;
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(64 * TASK_WAVES) void k_deblock_tasks(const uint8_t
           start = proc && sx == x;
         }
         const unsigned long long pm = __ballot(proc), sm = __ballot(start);
-        if (pass == 0) { if (lane == 0) s_proc[r][c] = pm; }
+        if (pass == 0) { if (lane == 0 && c < nch) s_proc[r][c] = pm; }
         else {
           if (start) tasks[base + cnt + __popcll(sm & ((1ull << lane) - 1))] = make_int2(r, x | (e << 16));
           if (x < mb_w) store_bottom[r * mb_w + x] = (uint8_t)(proc && r + 1 < mb_h && !((s_proc[r + 1][c] >> lane) & 1));
