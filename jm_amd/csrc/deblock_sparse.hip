@@ -27,36 +27,36 @@
 #define DB_MAX_LDS_MBS 40960                       // macroblocks whose flags it stages in LDS
 
 // Bit masks of one macroblock row (up to 256 macroblocks = four 64-bit words), uniform across the wave that handles the row.
-struct RowMask { unsigned long long w[4]; };
+template <int NW_> struct RowMask { unsigned long long w[NW_]; };
 // (every loop over the four words is unrolled with the word index as a constant: a run-time index would put the masks in scratch memory,
 // and each look at them would be a memory round trip)
-__device__ __forceinline__ int mask_prev_set(const RowMask &m, int x)            // highest set bit <= x (bit 0 is always set for a cut mask)
+template <int NW_> __device__ __forceinline__ int mask_prev_set(const RowMask<NW_> &m, int x)            // highest set bit <= x (bit 0 is always set for a cut mask)
 {
   int res = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < NW_; k++) {
     unsigned long long v = m.w[k];
     if (k == (x >> 6)) v &= ~0ull >> (63 - (x & 63)); else if (k > (x >> 6)) v = 0;
     if (v) res = k * 64 + 63 - __clzll((long long)v);
   }
   return res;
 }
-__device__ __forceinline__ int mask_next_set(const RowMask &m, int x, int n)     // lowest set bit > x, or n
+template <int NW_> __device__ __forceinline__ int mask_next_set(const RowMask<NW_> &m, int x, int n)     // lowest set bit > x, or n
 {
   int res = n;
 #pragma unroll
-  for (int k = 3; k >= 0; k--) {
+  for (int k = NW_ - 1; k >= 0; k--) {
     unsigned long long v = m.w[k];
     if (k == (x >> 6)) v &= (x & 63) == 63 ? 0ull : (~0ull << ((x & 63) + 1)); else if (k < (x >> 6)) v = 0;
     if (v) res = min(n, k * 64 + __ffsll((long long)v) - 1);
   }
   return res;
 }
-__device__ __forceinline__ bool mask_any(const RowMask &m, int s, int e)         // any set bit in [s, e), s < e
+template <int NW_> __device__ __forceinline__ bool mask_any(const RowMask<NW_> &m, int s, int e)         // any set bit in [s, e), s < e
 {
   bool r = false;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < NW_; k++) {
     unsigned long long v = m.w[k];
     const int lo = k * 64, hi = lo + 64;
     if (e <= lo || s >= hi) v = 0;
@@ -70,10 +70,11 @@ __device__ __forceinline__ bool mask_any(const RowMask &m, int s, int e)        
 // that belong to a run with work (s_proc) and the number of such runs; a scan over the rows gives every row's place in the task list;
 // pass 2 writes the tasks and, with the mask of the row below, who stores whose bottom rows.
 #define TASK_WAVES 16
+template <int NW_>        // 64-bit mask words per row: mb_w <= 64 * NW_
 __global__ __launch_bounds__(64 * TASK_WAVES) void k_deblock_tasks(const uint8_t *__restrict__ flags, int mb_w, int mb_h, int2 *__restrict__ tasks,
                                                        uint8_t *__restrict__ store_bottom, unsigned *__restrict__ ctl, int max_active_pct)
 {
-  __shared__ unsigned long long s_proc[DB_MAX_ROWS + 1][4];
+  __shared__ unsigned long long s_proc[DB_MAX_ROWS + 1][NW_];
   __shared__ int s_cnt[DB_MAX_ROWS], s_off[DB_MAX_ROWS], s_act[DB_MAX_ROWS], s_wsum[4], s_asum[4];
   // the flags go through LDS: every lane fetches its share with a few wide loads that are all in flight together (the buffer is padded
   // to a multiple of 16), so the kernel is one memory latency long however many rows a wave takes
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(64 * TASK_WAVES) void k_deblock_tasks(const uint8_t
   for (int pass = 0; pass < 2; pass++) {
 #pragma unroll 1
     for (int r = wave; r < mb_h; r += TASK_WAVES) {
-      RowMask cut = {{0, 0, 0, 0}}, act = {{0, 0, 0, 0}};
+      RowMask<NW_> cut, act;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {                                              // (no early exit: the word index must stay a constant)
+      for (int c = 0; c < NW_; c++) {                                            // (no early exit: the word index must stay a constant)
         const int x = c * 64 + lane;
         const int f = x < mb_w ? s_f[r * mb_w + x] : 0;
         cut.w[c] = __ballot(x < mb_w && (x == 0 || !(f & 2)));                  // a cut before x: nothing connects x to x - 1
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64 * TASK_WAVES) void k_deblock_tasks(const uint8_t
       }
       int cnt = 0, nact = 0, base = pass ? s_off[r] : 0;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; c < NW_; c++) {
         const int x = c * 64 + lane;
         bool proc = false, start = false;
         int e = 0;
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(192) void k_deblock_sparse(RowArgs A)
 // after k_deblock_prep on the context's stream; A as the band pipeline gets it (stride, ctl, tasks, store_bottom set by the caller)
 int jmhip_launch_deblock_sparse(jmhip_ctx *ctx, const RowArgs &A, const uint8_t *d_flags, int max_active_pct)
 {
-  hipLaunchKernelGGL(k_deblock_tasks, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
+  if (A.mb_w <= 64) hipLaunchKernelGGL(k_deblock_tasks<1>, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
+  else if (A.mb_w <= 128) hipLaunchKernelGGL(k_deblock_tasks<2>, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
+  else hipLaunchKernelGGL(k_deblock_tasks<4>, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
   hipLaunchKernelGGL(k_deblock_sparse, dim3(DB_MAX_TASKS * A.nkinds), dim3(192), 0, ctx->stream, A);
   return JMHIP_OK;
 }
