@@ -718,6 +718,76 @@ def test_deblock_sparse_side_info_vs_oracle(J, w, h, fmt, density, seed):
         ctx.close()
 
 
+@pytest.mark.parametrize("w,h,fmt,seed", [(1920, 1088, 1, 21), (704, 576, 2, 22), (320, 608, 0, 23), (16, 1088, 1, 24), (16, 304, 2, 25), (640, 1088, 1, 26)])
+def test_deblock_column_walks_vs_oracle(J, w, h, fmt, seed):
+    """Runs of ONE macroblock stacked on top of each other (deblock_sparse.hip, column walks: vertical edges of all rows at once, then one walk
+    down the horizontal edges with the bottom rows kept in registers).  Macroblocks whose coefficients sit in block columns 1 and 2 only and
+    whose motion equals their neighbours' have inactive left / right edges and active inner and top edges: columns of them, of random
+    lengths, across the 16-row groups of the walks, next to ordinary active macroblocks and rows; a picture one macroblock wide (every
+    macroblock a run of its own, intra ones with the strong filter included).  Repeated, and with the walks forced on."""
+    from jm_amd.lib import db_arrays_from_tap
+    rng = np.random.default_rng(seed)
+    mw, mh = w // 16, h // 16
+    nmb = mw * mh
+    y = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    y = (y // 8 + np.kron(rng.integers(40, 200, (h // 4, w // 4)), np.ones((4, 4), np.int64))).clip(0, 255).astype(np.uint8)
+    ch, cw = (h // 2 if fmt == 1 else h), w // 2
+    u = rng.integers(90, 150, (ch, cw)).astype(np.uint8) if fmt else None
+    v = rng.integers(90, 150, (ch, cw)).astype(np.uint8) if fmt else None
+    act = rng.random((mh, mw)) < (0.02 if mw > 1 else 0.7)
+    chain = np.zeros((mh, mw), bool)
+    if mw > 1:
+        act[mh - 1, :] = True
+        for cx in sorted(set([mw - 1] + [int(c) for c in rng.integers(2, mw - 2, 3)])):
+            r = 0
+            while r < mh - 1:
+                n = int(rng.integers(1, 40))
+                chain[r:min(r + n, mh - 1), cx] = True
+                r += n + int(rng.integers(1, 3))
+        chain[mh - 1, :] = False
+        near = np.zeros_like(chain)
+        near[:, 1:] |= chain[:, :-1]; near[:, :-1] |= chain[:, 1:]
+        act &= ~(near | chain)
+        act[mh - 1, :] = True
+    a, c = act.ravel(), chain.ravel()
+    m12 = np.zeros((nmb, 12), np.int32)
+    m12[:, 0] = np.where(a, rng.choice([1, 2, 3, 8, 9, 10], nmb), 0)
+    m12[c, 0] = 1
+    m12[:, 2] = 28; m12[:, 3] = 27; m12[:, 4] = 27
+    m12[:, 2] += np.where(a | c, rng.integers(-4, 9, nmb), 0)
+    m12[:, 6] = np.where(a, rng.integers(0, 1 << 16, nmb) * rng.integers(0, 2, nmb), 0)
+    m12[c, 6] = (rng.integers(0, 1 << 16, nmb) & 0x6666)[c]
+    m12[:, 5] = np.where(m12[:, 6] != 0, 15, 0)
+    m12[:, 9] = rng.integers(-2, 3); m12[:, 10] = rng.integers(-2, 3)
+    mot = np.zeros((h // 4, w // 4, 2, 3), np.int32)
+    mot[:, :, 0, 0], mot[:, :, 0, 1] = 12, -8
+    a4 = np.kron(act, np.ones((4, 4), bool))
+    rnd = rng.integers(-9, 10, (h // 4, w // 4, 2))
+    mot[:, :, 0, 0:2] = np.where(a4[:, :, None], rnd, mot[:, :, 0, 0:2])
+    mot[:, :, 1, 2] = -1
+    oy, ou, ov = J.deblock_frame(y, u, v, fmt, m12, mot, 255, 255, 1)
+    assert float((oy != y).mean()) > 0
+    if mw > 1:                                              # the chains really are filtered
+        cy = np.kron(chain, np.ones((16, 16), bool))
+        assert float((oy != y)[cy].mean()) > 0.02
+    mbs, mo = db_arrays_from_tap(m12, mot)
+    def same(g, o):
+        return (g is None and o is None) or (g == o).all()
+    for switch, value in ((None, None), ("JMHIP_DEBLOCK_SPARSE_PCT", "100")):
+        if switch:
+            os.environ[switch] = value
+        try:
+            ctx = make_ctx(w, h, fmt=fmt)
+            for rep in range(3):
+                gy, gu, gv = ctx.deblock_frame(y, u, v, mbs, mo, 1)
+                assert (gy == oy).all(), (switch, rep, np.argwhere(gy != oy)[:5])
+                assert same(gu, ou) and same(gv, ov), (switch, rep)
+            ctx.close()
+        finally:
+            if switch:
+                del os.environ[switch]
+
+
 def test_deblock_real_p_picture_side_info_1080p(J):
     """The deblocking stage exactly as bench.py runs it: the side information JM's DeblockFrame was given for the P picture of
     BASELINE.json configs[1] (tests/golden/g2_sideinfo.npz: 78 % skipped macroblocks, the padded last macroblock row all P8x8 / intra)
