@@ -117,7 +117,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   CK(hipMalloc((void **)&c->d_db_sync, 64 + (size_t)(c->H / 16) * 2 * 6 * 8));
   CK(hipMalloc(&c->d_db_hand, (size_t)(c->W / 16) * (c->H / 16) * 192));
   CK(hipMalloc((void **)&c->d_db_flags, (size_t)(c->W / 16) * (c->H / 16) * 2 + 16));
-  CK(hipMalloc(&c->d_db_tasks, 1024 * 8));
+  CK(hipMalloc(&c->d_db_tasks, 1024 * 8 + 256 * 8 * 8));      // task list + the task builder's row masks
   for (int k = 0; k < JMHIP_NKINDS; k++) { CK(hipEventCreate(&c->ev0[k])); CK(hipEventCreate(&c->ev1[k])); }
   CK(hipStreamSynchronize(c->stream));
 #undef CK

@@ -208,6 +208,7 @@ struct RowArgs {
   unsigned *ctl;                               // ctl[0] mode (1 = segment walks do the frame), ctl[1] number of segment tasks, ctl[2] their ticket
   const int2 *tasks;                           // segment tasks {row, first column | end column << 16}
 };
+#define DB_SYNC_ROWINFO 8                      // sync[8 ..]: one 64-bit word per macroblock row for k_deblock_tasks (deblock_sparse.hip)
 #define HAND_PER_MB 24                         // 8-byte granules per macroblock: [0,16) luma rows 12..15 x 4 dwords, [16,24) chroma
 
 #define DB_SPIN_LIMIT (1u << 21)
@@ -651,12 +652,12 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8)
 {
   const int mb_w = ctx->W / 16, mb_h = ctx->H / 16, nmb = mb_w * mb_h, fmt = ctx->cfg.yuv_format;
-  const int nkinds = fmt ? 2 : 1, nsync = 5;                                         // ticket, error | mode, tasks, task ticket
+  const int nkinds = fmt ? 2 : 1, nsync = DB_SYNC_ROWINFO + 2 * mb_h;                                         // ticket, error | mode, tasks, task ticket
   const int no_prefill = getenv("JMHIP_DEBLOCK_NO_PREFILL") != nullptr;              // A/B switches for profiling and tests
   // segment walks (deblock_sparse.hip) for pictures with few active macroblocks; the decision is taken on the device, per frame
   const char *pct = getenv("JMHIP_DEBLOCK_SPARSE_PCT");
   const int max_active_pct = pct ? atoi(pct) : 40;
-  const bool sparse_on = !no_prefill && max_active_pct > 0 && ctx->d_db_tasks && mb_w <= 256 && mb_h <= 256 && nmb <= 40960;
+  const bool sparse_on = !no_prefill && max_active_pct > 0 && ctx->d_db_tasks && mb_w <= 256 && mb_h <= 256;
   const int lr = no_prefill ? 0 : (sparse_on ? 1 : LR), cr = no_prefill ? 0 : (sparse_on ? 1 : (fmt == 2 ? 2 : 4));
   hipLaunchKernelGGL(k_deblock_prep, dim3((nmb + 7) / 8), dim3(256), 0, ctx->stream, d_mbs, d_motion, mb_w, mb_h, fmt, direct8x8,
                      (DbPrep *)ctx->d_db_prep, ctx->d_db_sync, nsync, (unsigned long long *)ctx->d_db_hand,

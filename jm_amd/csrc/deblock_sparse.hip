@@ -231,7 +231,6 @@ __device__ void chroma_col(const RowArgs &A, int r0, int n, uint8_t *s_tile /* 2
 
 #define DB_MAX_TASKS 1024
 #define DB_MAX_ROWS 256                            // macroblock rows (and, for the four-word masks, columns) the task builder takes
-#define DB_MAX_LDS_MBS 40960                       // macroblocks whose flags it stages in LDS
 
 // Bit masks of one macroblock row (up to 256 macroblocks = four 64-bit words), uniform across the wave that handles the row.
 template <int NW_> struct RowMask { unsigned long long w[NW_]; };
@@ -273,89 +272,101 @@ template <int NW_> __device__ __forceinline__ bool mask_any(const RowMask<NW_> &
   return r;
 }
 
-// One workgroup of sixteen waves; a wave takes every sixteenth row, a lane a macroblock of the row's 64-wide chunks.  Pass 1: per row the mask of macroblocks
-// that belong to a run with work (s_proc) and the number of such runs; a scan over the rows gives every row's place in the task list;
-// pass 2 writes the tasks and, with the mask of the row below, who stores whose bottom rows.
-#define TASK_WAVES 16
+// One single-wave workgroup per macroblock row (a lane takes a macroblock of each of the row's 64-wide chunks), so the rows are worked on by
+// as many compute units at once: (1) the row's masks -- macroblocks that belong to a run with work, runs of one macroblock -- and its
+// number of runs and of active macroblocks, published as {tag, active, runs} in ONE release store after the masks (the data is the flag,
+// as with the hand-over granules; k_deblock_prep zeroes the words); (2) every workgroup reads all rows' words (at most 256: four per
+// lane, bounded spin -- at most 256 one-wave workgroups are always resident together), which gives it its place in the task list, the
+// totals and thus the frame's mode; (3) it writes its tasks and, with the masks of the row below / of its group of DB_COL_ROWS rows, who
+// stores whose bottom rows and how long the column walks are.
+#define DB_MASK_WORDS 8                            // per row in the mask scratch: [0,4) runs with work, [4,8) runs of one macroblock
 template <int NW_>        // 64-bit mask words per row: mb_w <= 64 * NW_
-__global__ __launch_bounds__(64 * TASK_WAVES) void k_deblock_tasks(const uint8_t *__restrict__ flags, int mb_w, int mb_h, int2 *__restrict__ tasks,
-                                                       uint8_t *__restrict__ store_bottom, unsigned *__restrict__ ctl, int max_active_pct)
+__global__ __launch_bounds__(64) void k_deblock_tasks(const uint8_t *__restrict__ flags, int mb_w, int mb_h, int2 *__restrict__ tasks,
+                                                      uint8_t *__restrict__ store_bottom, unsigned *__restrict__ ctl, int max_active_pct,
+                                                      unsigned long long *rowinfo, unsigned long long *masks, unsigned *err)
 {
-  __shared__ unsigned long long s_proc[DB_MAX_ROWS + 1][NW_];
-  __shared__ unsigned long long s_one[DB_MAX_ROWS][NW_];                          // macroblocks that are a run with work all by themselves
-  __shared__ int s_cnt[DB_MAX_ROWS], s_off[DB_MAX_ROWS], s_act[DB_MAX_ROWS], s_wsum[4], s_asum[4];
-  // the flags go through LDS: every lane fetches its share with a few wide loads that are all in flight together (the buffer is padded
-  // to a multiple of 16), so the kernel is one memory latency long however many rows a wave takes
-  __shared__ __attribute__((aligned(16))) uint8_t s_f[DB_MAX_LDS_MBS + 16];
-  {
-    const int nvec = (mb_w * mb_h + 15) >> 4, i0 = threadIdx.x, i1 = i0 + 64 * TASK_WAVES, i2 = i1 + 64 * TASK_WAVES;   // 3 x 1024 x 16 >= DB_MAX_LDS_MBS
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    const uint4 v0 = i0 < nvec ? ((const uint4 *)flags)[i0] : z, v1 = i1 < nvec ? ((const uint4 *)flags)[i1] : z, v2 = i2 < nvec ? ((const uint4 *)flags)[i2] : z;
-    if (i0 < nvec) ((uint4 *)s_f)[i0] = v0;
-    if (i1 < nvec) ((uint4 *)s_f)[i1] = v1;
-    if (i2 < nvec) ((uint4 *)s_f)[i2] = v2;
+  __shared__ unsigned long long s_one[DB_COL_ROWS][NW_];
+  const int lane = threadIdx.x, r = blockIdx.x, nmb = mb_w * mb_h;
+  RowMask<NW_> cut, act;
+#pragma unroll
+  for (int c = 0; c < NW_; c++) {                                              // (no early exit: the word index must stay a constant)
+    const int x = c * 64 + lane;
+    const int f = x < mb_w ? flags[r * mb_w + x] : 0;
+    cut.w[c] = __ballot(x < mb_w && (x == 0 || !(f & 2)));                    // a cut before x: nothing connects x to x - 1
+    act.w[c] = __ballot(f & 1);
   }
-  __syncthreads();
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nmb = mb_w * mb_h, nch = (mb_w + 63) >> 6;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-#pragma unroll 1
-    for (int r = wave; r < mb_h; r += TASK_WAVES) {
-      RowMask<NW_> cut, act;
+  int cnt = 0, nact = 0, e[NW_];
+  bool proc[NW_], start[NW_];
+  unsigned long long sm[NW_];
 #pragma unroll
-      for (int c = 0; c < NW_; c++) {                                            // (no early exit: the word index must stay a constant)
-        const int x = c * 64 + lane;
-        const int f = x < mb_w ? s_f[r * mb_w + x] : 0;
-        cut.w[c] = __ballot(x < mb_w && (x == 0 || !(f & 2)));                  // a cut before x: nothing connects x to x - 1
-        act.w[c] = __ballot(f & 1);
-      }
-      int cnt = 0, nact = 0, base = pass ? s_off[r] : 0;
-#pragma unroll
-      for (int c = 0; c < NW_; c++) {
-        const int x = c * 64 + lane;
-        bool proc = false, start = false;
-        int e = 0;
-        if (x < mb_w) {
-          const int sx = mask_prev_set(cut, x);
-          e = mask_next_set(cut, x, mb_w);
-          proc = mask_any(act, sx, e);
-          start = proc && sx == x;
-        }
-        const unsigned long long pm = __ballot(proc), sm = __ballot(start), om = __ballot(start && e == x + 1);
-        if (pass == 0) { if (lane == 0 && c < nch) { s_proc[r][c] = pm; s_one[r][c] = om; } }
-        else {
-          // a run of one macroblock right below another one (same column, same group of DB_COL_ROWS rows) is filtered by the column walk
-          // that starts at the top of that chain: its task stays in the list with length 0
-          int len = 1;
-          if (start && e == x + 1) {
-            if ((r % DB_COL_ROWS) != 0 && ((s_one[r - 1][c] >> lane) & 1)) len = 0;
-            else for (int rr = r + 1; rr < mb_h && (rr % DB_COL_ROWS) != 0 && ((s_one[rr][c] >> lane) & 1); rr++) len++;
-          }
-          if (start) tasks[base + cnt + __popcll(sm & ((1ull << lane) - 1))] = make_int2(r | (len << 16), x | (e << 16));
-          if (x < mb_w) store_bottom[r * mb_w + x] = (uint8_t)(proc && r + 1 < mb_h && !((s_proc[r + 1][c] >> lane) & 1));
-        }
-        cnt += __popcll(sm); nact += __popcll(act.w[c]);
-      }
-      if (pass == 0 && lane == 0) { s_cnt[r] = cnt; s_act[r] = nact; }
+  for (int c = 0; c < NW_; c++) {
+    const int x = c * 64 + lane;
+    proc[c] = false; start[c] = false; e[c] = 0;
+    if (x < mb_w) {
+      const int sx = mask_prev_set(cut, x);
+      e[c] = mask_next_set(cut, x, mb_w);
+      proc[c] = mask_any(act, sx, e[c]);
+      start[c] = proc[c] && sx == x;
     }
-    if (pass == 1) break;
-    __syncthreads();
-    // exclusive scan of the rows' task counts (and the total of active macroblocks): rows <= 256 = one per thread
-    int v = tid < mb_h ? s_cnt[tid] : 0, a = tid < mb_h ? s_act[tid] : 0, inc = v;          // rows <= 256: waves 0..3 hold them
+    const unsigned long long pm = __ballot(proc[c]), om = __ballot(start[c] && e[c] == x + 1);
+    sm[c] = __ballot(start[c]);
+    if (lane == 0) {
+      __hip_atomic_store((gu64 *)(masks + (long)r * DB_MASK_WORDS + c), pm, RLX_AGENT);
+      __hip_atomic_store((gu64 *)(masks + (long)r * DB_MASK_WORDS + 4 + c), om, RLX_AGENT);
+    }
+    cnt += __popcll(sm[c]); nact += __popcll(act.w[c]);
+  }
+  if (lane == 0) __hip_atomic_store((gu64 *)(rowinfo + r), (1ull << 63) | ((unsigned long long)nact << 32) | (unsigned)cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- all rows' words
+  int before = 0, total = 0, active = 0;
+  {
+    unsigned long long v[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    for (int k = 0; k < 4; k++) if (k * 64 + lane < mb_h) v[k] = __hip_atomic_load((gu64 *)(rowinfo + k * 64 + lane), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 0;; spins++) {
+      bool ok = true;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-    if (lane == 63 && wave < 4) s_wsum[wave] = inc;
-    if (lane == 0 && wave < 4) s_asum[wave] = a;
-    __syncthreads();
-    int woff = 0, total = 0, active = 0;
-    for (int k = 0; k < 4; k++) { if (k < wave) woff += s_wsum[k]; total += s_wsum[k]; active += s_asum[k]; }
-    if (tid < mb_h) s_off[tid] = woff + inc - v;
-    const bool sparse = total <= DB_MAX_TASKS && active * 100 <= nmb * max_active_pct;
-    if (tid == 0) { ctl[1] = (unsigned)total; ctl[0] = sparse ? 1u : 0u; }
-    if (!sparse) return;                                                          // workgroup-uniform
-    __syncthreads();
+      for (int k = 0; k < 4; k++) ok = ok && (k * 64 + lane >= mb_h || (v[k] >> 63) != 0);
+      if (__all(ok)) break;
+      if (spins > DB_SPIN_LIMIT || ((spins & 31u) == 31u && __hip_atomic_load((gu32 *)err, RLX_AGENT) != 0)) { __hip_atomic_store((gu32 *)err, 1u, RLX_AGENT); return; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (k * 64 + lane < mb_h && (v[k] >> 63) == 0) v[k] = __hip_atomic_load((gu64 *)(rowinfo + k * 64 + lane), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)(v[k] & 0xffffffffu), a = (int)((v[k] >> 32) & 0x7fffffffu);
+      total += c; active += a; if (k * 64 + lane < r) before += c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { total += __shfl_xor(total, d, 64); active += __shfl_xor(active, d, 64); before += __shfl_xor(before, d, 64); }
+  }
+  const bool sparse = total <= DB_MAX_TASKS && active * 100 <= nmb * max_active_pct;
+  if (r == 0 && lane == 0) { ctl[1] = (unsigned)total; ctl[0] = sparse ? 1u : 0u; }
+  if (!sparse) return;                                                          // the same for every workgroup
+  // ---- the tasks of this row
+  const int g0 = r - (r % DB_COL_ROWS);                                         // its group of rows for the column walks
+  if (lane < DB_COL_ROWS * NW_) {
+    const int rr = g0 + lane / NW_, c = lane % NW_;
+    s_one[lane / NW_][c] = rr < mb_h ? __hip_atomic_load((gu64 *)(masks + (long)rr * DB_MASK_WORDS + 4 + c), RLX_AGENT) : 0ull;
+  }
+  unsigned long long below[NW_];
+#pragma unroll
+  for (int c = 0; c < NW_; c++) below[c] = r + 1 < mb_h ? __hip_atomic_load((gu64 *)(masks + (long)(r + 1) * DB_MASK_WORDS + c), RLX_AGENT) : 0ull;
+  __syncthreads();
+  int base = before;
+#pragma unroll
+  for (int c = 0; c < NW_; c++) {
+    const int x = c * 64 + lane;
+    // a run of one macroblock right below another one (same column, same group of DB_COL_ROWS rows) is filtered by the column walk that
+    // starts at the top of that chain: its task stays in the list with length 0
+    int len = 1;
+    if (start[c] && e[c] == x + 1) {
+      if (r > g0 && ((s_one[r - g0 - 1][c] >> lane) & 1)) len = 0;
+      else for (int rr = r + 1; rr < mb_h && rr < g0 + DB_COL_ROWS && ((s_one[rr - g0][c] >> lane) & 1); rr++) len++;
+    }
+    if (start[c]) tasks[base + __popcll(sm[c] & ((1ull << lane) - 1))] = make_int2(r | (len << 16), x | (e[c] << 16));
+    if (x < mb_w) store_bottom[r * mb_w + x] = (uint8_t)(proc[c] && r + 1 < mb_h && !((below[c] >> lane) & 1));
+    base += __popcll(sm[c]);
   }
 }
 
@@ -394,9 +405,10 @@ __global__ __launch_bounds__(192) void k_deblock_sparse(RowArgs A)
 // after k_deblock_prep on the context's stream; A as the band pipeline gets it (stride, ctl, tasks, store_bottom set by the caller)
 int jmhip_launch_deblock_sparse(jmhip_ctx *ctx, const RowArgs &A, const uint8_t *d_flags, int max_active_pct)
 {
-  if (A.mb_w <= 64) hipLaunchKernelGGL(k_deblock_tasks<1>, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
-  else if (A.mb_w <= 128) hipLaunchKernelGGL(k_deblock_tasks<2>, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
-  else hipLaunchKernelGGL(k_deblock_tasks<4>, dim3(1), dim3(64 * TASK_WAVES), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct);
+  unsigned long long *rowinfo = (unsigned long long *)(A.sync + DB_SYNC_ROWINFO), *masks = (unsigned long long *)((char *)ctx->d_db_tasks + DB_MAX_TASKS * 8);
+#define TASKS(NW) hipLaunchKernelGGL(k_deblock_tasks<NW>, dim3(A.mb_h), dim3(64), 0, ctx->stream, d_flags, A.mb_w, A.mb_h, (int2 *)A.tasks, (uint8_t *)A.store_bottom, A.ctl, max_active_pct, rowinfo, masks, A.sync + 1)
+  if (A.mb_w <= 64) TASKS(1); else if (A.mb_w <= 128) TASKS(2); else TASKS(4);
+#undef TASKS
   hipLaunchKernelGGL(k_deblock_sparse, dim3(DB_MAX_TASKS * A.nkinds), dim3(192), 0, ctx->stream, A);
   return JMHIP_OK;
 }
