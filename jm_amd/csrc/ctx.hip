@@ -264,14 +264,31 @@ static int refc_slot(jmhip_ctx *ctx, int slot)
   if (!ctx->d_refc[slot]) HIPCHK(ctx, hipMalloc((void **)&ctx->d_refc[slot], (size_t)2 * ctx->cw * ctx->ch));
   return JMHIP_OK;
 }
+// both chroma planes of a reference into the context's slot (U then V, pitch = width); 8 bytes per thread when everything is 8-byte aligned
+__global__ __launch_bounds__(256) void k_copy_chroma_planes(const uint8_t *__restrict__ u, const uint8_t *__restrict__ v, int pitch,
+                                                            uint8_t *__restrict__ dst, int cw, int ch, int units, int wide)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= units * ch) return;
+  const int y = i / units, x = i - y * units;
+  const uint8_t *src = (blockIdx.y ? v : u) + (size_t)y * pitch;
+  uint8_t *d = dst + (size_t)blockIdx.y * cw * ch + (size_t)y * cw;
+  if (wide) ((uint2 *)d)[x] = ((const uint2 *)src)[x];
+  else d[x] = src[x];
+}
+
 extern "C" int jmhip_set_reference_chroma_dev(jmhip_ctx *ctx, int32_t slot, const uint8_t *d_u, const uint8_t *d_v, int32_t pitch_bytes)
 {
   if (!ctx || !d_u || !d_v || slot < 0 || slot >= ctx->cfg.num_ref_slots || ctx->cfg.yuv_format == 0 || pitch_bytes < ctx->cw)
     return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_chroma_dev: bad argument") : JMHIP_EINVAL;
   int r = refc_slot(ctx, slot);
   if (r) return r;
-  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_refc[slot], ctx->cw, d_u, pitch_bytes, ctx->cw, ctx->ch, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_refc[slot] + (size_t)ctx->cw * ctx->ch, ctx->cw, d_v, pitch_bytes, ctx->cw, ctx->ch, hipMemcpyDeviceToDevice, ctx->stream));
+  // one launch for both planes (two 2-D copies of the runtime were 5 us each at 1080p)
+  const bool wide = !((ctx->cw | pitch_bytes) & 7) && !(((uintptr_t)d_u | (uintptr_t)d_v) & 7);
+  const int units = wide ? ctx->cw / 8 : ctx->cw;
+  hipLaunchKernelGGL(k_copy_chroma_planes, dim3((units * ctx->ch + 255) / 256, 2), dim3(256), 0, ctx->stream,
+                     d_u, d_v, pitch_bytes, ctx->d_refc[slot], ctx->cw, ctx->ch, units, wide ? 1 : 0);
+  HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
 }
 extern "C" int jmhip_set_reference_chroma(jmhip_ctx *ctx, int32_t slot, const uint16_t *u, const uint16_t *v, int32_t pitch_samples)

@@ -58,14 +58,19 @@ __global__ __launch_bounds__(256) void k_me_fullsearch(const jmhip_me_job *__res
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
                                                        const int16_t *__restrict__ spiral, int skip_fast,
-                                                       const unsigned *__restrict__ declined, unsigned *__restrict__ declined_next)
+                                                       const unsigned *__restrict__ declined, unsigned *__restrict__ declined_next, int njobs)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const jmhip_me_job *job = jobs + blockIdx.x;
   if (skip_fast) {                                         // k_me_fs_fast ran before this launch and counted the jobs it left for us
     if (blockIdx.x == 0 && threadIdx.x == 0) *declined_next = 0;          // the counter of the NEXT launch pair (ping-pong)
-    if (*declined == 0 || job_is_fast(job)) return;
+    if (*declined == 0) return;
   }
+  // after k_me_fs_fast the grid is a few workgroups per compute unit that walk the job list (an empty launch of one workgroup per job
+  // took 6.6 us at 1080p); on its own the kernel is launched with one workgroup per job
+  for (int jb = blockIdx.x; jb < njobs; jb += gridDim.x) {
+  const jmhip_me_job *job = jobs + jb;
+  if (skip_fast && job_is_fast(job)) continue;
+  __syncthreads();                                         // the previous job's LDS is no longer read
   const int R = job->search_range;
   const int wpitch = (2 * R + 16 + 4 + 3) & ~3;
   uint8_t *s_win = smem;                                                   // (2R+16) x wpitch
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(256) void k_me_fullsearch(const jmhip_me_job *__res
       b.mv_x = (int16_t)(cx + 4 * spiral[2 * idx]); b.mv_y = (int16_t)(cy + 4 * spiral[2 * idx + 1]);
       b.cost = (int32_t)(k >> 16);
     }
-    results[blockIdx.x].best[tid] = b;
+    results[jb].best[tid] = b;
+  }
   }
 }
 
@@ -195,9 +201,9 @@ extern "C" int jmhip_me_fullsearch_dev(jmhip_ctx *ctx, int32_t slot, const jmhip
   unsigned *dec = ctx->d_me_declined + (ctx->me_launches & 1), *dec_next = ctx->d_me_declined + ((ctx->me_launches + 1) & 1);
   ctx->me_launches++;
   if (use_fast) jmhip_launch_me_fast(ctx, slot, d_jobs, njobs, d_results, dec);
-  hipLaunchKernelGGL(k_me_fullsearch, dim3(njobs), dim3(256), me_lds_bytes(ctx->cfg.search_range), ctx->stream,
+  hipLaunchKernelGGL(k_me_fullsearch, dim3(use_fast ? (njobs < 1024 ? njobs : 1024) : njobs), dim3(256), me_lds_bytes(ctx->cfg.search_range), ctx->stream,
                      d_jobs, d_results, ctx->d_cur, ctx->cur_pitch, ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, use_fast,
-                     dec, dec_next);
+                     dec, dec_next, njobs);
   jmhip_time_end(ctx, 1);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;
