@@ -287,9 +287,9 @@ def main():
             marks[i][3].record(stream)
         # P16x16 reconstruction path, device resident: prediction with each macroblock's refined 16x16 vector, residual transform /
         # quantisation / reconstruction of the sixteen 4x4 blocks, reconstructed blocks assembled into the picture the deblocking reads
-        ctx.mc_mb16_dev(0, d_jobs.data_ptr(), d_fin.data_ptr(), nmb, halo, W // 4, d_predb.data_ptr())
-        ctx.tq_luma4x4_dev(tqp, d_orig.data_ptr(), d_predb.data_ptr(), nblk, d_tq.data_ptr())    # K7/K8
-        ctx.tq_rec_to_plane_dev(d_tq.data_ptr(), nblk, W // 4, work_y.data_ptr(), W)
+        # (one launch: jmhip_mb16_recon_luma_dev = jmhip_mc_mb16_dev + jmhip_tq_luma4x4_dev + jmhip_tq_rec_to_plane_dev)
+        ctx.mb16_recon_luma_dev(0, tqp, d_jobs.data_ptr(), d_fin.data_ptr(), nmb, halo, W // 4, d_orig.data_ptr(), d_tq.data_ptr(), 0,
+                                work_y.data_ptr(), W)                                            # MC + K7/K8
         # the same for both chroma planes (chroma_prediction_4x4, residual_transform_quant_chroma_4x4)
         ctx.mc_mb16_chroma_dev(0, d_jobs.data_ptr(), d_fin.data_ptr(), nmb, d_predc.data_ptr())
         ctx.tq_chroma_dev(tqcp, d_cmbs.data_ptr(), d_origc.data_ptr(), d_predc.data_ptr(), 2 * nmb, d_tqc.data_ptr())

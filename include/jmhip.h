@@ -445,6 +445,14 @@ int jmhip_mc_chroma_wp_dev(jmhip_ctx *ctx, const jmhip_mc_chroma_blk *d_blocks, 
 int jmhip_mc_mb16_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t njobs,
                       int32_t y_offset, int32_t blocks_per_row, uint8_t *d_pred_blocks);
 int jmhip_tq_rec_to_plane_dev(jmhip_ctx *ctx, const jmhip_tq_out *d_out, int32_t nblocks, int32_t blocks_per_row, uint8_t *d_plane, int32_t pitch_bytes);
+/* The three luma calls above in ONE launch (the prediction stays in registers): jmhip_mc_mb16_dev -> jmhip_tq_luma4x4_dev on
+ * (d_orig_blocks, that prediction) -> jmhip_tq_rec_to_plane_dev.  Same records in d_out (block order, every block of the listed
+ * macroblocks), same samples in d_plane (row 0 = picture row y_offset); d_pred_blocks may be NULL (else it receives the prediction).
+ * Replaces, per macroblock coded P16x16: luma_prediction (mc_prediction.c:144) + residual_transform_quant_luma_4x4 (block.c:661-725)
+ * of its sixteen blocks with the reconstruction written to enc_picture. */
+int jmhip_mb16_recon_luma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_tq_params *prm, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results,
+                              int32_t njobs, int32_t y_offset, int32_t blocks_per_row, const uint8_t *d_orig_blocks, jmhip_tq_out *d_out,
+                              uint8_t *d_pred_blocks, uint8_t *d_plane, int32_t pitch_bytes);
 int jmhip_mc_mb16_chroma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results, int32_t njobs, uint8_t *d_pred_items);
 int jmhip_tqc_rec_to_planes_dev(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, const jmhip_tqc_out *d_out, int32_t njobs, int32_t y_offset,
                                 uint8_t *d_u, uint8_t *d_v, int32_t pitch_bytes);

@@ -105,6 +105,63 @@ __global__ __launch_bounds__(64) void k_xform8(const int32_t *__restrict__ in, i
 }
 
 
+// residual_transform_quant_luma_4x4 of one block held in registers (block.c:661-725): orig / pred as four row dwords, the record into LDS
+__device__ __forceinline__ void tq_luma4x4_block(const jmhip_tq_params &prm, const uint32_t (&wo)[4], const uint32_t (&wp)[4], jmhip_tq_out &o)
+{
+  int m[16], pr[16], any = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    pr[k] = (wp[k >> 2] >> (8 * (k & 3))) & 255;
+    m[k] = (int)((wo[k >> 2] >> (8 * (k & 3))) & 255) - pr[k];
+    any |= m[k];
+  }
+  int nonzero = 0, ncoef = 0, cost = 0;
+  int16_t *s_lev = o.level; uint8_t *s_run = o.run;       // level/run lists are appended in LDS (dynamic index)
+#pragma unroll
+  for (int k = 0; k < 16; k++) { o.level[k] = 0; o.run[k] = 0; o.fadjust[k] = 0; }
+  if (any) {                                                                 // check_zero, block.c:627-640
+    forward4x4_regs(m);
+    const int q_bits = 15 + prm.qp_per;
+    int run = 0;
+    // zig-zag scan position k -> raster index j*4+i (SNGL_SCAN, block.c:170-176); the loop is fully
+    // unrolled so every m[] / q[] index is a literal and the block stays in registers
+    constexpr int ZZ[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+    constexpr int CC[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // COEFF_COST4x4[0], block.c:72-77
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int idx = ZZ[k];
+      const int c = m[idx];
+      int fadj = 0;
+      if (c != 0) {
+        const int scaled = iabs_(c) * prm.q[idx].ScaleComp;
+        int lev = (scaled + prm.q[idx].OffsetComp) >> q_bits;
+        if (lev != 0) {
+          if (prm.cavlc) lev = min(lev, 2063);
+          if (prm.adaptive_rounding) fadj = (prm.adapt_rnd_weight * (scaled - (lev << q_bits)) + (1 << q_bits)) >> (q_bits + 1);
+          int cc = 0;
+#pragma unroll
+          for (int t = 0; t < 16; t++) cc = (t == run) ? CC[t] : cc;
+          cost += (lev > 1) ? 999999 : cc;
+          lev = c < 0 ? -lev : lev;
+          m[idx] = (((lev * prm.q[idx].InvScaleComp) << prm.qp_per) + 8) >> 4;
+          s_lev[ncoef] = (int16_t)lev; s_run[ncoef] = (uint8_t)run; ncoef++;
+          run = 0; nonzero = 1;
+        } else { m[idx] = 0; run++; }
+      } else run++;
+      o.fadjust[idx] = (int16_t)fadj;
+    }
+  }
+  if (nonzero) {
+    inverse4x4_regs(m);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { int v = ((m[k] + 32) >> 6) + pr[k]; o.rec[k] = (uint8_t)(v < 0 ? 0 : (v > prm.max_pel ? prm.max_pel : v)); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) o.rec[k] = (uint8_t)pr[k];
+  }
+  o.coeff_cost = cost; o.nonzero = (uint8_t)nonzero; o.any_residual = any ? 1 : 0; o.ncoef = (uint8_t)ncoef; o.reserved_ = 0;
+}
+
 __global__ __launch_bounds__(256) void k_tq_luma4x4(jmhip_tq_params prm, const uint8_t *__restrict__ orig, const uint8_t *__restrict__ pred,
                                                     int n, jmhip_tq_out *__restrict__ out)
 {
@@ -114,58 +171,7 @@ __global__ __launch_bounds__(256) void k_tq_luma4x4(jmhip_tq_params prm, const u
   if (b < n) {
     const uint4 vo = *(const uint4 *)(orig + (long)b * 16), vp = *(const uint4 *)(pred + (long)b * 16);
     const uint32_t wo[4] = {vo.x, vo.y, vo.z, vo.w}, wp[4] = {vp.x, vp.y, vp.z, vp.w};
-    int m[16], pr[16], any = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      pr[k] = (wp[k >> 2] >> (8 * (k & 3))) & 255;
-      m[k] = (int)((wo[k >> 2] >> (8 * (k & 3))) & 255) - pr[k];
-      any |= m[k];
-    }
-    int nonzero = 0, ncoef = 0, cost = 0;
-    int16_t *s_lev = o.level; uint8_t *s_run = o.run;       // level/run lists are appended in LDS (dynamic index)
-#pragma unroll
-    for (int k = 0; k < 16; k++) { o.level[k] = 0; o.run[k] = 0; o.fadjust[k] = 0; }
-    if (any) {                                                                 // check_zero, block.c:627-640
-      forward4x4_regs(m);
-      const int q_bits = 15 + prm.qp_per;
-      int run = 0;
-      // zig-zag scan position k -> raster index j*4+i (SNGL_SCAN, block.c:170-176); the loop is fully
-      // unrolled so every m[] / q[] index is a literal and the block stays in registers
-      constexpr int ZZ[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
-      constexpr int CC[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // COEFF_COST4x4[0], block.c:72-77
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int idx = ZZ[k];
-        const int c = m[idx];
-        int fadj = 0;
-        if (c != 0) {
-          const int scaled = iabs_(c) * prm.q[idx].ScaleComp;
-          int lev = (scaled + prm.q[idx].OffsetComp) >> q_bits;
-          if (lev != 0) {
-            if (prm.cavlc) lev = min(lev, 2063);
-            if (prm.adaptive_rounding) fadj = (prm.adapt_rnd_weight * (scaled - (lev << q_bits)) + (1 << q_bits)) >> (q_bits + 1);
-            int cc = 0;
-#pragma unroll
-            for (int t = 0; t < 16; t++) cc = (t == run) ? CC[t] : cc;
-            cost += (lev > 1) ? 999999 : cc;
-            lev = c < 0 ? -lev : lev;
-            m[idx] = (((lev * prm.q[idx].InvScaleComp) << prm.qp_per) + 8) >> 4;
-            s_lev[ncoef] = (int16_t)lev; s_run[ncoef] = (uint8_t)run; ncoef++;
-            run = 0; nonzero = 1;
-          } else { m[idx] = 0; run++; }
-        } else run++;
-        o.fadjust[idx] = (int16_t)fadj;
-      }
-    }
-    if (nonzero) {
-      inverse4x4_regs(m);
-#pragma unroll
-      for (int k = 0; k < 16; k++) { int v = ((m[k] + 32) >> 6) + pr[k]; o.rec[k] = (uint8_t)(v < 0 ? 0 : (v > prm.max_pel ? prm.max_pel : v)); }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; k++) o.rec[k] = (uint8_t)pr[k];
-    }
-    o.coeff_cost = cost; o.nonzero = (uint8_t)nonzero; o.any_residual = any ? 1 : 0; o.ncoef = (uint8_t)ncoef; o.reserved_ = 0;
+    tq_luma4x4_block(prm, wo, wp, o);
   }
   __syncthreads();
   // coalesced copy-out of this workgroup's records (26 dwords each)
@@ -174,6 +180,64 @@ __global__ __launch_bounds__(256) void k_tq_luma4x4(jmhip_tq_params prm, const u
   uint32_t *dst = (uint32_t *)(out + first);
   const int ndw = cnt * (int)(sizeof(jmhip_tq_out) / 4);
   for (int k = threadIdx.x; k < ndw; k += 256) dst[k] = src[k];
+}
+
+// ---- P pictures coded as 16x16 macroblocks, one launch per picture: luma_prediction of each window job's 16x16 partition with the vector
+//      the refinement left (as k_mc_mb16), residual_transform_quant_luma_4x4 of its sixteen blocks (as k_tq_luma4x4) and the reconstructed
+//      samples written into the picture (as k_tq_rec_to_plane) -- the prediction never leaves the registers.  16 lanes per macroblock
+//      (lane = 4x4 block), 16 macroblocks per workgroup; records leave through LDS, the four blocks of a block row as one 416-byte run.
+__device__ __forceinline__ uint32_t ld4u_tq(const uint8_t *p) { struct __attribute__((packed)) U { uint32_t v; }; return ((const U *)p)->v; }
+__global__ __launch_bounds__(256) void k_mb16_recon_luma(jmhip_tq_params prm, const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ results, int n,
+                                                         const uint8_t *__restrict__ planes, int pitch, long plane_stride, int W, int H,
+                                                         int y_offset, int blocks_per_row, const uint8_t *__restrict__ orig,
+                                                         jmhip_tq_out *__restrict__ out, uint8_t *__restrict__ pred, uint8_t *__restrict__ plane, int plane_pitch)
+{
+  __shared__ __attribute__((aligned(16))) jmhip_tq_out s_out[256];
+  __shared__ int s_blk[256];
+  const int tid = threadIdx.x, j = blockIdx.x * 16 + (tid >> 4), l = tid & 15, bx = l & 3, by = l >> 2;
+  jmhip_tq_out &o = s_out[tid];
+  s_blk[tid] = -1;
+  if (j < n) {
+    const int mb_x = jobs[j].mb_x, mb_y = jobs[j].mb_y;
+    const jmhip_me_best mv = results[j].best[0];
+    const int qx = (mb_x << 2) + mv.mv_x, qy = (mb_y << 2) + mv.mv_y;
+    const int yy = min(max(qy >> 2, -JMHIP_PAD_Y), H + 3), xx = min(max(qx >> 2, -JMHIP_PAD_X), W + 15);     // one clamped origin per block (UMVLine4X)
+    const uint8_t *src = planes + ((qy & 3) * 4 + (qx & 3)) * plane_stride + (long)(yy + JMHIP_PAD_Y + 4 * by) * pitch + xx + JMHIP_PAD_X + 4 * bx;
+    const long blk = (long)(((mb_y - y_offset) >> 2) + by) * blocks_per_row + (mb_x >> 2) + bx;
+    const uint32_t wp[4] = {ld4u_tq(src), ld4u_tq(src + pitch), ld4u_tq(src + 2 * pitch), ld4u_tq(src + 3 * pitch)};
+    const uint4 vo = *(const uint4 *)(orig + blk * 16);
+    const uint32_t wo[4] = {vo.x, vo.y, vo.z, vo.w};
+    if (pred) *(uint4 *)(pred + blk * 16) = make_uint4(wp[0], wp[1], wp[2], wp[3]);
+    tq_luma4x4_block(prm, wo, wp, o);
+    s_blk[tid] = (int)blk;
+    uint8_t *d = plane + (long)(mb_y - y_offset + 4 * by) * plane_pitch + mb_x + 4 * bx;
+#pragma unroll
+    for (int r = 0; r < 4; r++) *(uint32_t *)(d + (long)r * plane_pitch) = *(const uint32_t *)(o.rec + 4 * r);
+  }
+  __syncthreads();
+  constexpr int RD = (int)(sizeof(jmhip_tq_out) / 4);                          // 26 dwords per record
+  const uint32_t *src = (const uint32_t *)s_out;
+  uint32_t *dst = (uint32_t *)out;
+  for (int k = tid; k < 256 * RD; k += 256) {
+    const int r = k / RD, w = k - r * RD, blk = s_blk[r];
+    if (blk >= 0) dst[(long)blk * RD + w] = src[k];
+  }
+}
+
+extern "C" int jmhip_mb16_recon_luma_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_tq_params *prm, const jmhip_me_job *d_jobs, const jmhip_me_result *d_results,
+                                         int32_t njobs, int32_t y_offset, int32_t blocks_per_row, const uint8_t *d_orig, jmhip_tq_out *d_out,
+                                         uint8_t *d_pred, uint8_t *d_plane, int32_t pitch_bytes)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  if (!prm || njobs < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots || blocks_per_row < 4 || pitch_bytes < 4 * blocks_per_row || (pitch_bytes & 3) ||
+      (njobs > 0 && (!d_jobs || !d_results || !d_orig || !d_out || !d_plane)))
+    return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mb16_recon_luma_dev: bad argument");
+  if (prm->qp_per < 0 || prm->qp_per > 8) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_mb16_recon_luma_dev: qp_per %d outside 0..8", prm->qp_per);
+  if (njobs == 0) return JMHIP_OK;
+  hipLaunchKernelGGL(k_mb16_recon_luma, dim3((njobs + 15) / 16), dim3(256), 0, ctx->stream, *prm, d_jobs, d_results, njobs, (const uint8_t *)ctx->d_sub[slot], ctx->pitch,
+                     (long)ctx->plane_stride, ctx->W, ctx->H, y_offset, blocks_per_row, d_orig, d_out, d_pred, d_plane, pitch_bytes);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
 }
 
 extern "C" int jmhip_tq_luma4x4_dev(jmhip_ctx *ctx, const jmhip_tq_params *prm, const uint8_t *d_orig, const uint8_t *d_pred, int32_t n, jmhip_tq_out *d_out)

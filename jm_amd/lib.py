@@ -85,7 +85,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
-           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
+           "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
 
 
@@ -464,6 +464,11 @@ class JmHip:
 
     def tq_rec_to_plane_dev(self, d_out, n, blocks_per_row, d_plane, pitch):
         self._ck(self.lib.jmhip_tq_rec_to_plane_dev(self.h, _vp(d_out), n, blocks_per_row, _vp(d_plane), pitch))
+
+    def mb16_recon_luma_dev(self, slot, prm, d_jobs, d_results, n, y_offset, blocks_per_row, d_orig, d_out, d_pred, d_plane, pitch):
+        """mc_mb16_dev + tq_luma4x4_dev + tq_rec_to_plane_dev in one launch (d_pred may be 0)"""
+        self._ck(self.lib.jmhip_mb16_recon_luma_dev(self.h, slot, _vp(prm), _vp(d_jobs), _vp(d_results), n, y_offset, blocks_per_row, _vp(d_orig), _vp(d_out),
+                                                    _vp(d_pred), _vp(d_plane), pitch))
 
     def mc_mb16_chroma_dev(self, slot, d_jobs, d_results, n, d_pred):
         self._ck(self.lib.jmhip_mc_mb16_chroma_dev(self.h, slot, _vp(d_jobs), _vp(d_results), n, _vp(d_pred)))

@@ -1136,6 +1136,35 @@ def test_mc_mb16_and_rec_to_plane_vs_oracle(J):
     out = d_out.cpu().numpy().view(TQ_OUT).reshape(nblk)
     want = out["rec"].reshape(h // 4, w // 4, 4, 4).transpose(0, 2, 1, 3).reshape(h, w)
     assert np.array_equal(d_plane.cpu().numpy(), want)
+    # the three calls as one launch (jmhip_mb16_recon_luma_dev): same prediction, same records, same plane; and against the oracle's
+    # residual_transform_quant_luma_4x4 on the oracle's own prediction
+    for with_pred in (True, False):
+        d_pred2 = torch.zeros_like(d_pred); d_out2 = torch.zeros_like(d_out); d_plane2 = torch.zeros_like(d_plane)
+        ctx.mb16_recon_luma_dev(0, prm, d_jobs.data_ptr(), d_res.data_ptr(), nmb, 0, w // 4, d_orig.data_ptr(), d_out2.data_ptr(),
+                                d_pred2.data_ptr() if with_pred else 0, d_plane2.data_ptr(), w)
+        ctx.synchronize()
+        assert torch.equal(d_out2, d_out) and torch.equal(d_plane2, d_plane)
+        assert torch.equal(d_pred2, d_pred) if with_pred else int(d_pred2.max()) == 0
+    ob, pb = blocks(cur), blocks(pred)
+    import ctypes as C
+    for b in rng.choice(nblk, 96, replace=False):
+        level = np.zeros(17, np.int32); run = np.zeros(17, np.int32); cost = C.c_int(0)
+        rec = np.zeros(16, np.uint16); fadj = np.zeros(16, np.int32)
+        nz = J.L.jmo_rtq_luma_4x4(J._p(ob[b].astype(np.uint16)), J._p(pb[b].astype(np.uint16)), 28, 0, 0, 4, 255, J._p(level), J._p(run), C.byref(cost), J._p(rec), J._p(fadj))
+        k = int(out["ncoef"][b])
+        assert int(out["nonzero"][b]) == nz and int(out["coeff_cost"][b]) == cost.value and (out["rec"][b] == rec).all(), b
+        assert out["level"][b][:k].tolist() == level[:k].tolist() and out["run"][b][:k].tolist() == run[:k].tolist(), b
+    # a band of a taller picture (y_offset) and a job list that is not in raster order
+    perm = rng.permutation(nmb)
+    sel = perm[jobs["mb_y"][perm] >= 16]
+    d_jobs_p = torch.from_numpy(jobs[sel].view(np.uint8).reshape(len(sel), -1)).to(dev)
+    d_res_p = torch.from_numpy(res[sel].view(np.uint8).reshape(len(sel), -1)).to(dev)
+    nb2 = (w // 4) * ((h - 16) // 4)
+    d_out3 = torch.zeros((nb2, TQ_OUT.itemsize), dtype=torch.uint8, device=dev); d_plane3 = torch.zeros((h - 16, w), dtype=torch.uint8, device=dev)
+    ctx.mb16_recon_luma_dev(0, prm, d_jobs_p.data_ptr(), d_res_p.data_ptr(), len(sel), 16, w // 4, d_orig[4 * (w // 4):].contiguous().data_ptr(),
+                            d_out3.data_ptr(), 0, d_plane3.data_ptr(), w)
+    ctx.synchronize()
+    assert torch.equal(d_out3, d_out[4 * (w // 4):]) and torch.equal(d_plane3, d_plane[16:])
     ctx.close()
 
 
