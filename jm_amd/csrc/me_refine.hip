@@ -152,6 +152,8 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
   __shared__ int s_mv[JMHIP_NPART][2];            // per partition: the motion vector the running stage refines
   __shared__ int s_min[JMHIP_NPART];              // min_mcost carried between the stages
   __shared__ unsigned s_dist[JMHIP_NPART * 9];    // distortion of (partition, candidate), summed over its 4x4 / 8x8 blocks
+  __shared__ uint8_t s_list[NPAIRS];              // the leader pairs, compacted
+  __shared__ int s_nlead[2];
   __shared__ uint16_t s_val[NPAIRS * 9];          // distortion of (block type, 4x4 block, candidate) as its lane computed it, for lanes with the same vector
   const int tid = threadIdx.x;
   const int jb = xcd_job_index(blockIdx.x, njobs);
@@ -178,53 +180,97 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
     const int lambda = stage == 0 ? prm.lambda_h : prm.lambda_q, metric = stage == 0 ? prm.metric_h : prm.metric_q;
     for (int k = tid; k < JMHIP_NPART * 9; k += REFINE_THREADS) s_dist[k] = 0;
     __syncthreads();
+    const bool sad = metric == JMHIP_METRIC_SAD;
+    const bool t8 = T8MODE && p <= 8 && !sad;                                                        // mv_search.c:1630 / :1770
     int leader = -1;
+    // Hadamard SATD takes every 4x4 sub-block from its own clamped origin (computeSATD), so the distortion of 4x4 block b at a candidate
+    // depends on the block and the vector only, not on the partition it is counted for: when partitions of several block types carry the
+    // same vector -- the common case, one motion per macroblock -- the pair of the smallest such type (the leader) is computed, the others
+    // pick the nine values up from LDS.  (SAD hangs a partition off one clamped origin, so every pair leads itself; so do the 8x8-Hadamard types.)
     if (act) {
-      const bool sad = metric == JMHIP_METRIC_SAD;
-      const bool t8 = T8MODE && p <= 8 && !sad;                                                      // mv_search.c:1630 / :1770
-      const int mvx = s_mv[p][0], mvy = s_mv[p][1];
-      // SAD: the whole partition hangs off ONE clamped origin (computeSAD), this block sits at a fixed offset from it;
-      // SATD: every 4x4 (8x8) sub-block has its own clamped origin (computeSATD)
-      const int qx0 = ((sad ? mb_x + gx : mb_x + 4 * bx4) << 2) + mvx, qy0 = ((sad ? mb_y + gy : mb_y + 4 * by4) << 2) + mvy;
-      const uint32_t inner = sad ? (uint32_t)(__mul24(4 * by4 - gy, ps.pitch) + (4 * bx4 - gx)) : 0u, pw = (uint32_t)ps.pitch;
-      // Hadamard SATD takes every 4x4 sub-block from its own clamped origin (computeSATD), so the distortion of 4x4 block b at a candidate
-      // depends on the block and the vector only, not on the partition it is counted for: when partitions of several block types carry the
-      // same vector -- the common case, one motion per macroblock -- the lane of the smallest such type computes, the others pick the nine
-      // values up from LDS.  (SAD hangs a partition off one clamped origin, so it is left alone; so are the 8x8-Hadamard types.)
       leader = t;
-      if (!sad && !t8)
+      if (!sad && !t8) {
+        const int mvx = s_mv[p][0], mvy = s_mv[p][1];
         for (int t2 = t - 1; t2 >= 0; t2--) {
           const int p2 = part_of(t2, bx4, by4);
           if (((mask >> p2) & 1) && !(T8MODE && p2 <= 8) && s_mv[p2][0] == mvx && s_mv[p2][1] == mvy) leader = t2;
         }
-      if (!t8) {
-        if (leader == t) {
-          const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
-          uint32_t rr[9][4];
-#pragma unroll
-          for (int cand = 0; cand < 9; cand++)
-            if (cand >= start) {
-              const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
-              rr[cand][0] = ld4o(ps.base, r); rr[cand][1] = ld4o(ps.base, r + pw); rr[cand][2] = ld4o(ps.base, r + 2 * pw); rr[cand][3] = ld4o(ps.base, r + 3 * pw);
-            }
-#pragma unroll
-          for (int cand = 0; cand < 9; cand++)
-            if (cand >= start) {
-              const unsigned d = (unsigned)(sad ? sad4_rows(c, rr[cand]) : hadamard4_rows(c, rr[cand]));
-              s_val[pair * 9 + cand] = (uint16_t)d;
-              atomicAdd(&s_dist[p * 9 + cand], d);
-            }
-        }
-      } else if (T8MODE && !((bx4 | by4) & 1)) {             // the top-left 4x4 leads its 8x8 block
-#pragma unroll 1
-        for (int cand = start; cand < 9; cand++) {
-          const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step);
-          atomicAdd(&s_dist[p * 9 + cand], (unsigned)hadamard8_lds(s_cur, 4 * by4, bx4, ps.base + (size_t)r, ps.pitch));
-        }
       }
     }
-    if (__syncthreads_or(leader >= 0 && leader != t)) {     // some lane waits for another lane's values (workgroup-uniform)
-      if (leader >= 0 && leader != t)
+    // With few leaders the (leader pair, candidate) items are dealt out to ALL lanes -- one motion per macroblock leaves 16 leaders: 144 items
+    // are two rounds of the workgroup instead of nine candidates in sequence on 16 lanes.  With many leaders a lane keeps its pair and walks
+    // the nine candidates (all 36 rows requested before the first distortion).
+    const bool lead4 = act && !t8 && leader == t;
+    const unsigned long long lm = __ballot(lead4);
+    if ((tid & 63) == 0) s_nlead[tid >> 6] = __popcll(lm);
+    __syncthreads();
+    const int nlead = s_nlead[0] + s_nlead[1], nc = 9 - start, nitems = nlead * nc;
+    const bool spread = nitems <= 4 * REFINE_THREADS;                            // workgroup-uniform
+    if (spread) {
+      if (lead4) s_list[((tid >> 6) ? s_nlead[0] : 0) + __popcll(lm & ((1ull << (tid & 63)) - 1))] = (uint8_t)pair;
+      __syncthreads();
+#pragma unroll 1
+      for (int it0 = tid; it0 < nitems; it0 += 2 * REFINE_THREADS) {
+        const int it1 = it0 + REFINE_THREADS;
+        const bool two = it1 < nitems;
+        int prs[2], cands[2];
+        uint32_t c[2][4], rr[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int it = (h == 0 || two) ? (h ? it1 : it0) : it0;                // the idle half repeats item 0 (its result is dropped)
+          const int li = it / nc, cand = start + (it - li * nc), pr = s_list[li];
+          const int tt = pr >> 4, bb = pr & 15, bx = bb & 3, by = bb >> 2, pp = part_of(tt, bx, by);
+          const int ggx = c_geom[pp][0], ggy = c_geom[pp][1];
+          const int qx0 = ((sad ? mb_x + ggx : mb_x + 4 * bx) << 2) + s_mv[pp][0], qy0 = ((sad ? mb_y + ggy : mb_y + 4 * by) << 2) + s_mv[pp][1];
+          const uint32_t inner = sad ? (uint32_t)(__mul24(4 * by - ggy, ps.pitch) + (4 * bx - ggx)) : 0u, pw = (uint32_t)ps.pitch;
+          const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
+          rr[h][0] = ld4o(ps.base, r); rr[h][1] = ld4o(ps.base, r + pw); rr[h][2] = ld4o(ps.base, r + 2 * pw); rr[h][3] = ld4o(ps.base, r + 3 * pw);
+#pragma unroll
+          for (int k = 0; k < 4; k++) c[h][k] = s_cur[(4 * by + k) * 4 + bx];
+          prs[h] = pr; cands[h] = cand;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const unsigned d = (unsigned)(sad ? sad4_rows(c[h], rr[h]) : hadamard4_rows(c[h], rr[h]));
+          if (h == 0 || two) s_val[prs[h] * 9 + cands[h]] = (uint16_t)d;
+        }
+      }
+    } else if (act && !t8) {
+      if (leader == t) {
+        const int mvx = s_mv[p][0], mvy = s_mv[p][1];
+        // SAD: the whole partition hangs off ONE clamped origin (computeSAD), this block sits at a fixed offset from it;
+        // SATD: every 4x4 (8x8) sub-block has its own clamped origin (computeSATD)
+        const int qx0 = ((sad ? mb_x + gx : mb_x + 4 * bx4) << 2) + mvx, qy0 = ((sad ? mb_y + gy : mb_y + 4 * by4) << 2) + mvy;
+        const uint32_t inner = sad ? (uint32_t)(__mul24(4 * by4 - gy, ps.pitch) + (4 * bx4 - gx)) : 0u, pw = (uint32_t)ps.pitch;
+        const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
+        uint32_t rr[9][4];
+#pragma unroll
+        for (int cand = 0; cand < 9; cand++)
+          if (cand >= start) {
+            const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
+            rr[cand][0] = ld4o(ps.base, r); rr[cand][1] = ld4o(ps.base, r + pw); rr[cand][2] = ld4o(ps.base, r + 2 * pw); rr[cand][3] = ld4o(ps.base, r + 3 * pw);
+          }
+#pragma unroll
+        for (int cand = 0; cand < 9; cand++)
+          if (cand >= start) {
+            const unsigned d = (unsigned)(sad ? sad4_rows(c, rr[cand]) : hadamard4_rows(c, rr[cand]));
+            s_val[pair * 9 + cand] = (uint16_t)d;
+            atomicAdd(&s_dist[p * 9 + cand], d);
+          }
+      }
+    }
+    if (T8MODE && act && t8 && !((bx4 | by4) & 1)) {                              // the top-left 4x4 leads its 8x8 block
+      const int qx0 = ((mb_x + 4 * bx4) << 2) + s_mv[p][0], qy0 = ((mb_y + 4 * by4) << 2) + s_mv[p][1];
+#pragma unroll 1
+      for (int cand = start; cand < 9; cand++) {
+        const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step);
+        atomicAdd(&s_dist[p * 9 + cand], (unsigned)hadamard8_lds(s_cur, 4 * by4, bx4, ps.base + (size_t)r, ps.pitch));
+      }
+    }
+    // values computed for another pair (or, after the items were dealt out, for any pair) are added up here
+    const bool pick = act && !t8 && (spread || leader != t);
+    if (__syncthreads_or(pick)) {                             // workgroup-uniform
+      if (pick)
         for (int cand = start; cand < 9; cand++) atomicAdd(&s_dist[p * 9 + cand], (unsigned)s_val[(leader * 16 + b4) * 9 + cand]);
       __syncthreads();
     }
