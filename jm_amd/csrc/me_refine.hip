@@ -243,20 +243,25 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_
         const int qx0 = ((sad ? mb_x + gx : mb_x + 4 * bx4) << 2) + mvx, qy0 = ((sad ? mb_y + gy : mb_y + 4 * by4) << 2) + mvy;
         const uint32_t inner = sad ? (uint32_t)(__mul24(4 * by4 - gy, ps.pitch) + (4 * bx4 - gx)) : 0u, pw = (uint32_t)ps.pitch;
         const uint32_t c[4] = {s_cur[(4 * by4) * 4 + bx4], s_cur[(4 * by4 + 1) * 4 + bx4], s_cur[(4 * by4 + 2) * 4 + bx4], s_cur[(4 * by4 + 3) * 4 + bx4]};
-        uint32_t rr[9][4];
+        // three candidates at a time (12 rows in flight): this path runs when most pairs lead themselves, and the registers of all nine
+        // candidates' rows would halve the number of workgroups a compute unit holds
 #pragma unroll
-        for (int cand = 0; cand < 9; cand++)
-          if (cand >= start) {
-            const uint32_t r = umv_off2(ps, qy0 + sp9_dy(cand) * step, qx0 + sp9_dx(cand) * step) + inner;
-            rr[cand][0] = ld4o(ps.base, r); rr[cand][1] = ld4o(ps.base, r + pw); rr[cand][2] = ld4o(ps.base, r + 2 * pw); rr[cand][3] = ld4o(ps.base, r + 3 * pw);
-          }
+        for (int c0 = 0; c0 < 9; c0 += 3) {
+          uint32_t rr[3][4];
 #pragma unroll
-        for (int cand = 0; cand < 9; cand++)
-          if (cand >= start) {
-            const unsigned d = (unsigned)(sad ? sad4_rows(c, rr[cand]) : hadamard4_rows(c, rr[cand]));
-            s_val[pair * 9 + cand] = (uint16_t)d;
-            atomicAdd(&s_dist[p * 9 + cand], d);
-          }
+          for (int k = 0; k < 3; k++)
+            if (c0 + k >= start) {
+              const uint32_t r = umv_off2(ps, qy0 + sp9_dy(c0 + k) * step, qx0 + sp9_dx(c0 + k) * step) + inner;
+              rr[k][0] = ld4o(ps.base, r); rr[k][1] = ld4o(ps.base, r + pw); rr[k][2] = ld4o(ps.base, r + 2 * pw); rr[k][3] = ld4o(ps.base, r + 3 * pw);
+            }
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+            if (c0 + k >= start) {
+              const unsigned d = (unsigned)(sad ? sad4_rows(c, rr[k]) : hadamard4_rows(c, rr[k]));
+              s_val[pair * 9 + c0 + k] = (uint16_t)d;
+              atomicAdd(&s_dist[p * 9 + c0 + k], d);
+            }
+        }
       }
     }
     if (T8MODE && act && t8 && !((bx4 | by4) & 1)) {                              // the top-left 4x4 leads its 8x8 block
