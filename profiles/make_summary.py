@@ -22,15 +22,15 @@ for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         t[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]))
     for k, v in t.items():
         acc[k][c] = sum(v) / len(v)
-alg = {"k_me_fs_fast": 56.99, "k_subplanes": 2.09 + 35.81, "k_tq_luma4x4": 130560 * 136 / 1e6,
+alg = {"k_mb16_recon_luma": 8160 * (256 + 256 + 256 + 16 * 104) / 1e6, "k_me_fs_fast": 56.99, "k_subplanes": 2.09 + 35.81, "k_tq_luma4x4": 130560 * 136 / 1e6,
        "k_deblock_rows": 2 * 1.5 * 1920 * 1088 / 1e6 + 8160 * 192 / 1e6, "k_me_refine_mb": 278.0}
-for k in ("k_me_fs_fast", "k_me_refine_mb", "k_subplanes", "k_mc_mb16", "k_tq_luma4x4", "k_tq_rec_to_plane", "k_mc_mb16_chroma", "k_tq_chroma", "k_tqc_rec_to_planes",
+for k in ("k_me_fs_fast", "k_me_refine_mb", "k_subplanes", "k_copy_chroma_planes", "k_mb16_recon_luma", "k_mc_mb16", "k_tq_luma4x4", "k_tq_rec_to_plane", "k_mc_mb16_chroma", "k_tq_chroma", "k_tqc_rec_to_planes",
           "k_deblock_prep", "k_deblock_tasks", "k_deblock_sparse", "k_deblock_rows"):
     f, w = acc[k].get("FETCH_SIZE", 0), acc[k].get("WRITE_SIZE", 0)
     out.append(f"| `{k}` | {f:.0f} | {2*f*1024/1e6:.2f} | {w:.0f} | {(2*f+w)*1024/1e6:.2f} | {round(alg[k],2) if k in alg else ''} |")
 tb = lambda k: (2 * acc[k].get("FETCH_SIZE", 0) + acc[k].get("WRITE_SIZE", 0)) * 1024
-print("TRAFFIC_BYTES =", [round(tb("k_subplanes")), round(tb("k_me_fs_fast") + tb("k_me_fullsearch")), round(tb("k_me_refine_mb")),
-                          round(sum(tb(k) for k in ("k_mc_mb16", "k_tq_luma4x4", "k_tq_rec_to_plane", "k_mc_mb16_chroma", "k_tq_chroma", "k_tqc_rec_to_planes"))),
+print("TRAFFIC_BYTES =", [round(tb("k_subplanes") + tb("k_copy_chroma_planes")), round(tb("k_me_fs_fast") + tb("k_me_fullsearch")), round(tb("k_me_refine_mb")),
+                          round(sum(tb(k) for k in ("k_mb16_recon_luma", "k_mc_mb16", "k_tq_luma4x4", "k_tq_rec_to_plane", "k_mc_mb16_chroma", "k_tq_chroma", "k_tqc_rec_to_planes"))),
                           round(tb("k_deblock_prep") + tb("k_deblock_tasks") + tb("k_deblock_sparse") + tb("k_deblock_rows"))])
 open(f"profiles/{tag}_kernel_stats.md", "w").write("\n".join(out) + "\n")
 shutil.copy(f"{O}/bench.json", f"profiles/{tag}_bench.json")
