@@ -144,7 +144,7 @@ __device__ __forceinline__ int part_of(int t, int bx4, int by4)
 
 // T8MODE: prm.transform8x8_mode != 0 (the Hadamard 8x8 path costs ~64 VGPRs; without it the kernel runs at full occupancy)
 template <bool T8MODE>
-__global__ __launch_bounds__(REFINE_THREADS) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
+__global__ __launch_bounds__(REFINE_THREADS, T8MODE ? 3 : 6) void k_me_refine_mb(const jmhip_me_job *__restrict__ jobs, const jmhip_me_result *__restrict__ ires,
                                                                  jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
                                                                  PlaneSet2 ps, const uint8_t *__restrict__ cur, int cur_pitch, int njobs)
 {
