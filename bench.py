@@ -38,9 +38,9 @@ W, H_SRC, H = 1920, 1080, 1088
 R = 32
 QP = 28
 # HBM bytes per launch, per stage (K5, K1-K3, K4, K7/K8, K9/K10): 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
-# MI355X_MICROARCH.md prescribes (profiles/r01_v12_kernel_stats.md).  The full search moves far less than its algorithmic 57.0 MB: neighbouring windows overlap
+# MI355X_MICROARCH.md prescribes (profiles/r01_v13_kernel_stats.md).  The full search moves far less than its algorithmic 57.0 MB: neighbouring windows overlap
 # and, with the XCD-aware job order, meet in the same L2
-TRAFFIC_BYTES = [44923328, 12324032, 45365304, 57171712, 9901856]
+TRAFFIC_BYTES = [44921952, 12328672, 84850992, 57237008, 9934464]
 MAX_VMV = 512       # level-4/5.1 vertical MV limit in pels (lencod/src/conformance.c:604-631): a search centre can sit this far away
 
 
@@ -336,7 +336,7 @@ def main():
 
     if rank == 0:
         total_mb = nmb * N * args.steps
-        # algorithmic bytes per launch and HBM traffic per launch from the PMC passes (profiles/r01_v12_kernel_stats.md)
+        # algorithmic bytes per launch and HBM traffic per launch from the PMC passes (profiles/r01_v13_kernel_stats.md)
         alg = [W * H + 16 * (W + 64) * (HL + 40),                               # K5: one plane in, 16 padded planes out
                (256 + (2 * R + 16) ** 2 + 328) * nmb,                           # K1-K3: SURVEY.md 8d per MB-reference: 6656 in + 328 out at R=32
                7 * 256 * 19 * nmb,                                              # K4: 18 candidate blocks + the current block, 7 block types

@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01l; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01m; rm -rf $O; mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err
