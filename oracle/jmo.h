@@ -240,6 +240,58 @@ void jmo_deblock_frame(jmo_pel *imgY, int pitchY, jmo_pel *imgU, jmo_pel *imgV, 
 void jmo_deblock_strength(uint8_t str[16], int dir, int edge, int mb_addr, int mb_w,
                           const jmo_db_mb *mbs, const jmo_db_motion *motion);
 
+/* ---- the RDO-off macroblock pipeline: encode_one_macroblock_low lencod/src/md_low.c:104 and everything it calls (see jmo_mbenc.c) ---- */
+#define JMO_MAX_REF 16
+typedef struct {
+  int32_t width, height;        /* coded luma size (multiples of 16) */
+  int32_t slice_type;           /* 0 P, 2 I (SliceType, lcommon/inc/types.h) */
+  int32_t first_mb, num_mb;     /* the slice: macroblocks [first_mb, first_mb + num_mb) in raster order */
+  int32_t qp, qpc;              /* currMB->qp, currMB->qpc[0] (= qpc[1]) */
+  int32_t search_range;         /* SearchRange (full-pel) */
+  int32_t num_ref;              /* currSlice->listXsize[LIST_0] */
+  int32_t lambda_mf[3];         /* p_Vid->lambda_mf[slice_type][qp][F_PEL, H_PEL, Q_PEL] */
+  int32_t lambda_mdfp;          /* LAMBDA_FACTOR(p_Vid->lambda_md[slice_type][qp]) */
+  int32_t max_mvd;              /* p_Vid->max_mvd, mv_search.c:327 */
+  int32_t mv_limit[4];          /* MaxHmvR[4], MaxHmvR[5], MaxVmvR[4], MaxVmvR[5] (quarter-pel limits of the level, conformance.c:604) */
+  int32_t inter_valid[8];       /* InterSearch[0][0][mode] */
+  int32_t intra4_valid, intra16_valid;   /* enc_mb.valid[I4MB], [I16MB] (mode_decision.c:127-131) */
+  int32_t subpel;               /* !DisableSubpelME */
+  int32_t q_offset[2];          /* quantiser offset (of 2048) of inter / intra blocks in this slice type: 342 / 682 in I, 342 / 342 in P slices (q_offsets.c:633-711 with the default lists) */
+  int32_t start_qp;             /* p_Vid->start_me_refinement_qp (mv_search.c:446); start_me_refinement_hp must be 0 */
+  int32_t refbits[JMO_MAX_REF]; /* p_Vid->refbits, mv_search.c:376-385 */
+} jmo_mbenc_cfg;
+
+/* What encode_one_macroblock_low leaves behind for write_macroblock (lencod/src/macroblock.c:2810), one record per macroblock. */
+typedef struct {
+  int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB (MBModeTypes) */
+  int8_t   i16mode;             /* currMB->i16mode as find_sad_16x16 left it */
+  int8_t   c_ipred_mode;        /* currMB->c_ipred_mode as rdo_low_intra_chroma_decision left it (written for intra macroblocks only) */
+  int8_t   pad0;
+  int16_t  cbp;                 /* currMB->cbp */
+  int16_t  pad1;
+  uint64_t cbp_blk;             /* currMB->cbp_blk */
+  int64_t  min_rdcost;          /* currMB->min_rdcost */
+  int8_t   b8mode[4];           /* currMB->b8x8[k].mode */
+  int8_t   b8ref[4];            /* reference index of each 8x8 block, -1 intra */
+  int8_t   ipredmode[16];       /* p_Vid->ipredmode, 4x4 raster */
+  int8_t   ipred_syntax[16];    /* currMB->intra_pred_modes[4 * b8 + b4] */
+  int16_t  mv[16][2];           /* enc_picture->mv_info[..].mv[LIST_0], 4x4 raster */
+  int16_t  luma[16][16];        /* quantised levels in zig-zag scan order, block 4 * b8 + b4 (cofAC order); Intra16x16: AC levels at [1..15] */
+  int16_t  luma_dc[16];         /* Intra16x16 DC levels, scan order */
+  int16_t  chroma_dc[2][4];
+  int16_t  chroma_ac[2][4][16]; /* [uv][b4][1..15] */
+} jmo_mb_record;                /* 944 bytes */
+
+typedef struct {                /* intermediate values, for localising a divergence (tests only) */
+  int64_t motion_cost[8][4];    /* p_Vid->motion_cost[mode][LIST_0][0][block] */
+  int16_t all_mv[8][16][2];     /* currSlice->all_mv[LIST_0][0][mode][by][bx] */
+  int32_t best_mode, pad;
+} jmo_mb_debug;
+
+int jmo_encode_slice(const jmo_mbenc_cfg *cfg, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
+                     const jmo_refpic *refs, const jmo_pel *const *refc, jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v,
+                     int16_t *mv, int8_t *ref_idx, int8_t *ipredmode, jmo_mb_record *out, jmo_mb_debug *dbg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,3 +430,84 @@ def sub_images_chroma(plane, yuv):
     out = np.zeros((ny, 8, h + 2 * pad_y, w + 2 * pad_x), np.uint16)
     L.jmo_sub_images_chroma(_p(p), w, w, h, int(yuv), _p(out))
     return out.astype(np.uint8)
+
+
+# ---- the RDO-off macroblock pipeline (jmo_mbenc.c) ----
+MAX_REF = 16
+
+
+class MbEncCfg(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("slice_type", C.c_int32), ("first_mb", C.c_int32), ("num_mb", C.c_int32),
+                ("qp", C.c_int32), ("qpc", C.c_int32), ("search_range", C.c_int32), ("num_ref", C.c_int32), ("lambda_mf", C.c_int32 * 3),
+                ("lambda_mdfp", C.c_int32), ("max_mvd", C.c_int32), ("mv_limit", C.c_int32 * 4), ("inter_valid", C.c_int32 * 8),
+                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF)]
+
+
+MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("pad0", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
+                      ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
+                      ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
+                      ("chroma_dc", "<i2", (2, 4)), ("chroma_ac", "<i2", (2, 4, 16))])
+MB_DEBUG = np.dtype([("motion_cost", "<i8", (8, 4)), ("all_mv", "<i2", (8, 16, 2)), ("best_mode", "<i4"), ("pad", "<i4")])
+assert MB_RECORD.itemsize == 944
+
+
+def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
+              subpel=1):
+    c = MbEncCfg()
+    c.width, c.height, c.slice_type, c.first_mb, c.num_mb = width, height, slice_type, first_mb, num_mb
+    c.qp = qp
+    c.qpc = qp if qp < 30 else [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39][qp - 30]
+    c.search_range, c.num_ref = R, num_ref
+    for i in range(3):
+        c.lambda_mf[i] = lambda_mf[i]
+    c.lambda_mdfp = lambda_mdfp
+    max_mv_bits = 3 + 2 * int(np.ceil(np.log2(4 * (2 * R + 3) + 1) + 1e-10))
+    c.max_mvd = (1 << (max_mv_bits >> 1)) - 1
+    for i in range(4):
+        c.mv_limit[i] = level_mv[i]
+    for m in range(8):
+        c.inter_valid[m] = 1
+    c.intra4_valid = c.intra16_valid = 1
+    c.subpel = subpel
+    c.start_qp = 1
+    c.q_offset[0] = 342
+    c.q_offset[1] = 682 if slice_type == 2 else 342
+    c.refbits[0] = 1
+    bits = 3
+    while True:
+        i_max = (1 << ((bits >> 1) + 1)) - 1
+        i_min = i_max >> 1
+        for i in range(i_min, min(i_max, MAX_REF)):
+            c.refbits[i] = bits
+        if i_max >= MAX_REF:
+            break
+        bits += 2
+    return c
+
+
+class Picture:
+    """Per-picture state the slices of a picture share: reconstruction, mv_info, ipredmode."""
+
+    def __init__(self, width, height):
+        self.w, self.h = width, height
+        self.rec = [np.zeros((height, width), np.uint16), np.zeros((height // 2, width // 2), np.uint16), np.zeros((height // 2, width // 2), np.uint16)]
+        self.mv = np.zeros((height // 4, width // 4, 2), np.int16)
+        self.ref_idx = np.full((height // 4, width // 4), -1, np.int8)
+        self.ipredmode = np.full((height // 4, width // 4), 2, np.int8)
+
+
+def encode_slice(cfg, cur, refs, refc, pic, debug=False):
+    """cur: (y, u, v) uint16 planes at the coded size; refs: list of RefPic; refc: list of (u, v) uint16 chroma planes per reference."""
+    cy, cu, cv = [np.ascontiguousarray(p, np.uint16) for p in cur]
+    n = cfg.num_mb
+    out = np.zeros(n, MB_RECORD)
+    dbg = np.zeros(n, MB_DEBUG) if debug else None
+    RA = RefPicS * max(1, len(refs))
+    ra = RA(*[r.s for r in refs]) if refs else RA()
+    keep = [np.ascontiguousarray(p, np.uint16) for pair in refc for p in pair]
+    PA = C.c_void_p * max(1, len(keep))
+    pa = PA(*[k.ctypes.data for k in keep]) if keep else PA()
+    r = L.jmo_encode_slice(C.byref(cfg), _p(cy), _p(cu), _p(cv), ra, pa, _p(pic.rec[0]), _p(pic.rec[1]), _p(pic.rec[2]),
+                           _p(pic.mv), _p(pic.ref_idx), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
+    assert r == 0, r
+    return (out, dbg) if debug else out

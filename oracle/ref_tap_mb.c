@@ -1,0 +1,119 @@
+/*
+ * oracle/ref_tap_mb.c -- TEST INFRASTRUCTURE: a tap on the REAL reference encoder's macroblock mode decision.
+ *
+ * Linked (oracle/Makefile.ref, target `tapmb`) with the unmodified JM 19.0 lencod objects using GNU ld's --wrap, it lets the
+ * reference's own encode_one_macroblock_low (lencod/src/md_low.c:104) run and then dumps what that call left behind for
+ * write_macroblock (lencod/src/macroblock.c:2810): macroblock type, sub-modes, vectors, reference indices, coded block pattern,
+ * intra modes, the coefficient (level, run) lists and the reconstructed samples -- plus the motion costs of every searched
+ * partition, which localise a divergence to one search.  tests/golden/make_mb_golden.py turns the dump into the committed
+ * fixtures that pin oracle/jmo_mbenc.c.
+ *
+ * Own code against JM's public headers; no reference source.  Builds only where /root/reference is present, only into oracle/_ref/.
+ * Output: $JM_TAP_DIR/mb_low.bin (default "."), fixed-size little-endian records (layout: MBREC below, mirrored in make_mb_golden.py).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "global.h"
+#include "image.h"
+#include "mbuffer.h"
+#include "mv_search.h"
+#include "macroblock.h"
+
+#pragma pack(push, 1)
+typedef struct {
+  int32_t frame_no, mb_addr, slice_type, slice_nr;
+  int32_t best_mode, mb_type, cbp, c_ipred_mode, i16mode, i16offset, transform8x8, qp;
+  int32_t lambda_mf[3], lambda_mdfp, num_ref, max_mvd, mv_limit[4], qpc, search_range;   /* the slice's parameters, repeated per record */
+  int64_t cbp_blk, min_rdcost;
+  int8_t  b8mode[4], b8pdir[4];
+  int8_t  ipred_syntax[16];                 /* currMB->intra_pred_modes[4*b8+b4] */
+  int8_t  ipredmode[16];                    /* p_Vid->ipredmode, 4x4 raster */
+  int16_t mv[16][2];                        /* enc_picture->mv_info[..].mv[LIST_0], 4x4 raster */
+  int8_t  ref_idx[16];
+  int64_t motion_cost[8][4];                /* p_Vid->motion_cost[mode][LIST_0][0][block] (reference 0) */
+  int16_t all_mv[8][16][2];                 /* currSlice->all_mv[LIST_0][0][mode][by][bx] */
+  int32_t luma_level[16][17], luma_run[16][17];      /* cofAC[b8][b4][0/1][k], b = 4*b8+b4 */
+  int32_t dc_level[3][18], dc_run[3][18];            /* cofDC[pl][0/1][k] */
+  int32_t chroma_level[8][17], chroma_run[8][17];    /* cofAC[4 + uv*2.. ][b4] for 4:2:0: b8 = 4, 5 hold U, V? see make_mb_golden.py */
+  uint8_t rec_y[256], rec_u[64], rec_v[64];
+} MBREC;
+#pragma pack(pop)
+
+extern void __real_encode_one_macroblock_low(Macroblock *currMB);
+void __wrap_encode_one_macroblock_low(Macroblock *currMB)
+{
+  static FILE *f = NULL;
+  static int n = 0, maxn = -1;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  Slice *currSlice = currMB->p_Slice;
+  PicMotionParams **motion = p_Vid->enc_picture->mv_info;
+  MBREC r;
+  int i, j, k, b8, b4, m;
+
+  __real_encode_one_macroblock_low(currMB);
+
+  if (maxn < 0) { const char *e = getenv("JM_TAPMB_MAX"); maxn = e ? atoi(e) : 1 << 30; }
+  if (n >= maxn) return;
+  if (!f) {
+    char path[1024];
+    const char *d = getenv("JM_TAP_DIR");
+    snprintf(path, sizeof path, "%s/mb_low.bin", d ? d : ".");
+    f = fopen(path, "wb");
+    if (!f) { perror(path); exit(3); }
+  }
+  memset(&r, 0, sizeof r);
+  r.frame_no = p_Vid->frame_no; r.mb_addr = currMB->mbAddrX; r.slice_type = currSlice->slice_type; r.slice_nr = currMB->slice_nr;
+  r.best_mode = currMB->best_mode; r.mb_type = currMB->mb_type; r.cbp = currMB->cbp; r.c_ipred_mode = currMB->c_ipred_mode;
+  r.i16mode = currMB->i16mode; r.i16offset = currMB->i16offset; r.transform8x8 = currMB->luma_transform_size_8x8_flag; r.qp = currMB->qp;
+  r.cbp_blk = currMB->cbp_blk; r.min_rdcost = currMB->min_rdcost;
+  for (i = 0; i < 3; i++) r.lambda_mf[i] = p_Vid->lambda_mf[currSlice->slice_type][p_Vid->masterQP][i];
+  r.lambda_mdfp = LAMBDA_FACTOR(p_Vid->lambda_md[currSlice->slice_type][p_Vid->masterQP]);
+  r.num_ref = currSlice->listXsize[LIST_0]; r.max_mvd = p_Vid->max_mvd; r.qpc = currMB->qpc[0]; r.search_range = p_Vid->searchRange.max_x >> 2;
+  r.mv_limit[0] = p_Vid->MaxHmvR[4]; r.mv_limit[1] = p_Vid->MaxHmvR[5]; r.mv_limit[2] = p_Vid->MaxVmvR[4]; r.mv_limit[3] = p_Vid->MaxVmvR[5];
+  for (i = 0; i < 4; i++) { r.b8mode[i] = currMB->b8x8[i].mode; r.b8pdir[i] = currMB->b8x8[i].pdir; }
+  memcpy(r.ipred_syntax, currMB->intra_pred_modes, 16);
+  for (j = 0; j < 4; j++)
+    for (i = 0; i < 4; i++) {
+      PicMotionParams *mp = &motion[currMB->block_y + j][currMB->block_x + i];
+      r.ipredmode[j * 4 + i] = p_Vid->ipredmode[currMB->block_y + j][currMB->block_x + i];
+      r.mv[j * 4 + i][0] = mp->mv[LIST_0].mv_x; r.mv[j * 4 + i][1] = mp->mv[LIST_0].mv_y;
+      r.ref_idx[j * 4 + i] = mp->ref_idx[LIST_0];
+    }
+  if (currSlice->slice_type != I_SLICE) {
+    for (m = 1; m < 8; m++) {
+      for (k = 0; k < 4; k++) r.motion_cost[m][k] = p_Vid->motion_cost[m][LIST_0][0][k];
+      for (j = 0; j < 4; j++)
+        for (i = 0; i < 4; i++) {
+          r.all_mv[m][j * 4 + i][0] = currSlice->all_mv[LIST_0][0][m][j][i].mv_x;
+          r.all_mv[m][j * 4 + i][1] = currSlice->all_mv[LIST_0][0][m][j][i].mv_y;
+        }
+    }
+  }
+  for (b8 = 0; b8 < 4; b8++)
+    for (b4 = 0; b4 < 4; b4++)
+      for (k = 0; k < 17; k++) {
+        r.luma_level[b8 * 4 + b4][k] = currSlice->cofAC[b8][b4][0][k];
+        r.luma_run[b8 * 4 + b4][k] = currSlice->cofAC[b8][b4][1][k];
+      }
+  for (m = 0; m < 3; m++)
+    for (k = 0; k < 18; k++) { r.dc_level[m][k] = currSlice->cofDC[m][0][k]; r.dc_run[m][k] = currSlice->cofDC[m][1][k]; }
+  if (p_Vid->yuv_format == YUV420)
+    for (b8 = 4; b8 < 6; b8++)                   /* 4:2:0: cofAC[4] = U, cofAC[5] = V (block.c:1107 `b8 = 4 + uv`) */
+      for (b4 = 0; b4 < 4; b4++)
+        for (k = 0; k < 17; k++) {
+          r.chroma_level[(b8 - 4) * 4 + b4][k] = currSlice->cofAC[b8][b4][0][k];
+          r.chroma_run[(b8 - 4) * 4 + b4][k] = currSlice->cofAC[b8][b4][1][k];
+        }
+  for (j = 0; j < 16; j++)
+    for (i = 0; i < 16; i++) r.rec_y[j * 16 + i] = (uint8_t)p_Vid->enc_picture->imgY[currMB->pix_y + j][currMB->pix_x + i];
+  if (p_Vid->yuv_format == YUV420)
+    for (j = 0; j < 8; j++)
+      for (i = 0; i < 8; i++) {
+        r.rec_u[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[0][currMB->pix_c_y + j][currMB->pix_c_x + i];
+        r.rec_v[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[1][currMB->pix_c_y + j][currMB->pix_c_x + i];
+      }
+  fwrite(&r, sizeof r, 1, f);
+  fflush(f);
+  n++;
+}

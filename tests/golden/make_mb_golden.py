@@ -1,0 +1,87 @@
+"""Regenerates tests/golden/mb_low_*.npz: what the REAL reference encoder's encode_one_macroblock_low (lencod/src/md_low.c:104) leaves behind per
+macroblock, for the configurations the RDO-off macroblock pipeline is pinned on.  TEST INFRASTRUCTURE; needs /root/reference (oracle/Makefile.ref,
+target `tapmb`, builds oracle/_ref/lencod_tapmb.exe from the unmodified lencod objects + oracle/ref_tap_mb.c).
+
+  python tests/golden/make_mb_golden.py
+
+Per configuration: canonical macroblock records of every picture (tests/golden/mb_tap.py), the slice parameters the encoder used (lambda tables come
+from its double arithmetic and are inputs, never recomputed), md5 of the bitstream and of the reconstruction file, and the md5 of every picture's
+reconstruction before the loop filter (assembled from the per-macroblock samples)."""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+G = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(G))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, G)
+import mb_tap  # noqa: E402
+
+EXE = os.path.join(ROOT, "oracle", "_ref", "lencod_tapmb.exe")
+RDO_OFF = {"RDOptimization": "0", "AdaptiveRounding": "0"}
+SYN1080 = {"InputFile": "syn1080p.yuv", "SourceWidth": "1920", "SourceHeight": "1080", "OutputWidth": "1920", "OutputHeight": "1080",
+           "FramesToBeEncoded": "2", "SearchMode": "-1", "SearchRange": "32", "NumberReferenceFrames": "1", "LevelIDC": "51"}
+CASES = {
+    # tag: (overrides on tests/golden/jm_baseline.cfg, source size, frames, synthetic clip?)
+    "q1r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1"), (176, 144), 3, False),
+    "q5r": (dict(RDO_OFF, SearchMode="-1", SearchRange="32"), (176, 144), 3, False),                      # five references
+    "q4r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", SliceMode="1", SliceArgument="33"), (176, 144), 3, False),
+    "q4s": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", SliceMode="1", SliceArgument="40", NumberReferenceFrames="2", DFParametersFlag="1",
+                 DFDisableRefISlice="2", DFDisableNRefISlice="2", DFDisableRefPSlice="2", DFDisableNRefPSlice="2"), (176, 144), 3, False),
+    "g2r": (dict(RDO_OFF, **SYN1080), (1920, 1080), 2, True),                                          # SURVEY 8c G2r = BASELINE configs[1], RDO off
+}
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def run(tag):
+    ov, (sw, sh), nfr, syn = CASES[tag]
+    W, H = (sw + 15) // 16 * 16, (sh + 15) // 16 * 16
+    tmp = tempfile.mkdtemp(prefix="mbgold_")
+    try:
+        for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
+            shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
+        if syn:
+            import bench
+            bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), nfr)
+        args = [EXE, "-d", os.path.join(G, "jm_baseline.cfg")]
+        for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
+            args += ["-p", f"{k}={v}"]
+        subprocess.run(args, cwd=tmp, env=dict(os.environ, JM_TAP_DIR=tmp), check=True, stdout=subprocess.DEVNULL)
+        tap = mb_tap.read(os.path.join(tmp, "mb_low.bin"))
+        nmb = (W // 16) * (H // 16)
+        assert len(tap) == nmb * nfr, (len(tap), nmb, nfr)
+        pre = []
+        for n in range(nfr):
+            T = tap[n * nmb:(n + 1) * nmb]
+            y = T["rec_y"].reshape(H // 16, W // 16, 16, 16).transpose(0, 2, 1, 3).reshape(H, W)
+            u = T["rec_u"].reshape(H // 16, W // 16, 8, 8).transpose(0, 2, 1, 3).reshape(H // 2, W // 2)
+            v = T["rec_v"].reshape(H // 16, W // 16, 8, 8).transpose(0, 2, 1, 3).reshape(H // 2, W // 2)
+            pre.append([md5(np.ascontiguousarray(p).tobytes()) for p in (y, u, v)])
+        t0 = tap[0]
+        lam = {int(t["slice_type"]): list(t["lambda_mf"]) + [int(t["lambda_mdfp"])] for t in tap[::nmb]}
+        np.savez_compressed(os.path.join(G, f"mb_low_{tag}.npz"),
+                            records=mb_tap.tap_to_records(tap), slice_type=tap["slice_type"][::nmb].astype(np.int32), slice_nr=tap["slice_nr"].astype(np.int16),
+                            lambda_i=np.array(lam.get(2, [0, 0, 0, 0]), np.int32), lambda_p=np.array(lam.get(0, [0, 0, 0, 0]), np.int32),
+                            qp=int(t0["qp"]), qpc=int(t0["qpc"]), search_range=int(t0["search_range"]), max_mvd=int(t0["max_mvd"]),
+                            mv_limit=t0["mv_limit"].astype(np.int32), num_ref=int(tap["num_ref"].max()), size=np.array([sw, sh, W, H], np.int32),
+                            motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if tag != "g2r" else np.zeros(0, np.int64),
+                            md5_264=md5(open(os.path.join(tmp, "o.264"), "rb").read()), md5_recon=md5(open(os.path.join(tmp, "o_rec.yuv"), "rb").read()),
+                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())))
+        print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-f", os.path.join(ROOT, "oracle", "Makefile.ref"), "all", "tapmb"])
+    for tag in (sys.argv[1:] or CASES):
+        run(tag)

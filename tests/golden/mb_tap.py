@@ -1,0 +1,167 @@
+"""Reader of oracle/ref_tap_mb.c's dump (mb_low.bin) and helpers shared by make_mb_golden.py and the tests: TEST INFRASTRUCTURE.
+
+The dump is what the REAL reference encoder's encode_one_macroblock_low left behind per macroblock; `to_records` turns it into the
+record layout of the product ABI / the oracle (jmhip_mb_record = jmo_mb_record, 944 bytes) so the three can be compared field by field."""
+import numpy as np
+
+TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), ("slice_nr", "<i4"),
+                ("best_mode", "<i4"), ("mb_type", "<i4"), ("cbp", "<i4"), ("c_ipred_mode", "<i4"), ("i16mode", "<i4"), ("i16offset", "<i4"),
+                ("transform8x8", "<i4"), ("qp", "<i4"),
+                ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("num_ref", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
+                ("qpc", "<i4"), ("search_range", "<i4"),
+                ("cbp_blk", "<i8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8pdir", "i1", (4,)),
+                ("ipred_syntax", "i1", (16,)), ("ipredmode", "i1", (16,)), ("mv", "<i2", (16, 2)), ("ref_idx", "i1", (16,)),
+                ("motion_cost", "<i8", (8, 4)), ("all_mv", "<i2", (8, 16, 2)),
+                ("luma_level", "<i4", (16, 17)), ("luma_run", "<i4", (16, 17)), ("dc_level", "<i4", (3, 18)), ("dc_run", "<i4", (3, 18)),
+                ("chroma_level", "<i4", (8, 17)), ("chroma_run", "<i4", (8, 17)),
+                ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,))])
+
+
+def read(path):
+    return np.fromfile(path, TAP)
+
+
+def dense(level, run, start, n=16):
+    """(level, run) list of JM (zero terminated) -> levels at their scan positions."""
+    out = np.zeros(n, np.int16)
+    pos = start
+    for lv, rn in zip(level, run):
+        if lv == 0:
+            break
+        pos += int(rn)
+        out[pos] = lv
+        pos += 1
+    return out
+
+
+def expected_coeffs(t):
+    """The coefficient arrays write_macroblock would read for tap record t, in the record layout; blocks the coded block pattern hides are zero."""
+    luma = np.zeros((16, 16), np.int16)
+    luma_dc = np.zeros(16, np.int16)
+    cdc = np.zeros((2, 4), np.int16)
+    cac = np.zeros((2, 4, 16), np.int16)
+    mbt, cbp = int(t["mb_type"]), int(t["cbp"])
+    if mbt == 10:
+        luma_dc = dense(t["dc_level"][0], t["dc_run"][0], 0)
+    for b8 in range(4):
+        if cbp & (1 << b8):
+            for b4 in range(4):
+                luma[4 * b8 + b4] = dense(t["luma_level"][4 * b8 + b4], t["luma_run"][4 * b8 + b4], 1 if mbt == 10 else 0)
+    if cbp > 15:
+        for uv in range(2):
+            cdc[uv] = dense(t["dc_level"][1 + uv], t["dc_run"][1 + uv], 0, 4)
+    if cbp >> 4 == 2:
+        for uv in range(2):
+            for b4 in range(4):
+                cac[uv][b4] = dense(t["chroma_level"][4 * uv + b4], t["chroma_run"][4 * uv + b4], 1)
+    return luma, luma_dc, cdc, cac
+
+
+def visible_coeffs(r):
+    """The same view of an oracle / device record: coefficients masked by the record's own coded block pattern."""
+    luma = np.array(r["luma"]).copy()
+    luma_dc = np.array(r["luma_dc"]).copy()
+    cdc = np.array(r["chroma_dc"]).copy()
+    cac = np.array(r["chroma_ac"]).copy()
+    mbt, cbp = int(r["mb_type"]), int(r["cbp"])
+    for b8 in range(4):
+        if not cbp & (1 << b8):
+            luma[4 * b8:4 * b8 + 4] = 0
+    if mbt != 10:
+        luma_dc[:] = 0
+    if cbp <= 15:
+        cdc[:] = 0
+    if cbp >> 4 != 2:
+        cac[:] = 0
+    return luma, luma_dc, cdc, cac
+
+
+def compare(t, r, rec_mb=None):
+    """List of differences between tap record t (the reference) and record r; empty when they agree on everything write_macroblock reads."""
+    d = []
+    mbt = int(t["mb_type"])
+    for k in ("mb_type", "cbp"):
+        if int(t[k]) != int(r[k]):
+            d.append((k, int(t[k]), int(r[k])))
+    if mbt in (1, 2, 3, 8):
+        if not np.array_equal(t["mv"], r["mv"]):
+            d.append(("mv", t["mv"].tolist(), np.array(r["mv"]).tolist()))
+        ref8 = [int(t["ref_idx"][j * 8 + i * 2]) for j in range(2) for i in range(2)]
+        if ref8 != [int(x) for x in r["b8ref"]]:
+            d.append(("ref", ref8, [int(x) for x in r["b8ref"]]))
+    if mbt == 8 and not np.array_equal(t["b8mode"], r["b8mode"]):
+        d.append(("b8mode", t["b8mode"].tolist(), np.array(r["b8mode"]).tolist()))
+    if mbt == 9 and not np.array_equal(t["ipred_syntax"], r["ipred_syntax"]):
+        d.append(("ipred", t["ipred_syntax"].tolist(), np.array(r["ipred_syntax"]).tolist()))
+    if mbt == 10 and int(t["i16mode"]) != int(r["i16mode"]):
+        d.append(("i16mode", int(t["i16mode"]), int(r["i16mode"])))
+    if mbt >= 9 and int(t["c_ipred_mode"]) != int(r["c_ipred_mode"]):
+        d.append(("c_ipred_mode", int(t["c_ipred_mode"]), int(r["c_ipred_mode"])))
+    if int(t["mb_type"]) == int(r["mb_type"]) and int(t["cbp"]) == int(r["cbp"]):
+        for name, a, b in zip(("luma", "luma_dc", "chroma_dc", "chroma_ac"), expected_coeffs(t), visible_coeffs(r)):
+            if not np.array_equal(a, b):
+                d.append((name, a.tolist(), b.tolist()))
+    if rec_mb is not None:
+        for name, a, b in zip(("rec_y", "rec_u", "rec_v"), (t["rec_y"].reshape(16, 16), t["rec_u"].reshape(8, 8), t["rec_v"].reshape(8, 8)), rec_mb):
+            if not np.array_equal(a, b):
+                d.append((name, int(np.abs(a.astype(int) - b.astype(int)).max())))
+    return d
+
+
+# ---- canonical records: what write_macroblock / DeblockFrame can observe, in the jmhip_mb_record layout -------------------------------
+def _record_dtype():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import pyjmo
+    return pyjmo.MB_RECORD
+
+
+def canonical(recs):
+    """Normalise an array of macroblock records (oracle or device output): fields the bitstream writer and the loop filter never read for the
+    record's macroblock type are set to fixed values, coefficient arrays are masked by the coded block pattern."""
+    out = np.array(recs, copy=True)
+    for r in out:
+        mbt, cbp = int(r["mb_type"]), int(r["cbp"])
+        r["pad0"] = 0
+        r["pad1"] = 0
+        luma, luma_dc, cdc, cac = visible_coeffs(r)
+        r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = luma, luma_dc, cdc, cac
+        if mbt >= 9:
+            r["mv"] = 0
+            r["b8ref"] = -1
+            r["cbp_blk"] = 0
+        else:
+            r["c_ipred_mode"] = 0
+            r["cbp_blk"] = int(r["cbp_blk"]) & 0xFFFF
+        if mbt != 10:
+            r["i16mode"] = 0
+        if mbt != 9:
+            r["ipred_syntax"] = 2
+            r["ipredmode"] = 2
+        if mbt != 8:
+            r["b8mode"] = 11 if mbt == 9 else (0 if mbt in (0, 10) else mbt)
+        if mbt == 0:
+            r["b8ref"] = 0
+        (cbp)
+    return out
+
+
+def tap_to_records(tap):
+    """The reference encoder's dump as canonical records."""
+    out = np.zeros(len(tap), _record_dtype())
+    for t, r in zip(tap, out):
+        mbt = int(t["mb_type"])
+        r["mb_type"], r["cbp"], r["min_rdcost"] = mbt, int(t["cbp"]), int(t["min_rdcost"])
+        r["i16mode"], r["c_ipred_mode"] = int(t["i16mode"]), int(t["c_ipred_mode"])
+        r["cbp_blk"] = int(t["cbp_blk"]) & 0xFFFFFFFFFFFFFFFF
+        r["b8mode"] = t["b8mode"]
+        r["b8ref"] = [int(t["ref_idx"][j * 8 + i * 2]) for j in range(2) for i in range(2)]
+        r["ipredmode"], r["ipred_syntax"], r["mv"] = t["ipredmode"], t["ipred_syntax"], t["mv"]
+        r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = expected_coeffs(t)
+    return canonical(out)
+
+
+def diff_fields(a, b):
+    """Names of the fields in which two canonical records differ."""
+    return [n for n in a.dtype.names if not np.array_equal(a[n], b[n])]

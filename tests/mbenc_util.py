@@ -1,0 +1,91 @@
+"""TEST INFRASTRUCTURE: the oracle's sequence encoder -- oracle/jmo_mbenc.c per slice, oracle deblocking, oracle sub-pel planes -- chained
+the way lencod chains pictures (IPPP, frame pictures, sliding-window references), plus the conversion of macroblock records into the
+loop filter's side information.  Used by tests/test_oracle_mbenc.py (against the real encoder's dumps) and by the GPU parity tests
+(as the checker of jmhip_encode_slice).  Nothing here is on the product path."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyjmo  # noqa: E402
+
+
+def slices_of(nmb, slice_mbs):
+    """[(first_mb, num_mb)] for SliceMode 0 (slice_mbs = 0) or 1 (fixed number of macroblocks)."""
+    if not slice_mbs:
+        return [(0, nmb)]
+    return [(f, min(slice_mbs, nmb - f)) for f in range(0, nmb, slice_mbs)]
+
+
+def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_idc=0):
+    """records (nmb) + per-macroblock slice numbers -> (mbs (nmb, 12) in pyjmo.deblock_frame's order, motion (H/4, W/4, 2, 3)).
+    ref_ids[r] = picture identity of reference index r of this picture's list 0."""
+    wmb = W // 16
+    nmb = len(records)
+    mbs = np.zeros((nmb, 12), np.int64)
+    mot = np.zeros((H // 4, W // 4, 2, 3), np.int32)
+    mot[:, :, :, 2] = -1
+    for k in range(nmb):
+        r = records[k]
+        mbs[k] = [int(r["mb_type"]), slice_type, qp, qpc, qpc, int(r["cbp"]), int(r["cbp_blk"]) & 0xFFFF, int(slice_nr[k]), disable_idc, 0, 0, 0]
+        mbx, mby = k % wmb, k // wmb
+        if int(r["mb_type"]) < 9:
+            mv = np.array(r["mv"]).reshape(4, 4, 2)
+            mot[mby * 4:mby * 4 + 4, mbx * 4:mbx * 4 + 4, 0, 0:2] = mv
+            for b8 in range(4):
+                rid = ref_ids[int(r["b8ref"][b8])]
+                mot[mby * 4 + (b8 >> 1) * 2:mby * 4 + (b8 >> 1) * 2 + 2, mbx * 4 + (b8 & 1) * 2:mbx * 4 + (b8 & 1) * 2 + 2, 0, 2] = rid
+    return mbs, mot
+
+
+class SeqEncoder:
+    """IPPP with num_ref sliding-window references, RDOptimization = 0, AdaptiveRounding = 0 (the scope of jmo_mbenc.c)."""
+
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0):
+        """lambdas[slice_type] = (lambda_mf[3], lambda_mdfp): JM's own tables (double arithmetic, never recomputed)."""
+        self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
+        self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
+        self.refs = []         # most recent first: (RefPic, (u, v), picture id)
+        self.npic = 0
+
+    def encode(self, cur, debug=False):
+        """cur = (y, u, v) at the coded size.  Returns (records, debug records or None, reconstruction before the loop filter, after it)."""
+        W, H = self.W, self.H
+        nmb = (W // 16) * (H // 16)
+        st = 2 if self.npic == 0 else 0
+        nref = min(self.num_ref, len(self.refs)) if st == 0 else 0
+        pic = pyjmo.Picture(W, H)
+        recs = np.zeros(nmb, pyjmo.MB_RECORD)
+        dbg = np.zeros(nmb, pyjmo.MB_DEBUG) if debug else None
+        slice_nr = np.zeros(nmb, np.int32)
+        cur16 = [np.ascontiguousarray(p, np.uint16) for p in cur]
+        qpc = None
+        for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
+            lam_mf, lam_md = self.lambdas[st]
+            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv)
+            qpc = cfg.qpc
+            res = pyjmo.encode_slice(cfg, cur16, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], pic, debug=debug)
+            if debug:
+                recs[first:first + num], dbg[first:first + num] = res
+            else:
+                recs[first:first + num] = res
+            slice_nr[first:first + num] = sn
+        pre = [p.copy() for p in pic.rec]
+        mbs, mot = db_side_info(recs, slice_nr, st, self.qp, qpc, W, H, [r[2] for r in self.refs[:nref]] or [0], self.disable_idc)
+        y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], 1, mbs, mot)
+        self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic))
+        self.refs = self.refs[:self.num_ref]
+        self.npic += 1
+        return recs, dbg, pre, (y, u, v)
+
+
+def lambdas_from_tap(tap):
+    """{slice_type: (lambda_mf[3], lambda_mdfp)} as the real encoder used them (oracle/ref_tap_mb.c records)."""
+    out = {}
+    for t in tap:
+        st = int(t["slice_type"])
+        if st not in out:
+            out[st] = ([int(x) for x in t["lambda_mf"]], int(t["lambda_mdfp"]))
+    return out

@@ -1,0 +1,80 @@
+"""not gpu: oracle/jmo_mbenc.c (the CPU restatement of encode_one_macroblock_low and its callees) against the REAL reference encoder.
+
+tests/golden/mb_low_*.npz hold, per macroblock, what JM's own encode_one_macroblock_low left behind (oracle/ref_tap_mb.c on the unmodified lencod,
+tests/golden/make_mb_golden.py).  The oracle encodes the same clips picture by picture -- its own reconstruction, loop filter and sub-pel planes
+feed the next picture, as in lencod -- and every macroblock record, the per-search motion costs and every picture's reconstruction before the loop
+filter must equal the reference's.  Configurations: one reference (q1r), five references SR 32 (q5r), three slices (q4r), slices that start mid-row
+with DFDisableIdc = 2 and two references (q4s), and BASELINE configs[1] with RDO off at full size (g2r = SURVEY 8c G2r, 8160 macroblocks, slow)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, G)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mb_tap  # noqa: E402
+import mbenc_util  # noqa: E402
+from oracle import pyjmo  # noqa: E402
+
+
+def load_case(tag):
+    z = np.load(os.path.join(G, f"mb_low_{tag}.npz"))
+    ov = dict(s.split("=") for s in z["overrides"])
+    sw, sh, W, H = [int(x) for x in z["size"]]
+    lam = {2: ([int(x) for x in z["lambda_i"][:3]], int(z["lambda_i"][3])), 0: ([int(x) for x in z["lambda_p"][:3]], int(z["lambda_p"][3]))}
+    didc = int(ov.get("DFDisableRefPSlice", 0))
+    return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
+                slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]], didc=didc,
+                nfr=len(z["slice_type"]), records=z["records"])
+
+
+def source_frames(c, tag):
+    if tag == "g2r":
+        import bench
+        data = bench.synthetic_frames(c["nfr"]) if hasattr(bench, "synthetic_frames") else None
+        if data is None:
+            import tempfile
+            with tempfile.TemporaryDirectory() as t:
+                bench.write_yuv(os.path.join(t, "s.yuv"), c["nfr"])
+                data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+    else:
+        data = np.fromfile(os.path.join(G, "foreman_part_qcif.yuv"), np.uint8)
+    fs = c["sw"] * c["sh"] * 3 // 2
+    return [pyjmo.load_frame(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], c["W"], c["H"], 1) for n in range(c["nfr"])]
+
+
+def run_case(tag):
+    c = load_case(tag)
+    enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
+    nmb = (c["W"] // 16) * (c["H"] // 16)
+    z = c["z"]
+    for n, cur in enumerate(source_frames(c, tag)):
+        recs, dbg, pre, post = enc.encode(cur, debug=True)
+        want = c["records"][n * nmb:(n + 1) * nmb]
+        got = mb_tap.canonical(recs)
+        bad = [k for k in range(nmb) if got[k].tobytes() != want[k].tobytes()]
+        assert not bad, (tag, n, bad[:5], mb_tap.diff_fields(want[bad[0]], got[bad[0]]))
+        for p, m in zip(pre, z["md5_pre_deblock"][n]):
+            assert hashlib.md5(np.ascontiguousarray(p.astype(np.uint8)).tobytes()).hexdigest() == m, (tag, n, "reconstruction before the loop filter")
+        if int(z["slice_type"][n]) == 0 and z["motion_cost"].size:
+            assert np.array_equal(dbg["motion_cost"][:, 1:, :], z["motion_cost"][n * nmb:(n + 1) * nmb]), (tag, n, "motion costs")
+    return enc
+
+
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s"])
+def test_oracle_macroblock_pipeline_equals_the_reference_encoder(tag):
+    run_case(tag)
+
+
+def test_oracle_macroblock_pipeline_configs1_full_size():
+    """BASELINE configs[1] with RDOptimization = 0 (G2r): I + P picture of the synthetic 1080p clip, 16 320 macroblocks (about half a minute)."""
+    run_case("g2r")
+
+
+def test_record_layout():
+    assert pyjmo.MB_RECORD.itemsize == 944
