@@ -511,9 +511,84 @@ int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pitchY, uint8_
                             const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int32_t direct_8x8_inference);
 
 /* ------------------------------------------------------------------------------------------
+ * The RDO-off macroblock pipeline of a whole slice
+ *
+ * encode_one_macroblock_low (lencod/src/md_low.c:104-687) for every macroblock of a P or I slice, in the wavefront order x + 2y
+ * that its neighbour dependencies allow: motion vector prediction (GetMotionVectorPredictorNormal lcommon/src/mv_prediction.c:194 over
+ * get_neighbors lencod/src/mv_search.c:268), BlockMotionSearch (mv_search.c:857: full_search_motion_estimation me_fullsearch.c:39 around
+ * each block's own rounded predictor with the (0,0) bonus of the RDO-off encoder, sub_pel_motion_estimation :186, the skip vector's
+ * cost mv_search.c:983-998), list_prediction_cost (mode_decision.c:275), submacroblock_mode_decision_low (mode_decision_P8x8.c:681),
+ * mode_decision_for_I4x4_MB (rd_intra_jm.c:386, rd_intra_jm_low.c:39), find_sad_16x16_JM (intra16x16.c:463), luma_residual_coding
+ * (macroblock.c:1182) / set_coeff_and_recon_8x8_p_slice (rdopt.c:1326), rdo_low_intra_chroma_decision (intra_chroma.c:460),
+ * chroma_residual_coding (macroblock.c:1439), the skip test (md_low.c:658).  What the call leaves behind per macroblock is what
+ * write_macroblock (macroblock.c:2810) and DeblockFrame read: one jmhip_mb_record.  The host keeps the entropy coder.
+ *
+ * Scope: frame macroblocks, 4:2:0, 8 bit, 4x4 transform, no adaptive rounding / weighted prediction / rate control, SearchMode -1,
+ * unconstrained intra prediction, num_ref * window bytes within the LDS (5 references at SearchRange 32, 16 at 16); anything else
+ * returns JMHIP_EUNSUPPORTED and the caller keeps JM's own function.
+ * The source picture is the one jmhip_set_current_frame loaded; the references are slots filled by jmhip_set_reference[_chroma] or
+ * jmhip_reference_from_recon.  The reconstruction stays on the device (jmhip_recon_planes_dev), so do the records' loop-filter
+ * side information (jmhip_deblock_picture[_dev]).
+ * ------------------------------------------------------------------------------------------ */
+#define JMHIP_MB_MAX_REF 16
+typedef struct {
+  int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB (MBModeTypes, lcommon/inc/types.h) */
+  int8_t   i16mode;             /* currMB->i16mode as find_sad_16x16 left it */
+  int8_t   c_ipred_mode;        /* currMB->c_ipred_mode as rdo_low_intra_chroma_decision left it (written for intra macroblocks) */
+  int8_t   reserved0_;
+  int16_t  cbp;                 /* currMB->cbp */
+  int16_t  reserved1_;
+  uint64_t cbp_blk;             /* currMB->cbp_blk */
+  int64_t  min_rdcost;          /* currMB->min_rdcost */
+  int8_t   b8mode[4];           /* currMB->b8x8[k].mode */
+  int8_t   b8ref[4];            /* reference index of each 8x8 block (enc_picture->mv_info[..].ref_idx[LIST_0]), -1 intra */
+  int8_t   ipredmode[16];       /* p_Vid->ipredmode, 4x4 raster */
+  int8_t   ipred_syntax[16];    /* currMB->intra_pred_modes[4 * b8 + b4] */
+  int16_t  mv[16][2];           /* enc_picture->mv_info[..].mv[LIST_0], 4x4 raster */
+  int16_t  luma[16][16];        /* quantised levels in zig-zag scan order, block 4 * b8 + b4 (cofAC order); Intra16x16: AC levels at [1..15] */
+  int16_t  luma_dc[16];         /* Intra16x16 DC levels (cofDC[0]), scan order */
+  int16_t  chroma_dc[2][4];     /* cofDC[1 + uv] */
+  int16_t  chroma_ac[2][4][16]; /* cofAC[4 + uv][b4], levels at [1..15] */
+} jmhip_mb_record;              /* 944 bytes */
+
+typedef struct {
+  int32_t slice_type;           /* 0 P, 2 I */
+  int32_t first_mb, num_mb;     /* macroblocks [first_mb, first_mb + num_mb) in raster order */
+  int32_t slice_nr;             /* Macroblock.slice_nr (loop filter side information) */
+  int32_t qp, qpc;              /* currMB->qp, currMB->qpc[0] (= qpc[1]) */
+  int32_t search_range;         /* SearchRange (full-pel), <= the context's */
+  int32_t num_ref;              /* currSlice->listXsize[LIST_0] */
+  int32_t ref_slot[JMHIP_MB_MAX_REF];  /* device slot of listX[LIST_0][r] */
+  int32_t ref_id[JMHIP_MB_MAX_REF];    /* identity of that picture for the loop filter's ref_pic comparison */
+  int32_t lambda_mf[3];         /* p_Vid->lambda_mf[slice_type][qp][F_PEL, H_PEL, Q_PEL]: JM's double arithmetic, never recomputed */
+  int32_t lambda_mdfp;          /* LAMBDA_FACTOR(p_Vid->lambda_md[slice_type][qp]) */
+  int32_t max_mvd;              /* p_Vid->max_mvd (mv_search.c:327) */
+  int32_t mv_limit[4];          /* MaxHmvR[4], MaxHmvR[5], MaxVmvR[4], MaxVmvR[5] */
+  int32_t inter_valid[8];       /* enc_mb.valid[mode] (InterSearch) */
+  int32_t intra4_valid, intra16_valid;
+  int32_t subpel;               /* !DisableSubpelME */
+  int32_t start_qp;             /* p_Vid->start_me_refinement_qp (mv_search.c:446); start_me_refinement_hp must be 0 */
+  int32_t refbits[JMHIP_MB_MAX_REF];   /* p_Vid->refbits */
+  jmhip_qparam q_luma[2][16];   /* p_Quant->q_params_4x4[0][intra][qp][j][i] at [intra][j * 4 + i] */
+  jmhip_qparam q_chroma[2][2][16];  /* p_Quant->q_params_4x4[1 + uv][intra][qpc + chroma scale] at [uv][intra][j * 4 + i] */
+  int32_t df_disable_idc, df_alpha_c0, df_beta;   /* Macroblock.DFDisableIdc, DFAlphaC0Offset, DFBetaOffset of the slice */
+  int32_t reserved_[5];
+} jmhip_slice_params;
+
+int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);
+int jmhip_encode_slice_dev(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *d_out /* device, or NULL: kept inside only */);
+/* the reconstruction the slices of the current picture left on the device (before / after jmhip_deblock_picture_dev) */
+int jmhip_recon_planes_dev(jmhip_ctx *ctx, uint8_t **d_y, int32_t *pitch_y, uint8_t **d_u, uint8_t **d_v, int32_t *pitch_c);
+int jmhip_get_recon(jmhip_ctx *ctx, uint16_t *y, int32_t pitch_y, uint16_t *u, uint16_t *v, int32_t pitch_c);   /* as imgpel, pitches in samples */
+/* DeblockFrame on that reconstruction with the side information the slices' macroblocks left on the device */
+int jmhip_deblock_picture_dev(jmhip_ctx *ctx, int32_t direct_8x8_inference);
+/* getSubImagesLuma (+ the integer chroma planes) of the reconstruction into a reference slot, without leaving the device */
+int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
+
+/* ------------------------------------------------------------------------------------------
  * Timing helper: elapsed milliseconds of the last `_dev` launch of each kind, measured with
  * hipEvents on the context's stream (bench.py uses it for the roofline object).
- * kind: 0 subplanes, 1 me_fullsearch, 2 me_subpel, 3 tq, 4 deblock.
+ * kind: 0 subplanes, 1 me_fullsearch, 2 me_subpel, 3 tq, 4 deblock, 5 encode_slice.
  * ------------------------------------------------------------------------------------------ */
 int jmhip_enable_timing(jmhip_ctx *ctx, int32_t on);
 int jmhip_last_kernel_ms(jmhip_ctx *ctx, int32_t kind, float *ms);

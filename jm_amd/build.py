@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libjmhip.so")
-SOURCES = ["ctx.hip", "input.hip", "interp.hip", "me_fullsearch.hip", "me_fast.hip", "me_subpel.hip", "me_refine.hip", "tq.hip", "tq8.hip", "tq16.hip", "tq_chroma.hip", "mc.hip", "intra.hip", "distortion.hip", "deblock.hip", "deblock_rows.hip", "deblock_sparse.hip"]
+SOURCES = ["ctx.hip", "input.hip", "interp.hip", "me_fullsearch.hip", "me_fast.hip", "me_subpel.hip", "me_refine.hip", "tq.hip", "tq8.hip", "tq16.hip", "tq_chroma.hip", "mc.hip", "intra.hip", "distortion.hip", "deblock.hip", "deblock_rows.hip", "deblock_sparse.hip", "mbpipe.hip"]
 
 
 def hipcc():
@@ -36,13 +36,24 @@ def build(force=False, verbose=False):
         return OUT
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "jmhip.h")]
-    hdr_time = max(os.path.getmtime(h) for h in headers)
+    import re
+
+    def deps(path, seen=None):
+        """the file and everything it #includes with quotes, recursively (deblock_sparse.hip includes deblock_rows.hip; mbpipe.hip its .inc parts)"""
+        seen = set() if seen is None else seen
+        path = os.path.normpath(path)
+        if path in seen or not os.path.exists(path):
+            return seen
+        seen.add(path)
+        with open(path) as f:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), re.M):
+                deps(os.path.join(os.path.dirname(path), inc), seen)
+        return seen
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-function"]
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps(src)):
             cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

@@ -144,6 +144,7 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
   if (c->d_db_hand) (void)hipFree(c->d_db_hand);
   if (c->d_db_flags) (void)hipFree(c->d_db_flags);
   if (c->d_db_tasks) (void)hipFree(c->d_db_tasks);
+  jmhip_mb_free(c);
   for (int k = 0; k < JMHIP_NKINDS; k++) { if (c->ev0[k]) (void)hipEventDestroy(c->ev0[k]); if (c->ev1[k]) (void)hipEventDestroy(c->ev1[k]); }
   free(c);
 }

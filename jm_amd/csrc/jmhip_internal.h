@@ -6,7 +6,7 @@
 #include <string.h>
 #include "../../include/jmhip.h"
 
-#define JMHIP_NKINDS 5
+#define JMHIP_NKINDS 6
 
 struct jmhip_ctx {
   jmhip_config cfg;
@@ -36,6 +36,17 @@ struct jmhip_ctx {
   uint8_t *d_db_flags;   // deblocking segment walks: per macroblock flags (nmb bytes), then store_bottom (nmb bytes)
   void *d_db_tasks;      // deblocking segment walks: task list (1024 x int2)
   int force_db_diag;     // JMHIP_DEBLOCK_DIAG=1: one launch per diagonal instead of the row pipeline (A/B testing)
+  // the macroblock pipeline (mbpipe.hip), allocated on first use
+  uint8_t *d_rec;        // reconstruction of the current picture: Y (cur_pitch x H), then U, V (cw x ch, pitch cw)
+  void *d_mb_edge;       // per macroblock: the samples / vectors / modes its right and lower neighbours read (136 bytes, write-through)
+  unsigned *d_mb_done;   // per macroblock: epoch of the launch that finished it
+  unsigned *d_mb_sync;   // [0] ticket, [1] error word
+  int *d_mb_order;       // wavefront order of the slice's macroblocks
+  int mb_order_first, mb_order_num;
+  unsigned mb_epoch;
+  void *d_mb_records;    // jmhip_mb_record per macroblock of the picture
+  void *d_mb_dbmb, *d_mb_dbmo;   // loop-filter side information written by the pipeline
+  void *h_mb_records;    // pinned host staging for jmhip_encode_slice
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];
@@ -55,6 +66,7 @@ void jmhip_time_end(jmhip_ctx *ctx, int kind);
 
 // kernels' launchers (defined next to the kernels)
 int jmhip_check_deblock_error(jmhip_ctx *ctx);
+void jmhip_mb_free(jmhip_ctx *ctx);   // mbpipe.hip
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);
 int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8);

@@ -1,0 +1,602 @@
+// mbpipe.hip -- the RDO-off macroblock pipeline of a slice on the MI355X (gfx950): SURVEY.md 8f row 1.
+//
+// What it computes, macroblock for macroblock, is what the reference's encode_one_macroblock_low (lencod/src/md_low.c:104-687) leaves behind
+// for write_macroblock and DeblockFrame; the entry point and the functions it stands for are listed in include/jmhip.h (jmhip_encode_slice).
+//
+// Design (not the reference's: JM walks macroblocks in raster order on one thread).
+//   * One persistent launch per slice.  A workgroup draws a ticket, the ticket names a macroblock in wavefront order x + 2y (every macroblock
+//     a macroblock depends on -- left, up-left, up, up-right -- has a smaller ticket), the workgroup waits for those neighbours' done flags
+//     and then owns the macroblock from motion search to reconstruction.  What neighbours read from each other (the bottom row / right column
+//     of the reconstruction, of mv_info and of ipredmode) travels in a 136-byte edge record written with write-through (sc1) stores and read
+//     with sc1 loads; the flag follows the drained stores (per-XCD L2s are not coherent, MI355X guide: inter-workgroup visibility).
+//   * Inside a macroblock the searches form independent chains: the sub-modes of an 8x8 block only read vectors of their own sub-blocks and of
+//     finished 8x8 blocks, 16x8 / 8x16 only their own first partition.  Eight waves: waves 0-3 take the sub-modes 4x4, 4x8, 8x4, 8x8 of the
+//     P8x8 chain (meeting after every 8x8 block), waves 4-6 the 16x16 (with the skip vector's cost), 16x8 and 8x16 searches, wave 7 the intra
+//     side (Intra4x4 chain, Intra16x16 search, chroma intra decision).  Then one wave decides and codes the winner.
+//   * A search = one wave.  The integer windows of all references sit in LDS once per macroblock: with RDOptimization = 0 JM clamps the
+//     search centre to +-SearchRange (mv_search.c:945-954), so every candidate of every partition lies within +-2 SearchRange of the macroblock.
+//     lane = window column, the lane slides down its column keeping one running SAD per candidate in flight (each window row is loaded and
+//     byte-aligned once and meets every row of the block), the block's samples are scalar operands.  Integer SAD (v_sad_u8), 64-bit keys
+//     (cost, spiral index): JM's "first in spiral order wins" is the unsigned minimum.
+//   * Sub-pel refinement: (candidate, 4x4 sub-block) items over the lanes, Hadamard SATD from the 16 quarter-pel planes in HBM/L2 with JM's
+//     per-sub-block origin clamp (UMVLine4X), JM's strict-'<' scan replayed on the nine sums.
+// No MFMA: the path is byte / integer add, sub, shift, abs, min.
+#include "jmhip_internal.h"
+#include "me_common.h"
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define MB_THREADS 512
+#define MAXC 0x7fffffff
+#define EDGE_WORDS 17                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
+                                            // 6/7 right U/V columns, 8 ipredmode (bytes 0-3 bottom row, 4-7 right column), 9-12 / 13-16 mv_info of the
+                                            // bottom row / right column {packed vector, reference index}
+#define SPIN_LIMIT (1u << 26)
+
+struct __attribute__((packed)) U32un { u32 v; };
+__device__ __forceinline__ u32 ldu32(const u8 *p) { return ((const U32un *)p)->v; }
+__device__ __forceinline__ int clampi3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int mvx(int p) { return (int)(int16_t)(p & 0xffff); }
+__device__ __forceinline__ int mvy(int p) { return p >> 16; }
+__device__ __forceinline__ int mvpack(int x, int y) { return (x & 0xffff) | (y << 16); }
+__device__ __forceinline__ int median3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
+
+static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 1492, "record sizes of include/jmhip.h");
+
+struct PipeArgs {
+  jmhip_slice_params p;
+  int W, H, wmb, hmb, cw, ch;
+  int cur_pitch, ref_pitch, rec_pitch;       // luma pitches (bytes); chroma planes are cw wide
+  long plane_stride;
+  int win_h, win_p, win_ox;                  // LDS window of a reference: (16 + 4R) rows of win_p bytes; the macroblock's column 0 sits at byte win_ox
+                                             // (2R rounded up to a multiple of 4, so picture dwords stay aligned)
+  const u8 *cur_y, *cur_u, *cur_v;
+  const u8 *ref_y[JMHIP_MB_MAX_REF];         // 16 quarter-pel planes of each reference (plane (0,0) first)
+  const u8 *ref_u[JMHIP_MB_MAX_REF], *ref_v[JMHIP_MB_MAX_REF];
+  u8 *rec_y, *rec_u, *rec_v;
+  u64 *edge;
+  unsigned *done, *sync;
+  const int *order;
+  unsigned epoch;
+  jmhip_mb_record *records;
+  jmhip_db_mb *dbmb;
+  jmhip_db_motion *dbmo;
+};
+
+// per-workgroup state in LDS
+struct Shared {
+  u32 cur_y[64];                             // the source macroblock, 16 rows of 4 dwords
+  u32 cur_c[2][16];                          // U, V: 8 rows of 2 dwords
+  u64 nb[4][EDGE_WORDS];                     // edge records of A (left), B (up), C (up-right), D (up-left)
+  int avail[4];
+  int ticket, addr, err;
+  int allmv[JMHIP_MB_MAX_REF][8][16];        // currSlice->all_mv[LIST_0][ref][mode][4x4 raster], packed
+  int mcost[8][JMHIP_MB_MAX_REF][4];         // p_Vid->motion_cost[mode][LIST_0][ref][block]
+  int mvi[8][16][2];                         // per wave: the macroblock's mv_info as that wave's chain sees it {packed mv, ref_idx}
+  int p8_cost[4][4], p8_bref[4][4];          // [block][mode - 4]
+  int p8_cnt;
+  int p8_mode[4], p8_ref[4], p8_total;
+  int m_cost[4], m_bref[4][4];               // modes 1..3: cost, best reference per 8x8 block
+  int skip_mv;
+  // intra side
+  int i4_cost, i4_cbp;
+  int8_t i4_ipm[16], i4_syn[16];
+  int16_t i4_lev[16][16];
+  u8 i4_rec[256];
+  u8 ip4[9][16];
+  int i16_cost, i16_mode;
+  u8 e16[36];
+  u8 ec[2][20];                              // chroma predictor samples: [0] corner, [1..8] up, [9..16] left
+  int c_ipred;
+  u8 icpred[2][4][64];
+  // final coding
+  u8 pred[256], rec[256];
+  u8 predc[2][64], recc[2][64];
+  int16_t dcbuf[16];
+  int red[8][80];
+  int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
+  u32 fin_cbp_blk;
+  jmhip_mb_record out;
+};
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+__device__ __forceinline__ u64 ld_sc1(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ------------------------------------------------------------------ neighbours of the current macroblock
+// mv_info entry at 4x4 position (x4, y4) relative to the macroblock, x4, y4 in [-1, 4]: {packed mv, ref} or unavailable.
+// Inside the macroblock: this wave's view; outside: the neighbour's edge record (words 9..12 bottom row, 13..16 right column).
+__device__ __forceinline__ bool mvinfo_at(const Shared &S, int wave, int x4, int y4, int &mv, int &ref)
+{
+  u64 w;
+  if (x4 < 0) {
+    if (y4 < 0) { if (!S.avail[3]) return false; w = S.nb[3][9 + 3]; }
+    else if (y4 < 4) { if (!S.avail[0]) return false; w = S.nb[0][13 + y4]; }
+    else return false;
+  } else if (x4 < 4) {
+    if (y4 < 0) { if (!S.avail[1]) return false; w = S.nb[1][9 + x4]; }
+    else if (y4 < 4) { mv = S.mvi[wave][y4 * 4 + x4][0]; ref = S.mvi[wave][y4 * 4 + x4][1]; return true; }
+    else return false;
+  } else {
+    if (y4 < 0) { if (!S.avail[2]) return false; w = S.nb[2][9 + 0]; }
+    else return false;
+  }
+  mv = (int)(u32)w; ref = (int)(int8_t)(w >> 32);
+  return true;
+}
+
+// get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325)
+__device__ int mv_predictor(const Shared &S, int wave, int ref, int mb_x, int mb_y, int bsx, int bsy)
+{
+  int mv[3] = {0, 0, 0}, rf[3] = {-1, -1, -1};
+  bool av[3];
+  av[0] = mvinfo_at(S, wave, (mb_x - 1) >> 2, mb_y >> 2, mv[0], rf[0]);
+  av[1] = mvinfo_at(S, wave, mb_x >> 2, (mb_y - 1) >> 2, mv[1], rf[1]);
+  av[2] = mvinfo_at(S, wave, (mb_x + bsx) >> 2, (mb_y - 1) >> 2, mv[2], rf[2]);
+  if (mb_y > 0) {
+    if (mb_x < 8) {
+      if (mb_y == 8) { if (bsx == 16) av[2] = false; }
+      else if (mb_x + bsx == 8) av[2] = false;
+    } else if (mb_x + bsx == 16) av[2] = false;
+  }
+  if (!av[2]) { mv[2] = 0; rf[2] = -1; av[2] = mvinfo_at(S, wave, (mb_x - 1) >> 2, (mb_y - 1) >> 2, mv[2], rf[2]); }
+  for (int k = 0; k < 3; k++) if (!av[k]) { mv[k] = 0; rf[k] = -1; }
+  int type = 0;
+  if (rf[0] == ref && rf[1] != ref && rf[2] != ref) type = 1;
+  else if (rf[0] != ref && rf[1] == ref && rf[2] != ref) type = 2;
+  else if (rf[0] != ref && rf[1] != ref && rf[2] == ref) type = 3;
+  if (bsx == 8 && bsy == 16) {
+    if (mb_x == 0) { if (rf[0] == ref) type = 1; }
+    else { if (rf[2] == ref) type = 3; }
+  } else if (bsx == 16 && bsy == 8) {
+    if (mb_y == 0) { if (rf[1] == ref) type = 2; }
+    else { if (rf[0] == ref) type = 1; }
+  }
+  if (type == 0) {
+    if (!(av[1] || av[2])) return mv[0];
+    return mvpack(median3(mvx(mv[0]), mvx(mv[1]), mvx(mv[2])), median3(mvy(mv[0]), mvy(mv[1]), mvy(mv[2])));
+  }
+  return mv[type - 1];
+}
+
+// FindSkipModeMotionVector mv_search.c:1333-1405
+__device__ int skip_vector(const Shared &S, int wave)
+{
+  int mA = 0, rA = -1, mB = 0, rB = -1;
+  const bool a = mvinfo_at(S, wave, -1, 0, mA, rA), b = mvinfo_at(S, wave, 0, -1, mB, rB);
+  const bool zl = !a || (rA == 0 && mA == 0), za = !b || (rB == 0 && mB == 0);
+  if (za || zl) return 0;
+  return mv_predictor(S, wave, 0, 0, 0, 16, 16);
+}
+
+// ------------------------------------------------------------------ integer search of one block by one wave
+template <int BW>
+__device__ __forceinline__ void load_row(const u8 *rowp, int sh, u32 (&b)[BW / 4])
+{
+  const u32 *rp = (const u32 *)rowp;
+  u32 a[BW / 4 + 1];
+#pragma unroll
+  for (int k = 0; k <= BW / 4; k++) a[k] = rp[k];
+#pragma unroll
+  for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
+}
+
+struct FsCost {                              // what turns a SAD into JM's motion cost
+  int lambda, cqx, cqy, pqx, pqy, Rs;        // lambda_factor[F_PEL], centre and predictor (quarter-pel), search range
+  int check00;
+};
+__device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, int bits_x)
+{
+  const int vx = c.cqx + 4 * dx, vy = c.cqy + 4 * dy;
+  int rate = c.lambda * (bits_x + mvbits(vy - c.pqy));
+  if (c.check00 && vx == 0 && vy == 0) rate = rate > 16 * c.lambda ? rate - 16 * c.lambda : 0;       // me_fullsearch.c:78-82
+  const u32 cost = (u32)((sad << 5) + rate);
+  return ((u64)cost << 32) | ((u64)spiral_index(dx, dy) << 16) | (u64)(((dy + 128) << 8) | (dx + 128));
+}
+
+// win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
+// (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
+template <int BW, int BH>
+__device__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane)
+{
+  u32 cb[BH][BW / 4];
+#pragma unroll
+  for (int r = 0; r < BH; r++)
+#pragma unroll
+    for (int k = 0; k < BW / 4; k++) cb[r][k] = __builtin_amdgcn_readfirstlane(cur[r * 4 + k]);
+  const int Rs = c.Rs, ncol = 2 * Rs + 1, nrows = 2 * Rs + BH;
+  u64 best = ~0ull;
+  {                                                            // columns 0..63: a lane slides down its column
+    const int col = lane < ncol ? lane : ncol - 1;
+    const bool live = lane < ncol;
+    const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
+    const u8 *colp = win + (xl & ~3);
+    const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
+    u32 acc[BH];
+#pragma unroll
+    for (int k = 0; k < BH; k++) acc[k] = 0;
+    for (int j0 = 0; j0 < nrows; j0 += BH) {
+#pragma unroll
+      for (int s = 0; s < BH; s++) {
+        const int j = j0 + s;
+        u32 b[BW / 4];
+        load_row<BW>(colp + (Y0 + (j < nrows ? j : nrows - 1)) * WP, sh, b);
+#pragma unroll
+        for (int r = 0; r < BH; r++) {                         // window row j is row r of the candidate that starts at row j - r
+          constexpr int dummy = 0; (void)dummy;
+          const int k = (s - r + BH) % BH;
+          u32 v = r == 0 ? 0u : acc[k];
+#pragma unroll
+          for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
+          acc[k] = v;
+        }
+        const int i = j - (BH - 1);                            // the candidate that ends with this row
+        if (live && i >= 0 && i <= 2 * Rs) {
+          const u64 key = fs_key(c, (int)acc[(s + 1) % BH], dx, i - Rs, bits_x);
+          best = key < best ? key : best;
+        }
+      }
+    }
+  }
+  for (int col = 64; col < ncol; col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
+    const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
+    const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
+    for (int i0 = 0; i0 <= 2 * Rs; i0 += 64) {
+      const int i = i0 + lane;
+      const bool live = i <= 2 * Rs;
+      const u8 *p = win + (xl & ~3) + (Y0 + (live ? i : 2 * Rs)) * WP;
+      u32 v = 0;
+#pragma unroll
+      for (int r = 0; r < BH; r++) {
+        u32 b[BW / 4];
+        load_row<BW>(p + r * WP, sh, b);
+#pragma unroll
+        for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
+      }
+      if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, bits_x); best = key < best ? key : best; }
+    }
+  }
+  return wave_min_u64(best);
+}
+
+// ------------------------------------------------------------------ Hadamard SATD of a 4x4 block (HadamardSAD4x4 me_distortion.c:175-258)
+__device__ __forceinline__ int hadamard4(const int (&d)[16])
+{
+  int m[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int s0 = d[4 * i] + d[4 * i + 3], s1 = d[4 * i + 1] + d[4 * i + 2], s2 = d[4 * i + 1] - d[4 * i + 2], s3 = d[4 * i] - d[4 * i + 3];
+    m[4 * i] = s0 + s1; m[4 * i + 1] = s0 - s1; m[4 * i + 2] = s2 + s3; m[4 * i + 3] = s3 - s2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int s0 = m[i] + m[12 + i], s1 = m[4 + i] + m[8 + i], s2 = m[4 + i] - m[8 + i], s3 = m[i] - m[12 + i];
+    s += iabs_(s0 + s1) + iabs_(s0 - s1) + iabs_(s2 + s3) + iabs_(s3 - s2);
+  }
+  return (s + 1) >> 1;
+}
+// source rows (dwords) against reference rows (dwords)
+__device__ __forceinline__ int satd4_rows(const u32 (&o)[4], const u32 (&r)[4])
+{
+  int d[16];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[4 * j + i] = (int)((o[j] >> (8 * i)) & 255) - (int)((r[j] >> (8 * i)) & 255);
+  return hadamard4(d);
+}
+// the four rows of the 4x4 block at absolute quarter-pel position (qx, qy) of reference `ref`, UMVLine4X origin clamp (refbuf.h:22-26)
+__device__ __forceinline__ void ref_rows4(const PipeArgs &A, int ref, int qx, int qy, u32 (&r)[4])
+{
+  const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);
+  const u8 *p = A.ref_y[ref] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y) * A.ref_pitch + ix + JMHIP_PAD_X;
+#pragma unroll
+  for (int j = 0; j < 4; j++) r[j] = ldu32(p + (long)j * A.ref_pitch);
+}
+
+__device__ const int8_t c_sp9[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+
+// one stage of sub_pel_motion_estimation (me_fullsearch.c:221-246 / :263-281): the nine SATDs around mv with the given step, into S.red[wave][0..8]
+__device__ void subpel_satds(Shared &S, const PipeArgs &A, int wave, int lane, int ref, int px, int py, int mb_x, int mb_y, int bw4, int bh4, int mv, int step)
+{
+  const int nb4 = bw4 * bh4, items = 9 * nb4;
+  for (int base = 0; base < items; base += 64) {
+    const int item = base + lane;
+    const bool live = item < items;
+    const int it = live ? item : 0, cnd = it / nb4, b = it % nb4, sbx = (b % bw4) * 4, sby = (b / bw4) * 4;
+    const int qx = ((px + sbx) << 2) + mvx(mv) + c_sp9[cnd][0] * step, qy = ((py + sby) << 2) + mvy(mv) + c_sp9[cnd][1] * step;
+    u32 r[4], o[4];
+    ref_rows4(A, ref, qx, qy, r);
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = S.cur_y[(mb_y + sby + j) * 4 + ((mb_x + sbx) >> 2)];
+    int v = live ? satd4_rows(o, r) : 0;
+    for (int off = 1; off < nb4; off <<= 1) v += __shfl_xor(v, off, 64);
+    if (live && b == 0) S.red[wave][cnd] = v;
+  }
+  wave_sync();
+}
+
+// BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
+__device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wave, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
+{
+  const jmhip_slice_params &P = A.p;
+  const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
+  const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
+  const int mbx = S.addr % A.wmb, mby = S.addr / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
+  const int R = P.search_range;
+  const int pred = mv_predictor(S, wave, ref, mb_x, mb_y, BW, BH);
+  int cx = ((mvx(pred) + 2) >> 2) * 4, cy = ((mvy(pred) + 2) >> 2) * 4;          // mv_search.c:931-932
+  int min_x = -(R << 2), max_x = R << 2, min_y = min_x, max_y = max_x;
+  {
+    const int ox = cx, oy = cy;
+    cx = clampi3(min_x, max_x, cx); cy = clampi3(min_y, max_y, cy);              // :949-950
+    if (cx != ox || cy != oy) {                                                  // CheckSearchRange :822-849
+      const int lim = P.max_mvd - 2;
+      int left = clampi3(ox - lim, ox + lim, cx + min_x), right = clampi3(ox - lim, ox + lim, cx + max_x);
+      int top = clampi3(oy - lim, oy + lim, cy + min_y), down = clampi3(oy - lim, oy + lim, cy + max_y);
+      if (left < right && top < down) {
+        cx = (left + right) >> 1; cy = (top + down) >> 1;
+        max_x = min(cx - left, right - cx); max_y = min(cy - top, down - cy);
+      } else { cx = ox; cy = oy; }
+    }
+  }
+  cx = clampi3(P.mv_limit[0], P.mv_limit[1], cx); cy = clampi3(P.mv_limit[2], P.mv_limit[3], cy);      // clip_mv_range :957
+  if (cx < -(R << 2) || cx > (R << 2) || cy < -(R << 2) || cy > (R << 2) || (cx & 3) || (cy & 3)) {   // outside the staged windows: cannot happen
+    if (lane == 0) S.err = 2;                                                                          // with the ranges accepted by the host
+    cx = clampi3(-(R << 2), R << 2, cx) & ~3; cy = clampi3(-(R << 2), R << 2, cy) & ~3;
+  }
+  FsCost c;
+  c.lambda = P.lambda_mf[0]; c.cqx = cx; c.cqy = cy; c.pqx = mvx(pred); c.pqy = mvy(pred);
+  c.Rs = min(max(min(max_x, max_y) >> 2, 0), R);
+  c.check00 = bt == 1 && ref == 0;
+  const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
+  const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
+  const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
+  u64 key;
+  switch (bt) {
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  }
+  int mv = mvpack(cx + 4 * ((int)(key & 255) - 128), cy + 4 * ((int)((key >> 8) & 255) - 128));
+  int min_mcost = (int)(key >> 32);
+
+  if (P.subpel) {                                             // sub_pel_motion_estimation me_fullsearch.c:186-289 (start_me_refinement_hp = 0)
+    const int check0 = ref == 0 && bt == 1 && mv == 0;
+    subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
+    min_mcost = MAXC;
+    int best = 0;
+    for (int pos = 0; pos < 9; pos++) {
+      const int qx = mvx(mv) + 2 * c_sp9[pos][0], qy = mvy(mv) + 2 * c_sp9[pos][1];
+      int mcost = P.lambda_mf[1] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
+      if (mcost >= min_mcost) continue;
+      mcost += S.red[wave][pos] << 5;
+      if (pos == 0 && check0) mcost -= P.lambda_mf[1] * 16;
+      if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
+    }
+    mv = mvpack(mvx(mv) + 2 * c_sp9[best][0], mvy(mv) + 2 * c_sp9[best][1]);
+    subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
+    if (!P.start_qp) min_mcost = MAXC;
+    best = 0;
+    for (int pos = P.start_qp; pos < 9; pos++) {
+      const int qx = mvx(mv) + c_sp9[pos][0], qy = mvy(mv) + c_sp9[pos][1];
+      int mcost = P.lambda_mf[2] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
+      if (mcost >= min_mcost) continue;
+      mcost += S.red[wave][pos] << 5;
+      if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
+    }
+    mv = mvpack(mvx(mv) + c_sp9[best][0], mvy(mv) + c_sp9[best][1]);
+  }
+  mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
+
+  if (bt == 1 && P.slice_type == 0) {                          // the skip vector against the 16x16 result: mv_search.c:983-998, GetSkipCostMB :1257
+    const int sv = skip_vector(S, wave);
+    if (lane == 0) S.skip_mv = sv;
+    const int qx = (mbx * 64) + mvx(sv), qy = (mby * 64) + mvy(sv);
+    const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);     // one origin for the 16x16 block
+    const int b = lane & 15, bx = (b & 3) * 4, by = (b >> 2) * 4;
+    const u8 *p = A.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + by) * A.ref_pitch + ix + JMHIP_PAD_X + bx;
+    u32 r[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { r[j] = ldu32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
+    int v = lane < 16 ? satd4_rows(o, r) : 0;
+    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+    v = __shfl(v, 0, 64);
+    const int cost = (v << 5) - P.lambda_mf[2] * 8;
+    if (cost < min_mcost) { min_mcost = cost; mv = sv; }
+  }
+  out_mv = mv;
+  return min_mcost;
+}
+
+// set_me_parameters (mv_search.c:100-113) on this wave's view
+__device__ __forceinline__ void set_mvi(Shared &S, int wave, int lane, int mv, int ref, int x4, int y4, int w4, int h4)
+{
+  if (lane < 16) {
+    const int x = lane & 3, y = lane >> 2;
+    if (x >= x4 && x < x4 + w4 && y >= y4 && y < y4 + h4) { S.mvi[wave][lane][0] = mv; S.mvi[wave][lane][1] = ref; }
+  }
+  wave_sync();
+}
+
+// list_prediction_cost (mode_decision.c:275, LIST_0) with update_mcost (:253)
+__device__ int list0_cost(const Shared &S, const jmhip_slice_params &P, int mode, int block, int &bref)
+{
+  const int ref_lambda = P.lambda_mf[2] >> 2;
+  int bm = MAXC;
+  for (int ref = 0; ref < P.num_ref; ref++) {
+    int mc = S.mcost[mode][ref][block];
+    if (mc < bm) {
+      mc += P.num_ref <= 1 ? 0 : ref_lambda * P.refbits[ref];
+      if (mc < bm) { bm = mc; bref = ref; }
+    }
+  }
+  return bm;
+}
+
+// ------------------------------------------------------------------ transform / quantisation of one 4x4 block in registers
+__device__ __forceinline__ void fwd4_(int &a, int &b, int &c, int &d) { int e0 = a + d, e1 = b + c, o0 = b - c, o1 = a - d; a = e0 + e1; b = (o1 << 1) + o0; c = e0 - e1; d = o1 - (o0 << 1); }
+__device__ __forceinline__ void inv4_(int &a, int &b, int &c, int &d) { int e0 = a + c, e1 = a - c, o0 = (b >> 1) - d, o1 = b + (d >> 1); a = e0 + o1; b = e1 + o0; c = e1 - o0; d = e0 - o1; }
+__device__ __forceinline__ void forward4x4(int (&m)[16])
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) fwd4_(m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) fwd4_(m[i], m[4 + i], m[8 + i], m[12 + i]);
+}
+__device__ __forceinline__ void inverse4x4(int (&m)[16])
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) inv4_(m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) inv4_(m[i], m[4 + i], m[8 + i], m[12 + i]);
+}
+__device__ const u8 c_cc[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};             // COEFF_COST4x4[0] (block.c:72)
+
+// quant_4x4_normal / quant_ac4x4_normal (quant4x4_normal.c:39 / :117) on the transformed block m (raster); first = 0 or 1 (AC only).
+// lev[16]: levels at their scan positions; m receives the dequantised coefficients.  Returns nonzero; cost accumulates the coefficient cost.
+__device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int qp_per, int first, int16_t *lev, int &cost)
+{
+  const int q_bits = 15 + qp_per;
+  int run = 0, nz = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (k < first) { lev[k] = 0; continue; }
+    constexpr int ZZ[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+    const int idx = ZZ[k], cf = m[idx];
+    int l = 0;
+    if (cf != 0) {
+      l = (iabs_(cf) * q[idx].ScaleComp + q[idx].OffsetComp) >> q_bits;
+      if (l != 0) {
+        l = min(l, 2063);                                      // CAVLC_LEVEL_LIMIT
+        cost += l > 1 ? 999999 : (int)c_cc[run];
+        l = cf < 0 ? -l : l;
+        m[idx] = (((l * q[idx].InvScaleComp) << qp_per) + 8) >> 4;
+        run = 0; nz = 1;
+      } else { m[idx] = 0; run++; }
+    } else run++;
+    lev[k] = (int16_t)l;
+  }
+  return nz;
+}
+// residual_transform_quant_luma_4x4 (block.c:661-725): o, p = source and prediction rows; rec = reconstructed rows
+__device__ __forceinline__ int tq_luma4(const u32 (&o)[4], const u32 (&p)[4], const jmhip_qparam *q, int qp_per, int16_t *lev, int &cost, u32 (&rec)[4])
+{
+  int m[16], pr[16], any = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { pr[k] = (p[k >> 2] >> (8 * (k & 3))) & 255; m[k] = (int)((o[k >> 2] >> (8 * (k & 3))) & 255) - pr[k]; any |= m[k]; }
+  int nz = 0;
+  if (any) { forward4x4(m); nz = quant4x4(m, q, qp_per, 0, lev, cost); }
+  else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) lev[k] = 0;
+  }
+  if (nz) {
+    inverse4x4(m);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      u32 w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) w |= (u32)clampi3(0, 255, ((m[4 * j + i] + 32) >> 6) + pr[4 * j + i]) << (8 * i);
+      rec[j] = w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) rec[j] = p[j];
+  }
+  return nz;
+}
+
+// ------------------------------------------------------------------ intra prediction samples
+// get_intrapred_4x4 (intra4x4.c:521; modes :72-308): e[0] = above left, e[1..8] = above and above right, e[9..12] = left
+__device__ __forceinline__ int e4t(const u8 *e, int x) { return x < 0 ? e[0] : e[1 + x]; }
+__device__ __forceinline__ int e4l(const u8 *e, int y) { return y < 0 ? e[0] : e[9 + y]; }
+__device__ int ipred4_sample(const u8 *e, int mode, int x, int y, int left, int up)
+{
+  switch (mode) {
+  case 0: return e4t(e, x);
+  case 1: return e4l(e, y);
+  case 2:
+    if (up && left) return (e[1] + e[2] + e[3] + e[4] + e[9] + e[10] + e[11] + e[12] + 4) >> 3;
+    if (left) return (e[9] + e[10] + e[11] + e[12] + 2) >> 2;
+    if (up) return (e[1] + e[2] + e[3] + e[4] + 2) >> 2;
+    return e[1];
+  case 3: return (x == 3 && y == 3) ? (e4t(e, 6) + 3 * e4t(e, 7) + 2) >> 2 : (e4t(e, x + y) + 2 * e4t(e, x + y + 1) + e4t(e, x + y + 2) + 2) >> 2;
+  case 4:
+    if (x > y) return (e4t(e, x - y - 2) + 2 * e4t(e, x - y - 1) + e4t(e, x - y) + 2) >> 2;
+    if (x < y) return (e4l(e, y - x - 2) + 2 * e4l(e, y - x - 1) + e4l(e, y - x) + 2) >> 2;
+    return (e4t(e, 0) + 2 * e[0] + e4l(e, 0) + 2) >> 2;
+  case 5: {
+    const int z = 2 * x - y, k = x - (y >> 1);
+    if (z >= 0 && !(z & 1)) return (e4t(e, k - 1) + e4t(e, k) + 1) >> 1;
+    if (z > 0) return (e4t(e, k - 2) + 2 * e4t(e, k - 1) + e4t(e, k) + 2) >> 2;
+    if (z == -1) return (e4l(e, 0) + 2 * e[0] + e4t(e, 0) + 2) >> 2;
+    return (e4l(e, y - 1) + 2 * e4l(e, y - 2) + e4l(e, y - 3) + 2) >> 2; }
+  case 6: {
+    const int z = 2 * y - x, k = y - (x >> 1);
+    if (z >= 0 && !(z & 1)) return (e4l(e, k - 1) + e4l(e, k) + 1) >> 1;
+    if (z > 0) return (e4l(e, k - 2) + 2 * e4l(e, k - 1) + e4l(e, k) + 2) >> 2;
+    if (z == -1) return (e4l(e, 0) + 2 * e[0] + e4t(e, 0) + 2) >> 2;
+    return (e4t(e, x - 1) + 2 * e4t(e, x - 2) + e4t(e, x - 3) + 2) >> 2; }
+  case 7: {
+    const int k = x + (y >> 1);
+    return (y & 1) ? (e4t(e, k) + 2 * e4t(e, k + 1) + e4t(e, k + 2) + 2) >> 2 : (e4t(e, k) + e4t(e, k + 1) + 1) >> 1; }
+  default: {
+    const int z = x + 2 * y, k = y + (x >> 1);
+    if (z > 5) return e4l(e, 3);
+    if (z == 5) return (e4l(e, 2) + 3 * e4l(e, 3) + 2) >> 2;
+    if (z & 1) return (e4l(e, k) + 2 * e4l(e, k + 1) + e4l(e, k + 2) + 2) >> 2;
+    return (e4l(e, k) + e4l(e, k + 1) + 1) >> 1; }
+  }
+}
+
+// luma sample of the reconstruction at (x, y) relative to the macroblock, for intra prediction: inside from `own` (16x16 bytes), outside
+// from the neighbours' edge records (words 0..1 bottom row, 2..3 right column)
+__device__ __forceinline__ int edge_byte(const u64 *w, int k) { return (int)((w[k >> 3] >> (8 * (k & 7))) & 255); }
+__device__ __forceinline__ int rec_luma_at(const Shared &S, const u8 *own, int x, int y)
+{
+  if (x < 0) return y < 0 ? edge_byte(&S.nb[3][0], 15) : edge_byte(&S.nb[0][2], y);
+  if (x < 16) return y < 0 ? edge_byte(&S.nb[1][0], x) : own[y * 16 + x];
+  return edge_byte(&S.nb[2][0], x - 16);
+}
+
+// JM's hadamard4x4 (transform.c:121-168): rows, then columns with >> 1
+__device__ __forceinline__ void hadamard4x4_jm(int (&m)[16])
+{
+  int u[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int e0 = m[4 * i] + m[4 * i + 3], e1 = m[4 * i + 1] + m[4 * i + 2], o0 = m[4 * i + 1] - m[4 * i + 2], o1 = m[4 * i] - m[4 * i + 3];
+    u[4 * i] = e0 + e1; u[4 * i + 1] = o1 + o0; u[4 * i + 2] = e0 - e1; u[4 * i + 3] = o1 - o0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int e0 = u[i] + u[12 + i], e1 = u[4 + i] + u[8 + i], o0 = u[4 + i] - u[8 + i], o1 = u[i] - u[12 + i];
+    m[i] = (e0 + e1) >> 1; m[4 + i] = (o0 + o1) >> 1; m[8 + i] = (e0 - e1) >> 1; m[12 + i] = (o1 - o0) >> 1;
+  }
+}
+// ihadamard4x4 (transform.c:170-218): no scaling
+__device__ __forceinline__ void ihadamard4x4_jm(int (&m)[16])
+{
+  int u[16];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int e0 = m[4 * i] + m[4 * i + 2], e1 = m[4 * i] - m[4 * i + 2], o0 = m[4 * i + 1] - m[4 * i + 3], o1 = m[4 * i + 1] + m[4 * i + 3];
+    u[4 * i] = e0 + o1; u[4 * i + 1] = e1 + o0; u[4 * i + 2] = e1 - o0; u[4 * i + 3] = e0 - o1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int e0 = u[i] + u[8 + i], e1 = u[i] - u[8 + i], o0 = u[4 + i] - u[12 + i], o1 = u[4 + i] + u[12 + i];
+    m[i] = e0 + o1; m[4 + i] = e1 + o0; m[8 + i] = e1 - o0; m[12 + i] = e0 - o1;
+  }
+}
+
+#include "mbpipe_intra.inc"
+#include "mbpipe_final.inc"
+#include "mbpipe_kernel.inc"

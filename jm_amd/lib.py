@@ -76,6 +76,18 @@ assert IP8_BLK.itemsize == 28
 IC_MB = np.dtype([("up", "u1", (2, 8)), ("left", "u1", (2, 16)), ("corner", "u1", (2,)), ("up_avail", "u1"), ("left_avail", "u1"), ("upleft_avail", "u1"),
                   ("reserved_", "u1", (3,))])
 assert IP4_BLK.itemsize == 16 and I16_MB.itemsize == 40 and I16_OUT.itemsize == 1040 and IC_MB.itemsize == 56
+MB_MAX_REF = 16
+MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("reserved0_", "i1"), ("cbp", "<i2"), ("reserved1_", "<i2"),
+                      ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
+                      ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
+                      ("chroma_dc", "<i2", (2, 4)), ("chroma_ac", "<i2", (2, 4, 16))])
+SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", "<i4"), ("slice_nr", "<i4"), ("qp", "<i4"), ("qpc", "<i4"),
+                         ("search_range", "<i4"), ("num_ref", "<i4"), ("ref_slot", "<i4", (MB_MAX_REF,)), ("ref_id", "<i4", (MB_MAX_REF,)),
+                         ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
+                         ("inter_valid", "<i4", (8,)), ("intra4_valid", "<i4"), ("intra16_valid", "<i4"), ("subpel", "<i4"), ("start_qp", "<i4"),
+                         ("refbits", "<i4", (MB_MAX_REF,)), ("q_luma", "<i4", (2, 16, 3)), ("q_chroma", "<i4", (2, 2, 16, 3)),
+                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("reserved_", "<i4", (5,))])
+assert MB_RECORD.itemsize == 944 and SLICE_PARAMS.itemsize == 1492
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
@@ -86,7 +98,8 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
-           "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms"]
+           "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
+           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_recon_planes_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon"]
 
 
 class JmHipError(RuntimeError):
@@ -522,6 +535,39 @@ class JmHip:
 
     def deblock_frame_dev(self, dY, pitchY, dU, dV, pitchC, d_mbs, d_motion, direct8x8=1):
         self._ck(self.lib.jmhip_deblock_frame_dev(self.h, _vp(dY), pitchY, _vp(dU), _vp(dV), pitchC, _vp(d_mbs), _vp(d_motion), direct8x8))
+
+
+    # ---- the RDO-off macroblock pipeline of a slice (encode_one_macroblock_low, lencod/src/md_low.c:104)
+    def encode_slice(self, prm):
+        """prm: one SLICE_PARAMS record -> MB_RECORD per macroblock of the slice; reconstruction and loop-filter side information stay on the device"""
+        prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
+        out = np.zeros(int(prm["num_mb"][0]), MB_RECORD)
+        self._ck(self.lib.jmhip_encode_slice(self.h, _vp(prm), _vp(out)))
+        return out
+
+    def encode_slice_dev(self, prm, d_out=None):
+        prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
+        self._ck(self.lib.jmhip_encode_slice_dev(self.h, _vp(prm), _vp(d_out)))
+
+    def recon_planes_dev(self):
+        py, pu, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self.lib.jmhip_recon_planes_dev(self.h, C.byref(py), C.byref(a), C.byref(pu), C.byref(pv), C.byref(b)))
+        return py.value, a.value, pu.value, pv.value, b.value
+
+    def get_recon(self):
+        """(y, u, v) uint8: the reconstruction on the device (before or after deblock_picture_dev)"""
+        y = np.zeros((self.H, self.W), np.uint16)
+        u = np.zeros((self.H // 2, self.W // 2), np.uint16)
+        v = np.zeros((self.H // 2, self.W // 2), np.uint16)
+        self._ck(self.lib.jmhip_get_recon(self.h, _vp(y), self.W, _vp(u), _vp(v), self.W // 2))
+        return y.astype(np.uint8), u.astype(np.uint8), v.astype(np.uint8)
+
+    def deblock_picture_dev(self, direct8x8=1):
+        self._ck(self.lib.jmhip_deblock_picture_dev(self.h, direct8x8))
+
+    def reference_from_recon(self, slot):
+        self._ck(self.lib.jmhip_reference_from_recon(self.h, slot))
 
 
 def db_arrays_from_tap(mbs12, mot):

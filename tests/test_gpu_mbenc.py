@@ -1,0 +1,205 @@
+"""gpu: jmhip_encode_slice (jm_amd/csrc/mbpipe.hip, the RDO-off macroblock pipeline of SURVEY.md 8f row 1) through the C ABI, against
+  * the committed dumps of the REAL reference encoder's encode_one_macroblock_low (tests/golden/mb_low_*.npz, oracle/ref_tap_mb.c), and
+  * the oracle (oracle/jmo_mbenc.c) on seeded synthetic clips, slices, several references, both search ranges.
+The device encodes whole sequences on its own: its reconstruction is deblocked on the device and becomes the next picture's reference without
+leaving HBM, exactly as the product uses it; every macroblock record and every picture before and after the loop filter must be identical."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, G)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mb_tap  # noqa: E402
+import mbenc_util  # noqa: E402
+from oracle import pyjmo  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0):
+    """jmhip_slice_params from the oracle's configuration record (same meaning field by field) plus JM's quantiser tables"""
+    p = np.zeros(1, L.SLICE_PARAMS)
+    for k in ("slice_type", "first_mb", "num_mb", "qp", "qpc", "search_range", "num_ref", "lambda_mdfp", "max_mvd", "intra4_valid", "intra16_valid", "subpel", "start_qp"):
+        p[k] = getattr(cfg, k)
+    p["slice_nr"] = slice_nr
+    p["lambda_mf"] = list(cfg.lambda_mf)
+    p["mv_limit"] = list(cfg.mv_limit)
+    p["inter_valid"] = list(cfg.inter_valid)
+    p["refbits"] = list(cfg.refbits)
+    for r, (s, i) in enumerate(zip(ref_slots, ref_ids)):
+        p["ref_slot"][0, r] = s
+        p["ref_id"][0, r] = i
+    for intra in range(2):
+        p["q_luma"][0, intra] = pyjmo.qparams_4x4(cfg.qp, intra, cfg.q_offset[intra])
+        for uv in range(2):
+            p["q_chroma"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc, intra, cfg.q_offset[intra])
+    p["df_disable_idc"] = disable_idc
+    return p
+
+
+class DevSeqEncoder:
+    """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
+
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0):
+        import jm_amd.lib as L
+        self.L = L
+        self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
+        self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
+        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=num_ref + 1, yuv_format=1)
+        self.refs = []          # most recent first: (slot, picture id)
+        self.npic = 0
+
+    def encode(self, raw, sw, sh, timing=None):
+        L, J = self.L, self.J
+        nmb = (self.W // 16) * (self.H // 16)
+        st = 2 if self.npic == 0 else 0
+        nref = min(self.num_ref, len(self.refs)) if st == 0 else 0
+        J.set_current_frame(raw, sw, sh)
+        recs = np.zeros(nmb, L.MB_RECORD)
+        for sn, (first, num) in enumerate(mbenc_util.slices_of(nmb, self.slice_mbs)):
+            lam_mf, lam_md = self.lambdas[st]
+            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv)
+            prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc)
+            if timing is not None:
+                J.enable_timing(True)
+            recs[first:first + num] = J.encode_slice(prm)
+            if timing is not None:
+                timing.append(J.last_kernel_ms(5))
+        pre = J.get_recon()
+        J.deblock_picture_dev(1)
+        post = J.get_recon()
+        used = {r[0] for r in self.refs[:max(self.num_ref - 1, 0)]}
+        slot = [s for s in range(self.num_ref + 1) if s not in used][0]
+        J.reference_from_recon(slot)
+        J.synchronize()
+        self.refs.insert(0, (slot, self.npic))
+        self.refs = self.refs[:self.num_ref]
+        self.npic += 1
+        return recs, pre, post
+
+
+def as_oracle_records(recs):
+    return np.frombuffer(np.ascontiguousarray(recs).tobytes(), pyjmo.MB_RECORD).copy()
+
+
+def load_case(tag):
+    z = np.load(os.path.join(G, f"mb_low_{tag}.npz"))
+    ov = dict(s.split("=") for s in z["overrides"])
+    sw, sh, W, H = [int(x) for x in z["size"]]
+    lam = {2: ([int(x) for x in z["lambda_i"][:3]], int(z["lambda_i"][3])), 0: ([int(x) for x in z["lambda_p"][:3]], int(z["lambda_p"][3]))}
+    return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
+                slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]],
+                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"])
+
+
+def clip_bytes(tag, c):
+    if tag == "g2r":
+        import tempfile
+        import bench
+        with tempfile.TemporaryDirectory() as t:
+            bench.write_yuv(os.path.join(t, "s.yuv"), c["nfr"])
+            return np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+    return np.fromfile(os.path.join(G, "foreman_part_qcif.yuv"), np.uint8)
+
+
+def first_difference(want, got):
+    bad = [k for k in range(len(want)) if got[k].tobytes() != want[k].tobytes()]
+    return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
+
+
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r"])
+def test_encode_slice_equals_the_reference_encoder(tag):
+    """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
+    mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks)."""
+    c = load_case(tag)
+    enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
+    nmb = (c["W"] // 16) * (c["H"] // 16)
+    data = clip_bytes(tag, c)
+    fs = c["sw"] * c["sh"] * 3 // 2
+    z = c["z"]
+    for n in range(c["nfr"]):
+        recs, pre, post = enc.encode(data[n * fs:(n + 1) * fs], c["sw"], c["sh"])
+        got = mb_tap.canonical(as_oracle_records(recs))
+        want = c["records"][n * nmb:(n + 1) * nmb]
+        d = first_difference(want, got)
+        assert d is None, (tag, n, d)
+        for p, m in zip(pre, z["md5_pre_deblock"][n]):
+            assert hashlib.md5(np.ascontiguousarray(p).tobytes()).hexdigest() == m, (tag, n, "reconstruction before the loop filter")
+
+
+def synthetic_clip(W, H, nfr, seed):
+    """moving blurred blocks + noise (the generator of SURVEY Appendix A at a small size), planar 4:2:0 bytes per frame"""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, ((H + 64) // 8 + 1, (W + 64) // 8 + 1)).astype(np.float64)
+    big = np.kron(base, np.ones((8, 8)))
+    k = 5
+    pad = np.pad(big, k // 2, mode="edge")
+    blur = sum(pad[i:i + big.shape[0], j:j + big.shape[1]] for i in range(k) for j in range(k)) / (k * k)
+    frames = []
+    for n in range(nfr):
+        y = blur[2 * n:2 * n + H, 3 * n:3 * n + W] + rng.normal(0, 2 + 3 * (seed % 3), (H, W))
+        y = np.clip(np.rint(y), 0, 255).astype(np.uint8)
+        yd = y.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
+        u = np.clip(np.rint(128 + 0.25 * (yd - 128)), 0, 255).astype(np.uint8)
+        v = np.clip(np.rint(128 - 0.25 * (yd - 128)), 0, 255).astype(np.uint8)
+        frames.append(np.concatenate([y.ravel(), u.ravel(), v.ravel()]))
+    return frames
+
+
+LAMBDAS = {2: ([192, 192, 192], 192), 0: ([192, 192, 192], 192)}     # JM's tables at QP 28 with RDOptimization = 0 (tests/golden/mb_low_*.npz)
+
+
+@pytest.mark.parametrize("W,H,R,num_ref,slice_mbs,qp,seed", [
+    (176, 144, 16, 1, 0, 28, 1),
+    (64, 48, 32, 2, 0, 28, 2),        # a picture smaller than the search window: every window clamps on all sides
+    (320, 192, 32, 3, 50, 36, 3),     # slices that start mid-row, three references, coarse quantiser
+    (208, 160, 8, 1, 13, 20, 4),      # one slice per macroblock row, fine quantiser
+    (16, 16, 16, 1, 0, 28, 5),        # a single macroblock
+])
+def test_encode_slice_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed):
+    f = int(192 * 2 ** ((qp - 28) / 6))          # any positive factors serve: they are inputs of both sides
+    lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    nfr = 3 if num_ref < 3 else 4
+    frames = synthetic_clip(W, H, nfr, seed)
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs)
+    ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs)
+    for n, raw in enumerate(frames):
+        recs, pre, post = dev.encode(raw, W, H)
+        cur = pyjmo.load_frame(raw, W, H, W, H, 1)
+        orecs, _, opre, opost = ora.encode(cur)
+        d = first_difference(mb_tap.canonical(orecs), mb_tap.canonical(as_oracle_records(recs)))
+        assert d is None, (n, d)
+        for a, b in zip(pre, opre):
+            assert np.array_equal(a, b.astype(np.uint8)), (n, "reconstruction before the loop filter")
+        for a, b in zip(post, opost):
+            assert np.array_equal(a, b.astype(np.uint8)), (n, "reconstruction after the loop filter")
+
+
+def test_encode_slice_rejects_what_it_does_not_cover():
+    import jm_amd.lib as L
+    J = L.JmHip(64, 48, search_range=16, num_ref_slots=2, yuv_format=1)
+    cfg = pyjmo.mbenc_cfg(64, 48, 0, 0, 12, 28, 16, 1, [187] * 3, 1097)
+    prm = slice_params(L, cfg, 0, [0], [0])
+    with pytest.raises(L.JmHipError):       # no current picture
+        J.encode_slice(prm)
+    J.set_current_frame(np.zeros(64 * 48 * 3 // 2, np.uint8), 64, 48)
+    with pytest.raises(L.JmHipError):       # reference slot without chroma planes
+        J.encode_slice(prm)
+    bad = prm.copy(); bad["slice_type"] = 1
+    with pytest.raises(L.JmHipError):
+        J.encode_slice(bad)
+    bad = prm.copy(); bad["num_mb"] = 13
+    with pytest.raises(L.JmHipError):
+        J.encode_slice(bad)
+    bad = prm.copy(); bad["search_range"] = 32
+    with pytest.raises(L.JmHipError):
+        J.encode_slice(bad)
+    J4 = L.JmHip(64, 48, search_range=16, num_ref_slots=1, yuv_format=2)
+    with pytest.raises(L.JmHipError):
+        J4.encode_slice(prm)
