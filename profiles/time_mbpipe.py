@@ -1,0 +1,21 @@
+"""Times jmhip_encode_slice on BASELINE configs[1] (1080p, SR 32, one reference, RDO off): I picture, then P pictures. gpu only."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import bench, tempfile
+from test_gpu_mbenc import DevSeqEncoder, load_case
+c = load_case("g2r")
+nfr = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+with tempfile.TemporaryDirectory() as t:
+    bench.write_yuv(os.path.join(t, "s.yuv"), nfr)
+    data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+fs = c["sw"] * c["sh"] * 3 // 2
+enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
+for n in range(nfr):
+    tm = []
+    t0 = time.time()
+    recs, pre, post = enc.encode(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], timing=tm)
+    t1 = time.time()
+    types = np.bincount(recs["mb_type"].astype(int), minlength=11)
+    print(f"picture {n}: kernel {tm} ms, whole call {1000*(t1-t0):.1f} ms, mb types {types.tolist()}", flush=True)
