@@ -81,6 +81,9 @@ int jmhip_set_current_dev(jmhip_ctx *ctx, const uint8_t *d_luma, int32_t pitch_b
  * jmhip_get_current_planes copies them out as imgpel (tight pitches W and W / 2: what p_Vid->pImgOrg[0..2] hold). */
 int jmhip_set_current_frame(jmhip_ctx *ctx, const uint8_t *raw, int32_t src_w, int32_t src_h);
 int jmhip_set_current_frame_dev(jmhip_ctx *ctx, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
+/* the same from imgpel planes that already have the coded size (p_Vid->pCurImg, p_Vid->pImgOrg[1], [2] after pad_borders, lcommon/src/input.c:880);
+ * asynchronous on the context's stream (the samples are copied into pinned staging before the call returns) */
+int jmhip_set_current_planes(jmhip_ctx *ctx, const uint16_t *y, int32_t pitch_y, const uint16_t *u, const uint16_t *v, int32_t pitch_c);
 int jmhip_current_planes_dev(jmhip_ctx *ctx, const uint8_t **d_y, int32_t *pitch_y, const uint8_t **d_u, const uint8_t **d_v, int32_t *pitch_c);
 int jmhip_get_current_planes(jmhip_ctx *ctx, uint16_t *y, uint16_t *u, uint16_t *v);
 

@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "global.h"
 #include "image.h"
 #include "mbuffer.h"
@@ -56,7 +57,7 @@
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic, part_ip8;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic, part_ip8, part_mbpipe;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -71,9 +72,14 @@ static struct {
   long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load, n_ic, n_ip8;
 } G;
 
+static void pipe_report(void);
+static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV);
+static int pipe_reference(StorablePicture *s);
+
 static void adapter_report(void)
 {
   if (!G.init_done) return;
+  pipe_report();
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
@@ -123,7 +129,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
-    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic"); G.part_ip8 = has_part(parts, "ip8");
+    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic"); G.part_ip8 = has_part(parts, "ip8"); G.part_mbpipe = has_part(parts, "mbpipe");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -189,6 +195,7 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
 {
   int rc, k, j, i, y;
   const int Wp = s->size_x + 2 * JMHIP_PAD_X, Hp = s->size_y + 2 * JMHIP_PAD_Y;
+  if (adapter_on(p_Vid) && pipe_reference(s)) return;       /* the macroblock pipeline's picture: the planes are made on the device and stay there */
   if (!adapter_on(p_Vid) || !G.part_interp || s->size_x != G.W || s->size_y != G.H ||
       s->size_x_padded != Wp || s->size_y_padded != Hp) {
     G.n_passed++;
@@ -218,6 +225,7 @@ void __wrap_getSubImagesChroma(VideoParameters *p_Vid, StorablePicture *s)
   const int fmt = p_Vid->yuv_format, ny = fmt == YUV422 ? 4 : 8, py = p_Vid->pad_size_uv_y, px = p_Vid->pad_size_uv_x;
   const int Wp = s->size_x_cr + 2 * px, Hp = s->size_y_cr + 2 * py;
   int uv, j, i, y, k, rc;
+  if (adapter_on(p_Vid) && slot_find(s) >= 0 && G.slot_chroma[slot_find(s)] == 2) return;   /* the macroblock pipeline's picture (see pipe_reference) */
   if (!adapter_on(p_Vid) || !G.part_interpc || (fmt != YUV420 && fmt != YUV422) || p_Vid->p_Inp->OnTheFlyFractMCP ||
       s->size_x != G.W || s->size_y != G.H || px != (JMHIP_PAD_X >> 1) || py != (fmt == YUV422 ? JMHIP_PAD_Y : JMHIP_PAD_Y >> 1)) {
     G.n_passed++;
@@ -794,6 +802,7 @@ void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
   StorablePicture *ids[64];
   int nids = 0, rc, x, y, l, k;
   unsigned i;
+  if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) return;
   if (!adapter_on(p_Vid) || !G.part_deblock || p_Vid->structure != FRAME || p_Vid->mb_aff_frame_flag ||
       (int)p_Vid->PicSizeInMbs != (G.W / 16) * (G.H / 16)) {
     G.n_passed++;
@@ -1057,4 +1066,236 @@ extern int __real_residual_transform_quant_luma_8x8_cavlc(Macroblock *, ColorPla
 int __wrap_residual_transform_quant_luma_8x8_cavlc(Macroblock *m, ColorPlane pl, int b8, int *cc, int intra)
 {
   return tq8_common(m, pl, b8, cc, intra, 1, __real_residual_transform_quant_luma_8x8_cavlc);
+}
+
+/* ------------------------------------------------------------------ the RDO-off macroblock pipeline
+ * encode_one_macroblock_low (lencod/src/md_low.c:104; Slice.encode_one_macroblock, bound in rdopt.c:242-260 when RDOptimization = 0).
+ * JM calls it macroblock after macroblock from encode_one_slice (slice.c:512).  At a slice's first macroblock the whole slice is encoded
+ * on the MI355X (jmhip_encode_slice: motion search, mode decision, transform / quantisation, reconstruction of every macroblock in
+ * wavefront order); each call then only unpacks its macroblock's record into the structures JM's own write_macroblock
+ * (macroblock.c:2810) reads, so the entropy coder and the bitstream writer stay JM's.  The reconstruction stays on the device:
+ * DeblockFrame runs there (jmhip_deblock_picture_dev) and hands the picture back once, getSubImagesLuma / getSubImagesChroma become
+ * jmhip_reference_from_recon (no sub-pel plane ever crosses PCIe; the host does no motion compensation in this mode).
+ * Part name: mbpipe.  Eligibility is decided once per sequence from the configuration (pipe_config_ok); a sequence is either
+ * entirely on this path or not at all. */
+#include "mode_decision.h"
+#include "macroblock.h"
+#include "md_common.h"
+
+static struct {
+  int checked, ok;
+  jmhip_mb_record *recs;              /* one per macroblock of the picture */
+  StorablePicture *pic;               /* the picture the records / the device reconstruction belong to */
+  int mbs;                            /* its macroblocks served so far */
+  int deblocked;
+  long n_slices, n_mbs, n_refs;
+  double t_dev, t_fill;
+} P;
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+static int pipe_config_ok(VideoParameters *p_Vid)
+{
+  if (!P.checked) {
+    InputParameters *p = p_Vid->p_Inp;
+    const char *why = NULL;
+    const int R = imax(p->search_range[0], p->search_range[1]);
+    const int ox = (2 * R + 3) & ~3;
+    P.checked = 1;
+    if (!G.part_mbpipe) why = "part mbpipe not selected";
+    else if (p->rdopt != 0) why = "RDOptimization != 0";
+    else if (p_Vid->yuv_format != YUV420) why = "not 4:2:0";
+    else if (p->SearchMode[0] != FULL_SEARCH) why = "SearchMode != -1";
+    else if (p->Transform8x8Mode != 0) why = "Transform8x8Mode";
+    else if (p->AdaptiveRounding != 0) why = "AdaptiveRounding";
+    else if (p->WeightedPrediction || p->WeightedBiprediction) why = "weighted prediction";
+    else if (p->RCEnable) why = "rate control";
+    else if (p->slice_mode != NO_SLICES && p->slice_mode != FIXED_MB) why = "SliceMode > 1";
+    else if (p->num_slice_groups_minus1 != 0) why = "FMO";
+    else if (p->UseConstrainedIntraPred) why = "UseConstrainedIntraPred";
+    else if (p->symbol_mode != CAVLC) why = "CABAC";
+    else if (p->RestrictRef || p->UseRDOQuant || p->ChromaMEEnable) why = "RestrictRefFrames / UseRDOQuant / ChromaMEEnable";
+    else if (p->MEErrorMetric[F_PEL] != ERROR_SAD || p->MEErrorMetric[H_PEL] != ERROR_SATD || p->MEErrorMetric[Q_PEL] != ERROR_SATD || p->ModeDecisionMetric != ERROR_SATD) why = "distortion metrics other than SAD / SATD / SATD / SATD";
+    else if (p->disthres != 0) why = "DisableThresholding";
+    else if (p->Intra4x4ParDisable || p->Intra4x4DiagDisable || p->Intra4x4DirDisable || p->Intra16x16ParDisable || p->Intra16x16PlaneDisable || p->ChromaIntraDisable) why = "intra mode restrictions";
+    else if (!p->FastCrIntraDecision) why = "FastCrIntraDecision = 0";
+    else if (p->SkipIntraInInterSlices || p->SelectiveIntraEnable || p->RandomIntraMBRefresh || p->intra_upd || p->CtxAdptLagrangeMult) why = "intra refresh / selective intra / CtxAdptLagrangeMult";
+    else if (p->NumberBFrames != 0 || p->sp_periodicity != 0) why = "B or SP pictures";
+    else if (p->full_search != 2) why = "RestrictSearchRange != 2";
+    else if (p->num_of_views != 1 || p->separate_colour_plane_flag) why = "MVC / separate colour planes";
+    else if (!p->InterSearch[0][0][0]) why = "PSliceSkip = 0";
+    else if (p->HierarchicalCoding || p->PicInterlace != FRAME_CODING || p->MbInterlace != FRAME_CODING) why = "hierarchical / interlaced coding";
+    else if (R < 1 || R > 32) why = "SearchRange outside 1..32";
+    else if (p_Vid->max_num_references > JMHIP_MB_MAX_REF) why = "more than 16 references";
+    else if ((size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
+    else if (p_Vid->bitdepth_chroma_qp_scale != 0) why = "chroma QP scale";
+    P.ok = why == NULL;
+    if (P.ok) {
+      P.recs = (jmhip_mb_record *)malloc((size_t)p_Vid->PicSizeInMbs * sizeof(jmhip_mb_record));
+      if (!P.recs) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+    } else if (G.part_mbpipe && p->rdopt == 0)
+      fprintf(stderr, "jmhip adapter: macroblock pipeline not used (%s): JM's own encode_one_macroblock_low runs\n", why);
+  }
+  return P.ok;
+}
+
+/* (level, run) list of JM from levels at their scan positions */
+static void list_from_dense(const int16_t *dense, int first, int n, int *level, int *run)
+{
+  int k, c = 0, r = 0;
+  for (k = first; k < n; k++) {
+    if (dense[k]) { level[c] = dense[k]; run[c] = r; c++; r = 0; }
+    else r++;
+  }
+  level[c] = 0; run[c] = 0;
+}
+
+static void pipe_run_slice(Macroblock *currMB)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  InputParameters *p_Inp = currMB->p_Inp;
+  QuantParameters *p_Quant = p_Vid->p_Quant;
+  jmhip_slice_params prm;
+  RD_PARAMS enc_mb;
+  const int first = currMB->mbAddrX, left = (int)p_Vid->PicSizeInMbs - first;
+  int r, rc, intra, uv, j, i, m;
+  double t0 = now_s();
+  if (P.pic != p_Vid->enc_picture || first == 0) {          /* a new picture: its source planes go up once */
+    P.pic = p_Vid->enc_picture; P.mbs = 0; P.deblocked = 0;
+    rc = jmhip_set_current_planes(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
+                                  p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0]));
+    if (rc) adapter_die("jmhip_set_current_planes", rc);
+    G.n_cur++;
+  }
+  memset(&prm, 0, sizeof prm);
+  init_enc_mb_params(currMB, &enc_mb, currSlice->slice_type == I_SLICE);
+  prm.slice_type = currSlice->slice_type;
+  prm.first_mb = first;
+  prm.num_mb = p_Inp->slice_mode == FIXED_MB ? imin(p_Inp->slice_argument, left) : left;
+  prm.slice_nr = currMB->slice_nr;
+  prm.qp = currMB->qp; prm.qpc = currMB->qpc[0];
+  if (currMB->qpc[0] != currMB->qpc[1]) { fprintf(stderr, "jmhip adapter: macroblock pipeline: different chroma QPs\n"); exit(70); }
+  prm.search_range = p_Vid->searchRange.max_x >> 2;
+  prm.num_ref = currSlice->slice_type == I_SLICE ? 0 : currSlice->listXsize[LIST_0];
+  for (r = 0; r < prm.num_ref; r++) {
+    prm.ref_slot[r] = slot_with_chroma(currSlice->listX[LIST_0][r]);
+    prm.ref_id[r] = prm.ref_slot[r];
+  }
+  for (m = 0; m < 3; m++) prm.lambda_mf[m] = enc_mb.lambda_mf[m];
+  prm.lambda_mdfp = enc_mb.lambda_mdfp;
+  prm.max_mvd = p_Vid->max_mvd;
+  prm.mv_limit[0] = p_Vid->MaxHmvR[4]; prm.mv_limit[1] = p_Vid->MaxHmvR[5]; prm.mv_limit[2] = p_Vid->MaxVmvR[4]; prm.mv_limit[3] = p_Vid->MaxVmvR[5];
+  for (m = 0; m < 8; m++) prm.inter_valid[m] = enc_mb.valid[m];
+  prm.intra4_valid = enc_mb.valid[I4MB]; prm.intra16_valid = enc_mb.valid[I16MB];
+  prm.subpel = !p_Inp->DisableSubpelME[0];
+  prm.start_qp = p_Vid->start_me_refinement_qp;
+  if (p_Vid->start_me_refinement_hp != 0) { fprintf(stderr, "jmhip adapter: macroblock pipeline: start_me_refinement_hp != 0\n"); exit(70); }
+  for (r = 0; r < JMHIP_MB_MAX_REF; r++) prm.refbits[r] = p_Vid->refbits[r];   /* at least 31 entries (mv_search.c:323-345); the sub-macroblock types' cost reads [0..3] */
+  for (intra = 0; intra < 2; intra++)
+    for (j = 0; j < 4; j++)
+      for (i = 0; i < 4; i++) {
+        const LevelQuantParams *q = &p_Quant->q_params_4x4[0][intra][currMB->qp_scaled[0]][j][i];
+        prm.q_luma[intra][j * 4 + i].OffsetComp = q->OffsetComp; prm.q_luma[intra][j * 4 + i].ScaleComp = q->ScaleComp; prm.q_luma[intra][j * 4 + i].InvScaleComp = q->InvScaleComp;
+        for (uv = 0; uv < 2; uv++) {
+          q = &p_Quant->q_params_4x4[uv + 1][intra][currMB->qpc[uv] + currSlice->bitdepth_chroma_qp_scale][j][i];
+          prm.q_chroma[uv][intra][j * 4 + i].OffsetComp = q->OffsetComp; prm.q_chroma[uv][intra][j * 4 + i].ScaleComp = q->ScaleComp; prm.q_chroma[uv][intra][j * 4 + i].InvScaleComp = q->InvScaleComp;
+        }
+      }
+  prm.df_disable_idc = currMB->DFDisableIdc; prm.df_alpha_c0 = currMB->DFAlphaC0Offset; prm.df_beta = currMB->DFBetaOffset;
+  if (currMB->qp_scaled[0] != currMB->qp) { fprintf(stderr, "jmhip adapter: macroblock pipeline: luma QP scale\n"); exit(70); }
+  if ((rc = jmhip_encode_slice(G.ctx, &prm, P.recs + first))) adapter_die("jmhip_encode_slice", rc);
+  P.n_slices++; P.n_refs += prm.num_ref;
+  P.t_dev += now_s() - t0;
+}
+
+/* one macroblock's record into what write_macroblock (macroblock.c:2810), the MV predictor of later macroblocks and JM's statistics read */
+static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  PicMotionParams **motion = p_Vid->enc_picture->mv_info;
+  const int mbt = r->mb_type, intra = mbt >= I4MB;
+  int k, j, i, uv;
+  currMB->mb_type = (short)mbt;
+  currMB->best_mode = (short)(mbt == 0 ? 1 : mbt);
+  currMB->ar_mode = currMB->best_mode;
+  currMB->cbp = r->cbp; currMB->cbp_blk = (int64)r->cbp_blk;
+  currMB->luma_transform_size_8x8_flag = FALSE;
+  currMB->i16mode = r->i16mode;
+  currMB->i16offset = mbt == I16MB ? I16Offset(r->cbp, r->i16mode) : 0;
+  currMB->c_ipred_mode = intra ? r->c_ipred_mode : DC_PRED_8;
+  currMB->min_rdcost = (distblk)r->min_rdcost;
+  for (k = 0; k < 4; k++) {
+    currMB->b8x8[k].mode = r->b8mode[k]; currMB->b8x8[k].pdir = (char)(intra ? -1 : 0);
+    currMB->b8x8[k].ref[LIST_0] = r->b8ref[k]; currMB->b8x8[k].ref[LIST_1] = -1; currMB->b8x8[k].bipred = 0;
+  }
+  memcpy(currMB->intra_pred_modes, r->ipred_syntax, 16);
+  for (j = 0; j < 4; j++)
+    for (i = 0; i < 4; i++) {
+      PicMotionParams *mp = &motion[currMB->block_y + j][currMB->block_x + i];
+      const int ref = intra ? -1 : r->b8ref[(j >> 1) * 2 + (i >> 1)];
+      p_Vid->ipredmode[currMB->block_y + j][currMB->block_x + i] = r->ipredmode[j * 4 + i];
+      mp->mv[LIST_0].mv_x = r->mv[j * 4 + i][0]; mp->mv[LIST_0].mv_y = r->mv[j * 4 + i][1];
+      mp->ref_idx[LIST_0] = (char)ref; mp->ref_pic[LIST_0] = ref < 0 ? NULL : currSlice->listX[LIST_0][ref];
+      mp->mv[LIST_1].mv_x = mp->mv[LIST_1].mv_y = 0; mp->ref_idx[LIST_1] = -1; mp->ref_pic[LIST_1] = NULL;
+    }
+  for (k = 0; k < 16; k++) list_from_dense(r->luma[k], mbt == I16MB ? 1 : 0, 16, currSlice->cofAC[k >> 2][k & 3][0], currSlice->cofAC[k >> 2][k & 3][1]);
+  list_from_dense(r->luma_dc, 0, mbt == I16MB ? 16 : 0, currSlice->cofDC[0][0], currSlice->cofDC[0][1]);
+  for (uv = 0; uv < 2; uv++) {
+    list_from_dense(r->chroma_dc[uv], 0, 4, currSlice->cofDC[uv + 1][0], currSlice->cofDC[uv + 1][1]);
+    for (k = 0; k < 4; k++) list_from_dense(r->chroma_ac[uv][k], 1, 16, currSlice->cofAC[4 + uv][k][0], currSlice->cofAC[4 + uv][k][1]);
+  }
+}
+
+extern void __real_encode_one_macroblock_low(Macroblock *);
+void __wrap_encode_one_macroblock_low(Macroblock *currMB)
+{
+  Slice *currSlice = currMB->p_Slice;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  double t0;
+  if (!adapter_on(p_Vid) || !pipe_config_ok(p_Vid) || (currSlice->slice_type != P_SLICE && currSlice->slice_type != I_SLICE) ||
+      currSlice->mb_aff_frame_flag || p_Vid->structure != FRAME) {
+    if (P.n_slices) { fprintf(stderr, "jmhip adapter: macroblock pipeline: a slice outside its scope after %ld slices on the device\n", P.n_slices); exit(70); }
+    G.n_passed++;
+    __real_encode_one_macroblock_low(currMB);
+    return;
+  }
+  if (currMB->mbAddrX == currSlice->start_mb_nr) pipe_run_slice(currMB);
+  t0 = now_s();
+  mb_from_record(currMB, &P.recs[currMB->mbAddrX]);
+  P.t_fill += now_s() - t0;
+  P.mbs++; P.n_mbs++;
+}
+
+/* DeblockFrame / getSubImagesLuma / getSubImagesChroma of a picture the pipeline encoded: 1 = served here */
+static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
+{
+  int rc;
+  double t0 = now_s();
+  if (!P.ok || P.pic != p_Vid->enc_picture || imgY != p_Vid->enc_picture->imgY || P.mbs != (int)p_Vid->PicSizeInMbs) return 0;
+  if ((rc = jmhip_deblock_picture_dev(G.ctx, p_Vid->active_sps->direct_8x8_inference_flag))) adapter_die("jmhip_deblock_picture_dev", rc);
+  if ((rc = jmhip_get_recon(G.ctx, imgY[0], (int)(imgY[1] - imgY[0]), imgUV[0][0], imgUV[1][0], (int)(imgUV[0][1] - imgUV[0][0])))) adapter_die("jmhip_get_recon", rc);
+  P.deblocked = 1;
+  G.n_deblock++;
+  P.t_dev += now_s() - t0;
+  return 1;
+}
+static int pipe_reference(StorablePicture *s)
+{
+  int k, rc;
+  double t0 = now_s();
+  if (!P.ok || P.pic != s || !P.deblocked) return 0;
+  k = slot_take(s);
+  if ((rc = jmhip_reference_from_recon(G.ctx, k))) adapter_die("jmhip_reference_from_recon", rc);
+  G.slot_chroma[k] = 2;                                     /* on the device, and nobody on the host needs the sub-images */
+  G.n_interp++;
+  P.t_dev += now_s() - t0;
+  return 1;
+}
+static void pipe_report(void)
+{
+  if (P.n_slices)
+    fprintf(stderr, "jmhip adapter: macroblock pipeline: %ld slices, %ld macroblocks encoded on the MI355X (encode_one_macroblock_low never ran on the host); "
+                    "device calls %.3f s, unpacking records %.3f s\n", P.n_slices, P.n_mbs, P.t_dev, P.t_fill);
 }

@@ -68,6 +68,27 @@ extern "C" int jmhip_set_current_frame(jmhip_ctx *ctx, const uint8_t *raw, int32
   return JMHIP_OK;
 }
 
+// the current picture from imgpel planes that already have the coded size (p_Vid->pCurImg = pImgOrg[0], pImgOrg[1], pImgOrg[2] after pad_borders)
+extern "C" int jmhip_set_current_planes(jmhip_ctx *ctx, const uint16_t *y, int32_t pitch_y, const uint16_t *u, const uint16_t *v, int32_t pitch_c)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  const int fmt = ctx->cfg.yuv_format;
+  if (!y || pitch_y < ctx->W || (fmt && (!u || !v || pitch_c < ctx->cw))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_current_planes: bad argument");
+  const size_t ny = (size_t)ctx->W * ctx->H, nc = (size_t)ctx->cw * ctx->ch;
+  if (ny + 2 * nc > ctx->h_stage_bytes) return jmhip_fail(ctx, JMHIP_ENOMEM, "jmhip_set_current_planes: staging area too small");
+  if (fmt && !ctx->d_cur_c) HIPCHK(ctx, hipMalloc((void **)&ctx->d_cur_c, 2 * nc));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));            // the staging area may still be in flight
+  uint8_t *st = ctx->h_stage;
+  for (int j = 0; j < ctx->H; j++) { const uint16_t *s = y + (size_t)j * pitch_y; uint8_t *d = st + (size_t)j * ctx->W; for (int i = 0; i < ctx->W; i++) d[i] = (uint8_t)s[i]; }
+  for (int k = 0; k < (fmt ? 2 : 0); k++) {
+    const uint16_t *src = k ? v : u;
+    for (int j = 0; j < ctx->ch; j++) { const uint16_t *s = src + (size_t)j * pitch_c; uint8_t *d = st + ny + k * nc + (size_t)j * ctx->cw; for (int i = 0; i < ctx->cw; i++) d[i] = (uint8_t)s[i]; }
+  }
+  HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_cur, ctx->cur_pitch, st, ctx->W, ctx->W, ctx->H, hipMemcpyHostToDevice, ctx->stream));
+  if (fmt) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cur_c, st + ny, 2 * nc, hipMemcpyHostToDevice, ctx->stream));
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_current_planes_dev(jmhip_ctx *ctx, const uint8_t **d_y, int32_t *pitch_y, const uint8_t **d_u, const uint8_t **d_v, int32_t *pitch_c)
 {
   if (!ctx) return JMHIP_EINVAL;

@@ -92,7 +92,7 @@ assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.items
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
 EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_set_stream", "jmhip_plane_geometry",
-           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_current_frame", "jmhip_set_current_frame_dev", "jmhip_current_planes_dev", "jmhip_get_current_planes", "jmhip_set_reference", "jmhip_set_reference_dev",
+           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_current_frame", "jmhip_set_current_frame_dev", "jmhip_set_current_planes", "jmhip_current_planes_dev", "jmhip_get_current_planes", "jmhip_set_reference", "jmhip_set_reference_dev",
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",

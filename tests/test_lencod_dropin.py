@@ -110,6 +110,81 @@ def test_lencod_configs1_full_size_1080p(tmp_path):
         print(f"P frame with the hot path on the device (per-call offload): {m.group(1)} ms total, {m.group(2)} ms ME")
 
 
+def run_rdo_off_case(tag, tmp, exe=EXE, env_extra=None, frames=None):
+    """lencod with the overrides of tests/golden/mb_low_<tag>.npz (RDOptimization = 0: the macroblock pipeline's configurations)"""
+    import numpy as np
+    z = np.load(os.path.join(G, f"mb_low_{tag}.npz"))
+    ov = dict(s.split("=") for s in z["overrides"])
+    if frames:
+        ov["FramesToBeEncoded"] = str(frames)
+    for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
+        shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
+    if tag == "g2r":
+        import sys
+        sys.path.insert(0, ROOT)
+        import bench
+        bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), int(ov["FramesToBeEncoded"]))
+    args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+    for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
+        args += ["-p", f"{k}={v}"]
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run(args, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    return r, z
+
+
+def pipeline_report(stderr):
+    m = re.search(r"macroblock pipeline: (\d+) slices, (\d+) macroblocks encoded on the MI355X .*device calls ([\d.]+) s, unpacking records ([\d.]+) s", stderr)
+    return None if not m else dict(slices=int(m.group(1)), mbs=int(m.group(2)), t_dev=float(m.group(3)), t_fill=float(m.group(4)))
+
+
+def frame_times(stdout):
+    """{frame type: [total ms per frame]} from lencod's per-frame lines"""
+    out = {}
+    for m in re.finditer(r"^\s*\d+\(\s*(IDR|I|P)\s*\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", stdout, re.M):
+        out.setdefault("I" if m.group(1) != "P" else "P", []).append(int(m.group(2)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,nmb_total", [("q1r", 297), ("q5r", 297), ("q4r", 297), ("q4s", 297)])
+def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
+    """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
+    JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction
+    must equal CPU JM's (md5s inside tests/golden/mb_low_*.npz, from the unmodified encoder).  One / five references, three slices, slices that
+    start mid-row with DFDisableIdc = 2."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing: run __graft_entry__.build() where /root/reference exists")
+    r, z = run_rdo_off_case(tag, str(tmp_path))
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
+    rep = pipeline_report(err)
+    c = counters(err)
+    assert rep and rep["mbs"] == nmb_total, (rep, err[-1500:])
+    assert c["passed"] == 0 and c["fs"] == 0 and c["subpel"] == 0 and c["tq4"] == 0, c        # nothing per block, nothing on the host
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), (tag, "bitstream differs from CPU JM", rep)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), (tag, "reconstruction differs from CPU JM", rep)
+
+
+@pytest.mark.gpu
+def test_lencod_macroblock_pipeline_configs1_full_size_1080p(tmp_path):
+    """BASELINE.json configs[1] with RDOptimization = 0 end to end: .264 md5 04ce4cdee722defe8c3c7c0b249eda7e, zero
+    per-block calls, and the P picture's wall time as lencod itself prints it."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, z = run_rdo_off_case("g2r", str(tmp_path))
+    err, out = r.stderr.decode(errors="replace"), r.stdout.decode(errors="replace")
+    assert r.returncode == 0, (out[-1500:], err[-1500:])
+    rep = pipeline_report(err)
+    c = counters(err)
+    assert rep and rep["mbs"] == 2 * 8160 and rep["slices"] == 2, (rep, err[-1500:])
+    assert c["passed"] == 0 and c["fs"] == 0 and c["subpel"] == 0, c
+    assert str(z["md5_264"]) == "04ce4cdee722defe8c3c7c0b249eda7e"
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
+    print(f"configs[1], RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
+
+
 def test_adapter_fails_loudly_without_a_device(tmp_path):
     """not gpu: on a box without a HIP device the adapter must stop the encoder, not fall back to the CPU."""
     import torch
