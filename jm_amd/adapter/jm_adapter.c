@@ -73,6 +73,8 @@ static struct {
 } G;
 
 static void pipe_report(void);
+static double now_s(void);
+static double T_slice, T_pad, T_deblock, T_interp;
 static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV);
 static int pipe_reference(StorablePicture *s);
 
@@ -195,7 +197,7 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
 {
   int rc, k, j, i, y;
   const int Wp = s->size_x + 2 * JMHIP_PAD_X, Hp = s->size_y + 2 * JMHIP_PAD_Y;
-  if (adapter_on(p_Vid) && pipe_reference(s)) return;       /* the macroblock pipeline's picture: the planes are made on the device and stay there */
+  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_reference(s)) { T_interp += now_s() - t0_; return; } }   /* the macroblock pipeline's picture: the planes are made on the device and stay there */
   if (!adapter_on(p_Vid) || !G.part_interp || s->size_x != G.W || s->size_y != G.H ||
       s->size_x_padded != Wp || s->size_y_padded != Hp) {
     G.n_passed++;
@@ -250,12 +252,16 @@ void __wrap_getSubImagesChroma(VideoParameters *p_Vid, StorablePicture *s)
 extern int __real_encode_one_slice(VideoParameters *, int, int);
 int __wrap_encode_one_slice(VideoParameters *p_Vid, int SliceGroupId, int TotalCodedMBs)
 {
+  const double t0_ = now_s();
+  int n_;
   if (TotalCodedMBs == 0 && adapter_on(p_Vid) && (G.part_fs || G.part_subpel || G.part_ffs) && p_Vid->structure == FRAME) {
     int rc = jmhip_set_current(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]));
     if (rc) adapter_die("jmhip_set_current", rc);
     G.n_cur++;
   }
-  return __real_encode_one_slice(p_Vid, SliceGroupId, TotalCodedMBs);
+  n_ = __real_encode_one_slice(p_Vid, SliceGroupId, TotalCodedMBs);
+  T_slice += now_s() - t0_;
+  return n_;
 }
 
 /* partition index of the ABI (jmhip.h) from JM's (blocktype, block_x, block_y) with block_* in 4x4 units */
@@ -774,6 +780,7 @@ void __wrap_pad_borders(FrameFormat output, int img_size_x, int img_size_y, int 
     __real_pad_borders(output, img_size_x, img_size_y, img_size_x_cr, img_size_y_cr, pImage);
     return;
   }
+  T_pad -= now_s();
   raw = (uint8_t *)malloc((size_t)sw * sh + (size_t)2 * scw * sch);
   planes = (uint16_t *)malloc(((size_t)G.W * G.H + (size_t)2 * img_size_x_cr * img_size_y_cr + 1) * sizeof(uint16_t));
   if (!raw || !planes) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
@@ -792,6 +799,7 @@ void __wrap_pad_borders(FrameFormat output, int img_size_x, int img_size_y, int 
     }
   }
   free(raw); free(planes);
+  T_pad += now_s();
   G.n_load++;
 }
 
@@ -802,7 +810,7 @@ void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
   StorablePicture *ids[64];
   int nids = 0, rc, x, y, l, k;
   unsigned i;
-  if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) return;
+  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) { T_deblock += now_s() - t0_; return; } }
   if (!adapter_on(p_Vid) || !G.part_deblock || p_Vid->structure != FRAME || p_Vid->mb_aff_frame_flag ||
       (int)p_Vid->PicSizeInMbs != (G.W / 16) * (G.H / 16)) {
     G.n_passed++;
@@ -1297,5 +1305,6 @@ static void pipe_report(void)
 {
   if (P.n_slices)
     fprintf(stderr, "jmhip adapter: macroblock pipeline: %ld slices, %ld macroblocks encoded on the MI355X (encode_one_macroblock_low never ran on the host); "
-                    "device calls %.3f s, unpacking records %.3f s\n", P.n_slices, P.n_mbs, P.t_dev, P.t_fill);
+                    "device calls %.3f s, unpacking records %.3f s; wall time inside encode_one_slice %.3f s, pad_borders %.3f s, DeblockFrame %.3f s, getSubImagesLuma %.3f s\n",
+            P.n_slices, P.n_mbs, P.t_dev, P.t_fill, T_slice, T_pad, T_deblock, T_interp);
 }

@@ -114,3 +114,29 @@ class YuvExchange:
         torch.index_select(self.gathered, 0, self.idx_y, out=self.out_y)
         torch.index_select(self.gathered, 0, self.idx_c, out=self.out_c)
         return self.out_y, self.out_c[:, : self.width // 2], self.out_c[:, self.width // 2:]
+
+
+class PictureGather:
+    """Every rank holds the whole reconstruction: all-gather of equal bands of a 4:2:0 picture's three planes, one collective per picture.
+
+    The planes are (rows, pitch) uint8 tensors that may alias library memory (the macroblock pipeline's reconstruction); rank r owns
+    luma rows [r * band_rows, (r + 1) * band_rows) and chroma rows [r * band_rows / 2, ...).  pack -> all_gather_into_tensor -> three
+    strided copies back into the planes (the packed buffer keeps the collective's input and output from aliasing)."""
+
+    def __init__(self, y, u, v, world, rank, group=None):
+        self.y, self.u, self.v, self.world, self.rank, self.group = y, u, v, world, rank, group
+        assert y.shape[0] % world == 0 and u.shape[0] % world == 0 and v.shape == u.shape, (y.shape, u.shape, v.shape, world)
+        self.ny = (y.shape[0] // world) * y.shape[1]
+        self.nc = (u.shape[0] // world) * u.shape[1]
+        self.own = torch.empty(self.ny + 2 * self.nc, dtype=torch.uint8, device=y.device)
+        self.all = torch.empty((world, self.ny + 2 * self.nc), dtype=torch.uint8, device=y.device)
+
+    def __call__(self):
+        r, ny, nc = self.rank, self.ny, self.nc
+        self.own[:ny].copy_(self.y.view(self.world, ny)[r])
+        self.own[ny:ny + nc].copy_(self.u.view(self.world, nc)[r])
+        self.own[ny + nc:].copy_(self.v.view(self.world, nc)[r])
+        dist.all_gather_into_tensor(self.all.view(-1), self.own, group=self.group)
+        self.y.view(self.world, ny).copy_(self.all[:, :ny])
+        self.u.view(self.world, nc).copy_(self.all[:, ny:ny + nc])
+        self.v.view(self.world, nc).copy_(self.all[:, ny + nc:])

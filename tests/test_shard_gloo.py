@@ -120,3 +120,38 @@ def test_slice_argument_matches_jm_config():
     bands = [shard.band_of(r, 8, 135) for r in range(8)]
     assert [b.mb_rows for b in bands] == [17] * 7 + [16]
     assert shard.halo_rows(32, 512) == 576
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows, pitch, cw = 32 * world, 64, 24
+        full = [_full_picture(rows, pitch, 3), _full_picture(rows // 2, cw, 4), _full_picture(rows // 2, cw, 5)]
+        mine = [torch.zeros(p.shape, dtype=torch.uint8) for p in full]
+        for p, m in zip(full, mine):                                     # each rank starts with its own band only
+            b = p.shape[0] // world
+            m[rank * b:(rank + 1) * b] = torch.from_numpy(p[rank * b:(rank + 1) * b])
+        g = shard.PictureGather(mine[0], mine[1], mine[2], world, rank)
+        ok = True
+        for rep in range(2):
+            g()
+            ok &= all(bool((m.numpy() == p).all()) for p, m in zip(full, mine))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_picture_gather_gloo(world):
+    """bench.py's N > 1 exchange: after one collective every rank holds the whole reconstruction (all three planes)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
