@@ -47,6 +47,7 @@ struct jmhip_ctx {
   void *d_mb_records;    // jmhip_mb_record per macroblock of the picture
   void *d_mb_dbmb, *d_mb_dbmo;   // loop-filter side information written by the pipeline
   void *h_mb_records;    // pinned host staging for jmhip_encode_slice
+  void *d_mb_prof;       // JMHIP_MB_PROF=1: time stamps per macroblock
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];

@@ -63,6 +63,7 @@ struct PipeArgs {
   jmhip_mb_record *records;
   jmhip_db_mb *dbmb;
   jmhip_db_motion *dbmo;
+  unsigned long long *prof;                  // profiling aid (JMHIP_MB_PROF=1): 24 time stamps (100 MHz) per macroblock, or null
 };
 
 // per-workgroup state in LDS
@@ -101,6 +102,8 @@ struct Shared {
   jmhip_mb_record out;
 };
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// a value every lane of the wave holds alike, moved to a scalar register (loop bounds, addresses and branches on it become scalar)
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ u64 ld_sc1(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -112,23 +115,23 @@ __device__ __forceinline__ bool mvinfo_at(const Shared &S, int wave, int x4, int
 {
   u64 w;
   if (x4 < 0) {
-    if (y4 < 0) { if (!S.avail[3]) return false; w = S.nb[3][9 + 3]; }
-    else if (y4 < 4) { if (!S.avail[0]) return false; w = S.nb[0][13 + y4]; }
+    if (y4 < 0) { if (!rfl(S.avail[3])) return false; w = S.nb[3][9 + 3]; }
+    else if (y4 < 4) { if (!rfl(S.avail[0])) return false; w = S.nb[0][13 + y4]; }
     else return false;
   } else if (x4 < 4) {
-    if (y4 < 0) { if (!S.avail[1]) return false; w = S.nb[1][9 + x4]; }
-    else if (y4 < 4) { mv = S.mvi[wave][y4 * 4 + x4][0]; ref = S.mvi[wave][y4 * 4 + x4][1]; return true; }
+    if (y4 < 0) { if (!rfl(S.avail[1])) return false; w = S.nb[1][9 + x4]; }
+    else if (y4 < 4) { mv = rfl(S.mvi[wave][y4 * 4 + x4][0]); ref = rfl(S.mvi[wave][y4 * 4 + x4][1]); return true; }
     else return false;
   } else {
-    if (y4 < 0) { if (!S.avail[2]) return false; w = S.nb[2][9 + 0]; }
+    if (y4 < 0) { if (!rfl(S.avail[2])) return false; w = S.nb[2][9 + 0]; }
     else return false;
   }
-  mv = (int)(u32)w; ref = (int)(int8_t)(w >> 32);
+  mv = rfl((int)(u32)w); ref = rfl((int)(int8_t)(w >> 32));
   return true;
 }
 
 // get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325)
-__device__ int mv_predictor(const Shared &S, int wave, int ref, int mb_x, int mb_y, int bsx, int bsy)
+__device__ __forceinline__ int mv_predictor(const Shared &S, int wave, int ref, int mb_x, int mb_y, int bsx, int bsy)
 {
   int mv[3] = {0, 0, 0}, rf[3] = {-1, -1, -1};
   bool av[3];
@@ -162,7 +165,7 @@ __device__ int mv_predictor(const Shared &S, int wave, int ref, int mb_x, int mb
 }
 
 // FindSkipModeMotionVector mv_search.c:1333-1405
-__device__ int skip_vector(const Shared &S, int wave)
+__device__ __forceinline__ int skip_vector(const Shared &S, int wave)
 {
   int mA = 0, rA = -1, mB = 0, rB = -1;
   const bool a = mvinfo_at(S, wave, -1, 0, mA, rA), b = mvinfo_at(S, wave, 0, -1, mB, rB);
@@ -199,7 +202,7 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
 template <int BW, int BH>
-__device__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane)
+__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane)
 {
   u32 cb[BH][BW / 4];
 #pragma unroll
@@ -213,7 +216,12 @@ __device__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, co
     const bool live = lane < ncol;
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
     const u8 *colp = win + (xl & ~3);
-    const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
+    const int vx = c.cqx + 4 * dx;
+    const u32 rate_x = (u32)(c.lambda * mvbits(vx - c.pqx));
+    // The column keeps (cost, row) of its best candidate; a candidate replaces it on a smaller cost, and on an equal cost only if it comes
+    // earlier in JM's spiral (strict '<' in spiral order, me_fullsearch.c:89) -- the spiral index is worked out on ties only.
+    u32 bcost = 0xffffffffu;
+    int brow = 0;
     u32 acc[BH];
 #pragma unroll
     for (int k = 0; k < BH; k++) acc[k] = 0;
@@ -225,20 +233,29 @@ __device__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, co
         load_row<BW>(colp + (Y0 + (j < nrows ? j : nrows - 1)) * WP, sh, b);
 #pragma unroll
         for (int r = 0; r < BH; r++) {                         // window row j is row r of the candidate that starts at row j - r
-          constexpr int dummy = 0; (void)dummy;
           const int k = (s - r + BH) % BH;
           u32 v = r == 0 ? 0u : acc[k];
 #pragma unroll
           for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
           acc[k] = v;
         }
-        const int i = j - (BH - 1);                            // the candidate that ends with this row
-        if (live && i >= 0 && i <= 2 * Rs) {
-          const u64 key = fs_key(c, (int)acc[(s + 1) % BH], dx, i - Rs, bits_x);
-          best = key < best ? key : best;
+        const int i = j - (BH - 1);                            // the candidate that ends with this row (the same for every lane)
+        if (i >= 0 && i <= 2 * Rs) {
+          const int vy = c.cqy + 4 * (i - Rs);
+          const u32 rate_y = (u32)(c.lambda * mvbits(vy - c.pqy));
+          u32 rate = rate_x + rate_y;
+          if (c.check00 && vy == 0 && vx == 0) rate = rate > 16u * (u32)c.lambda ? rate - 16u * (u32)c.lambda : 0u;      // me_fullsearch.c:78-82
+          u32 cost = (acc[(s + 1) % BH] << 5) + rate;
+          cost = live ? cost : 0xffffffffu;
+          const bool tie = cost == bcost && live;
+          if (cost < bcost) { bcost = cost; brow = i; }
+          if (__builtin_amdgcn_ballot_w64(tie) != 0) {
+            if (tie && spiral_index(dx, i - Rs) < spiral_index(dx, brow - Rs)) brow = i;
+          }
         }
       }
     }
+    if (live) best = ((u64)bcost << 32) | ((u64)spiral_index(dx, brow - Rs) << 16) | (u64)(((brow - Rs + 128) << 8) | (dx + 128));
   }
   for (int col = 64; col < ncol; col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
@@ -299,7 +316,7 @@ __device__ __forceinline__ void ref_rows4(const PipeArgs &A, int ref, int qx, in
 __device__ const int8_t c_sp9[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
 
 // one stage of sub_pel_motion_estimation (me_fullsearch.c:221-246 / :263-281): the nine SATDs around mv with the given step, into S.red[wave][0..8]
-__device__ void subpel_satds(Shared &S, const PipeArgs &A, int wave, int lane, int ref, int px, int py, int mb_x, int mb_y, int bw4, int bh4, int mv, int step)
+__device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int wave, int lane, int ref, int px, int py, int mb_x, int mb_y, int bw4, int bh4, int mv, int step)
 {
   const int nb4 = bw4 * bh4, items = 9 * nb4;
   for (int base = 0; base < items; base += 64) {
@@ -319,14 +336,18 @@ __device__ void subpel_satds(Shared &S, const PipeArgs &A, int wave, int lane, i
 }
 
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
-__device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wave, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
+__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wave, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
 {
   const jmhip_slice_params &P = A.p;
   const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
-  const int mbx = S.addr % A.wmb, mby = S.addr / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
+  const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const int pred = mv_predictor(S, wave, ref, mb_x, mb_y, BW, BH);
+  const bool prof_ = A.prof && bt == 7 && mb_x == 0 && mb_y == 0 && ref == 0 && lane == 0;
+#define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 24 + (k)] = wall_clock64(); } while (0)
+  BS_STAMP(18);
+  const int pred = rfl(mv_predictor(S, wave, ref, mb_x, mb_y, BW, BH));
+  BS_STAMP(19);
   int cx = ((mvx(pred) + 2) >> 2) * 4, cy = ((mvy(pred) + 2) >> 2) * 4;          // mv_search.c:931-932
   int min_x = -(R << 2), max_x = R << 2, min_y = min_x, max_y = max_x;
   {
@@ -364,8 +385,10 @@ __device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wa
   case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
   default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane); break;
   }
-  int mv = mvpack(cx + 4 * ((int)(key & 255) - 128), cy + 4 * ((int)((key >> 8) & 255) - 128));
-  int min_mcost = (int)(key >> 32);
+  const int klo = rfl((int)(u32)key), khi = rfl((int)(u32)(key >> 32));
+  BS_STAMP(20);
+  int mv = mvpack(cx + 4 * ((klo & 255) - 128), cy + 4 * (((klo >> 8) & 255) - 128));
+  int min_mcost = khi;
 
   if (P.subpel) {                                             // sub_pel_motion_estimation me_fullsearch.c:186-289 (start_me_refinement_hp = 0)
     const int check0 = ref == 0 && bt == 1 && mv == 0;
@@ -376,11 +399,12 @@ __device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wa
       const int qx = mvx(mv) + 2 * c_sp9[pos][0], qy = mvy(mv) + 2 * c_sp9[pos][1];
       int mcost = P.lambda_mf[1] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
       if (mcost >= min_mcost) continue;
-      mcost += S.red[wave][pos] << 5;
+      mcost += rfl(S.red[wave][pos]) << 5;
       if (pos == 0 && check0) mcost -= P.lambda_mf[1] * 16;
       if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
     }
     mv = mvpack(mvx(mv) + 2 * c_sp9[best][0], mvy(mv) + 2 * c_sp9[best][1]);
+    BS_STAMP(21);
     subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
     if (!P.start_qp) min_mcost = MAXC;
     best = 0;
@@ -388,7 +412,7 @@ __device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wa
       const int qx = mvx(mv) + c_sp9[pos][0], qy = mvy(mv) + c_sp9[pos][1];
       int mcost = P.lambda_mf[2] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
       if (mcost >= min_mcost) continue;
-      mcost += S.red[wave][pos] << 5;
+      mcost += rfl(S.red[wave][pos]) << 5;
       if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
     }
     mv = mvpack(mvx(mv) + c_sp9[best][0], mvy(mv) + c_sp9[best][1]);
@@ -396,7 +420,7 @@ __device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wa
   mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
 
   if (bt == 1 && P.slice_type == 0) {                          // the skip vector against the 16x16 result: mv_search.c:983-998, GetSkipCostMB :1257
-    const int sv = skip_vector(S, wave);
+    const int sv = rfl(skip_vector(S, wave));
     if (lane == 0) S.skip_mv = sv;
     const int qx = (mbx * 64) + mvx(sv), qy = (mby * 64) + mvy(sv);
     const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);     // one origin for the 16x16 block
@@ -407,10 +431,11 @@ __device__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wa
     for (int j = 0; j < 4; j++) { r[j] = ldu32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
     int v = lane < 16 ? satd4_rows(o, r) : 0;
     for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-    v = __shfl(v, 0, 64);
+    v = rfl(v);
     const int cost = (v << 5) - P.lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = sv; }
   }
+  BS_STAMP(22);
   out_mv = mv;
   return min_mcost;
 }
@@ -426,12 +451,12 @@ __device__ __forceinline__ void set_mvi(Shared &S, int wave, int lane, int mv, i
 }
 
 // list_prediction_cost (mode_decision.c:275, LIST_0) with update_mcost (:253)
-__device__ int list0_cost(const Shared &S, const jmhip_slice_params &P, int mode, int block, int &bref)
+__device__ __forceinline__ int list0_cost(const Shared &S, const jmhip_slice_params &P, int mode, int block, int &bref)
 {
   const int ref_lambda = P.lambda_mf[2] >> 2;
   int bm = MAXC;
   for (int ref = 0; ref < P.num_ref; ref++) {
-    int mc = S.mcost[mode][ref][block];
+    int mc = rfl(S.mcost[mode][ref][block]);
     if (mc < bm) {
       mc += P.num_ref <= 1 ? 0 : ref_lambda * P.refbits[ref];
       if (mc < bm) { bm = mc; bref = ref; }

@@ -1,0 +1,34 @@
+"""Where a macroblock's time goes inside k_mb_pipe (JMHIP_MB_PROF=1: 100 MHz time stamps per macroblock), configs[1] P picture.  gpu only."""
+import os, sys, ctypes as C
+os.environ["JMHIP_MB_PROF"] = "1"
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import bench, tempfile
+from test_gpu_mbenc import DevSeqEncoder, load_case
+c = load_case("g2r")
+with tempfile.TemporaryDirectory() as t:
+    bench.write_yuv(os.path.join(t, "s.yuv"), 2)
+    data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+fs = c["sw"] * c["sh"] * 3 // 2
+enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
+nmb = 8160
+for n in range(2):
+    tm = []
+    recs, pre, post = enc.encode(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], timing=tm)
+    st = np.zeros((nmb, 24), np.uint64)
+    assert enc.J.lib.jmhip_debug_read_mb_prof(enc.J.h, st.ctypes.data_as(C.c_void_p), st.nbytes) == 0
+    st = st.astype(np.int64)
+    us = lambda a, b: (st[:, b] - st[:, a]) / 100.0
+    print(f"picture {n}: kernel {tm[0]:.1f} ms; per macroblock (median / mean us):")
+    for name, a, b in [("ticket -> neighbours done + staged", 0, 1), ("edge records", 1, 2), ("phase 0 (8x8 block 0 + modes 1-3 + intra)", 2, 3), ("phase 1", 3, 4), ("phase 2", 4, 5),
+                       ("phase 3", 5, 6), ("decision + coding the winner", 6, 16), ("publish", 16, 17), ("whole macroblock", 0, 17), ("after neighbours: edge .. publish", 1, 17)]:
+        d = us(a, b)
+        print(f"  {name:45s} {np.median(d):8.1f} {d.mean():8.1f}")
+    print("  phase 0 per wave (from phase start to the wave's end; waves 0-3: 8x8, 8x4, 4x8, 4x4 of block 0; 4-6: 16x16, 16x8, 8x16; 7: intra):")
+    print("   ", " ".join(f"{np.median((st[:, 8 + w] - st[:, 2]) / 100.0):7.1f}" for w in range(8)))
+    if n == 1:
+        print("  first 4x4 search of the macroblock (wave 3): predictor %.2f, integer search %.2f, half-pel stage %.2f, quarter-pel stage + clip %.2f us (medians)" % tuple(
+            np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
+    span = (st[:, 17].max() - st[:, 0].min()) / 100.0
+    print(f"  first ticket -> last publish {span / 1000:.2f} ms; sum of per-macroblock busy time / span = {us(1, 17).sum() / span:.1f} macroblocks in flight on average")
