@@ -63,6 +63,7 @@ struct PipeArgs {
   jmhip_mb_record *records;
   jmhip_db_mb *dbmb;
   jmhip_db_motion *dbmo;
+  int prof_mode;                             // JMHIP_MB_PROF value: 1 = a 4x4 search's parts in stamps 18..22, 2 = an Intra4x4 block's parts there
   unsigned long long *prof;                  // profiling aid (JMHIP_MB_PROF=1): 24 time stamps (100 MHz) per macroblock, or null
 };
 
@@ -86,7 +87,8 @@ struct Shared {
   int8_t i4_ipm[16], i4_syn[16];
   int16_t i4_lev[16][16];
   u8 i4_rec[256];
-  u8 ip4[9][16];
+  u8 i4p[16], i4val[44], i4tab[144];
+  jmhip_qparam q_luma[2][16], q_chroma[2][2][16];   // the slice's quantiser tables (out of the kernel arguments once per workgroup: LDS reads can be batched)
   int i16_cost, i16_mode;
   u8 e16[36];
   u8 ec[2][20];                              // chroma predictor samples: [0] corner, [1..8] up, [9..16] left
@@ -208,29 +210,37 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
 #pragma unroll
   for (int r = 0; r < BH; r++)
 #pragma unroll
-    for (int k = 0; k < BW / 4; k++) cb[r][k] = __builtin_amdgcn_readfirstlane(cur[r * 4 + k]);
+    for (int k = 0; k < BW / 4; k++) cb[r][k] = BW * BH >= 128 ? cur[r * 4 + k] : (u32)__builtin_amdgcn_readfirstlane(cur[r * 4 + k]);
   const int Rs = c.Rs, ncol = 2 * Rs + 1, nrows = 2 * Rs + BH;
   u64 best = ~0ull;
   {                                                            // columns 0..63: a lane slides down its column
+    // A lane beyond the last column repeats the last column's candidates (same keys: harmless).  The column keeps ONE 32-bit key per
+    // candidate: (cost << 7) | rank, rank = the candidate's place among the column's candidates in JM's spiral order (rows -|dx| .. |dx|
+    // downwards first, then -(|dx| + 1), +(|dx| + 1), ...: mv_search.c:405-442), so that the unsigned minimum is JM's strict '<' scan
+    // restricted to the column.  cost < 2^25: SAD << 5 < 2^21, rate < 2^22 with the lambda the host accepts.
     const int col = lane < ncol ? lane : ncol - 1;
-    const bool live = lane < ncol;
-    const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
-    const u8 *colp = win + (xl & ~3);
+    const int dx = col - Rs, adx = dx < 0 ? -dx : dx, xl = X0 + col, sh = xl & 3;
+    const u8 *p = win + (xl & ~3) + Y0 * WP;
     const int vx = c.cqx + 4 * dx;
     const u32 rate_x = (u32)(c.lambda * mvbits(vx - c.pqx));
-    // The column keeps (cost, row) of its best candidate; a candidate replaces it on a smaller cost, and on an equal cost only if it comes
-    // earlier in JM's spiral (strict '<' in spiral order, me_fullsearch.c:89) -- the spiral index is worked out on ties only.
-    u32 bcost = 0xffffffffu;
-    int brow = 0;
+    const bool zero_x = c.check00 && vx == 0;
+    u32 bkey = 0xffffffffu;
     u32 acc[BH];
 #pragma unroll
     for (int k = 0; k < BH; k++) acc[k] = 0;
-    for (int j0 = 0; j0 < nrows; j0 += BH) {
+    u32 a[BW / 4 + 1], an[BW / 4 + 1];
+#pragma unroll
+    for (int k = 0; k <= BW / 4; k++) a[k] = ((const u32 *)p)[k];
+    for (int j0 = 0; j0 < nrows; j0 += BH) {                   // rows past the last one (a partial final group) lie in the window's slack rows
 #pragma unroll
       for (int s = 0; s < BH; s++) {
         const int j = j0 + s;
+        p += WP;
+#pragma unroll
+        for (int k = 0; k <= BW / 4; k++) an[k] = ((const u32 *)p)[k];      // the next row is on its way while this one is summed
         u32 b[BW / 4];
-        load_row<BW>(colp + (Y0 + (j < nrows ? j : nrows - 1)) * WP, sh, b);
+#pragma unroll
+        for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
 #pragma unroll
         for (int r = 0; r < BH; r++) {                         // window row j is row r of the candidate that starts at row j - r
           const int k = (s - r + BH) % BH;
@@ -241,21 +251,25 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         }
         const int i = j - (BH - 1);                            // the candidate that ends with this row (the same for every lane)
         if (i >= 0 && i <= 2 * Rs) {
-          const int vy = c.cqy + 4 * (i - Rs);
-          const u32 rate_y = (u32)(c.lambda * mvbits(vy - c.pqy));
+          const int dy = i - Rs, ady = dy < 0 ? -dy : dy, vy = c.cqy + 4 * dy;
+          const u32 rate_y = (u32)rfl(c.lambda * mvbits(vy - c.pqy));
+          const int far_rank = 2 * ady - 1 + (dy > 0 ? 1 : 0);
+          const u32 rank = (u32)(ady <= adx ? dy + adx : far_rank);
           u32 rate = rate_x + rate_y;
-          if (c.check00 && vy == 0 && vx == 0) rate = rate > 16u * (u32)c.lambda ? rate - 16u * (u32)c.lambda : 0u;      // me_fullsearch.c:78-82
-          u32 cost = (acc[(s + 1) % BH] << 5) + rate;
-          cost = live ? cost : 0xffffffffu;
-          const bool tie = cost == bcost && live;
-          if (cost < bcost) { bcost = cost; brow = i; }
-          if (__builtin_amdgcn_ballot_w64(tie) != 0) {
-            if (tie && spiral_index(dx, i - Rs) < spiral_index(dx, brow - Rs)) brow = i;
-          }
+          if (c.check00 && vy == 0) { const u32 t = 16u * (u32)c.lambda; rate = zero_x ? (rate > t ? rate - t : 0u) : rate; }       // me_fullsearch.c:78-82
+          const u32 key = (((acc[(s + 1) % BH] << 5) + rate) << 7) | rank;
+          bkey = key < bkey ? key : bkey;
         }
+#pragma unroll
+        for (int k = 0; k <= BW / 4; k++) a[k] = an[k];
       }
     }
-    if (live) best = ((u64)bcost << 32) | ((u64)spiral_index(dx, brow - Rs) << 16) | (u64)(((brow - Rs + 128) << 8) | (dx + 128));
+    {
+      const int rank = (int)(bkey & 127u);
+      const int l = (rank + 1) >> 1;
+      const int dy = rank <= 2 * adx ? rank - adx : ((rank & 1) ? -l : l);
+      best = ((u64)(bkey >> 7) << 32) | ((u64)spiral_index(dx, dy) << 16) | (u64)(((dy + 128) << 8) | (dx + 128));
+    }
   }
   for (int col = 64; col < ncol; col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
@@ -313,7 +327,10 @@ __device__ __forceinline__ void ref_rows4(const PipeArgs &A, int ref, int qx, in
   for (int j = 0; j < 4; j++) r[j] = ldu32(p + (long)j * A.ref_pitch);
 }
 
-__device__ const int8_t c_sp9[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+// spiral positions 0..8 (mv_search.c:405-442): {0,0}, {0,-1}, {0,1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {1,1} as two packed constants (a table in
+// memory would put a global load on every sub-pel stage's critical path)
+__device__ __forceinline__ int sp9x(int k) { return (int)((0x22215u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ int sp9y(int k) { return (int)((0x29421u >> (2 * k)) & 3u) - 1; }
 
 // one stage of sub_pel_motion_estimation (me_fullsearch.c:221-246 / :263-281): the nine SATDs around mv with the given step, into S.red[wave][0..8]
 __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int wave, int lane, int ref, int px, int py, int mb_x, int mb_y, int bw4, int bh4, int mv, int step)
@@ -323,7 +340,7 @@ __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int w
     const int item = base + lane;
     const bool live = item < items;
     const int it = live ? item : 0, cnd = it / nb4, b = it % nb4, sbx = (b % bw4) * 4, sby = (b / bw4) * 4;
-    const int qx = ((px + sbx) << 2) + mvx(mv) + c_sp9[cnd][0] * step, qy = ((py + sby) << 2) + mvy(mv) + c_sp9[cnd][1] * step;
+    const int qx = ((px + sbx) << 2) + mvx(mv) + sp9x(cnd) * step, qy = ((py + sby) << 2) + mvy(mv) + sp9y(cnd) * step;
     u32 r[4], o[4];
     ref_rows4(A, ref, qx, qy, r);
 #pragma unroll
@@ -343,7 +360,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const bool prof_ = A.prof && bt == 7 && mb_x == 0 && mb_y == 0 && ref == 0 && lane == 0;
+  const bool prof_ = A.prof && A.prof_mode == 1 && bt == 7 && mb_x == 0 && mb_y == 0 && ref == 0 && lane == 0;
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 24 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
   const int pred = rfl(mv_predictor(S, wave, ref, mb_x, mb_y, BW, BH));
@@ -396,26 +413,26 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     min_mcost = MAXC;
     int best = 0;
     for (int pos = 0; pos < 9; pos++) {
-      const int qx = mvx(mv) + 2 * c_sp9[pos][0], qy = mvy(mv) + 2 * c_sp9[pos][1];
+      const int qx = mvx(mv) + 2 * sp9x(pos), qy = mvy(mv) + 2 * sp9y(pos);
       int mcost = P.lambda_mf[1] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
       if (mcost >= min_mcost) continue;
       mcost += rfl(S.red[wave][pos]) << 5;
       if (pos == 0 && check0) mcost -= P.lambda_mf[1] * 16;
       if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
     }
-    mv = mvpack(mvx(mv) + 2 * c_sp9[best][0], mvy(mv) + 2 * c_sp9[best][1]);
+    mv = mvpack(mvx(mv) + 2 * sp9x(best), mvy(mv) + 2 * sp9y(best));
     BS_STAMP(21);
     subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
     if (!P.start_qp) min_mcost = MAXC;
     best = 0;
     for (int pos = P.start_qp; pos < 9; pos++) {
-      const int qx = mvx(mv) + c_sp9[pos][0], qy = mvy(mv) + c_sp9[pos][1];
+      const int qx = mvx(mv) + sp9x(pos), qy = mvy(mv) + sp9y(pos);
       int mcost = P.lambda_mf[2] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
       if (mcost >= min_mcost) continue;
       mcost += rfl(S.red[wave][pos]) << 5;
       if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
     }
-    mv = mvpack(mvx(mv) + c_sp9[best][0], mvy(mv) + c_sp9[best][1]);
+    mv = mvpack(mvx(mv) + sp9x(best), mvy(mv) + sp9y(best));
   }
   mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
 
@@ -482,7 +499,6 @@ __device__ __forceinline__ void inverse4x4(int (&m)[16])
 #pragma unroll
   for (int i = 0; i < 4; i++) inv4_(m[i], m[4 + i], m[8 + i], m[12 + i]);
 }
-__device__ const u8 c_cc[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};             // COEFF_COST4x4[0] (block.c:72)
 
 // quant_4x4_normal / quant_ac4x4_normal (quant4x4_normal.c:39 / :117) on the transformed block m (raster); first = 0 or 1 (AC only).
 // lev[16]: levels at their scan positions; m receives the dequantised coefficients.  Returns nonzero; cost accumulates the coefficient cost.
@@ -490,6 +506,9 @@ __device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int
 {
   const int q_bits = 15 + qp_per;
   int run = 0, nz = 0;
+  int qs[16], qo[16], qi[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { qo[k] = q[k].OffsetComp; qs[k] = q[k].ScaleComp; qi[k] = q[k].InvScaleComp; }
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     if (k < first) { lev[k] = 0; continue; }
@@ -497,12 +516,12 @@ __device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int
     const int idx = ZZ[k], cf = m[idx];
     int l = 0;
     if (cf != 0) {
-      l = (iabs_(cf) * q[idx].ScaleComp + q[idx].OffsetComp) >> q_bits;
+      l = (iabs_(cf) * qs[idx] + qo[idx]) >> q_bits;
       if (l != 0) {
         l = min(l, 2063);                                      // CAVLC_LEVEL_LIMIT
-        cost += l > 1 ? 999999 : (int)c_cc[run];
+        cost += l > 1 ? 999999 : (run == 0 ? 3 : (run <= 2 ? 2 : (run <= 5 ? 1 : 0)));       // COEFF_COST4x4[0][run], block.c:72
         l = cf < 0 ? -l : l;
-        m[idx] = (((l * q[idx].InvScaleComp) << qp_per) + 8) >> 4;
+        m[idx] = (((l * qi[idx]) << qp_per) + 8) >> 4;
         run = 0; nz = 1;
       } else { m[idx] = 0; run++; }
     } else run++;

@@ -1,6 +1,7 @@
 """Where a macroblock's time goes inside k_mb_pipe (JMHIP_MB_PROF=1: 100 MHz time stamps per macroblock), configs[1] P picture.  gpu only."""
 import os, sys, ctypes as C
-os.environ["JMHIP_MB_PROF"] = "1"
+MODE = sys.argv[1] if len(sys.argv) > 1 else "1"
+os.environ["JMHIP_MB_PROF"] = sys.argv[1] if len(sys.argv) > 1 else "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -27,7 +28,11 @@ for n in range(2):
         print(f"  {name:45s} {np.median(d):8.1f} {d.mean():8.1f}")
     print("  phase 0 per wave (from phase start to the wave's end; waves 0-3: 8x8, 8x4, 4x8, 4x4 of block 0; 4-6: 16x16, 16x8, 8x16; 7: intra):")
     print("   ", " ".join(f"{np.median((st[:, 8 + w] - st[:, 2]) / 100.0):7.1f}" for w in range(8)))
-    if n == 1:
+    print("  intra wave: Intra4x4 chain %.1f, Intra16x16 search %.1f, chroma decision %.1f us (medians)" % tuple(np.median(us(a, b)) for a, b in ((2, 7), (7, 23), (23, 15))))
+    if MODE == "2":
+        print("  Intra4x4 block 5: neighbours + values %.2f, nine predictions + SATD + minimum %.2f, transform/quant/reconstruction %.2f, stores %.2f us (medians)" % tuple(
+            np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
+    if n == 1 and MODE == "1":
         print("  first 4x4 search of the macroblock (wave 3): predictor %.2f, integer search %.2f, half-pel stage %.2f, quarter-pel stage + clip %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
     span = (st[:, 17].max() - st[:, 0].min()) / 100.0
