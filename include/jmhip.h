@@ -580,6 +580,12 @@ typedef struct {
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);
 int jmhip_encode_slice_dev(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *d_out /* device, or NULL: kept inside only */);
+/* The same, streamed, for a host that codes macroblocks in raster order while the device is still encoding (JM's write_macroblock after every
+ * encode_one_macroblock): _begin launches and returns; _record waits until macroblock mb_addr's record is complete in pinned host memory and
+ * returns a pointer to it (valid until the next _begin); _end waits for the launch and reports its errors.  One slice at a time. */
+int jmhip_encode_slice_begin(jmhip_ctx *ctx, const jmhip_slice_params *prm);
+int jmhip_slice_record(jmhip_ctx *ctx, int32_t mb_addr, const jmhip_mb_record **rec);
+int jmhip_encode_slice_end(jmhip_ctx *ctx);
 /* the reconstruction the slices of the current picture left on the device (before / after jmhip_deblock_picture_dev) */
 int jmhip_recon_planes_dev(jmhip_ctx *ctx, uint8_t **d_y, int32_t *pitch_y, uint8_t **d_u, uint8_t **d_v, int32_t *pitch_c);
 int jmhip_get_recon(jmhip_ctx *ctx, uint16_t *y, int32_t pitch_y, uint16_t *u, uint16_t *v, int32_t pitch_c);   /* as imgpel, pitches in samples */

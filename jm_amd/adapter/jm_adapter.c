@@ -77,6 +77,8 @@ static double now_s(void);
 static double T_slice, T_pad, T_deblock, T_interp;
 static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV);
 static int pipe_reference(StorablePicture *s);
+static int pipe_config_ok(VideoParameters *p_Vid);
+static int pipe_active(void);
 
 static void adapter_report(void)
 {
@@ -773,10 +775,10 @@ void __wrap_pad_borders(FrameFormat output, int img_size_x, int img_size_y, int 
   uint16_t *planes;
   int k, x, y, rc;
   size_t n = 0;
-  if (!p_Vid || !adapter_on(p_Vid) || !G.part_load || fmt != G.fmt || img_size_x != G.W || img_size_y != G.H || sw > G.W || sh > G.H ||
+  if (!p_Vid || !adapter_on(p_Vid) || !G.part_load || pipe_config_ok(p_Vid) || fmt != G.fmt || img_size_x != G.W || img_size_y != G.H || sw > G.W || sh > G.H ||
       G.W - sw >= 16 || G.H - sh >= 16 || output.bit_depth[0] != 8 || (fmt && (output.bit_depth[1] != 8 || scw != sw / 2 || (sw & 1))) ||
       (fmt == 1 && (sch != sh / 2 || (sh & 1))) || (fmt == 2 && sch != sh) || (fmt && (img_size_x_cr != G.W / 2 || img_size_y_cr != (fmt == 1 ? G.H / 2 : G.H)))) {
-    G.n_passed++;
+    if (!pipe_active()) G.n_passed++;  /* with the macroblock pipeline JM pads on the host by design: the padded planes go up once per picture */
     __real_pad_borders(output, img_size_x, img_size_y, img_size_x_cr, img_size_y_cr, pImage);
     return;
   }
@@ -1092,14 +1094,15 @@ int __wrap_residual_transform_quant_luma_8x8_cavlc(Macroblock *m, ColorPlane pl,
 
 static struct {
   int checked, ok;
-  jmhip_mb_record *recs;              /* one per macroblock of the picture */
   StorablePicture *pic;               /* the picture the records / the device reconstruction belong to */
   int mbs;                            /* its macroblocks served so far */
   int deblocked;
+  int slice_last;                     /* last macroblock of the slice the device is encoding */
   long n_slices, n_mbs, n_refs;
-  double t_dev, t_fill;
+  double t_dev, t_fill, t_wait;
 } P;
 
+static int pipe_active(void) { return G.ctx && !G.off && P.ok; }
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 static int pipe_config_ok(VideoParameters *p_Vid)
@@ -1138,10 +1141,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if ((size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
     else if (p_Vid->bitdepth_chroma_qp_scale != 0) why = "chroma QP scale";
     P.ok = why == NULL;
-    if (P.ok) {
-      P.recs = (jmhip_mb_record *)malloc((size_t)p_Vid->PicSizeInMbs * sizeof(jmhip_mb_record));
-      if (!P.recs) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
-    } else if (G.part_mbpipe && p->rdopt == 0)
+    if (!P.ok && G.part_mbpipe && p->rdopt == 0)
       fprintf(stderr, "jmhip adapter: macroblock pipeline not used (%s): JM's own encode_one_macroblock_low runs\n", why);
   }
   return P.ok;
@@ -1212,7 +1212,8 @@ static void pipe_run_slice(Macroblock *currMB)
       }
   prm.df_disable_idc = currMB->DFDisableIdc; prm.df_alpha_c0 = currMB->DFAlphaC0Offset; prm.df_beta = currMB->DFBetaOffset;
   if (currMB->qp_scaled[0] != currMB->qp) { fprintf(stderr, "jmhip adapter: macroblock pipeline: luma QP scale\n"); exit(70); }
-  if ((rc = jmhip_encode_slice(G.ctx, &prm, P.recs + first))) adapter_die("jmhip_encode_slice", rc);
+  if ((rc = jmhip_encode_slice_begin(G.ctx, &prm))) adapter_die("jmhip_encode_slice_begin", rc);
+  P.slice_last = first + prm.num_mb - 1;
   P.n_slices++; P.n_refs += prm.num_ref;
   P.t_dev += now_s() - t0;
 }
@@ -1270,9 +1271,17 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
     return;
   }
   if (currMB->mbAddrX == currSlice->start_mb_nr) pipe_run_slice(currMB);
-  t0 = now_s();
-  mb_from_record(currMB, &P.recs[currMB->mbAddrX]);
-  P.t_fill += now_s() - t0;
+  {
+    const jmhip_mb_record *rec;
+    int rc;
+    t0 = now_s();
+    if ((rc = jmhip_slice_record(G.ctx, currMB->mbAddrX, &rec))) adapter_die("jmhip_slice_record", rc);     /* waits while the device is behind */
+    P.t_wait += now_s() - t0;
+    t0 = now_s();
+    mb_from_record(currMB, rec);
+    P.t_fill += now_s() - t0;
+    if (currMB->mbAddrX == P.slice_last && (rc = jmhip_encode_slice_end(G.ctx))) adapter_die("jmhip_encode_slice_end", rc);
+  }
   P.mbs++; P.n_mbs++;
 }
 
@@ -1305,6 +1314,18 @@ static void pipe_report(void)
 {
   if (P.n_slices)
     fprintf(stderr, "jmhip adapter: macroblock pipeline: %ld slices, %ld macroblocks encoded on the MI355X (encode_one_macroblock_low never ran on the host); "
-                    "device calls %.3f s, unpacking records %.3f s; wall time inside encode_one_slice %.3f s, pad_borders %.3f s, DeblockFrame %.3f s, getSubImagesLuma %.3f s\n",
-            P.n_slices, P.n_mbs, P.t_dev, P.t_fill, T_slice, T_pad, T_deblock, T_interp);
+                    "device calls %.3f s, waiting for records %.3f s, unpacking them %.3f s; wall time inside encode_one_slice %.3f s, pad_borders %.3f s, DeblockFrame %.3f s, getSubImagesLuma %.3f s\n",
+            P.n_slices, P.n_mbs, P.t_dev, P.t_wait, P.t_fill, T_slice, T_pad, T_deblock, T_interp);
+}
+
+/* ------------------------------------------------------------------ FmoGetLastCodedMBOfSliceGroup (lencod/src/fmo.c:676)
+ * end_macroblock (macroblock.c:512) asks for it once per macroblock and JM answers with a loop over the whole macroblock-to-slice-group map:
+ * PicSizeInMbs^2 steps per picture (66 million at 1080p, a fifth of the host time left once the macroblock decisions are off the CPU).
+ * Without FMO there is one slice group and the answer is the picture's last macroblock; with FMO JM's own loop runs. */
+extern int __real_FmoGetLastCodedMBOfSliceGroup(VideoParameters *, int);
+int __wrap_FmoGetLastCodedMBOfSliceGroup(VideoParameters *p_Vid, int SliceGroupID)
+{
+  if (p_Vid->p_Inp->num_slice_groups_minus1 == 0 && SliceGroupID == 0 && p_Vid->PicSizeInMbs > 0 && !(G.init_done && G.off))
+    return (int)p_Vid->PicSizeInMbs - 1;
+  return __real_FmoGetLastCodedMBOfSliceGroup(p_Vid, SliceGroupID);
 }

@@ -47,6 +47,9 @@ struct jmhip_ctx {
   void *d_mb_records;    // jmhip_mb_record per macroblock of the picture
   void *d_mb_dbmb, *d_mb_dbmo;   // loop-filter side information written by the pipeline
   void *h_mb_records;    // pinned host staging for jmhip_encode_slice
+  unsigned *h_mb_flags;  // pinned, device-visible: per macroblock the epoch whose record is complete in h_mb_records (streaming)
+  void *d_h_mb_records; unsigned *d_h_mb_flags;   // the device's addresses of the two
+  int mb_streaming, mb_stream_first, mb_stream_num;
   void *d_mb_prof;       // JMHIP_MB_PROF=1: time stamps per macroblock
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)

@@ -63,6 +63,8 @@ struct PipeArgs {
   jmhip_mb_record *records;
   jmhip_db_mb *dbmb;
   jmhip_db_motion *dbmo;
+  jmhip_mb_record *hrecords;                 // streaming to the host (jmhip_encode_slice_begin): pinned, device-visible copies of the records
+  unsigned *hflags;                          // ... and per macroblock the epoch of the launch whose record is complete there; null otherwise
   int prof_mode;                             // JMHIP_MB_PROF value: 1 = a 4x4 search's parts in stamps 18..22, 2 = an Intra4x4 block's parts there
   unsigned long long *prof;                  // profiling aid (JMHIP_MB_PROF=1): 24 time stamps (100 MHz) per macroblock, or null
 };

@@ -99,7 +99,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
-           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_recon_planes_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon"]
+           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon"]
 
 
 class JmHipError(RuntimeError):
@@ -548,6 +548,19 @@ class JmHip:
     def encode_slice_dev(self, prm, d_out=None):
         prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
         self._ck(self.lib.jmhip_encode_slice_dev(self.h, _vp(prm), _vp(d_out)))
+
+    def encode_slice_streamed(self, prm):
+        """jmhip_encode_slice_begin / _record (raster order, while the device is still encoding) / _end; returns the records"""
+        prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
+        first, num = int(prm["first_mb"][0]), int(prm["num_mb"][0])
+        out = np.zeros(num, MB_RECORD)
+        self._ck(self.lib.jmhip_encode_slice_begin(self.h, _vp(prm)))
+        p = C.c_void_p()
+        for k in range(num):
+            self._ck(self.lib.jmhip_slice_record(self.h, first + k, C.byref(p)))
+            out[k] = np.frombuffer((C.c_char * MB_RECORD.itemsize).from_address(p.value), MB_RECORD)[0]
+        self._ck(self.lib.jmhip_encode_slice_end(self.h))
+        return out
 
     def recon_planes_dev(self):
         py, pu, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -181,6 +181,29 @@ def test_encode_slice_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed):
             assert np.array_equal(a, b.astype(np.uint8)), (n, "reconstruction after the loop filter")
 
 
+def test_streamed_records_equal_the_blocking_call():
+    """jmhip_encode_slice_begin / jmhip_slice_record / jmhip_encode_slice_end (what the adapter uses: JM's entropy coder reads each record in raster
+    order while the device is still encoding) hands over the same records as jmhip_encode_slice, picture after picture, with mid-row slices."""
+    import jm_amd.lib as L
+    W, H, R = 320, 192, 16
+    frames = synthetic_clip(W, H, 3, 9)
+    J = L.JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1)
+    nmb = (W // 16) * (H // 16)
+    for n, raw in enumerate(frames):
+        J.set_current_frame(raw, W, H)
+        st, nref = (2, 0) if n == 0 else (0, 1)
+        for sn, (first, num) in enumerate(mbenc_util.slices_of(nmb, 70)):
+            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, 28, R, nref, LAMBDAS[st][0], LAMBDAS[st][1])
+            prm = slice_params(L, cfg, sn, [n & 1], [n - 1])
+            a = J.encode_slice(prm)
+            b = J.encode_slice_streamed(prm)
+            assert a.tobytes() == b.tobytes(), (n, sn)
+        J.deblock_picture_dev(1)
+        J.reference_from_recon((n + 1) & 1)
+    with pytest.raises(L.JmHipError):
+        J._ck(J.lib.jmhip_encode_slice_end(J.h))             # nothing to end
+
+
 def test_encode_slice_rejects_what_it_does_not_cover():
     import jm_amd.lib as L
     J = L.JmHip(64, 48, search_range=16, num_ref_slots=2, yuv_format=1)

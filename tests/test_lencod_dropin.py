@@ -134,8 +134,8 @@ def run_rdo_off_case(tag, tmp, exe=EXE, env_extra=None, frames=None):
 
 
 def pipeline_report(stderr):
-    m = re.search(r"macroblock pipeline: (\d+) slices, (\d+) macroblocks encoded on the MI355X .*device calls ([\d.]+) s, unpacking records ([\d.]+) s", stderr)
-    return None if not m else dict(slices=int(m.group(1)), mbs=int(m.group(2)), t_dev=float(m.group(3)), t_fill=float(m.group(4)))
+    m = re.search(r"macroblock pipeline: (\d+) slices, (\d+) macroblocks encoded on the MI355X .*device calls ([\d.]+) s, waiting for records ([\d.]+) s, unpacking them ([\d.]+) s", stderr)
+    return None if not m else dict(slices=int(m.group(1)), mbs=int(m.group(2)), t_dev=float(m.group(3)), t_wait=float(m.group(4)), t_fill=float(m.group(5)))
 
 
 def frame_times(stdout):
