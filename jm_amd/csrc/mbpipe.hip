@@ -101,6 +101,7 @@ struct Shared {
   u8 predc[2][64], recc[2][64];
   int16_t dcbuf[16];
   int red[8][80];
+  u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
   u32 fin_cbp_blk;
   jmhip_mb_record out;
@@ -113,43 +114,48 @@ __device__ __forceinline__ u64 ld_sc1(const u64 *p) { return __hip_atomic_load(p
 __device__ __forceinline__ void st_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------ neighbours of the current macroblock
-// mv_info entry at 4x4 position (x4, y4) relative to the macroblock, x4, y4 in [-1, 4]: {packed mv, ref} or unavailable.
-// Inside the macroblock: this wave's view; outside: the neighbour's edge record (words 9..12 bottom row, 13..16 right column).
-__device__ __forceinline__ bool mvinfo_at(const Shared &S, int wave, int x4, int y4, int &mv, int &ref)
+// mv_info entry at 4x4 position (x4, y4) relative to the macroblock, x4, y4 in [-1, 4]: where its {packed mv, ref} lies in LDS, and whether it exists.
+// Inside the macroblock: this chain's view (two ints); outside: the neighbour's edge record (words 9..12 bottom row, 13..16 right column: the vector
+// in the low half, the reference index in byte 4).  Both read as one 64-bit word: mv = low half, ref = sign-extended byte 4.
+// avm: bit n = neighbour n (A left, B up, C up-right, D up-left) is inside the picture and the slice.
+__device__ __forceinline__ const u64 *mvinfo_ptr(const Shared &S, int view, int avm, int x4, int y4, bool &ok)
 {
-  u64 w;
   if (x4 < 0) {
-    if (y4 < 0) { if (!rfl(S.avail[3])) return false; w = S.nb[3][9 + 3]; }
-    else if (y4 < 4) { if (!rfl(S.avail[0])) return false; w = S.nb[0][13 + y4]; }
-    else return false;
-  } else if (x4 < 4) {
-    if (y4 < 0) { if (!rfl(S.avail[1])) return false; w = S.nb[1][9 + x4]; }
-    else if (y4 < 4) { mv = rfl(S.mvi[wave][y4 * 4 + x4][0]); ref = rfl(S.mvi[wave][y4 * 4 + x4][1]); return true; }
-    else return false;
-  } else {
-    if (y4 < 0) { if (!rfl(S.avail[2])) return false; w = S.nb[2][9 + 0]; }
-    else return false;
+    if (y4 < 0) { ok = (avm >> 3) & 1; return &S.nb[3][9 + 3]; }
+    ok = y4 < 4 && (avm & 1); return &S.nb[0][13 + (y4 & 3)];
   }
-  mv = rfl((int)(u32)w); ref = rfl((int)(int8_t)(w >> 32));
-  return true;
+  if (x4 < 4) {
+    if (y4 < 0) { ok = (avm >> 1) & 1; return &S.nb[1][9 + x4]; }
+    ok = y4 < 4; return (const u64 *)&S.mvi[view][(y4 & 3) * 4 + x4][0];
+  }
+  ok = y4 < 0 && ((avm >> 2) & 1); return &S.nb[2][9 + 0];
+}
+__device__ __forceinline__ void mvinfo_get(const u64 *p, bool ok, int &mv, int &ref)
+{
+  const u64 w = *p;
+  mv = ok ? rfl((int)(u32)w) : 0; ref = ok ? rfl((int)(int8_t)(w >> 32)) : -1;
 }
 
-// get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325)
-__device__ __forceinline__ int mv_predictor(const Shared &S, int wave, int ref, int mb_x, int mb_y, int bsx, int bsy)
+// get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325); the four candidates are read at once
+__device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, int ref, int mb_x, int mb_y, int bsx, int bsy)
 {
-  int mv[3] = {0, 0, 0}, rf[3] = {-1, -1, -1};
-  bool av[3];
-  av[0] = mvinfo_at(S, wave, (mb_x - 1) >> 2, mb_y >> 2, mv[0], rf[0]);
-  av[1] = mvinfo_at(S, wave, mb_x >> 2, (mb_y - 1) >> 2, mv[1], rf[1]);
-  av[2] = mvinfo_at(S, wave, (mb_x + bsx) >> 2, (mb_y - 1) >> 2, mv[2], rf[2]);
+  int mv[3], rf[3], mD, rD;
+  bool av[3], avD;
+  const u64 *pA = mvinfo_ptr(S, view, avm, (mb_x - 1) >> 2, mb_y >> 2, av[0]);
+  const u64 *pB = mvinfo_ptr(S, view, avm, mb_x >> 2, (mb_y - 1) >> 2, av[1]);
+  const u64 *pC = mvinfo_ptr(S, view, avm, (mb_x + bsx) >> 2, (mb_y - 1) >> 2, av[2]);
+  const u64 *pD = mvinfo_ptr(S, view, avm, (mb_x - 1) >> 2, (mb_y - 1) >> 2, avD);
   if (mb_y > 0) {
     if (mb_x < 8) {
       if (mb_y == 8) { if (bsx == 16) av[2] = false; }
       else if (mb_x + bsx == 8) av[2] = false;
     } else if (mb_x + bsx == 16) av[2] = false;
   }
-  if (!av[2]) { mv[2] = 0; rf[2] = -1; av[2] = mvinfo_at(S, wave, (mb_x - 1) >> 2, (mb_y - 1) >> 2, mv[2], rf[2]); }
-  for (int k = 0; k < 3; k++) if (!av[k]) { mv[k] = 0; rf[k] = -1; }
+  mvinfo_get(pA, av[0], mv[0], rf[0]);
+  mvinfo_get(pB, av[1], mv[1], rf[1]);
+  mvinfo_get(pC, av[2], mv[2], rf[2]);
+  mvinfo_get(pD, avD, mD, rD);
+  if (!av[2]) { mv[2] = mD; rf[2] = rD; av[2] = avD; }
   int type = 0;
   if (rf[0] == ref && rf[1] != ref && rf[2] != ref) type = 1;
   else if (rf[0] != ref && rf[1] == ref && rf[2] != ref) type = 2;
@@ -165,17 +171,19 @@ __device__ __forceinline__ int mv_predictor(const Shared &S, int wave, int ref, 
     if (!(av[1] || av[2])) return mv[0];
     return mvpack(median3(mvx(mv[0]), mvx(mv[1]), mvx(mv[2])), median3(mvy(mv[0]), mvy(mv[1]), mvy(mv[2])));
   }
-  return mv[type - 1];
+  return type == 1 ? mv[0] : (type == 2 ? mv[1] : mv[2]);
 }
 
 // FindSkipModeMotionVector mv_search.c:1333-1405
-__device__ __forceinline__ int skip_vector(const Shared &S, int wave)
+__device__ __forceinline__ int skip_vector(const Shared &S, int view, int avm)
 {
-  int mA = 0, rA = -1, mB = 0, rB = -1;
-  const bool a = mvinfo_at(S, wave, -1, 0, mA, rA), b = mvinfo_at(S, wave, 0, -1, mB, rB);
+  int mA, rA, mB, rB;
+  bool a, b;
+  const u64 *pA = mvinfo_ptr(S, view, avm, -1, 0, a), *pB = mvinfo_ptr(S, view, avm, 0, -1, b);
+  mvinfo_get(pA, a, mA, rA); mvinfo_get(pB, b, mB, rB);
   const bool zl = !a || (rA == 0 && mA == 0), za = !b || (rB == 0 && mB == 0);
   if (za || zl) return 0;
-  return mv_predictor(S, wave, 0, 0, 0, 16, 16);
+  return mv_predictor(S, view, avm, 0, 0, 0, 16, 16);
 }
 
 // ------------------------------------------------------------------ integer search of one block by one wave
@@ -206,7 +214,7 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
 template <int BW, int BH>
-__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane)
+__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab, unsigned long long *pf)
 {
   u32 cb[BH][BW / 4];
 #pragma unroll
@@ -230,19 +238,39 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     u32 acc[BH];
 #pragma unroll
     for (int k = 0; k < BH; k++) acc[k] = 0;
-    u32 a[BW / 4 + 1], an[BW / 4 + 1];
+    for (int i = lane; i <= 2 * Rs; i += 64) {                 // the row table (one LDS read per row instead of a dozen scalar instructions)
+      const int dy = i - Rs, vy = c.cqy + 4 * dy;
+      ytab[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 8) | (vy == 0 ? 128u : 0u) | (u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u;
+    }
+    wave_sync();
+    // window rows and row-table entries travel PF rows ahead of their use (an LDS read takes a couple of hundred cycles; a row of a small block
+    // is summed in far less)
+    constexpr int PF = BW * BH <= 64 ? 4 : (BW * BH <= 128 ? 2 : 1);
+    u32 a[PF][BW / 4 + 1], yt[PF];
 #pragma unroll
-    for (int k = 0; k <= BW / 4; k++) a[k] = ((const u32 *)p)[k];
+    for (int f = 0; f < PF; f++) {
+#pragma unroll
+      for (int k = 0; k <= BW / 4; k++) a[f][k] = ((const u32 *)(p + f * WP))[k];
+      const int i = f - (BH - 1);
+      yt[f] = ytab[i < 0 ? 0 : i];
+    }
+    const u32 t16 = 16u * (u32)c.lambda;
     for (int j0 = 0; j0 < nrows; j0 += BH) {                   // rows past the last one (a partial final group) lie in the window's slack rows
 #pragma unroll
       for (int s = 0; s < BH; s++) {
         const int j = j0 + s;
-        p += WP;
-#pragma unroll
-        for (int k = 0; k <= BW / 4; k++) an[k] = ((const u32 *)p)[k];      // the next row is on its way while this one is summed
+        const int i = j - (BH - 1);                            // the candidate that ends with this row (the same for every lane)
         u32 b[BW / 4];
 #pragma unroll
-        for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
+        for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[s % PF][k + 1], a[s % PF][k], sh);
+        const u32 ytc = yt[s % PF];
+        {                                                      // row j + PF into the slot just freed
+          const u8 *pn = p + (j + PF) * WP;
+#pragma unroll
+          for (int k = 0; k <= BW / 4; k++) a[s % PF][k] = ((const u32 *)pn)[k];
+          const int in = i + PF;
+          yt[s % PF] = ytab[in < 0 ? 0 : (in > 2 * Rs ? 2 * Rs : in)];
+        }
 #pragma unroll
         for (int r = 0; r < BH; r++) {                         // window row j is row r of the candidate that starts at row j - r
           const int k = (s - r + BH) % BH;
@@ -251,19 +279,16 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
           for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
           acc[k] = v;
         }
-        const int i = j - (BH - 1);                            // the candidate that ends with this row (the same for every lane)
-        if (i >= 0 && i <= 2 * Rs) {
-          const int dy = i - Rs, ady = dy < 0 ? -dy : dy, vy = c.cqy + 4 * dy;
-          const u32 rate_y = (u32)rfl(c.lambda * mvbits(vy - c.pqy));
-          const int far_rank = 2 * ady - 1 + (dy > 0 ? 1 : 0);
-          const u32 rank = (u32)(ady <= adx ? dy + adx : far_rank);
-          u32 rate = rate_x + rate_y;
-          if (c.check00 && vy == 0) { const u32 t = 16u * (u32)c.lambda; rate = zero_x ? (rate > t ? rate - t : 0u) : rate; }       // me_fullsearch.c:78-82
-          const u32 key = (((acc[(s + 1) % BH] << 5) + rate) << 7) | rank;
+        {                                                      // no branch: rows that end no candidate give the key ~0
+          const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
+          const u32 rank = ady <= adx ? (u32)(dy + adx) : (ytc & 127u);
+          u32 rate = rate_x + (ytc >> 8);
+          const u32 rz = rate > t16 ? rate - t16 : 0u;         // me_fullsearch.c:78-82
+          rate = (zero_x && (ytc & 128u)) ? rz : rate;
+          u32 key = (((acc[(s + 1) % BH] << 5) + rate) << 7) | rank;
+          key = (i >= 0 && i <= 2 * Rs) ? key : 0xffffffffu;
           bkey = key < bkey ? key : bkey;
         }
-#pragma unroll
-        for (int k = 0; k <= BW / 4; k++) a[k] = an[k];
       }
     }
     {
@@ -273,6 +298,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       best = ((u64)(bkey >> 7) << 32) | ((u64)spiral_index(dx, dy) << 16) | (u64)(((dy + 128) << 8) | (dx + 128));
     }
   }
+  if (pf && lane == 0) pf[7] = wall_clock64();
   for (int col = 64; col < ncol; col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
     const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
@@ -291,6 +317,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, bits_x); best = key < best ? key : best; }
     }
   }
+  if (pf && lane == 0) pf[23] = wall_clock64();
   return wave_min_u64(best);
 }
 
@@ -354,8 +381,26 @@ __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int w
   wave_sync();
 }
 
+// The strict-'<' scan over the nine positions of one stage of sub_pel_motion_estimation (me_fullsearch.c:221-246 / :263-281), nine lanes at once:
+// JM skips a position whose vector cost alone reaches the running minimum -- such a position could not have won -- so the winner is the first
+// position with the smallest total cost.  first = 1 (the quarter-pel stage when both stages use the same metric): position 0 is not evaluated,
+// it stands for the minimum the half-pel stage left (`incumbent`).  SATD sums in S.red[wave][0..8].
+__device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv, int step, int lambda, int pqx, int pqy, int bonus0, int incumbent, int first, int &min_out)
+{
+  const int pos = lane < 9 ? lane : 0;
+  const int qx = mvx(mv) + step * sp9x(pos), qy = mvy(mv) + step * sp9y(pos);
+  int cost = lambda * (mvbits(qx - pqx) + mvbits(qy - pqy)) + (S.red[wave][pos] << 5);
+  if (pos == 0) cost = first ? incumbent : cost - bonus0;
+  u32 key = lane < 9 ? (((u32)(cost + (1 << 27))) << 4) | (u32)pos : 0xffffffffu;       // costs stay far below 2^27 in magnitude
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) { const u32 t = (u32)__shfl_xor((int)key, off, 64); key = t < key ? t : key; }
+  key = (u32)rfl((int)key);
+  min_out = (int)(key >> 4) - (1 << 27);
+  return (int)(key & 15u);
+}
+
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
-__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wave, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
+__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
 {
   const jmhip_slice_params &P = A.p;
   const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
@@ -365,7 +410,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const bool prof_ = A.prof && A.prof_mode == 1 && bt == 7 && mb_x == 0 && mb_y == 0 && ref == 0 && lane == 0;
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 24 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
-  const int pred = rfl(mv_predictor(S, wave, ref, mb_x, mb_y, BW, BH));
+  const int pred = rfl(mv_predictor(S, wave, avm, ref, mb_x, mb_y, BW, BH));
   BS_STAMP(19);
   int cx = ((mvx(pred) + 2) >> 2) * 4, cy = ((mvy(pred) + 2) >> 2) * 4;          // mv_search.c:931-932
   int min_x = -(R << 2), max_x = R << 2, min_y = min_x, max_y = max_x;
@@ -396,13 +441,13 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
   u64 key;
   switch (bt) {
-  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane); break;
-  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
-  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane); break;
-  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
-  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane); break;
-  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane); break;
-  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane); break;
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
   }
   const int klo = rfl((int)(u32)key), khi = rfl((int)(u32)(key >> 32));
   BS_STAMP(20);
@@ -412,34 +457,17 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   if (P.subpel) {                                             // sub_pel_motion_estimation me_fullsearch.c:186-289 (start_me_refinement_hp = 0)
     const int check0 = ref == 0 && bt == 1 && mv == 0;
     subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
-    min_mcost = MAXC;
-    int best = 0;
-    for (int pos = 0; pos < 9; pos++) {
-      const int qx = mvx(mv) + 2 * sp9x(pos), qy = mvy(mv) + 2 * sp9y(pos);
-      int mcost = P.lambda_mf[1] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
-      if (mcost >= min_mcost) continue;
-      mcost += rfl(S.red[wave][pos]) << 5;
-      if (pos == 0 && check0) mcost -= P.lambda_mf[1] * 16;
-      if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
-    }
+    int best = scan9(S, wave, lane, mv, 2, P.lambda_mf[1], c.pqx, c.pqy, check0 ? P.lambda_mf[1] * 16 : 0, 0, 0, min_mcost);
     mv = mvpack(mvx(mv) + 2 * sp9x(best), mvy(mv) + 2 * sp9y(best));
     BS_STAMP(21);
     subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
-    if (!P.start_qp) min_mcost = MAXC;
-    best = 0;
-    for (int pos = P.start_qp; pos < 9; pos++) {
-      const int qx = mvx(mv) + sp9x(pos), qy = mvy(mv) + sp9y(pos);
-      int mcost = P.lambda_mf[2] * (mvbits(qx - c.pqx) + mvbits(qy - c.pqy));
-      if (mcost >= min_mcost) continue;
-      mcost += rfl(S.red[wave][pos]) << 5;
-      if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
-    }
+    best = scan9(S, wave, lane, mv, 1, P.lambda_mf[2], c.pqx, c.pqy, 0, min_mcost, P.start_qp, min_mcost);
     mv = mvpack(mvx(mv) + sp9x(best), mvy(mv) + sp9y(best));
   }
   mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
 
   if (bt == 1 && P.slice_type == 0) {                          // the skip vector against the 16x16 result: mv_search.c:983-998, GetSkipCostMB :1257
-    const int sv = rfl(skip_vector(S, wave));
+    const int sv = rfl(skip_vector(S, wave, avm));
     if (lane == 0) S.skip_mv = sv;
     const int qx = (mbx * 64) + mvx(sv), qy = (mby * 64) + mvy(sv);
     const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);     // one origin for the 16x16 block
@@ -543,6 +571,48 @@ __device__ __forceinline__ int tq_luma4(const u32 (&o)[4], const u32 (&p)[4], co
 #pragma unroll
     for (int k = 0; k < 16; k++) lev[k] = 0;
   }
+  if (nz) {
+    inverse4x4(m);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      u32 w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) w |= (u32)clampi3(0, 255, ((m[4 * j + i] + 32) >> 6) + pr[4 * j + i]) << (8 * i);
+      rec[j] = w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) rec[j] = p[j];
+  }
+  return nz;
+}
+
+// The same for a block that EVERY lane of the wave holds alike (the Intra4x4 chain: one block after the other): the sixteen coefficients are
+// quantised by sixteen lanes at once (lane = scan position) instead of a sixteen-step chain in every lane; the dequantised coefficients come
+// back to all lanes by wave shuffles.  lev: sixteen int16 in LDS (written by the sixteen lanes).  No coefficient cost (Intra4x4 does not use it).
+__device__ __forceinline__ int tq_luma4_wave(const u32 (&o)[4], const u32 (&p)[4], const jmhip_qparam *q, int qp_per, int lane, int16_t *lev, u32 (&rec)[4])
+{
+  constexpr int ZZ[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+  const int k = lane & 15;
+  int zz = 0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) zz = (c == k) ? ZZ[c] : zz;
+  const jmhip_qparam qk = q[zz];                               // on its way while the transform runs
+  int m[16], pr[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { pr[c] = (p[c >> 2] >> (8 * (c & 3))) & 255; m[c] = (int)((o[c >> 2] >> (8 * (c & 3))) & 255) - pr[c]; }
+  forward4x4(m);                                               // an all-zero residual transforms to zeros and quantises to zeros: no special case needed
+  int cf = 0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) cf = (c == zz) ? m[c] : cf;
+  int l = (iabs_(cf) * qk.ScaleComp + qk.OffsetComp) >> (15 + qp_per);
+  l = min(l, 2063);                                            // CAVLC_LEVEL_LIMIT
+  l = cf < 0 ? -l : l;
+  const int dq = (((l * qk.InvScaleComp) << qp_per) + 8) >> 4;
+  if (lane < 16) lev[k] = (int16_t)l;
+  const int nz = (__ballot(l != 0) & 0xffffull) != 0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) m[ZZ[c]] = __shfl(dq, c, 64);
   if (nz) {
     inverse4x4(m);
 #pragma unroll

@@ -28,7 +28,13 @@ for n in range(2):
         print(f"  {name:45s} {np.median(d):8.1f} {d.mean():8.1f}")
     print("  phase 0 per wave (from phase start to the wave's end; waves 0-3: 8x8, 8x4, 4x8, 4x4 of block 0; 4-6: 16x16, 16x8, 8x16; 7: intra):")
     print("   ", " ".join(f"{np.median((st[:, 8 + w] - st[:, 2]) / 100.0):7.1f}" for w in range(8)))
-    print("  intra wave: Intra4x4 chain %.1f, Intra16x16 search %.1f, chroma decision %.1f us (medians)" % tuple(np.median(us(a, b)) for a, b in ((2, 7), (7, 23), (23, 15))))
+    if MODE == "1" and n == 1:
+        print("  ... of the integer search: centre + tables + column loop %.2f, column 64 %.2f, wave minimum %.2f us" % tuple(np.median(us(a, b)) for a, b in ((19, 7), (7, 23), (23, 20))))
+    if MODE == "2":
+        print("  intra wave: Intra4x4 chain %.1f, Intra16x16 search %.1f, chroma decision %.1f us (medians)" % tuple(np.median(us(a, b)) for a, b in ((2, 7), (7, 23), (23, 15))))
+    if MODE == "3":
+        d = (st[:, 19] - st[:, 18]) / np.maximum(us(0, 17), 1e-9)
+        print("  shader clock while the kernel runs (s_memtime ticks per microsecond of s_memrealtime): median %.0f MHz" % np.median(d))
     if MODE == "2":
         print("  Intra4x4 block 5: neighbours + values %.2f, nine predictions + SATD + minimum %.2f, transform/quant/reconstruction %.2f, stores %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
