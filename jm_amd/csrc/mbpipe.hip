@@ -29,6 +29,10 @@ typedef uint32_t u32;
 typedef uint8_t u8;
 
 #define MB_THREADS 512
+// 1: in the 8x8 blocks 1-3 every sub-mode search is shared by two waves (candidate rows split, hand-over through LDS).  Measured on the MI355X it is
+// no faster than one wave per search (38.5 vs 39.5 us per block: a row costs each of the two waves 1.5x what it costs a lone wave, and the hand-over
+// adds 1.3 us per search), so it is off; the parity tests pass either way.
+#define MB_PAIR 0
 #define MAXC 0x7fffffff
 #define EDGE_WORDS 17                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
                                             // 6/7 right U/V columns, 8 ipredmode (bytes 0-3 bottom row, 4-7 right column), 9-12 / 13-16 mv_info of the
@@ -101,6 +105,8 @@ struct Shared {
   u8 predc[2][64], recc[2][64];
   int16_t dcbuf[16];
   int red[8][80];
+  u64 xkey[4];                               // two waves on one search: the helper's best key, its sequence number, the main wave's "results are in" number
+  int xseq_h[4], xseq_m[4];
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
   u32 fin_cbp_blk;
@@ -109,6 +115,38 @@ struct Shared {
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value every lane of the wave holds alike, moved to a scalar register (loop bounds, addresses and branches on it become scalar)
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// hand-over between two waves of the workgroup through a sequence number in LDS (a wave's LDS operations execute in order)
+__device__ __forceinline__ void lds_signal(int *f, int seq, int lane) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) *(volatile int *)f = seq; }
+__device__ __forceinline__ void lds_wait(const int *f, int seq) { while (*(const volatile int *)f != seq) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// Cross-lane steps inside a row of 16 lanes as DPP operands of the ALU (no trip through the LDS crossbar that __shfl_xor takes):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after n of them every lane holds the result over its 2^n neighbours.
+template <int CTRL> __device__ __forceinline__ int dpp_(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 umin_(u32 a, u32 b) { return a < b ? a : b; }
+// minimum over each row of 16 lanes (every lane of the row gets it)
+__device__ __forceinline__ u32 row16_min_u32(u32 x)
+{
+  x = umin_(x, (u32)dpp_<0xB1>((int)x)); x = umin_(x, (u32)dpp_<0x4E>((int)x));
+  x = umin_(x, (u32)dpp_<0x141>((int)x)); x = umin_(x, (u32)dpp_<0x140>((int)x));
+  return x;
+}
+// minimum over the wave, in a scalar register
+__device__ __forceinline__ u32 wave_min_u32(u32 x)
+{
+  x = row16_min_u32(x);
+  const u32 a = (u32)__builtin_amdgcn_readlane((int)x, 0), b = (u32)__builtin_amdgcn_readlane((int)x, 16);
+  const u32 c = (u32)__builtin_amdgcn_readlane((int)x, 32), d = (u32)__builtin_amdgcn_readlane((int)x, 48);
+  return umin_(umin_(a, b), umin_(c, d));
+}
+// sum over aligned groups of n = 1, 2, 4, 8 or 16 lanes (every lane of the group gets it)
+__device__ __forceinline__ int group_sum(int v, int n)
+{
+  if (n > 1) v += dpp_<0xB1>(v);
+  if (n > 2) v += dpp_<0x4E>(v);
+  if (n > 4) v += dpp_<0x141>(v);
+  if (n > 8) v += dpp_<0x140>(v);
+  return v;
+}
 
 __device__ __forceinline__ u64 ld_sc1(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -214,15 +252,17 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
 template <int BW, int BH>
-__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab, unsigned long long *pf)
+__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab, unsigned long long *pf, int i_lo, int i_hi, bool col64)
 {
   u32 cb[BH][BW / 4];
 #pragma unroll
   for (int r = 0; r < BH; r++)
 #pragma unroll
     for (int k = 0; k < BW / 4; k++) cb[r][k] = BW * BH >= 128 ? cur[r * 4 + k] : (u32)__builtin_amdgcn_readfirstlane(cur[r * 4 + k]);
-  const int Rs = c.Rs, ncol = 2 * Rs + 1, nrows = 2 * Rs + BH;
+  // candidate rows i_lo .. i_hi of the (2 Rs + 1) x (2 Rs + 1) positions (all of them, or one of two waves' halves)
+  const int Rs = c.Rs, ncol = 2 * Rs + 1, nrows = (i_hi - i_lo + 1) + BH - 1;
   u64 best = ~0ull;
+  if (pf && lane == 0) pf[25] = wall_clock64();
   {                                                            // columns 0..63: a lane slides down its column
     // A lane beyond the last column repeats the last column's candidates (same keys: harmless).  The column keeps ONE 32-bit key per
     // candidate: (cost << 7) | rank, rank = the candidate's place among the column's candidates in JM's spiral order (rows -|dx| .. |dx|
@@ -230,7 +270,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     // restricted to the column.  cost < 2^25: SAD << 5 < 2^21, rate < 2^22 with the lambda the host accepts.
     const int col = lane < ncol ? lane : ncol - 1;
     const int dx = col - Rs, adx = dx < 0 ? -dx : dx, xl = X0 + col, sh = xl & 3;
-    const u8 *p = win + (xl & ~3) + Y0 * WP;
+    const u8 *p = win + (xl & ~3) + (Y0 + i_lo) * WP;
     const int vx = c.cqx + 4 * dx;
     const u32 rate_x = (u32)(c.lambda * mvbits(vx - c.pqx));
     const bool zero_x = c.check00 && vx == 0;
@@ -243,6 +283,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       ytab[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 8) | (vy == 0 ? 128u : 0u) | (u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u;
     }
     wave_sync();
+    if (pf && lane == 0) pf[24] = wall_clock64();
     // window rows and row-table entries travel PF rows ahead of their use (an LDS read takes a couple of hundred cycles; a row of a small block
     // is summed in far less)
     constexpr int PF = BW * BH <= 64 ? 4 : (BW * BH <= 128 ? 2 : 1);
@@ -251,26 +292,27 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     for (int f = 0; f < PF; f++) {
 #pragma unroll
       for (int k = 0; k <= BW / 4; k++) a[f][k] = ((const u32 *)(p + f * WP))[k];
-      const int i = f - (BH - 1);
-      yt[f] = ytab[i < 0 ? 0 : i];
+      const int i = i_lo + f - (BH - 1);
+      yt[f] = ytab[i < 0 ? 0 : (i > 2 * Rs ? 2 * Rs : i)];
     }
     const u32 t16 = 16u * (u32)c.lambda;
     for (int j0 = 0; j0 < nrows; j0 += BH) {                   // rows past the last one (a partial final group) lie in the window's slack rows
+      u32 fin[BH], ytf[BH];
 #pragma unroll
       for (int s = 0; s < BH; s++) {
         const int j = j0 + s;
-        const int i = j - (BH - 1);                            // the candidate that ends with this row (the same for every lane)
         u32 b[BW / 4];
 #pragma unroll
         for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[s % PF][k + 1], a[s % PF][k], sh);
-        const u32 ytc = yt[s % PF];
+        ytf[s] = yt[s % PF];
         {                                                      // row j + PF into the slot just freed
           const u8 *pn = p + (j + PF) * WP;
 #pragma unroll
           for (int k = 0; k <= BW / 4; k++) a[s % PF][k] = ((const u32 *)pn)[k];
-          const int in = i + PF;
+          const int in = i_lo + j - (BH - 1) + PF;
           yt[s % PF] = ytab[in < 0 ? 0 : (in > 2 * Rs ? 2 * Rs : in)];
         }
+        __builtin_amdgcn_sched_barrier(0);                     // keeps the compiler from sinking the read-ahead to where the data is needed
 #pragma unroll
         for (int r = 0; r < BH; r++) {                         // window row j is row r of the candidate that starts at row j - r
           const int k = (s - r + BH) % BH;
@@ -279,17 +321,27 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
           for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
           acc[k] = v;
         }
-        {                                                      // no branch: rows that end no candidate give the key ~0
-          const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
-          const u32 rank = ady <= adx ? (u32)(dy + adx) : (ytc & 127u);
-          u32 rate = rate_x + (ytc >> 8);
-          const u32 rz = rate > t16 ? rate - t16 : 0u;         // me_fullsearch.c:78-82
-          rate = (zero_x && (ytc & 128u)) ? rz : rate;
-          u32 key = (((acc[(s + 1) % BH] << 5) + rate) << 7) | rank;
-          key = (i >= 0 && i <= 2 * Rs) ? key : 0xffffffffu;
-          bkey = key < bkey ? key : bkey;
-        }
+        fin[s] = acc[(s + 1) % BH];                            // the candidate that ends with this row
       }
+      // the group's keys side by side: BH independent chains (a lone wave issues a dependent instruction only every ~9 cycles), no branch: rows that
+      // end no candidate of this wave's range give the key ~0
+      u32 gk[BH];
+#pragma unroll
+      for (int s = 0; s < BH; s++) {
+        const int i = i_lo + j0 + s - (BH - 1);                // the same for every lane
+        const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
+        const u32 rank = ady <= adx ? (u32)(dy + adx) : (ytf[s] & 127u);
+        u32 rate = rate_x + (ytf[s] >> 8);
+        const u32 rz = rate > t16 ? rate - t16 : 0u;           // me_fullsearch.c:78-82
+        rate = (zero_x && (ytf[s] & 128u)) ? rz : rate;
+        const u32 key = (((fin[s] << 5) + rate) << 7) | rank;
+        gk[s] = (i >= i_lo && i <= i_hi) ? key : 0xffffffffu;
+      }
+#pragma unroll
+      for (int w = BH / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int s = 0; s < w; s++) gk[s] = gk[s] < gk[s + w] ? gk[s] : gk[s + w];
+      bkey = gk[0] < bkey ? gk[0] : bkey;
     }
     {
       const int rank = (int)(bkey & 127u);
@@ -299,7 +351,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     }
   }
   if (pf && lane == 0) pf[7] = wall_clock64();
-  for (int col = 64; col < ncol; col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
+  for (int col = 64; col < (col64 ? ncol : 64); col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
     const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
     for (int i0 = 0; i0 <= 2 * Rs; i0 += 64) {
@@ -318,7 +370,9 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     }
   }
   if (pf && lane == 0) pf[23] = wall_clock64();
-  return wave_min_u64(best);
+  const u32 hi = wave_min_u32((u32)(best >> 32));              // the smallest cost, then the earliest spiral index among the candidates that have it
+  const u32 lo = wave_min_u32((u32)(best >> 32) == hi ? (u32)best : 0xffffffffu);
+  return ((u64)hi << 32) | lo;
 }
 
 // ------------------------------------------------------------------ Hadamard SATD of a 4x4 block (HadamardSAD4x4 me_distortion.c:175-258)
@@ -375,7 +429,7 @@ __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int w
 #pragma unroll
     for (int j = 0; j < 4; j++) o[j] = S.cur_y[(mb_y + sby + j) * 4 + ((mb_x + sbx) >> 2)];
     int v = live ? satd4_rows(o, r) : 0;
-    for (int off = 1; off < nb4; off <<= 1) v += __shfl_xor(v, off, 64);
+    v = group_sum(v, nb4);
     if (live && b == 0) S.red[wave][cnd] = v;
   }
   wave_sync();
@@ -392,25 +446,26 @@ __device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv
   int cost = lambda * (mvbits(qx - pqx) + mvbits(qy - pqy)) + (S.red[wave][pos] << 5);
   if (pos == 0) cost = first ? incumbent : cost - bonus0;
   u32 key = lane < 9 ? (((u32)(cost + (1 << 27))) << 4) | (u32)pos : 0xffffffffu;       // costs stay far below 2^27 in magnitude
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) { const u32 t = (u32)__shfl_xor((int)key, off, 64); key = t < key ? t : key; }
-  key = (u32)rfl((int)key);
+  key = (u32)rfl((int)row16_min_u32(key));
   min_out = (int)(key >> 4) - (1 << 27);
   return (int)(key & 15u);
 }
 
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
-__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
+// view: which chain's picture of the macroblock's vectors the predictor reads; wave: this wave's own scratch (row table, SATD sums).
+// G = 2: two waves share the integer search (part 0 the upper candidate rows and everything after the search, part 1 the lower rows only; part 1
+// returns nothing); seq: the pair's running search number.
+__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int part, int G, int seq, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
 {
   const jmhip_slice_params &P = A.p;
   const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const bool prof_ = A.prof && A.prof_mode == 1 && bt == 7 && mb_x == 0 && mb_y == 0 && ref == 0 && lane == 0;
-#define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 24 + (k)] = wall_clock64(); } while (0)
+  const bool prof_ = A.prof && ((A.prof_mode == 1 && mb_x == 0) || (A.prof_mode == 4 && mb_x == 8)) && part == 0 && bt == 7 && mb_y == 0 && ref == 0 && lane == 0;
+#define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
-  const int pred = rfl(mv_predictor(S, wave, avm, ref, mb_x, mb_y, BW, BH));
+  const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH));
   BS_STAMP(19);
   int cx = ((mvx(pred) + 2) >> 2) * 4, cy = ((mvy(pred) + 2) >> 2) * 4;          // mv_search.c:931-932
   int min_x = -(R << 2), max_x = R << 2, min_y = min_x, max_y = max_x;
@@ -439,15 +494,28 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
+  const int i_lo = part ? c.Rs + 1 : 0, i_hi = (G == 2 && !part) ? c.Rs : 2 * c.Rs;
   u64 key;
   switch (bt) {
-  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
-  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
-  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
-  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
-  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
-  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
-  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 24 : nullptr); break;
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  }
+  if (G == 2) {
+    if (part) {                                               // the helper hands its half over and is done with this search
+      if (lane == 0) S.xkey[view] = key;
+      lds_signal(&S.xseq_h[view], seq, lane);
+      out_mv = 0;
+      return 0;
+    }
+    if (prof_) A.prof[(long)addr_ * 32 + 26] = wall_clock64();
+    lds_wait(&S.xseq_h[view], seq);
+    const u64 other = S.xkey[view];
+    key = other < key ? other : key;
   }
   const int klo = rfl((int)(u32)key), khi = rfl((int)(u32)(key >> 32));
   BS_STAMP(20);
@@ -467,7 +535,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
 
   if (bt == 1 && P.slice_type == 0) {                          // the skip vector against the 16x16 result: mv_search.c:983-998, GetSkipCostMB :1257
-    const int sv = rfl(skip_vector(S, wave, avm));
+    const int sv = rfl(skip_vector(S, view, avm));
     if (lane == 0) S.skip_mv = sv;
     const int qx = (mbx * 64) + mvx(sv), qy = (mby * 64) + mvy(sv);
     const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);     // one origin for the 16x16 block
@@ -477,8 +545,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
 #pragma unroll
     for (int j = 0; j < 4; j++) { r[j] = ldu32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
     int v = lane < 16 ? satd4_rows(o, r) : 0;
-    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-    v = rfl(v);
+    v = rfl(group_sum(v, 16));
     const int cost = (v << 5) - P.lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = sv; }
   }

@@ -17,7 +17,7 @@ nmb = 8160
 for n in range(2):
     tm = []
     recs, pre, post = enc.encode(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], timing=tm)
-    st = np.zeros((nmb, 24), np.uint64)
+    st = np.zeros((nmb, 32), np.uint64)
     assert enc.J.lib.jmhip_debug_read_mb_prof(enc.J.h, st.ctypes.data_as(C.c_void_p), st.nbytes) == 0
     st = st.astype(np.int64)
     us = lambda a, b: (st[:, b] - st[:, a]) / 100.0
@@ -28,8 +28,11 @@ for n in range(2):
         print(f"  {name:45s} {np.median(d):8.1f} {d.mean():8.1f}")
     print("  phase 0 per wave (from phase start to the wave's end; waves 0-3: 8x8, 8x4, 4x8, 4x4 of block 0; 4-6: 16x16, 16x8, 8x16; 7: intra):")
     print("   ", " ".join(f"{np.median((st[:, 8 + w] - st[:, 2]) / 100.0):7.1f}" for w in range(8)))
+    if MODE == "4" and n == 1:
+        print("  first 4x4 search of the SECOND 8x8 block (two waves): predictor %.2f, centre + block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f, waiting for the helper %.2f, half-pel %.2f, quarter-pel %.2f us" % tuple(
+            np.median(us(a, b)) for a, b in ((18, 19), (19, 25), (25, 24), (24, 7), (7, 23), (23, 26), (26, 20), (20, 21), (21, 22))))
     if MODE == "1" and n == 1:
-        print("  ... of the integer search: centre + tables + column loop %.2f, column 64 %.2f, wave minimum %.2f us" % tuple(np.median(us(a, b)) for a, b in ((19, 7), (7, 23), (23, 20))))
+        print("  ... of the integer search: centre + source block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f us" % tuple(np.median(us(a, b)) for a, b in ((19, 25), (25, 24), (24, 7), (7, 23), (23, 20))))
     if MODE == "2":
         print("  intra wave: Intra4x4 chain %.1f, Intra16x16 search %.1f, chroma decision %.1f us (medians)" % tuple(np.median(us(a, b)) for a, b in ((2, 7), (7, 23), (23, 15))))
     if MODE == "3":
