@@ -109,6 +109,8 @@ struct Shared {
   int xseq_h[4], xseq_m[4];
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
+  int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
+  u64 fl_cbp_blk, fc_bits;
   u32 fin_cbp_blk;
   jmhip_mb_record out;
 };
