@@ -113,6 +113,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   }
   CK(hipMalloc((void **)&c->d_me_declined, 64));
   CK(hipMemsetAsync(c->d_me_declined, 0, 64, c->stream));
+  CK(hipMemsetAsync(c->d_me_declined + 5, 0xff, 4, c->stream));       // index of the first bad job: none
   CK(hipMalloc(&c->d_db_prep, (size_t)(c->W / 16) * (c->H / 16) * 192));
   CK(hipMalloc((void **)&c->d_db_sync, 64 + (size_t)(c->H / 16) * 2 * 6 * 8));
   CK(hipMalloc(&c->d_db_hand, (size_t)(c->W / 16) * (c->H / 16) * 192));
@@ -182,6 +183,8 @@ extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
 {
   if (!ctx) return JMHIP_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int r = jmhip_check_job_error(ctx);
+  if (r) return r;
   return jmhip_check_deblock_error(ctx);
 }
 

@@ -27,7 +27,8 @@ struct jmhip_ctx {
   void *d_scratch; size_t scratch_bytes;     // grows on demand: jobs/results/tables for host entry points
   void *d_scratch2; size_t scratch2_bytes;
   int16_t *d_spiral;     // [(2R+1)^2][2] spiral offsets for R = cfg.search_range
-  unsigned *d_me_declined; // [2] jobs k_me_fs_fast left to k_me_fullsearch, ping-pong by launch parity
+  unsigned *d_me_declined; // [0..1] jobs k_me_fs_fast left to k_me_fullsearch, ping-pong by launch parity; [4] job error flag, [5] index of the first bad job
+  int me_jobs_checked;     // a job check kernel has run since the error word was last read
   unsigned me_launches;
   void *d_db_prep;       // deblocking: 192-byte strength/parameter record per macroblock (k_deblock_prep)
   unsigned *d_db_sync;   // deblocking row pipeline: ticket, error
@@ -70,6 +71,9 @@ void jmhip_time_end(jmhip_ctx *ctx, int kind);
 
 // kernels' launchers (defined next to the kernels)
 int jmhip_check_deblock_error(jmhip_ctx *ctx);
+int jmhip_check_job_error(jmhip_ctx *ctx);      // me_fullsearch.hip: device-side validation of job records
+void jmhip_launch_check_me_jobs(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, int n);
+void jmhip_launch_check_subpel_jobs(jmhip_ctx *ctx, const jmhip_subpel_job *d_jobs, int n);
 void jmhip_mb_free(jmhip_ctx *ctx);   // mbpipe.hip
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);
 int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,

@@ -164,8 +164,9 @@ __device__ __forceinline__ unsigned long long full_key(unsigned kk, int p, int d
 __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__restrict__ jobs, jmhip_me_result *__restrict__ results,
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
-                                                       unsigned *__restrict__ declined, int njobs)
+                                                       unsigned *__restrict__ declined, int njobs, const unsigned *__restrict__ jerr)
 {
+  if (*jerr) return;                                        // a job record failed k_check_me_jobs (me_fullsearch.hip)
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[COPY_DWORDS];        // window copies, later the wave-merge area
   __shared__ __attribute__((aligned(16))) uint32_t s_ry[65 * RYP];            // (lambda * mvbits(cand_y - pred_y[p])) << cost_shift, [row][partition]; later the 65th column's keys
   __shared__ uint32_t s_rx64[RYP];                                              // x rate of column 64, per partition
@@ -353,5 +354,5 @@ __global__ __launch_bounds__(NT, 4) void k_me_fs_fast(const jmhip_me_job *__rest
 void jmhip_launch_me_fast(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, jmhip_me_result *d_results, unsigned *d_declined)
 {
   hipLaunchKernelGGL(k_me_fs_fast, dim3(njobs), dim3(NT), 0, ctx->stream, d_jobs, d_results, ctx->d_cur, ctx->cur_pitch,
-                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, d_declined, njobs);
+                     ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, d_declined, njobs, ctx->d_me_declined + 4);
 }

@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void k_me_fullsearch(const jmhip_me_job *__res
                                                        const uint8_t *__restrict__ cur, int cur_pitch,
                                                        const uint8_t *__restrict__ ref00, int pitch, long plane_stride, int W, int H,
                                                        const int16_t *__restrict__ spiral, int skip_fast,
-                                                       const unsigned *__restrict__ declined, unsigned *__restrict__ declined_next, int njobs)
+                                                       const unsigned *__restrict__ declined, unsigned *__restrict__ declined_next, int njobs, const unsigned *__restrict__ jerr)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (*jerr) return;                                       // a job record failed k_check_me_jobs
   if (skip_fast) {                                         // k_me_fs_fast ran before this launch and counted the jobs it left for us
     if (blockIdx.x == 0 && threadIdx.x == 0) *declined_next = 0;          // the counter of the NEXT launch pair (ping-pong)
     if (*declined == 0) return;
@@ -179,6 +180,51 @@ static size_t me_lds_bytes(int R)
   return win + 64 * 4 + sizeof(JobLds) + 4 * NP * 8 + 64;
 }
 
+// ---- device-resident job records are checked on the device (the `_dev` entry points never see them on the host): a bad record raises the
+// context's job error word -- 1 + the index of the first bad job -- and every ME kernel returns at once while the word is set, so a bad job list
+// costs an error at the next jmhip_synchronize instead of an out-of-range LDS / plane access.  The word stays set until it has been reported.
+__global__ __launch_bounds__(256) void k_check_me_jobs(const jmhip_me_job *__restrict__ jobs, int n, int R_cfg, int W, int H, unsigned *__restrict__ err)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const jmhip_me_job *j = jobs + i;
+  const bool bad = j->search_range < 1 || j->search_range > R_cfg || j->mb_x < 0 || j->mb_y < 0 || j->mb_x + 16 > W || j->mb_y + 16 > H || (j->mb_x & 3);
+  if (bad) atomicMin(err + 1, (unsigned)i), atomicOr(err, 1u);
+}
+__global__ __launch_bounds__(256) void k_check_subpel_jobs(const jmhip_subpel_job *__restrict__ jobs, int n, int W, int H, unsigned *__restrict__ err)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const jmhip_subpel_job *j = jobs + i;
+  const bool bad = j->pos_x < 0 || j->pos_y < 0 || j->bsx < 4 || j->bsy < 4 || j->bsx > 16 || j->bsy > 16 || (j->bsx & 3) || (j->bsy & 3) || j->pos_x + j->bsx > W || j->pos_y + j->bsy > H;
+  if (bad) atomicMin(err + 1, (unsigned)i), atomicOr(err, 1u);
+}
+void jmhip_launch_check_me_jobs(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, int n)
+{
+  hipLaunchKernelGGL(k_check_me_jobs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, n, ctx->cfg.search_range, ctx->W, ctx->H, ctx->d_me_declined + 4);
+  ctx->me_jobs_checked = 1;
+}
+void jmhip_launch_check_subpel_jobs(jmhip_ctx *ctx, const jmhip_subpel_job *d_jobs, int n)
+{
+  hipLaunchKernelGGL(k_check_subpel_jobs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, n, ctx->W, ctx->H, ctx->d_me_declined + 4);
+  ctx->me_jobs_checked = 1;
+}
+int jmhip_check_job_error(jmhip_ctx *ctx)
+{
+  if (!ctx->me_jobs_checked) return JMHIP_OK;
+  unsigned w[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(w, ctx->d_me_declined + 4, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->me_jobs_checked = 0;
+  if (w[0]) {
+    const unsigned clear[2] = {0, 0xffffffffu};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_me_declined + 4, clear, sizeof clear, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return jmhip_fail(ctx, JMHIP_EINVAL, "device-resident job %u is invalid (search range beyond the context's, or a block outside the picture): the motion estimation launches since then did nothing", w[1]);
+  }
+  return JMHIP_OK;
+}
+
 static int check_jobs_host(jmhip_ctx *ctx, const jmhip_me_job *jobs, int n)
 {
   for (int i = 0; i < n; i++) {
@@ -197,13 +243,14 @@ extern "C" int jmhip_me_fullsearch_dev(jmhip_ctx *ctx, int32_t slot, const jmhip
   if (!d_jobs || !d_results || njobs < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_fullsearch_dev: bad argument");
   if (njobs == 0) return JMHIP_OK;
   const int use_fast = !ctx->force_generic;
+  jmhip_launch_check_me_jobs(ctx, d_jobs, njobs);
   jmhip_time_begin(ctx, 1);
   unsigned *dec = ctx->d_me_declined + (ctx->me_launches & 1), *dec_next = ctx->d_me_declined + ((ctx->me_launches + 1) & 1);
   ctx->me_launches++;
   if (use_fast) jmhip_launch_me_fast(ctx, slot, d_jobs, njobs, d_results, dec);
   hipLaunchKernelGGL(k_me_fullsearch, dim3(use_fast ? (njobs < 1024 ? njobs : 1024) : njobs), dim3(256), me_lds_bytes(ctx->cfg.search_range), ctx->stream,
                      d_jobs, d_results, ctx->d_cur, ctx->cur_pitch, ctx->d_sub[slot], ctx->pitch, (long)ctx->plane_stride, ctx->W, ctx->H, ctx->d_spiral, use_fast,
-                     dec, dec_next, njobs);
+                     dec, dec_next, njobs, ctx->d_me_declined + 4);
   jmhip_time_end(ctx, 1);
   HIPCHK(ctx, hipGetLastError());
   return JMHIP_OK;

@@ -17,7 +17,7 @@
 #include "jmhip_internal.h"
 #include "me_common.h"
 
-struct PlaneSet2 { const uint8_t *base; int pitch; long plane_stride; int W, H; };
+struct PlaneSet2 { const uint8_t *base; int pitch; long plane_stride; int W, H; const unsigned *jerr; };   // jerr: the context's job error word (me_fullsearch.hip)
 
 __device__ __forceinline__ int iabs2_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int mvbits2(int d) { int a = iabs2_(d); return a == 0 ? 1 : 2 * (31 - __clz(a)) + 3; }
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(REFINE_THREADS, T8MODE ? 3 : 6) void k_me_refine_mb
   __shared__ uint8_t s_list[NPAIRS];              // the leader pairs, compacted
   __shared__ int s_nlead[2];
   __shared__ uint16_t s_val[NPAIRS * 9];          // distortion of (block type, 4x4 block, candidate) as its lane computed it, for lanes with the same vector
+  if (*ps.jerr) return;                            // a job record failed k_check_me_jobs
   const int tid = threadIdx.x;
   const int jb = xcd_job_index(blockIdx.x, njobs);
   const jmhip_me_job *job = jobs + jb;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(REFINE_THREADS, T8MODE ? 3 : 6) void k_me_refine_mb
 void jmhip_launch_refine_mb(jmhip_ctx *ctx, int slot, const jmhip_me_job *d_jobs, int njobs, const jmhip_me_result *d_int,
                             const jmhip_refine_params *prm, jmhip_me_result *d_out)
 {
-  PlaneSet2 ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H;
+  PlaneSet2 ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H; ps.jerr = ctx->d_me_declined + 4;
   if (prm->transform8x8_mode)
     hipLaunchKernelGGL(k_me_refine_mb<true>, dim3(njobs), dim3(REFINE_THREADS), 0, ctx->stream, d_jobs, d_int, *prm, d_out, ps, ctx->d_cur, ctx->cur_pitch, njobs);
   else

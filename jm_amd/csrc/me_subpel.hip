@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include "jmhip_internal.h"
 
-struct PlaneSet { const uint8_t *base; int pitch; long plane_stride; int W, H; };
+struct PlaneSet { const uint8_t *base; int pitch; long plane_stride; int W, H; const unsigned *jerr; };   // jerr: the context's job error word (me_fullsearch.hip)
 
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int mvbits(int d) { int a = iabs_(d); return a == 0 ? 1 : 2 * (31 - __clz(a)) + 3; }
@@ -140,6 +140,7 @@ __device__ __forceinline__ int pred_at(const PredSrc &p, int j, int i)
 __global__ __launch_bounds__(64) void k_me_eval_pred(const jmhip_pred_cand *__restrict__ cands, int n, int32_t *__restrict__ dist, SlotBases slots, int nslots,
                                                      PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
 {
+  if (*ps.jerr) return;                                   // a job record failed k_check_subpel_jobs
   const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   const bool live = g < n;
   const jmhip_pred_cand c = cands[live ? g : 0];
@@ -256,6 +257,7 @@ __device__ jmhip_me_best subpel_group(const jmhip_subpel_job &j, int l, const Pl
 __global__ __launch_bounds__(64) void k_me_subpel(const jmhip_subpel_job *__restrict__ jobs, int n, jmhip_me_best *__restrict__ out,
                                                   PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
 {
+  if (*ps.jerr) return;                                   // a job record failed k_check_subpel_jobs
   const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   const bool live = g < n;
   jmhip_subpel_job j = jobs[live ? g : 0];
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(64) void k_me_refine(const jmhip_me_job *__restrict
                                                   jmhip_refine_params prm, jmhip_me_result *__restrict__ out,
                                                   PlaneSet ps, const uint8_t *__restrict__ cur, int cur_pitch)
 {
+  if (*ps.jerr) return;                                   // a job record failed k_check_me_jobs
   const int g = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   const int ji = g / JMHIP_NPART, p = g - ji * JMHIP_NPART;
   const bool live = ji < njobs;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64) void k_me_refine(const jmhip_me_job *__restrict
 
 static PlaneSet planes_of(jmhip_ctx *ctx, int slot)
 {
-  PlaneSet ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H;
+  PlaneSet ps; ps.base = ctx->d_sub[slot]; ps.pitch = ctx->pitch; ps.plane_stride = (long)ctx->plane_stride; ps.W = ctx->W; ps.H = ctx->H; ps.jerr = ctx->d_me_declined + 4;
   return ps;
 }
 
@@ -308,6 +311,7 @@ extern "C" int jmhip_me_subpel_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_sub
   if (!ctx) return JMHIP_EINVAL;
   if (!d_jobs || !d_results || n < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_subpel_dev: bad argument");
   if (n == 0) return JMHIP_OK;
+  jmhip_launch_check_subpel_jobs(ctx, d_jobs, n);
   jmhip_time_begin(ctx, 2);
   hipLaunchKernelGGL(k_me_subpel, dim3((n + 3) / 4), dim3(64), 0, ctx->stream, d_jobs, n, d_results, planes_of(ctx, slot), ctx->d_cur, ctx->cur_pitch);
   jmhip_time_end(ctx, 2);
@@ -345,6 +349,7 @@ extern "C" int jmhip_me_refine_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_
   if (!ctx) return JMHIP_EINVAL;
   if (!d_jobs || !d_int || !prm || !d_out || njobs < 0 || slot < 0 || slot >= ctx->cfg.num_ref_slots) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_me_refine_dev: bad argument");
   if (njobs == 0) return JMHIP_OK;
+  jmhip_launch_check_me_jobs(ctx, d_jobs, njobs);
   jmhip_time_begin(ctx, 2);
   if (getenv("JMHIP_REFINE_PER_BLOCK")) {                 // the per-block kernel (one 16-lane group per partition): A/B testing
     const long groups = (long)njobs * JMHIP_NPART;

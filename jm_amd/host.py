@@ -8,7 +8,7 @@ JM-style block searches into libjmhip jobs:
   level_mv_limits() lencod/src/conformance.c:37-67,604-646 (MaxHmvR/MaxVmvR for a LevelIDC)
   group_fs_jobs()   one jmhip_me_job per (macroblock, distinct search centre); this is how
                     full_search_motion_estimation's per-block windows map onto window jobs
-  lambda_factors()  lencod/src/lambda.c:83-125 for P slices: kept on the host, double math
+  (the Lagrangian factors are never recomputed here: they are JM's -ffloat-store double arithmetic and reach the library as inputs)
 """
 import math
 import numpy as np
@@ -33,15 +33,6 @@ def search_center(pred, limits):
     cx = min(max(cx, limits[0]), limits[1])
     cy = min(max(cy, limits[2]), limits[3])
     return cx, cy
-
-
-def lambda_factors(qp, num_b_frames=0, satd_subpel=True):
-    """lambda_mf[F_PEL/H_PEL/Q_PEL] of a P slice (lencod/src/lambda.c:19-32,83-125, defines.h:131)."""
-    lambda_md = (0.68 if num_b_frames > 0 else 0.85) * 2.0 ** ((qp - 12) / 3.0)
-    if not satd_subpel:
-        lambda_md *= 0.95
-    lam = int(32.0 * math.sqrt(lambda_md) + 0.5)
-    return lam, lam, lam
 
 
 def group_fs_jobs(mb_x, mb_y, preds, limits, search_range, lam):

@@ -97,7 +97,7 @@ def test_fullsearch_golden_records(fs):
 
 
 @pytest.mark.parametrize("w,h,R,seed", [(176, 144, 16, 1), (320, 192, 32, 2), (64, 48, 8, 3), (208, 112, 1, 4), (16, 16, 3, 5),
-                                        (144, 96, 48, 6), (80, 64, 64, 7), (1920, 1088, 31, 8)])
+                                        (144, 96, 48, 6), (80, 64, 64, 7), (1920, 1088, 31, 8), (3840, 2160, 32, 9)])   # the last: configs[3]'s picture size and range
 def test_fullsearch_all_partitions_vs_oracle(J, w, h, R, seed):
     """window jobs with all 41 partitions, random predictors and centres, windows hanging off every
     picture edge; FS semantics (max_mvd 0) and FFS semantics (max_mvd guard)."""

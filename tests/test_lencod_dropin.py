@@ -185,6 +185,55 @@ def test_lencod_macroblock_pipeline_configs1_full_size_1080p(tmp_path):
     print(f"configs[1], RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
 
 
+def run_2160p(tag, tmp, env_extra=None):
+    """lencod_hip.exe on BASELINE configs[3] at its own size: synthetic 2160p, 8 slices of 4080 macroblocks, two pictures (tests/golden/make_g4.py)"""
+    import sys
+    sys.path.insert(0, G)
+    import synclip
+    e = MD5[tag]
+    synclip.syn2160p(os.path.join(tmp, "syn2160p.yuv"))
+    args = [EXE, "-d", os.path.join(G, "jm_baseline.cfg")]
+    for k, v in dict(e["overrides"], OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
+        args += ["-p", f"{k}={v}"]
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    return subprocess.run(args, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=2400), e
+
+
+@pytest.mark.gpu
+def test_lencod_macroblock_pipeline_configs3_2160p_8_slices(tmp_path):
+    """BASELINE.json configs[3] at 3840x2160 with RDOptimization = 0 (G4r): 8 slices per picture, 64 800 macroblocks through jmhip_encode_slice, the
+    bitstream and the reconstruction equal CPU JM's."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, e = run_2160p("G4r", str(tmp_path))
+    err, out = r.stderr.decode(errors="replace"), r.stdout.decode(errors="replace")
+    assert r.returncode == 0, (out[-1500:], err[-1500:])
+    rep = pipeline_report(err)
+    c = counters(err)
+    assert rep and rep["mbs"] == 2 * 32400 and rep["slices"] == 16, (rep, err[-1500:])
+    assert c["passed"] == 0 and c["fs"] == 0 and c["subpel"] == 0, c
+    assert md5(os.path.join(str(tmp_path), "o.264")) == e["md5_264"], ("bitstream differs from CPU JM", rep)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == e["md5_recon"], ("reconstruction differs from CPU JM", rep)
+    print(f"configs[3] at 2160p, RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
+
+
+@pytest.mark.gpu
+def test_lencod_configs3_full_size_2160p_per_call(tmp_path):
+    """BASELINE.json configs[3] as SURVEY.md 8c states it (G4: RDO on, 2160p, 8 slices, md5 933ebd28...): the per-call path (every BlockMotionSearch of
+    the P picture on the device one by one, sub-pel planes, deblocking), as the 1080p test does for configs[1].  Minutes, not seconds."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, e = run_2160p("G4", str(tmp_path), {"JMHIP_ADAPTER_PARTS": "load,interp,fs,subpel,deblock"})
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
+    c = counters(err)
+    assert e["md5_264"] == "933ebd28693881fb1a22886d332d751d"
+    assert c["fs"] > 1000000 and c["subpel"] > 1000000 and c["interp"] == 2 and c["deblock"] == 2, c
+    assert md5(os.path.join(str(tmp_path), "o.264")) == e["md5_264"], ("bitstream differs from CPU JM", c)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == e["md5_recon"], ("reconstruction differs from CPU JM", c)
+
+
 def test_adapter_fails_loudly_without_a_device(tmp_path):
     """not gpu: on a box without a HIP device the adapter must stop the encoder, not fall back to the CPU."""
     import torch
