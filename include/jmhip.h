@@ -575,7 +575,9 @@ typedef struct {
   jmhip_qparam q_luma[2][16];   /* p_Quant->q_params_4x4[0][intra][qp][j][i] at [intra][j * 4 + i] */
   jmhip_qparam q_chroma[2][2][16];  /* p_Quant->q_params_4x4[1 + uv][intra][qpc + chroma scale] at [uv][intra][j * 4 + i] */
   int32_t df_disable_idc, df_alpha_c0, df_beta;   /* Macroblock.DFDisableIdc, DFAlphaC0Offset, DFBetaOffset of the slice */
-  int32_t reserved_[5];
+  int32_t num_slices;           /* 0 or 1: one slice.  n > 1: the call covers n consecutive slices of num_mb macroblocks each (the last one ends with the
+                                   picture), same parameters, slice_nr counting up -- SliceMode 1 pictures: the slices' wavefronts run side by side */
+  int32_t reserved_[4];
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);

@@ -1097,7 +1097,7 @@ static struct {
   StorablePicture *pic;               /* the picture the records / the device reconstruction belong to */
   int mbs;                            /* its macroblocks served so far */
   int deblocked;
-  int slice_last;                     /* last macroblock of the slice the device is encoding */
+  int slice_last;                     /* last macroblock the running launch covers (one slice, or every slice of the picture) */
   long n_slices, n_mbs, n_refs;
   double t_dev, t_fill, t_wait;
 } P;
@@ -1169,6 +1169,7 @@ static void pipe_run_slice(Macroblock *currMB)
   const int first = currMB->mbAddrX, left = (int)p_Vid->PicSizeInMbs - first;
   int r, rc, intra, uv, j, i, m;
   double t0 = now_s();
+  if (P.pic == p_Vid->enc_picture && first > 0 && first <= P.slice_last) { P.n_slices++; return; }      /* launched together with the picture's first slice */
   if (P.pic != p_Vid->enc_picture || first == 0) {          /* a new picture: its source planes go up once */
     P.pic = p_Vid->enc_picture; P.mbs = 0; P.deblocked = 0;
     rc = jmhip_set_current_planes(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
@@ -1212,8 +1213,11 @@ static void pipe_run_slice(Macroblock *currMB)
       }
   prm.df_disable_idc = currMB->DFDisableIdc; prm.df_alpha_c0 = currMB->DFAlphaC0Offset; prm.df_beta = currMB->DFBetaOffset;
   if (currMB->qp_scaled[0] != currMB->qp) { fprintf(stderr, "jmhip adapter: macroblock pipeline: luma QP scale\n"); exit(70); }
+  /* SliceMode 1: every slice of the picture has the same parameters (no rate control here), so all of them are launched with the first one and
+   * their wavefronts run side by side on the device; JM still codes them one after the other */
+  if (p_Inp->slice_mode == FIXED_MB && first == 0 && prm.num_mb < left) prm.num_slices = (left + prm.num_mb - 1) / prm.num_mb;
   if ((rc = jmhip_encode_slice_begin(G.ctx, &prm))) adapter_die("jmhip_encode_slice_begin", rc);
-  P.slice_last = first + prm.num_mb - 1;
+  P.slice_last = prm.num_slices > 1 ? (int)p_Vid->PicSizeInMbs - 1 : first + prm.num_mb - 1;
   P.n_slices++; P.n_refs += prm.num_ref;
   P.t_dev += now_s() - t0;
 }

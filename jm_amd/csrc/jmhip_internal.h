@@ -43,7 +43,7 @@ struct jmhip_ctx {
   unsigned *d_mb_done;   // per macroblock: epoch of the launch that finished it
   unsigned *d_mb_sync;   // [0] ticket, [1] error word
   int *d_mb_order;       // wavefront order of the slice's macroblocks
-  int mb_order_first, mb_order_num;
+  int mb_order_first, mb_order_num, mb_order_per;
   unsigned mb_epoch;
   void *d_mb_records;    // jmhip_mb_record per macroblock of the picture
   void *d_mb_dbmb, *d_mb_dbmo;   // loop-filter side information written by the pipeline

@@ -52,6 +52,7 @@ static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 14
 struct PipeArgs {
   jmhip_slice_params p;
   int W, H, wmb, hmb, cw, ch;
+  int total_mb;                              // macroblocks of the launch (num_slices slices of p.num_mb, cut at the end of the picture)
   int cur_pitch, ref_pitch, rec_pitch;       // luma pitches (bytes); chroma planes are cw wide
   long plane_stride;
   int win_h, win_p, win_ox;                  // LDS window of a reference: (16 + 4R) rows of win_p bytes; the macroblock's column 0 sits at byte win_ox

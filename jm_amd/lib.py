@@ -86,7 +86,7 @@ SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", 
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
                          ("inter_valid", "<i4", (8,)), ("intra4_valid", "<i4"), ("intra16_valid", "<i4"), ("subpel", "<i4"), ("start_qp", "<i4"),
                          ("refbits", "<i4", (MB_MAX_REF,)), ("q_luma", "<i4", (2, 16, 3)), ("q_chroma", "<i4", (2, 2, 16, 3)),
-                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("reserved_", "<i4", (5,))])
+                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("num_slices", "<i4"), ("reserved_", "<i4", (4,))])
 assert MB_RECORD.itemsize == 944 and SLICE_PARAMS.itemsize == 1492
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
@@ -541,9 +541,14 @@ class JmHip:
     def encode_slice(self, prm):
         """prm: one SLICE_PARAMS record -> MB_RECORD per macroblock of the slice; reconstruction and loop-filter side information stay on the device"""
         prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
-        out = np.zeros(int(prm["num_mb"][0]), MB_RECORD)
+        out = np.zeros(self.slice_call_macroblocks(prm), MB_RECORD)
         self._ck(self.lib.jmhip_encode_slice(self.h, _vp(prm), _vp(out)))
         return out
+
+    def slice_call_macroblocks(self, prm):
+        """macroblocks one jmhip_encode_slice call covers (num_slices slices of num_mb, the last one ends with the picture)"""
+        first, num, ns = int(prm["first_mb"][0]), int(prm["num_mb"][0]), max(1, int(prm["num_slices"][0]))
+        return min(num * ns, (self.W // 16) * (self.H // 16) - first)
 
     def encode_slice_dev(self, prm, d_out=None):
         prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
@@ -552,7 +557,7 @@ class JmHip:
     def encode_slice_streamed(self, prm):
         """jmhip_encode_slice_begin / _record (raster order, while the device is still encoding) / _end; returns the records"""
         prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
-        first, num = int(prm["first_mb"][0]), int(prm["num_mb"][0])
+        first, num = int(prm["first_mb"][0]), self.slice_call_macroblocks(prm)
         out = np.zeros(num, MB_RECORD)
         self._ck(self.lib.jmhip_encode_slice_begin(self.h, _vp(prm)))
         p = C.c_void_p()

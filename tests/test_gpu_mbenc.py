@@ -46,8 +46,9 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0):
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False):
         import jm_amd.lib as L
+        self.together = together      # all slices of a picture in one launch (num_slices), as the adapter does for SliceMode 1
         self.L = L
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
@@ -62,12 +63,19 @@ class DevSeqEncoder:
         nref = min(self.num_ref, len(self.refs)) if st == 0 else 0
         J.set_current_frame(raw, sw, sh)
         recs = np.zeros(nmb, L.MB_RECORD)
-        for sn, (first, num) in enumerate(mbenc_util.slices_of(nmb, self.slice_mbs)):
+        slices = mbenc_util.slices_of(nmb, self.slice_mbs)
+        for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
             cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc)
             if timing is not None:
                 J.enable_timing(True)
+            if self.together and len(slices) > 1:
+                prm["num_slices"] = len(slices)
+                recs[:] = J.encode_slice_streamed(prm) if self.npic & 1 else J.encode_slice(prm)
+                if timing is not None:
+                    timing.append(J.last_kernel_ms(5))
+                break
             recs[first:first + num] = J.encode_slice(prm)
             if timing is not None:
                 timing.append(J.last_kernel_ms(5))
@@ -156,6 +164,9 @@ LAMBDAS = {2: ([192, 192, 192], 192), 0: ([192, 192, 192], 192)}     # JM's tabl
 
 
 @pytest.mark.parametrize("W,H,R,num_ref,slice_mbs,qp,seed", [
+    (320, 192, 32, 3, -50, 36, 3),    # negative slice size: the slices of a picture in ONE launch (num_slices), their wavefronts side by side
+    (208, 160, 8, 1, -13, 20, 4),
+    (256, 128, 16, 2, -100, 28, 6),   # the last slice shorter than the others
     (176, 144, 16, 1, 0, 28, 1),
     (64, 48, 32, 2, 0, 28, 2),        # a picture smaller than the search window: every window clamps on all sides
     (320, 192, 32, 3, 50, 36, 3),     # slices that start mid-row, three references, coarse quantiser
@@ -167,7 +178,8 @@ def test_encode_slice_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed):
     lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
     nfr = 3 if num_ref < 3 else 4
     frames = synthetic_clip(W, H, nfr, seed)
-    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs)
+    together, slice_mbs = slice_mbs < 0, abs(slice_mbs)
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, together=together)
     ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs)
     for n, raw in enumerate(frames):
         recs, pre, post = dev.encode(raw, W, H)
