@@ -38,6 +38,9 @@ QP = 28
 G2R_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", "OutputWidth=1920", "OutputHeight=1080", "SearchMode=-1", "SearchRange=32",
              "NumberReferenceFrames=1", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
 G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's .264 for two frames of the clip with these flags
+# HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
+# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r02_v2_kernel_stats.md)
+PIPE_TRAFFIC_BYTES = 318760000
 
 
 def synth_luma(n_frames, seed=1234):
@@ -297,6 +300,7 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
+    ctx.synchronize()                                                    # surfaces the device-side error words (a bounded wait that ran out, a bad job record)
     pipe_ms = ctx.last_kernel_ms(5)                                      # HIP events on the launch stream around the last k_mb_pipe launch
     if N > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
@@ -329,7 +333,7 @@ def main():
         alg = alg_mb * nmb
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
         roof = {"kernel": "k_mb_pipe", "bound": "valu", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": None, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
+                "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
                 "abs_diff_per_s": round(sad_ops / (pipe_ms * 1e-3) / 1e12, 3), "valu_frac": round(sad_ops / (pipe_ms * 1e-3) / 148.4e12, 5),
                 "note": "a dependency-bound wavefront (x + 2y: at most 60 of 8160 macroblocks in flight at 1080p), not an HBM stream: frac prices the algorithmic "
                         "bytes against 8 TB/s as the contract asks; valu_frac = the searches' abs-diff/s over the measured v_sad_u8 peak of 148.4 T/s "

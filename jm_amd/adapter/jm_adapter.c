@@ -51,13 +51,14 @@
 #include "intra16x16.h"
 #include "intra4x4.h"
 #include "intra8x8.h"
+#include "me_epzs_common.h"
 #include "jmhip.h"
 
 #define MAX_SLOTS 20
 
 static struct {
   int         init_done, off;
-  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic, part_ip8, part_mbpipe;
+  int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic, part_ip8, part_mbpipe, part_evalbatch;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
   int         W, H, fmt, R, nslots;
@@ -69,7 +70,7 @@ static struct {
   uint16_t   *tables;                 /* 7 x 16 x max_pos uint16, jmhip_me_sad_tables output */
   jmhip_db_mb     *dbmb;
   jmhip_db_motion *dbmo;
-  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load, n_ic, n_ip8;
+  long        n_interp, n_fs, n_subpel, n_ffs, n_deblock, n_cur, n_passed, n_tq4, n_tq8, n_tqc, n_tq16, n_mcl, n_mcc, n_eval, n_ip4, n_i16, n_interpc, n_evalp, n_load, n_ic, n_ip8, n_eval_hits, n_eval_calls, n_eval_cands;
 } G;
 
 static void pipe_report(void);
@@ -84,6 +85,7 @@ static void adapter_report(void)
 {
   if (!G.init_done) return;
   pipe_report();
+  if (G.n_eval) fprintf(stderr, "jmhip adapter: candidate distortions: %ld requests served by %ld jmhip_me_eval calls (%ld candidates evaluated, %ld requests answered from the cache)\n", G.n_eval, G.n_eval_calls, G.n_eval_cands, G.n_eval_hits);
   fprintf(stderr, "jmhip adapter: on the MI355X: %ld getSubImagesLuma, %ld full_search_motion_estimation, %ld sub_pel_motion_estimation, "
                   "%ld setup_fast_full_search, %ld DeblockFrame (%ld current pictures uploaded); passed to JM's own code: %ld calls; "
                   "transform/quant blocks on the MI355X: %ld 4x4, %ld 8x8, %ld chroma planes; prediction blocks on the MI355X: %ld luma, %ld chroma; "
@@ -133,7 +135,7 @@ static int adapter_on(VideoParameters *p_Vid)
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
     G.part_mcl = has_part(parts, "mcl"); G.part_mcc = has_part(parts, "mcc"); G.part_tq16 = has_part(parts, "tq16");
     G.part_eval = has_part(parts, "eval"); G.part_ip4 = has_part(parts, "ip4"); G.part_i16 = has_part(parts, "i16");
-    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic"); G.part_ip8 = has_part(parts, "ip8"); G.part_mbpipe = has_part(parts, "mbpipe");
+    G.part_interpc = has_part(parts, "interpc"); G.part_evalp = has_part(parts, "evalp"); G.part_load = has_part(parts, "load"); G.part_ic = has_part(parts, "ic"); G.part_ip8 = has_part(parts, "ip8"); G.part_mbpipe = has_part(parts, "mbpipe"); G.part_evalbatch = has_part(parts, "evalbatch");
     if (e && !strcmp(e, "off")) { G.off = 1; return 0; }
     if (p_Vid->bitdepth_luma != 8 || p_Vid->bitdepth_chroma != 8 || p_Vid->yuv_format > YUV422 ||
         p_Inp->PicInterlace != FRAME_CODING || p_Inp->MbInterlace != FRAME_CODING) {
@@ -256,7 +258,7 @@ int __wrap_encode_one_slice(VideoParameters *p_Vid, int SliceGroupId, int TotalC
 {
   const double t0_ = now_s();
   int n_;
-  if (TotalCodedMBs == 0 && adapter_on(p_Vid) && (G.part_fs || G.part_subpel || G.part_ffs) && p_Vid->structure == FRAME) {
+  if (TotalCodedMBs == 0 && adapter_on(p_Vid) && (G.part_fs || G.part_subpel || G.part_ffs || G.part_eval || G.part_evalp) && !pipe_active() && p_Vid->structure == FRAME) {
     int rc = jmhip_set_current(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]));
     if (rc) adapter_die("jmhip_set_current", rc);
     G.n_cur++;
@@ -414,13 +416,78 @@ void __wrap_setup_fast_full_search(Macroblock *currMB, MEBlock *mv_block, int li
  * by the searches that stay on the host: EPZS's predictor and pattern walk (me_epzs*.c) evaluates its candidates one by one.
  * JM's early exit returns min_mcost itself as soon as a partial sum exceeds min_mcost >> 5 (dist_scale_f, mv_search.h:20), and the
  * last check covers the whole block: the result is min_mcost when the full distortion exceeds that bound, else distortion << 5. */
+/* EPZS asks for its candidates one by one (a predictor list, then pattern rounds around the running best: me_epzs_int.c:212-247 / :289-330; patterns
+ * me_epzs_common.c:48-73, steps of 2, 4 and 8 quarter-pel units).  A distortion is a pure function of (reference, block, candidate, metric), so
+ * the adapter answers from a cache and fills it a batch at a time: on a miss the device evaluates, in ONE jmhip_me_eval call, the candidate asked for,
+ * the 5 x 5 grid of step 4 around it plus the four step-2 neighbours (every point a pattern round can ask for next; for the SATD metric of the sub-pel
+ * stages the 5 x 5 grid of step 1 instead), and -- when the candidate is an entry of the slice's predictor list -- the entries that follow it.  JM's control flow, its strict-'<' scans and its early-exit return values are
+ * untouched; only the number of PCIe round trips changes. */
+#define EC_CAP 1024
+#define EC_CTX 8
+static struct ec_ctx {
+  StorablePicture *ref; int pos_x, pos_y, bsx, bsy, metric, t8; long pic; unsigned tick;
+  int n; int16_t x[EC_CAP], y[EC_CAP]; int32_t d[EC_CAP];
+} EC_[EC_CTX], *ECp;                                          /* a few (reference, block, metric) contexts: JM comes back to a block for the next reference / stage */
+#define EC (*ECp)
+static unsigned ec_tick;
+static int ec_find(int x, int y) { int k; for (k = EC.n - 1; k >= 0; k--) if (EC.x[k] == x && EC.y[k] == y) return k; return -1; }
+static int32_t cand_cache_get(StorablePicture *ref1, MEBlock *mv_block, int bsx, int bsy, int metric, int rx, int ry)
+{
+  static const int8_t cross[4][2] = {{2, 0}, {-2, 0}, {0, 2}, {0, -2}};
+  jmhip_cand c[96];
+  int32_t dist[96];
+  int n = 0, k, i, j, rc;
+  const int t8 = mv_block->test8x8 != 0;
+  {
+    struct ec_ctx *lru = &EC_[0];
+    ECp = NULL;
+    for (k = 0; k < EC_CTX; k++) {
+      struct ec_ctx *e = &EC_[k];
+      if (e->ref == ref1 && e->pos_x == mv_block->pos_x && e->pos_y == mv_block->pos_y && e->bsx == bsx && e->bsy == bsy && e->metric == metric && e->t8 == t8 && e->pic == G.n_cur) { ECp = e; break; }
+      if (e->tick < lru->tick) lru = e;
+    }
+    if (!ECp) {
+      ECp = lru;
+      EC.ref = ref1; EC.pos_x = mv_block->pos_x; EC.pos_y = mv_block->pos_y; EC.bsx = bsx; EC.bsy = bsy; EC.metric = metric; EC.t8 = t8; EC.pic = G.n_cur; EC.n = 0;
+    }
+    EC.tick = ++ec_tick;
+  }
+  if ((k = ec_find(rx, ry)) >= 0) { G.n_eval_hits++; return EC.d[k]; }
+  if (EC.n + 96 > EC_CAP) EC.n = 0;
+#define EC_ADD(X, Y) do { const int x_ = (X), y_ = (Y); int q_, dup_ = 0; if (x_ >= -32768 && x_ <= 32767 && y_ >= -32768 && y_ <= 32767 && n < 96 && ec_find(x_, y_) < 0) { \
+    for (q_ = 0; q_ < n; q_++) if (c[q_].cand_x == x_ && c[q_].cand_y == y_) { dup_ = 1; break; } \
+    if (!dup_) { memset(&c[n], 0, sizeof c[n]); c[n].pos_x = mv_block->pos_x; c[n].pos_y = mv_block->pos_y; c[n].bsx = (int16_t)bsx; c[n].bsy = (int16_t)bsy; \
+      c[n].cand_x = (int16_t)x_; c[n].cand_y = (int16_t)y_; c[n].metric = (int16_t)metric; c[n].test8x8 = (int16_t)t8; n++; } } } while (0)
+  EC_ADD(rx, ry);
+  if (G.part_evalbatch) {
+    Slice *sl = mv_block->p_Vid->currentSlice;
+    if (metric == JMHIP_METRIC_SAD) {                       /* the integer / EPZS stage: pattern steps of 4 and 8 (and 2) */
+      for (j = -8; j <= 8; j += 4) for (i = -8; i <= 8; i += 4) EC_ADD(rx + i, ry + j);
+      for (k = 0; k < 4; k++) EC_ADD(rx + cross[k][0], ry + cross[k][1]);
+    } else {                                                 /* the sub-pel stages: steps of 1 and 2 quarter-pel units */
+      for (j = -2; j <= 2; j++) for (i = -2; i <= 2; i++) EC_ADD(rx + i, ry + j);
+    }
+    if (sl && sl->p_EPZS && sl->p_EPZS->predictor && sl->p_EPZS->predictor->point) {        /* the predictors JM is about to ask for */
+      const EPZSStructure *pr = sl->p_EPZS->predictor;
+      for (k = 0; k < pr->searchPoints && k < 64; k++)
+        if (pr->point[k].motion.mv_x == rx && pr->point[k].motion.mv_y == ry) {
+          for (i = k + 1; i < pr->searchPoints && i < k + 40; i++) EC_ADD(pr->point[i].motion.mv_x, pr->point[i].motion.mv_y);
+          break;
+        }
+    }
+  }
+#undef EC_ADD
+  if ((rc = jmhip_me_eval(G.ctx, slot_of_reference(ref1), c, n, dist))) adapter_die("jmhip_me_eval", rc);
+  G.n_eval_calls++; G.n_eval_cands += n;
+  for (k = 0; k < n; k++) { EC.x[EC.n] = c[k].cand_x; EC.y[EC.n] = c[k].cand_y; EC.d[EC.n] = dist[k]; EC.n++; }
+  return dist[0];
+}
+
 static distblk eval_candidate(StorablePicture *ref1, MEBlock *mv_block, distblk min_mcost, MotionVector *cand, int metric,
                               distblk (*real)(StorablePicture *, MEBlock *, distblk, MotionVector *))
 {
   VideoParameters *p_Vid = mv_block->p_Vid;
-  jmhip_cand c;
   int32_t dist;
-  int rc;
   const int bsx = mv_block->blocksize_x, bsy = mv_block->blocksize_y;
   const int rx = cand->mv_x - (mv_block->pos_x << 2), ry = cand->mv_y - (mv_block->pos_y << 2);
   if (G.in_real_me || !adapter_on(p_Vid) || !G.part_eval || G.n_cur == 0 || p_Vid->structure != FRAME || mv_block->ChromaMEEnable ||
@@ -429,10 +496,7 @@ static distblk eval_candidate(StorablePicture *ref1, MEBlock *mv_block, distblk 
     G.n_passed++;
     return real(ref1, mv_block, min_mcost, cand);
   }
-  memset(&c, 0, sizeof c);
-  c.pos_x = mv_block->pos_x; c.pos_y = mv_block->pos_y; c.bsx = (int16_t)bsx; c.bsy = (int16_t)bsy;
-  c.cand_x = (int16_t)rx; c.cand_y = (int16_t)ry; c.metric = (int16_t)metric; c.test8x8 = (int16_t)(mv_block->test8x8 != 0);
-  if ((rc = jmhip_me_eval(G.ctx, slot_of_reference(ref1), &c, 1, &dist))) adapter_die("jmhip_me_eval", rc);
+  dist = cand_cache_get(ref1, mv_block, bsx, bsy, metric, rx, ry);
   G.n_eval++;
   return ((distblk)dist >> 5) > (min_mcost >> 5) ? min_mcost : (distblk)dist;
 }

@@ -283,7 +283,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     for (int k = 0; k < BH; k++) acc[k] = 0;
     for (int i = lane; i <= 2 * Rs; i += 64) {                 // the row table (one LDS read per row instead of a dozen scalar instructions)
       const int dy = i - Rs, vy = c.cqy + 4 * dy;
-      ytab[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 8) | (vy == 0 ? 128u : 0u) | (u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u;
+      ytab[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 7) | ((u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u);     // (rate of the row) << 7 | far rank
     }
     wave_sync();
     if (pf && lane == 0) pf[24] = wall_clock64();
@@ -298,7 +298,9 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       const int i = i_lo + f - (BH - 1);
       yt[f] = ytab[i < 0 ? 0 : (i > 2 * Rs ? 2 * Rs : i)];
     }
-    const u32 t16 = 16u * (u32)c.lambda;
+    const u32 rx7 = rate_x << 7;
+    const int k1 = adx - Rs;                                   // rank of a row within |dx| of the centre row: dy + |dx| = i + k1
+    u32 sad00 = 0;
     for (int j0 = 0; j0 < nrows; j0 += BH) {                   // rows past the last one (a partial final group) lie in the window's slack rows
       u32 fin[BH], ytf[BH];
 #pragma unroll
@@ -331,13 +333,14 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       u32 gk[BH];
 #pragma unroll
       for (int s = 0; s < BH; s++) {
+        // key = ((SAD << 5) + rate_x + rate_y) << 7 | rank.  With the row's (rate_y << 7 | far rank) from the table that is one shift-add and one add for
+        // the rows beyond |dx| (far rank); for the rows within, the low seven bits are replaced by dy + |dx|.
         const int i = i_lo + j0 + s - (BH - 1);                // the same for every lane
         const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
-        const u32 rank = ady <= adx ? (u32)(dy + adx) : (ytf[s] & 127u);
-        u32 rate = rate_x + (ytf[s] >> 8);
-        const u32 rz = rate > t16 ? rate - t16 : 0u;           // me_fullsearch.c:78-82
-        rate = (zero_x && (ytf[s] & 128u)) ? rz : rate;
-        const u32 key = (((fin[s] << 5) + rate) << 7) | rank;
+        const u32 kf = (fin[s] << 12) + rx7 + ytf[s];
+        const u32 kn = (kf & ~127u) | (u32)(i + k1);
+        const u32 key = (u32)ady <= (u32)adx ? kn : kf;
+        if (BW == 16 && BH == 16) sad00 = (c.check00 && c.cqy + 4 * dy == 0) ? fin[s] : sad00;       // the (0,0) vector's row, for its bonus below
         gk[s] = (i >= i_lo && i <= i_hi) ? key : 0xffffffffu;
       }
 #pragma unroll
@@ -345,6 +348,16 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
 #pragma unroll
         for (int s = 0; s < w; s++) gk[s] = gk[s] < gk[s + w] ? gk[s] : gk[s + w];
       bkey = gk[0] < bkey ? gk[0] : bkey;
+    }
+    if (BW == 16 && BH == 16 && zero_x) {                       // me_fullsearch.c:78-82: the (0,0) vector of the 16x16 search on reference 0 gets 16 lambda off its rate
+      const int i0 = Rs - (c.cqy >> 2);                        // its row, if the window holds it
+      if (i0 >= i_lo && i0 <= i_hi) {
+        const int dy = i0 - Rs, ady = dy < 0 ? -dy : dy;
+        const u32 rate = rate_x + (u32)(c.lambda * mvbits(0 - c.pqy)), t16 = 16u * (u32)c.lambda;
+        const u32 rank = ady <= adx ? (u32)(dy + adx) : (u32)(2 * ady - 1 + (dy > 0 ? 1 : 0));
+        const u32 key = (((sad00 << 5) + (rate > t16 ? rate - t16 : 0u)) << 7) | rank;
+        bkey = key < bkey ? key : bkey;
+      }
     }
     {
       const int rank = (int)(bkey & 127u);
