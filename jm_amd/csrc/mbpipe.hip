@@ -263,9 +263,21 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
 #pragma unroll
     for (int k = 0; k < BW / 4; k++) cb[r][k] = BW * BH >= 128 ? cur[r * 4 + k] : (u32)__builtin_amdgcn_readfirstlane(cur[r * 4 + k]);
   // candidate rows i_lo .. i_hi of the (2 Rs + 1) x (2 Rs + 1) positions (all of them, or one of two waves' halves)
-  const int Rs = c.Rs, ncol = 2 * Rs + 1, nrows = (i_hi - i_lo + 1) + BH - 1;
+  const int Rs = c.Rs, ncol = 2 * Rs + 1;
   u64 best = ~0ull;
   if (pf && lane == 0) pf[25] = wall_clock64();
+  // JM skips a candidate whose vector cost alone reaches the running minimum (me_fullsearch.c:83) -- result-neutral, and what makes its full search
+  // affordable on a CPU.  The same bound by rows: after the five candidate rows nearest the predictor every row whose cheapest possible vector cost
+  // (the row's own bits + the cheapest column's) EXCEEDS the best cost so far cannot hold the minimum, nor tie with it, and is never read.
+  const int t_y = c.pqy - c.cqy, t_x = c.pqx - c.cqx;           // the predictor relative to the search centre, quarter-pel
+  const int ip = clampi3(i_lo, i_hi, Rs + ((t_y + 2) >> 2));   // the row nearest the predictor
+  // Only the blocks of at most 64 samples are pruned: a larger block's SAD dwarfs any vector cost (the bound excludes nothing) and each segment costs
+  // BH - 1 rows of lead-in; nor is the 16x16 search on reference 0, whose (0,0) vector's cost is not its rate.
+  const bool prune = BW * BH <= 64 && !c.check00 && c.lambda > 0;
+  const int a_lo = prune ? max(i_lo, ip - 2) : i_lo, a_hi = prune ? min(i_hi, ip + 2) : i_hi;
+  int lo2 = i_lo, hi2 = i_hi;                                  // the rows still worth reading, set after the first segment
+  int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read
+  u32 bound = 0xffffffffu;                                     // the best cost after the first segment
   {                                                            // columns 0..63: a lane slides down its column
     // A lane beyond the last column repeats the last column's candidates (same keys: harmless).  The column keeps ONE 32-bit key per
     // candidate: (cost << 7) | rank, rank = the candidate's place among the column's candidates in JM's spiral order (rows -|dx| .. |dx|
@@ -273,81 +285,100 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     // restricted to the column.  cost < 2^25: SAD << 5 < 2^21, rate < 2^22 with the lambda the host accepts.
     const int col = lane < ncol ? lane : ncol - 1;
     const int dx = col - Rs, adx = dx < 0 ? -dx : dx, xl = X0 + col, sh = xl & 3;
-    const u8 *p = win + (xl & ~3) + (Y0 + i_lo) * WP;
+    const u8 *pbase = win + (xl & ~3) + Y0 * WP;
     const int vx = c.cqx + 4 * dx;
     const u32 rate_x = (u32)(c.lambda * mvbits(vx - c.pqx));
     const bool zero_x = c.check00 && vx == 0;
     u32 bkey = 0xffffffffu;
-    u32 acc[BH];
-#pragma unroll
-    for (int k = 0; k < BH; k++) acc[k] = 0;
     for (int i = lane; i <= 2 * Rs; i += 64) {                 // the row table (one LDS read per row instead of a dozen scalar instructions)
       const int dy = i - Rs, vy = c.cqy + 4 * dy;
       ytab[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 7) | ((u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u);     // (rate of the row) << 7 | far rank
     }
     wave_sync();
     if (pf && lane == 0) pf[24] = wall_clock64();
-    // window rows and row-table entries travel PF rows ahead of their use (an LDS read takes a couple of hundred cycles; a row of a small block
-    // is summed in far less)
-    constexpr int PF = BW * BH <= 64 ? 4 : (BW * BH <= 128 ? 2 : 1);
-    u32 a[PF][BW / 4 + 1], yt[PF];
-#pragma unroll
-    for (int f = 0; f < PF; f++) {
-#pragma unroll
-      for (int k = 0; k <= BW / 4; k++) a[f][k] = ((const u32 *)(p + f * WP))[k];
-      const int i = i_lo + f - (BH - 1);
-      yt[f] = ytab[i < 0 ? 0 : (i > 2 * Rs ? 2 * Rs : i)];
-    }
     const u32 rx7 = rate_x << 7;
     const int k1 = adx - Rs;                                   // rank of a row within |dx| of the centre row: dy + |dx| = i + k1
     u32 sad00 = 0;
-    for (int j0 = 0; j0 < nrows; j0 += BH) {                   // rows past the last one (a partial final group) lie in the window's slack rows
-      u32 fin[BH], ytf[BH];
+    for (int seg = 0; seg < 3; seg++) {                        // the rows around the predictor, then what the bound leaves above and below them
+      // (with lead-ins of seven rows one pass over both sides and the rows between them is cheaper than two)
+      const bool both = BH >= 8 && lo2 < a_lo && hi2 > a_hi;
+      const int s_lo = seg == 0 ? a_lo : (seg == 1 ? lo2 : a_hi + 1), s_hi = seg == 0 ? a_hi : (seg == 1 ? (both ? hi2 : a_lo - 1) : (both ? a_hi : hi2));
+      if (s_lo <= s_hi) {
+        ev_lo = min(ev_lo, s_lo); ev_hi = max(ev_hi, s_hi);
+        const int nrows = (s_hi - s_lo + 1) + BH - 1;
+        const u8 *p = pbase + s_lo * WP;
+        u32 acc[BH];
 #pragma unroll
-      for (int s = 0; s < BH; s++) {
-        const int j = j0 + s;
-        u32 b[BW / 4];
+        for (int k = 0; k < BH; k++) acc[k] = 0;
+        // window rows and row-table entries travel PF rows ahead of their use (an LDS read takes a couple of hundred cycles; a row of a small
+        // block is summed in far less)
+        constexpr int PF = BW * BH <= 64 ? 4 : (BW * BH <= 128 ? 2 : 1);
+        u32 a[PF][BW / 4 + 1], yt[PF];
 #pragma unroll
-        for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[s % PF][k + 1], a[s % PF][k], sh);
-        ytf[s] = yt[s % PF];
-        {                                                      // row j + PF into the slot just freed
-          const u8 *pn = p + (j + PF) * WP;
+        for (int f = 0; f < PF; f++) {
 #pragma unroll
-          for (int k = 0; k <= BW / 4; k++) a[s % PF][k] = ((const u32 *)pn)[k];
-          const int in = i_lo + j - (BH - 1) + PF;
-          yt[s % PF] = ytab[in < 0 ? 0 : (in > 2 * Rs ? 2 * Rs : in)];
+          for (int k = 0; k <= BW / 4; k++) a[f][k] = ((const u32 *)(p + f * WP))[k];
+          const int i = s_lo + f - (BH - 1);
+          yt[f] = ytab[i < 0 ? 0 : (i > 2 * Rs ? 2 * Rs : i)];
         }
-        __builtin_amdgcn_sched_barrier(0);                     // keeps the compiler from sinking the read-ahead to where the data is needed
+        for (int j0 = 0; j0 < nrows; j0 += BH) {               // rows past the last one (a partial final group) lie in the window's slack rows
+          u32 fin[BH], ytf[BH];
 #pragma unroll
-        for (int r = 0; r < BH; r++) {                         // window row j is row r of the candidate that starts at row j - r
-          const int k = (s - r + BH) % BH;
-          u32 v = r == 0 ? 0u : acc[k];
+          for (int s = 0; s < BH; s++) {
+            const int j = j0 + s;
+            u32 b[BW / 4];
 #pragma unroll
-          for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
-          acc[k] = v;
+            for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[s % PF][k + 1], a[s % PF][k], sh);
+            ytf[s] = yt[s % PF];
+            {                                                  // row j + PF into the slot just freed
+              const u8 *pn = p + (j + PF) * WP;
+#pragma unroll
+              for (int k = 0; k <= BW / 4; k++) a[s % PF][k] = ((const u32 *)pn)[k];
+              const int in = s_lo + j - (BH - 1) + PF;
+              yt[s % PF] = ytab[in < 0 ? 0 : (in > 2 * Rs ? 2 * Rs : in)];
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // keeps the compiler from sinking the read-ahead to where the data is needed
+#pragma unroll
+            for (int r = 0; r < BH; r++) {                     // window row j is row r of the candidate that starts at row j - r
+              const int k = (s - r + BH) % BH;
+              u32 v = r == 0 ? 0u : acc[k];
+#pragma unroll
+              for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
+              acc[k] = v;
+            }
+            fin[s] = acc[(s + 1) % BH];                        // the candidate that ends with this row
+          }
+          // the group's keys side by side: BH independent chains (a lone wave issues a dependent instruction only every ~9 cycles), no branch:
+          // rows that end no candidate of this segment give the key ~0
+          u32 gk[BH];
+#pragma unroll
+          for (int s = 0; s < BH; s++) {
+            // key = ((SAD << 5) + rate_x + rate_y) << 7 | rank.  With the row's (rate_y << 7 | far rank) from the table that is one shift-add and one add
+            // for the rows beyond |dx| (far rank); for the rows within, the low seven bits are replaced by dy + |dx|.
+            const int i = s_lo + j0 + s - (BH - 1);            // the same for every lane
+            const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
+            const u32 kf = (fin[s] << 12) + rx7 + ytf[s];
+            const u32 kn = (kf & ~127u) | (u32)(i + k1);
+            const u32 key = (u32)ady <= (u32)adx ? kn : kf;
+            if (BW == 16 && BH == 16) sad00 = (c.check00 && c.cqy + 4 * dy == 0 && i >= s_lo) ? fin[s] : sad00;     // the (0,0) vector's row, for its bonus below
+            gk[s] = (i >= s_lo && i <= s_hi) ? key : 0xffffffffu;
+          }
+#pragma unroll
+          for (int w = BH / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int s = 0; s < w; s++) gk[s] = gk[s] < gk[s + w] ? gk[s] : gk[s + w];
+          bkey = gk[0] < bkey ? gk[0] : bkey;
         }
-        fin[s] = acc[(s + 1) % BH];                            // the candidate that ends with this row
       }
-      // the group's keys side by side: BH independent chains (a lone wave issues a dependent instruction only every ~9 cycles), no branch: rows that
-      // end no candidate of this wave's range give the key ~0
-      u32 gk[BH];
-#pragma unroll
-      for (int s = 0; s < BH; s++) {
-        // key = ((SAD << 5) + rate_x + rate_y) << 7 | rank.  With the row's (rate_y << 7 | far rank) from the table that is one shift-add and one add for
-        // the rows beyond |dx| (far rank); for the rows within, the low seven bits are replaced by dy + |dx|.
-        const int i = i_lo + j0 + s - (BH - 1);                // the same for every lane
-        const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
-        const u32 kf = (fin[s] << 12) + rx7 + ytf[s];
-        const u32 kn = (kf & ~127u) | (u32)(i + k1);
-        const u32 key = (u32)ady <= (u32)adx ? kn : kf;
-        if (BW == 16 && BH == 16) sad00 = (c.check00 && c.cqy + 4 * dy == 0) ? fin[s] : sad00;       // the (0,0) vector's row, for its bonus below
-        gk[s] = (i >= i_lo && i <= i_hi) ? key : 0xffffffffu;
+      if (seg == 0 && prune) {
+        bound = wave_min_u32(bkey) >> 7;
+        const int dxc = clampi3(-Rs, Rs, (t_x + 2) >> 2), dmx = t_x - 4 * dxc;
+        const int kb = (int)(bound / (u32)c.lambda) - mvbits(dmx);      // a row is worth reading while its bits do not exceed this
+        const int e = (kb - 3) >> 1;
+        const int dq = kb < 1 ? -1 : (kb < 3 ? 0 : (e >= 14 ? (1 << 20) : (2 << e) - 1));       // ... i.e. while |vy - py| <= dq
+        lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2));
+        hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
       }
-#pragma unroll
-      for (int w = BH / 2; w >= 1; w >>= 1)
-#pragma unroll
-        for (int s = 0; s < w; s++) gk[s] = gk[s] < gk[s + w] ? gk[s] : gk[s + w];
-      bkey = gk[0] < bkey ? gk[0] : bkey;
     }
     if (BW == 16 && BH == 16 && zero_x) {                       // me_fullsearch.c:78-82: the (0,0) vector of the 16x16 search on reference 0 gets 16 lambda off its rate
       const int i0 = Rs - (c.cqy >> 2);                        // its row, if the window holds it
@@ -370,10 +401,14 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   for (int col = 64; col < (col64 ? ncol : 64); col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
     const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
-    for (int i0 = 0; i0 <= 2 * Rs; i0 += 64) {
+    {                                                          // the same bound: the column's bits + the cheapest row's against the best cost of the first segment
+      const int dyc = clampi3(-Rs, Rs, (t_y + 2) >> 2);
+      if (bound != 0xffffffffu && (u32)c.lambda * (u32)(bits_x + mvbits(t_y - 4 * dyc)) > bound) continue;
+    }
+    for (int i0 = ev_lo; i0 <= ev_hi; i0 += 64) {              // only the rows the main columns read (the others fail the bound for every column)
       const int i = i0 + lane;
-      const bool live = i <= 2 * Rs;
-      const u8 *p = win + (xl & ~3) + (Y0 + (live ? i : 2 * Rs)) * WP;
+      const bool live = i <= ev_hi;
+      const u8 *p = win + (xl & ~3) + (Y0 + (live ? i : ev_hi)) * WP;
       u32 v = 0;
 #pragma unroll
       for (int r = 0; r < BH; r++) {
