@@ -108,6 +108,7 @@ struct Shared {
   int red[8][80];
   u64 xkey[4];                               // two waves on one search: the helper's best key, its sequence number, the main wave's "results are in" number
   int xseq_h[4], xseq_m[4];
+  int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
   int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
@@ -120,6 +121,7 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // hand-over between two waves of the workgroup through a sequence number in LDS (a wave's LDS operations execute in order)
 __device__ __forceinline__ void lds_signal(int *f, int seq, int lane) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) *(volatile int *)f = seq; }
+__device__ __forceinline__ void lds_wait_ge(const int *f, int seq) { while (*(const volatile int *)f < seq) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ void lds_wait(const int *f, int seq) { while (*(const volatile int *)f != seq) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 // Cross-lane steps inside a row of 16 lanes as DPP operands of the ALU (no trip through the LDS crossbar that __shfl_xor takes):
@@ -513,7 +515,8 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const bool prof_ = A.prof && ((A.prof_mode == 1 && mb_x == 0) || (A.prof_mode == 4 && mb_x == 8)) && part == 0 && bt == 7 && mb_y == 0 && ref == 0 && lane == 0;
+  const bool prof_ = A.prof && ((A.prof_mode == 1 && mb_x == 0 && bt == 7) || (A.prof_mode == 4 && mb_x == 8 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 7 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : 4)))) &&
+                     part == 0 && mb_y == 0 && ref == 0 && lane == 0;       // modes 5, 6, 7: the first 16x8 / the 16x16 / the first 8x8 search
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
   const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH));

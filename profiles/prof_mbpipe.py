@@ -45,6 +45,9 @@ for n in range(2):
     if MODE == "2":
         print("  Intra4x4 block 5: neighbours + values %.2f, nine predictions + SATD + minimum %.2f, transform/quant/reconstruction %.2f, stores %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
+    if n == 1 and MODE in ("5", "6", "7"):
+        print("  first %s search: predictor %.2f, centre + block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f, half-pel %.2f, quarter-pel + skip %.2f us" % (({"5": "16x8", "6": "16x16", "7": "8x8"}[MODE],) + tuple(
+            np.median(us(a, b)) for a, b in ((18, 19), (19, 25), (25, 24), (24, 7), (7, 23), (23, 20), (20, 21), (21, 22)))))
     if n == 1 and MODE == "1":
         print("  first 4x4 search of the macroblock (wave 3): predictor %.2f, integer search %.2f, half-pel stage %.2f, quarter-pel stage + clip %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
