@@ -241,6 +241,13 @@ __device__ __forceinline__ void load_row(const u8 *rowp, int sh, u32 (&b)[BW / 4
   for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
 }
 
+// the largest |d| whose mvbits(d) stay within `bits` (-1: none): mvbits = 1, 3, 5, 7, ... for |d| = 0, 1, 2..3, 4..7, ...
+__device__ __forceinline__ int bits_reach(int bits)
+{
+  const int e = (bits - 3) >> 1;
+  return bits < 1 ? -1 : (bits < 3 ? 0 : (e >= 14 ? (1 << 20) : (2 << e) - 1));
+}
+
 struct FsCost {                              // what turns a SAD into JM's motion cost
   int lambda, cqx, cqy, pqx, pqy, Rs;        // lambda_factor[F_PEL], centre and predictor (quarter-pel), search range
   int check00;
@@ -269,17 +276,22 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   u64 best = ~0ull;
   if (pf && lane == 0) pf[25] = wall_clock64();
   // JM skips a candidate whose vector cost alone reaches the running minimum (me_fullsearch.c:83) -- result-neutral, and what makes its full search
-  // affordable on a CPU.  The same bound by rows: after the five candidate rows nearest the predictor every row whose cheapest possible vector cost
-  // (the row's own bits + the cheapest column's) EXCEEDS the best cost so far cannot hold the minimum, nor tie with it, and is never read.
+  // affordable on a CPU.  Here the same bound, for the blocks of at most 64 samples (a larger block's SAD dwarfs any vector cost: the bound
+  // excludes nothing; nor for the 16x16 search on reference 0, whose (0,0) vector's cost is not its rate), in three steps.  A candidate whose
+  // vector cost EXCEEDS a cost already seen can neither hold the minimum nor tie with it:
+  //   0. the five candidate rows nearest the predictor, every column (a lane slides down its column)            -> bound B0
+  //   1. the rows within h of the predictor's row that B0 leaves, every column, the same way                     -> bound B1 <= B0
+  //   2. the rows beyond, as far as B1 leaves any: only the columns whose bits + the cheapest such row's bits stay within B1 -- few, so
+  //      one lane per candidate (plain SADs).
+  // h is the one of 2, 3, 7, 15, 31, all that makes steps 1 + 2 cheapest (vector bits double their reach every two bits, hence the values).
   const int t_y = c.pqy - c.cqy, t_x = c.pqx - c.cqx;           // the predictor relative to the search centre, quarter-pel
   const int ip = clampi3(i_lo, i_hi, Rs + ((t_y + 2) >> 2));   // the row nearest the predictor
-  // Only the blocks of at most 64 samples are pruned: a larger block's SAD dwarfs any vector cost (the bound excludes nothing) and each segment costs
-  // BH - 1 rows of lead-in; nor is the 16x16 search on reference 0, whose (0,0) vector's cost is not its rate.
   const bool prune = BW * BH <= 64 && !c.check00 && c.lambda > 0;
   const int a_lo = prune ? max(i_lo, ip - 2) : i_lo, a_hi = prune ? min(i_hi, ip + 2) : i_hi;
-  int lo2 = i_lo, hi2 = i_hi;                                  // the rows still worth reading, set after the first segment
-  int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read
-  u32 bound = 0xffffffffu;                                     // the best cost after the first segment
+  const int bx_min = mvbits(t_x - 4 * clampi3(-Rs, Rs, (t_x + 2) >> 2));       // the cheapest column's bits
+  int lo1 = i_lo, hi1 = i_hi;                                  // step 1's rows, set after step 0
+  int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read by the sliding lanes
+  u32 bound = 0xffffffffu;                                     // the best cost so far
   {                                                            // columns 0..63: a lane slides down its column
     // A lane beyond the last column repeats the last column's candidates (same keys: harmless).  The column keeps ONE 32-bit key per
     // candidate: (cost << 7) | rank, rank = the candidate's place among the column's candidates in JM's spiral order (rows -|dx| .. |dx|
@@ -303,8 +315,8 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     u32 sad00 = 0;
     for (int seg = 0; seg < 3; seg++) {                        // the rows around the predictor, then what the bound leaves above and below them
       // (with lead-ins of seven rows one pass over both sides and the rows between them is cheaper than two)
-      const bool both = BH >= 8 && lo2 < a_lo && hi2 > a_hi;
-      const int s_lo = seg == 0 ? a_lo : (seg == 1 ? lo2 : a_hi + 1), s_hi = seg == 0 ? a_hi : (seg == 1 ? (both ? hi2 : a_lo - 1) : (both ? a_hi : hi2));
+      const bool both = BH >= 8 && lo1 < a_lo && hi1 > a_hi;
+      const int s_lo = seg == 0 ? a_lo : (seg == 1 ? lo1 : a_hi + 1), s_hi = seg == 0 ? a_hi : (seg == 1 ? (both ? hi1 : a_lo - 1) : (both ? a_hi : hi1));
       if (s_lo <= s_hi) {
         ev_lo = min(ev_lo, s_lo); ev_hi = max(ev_hi, s_hi);
         const int nrows = (s_hi - s_lo + 1) + BH - 1;
@@ -374,12 +386,24 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       }
       if (seg == 0 && prune) {
         bound = wave_min_u32(bkey) >> 7;
-        const int dxc = clampi3(-Rs, Rs, (t_x + 2) >> 2), dmx = t_x - 4 * dxc;
-        const int kb = (int)(bound / (u32)c.lambda) - mvbits(dmx);      // a row is worth reading while its bits do not exceed this
-        const int e = (kb - 3) >> 1;
-        const int dq = kb < 1 ? -1 : (kb < 3 ? 0 : (e >= 14 ? (1 << 20) : (2 << e) - 1));       // ... i.e. while |vy - py| <= dq
-        lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2));
-        hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
+        const int kq = (int)(bound / (u32)c.lambda);           // a candidate is worth reading while its vector's bits do not exceed this
+        const int dq = bits_reach(kq - bx_min);                // ... a row, while |vy - py| <= dq
+        const int lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
+        // the cheapest h, one lane per choice: sliding steps of step 1 (with their BH - 1 rows of lead-in) against passes of step 2
+        const int hk = lane == 0 ? 2 : (2 << (lane < 5 ? lane : 5)) - 1;
+        const int l1 = max(lo2, ip - hk), h1 = min(hi2, ip + hk);
+        int byo = 1 << 20;
+        if (l1 - 1 >= lo2) byo = min(byo, mvbits(4 * (l1 - 1 - Rs) - t_y));
+        if (h1 + 1 <= hi2) byo = min(byo, mvbits(4 * (h1 + 1 - Rs) - t_y));
+        const int dqx = bits_reach(kq - byo);
+        const int nc = dqx < 0 ? 0 : max(0, min(2 * Rs, Rs + ((t_x + dqx) >> 2)) - max(0, Rs + ((t_x - dqx + 3) >> 2)) + 1);
+        const int passes = ((max(0, l1 - lo2) + max(0, hi2 - h1)) * nc + 63) >> 6;
+        const int up = max(0, a_lo - l1), dn = max(0, h1 - a_hi);
+        const int steps = (BH >= 8 && up && dn) ? (h1 - l1 + 1) + BH - 1 : (up ? up + BH - 1 : 0) + (dn ? dn + BH - 1 : 0);
+        const u32 est = (u32)(steps * (BW * BH / 4 + 12) + passes * (BH * (BW / 2 + 3) + 45));
+        const u32 pick = (u32)rfl((int)row16_min_u32(lane < 6 ? (est << 3) | (u32)lane : 0xffffffffu)) & 7u;
+        const int h = pick == 0 ? 2 : (2 << pick) - 1;
+        lo1 = max(lo2, ip - h); hi1 = min(hi2, ip + h);
       }
     }
     if (BW == 16 && BH == 16 && zero_x) {                       // me_fullsearch.c:78-82: the (0,0) vector of the 16x16 search on reference 0 gets 16 lambda off its rate
@@ -392,6 +416,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         bkey = key < bkey ? key : bkey;
       }
     }
+    if (prune) bound = wave_min_u32(bkey) >> 7;                 // B1
     {
       const int rank = (int)(bkey & 127u);
       const int l = (rank + 1) >> 1;
@@ -403,11 +428,11 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   for (int col = 64; col < (col64 ? ncol : 64); col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
     const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
-    {                                                          // the same bound: the column's bits + the cheapest row's against the best cost of the first segment
+    {                                                          // the same bound: the column's bits + the cheapest row's against the best cost so far
       const int dyc = clampi3(-Rs, Rs, (t_y + 2) >> 2);
       if (bound != 0xffffffffu && (u32)c.lambda * (u32)(bits_x + mvbits(t_y - 4 * dyc)) > bound) continue;
     }
-    for (int i0 = ev_lo; i0 <= ev_hi; i0 += 64) {              // only the rows the main columns read (the others fail the bound for every column)
+    for (int i0 = ev_lo; i0 <= ev_hi; i0 += 64) {              // the rows the sliding lanes read
       const int i = i0 + lane;
       const bool live = i <= ev_hi;
       const u8 *p = win + (xl & ~3) + (Y0 + (live ? i : ev_hi)) * WP;
@@ -420,6 +445,37 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
       }
       if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, bits_x); best = key < best ? key : best; }
+    }
+  }
+  if (prune) {                                                 // step 2: the rows beyond the hull, one lane per candidate
+    const int kq = (int)(bound / (u32)c.lambda);
+    const int dq = bits_reach(kq - bx_min);
+    const int r_lo = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), r_hi = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
+    const int n_up = max(0, ev_lo - r_lo), n_dn = max(0, r_hi - ev_hi), nr = n_up + n_dn;
+    int byo = 1 << 20;
+    if (n_up) byo = min(byo, mvbits(4 * (ev_lo - 1 - Rs) - t_y));
+    if (n_dn) byo = min(byo, mvbits(4 * (ev_hi + 1 - Rs) - t_y));
+    const int dqx = bits_reach(kq - byo);
+    const int cl = max(0, Rs + ((t_x - dqx + 3) >> 2)), ch = min(2 * Rs, Rs + ((t_x + dqx) >> 2));
+    const int total = (dqx < 0 || ch < cl) ? 0 : nr * (ch - cl + 1);
+    const float inv = 1.0f / (float)(nr > 0 ? nr : 1);
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      const bool live = item < total;
+      const int it = live ? item : 0;
+      const int ci = (int)(((float)it + 0.5f) * inv), ri = it - ci * nr;       // exact: it < 2^13, the fraction is at least 1 / (2 nr) off an integer
+      const int i = ri < n_up ? r_lo + ri : ev_hi + 1 + (ri - n_up);
+      const int col = cl + ci, dx = col - Rs, xl = X0 + col, sh = xl & 3;
+      const u8 *p = win + (xl & ~3) + (Y0 + i) * WP;
+      u32 v = 0;
+#pragma unroll
+      for (int r = 0; r < BH; r++) {
+        u32 b[BW / 4];
+        load_row<BW>(p + r * WP, sh, b);
+#pragma unroll
+        for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
+      }
+      if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, mvbits(c.cqx + 4 * dx - c.pqx)); best = key < best ? key : best; }
     }
   }
   if (pf && lane == 0) pf[23] = wall_clock64();
@@ -515,8 +571,8 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const bool prof_ = A.prof && ((A.prof_mode == 1 && mb_x == 0 && bt == 7) || (A.prof_mode == 4 && mb_x == 8 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 7 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : 4)))) &&
-                     part == 0 && mb_y == 0 && ref == 0 && lane == 0;       // modes 5, 6, 7: the first 16x8 / the 16x16 / the first 8x8 search
+  const bool prof_ = A.prof && ((A.prof_mode == 1 && mb_x == 0 && bt == 7) || (A.prof_mode == 4 && mb_x == 8 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
+                     part == 0 && mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
   const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH));

@@ -45,11 +45,28 @@ for n in range(2):
     if MODE == "2":
         print("  Intra4x4 block 5: neighbours + values %.2f, nine predictions + SATD + minimum %.2f, transform/quant/reconstruction %.2f, stores %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
-    if n == 1 and MODE in ("5", "6", "7"):
-        print("  first %s search: predictor %.2f, centre + block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f, half-pel %.2f, quarter-pel + skip %.2f us" % (({"5": "16x8", "6": "16x16", "7": "8x8"}[MODE],) + tuple(
+    if n == 1 and MODE in ("5", "6", "7", "8", "9"):
+        print("  first %s search: predictor %.2f, centre + block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f, half-pel %.2f, quarter-pel + skip %.2f us" % (({"5": "16x8", "6": "16x16", "7": "8x8", "8": "8x4", "9": "4x8"}[MODE],) + tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 25), (25, 24), (24, 7), (7, 23), (23, 20), (20, 21), (21, 22)))))
     if n == 1 and MODE == "1":
         print("  first 4x4 search of the macroblock (wave 3): predictor %.2f, integer search %.2f, half-pel stage %.2f, quarter-pel stage + clip %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
+    if n == 1:                                                 # the hand-over: from the last neighbour's flag store to this macroblock's start
+        wmb = c["W"] // 16
+        t17 = st[:, 17].reshape(-1, wmb); t1 = st[:, 1].reshape(-1, wmb); t0 = st[:, 0].reshape(-1, wmb)
+        last = np.zeros_like(t17)
+        last[:, 1:] = np.maximum(last[:, 1:], t17[:, :-1]); last[1:, :] = np.maximum(last[1:, :], t17[:-1, :]); last[1:, :-1] = np.maximum(last[1:, :-1], t17[:-1, 1:])
+        ho = (t1 - last)[last > 0] / 100.0
+        early = (t0 < last)[last > 0]
+        print("  hand-over (last neighbour's flag store -> start, macroblocks whose ticket was taken before that store: %.0f %%): median %.2f, mean %.2f, 90th percentile %.2f us" % (
+            100.0 * early.mean(), np.median(ho[early]), ho[early].mean(), np.percentile(ho[early], 90)))
+    if n == 1:
+        d = us(1, 17)
+        print("  edge .. publish percentiles 10/50/90/99/max: " + " ".join("%.1f" % np.percentile(d, q) for q in (10, 50, 90, 99, 100)))
+        for nm, a, b in (("phase 0", 2, 3), ("phase 1", 3, 4), ("phase 2", 4, 5), ("phase 3", 5, 6), ("wait for the free waves", 6, 6), ("decision + coding", 6, 16)):
+            if a != b: print("    %-26s 10/50/90/99: " % nm + " ".join("%.1f" % np.percentile(us(a, b), q) for q in (10, 50, 90, 99)))
+        types = recs["mb_type"] if "mb_type" in recs.dtype.names else None
+        if types is not None:
+            for t in np.unique(types): print("    mb_type %2d: %5d macroblocks, median %.1f us" % (t, (types == t).sum(), np.median(d[types == t])))
     span = (st[:, 17].max() - st[:, 0].min()) / 100.0
     print(f"  first ticket -> last publish {span / 1000:.2f} ms; sum of per-macroblock busy time / span = {us(1, 17).sum() / span:.1f} macroblocks in flight on average")
