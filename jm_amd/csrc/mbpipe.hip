@@ -109,6 +109,7 @@ struct Shared {
   u64 xkey[4];                               // two waves on one search: the helper's best key, its sequence number, the main wave's "results are in" number
   int xseq_h[4], xseq_m[4];
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
+  u32 ytab4[4][72];                          // the same for the four usual offsets of the predictor from the search centre (-2 .. 1 quarter-pels), full range: once per launch
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
   int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
@@ -249,7 +250,7 @@ __device__ __forceinline__ int bits_reach(int bits)
 }
 
 struct FsCost {                              // what turns a SAD into JM's motion cost
-  int lambda, cqx, cqy, pqx, pqy, Rs;        // lambda_factor[F_PEL], centre and predictor (quarter-pel), search range
+  int lambda, cqx, cqy, pqx, pqy, Rs, R;     // lambda_factor[F_PEL], centre and predictor (quarter-pel), search range of this search and of the slice
   int check00;
 };
 __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, int bits_x)
@@ -264,7 +265,7 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
 template <int BW, int BH>
-__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab, unsigned long long *pf, int i_lo, int i_hi, bool col64)
+__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab_own, const u32 *ytab4, unsigned long long *pf, int i_lo, int i_hi, bool col64)
 {
   u32 cb[BH][BW / 4];
 #pragma unroll
@@ -292,6 +293,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   int lo1 = i_lo, hi1 = i_hi;                                  // step 1's rows, set after step 0
   int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read by the sliding lanes
   u32 bound = 0xffffffffu;                                     // the best cost so far
+  const float rcp_lambda = __builtin_amdgcn_rcpf((float)(c.lambda > 0 ? c.lambda : 1));
   {                                                            // columns 0..63: a lane slides down its column
     // A lane beyond the last column repeats the last column's candidates (same keys: harmless).  The column keeps ONE 32-bit key per
     // candidate: (cost << 7) | rank, rank = the candidate's place among the column's candidates in JM's spiral order (rows -|dx| .. |dx|
@@ -304,11 +306,17 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     const u32 rate_x = (u32)(c.lambda * mvbits(vx - c.pqx));
     const bool zero_x = c.check00 && vx == 0;
     u32 bkey = 0xffffffffu;
-    for (int i = lane; i <= 2 * Rs; i += 64) {                 // the row table (one LDS read per row instead of a dozen scalar instructions)
-      const int dy = i - Rs, vy = c.cqy + 4 * dy;
-      ytab[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 7) | ((u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u);     // (rate of the row) << 7 | far rank
+    // the row table (one LDS read per row instead of a dozen scalar instructions): (rate of the row) << 7 | far rank.  It depends on the row's
+    // distance from the predictor only: with the predictor at its usual -2 .. 1 quarter-pels from the centre the launch's own tables serve.
+    const u32 *ytab = ytab4 + (t_y + 2) * 72 + (c.R - Rs);
+    if (t_y < -2 || t_y > 1) {
+      for (int i = lane; i <= 2 * Rs; i += 64) {
+        const int dy = i - Rs, vy = c.cqy + 4 * dy;
+        ytab_own[i] = ((u32)(c.lambda * mvbits(vy - c.pqy)) << 7) | ((u32)(2 * (dy < 0 ? -dy : dy) - 1 + (dy > 0 ? 1 : 0)) & 127u);
+      }
+      wave_sync();
+      ytab = ytab_own;
     }
-    wave_sync();
     if (pf && lane == 0) pf[24] = wall_clock64();
     const u32 rx7 = rate_x << 7;
     const int k1 = adx - Rs;                                   // rank of a row within |dx| of the centre row: dy + |dx| = i + k1
@@ -386,7 +394,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       }
       if (seg == 0 && prune) {
         bound = wave_min_u32(bkey) >> 7;
-        const int kq = (int)(bound / (u32)c.lambda);           // a candidate is worth reading while its vector's bits do not exceed this
+        const int kq = (int)((float)bound * rcp_lambda) + 1;    // a candidate is worth reading while its vector's bits do not exceed bound / lambda (rounded up: safe)
         const int dq = bits_reach(kq - bx_min);                // ... a row, while |vy - py| <= dq
         const int lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
         // the cheapest h, one lane per choice: sliding steps of step 1 (with their BH - 1 rows of lead-in) against passes of step 2
@@ -448,7 +456,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     }
   }
   if (prune) {                                                 // step 2: the rows beyond the hull, one lane per candidate
-    const int kq = (int)(bound / (u32)c.lambda);
+    const int kq = (int)((float)bound * rcp_lambda) + 1;
     const int dq = bits_reach(kq - bx_min);
     const int r_lo = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), r_hi = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
     const int n_up = max(0, ev_lo - r_lo), n_dn = max(0, r_hi - ev_hi), nr = n_up + n_dn;
@@ -458,7 +466,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     const int dqx = bits_reach(kq - byo);
     const int cl = max(0, Rs + ((t_x - dqx + 3) >> 2)), ch = min(2 * Rs, Rs + ((t_x + dqx) >> 2));
     const int total = (dqx < 0 || ch < cl) ? 0 : nr * (ch - cl + 1);
-    const float inv = 1.0f / (float)(nr > 0 ? nr : 1);
+    const float inv = __builtin_amdgcn_rcpf((float)(nr > 0 ? nr : 1));
     for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
       const bool live = item < total;
@@ -544,15 +552,31 @@ __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int w
   wave_sync();
 }
 
+// Both stages of a 4x4 block's sub-pel search need SATDs only within three quarter-pels of the integer vector: all 49 of them at once, a lane each, so
+// that the quarter-pel stage does not wait for a second trip to the sub-pel planes (the 4x4 searches are the macroblock's longest dependent chain).
+__device__ __forceinline__ void subpel_grid49(Shared &S, const PipeArgs &A, int wave, int lane, int ref, int px, int py, int mb_x, int mb_y, int mv)
+{
+  const bool live = lane < 49;
+  const int it = live ? lane : 0, oy = it / 7 - 3, ox = it - (oy + 3) * 7 - 3;
+  u32 r[4], o[4];
+  ref_rows4(A, ref, (px << 2) + mvx(mv) + ox, (py << 2) + mvy(mv) + oy, r);
+#pragma unroll
+  for (int j = 0; j < 4; j++) o[j] = S.cur_y[(mb_y + j) * 4 + (mb_x >> 2)];
+  if (live) S.red[wave][lane] = satd4_rows(o, r);
+  wave_sync();
+}
+
 // The strict-'<' scan over the nine positions of one stage of sub_pel_motion_estimation (me_fullsearch.c:221-246 / :263-281), nine lanes at once:
 // JM skips a position whose vector cost alone reaches the running minimum -- such a position could not have won -- so the winner is the first
 // position with the smallest total cost.  first = 1 (the quarter-pel stage when both stages use the same metric): position 0 is not evaluated,
 // it stands for the minimum the half-pel stage left (`incumbent`).  SATD sums in S.red[wave][0..8].
-__device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv, int step, int lambda, int pqx, int pqy, int bonus0, int incumbent, int first, int &min_out)
+__device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv, int step, int lambda, int pqx, int pqy, int bonus0, int incumbent, int first, int &min_out, bool grid = false, int mv0 = 0)
 {
   const int pos = lane < 9 ? lane : 0;
   const int qx = mvx(mv) + step * sp9x(pos), qy = mvy(mv) + step * sp9y(pos);
-  int cost = lambda * (mvbits(qx - pqx) + mvbits(qy - pqy)) + (S.red[wave][pos] << 5);
+  // grid: the SATDs lie in a 7 x 7 grid of quarter-pel offsets -3 .. 3 around the integer vector mv0 (subpel_grid49)
+  const int idx = grid ? (qy - mvy(mv0) + 3) * 7 + (qx - mvx(mv0) + 3) : pos;
+  int cost = lambda * (mvbits(qx - pqx) + mvbits(qy - pqy)) + (S.red[wave][idx] << 5);
   if (pos == 0) cost = first ? incumbent : cost - bonus0;
   u32 key = lane < 9 ? (((u32)(cost + (1 << 27))) << 4) | (u32)pos : 0xffffffffu;       // costs stay far below 2^27 in magnitude
   key = (u32)rfl((int)row16_min_u32(key));
@@ -599,7 +623,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   }
   FsCost c;
   c.lambda = P.lambda_mf[0]; c.cqx = cx; c.cqy = cy; c.pqx = mvx(pred); c.pqy = mvy(pred);
-  c.Rs = min(max(min(max_x, max_y) >> 2, 0), R);
+  c.Rs = min(max(min(max_x, max_y) >> 2, 0), R); c.R = R;
   c.check00 = bt == 1 && ref == 0;
   const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
@@ -607,13 +631,13 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const int i_lo = part ? c.Rs + 1 : 0, i_hi = (G == 2 && !part) ? c.Rs : 2 * c.Rs;
   u64 key;
   switch (bt) {
-  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
   }
   if (G == 2) {
     if (part) {                                               // the helper hands its half over and is done with this search
@@ -634,12 +658,15 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
 
   if (P.subpel) {                                             // sub_pel_motion_estimation me_fullsearch.c:186-289 (start_me_refinement_hp = 0)
     const int check0 = ref == 0 && bt == 1 && mv == 0;
-    subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
-    int best = scan9(S, wave, lane, mv, 2, P.lambda_mf[1], c.pqx, c.pqy, check0 ? P.lambda_mf[1] * 16 : 0, 0, 0, min_mcost);
+    const bool grid = bt == 7;
+    const int mv0 = mv;
+    if (grid) subpel_grid49(S, A, wave, lane, ref, px, py, mb_x, mb_y, mv);
+    else subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
+    int best = scan9(S, wave, lane, mv, 2, P.lambda_mf[1], c.pqx, c.pqy, check0 ? P.lambda_mf[1] * 16 : 0, 0, 0, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + 2 * sp9x(best), mvy(mv) + 2 * sp9y(best));
     BS_STAMP(21);
-    subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
-    best = scan9(S, wave, lane, mv, 1, P.lambda_mf[2], c.pqx, c.pqy, 0, min_mcost, P.start_qp, min_mcost);
+    if (!grid) subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
+    best = scan9(S, wave, lane, mv, 1, P.lambda_mf[2], c.pqx, c.pqy, 0, min_mcost, P.start_qp, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + sp9x(best), mvy(mv) + sp9y(best));
   }
   mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
