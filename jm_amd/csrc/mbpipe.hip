@@ -108,6 +108,7 @@ struct Shared {
   int red[8][80];
   u64 xkey[4];                               // two waves on one search: the helper's best key, its sequence number, the main wave's "results are in" number
   int xseq_h[4], xseq_m[4];
+  int nbflag;                                // the neighbours' samples are in nb (running count over the launch)
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
   u32 ytab4[4][72];                          // the same for the four usual offsets of the predictor from the search centre (-2 .. 1 quarter-pels), full range: once per launch
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank

@@ -53,7 +53,8 @@ for n in range(2):
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
     if n == 1:                                                 # the hand-over: from the last neighbour's flag store to this macroblock's start
         wmb = c["W"] // 16
-        t17 = st[:, 17].reshape(-1, wmb); t1 = st[:, 1].reshape(-1, wmb); t0 = st[:, 0].reshape(-1, wmb)
+        PUB = 31 if st[:, 31].any() else 17                   # the stamp after which the neighbours' searches may start (the vectors' flag)
+        t17 = st[:, PUB].reshape(-1, wmb); t1 = st[:, 1].reshape(-1, wmb); t0 = st[:, 0].reshape(-1, wmb)
         last = np.zeros_like(t17)
         last[:, 1:] = np.maximum(last[:, 1:], t17[:, :-1]); last[1:, :] = np.maximum(last[1:, :], t17[:-1, :]); last[1:, :-1] = np.maximum(last[1:, :-1], t17[:-1, 1:])
         ho = (t1 - last)[last > 0] / 100.0
@@ -68,5 +69,19 @@ for n in range(2):
         types = recs["mb_type"] if "mb_type" in recs.dtype.names else None
         if types is not None:
             for t in np.unique(types): print("    mb_type %2d: %5d macroblocks, median %.1f us" % (t, (types == t).sum(), np.median(d[types == t])))
+    if n == 1:                                                 # the critical path: from the last macroblock back through whichever neighbour finished last
+        hmb = c["H"] // 16
+        x, y = wmb - 1, hmb - 1
+        path = []
+        while True:
+            path.append(y * wmb + x)
+            cand = [(t17[yy, xx], xx, yy) for xx, yy in ((x - 1, y), (x, y - 1), (x + 1, y - 1), (x - 1, y - 1)) if 0 <= xx < wmb and yy >= 0]
+            if not cand: break
+            _, x, y = max(cand)
+        path = np.array(path)
+        dp = us(1, PUB)[path]
+        print("  critical path: %d macroblocks, start .. vectors published on it: median %.1f, mean %.1f us (all macroblocks: mean %.1f); sum %.2f ms" % (len(path), np.median(dp), dp.mean(), us(1, PUB).mean(), dp.sum() / 1000))
+        for nm, a, b in (("phase 0", 2, 3), ("phase 1", 3, 4), ("phase 2", 4, 5), ("phase 3", 5, 6), ("final barrier .. vectors out", 6, PUB), ("final barrier .. end", 6, 16), ("publish", 16, 17)):
+            print("    on the path, %-22s mean %.1f (all: %.1f)" % (nm, us(a, b)[path].mean(), us(a, b).mean()))
     span = (st[:, 17].max() - st[:, 0].min()) / 100.0
     print(f"  first ticket -> last publish {span / 1000:.2f} ms; sum of per-macroblock busy time / span = {us(1, 17).sum() / span:.1f} macroblocks in flight on average")
