@@ -265,8 +265,10 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
 
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
-template <int BW, int BH>
-__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab_own, const u32 *ytab4, unsigned long long *pf, int i_lo, int i_hi, bool col64)
+// spec(mv): called (pruned searches only) with the best integer vector of the first rows -- most often the search's result -- so that the caller can
+// start fetching what its sub-pel stage will need.
+template <int BW, int BH, class Spec>
+__device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, int X0, int Y0, const FsCost &c, int lane, u32 *ytab_own, const u32 *ytab4, unsigned long long *pf, int i_lo, int i_hi, bool col64, Spec spec)
 {
   u32 cb[BH][BW / 4];
 #pragma unroll
@@ -394,7 +396,13 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         }
       }
       if (seg == 0 && prune) {
-        bound = wave_min_u32(bkey) >> 7;
+        const u32 mk = wave_min_u32(bkey);
+        bound = mk >> 7;
+        {
+          const int gl = __ffsll((unsigned long long)__ballot(bkey == mk)) - 1, gdx = (gl < ncol ? gl : ncol - 1) - Rs, gadx = gdx < 0 ? -gdx : gdx;
+          const int grank = (int)(mk & 127u), gh = (grank + 1) >> 1, gdy = grank <= 2 * gadx ? grank - gadx : ((grank & 1) ? -gh : gh);
+          spec(mvpack(c.cqx + 4 * gdx, c.cqy + 4 * gdy));
+        }
         const int kq = (int)((float)bound * rcp_lambda) + 1;    // a candidate is worth reading while its vector's bits do not exceed bound / lambda (rounded up: safe)
         const int dq = bits_reach(kq - bx_min);                // ... a row, while |vy - py| <= dq
         const int lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
@@ -553,20 +561,8 @@ __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int w
   wave_sync();
 }
 
-// Both stages of a 4x4 block's sub-pel search need SATDs only within three quarter-pels of the integer vector: all 49 of them at once, a lane each, so
-// that the quarter-pel stage does not wait for a second trip to the sub-pel planes (the 4x4 searches are the macroblock's longest dependent chain).
-__device__ __forceinline__ void subpel_grid49(Shared &S, const PipeArgs &A, int wave, int lane, int ref, int px, int py, int mb_x, int mb_y, int mv)
-{
-  const bool live = lane < 49;
-  const int it = live ? lane : 0, oy = it / 7 - 3, ox = it - (oy + 3) * 7 - 3;
-  u32 r[4], o[4];
-  ref_rows4(A, ref, (px << 2) + mvx(mv) + ox, (py << 2) + mvy(mv) + oy, r);
-#pragma unroll
-  for (int j = 0; j < 4; j++) o[j] = S.cur_y[(mb_y + j) * 4 + (mb_x >> 2)];
-  if (live) S.red[wave][lane] = satd4_rows(o, r);
-  wave_sync();
-}
-
+// (A 4x4 block's sub-pel search reads all 49 SATDs within three quarter-pels of the integer vector at once, a lane each -- block_search -- so that
+// the quarter-pel stage does not wait for a second trip to the sub-pel planes.)
 // The strict-'<' scan over the nine positions of one stage of sub_pel_motion_estimation (me_fullsearch.c:221-246 / :263-281), nine lanes at once:
 // JM skips a position whose vector cost alone reaches the running minimum -- such a position could not have won -- so the winner is the first
 // position with the smallest total cost.  first = 1 (the quarter-pel stage when both stages use the same metric): position 0 is not evaluated,
@@ -631,14 +627,25 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
   const int i_lo = part ? c.Rs + 1 : 0, i_hi = (G == 2 && !part) ? c.Rs : 2 * c.Rs;
   u64 key;
+  // the 4x4 searches (the macroblock's longest dependent chain) fetch their sub-pel neighbourhood while the rest of the integer search runs
+  u32 sr[4] = {0, 0, 0, 0};
+  int spec_mv = 0x7fffffff;
+  const int g_oy = (lane < 49 ? lane : 0) / 7 - 3, g_ox = (lane < 49 ? lane : 0) - (g_oy + 3) * 7 - 3;
+  auto nospec = [](int) {};
+  auto spec4 = [&](int mvg) {
+    if (!P.subpel) return;
+    spec_mv = mvg;
+    ref_rows4(A, ref, (px << 2) + mvx(mvg) + g_ox, (py << 2) + mvy(mvg) + g_oy, sr);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   switch (bt) {
-  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
-  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0); break;
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, spec4); break;
   }
   if (G == 2) {
     if (part) {                                               // the helper hands its half over and is done with this search
@@ -661,7 +668,14 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     const int check0 = ref == 0 && bt == 1 && mv == 0;
     const bool grid = bt == 7;
     const int mv0 = mv;
-    if (grid) subpel_grid49(S, A, wave, lane, ref, px, py, mb_x, mb_y, mv);
+    if (grid) {                                               // subpel_grid49 with the rows fetched ahead, if the guess held
+      if (mv != spec_mv) ref_rows4(A, ref, (px << 2) + mvx(mv) + g_ox, (py << 2) + mvy(mv) + g_oy, sr);
+      u32 o[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[j] = S.cur_y[(mb_y + j) * 4 + (mb_x >> 2)];
+      if (lane < 49) S.red[wave][lane] = satd4_rows(o, sr);
+      wave_sync();
+    }
     else subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
     int best = scan9(S, wave, lane, mv, 2, P.lambda_mf[1], c.pqx, c.pqy, check0 ? P.lambda_mf[1] * 16 : 0, 0, 0, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + 2 * sp9x(best), mvy(mv) + 2 * sp9y(best));
