@@ -29,10 +29,12 @@
  * encoder.  Throughput comes from the batched entry points (bench.py); see INTEGRATION.md for how a maintainer
  * batches macroblock rows of ME behind the same slots.
  */
+#define _GNU_SOURCE                                         /* fopencookie */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/types.h>
 #include "global.h"
 #include "image.h"
 #include "mbuffer.h"
@@ -76,6 +78,9 @@ static struct {
 static void pipe_report(void);
 static double now_s(void);
 static double T_slice, T_pad, T_deblock, T_interp;
+/* per picture (the first 64): when encode_one_slice was entered and left, and the time inside DeblockFrame / getSubImagesLuma (JMHIP_ADAPTER_TIMELINE=1 prints them) */
+static double TL_in[64], TL_out[64], TL_db[64], TL_ip[64], TL_begun[64], TL_first[64], TL_last[64], TL_ended[64], TL_wait[64];
+static int TL_n;
 static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV);
 static int pipe_reference(StorablePicture *s);
 static int pipe_config_ok(VideoParameters *p_Vid);
@@ -105,6 +110,63 @@ static void adapter_die(const char *what, int rc)
 }
 
 /* is `name` one of the comma-separated tokens of `list` (NULL list = everything) */
+/* ------------------------------------------------------------------ the host's own per-picture chores, once the macroblocks come from the device
+ * (profiles/host_gprof.sh): none of them changes a byte JM writes.
+ *
+ * part "nulltrace": the reference is built with TRACE on (lencod/inc/defines.h:25): per syntax element trace2out (vlc.c:1364-1398) formats a line with
+ * some seventy stdio calls and an fflush -- 80 000 times per 1080p picture, which is most of the host's time per macroblock once the decisions come
+ * from the device.  When the configuration sends the trace to /dev/null, the trace FILE is replaced by a sink inside the process and the stdio calls
+ * JM's objects make ON THAT FILE (fprintf, putc, fputc, fflush, bound with --wrap like everything else here) return at once: the bytes were going
+ * nowhere.  Every other FILE, and any other TraceFile, goes to libc untouched. */
+#include <stdarg.h>
+static FILE *null_sink;
+static ssize_t null_write(void *cookie, const char *buf, size_t size) { (void)cookie; (void)buf; return (ssize_t)size; }
+static void trace_to_null_sink(InputParameters *p_Inp)
+{
+  cookie_io_functions_t io;
+  FILE *f;
+  if (!p_Enc || !p_Enc->p_trace || strcmp(p_Inp->TraceFile, "/dev/null")) return;
+  memset(&io, 0, sizeof io);
+  io.write = null_write;
+  if (!(f = fopencookie(NULL, "w", io))) return;
+  fclose(p_Enc->p_trace);
+  p_Enc->p_trace = f;
+  null_sink = f;
+}
+extern int __real_putc(int, FILE *);
+extern int __real_fputc(int, FILE *);
+extern int __real_fflush(FILE *);
+extern int __vfprintf_chk(FILE *, int, const char *, va_list);
+int __wrap_putc(int c, FILE *f) { return f == null_sink ? c : __real_putc(c, f); }
+int __wrap_fputc(int c, FILE *f) { return f == null_sink ? c : __real_fputc(c, f); }
+int __wrap_fflush(FILE *f) { return (f && f == null_sink) ? 0 : __real_fflush(f); }
+int __wrap___fprintf_chk(FILE *f, int flag, const char *fmt, ...)
+{
+  va_list ap;
+  int r;
+  if (f == null_sink) return 0;
+  va_start(ap, fmt);
+  r = __vfprintf_chk(f, flag, fmt, ap);
+  va_end(ap);
+  return r;
+}
+/* part "readframe": buf2img_basic (lcommon/src/input.c:552) widens the file's bytes to imgpel one memcpy at a time (12 ms per 1080p picture); the same
+ * assignment as a plain loop the compiler vectorises, for the case JM's first branch of the 8-bit path covers (equal sizes); everything else is JM's. */
+extern void buf2img_basic(imgpel **imgX, unsigned char *buf, int size_x, int size_y, int o_size_x, int o_size_y, int symbol_size_in_bytes, int bitshift);
+static void buf2img_bytes(imgpel **imgX, unsigned char *buf, int size_x, int size_y, int o_size_x, int o_size_y, int symbol_size_in_bytes, int bitshift)
+{
+  int i, j;
+  if (symbol_size_in_bytes != 1 || sizeof(imgpel) != 2 || size_x != o_size_x || size_y != o_size_y) {
+    buf2img_basic(imgX, buf, size_x, size_y, o_size_x, o_size_y, symbol_size_in_bytes, bitshift);
+    return;
+  }
+  for (j = 0; j < o_size_y; j++) {
+    imgpel *restrict d = imgX[j];
+    const unsigned char *restrict q = buf + (size_t)j * size_x;
+    for (i = 0; i < o_size_x; i++) d[i] = (imgpel)q[i];
+  }
+}
+
 static int has_part(const char *list, const char *name)
 {
   const size_t n = strlen(name);
@@ -160,6 +222,8 @@ static int adapter_on(VideoParameters *p_Vid)
     G.dbmb = (jmhip_db_mb *)calloc((size_t)(G.W / 16) * (G.H / 16), sizeof(jmhip_db_mb));
     G.dbmo = (jmhip_db_motion *)calloc((size_t)(G.W / 4) * (G.H / 4), sizeof(jmhip_db_motion));
     if (!G.planes || !G.tables || !G.dbmb || !G.dbmo) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+    if (has_part(parts, "nulltrace")) trace_to_null_sink(p_Inp);
+    if (has_part(parts, "readframe") && p_Vid->buf2img == buf2img_basic) p_Vid->buf2img = buf2img_bytes;
   }
   return !G.off;
 }
@@ -201,7 +265,7 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
 {
   int rc, k, j, i, y;
   const int Wp = s->size_x + 2 * JMHIP_PAD_X, Hp = s->size_y + 2 * JMHIP_PAD_Y;
-  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_reference(s)) { T_interp += now_s() - t0_; return; } }   /* the macroblock pipeline's picture: the planes are made on the device and stay there */
+  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_reference(s)) { T_interp += now_s() - t0_; if (TL_n) TL_ip[TL_n - 1] += now_s() - t0_; return; } }   /* the macroblock pipeline's picture: the planes are made on the device and stay there */
   if (!adapter_on(p_Vid) || !G.part_interp || s->size_x != G.W || s->size_y != G.H ||
       s->size_x_padded != Wp || s->size_y_padded != Hp) {
     G.n_passed++;
@@ -263,8 +327,10 @@ int __wrap_encode_one_slice(VideoParameters *p_Vid, int SliceGroupId, int TotalC
     if (rc) adapter_die("jmhip_set_current", rc);
     G.n_cur++;
   }
+  if (TotalCodedMBs == 0 && TL_n < 64) TL_in[TL_n++] = t0_;
   n_ = __real_encode_one_slice(p_Vid, SliceGroupId, TotalCodedMBs);
   T_slice += now_s() - t0_;
+  if (TL_n) TL_out[TL_n - 1] = now_s();
   return n_;
 }
 
@@ -876,7 +942,7 @@ void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
   StorablePicture *ids[64];
   int nids = 0, rc, x, y, l, k;
   unsigned i;
-  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) { T_deblock += now_s() - t0_; return; } }
+  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) { T_deblock += now_s() - t0_; if (TL_n) TL_db[TL_n - 1] += now_s() - t0_; return; } }
   if (!adapter_on(p_Vid) || !G.part_deblock || p_Vid->structure != FRAME || p_Vid->mb_aff_frame_flag ||
       (int)p_Vid->PicSizeInMbs != (G.W / 16) * (G.H / 16)) {
     G.n_passed++;
@@ -1284,6 +1350,7 @@ static void pipe_run_slice(Macroblock *currMB)
   P.slice_last = prm.num_slices > 1 ? (int)p_Vid->PicSizeInMbs - 1 : first + prm.num_mb - 1;
   P.n_slices++; P.n_refs += prm.num_ref;
   P.t_dev += now_s() - t0;
+  if (TL_n && first == 0) TL_begun[TL_n - 1] = now_s();
 }
 
 /* one macroblock's record into what write_macroblock (macroblock.c:2810), the MV predictor of later macroblocks and JM's statistics read */
@@ -1345,10 +1412,12 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
     t0 = now_s();
     if ((rc = jmhip_slice_record(G.ctx, currMB->mbAddrX, &rec))) adapter_die("jmhip_slice_record", rc);     /* waits while the device is behind */
     P.t_wait += now_s() - t0;
+    if (TL_n) { TL_wait[TL_n - 1] += now_s() - t0; if (currMB->mbAddrX == 0) TL_first[TL_n - 1] = now_s(); if (currMB->mbAddrX == (int)p_Vid->PicSizeInMbs - 1) TL_last[TL_n - 1] = now_s(); }
     t0 = now_s();
     mb_from_record(currMB, rec);
     P.t_fill += now_s() - t0;
     if (currMB->mbAddrX == P.slice_last && (rc = jmhip_encode_slice_end(G.ctx))) adapter_die("jmhip_encode_slice_end", rc);
+    if (TL_n && currMB->mbAddrX == P.slice_last) TL_ended[TL_n - 1] = now_s();
   }
   P.mbs++; P.n_mbs++;
 }
@@ -1384,6 +1453,12 @@ static void pipe_report(void)
     fprintf(stderr, "jmhip adapter: macroblock pipeline: %ld slices, %ld macroblocks encoded on the MI355X (encode_one_macroblock_low never ran on the host); "
                     "device calls %.3f s, waiting for records %.3f s, unpacking them %.3f s; wall time inside encode_one_slice %.3f s, pad_borders %.3f s, DeblockFrame %.3f s, getSubImagesLuma %.3f s\n",
             P.n_slices, P.n_mbs, P.t_dev, P.t_wait, P.t_fill, T_slice, T_pad, T_deblock, T_interp);
+  if (getenv("JMHIP_ADAPTER_TIMELINE")) {
+    int i;
+    for (i = 0; i < TL_n; i++)
+      fprintf(stderr, "jmhip adapter: picture %d: slices %.1f ms (after its start: launched %.1f, first record %.1f, last record %.1f, launch closed %.1f ms; waiting for records %.1f ms), DeblockFrame %.1f ms, getSubImagesLuma %.1f ms, everything else up to the next picture's first slice %.1f ms\n", i,
+              1e3 * (TL_out[i] - TL_in[i]), 1e3 * (TL_begun[i] - TL_in[i]), 1e3 * (TL_first[i] - TL_in[i]), 1e3 * (TL_last[i] - TL_in[i]), 1e3 * (TL_ended[i] - TL_in[i]), 1e3 * TL_wait[i], 1e3 * TL_db[i], 1e3 * TL_ip[i], i + 1 < TL_n ? 1e3 * (TL_in[i + 1] - TL_out[i] - TL_db[i] - TL_ip[i]) : 0.0);
+  }
 }
 
 /* ------------------------------------------------------------------ FmoGetLastCodedMBOfSliceGroup (lencod/src/fmo.c:676)
