@@ -85,6 +85,10 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   c->stream = (hipStream_t)cfg->stream;
   { const char *fg = getenv("JMHIP_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
   { const char *fg = getenv("JMHIP_DEBLOCK_DIAG"); c->force_db_diag = fg && fg[0] == '1'; }
+  c->db_no_prefill = getenv("JMHIP_DEBLOCK_NO_PREFILL") != nullptr;
+  { const char *e = getenv("JMHIP_DEBLOCK_SPARSE_PCT"); c->db_sparse_pct = e ? atoi(e) : 40; }
+  c->refine_per_block = getenv("JMHIP_REFINE_PER_BLOCK") != nullptr;
+  { const char *e = getenv("JMHIP_MB_PROF"); c->mb_prof_mode = e ? atoi(e) : 0; }
   c->W = cfg->width; c->H = cfg->height;
   c->Wp = c->W + 2 * JMHIP_PAD_X; c->Hp = c->H + 2 * JMHIP_PAD_Y;
   c->pitch = (c->Wp + 63) & ~63;

@@ -653,10 +653,9 @@ int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t 
 {
   const int mb_w = ctx->W / 16, mb_h = ctx->H / 16, nmb = mb_w * mb_h, fmt = ctx->cfg.yuv_format;
   const int nkinds = fmt ? 2 : 1, nsync = DB_SYNC_ROWINFO + 2 * mb_h;                                         // ticket, error | mode, tasks, task ticket
-  const int no_prefill = getenv("JMHIP_DEBLOCK_NO_PREFILL") != nullptr;              // A/B switches for profiling and tests
+  const int no_prefill = ctx->db_no_prefill;                                         // A/B switches for profiling and tests (environment, read in jmhip_create)
   // segment walks (deblock_sparse.hip) for pictures with few active macroblocks; the decision is taken on the device, per frame
-  const char *pct = getenv("JMHIP_DEBLOCK_SPARSE_PCT");
-  const int max_active_pct = pct ? atoi(pct) : 40;
+  const int max_active_pct = ctx->db_sparse_pct;
   const bool sparse_on = !no_prefill && max_active_pct > 0 && ctx->d_db_tasks && mb_w <= 256 && mb_h <= 256;
   const int lr = no_prefill ? 0 : (sparse_on ? 1 : LR), cr = no_prefill ? 0 : (sparse_on ? 1 : (fmt == 2 ? 2 : 4));
   hipLaunchKernelGGL(k_deblock_prep, dim3((nmb + 7) / 8), dim3(256), 0, ctx->stream, d_mbs, d_motion, mb_w, mb_h, fmt, direct8x8,

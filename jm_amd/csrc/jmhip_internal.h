@@ -36,6 +36,7 @@ struct jmhip_ctx {
   void *d_db_hand;       // deblocking row pipeline: 24 8-byte hand-over granules per macroblock
   uint8_t *d_db_flags;   // deblocking segment walks: per macroblock flags (nmb bytes), then store_bottom (nmb bytes)
   void *d_db_tasks;      // deblocking segment walks: task list (1024 x int2)
+  int db_no_prefill, db_sparse_pct, refine_per_block, mb_prof_mode;   // JMHIP_DEBLOCK_NO_PREFILL, JMHIP_DEBLOCK_SPARSE_PCT (default 40), JMHIP_REFINE_PER_BLOCK, JMHIP_MB_PROF: read once, in jmhip_create
   int force_db_diag;     // JMHIP_DEBLOCK_DIAG=1: one launch per diagonal instead of the row pipeline (A/B testing)
   // the macroblock pipeline (mbpipe.hip), allocated on first use
   uint8_t *d_rec;        // reconstruction of the current picture: Y (cur_pitch x H), then U, V (cw x ch, pitch cw)

@@ -351,7 +351,7 @@ extern "C" int jmhip_me_refine_dev(jmhip_ctx *ctx, int32_t slot, const jmhip_me_
   if (njobs == 0) return JMHIP_OK;
   jmhip_launch_check_me_jobs(ctx, d_jobs, njobs);
   jmhip_time_begin(ctx, 2);
-  if (getenv("JMHIP_REFINE_PER_BLOCK")) {                 // the per-block kernel (one 16-lane group per partition): A/B testing
+  if (ctx->refine_per_block) {                 // the per-block kernel (one 16-lane group per partition): A/B testing
     const long groups = (long)njobs * JMHIP_NPART;
     hipLaunchKernelGGL(k_me_refine, dim3((unsigned)((groups + 3) / 4)), dim3(64), 0, ctx->stream, d_jobs, njobs, d_int, *prm, d_out,
                        planes_of(ctx, slot), ctx->d_cur, ctx->cur_pitch);

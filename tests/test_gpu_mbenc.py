@@ -193,6 +193,54 @@ def test_encode_slice_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed):
             assert np.array_equal(a, b.astype(np.uint8)), (n, "reconstruction after the loop filter")
 
 
+def hard_clip(kind, W, H, nfr, seed):
+    """content chosen against the search's pruning and tie-breaking: everything equal, nothing alike, exact periodic ties, zero distortion at the predictor"""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    frames = []
+    still = rng.integers(0, 256, (H, W))
+    for n in range(nfr):
+        if kind == "flat":
+            y = np.full((H, W), 128)
+            y[8 + 3 * n:16 + 3 * n, 20 + 5 * n:28 + 5 * n] = 230          # one small object crossing macroblock borders
+        elif kind == "noise":
+            y = rng.integers(0, 256, (H, W))
+        elif kind == "stripes":
+            y = 40 + 170 * (((xs + n) // 2) % 2) + 20 * (((ys + 2 * n) // 8) % 2)      # period 4 across, 16 down: whole families of equal SADs
+        elif kind == "still":
+            y = still
+        elif kind == "ramp":
+            y = (3 * xs + 2 * ys + 7 * n) % 256                             # a gradient: SAD grows linearly with the displacement
+        y = np.clip(y, 0, 255).astype(np.uint8)
+        yd = y.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
+        u = np.clip(np.rint(128 + 0.25 * (yd - 128)), 0, 255).astype(np.uint8)
+        v = np.clip(np.rint(128 - 0.25 * (yd - 128)), 0, 255).astype(np.uint8)
+        frames.append(np.concatenate([y.ravel(), u.ravel(), v.ravel()]))
+    return frames
+
+
+@pytest.mark.parametrize("kind,R,num_ref,qp", [("flat", 32, 1, 44), ("flat", 16, 2, 28), ("noise", 32, 1, 12), ("noise", 16, 2, 40), ("stripes", 32, 2, 28),
+                                               ("stripes", 8, 1, 20), ("still", 32, 1, 36), ("still", 16, 2, 16), ("ramp", 32, 1, 28), ("ramp", 16, 1, 48)])
+def test_encode_slice_vs_oracle_hard_content(kind, R, num_ref, qp):
+    """The search skips candidates by JM's own cost bound (rows near the predictor, then only what the best cost so far leaves: mbpipe.hip fs_wave);
+    the result must stay JM's whatever the content does to that bound: pictures where every candidate ties (flat, periodic stripes: the spiral
+    order decides), where nothing matches (noise: the bound excludes nothing), where the distortion at the predictor is zero (a still picture:
+    the bound excludes almost everything), and a gradient; lambda from very small to very large."""
+    W, H = 96, 80
+    f = max(1, int(192 * 2 ** ((qp - 28) / 6)))
+    lam = {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    frames = hard_clip(kind, W, H, 3 if num_ref == 1 else 4, 11)
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, 0)
+    ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, 0)
+    for n, raw in enumerate(frames):
+        recs, pre, post = dev.encode(raw, W, H)
+        orecs, _, opre, opost = ora.encode(pyjmo.load_frame(raw, W, H, W, H, 1))
+        d = first_difference(mb_tap.canonical(orecs), mb_tap.canonical(as_oracle_records(recs)))
+        assert d is None, (kind, n, d)
+        for a, b in zip(post, opost):
+            assert np.array_equal(a, b.astype(np.uint8)), (kind, n, "reconstruction after the loop filter")
+
+
 def test_streamed_records_equal_the_blocking_call():
     """jmhip_encode_slice_begin / jmhip_slice_record / jmhip_encode_slice_end (what the adapter uses: JM's entropy coder reads each record in raster
     order while the device is still encoding) hands over the same records as jmhip_encode_slice, picture after picture, with mid-row slices."""
