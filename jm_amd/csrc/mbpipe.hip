@@ -279,6 +279,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   const int Rs = c.Rs, ncol = 2 * Rs + 1;
   u64 best = ~0ull;
   if (pf && lane == 0) pf[25] = wall_clock64();
+  int dbg_steps = 0, dbg_items = 0;                             // JMHIP_MB_PROF: window rows the sliding lanes read, candidates of step 2
   // JM skips a candidate whose vector cost alone reaches the running minimum (me_fullsearch.c:83) -- result-neutral, and what makes its full search
   // affordable on a CPU.  Here the same bound, for the blocks of at most 64 samples (a larger block's SAD dwarfs any vector cost: the bound
   // excludes nothing; nor for the 16x16 search on reference 0, whose (0,0) vector's cost is not its rate), in three steps.  A candidate whose
@@ -294,6 +295,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   const int a_lo = prune ? max(i_lo, ip - 2) : i_lo, a_hi = prune ? min(i_hi, ip + 2) : i_hi;
   const int bx_min = mvbits(t_x - 4 * clampi3(-Rs, Rs, (t_x + 2) >> 2));       // the cheapest column's bits
   int lo1 = i_lo, hi1 = i_hi;                                  // step 1's rows, set after step 0
+  bool step1 = false;
   int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read by the sliding lanes
   u32 bound = 0xffffffffu;                                     // the best cost so far
   const float rcp_lambda = __builtin_amdgcn_rcpf((float)(c.lambda > 0 ? c.lambda : 1));
@@ -328,9 +330,41 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       // (with lead-ins of seven rows one pass over both sides and the rows between them is cheaper than two)
       const bool both = BH >= 8 && lo1 < a_lo && hi1 > a_hi;
       const int s_lo = seg == 0 ? a_lo : (seg == 1 ? lo1 : a_hi + 1), s_hi = seg == 0 ? a_hi : (seg == 1 ? (both ? hi1 : a_lo - 1) : (both ? a_hi : hi1));
-      if (s_lo <= s_hi) {
+      if (BW * BH <= 64 && seg == 0 && prune) {
+        // step 0 as straight-line code: the (at most) five candidate rows and the BH - 1 window rows below them are read at once and summed side
+        // by side (independent instructions: a lone wave issues a dependent one only every ~9 cycles); rows past the last candidate lie in the
+        // window's slack rows
+        constexpr int NB = 5, NR = NB + BH - 1;
+        const u8 *p = pbase + a_lo * WP;
+        u32 bb[NR][BW / 4], ytv[NB];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          u32 a[BW / 4 + 1];
+#pragma unroll
+          for (int k = 0; k <= BW / 4; k++) a[k] = ((const u32 *)(p + r * WP))[k];
+#pragma unroll
+          for (int k = 0; k < BW / 4; k++) bb[r][k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) ytv[k] = ytab[a_lo + k > 2 * Rs ? 2 * Rs : a_lo + k];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          u32 v = 0;
+#pragma unroll
+          for (int r = 0; r < BH; r++)
+#pragma unroll
+            for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(bb[k + r][q], cb[r][q], v);
+          const int i = a_lo + k, dy = i - Rs, ady = dy < 0 ? -dy : dy;
+          const u32 kf = (v << 12) + rx7 + ytv[k];
+          const u32 kn = (kf & ~127u) | (u32)(i + k1);
+          const u32 key = (u32)ady <= (u32)adx ? kn : kf;
+          bkey = (i <= a_hi && key < bkey) ? key : bkey;
+        }
+        dbg_steps += NR;
+      } else if (s_lo <= s_hi) {
         ev_lo = min(ev_lo, s_lo); ev_hi = max(ev_hi, s_hi);
         const int nrows = (s_hi - s_lo + 1) + BH - 1;
+        dbg_steps += nrows;
         const u8 *p = pbase + s_lo * WP;
         u32 acc[BH];
 #pragma unroll
@@ -396,6 +430,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         }
       }
       if (seg == 0 && prune) {
+        if (pf && lane == 0) pf[27] = wall_clock64();
         const u32 mk = wave_min_u32(bkey);
         bound = mk >> 7;
         {
@@ -403,26 +438,39 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
           const int grank = (int)(mk & 127u), gh = (grank + 1) >> 1, gdy = grank <= 2 * gadx ? grank - gadx : ((grank & 1) ? -gh : gh);
           spec(mvpack(c.cqx + 4 * gdx, c.cqy + 4 * gdy));
         }
+        if (pf && lane == 0) pf[28] = wall_clock64();
         const int kq = (int)((float)bound * rcp_lambda) + 1;    // a candidate is worth reading while its vector's bits do not exceed bound / lambda (rounded up: safe)
         const int dq = bits_reach(kq - bx_min);                // ... a row, while |vy - py| <= dq
         const int lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
-        // the cheapest h, one lane per choice: sliding steps of step 1 (with their BH - 1 rows of lead-in) against passes of step 2
-        const int hk = lane == 0 ? 2 : (2 << (lane < 5 ? lane : 5)) - 1;
-        const int l1 = max(lo2, ip - hk), h1 = min(hi2, ip + hk);
-        int byo = 1 << 20;
-        if (l1 - 1 >= lo2) byo = min(byo, mvbits(4 * (l1 - 1 - Rs) - t_y));
-        if (h1 + 1 <= hi2) byo = min(byo, mvbits(4 * (h1 + 1 - Rs) - t_y));
-        const int dqx = bits_reach(kq - byo);
-        const int nc = dqx < 0 ? 0 : max(0, min(2 * Rs, Rs + ((t_x + dqx) >> 2)) - max(0, Rs + ((t_x - dqx + 3) >> 2)) + 1);
-        const int passes = ((max(0, l1 - lo2) + max(0, hi2 - h1)) * nc + 63) >> 6;
-        const int up = max(0, a_lo - l1), dn = max(0, h1 - a_hi);
-        const int steps = (BH >= 8 && up && dn) ? (h1 - l1 + 1) + BH - 1 : (up ? up + BH - 1 : 0) + (dn ? dn + BH - 1 : 0);
-        const u32 est = (u32)(steps * (BW * BH / 4 + 12) + passes * (BH * (BW / 2 + 3) + 45));
-        const u32 pick = (u32)rfl((int)row16_min_u32(lane < 6 ? (est << 3) | (u32)lane : 0xffffffffu)) & 7u;
-        const int h = pick == 0 ? 2 : (2 << pick) - 1;
-        lo1 = max(lo2, ip - h); hi1 = min(hi2, ip + h);
+        // h = 2 (no step 1) when step 2 then fits one pass -- the usual case, decided with a few scalar instructions
+        int byo2 = 1 << 20;
+        if (a_lo - 1 >= lo2) byo2 = min(byo2, mvbits(4 * (a_lo - 1 - Rs) - t_y));
+        if (a_hi + 1 <= hi2) byo2 = min(byo2, mvbits(4 * (a_hi + 1 - Rs) - t_y));
+        const int dqx2 = bits_reach(kq - byo2);
+        const int nc2 = dqx2 < 0 ? 0 : max(0, min(2 * Rs, Rs + ((t_x + dqx2) >> 2)) - max(0, Rs + ((t_x - dqx2 + 3) >> 2)) + 1);
+        if ((max(0, a_lo - lo2) + max(0, hi2 - a_hi)) * nc2 <= 64) { lo1 = a_lo; hi1 = a_hi; }
+        else {
+          // the cheapest h, one lane per choice: sliding steps of step 1 (with their BH - 1 rows of lead-in) against passes of step 2
+          const int hk = lane == 0 ? 2 : (2 << (lane < 5 ? lane : 5)) - 1;
+          const int l1 = max(lo2, ip - hk), h1 = min(hi2, ip + hk);
+          int byo = 1 << 20;
+          if (l1 - 1 >= lo2) byo = min(byo, mvbits(4 * (l1 - 1 - Rs) - t_y));
+          if (h1 + 1 <= hi2) byo = min(byo, mvbits(4 * (h1 + 1 - Rs) - t_y));
+          const int dqx = bits_reach(kq - byo);
+          const int nc = dqx < 0 ? 0 : max(0, min(2 * Rs, Rs + ((t_x + dqx) >> 2)) - max(0, Rs + ((t_x - dqx + 3) >> 2)) + 1);
+          const int passes = ((max(0, l1 - lo2) + max(0, hi2 - h1)) * nc + 63) >> 6;
+          const int up = max(0, a_lo - l1), dn = max(0, h1 - a_hi);
+          const int steps = (BH >= 8 && up && dn) ? (h1 - l1 + 1) + BH - 1 : (up ? up + BH - 1 : 0) + (dn ? dn + BH - 1 : 0);
+          const u32 est = (u32)(steps * (BW * BH / 4 + 12) + passes * (BH * (BW / 2 + 3) + 45));
+          const u32 pick = (u32)rfl((int)row16_min_u32(lane < 6 ? (est << 3) | (u32)lane : 0xffffffffu)) & 7u;
+          const int h = pick == 0 ? 2 : (2 << pick) - 1;
+          lo1 = max(lo2, ip - h); hi1 = min(hi2, ip + h);
+          step1 = lo1 < a_lo || hi1 > a_hi;
+        }
+        if (pf && lane == 0) pf[29] = wall_clock64();
       }
     }
+    if (pf && lane == 0) pf[30] = wall_clock64();
     if (BW == 16 && BH == 16 && zero_x) {                       // me_fullsearch.c:78-82: the (0,0) vector of the 16x16 search on reference 0 gets 16 lambda off its rate
       const int i0 = Rs - (c.cqy >> 2);                        // its row, if the window holds it
       if (i0 >= i_lo && i0 <= i_hi) {
@@ -433,7 +481,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         bkey = key < bkey ? key : bkey;
       }
     }
-    if (prune) bound = wave_min_u32(bkey) >> 7;                 // B1
+    if (prune && step1) bound = wave_min_u32(bkey) >> 7;        // B1 (= B0 if step 1 read nothing)
     {
       const int rank = (int)(bkey & 127u);
       const int l = (rank + 1) >> 1;
@@ -476,6 +524,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     const int cl = max(0, Rs + ((t_x - dqx + 3) >> 2)), ch = min(2 * Rs, Rs + ((t_x + dqx) >> 2));
     const int total = (dqx < 0 || ch < cl) ? 0 : nr * (ch - cl + 1);
     const float inv = __builtin_amdgcn_rcpf((float)(nr > 0 ? nr : 1));
+    dbg_items = total;
     for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
       const bool live = item < total;
@@ -495,7 +544,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, mvbits(c.cqx + 4 * dx - c.pqx)); best = key < best ? key : best; }
     }
   }
-  if (pf && lane == 0) pf[23] = wall_clock64();
+  if (pf && lane == 0) { pf[23] = wall_clock64(); pf[26] = (unsigned long long)dbg_steps | ((unsigned long long)dbg_items << 16) | ((unsigned long long)(hi1 - lo1 + 1 > 0 ? hi1 - lo1 + 1 : 0) << 32); }
   const u32 hi = wave_min_u32((u32)(best >> 32));              // the smallest cost, then the earliest spiral index among the candidates that have it
   const u32 lo = wave_min_u32((u32)(best >> 32) == hi ? (u32)best : 0xffffffffu);
   return ((u64)hi << 32) | lo;
@@ -592,7 +641,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const bool prof_ = A.prof && ((A.prof_mode == 1 && mb_x == 0 && bt == 7) || (A.prof_mode == 4 && mb_x == 8 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
+  const bool prof_ = A.prof && (((A.prof_mode == 1 || A.prof_mode == 10) && mb_x == 0 && bt == 7) || (A.prof_mode == 4 && mb_x == 8 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
                      part == 0 && mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);

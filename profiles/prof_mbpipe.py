@@ -48,7 +48,14 @@ for n in range(2):
     if n == 1 and MODE in ("5", "6", "7", "8", "9"):
         print("  first %s search: predictor %.2f, centre + block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f, half-pel %.2f, quarter-pel + skip %.2f us" % (({"5": "16x8", "6": "16x16", "7": "8x8", "8": "8x4", "9": "4x8"}[MODE],) + tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 25), (25, 24), (24, 7), (7, 23), (23, 20), (20, 21), (21, 22)))))
-    if n == 1 and MODE == "1":
+    if n == 1 and MODE in ("1", "5", "6", "7", "8", "9"):
+        w = st[:, 26]
+        print("  ... that search: window rows read by the sliding lanes: median %d (mean %.1f); candidates of step 2: median %d (mean %.1f); rows of step 1: median %d (mean %.1f)" % (
+            np.median(w & 0xffff), (w & 0xffff).mean(), np.median((w >> 16) & 0xffff), ((w >> 16) & 0xffff).mean(), np.median(w >> 32), (w >> 32).mean()))
+    if n == 1 and MODE == "10":
+        print("  first 4x4 search, the sliding part in detail: first rows %.2f, their minimum + the sub-pel fetch started %.2f, what remains decided %.2f, steps 1 %.2f, B1 + keys widened %.2f; step 2 %.2f, wave minimum %.2f us" % tuple(
+            np.median(us(a, b)) for a, b in ((24, 27), (27, 28), (28, 29), (29, 30), (30, 7), (7, 23), (23, 20))))
+    if n == 1 and MODE in ("1", "10"):
         print("  first 4x4 search of the macroblock (wave 3): predictor %.2f, integer search %.2f, half-pel stage %.2f, quarter-pel stage + clip %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
     if n == 1:                                                 # the hand-over: from the last neighbour's flag store to this macroblock's start
@@ -83,5 +90,9 @@ for n in range(2):
         print("  critical path: %d macroblocks, start .. vectors published on it: median %.1f, mean %.1f us (all macroblocks: mean %.1f); sum %.2f ms" % (len(path), np.median(dp), dp.mean(), us(1, PUB).mean(), dp.sum() / 1000))
         for nm, a, b in (("phase 0", 2, 3), ("phase 1", 3, 4), ("phase 2", 4, 5), ("phase 3", 5, 6), ("final barrier .. vectors out", 6, PUB), ("final barrier .. end", 6, 16), ("publish", 16, 17)):
             print("    on the path, %-22s mean %.1f (all: %.1f)" % (nm, us(a, b)[path].mean(), us(a, b).mean()))
+        print("    on the path, first 8x8 block, waves 0-3 (8x8, 8x4, 4x8, 4x4) from phase start to the wave's end: " + " ".join("%.1f" % ((st[path, 8 + w] - st[path, 2]) / 100.0).mean() for w in range(4)) +
+              "  (all: " + " ".join("%.1f" % ((st[:, 8 + w] - st[:, 2]) / 100.0).mean() for w in range(4)) + ")")
+        wl = np.argmax(np.stack([st[path, 8 + w] for w in range(4)]), 0)
+        print("    ... the last of the four to finish, share of the path's macroblocks: " + " ".join("%s %.0f %%" % (nm, 100.0 * (wl == w).mean()) for w, nm in enumerate(("8x8", "8x4", "4x8", "4x4"))))
     span = (st[:, 17].max() - st[:, 0].min()) / 100.0
     print(f"  first ticket -> last publish {span / 1000:.2f} ms; sum of per-macroblock busy time / span = {us(1, 17).sum() / span:.1f} macroblocks in flight on average")
