@@ -32,7 +32,6 @@ typedef uint8_t u8;
 // 1: in the 8x8 blocks 1-3 every sub-mode search is shared by two waves (candidate rows split, hand-over through LDS).  Measured on the MI355X it is
 // no faster than one wave per search (38.5 vs 39.5 us per block: a row costs each of the two waves 1.5x what it costs a lone wave, and the hand-over
 // adds 1.3 us per search), so it is off; the parity tests pass either way.
-#define MB_PAIR 0
 #define MAXC 0x7fffffff
 #define EDGE_WORDS 17                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
                                             // 6/7 right U/V columns, 8 ipredmode (bytes 0-3 bottom row, 4-7 right column), 9-12 / 13-16 mv_info of the
@@ -106,8 +105,6 @@ struct Shared {
   u8 predc[2][64], recc[2][64];
   int16_t dcbuf[16];
   int red[8][80];
-  u64 xkey[4];                               // two waves on one search: the helper's best key, its sequence number, the main wave's "results are in" number
-  int xseq_h[4], xseq_m[4];
   int nbflag;                                // the neighbours' samples are in nb (running count over the launch)
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
   u32 ytab4[4][72];                          // the same for the four usual offsets of the predictor from the search centre (-2 .. 1 quarter-pels), full range: once per launch
@@ -124,7 +121,6 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // hand-over between two waves of the workgroup through a sequence number in LDS (a wave's LDS operations execute in order)
 __device__ __forceinline__ void lds_signal(int *f, int seq, int lane) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) *(volatile int *)f = seq; }
 __device__ __forceinline__ void lds_wait_ge(const int *f, int seq) { while (*(const volatile int *)f < seq) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-__device__ __forceinline__ void lds_wait(const int *f, int seq) { while (*(const volatile int *)f != seq) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 // Cross-lane steps inside a row of 16 lanes as DPP operands of the ALU (no trip through the LDS crossbar that __shfl_xor takes):
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after n of them every lane holds the result over its 2^n neighbours.
@@ -632,17 +628,15 @@ __device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv
 
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
 // view: which chain's picture of the macroblock's vectors the predictor reads; wave: this wave's own scratch (row table, SATD sums).
-// G = 2: two waves share the integer search (part 0 the upper candidate rows and everything after the search, part 1 the lower rows only; part 1
-// returns nothing); seq: the pair's running search number.
-__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int part, int G, int seq, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
+__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
 {
   const jmhip_slice_params &P = A.p;
   const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
   const int R = P.search_range;
-  const bool prof_ = A.prof && (((A.prof_mode == 1 || A.prof_mode == 10) && mb_x == 0 && bt == 7) || (A.prof_mode == 4 && mb_x == 8 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
-                     part == 0 && mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
+  const bool prof_ = A.prof && (((A.prof_mode == 1 || A.prof_mode == 10) && mb_x == 0 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
+                     mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
   const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH));
@@ -674,7 +668,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
-  const int i_lo = part ? c.Rs + 1 : 0, i_hi = (G == 2 && !part) ? c.Rs : 2 * c.Rs;
+  const int i_lo = 0, i_hi = 2 * c.Rs;
   u64 key;
   // the 4x4 searches (the macroblock's longest dependent chain) fetch their sub-pel neighbourhood while the rest of the integer search runs
   u32 sr[4] = {0, 0, 0, 0};
@@ -688,25 +682,13 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     __builtin_amdgcn_sched_barrier(0);
   };
   switch (bt) {
-  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
-  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
-  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
-  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
-  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
-  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, nospec); break;
-  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, part == 0, spec4); break;
-  }
-  if (G == 2) {
-    if (part) {                                               // the helper hands its half over and is done with this search
-      if (lane == 0) S.xkey[view] = key;
-      lds_signal(&S.xseq_h[view], seq, lane);
-      out_mv = 0;
-      return 0;
-    }
-    if (prof_) A.prof[(long)addr_ * 32 + 26] = wall_clock64();
-    lds_wait(&S.xseq_h[view], seq);
-    const u64 other = S.xkey[view];
-    key = other < key ? other : key;
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, spec4); break;
   }
   const int klo = rfl((int)(u32)key), khi = rfl((int)(u32)(key >> 32));
   BS_STAMP(20);

@@ -32,9 +32,6 @@ for n in range(2):
         m = (st[:, 27] > 0) & (st[:, 30] > st[:, 27])
         f = lambda a, b: np.median((st[m, b] - st[m, a]) / 100.0)
         print("  final stage, inter luma (wave 0): decision %.2f, prediction fetch %.2f, transform/quant %.2f, thresholds + stores %.2f, rest up to the barrier %.2f us" % (f(6, 27), f(27, 28), f(28, 29), f(29, 30), f(30, 16)))
-    if MODE == "4" and n == 1:
-        print("  first 4x4 search of the SECOND 8x8 block (two waves): predictor %.2f, centre + block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f, waiting for the helper %.2f, half-pel %.2f, quarter-pel %.2f us" % tuple(
-            np.median(us(a, b)) for a, b in ((18, 19), (19, 25), (25, 24), (24, 7), (7, 23), (23, 26), (26, 20), (20, 21), (21, 22))))
     if MODE == "1" and n == 1:
         print("  ... of the integer search: centre + source block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f us" % tuple(np.median(us(a, b)) for a, b in ((19, 25), (25, 24), (24, 7), (7, 23), (23, 20))))
     if MODE == "2":
