@@ -31,6 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # before the HIP runtime starts: one hardware queue per stream for the concurrent_streams figure
 
 W, H_SRC, H = 1920, 1080, 1088
 R = 32
@@ -166,6 +167,48 @@ def end_to_end(cpu, max_seconds=300):
     return out
 
 
+def concurrent_streams(S, raw0, raw1, src_h, slice_prm, device, steps):
+    """An extra figure, never `value`: S independent 1080p sequences (the same step each: P picture through k_mb_pipe + DeblockFrame + getSubImagesLuma)
+    on S contexts with their own HIP streams, each slice's launch limited to its share of the chip (jmhip_set_pipeline_workgroups).  One sequence
+    is a dependency chain that keeps ~27 of 256 compute units busy; a server encodes several at once."""
+    import torch
+    from jm_amd import JmHip
+    share = max(16, (256 - 32) // S)                                     # 32 compute units stay free for the short kernels (loop filter, interpolation) of all streams
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]      # the stream the bench already owns + S - 1 more: a hardware queue each
+    ctxs = []
+    for st in streams:
+        c = JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1, device=device, stream=st.cuda_stream)
+        c.set_pipeline_workgroups(share)
+        c.set_current_frame(raw0, W, src_h)
+        c.encode_slice_dev(slice_prm(2, 0, 8160, 0, 0))
+        c.deblock_picture_dev(1)
+        c.reference_from_recon(0)
+        c.set_current_frame(raw1, W, src_h)
+        ctxs.append(c)
+    prm = slice_prm(0, 0, 8160, 0, 1)
+    prm["ref_slot"][0, 0] = 0
+
+    def round_():
+        for c in ctxs:
+            c.encode_slice_dev(prm)
+            c.deblock_picture_dev(1)
+            c.reference_from_recon(1)
+    round_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        round_()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.synchronize()                                                  # device-side error words
+        c.close()
+    return {"streams": S, "workgroups_per_stream": share, "steps": steps, "ms_per_round": round(dt / steps * 1e3, 3),
+            "macroblocks_per_s": round(S * 8160 * steps / dt, 1),
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "note": "S sequences side by side on one MI355X, one context + HIP stream each (GPU_MAX_HW_QUEUES raised from its default 4 so that the streams get a hardware queue each); the same step as `value` per sequence; not the BASELINE metric (one sequence)"}
+
+
 class _DevMem:
     """device memory of the library as a torch tensor (for the collective)"""
     def __init__(self, ptr, nbytes):
@@ -179,6 +222,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--streams", type=int, default=8, help="sequences encoded side by side for the extra concurrent_streams figure (0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -363,6 +407,8 @@ def main():
             out["cpu_baseline"] = cpu
         if not args.no_end_to_end and N == 1:
             out["end_to_end"] = end_to_end(cpu)
+        if args.streams > 1 and N == 1:
+            out["concurrent_streams"] = concurrent_streams(args.streams, raw0, raw1, src_h, slice_prm, local, min(args.steps, 20))
         print(json.dumps(out))
     if N > 1:
         dist.destroy_process_group()

@@ -581,6 +581,11 @@ typedef struct {
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);
+/* How many workgroups (= compute units) a slice's launch may occupy; 0 = the default (256, the whole MI355X).  A slice is a dependency chain: at
+ * 1080p at most 60 macroblocks can be in flight, 27 on average, so one stream leaves most of the chip idle.  A server that encodes several
+ * sequences at once (one context and one HIP stream each -- JM itself has no such mode: one lencod process per sequence) gives each context its
+ * share, e.g. 32 for eight 1080p streams; the records are the same for any value (tests/test_gpu_mbenc.py). */
+int jmhip_set_pipeline_workgroups(jmhip_ctx *ctx, int32_t workgroups);
 int jmhip_encode_slice_dev(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *d_out /* device, or NULL: kept inside only */);
 /* The same, streamed, for a host that codes macroblocks in raster order while the device is still encoding (JM's write_macroblock after every
  * encode_one_macroblock): _begin launches and returns; _record waits until macroblock mb_addr's record is complete in pinned host memory and

@@ -46,6 +46,7 @@ struct jmhip_ctx {
   int *d_mb_order;       // wavefront order of the slice's macroblocks
   int mb_order_first, mb_order_num, mb_order_per;
   unsigned mb_epoch;
+  int mb_grid;           // jmhip_set_pipeline_workgroups (0: 256)
   void *d_mb_records;    // jmhip_mb_record per macroblock of the picture
   void *d_mb_dbmb, *d_mb_dbmo;   // loop-filter side information written by the pipeline
   void *h_mb_records;    // pinned host staging for jmhip_encode_slice

@@ -99,7 +99,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
-           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon"]
+           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups"]
 
 
 class JmHipError(RuntimeError):
@@ -190,6 +190,10 @@ class JmHip:
         return ms.value
 
     # ---- frames
+    def set_pipeline_workgroups(self, n):
+        """how many workgroups a slice's launch may occupy (0 = 256): a context's share of the chip when several sequences are encoded at once"""
+        self._ck(self.lib.jmhip_set_pipeline_workgroups(self.h, C.c_int32(int(n))))
+
     def set_stream(self, hip_stream):
         """launch every later call on this HIP stream (an int handle, e.g. torch.cuda.Stream.cuda_stream); ordering is the caller's"""
         self._ck(self.lib.jmhip_set_stream(self.h, C.c_void_p(int(hip_stream))))

@@ -241,6 +241,51 @@ def test_encode_slice_vs_oracle_hard_content(kind, R, num_ref, qp):
             assert np.array_equal(a, b.astype(np.uint8)), (kind, n, "reconstruction after the loop filter")
 
 
+def test_sequences_side_by_side_on_their_own_streams():
+    """Three contexts, each on its own HIP stream with a share of the chip (jmhip_set_pipeline_workgroups), their slices launched without waiting
+    for each other: every sequence's records and reconstruction equal what it produces alone with the default width.  (With one workgroup a
+    slice still completes: tickets are drawn only by running workgroups.)"""
+    import torch
+    W, H, R = 208, 160, 16
+    clips = [synthetic_clip(W, H, 3, 20 + k) for k in range(3)]
+    alone = []
+    for k in range(3):
+        enc = DevSeqEncoder(W, H, 28, R, 1, LAMBDAS, 0)
+        alone.append([enc.encode(raw, W, H) for raw in clips[k]])
+        enc.J.close()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    encs = [DevSeqEncoder(W, H, 28, R, 1, LAMBDAS, 0) for _ in range(3)]
+    for e, st, wg in zip(encs, streams, (1, 7, 40)):
+        e.J.set_stream(st.cuda_stream)
+        e.J.set_pipeline_workgroups(wg)
+    L = encs[0].L
+    nmb = (W // 16) * (H // 16)
+    for n in range(3):
+        prms = []
+        for k, e in enumerate(encs):                       # everything of picture n queued on every stream before anything is read back
+            st = 2 if n == 0 else 0
+            e.J.set_current_frame(clips[k][n], W, H)
+            cfg = pyjmo.mbenc_cfg(W, H, st, 0, nmb, 28, R, min(n, 1), *LAMBDAS[st])
+            prm = slice_params(L, cfg, 0, [r[0] for r in e.refs[:min(n, 1)]], [r[1] for r in e.refs[:min(n, 1)]], 0)
+            e.J.encode_slice_dev(prm)
+            prms.append(prm)
+        for k, e in enumerate(encs):
+            e.J.synchronize()
+            recs = e.J.encode_slice(prms[k])               # the same launch once more, blocking: the records (the first launch's are device-resident only)
+            want = alone[k][n][0]
+            assert recs.tobytes() == want.tobytes(), (k, n)
+            e.J.deblock_picture_dev(1)
+            post = e.J.get_recon()
+            for a, b in zip(post, alone[k][n][2]):
+                assert np.array_equal(a, b), (k, n)
+            slot = n & 1
+            e.J.reference_from_recon(slot)
+            e.J.synchronize()
+            e.refs = [(slot, n)]
+    for e in encs:
+        e.J.close()
+
+
 def test_streamed_records_equal_the_blocking_call():
     """jmhip_encode_slice_begin / jmhip_slice_record / jmhip_encode_slice_end (what the adapter uses: JM's entropy coder reads each record in raster
     order while the device is still encoding) hands over the same records as jmhip_encode_slice, picture after picture, with mid-row slices."""
