@@ -140,6 +140,16 @@ extern int __vfprintf_chk(FILE *, int, const char *, va_list);
 int __wrap_putc(int c, FILE *f) { return f == null_sink ? c : __real_putc(c, f); }
 int __wrap_fputc(int c, FILE *f) { return f == null_sink ? c : __real_fputc(c, f); }
 int __wrap_fflush(FILE *f) { return (f && f == null_sink) ? 0 : __real_fflush(f); }
+int __wrap_fprintf(FILE *f, const char *fmt, ...)             /* a build without _FORTIFY_SOURCE calls fprintf itself */
+{
+  va_list ap;
+  int r;
+  if (f == null_sink) return 0;
+  va_start(ap, fmt);
+  r = vfprintf(f, fmt, ap);
+  va_end(ap);
+  return r;
+}
 int __wrap___fprintf_chk(FILE *f, int flag, const char *fmt, ...)
 {
   va_list ap;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void k_deblock_diag(DbArgs A)
         if (alpha | beta) {
           const int bS = S[lane >> 2];
           uint8_t *s = dir == 0 ? &s_y[(lane + 4) * LP + edge * 4 + 4] : &s_y[(edge * 4 + 4) * LP + lane + 4];
-          luma_line(s, dir == 0 ? 1 : LP, bS, alpha, beta, c_tc0[iA][bS > 3 ? 3 : bS]);
+          filter_luma_line(s, dir == 0 ? 1 : LP, bS, alpha, beta, c_tc0[iA][bS > 3 ? 3 : bS]);
         }
       }
       if (fmt == 1 || fmt == 2) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_deblock_diag(DbArgs A)
           if (alpha | beta) {
             const int bS = S[pelnum == 8 ? (k >> 1) : (k >> 2)];
             uint8_t *s = dir == 0 ? &s_c[uv][(k + 2) * CP + ecr + 2] : &s_c[uv][(ecr + 2) * CP + k + 2];
-            chroma_line(s, dir == 0 ? 1 : CP, bS, alpha, beta, c_tc0[iA][bS > 3 ? 3 : bS]);
+            filter_chroma_line(s, dir == 0 ? 1 : CP, bS, alpha, beta, c_tc0[iA][bS > 3 ? 3 : bS]);
           }
         }
       }

@@ -29,60 +29,58 @@ static __device__ __forceinline__ int cmp_mv(const int16_t a[2], const int16_t b
 #define LP 24
 #define CP 12
 
-static __device__ void luma_line(uint8_t *q0p, int st, int bS, int alpha, int beta, int c0)
+// One line of samples across an edge, H.264 8.7.2.3 / 8.7.2.4 in the standard's own notation (p3 p2 p1 p0 | q0 q1 q2 q3), used by the
+// one-launch-per-diagonal fallback (k_deblock_diag: planes whose alignment the band kernels cannot take).  All eight samples are read, the six
+// results are formed as selects and stored where they differ -- the same arithmetic as the band kernels' filters (deblock_rows.hip), one line at a time.
+static __device__ void filter_luma_line(uint8_t *e, int st, int bS, int alpha, int beta, int tc0)
 {
-  const int L0 = q0p[-st], R0 = q0p[0];
-  if (bS == 4) {
-    if (iabs_(R0 - L0) < alpha) {
-      const int R1 = q0p[st], L1 = q0p[-2 * st];
-      if (iabs_(R0 - R1) < beta && iabs_(L0 - L1) < beta) {
-        const int R2 = q0p[2 * st], L2 = q0p[-3 * st], RL0 = L0 + R0;
-        const int small_gap = iabs_(R0 - L0) < ((alpha >> 2) + 2);
-        const int aq = (iabs_(R0 - R2) < beta) & small_gap, ap = (iabs_(L0 - L2) < beta) & small_gap;
-        if (ap) {
-          const int L3 = q0p[-4 * st];
-          q0p[-st]     = (uint8_t)((R1 + ((L1 + RL0) << 1) + L2 + 4) >> 3);
-          q0p[-2 * st] = (uint8_t)((L2 + L1 + RL0 + 2) >> 2);
-          q0p[-3 * st] = (uint8_t)((((L3 + L2) << 1) + L2 + L1 + RL0 + 4) >> 3);
-        } else q0p[-st] = (uint8_t)(((L1 << 1) + L0 + R1 + 2) >> 2);
-        if (aq) {
-          const int R3 = q0p[3 * st];
-          q0p[0]      = (uint8_t)((L1 + ((R1 + RL0) << 1) + R2 + 4) >> 3);
-          q0p[st]     = (uint8_t)((R2 + R0 + L0 + R1 + 2) >> 2);
-          q0p[2 * st] = (uint8_t)((((R3 + R2) << 1) + R2 + R1 + RL0 + 4) >> 3);
-        } else q0p[0] = (uint8_t)(((R1 << 1) + R0 + L1 + 2) >> 2);
-      }
-    }
-  } else if (bS != 0) {
-    const int diff = R0 - L0;
-    if (iabs_(diff) < alpha) {
-      const int R1 = q0p[st], L1 = q0p[-2 * st];
-      if (iabs_(R0 - R1) < beta && iabs_(L0 - L1) < beta) {
-        const int RL0 = (L0 + R0 + 1) >> 1, R2 = q0p[2 * st], L2 = q0p[-3 * st];
-        const int aq = iabs_(R0 - R2) < beta, ap = iabs_(L0 - L2) < beta;
-        const int tc = c0 + ap + aq;
-        const int dif = clip3(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
-        if (ap) q0p[-2 * st] = (uint8_t)(L1 + clip3(-c0, c0, (L2 + RL0 - (L1 << 1)) >> 1));
-        if (dif != 0) { q0p[-st] = (uint8_t)clip3(0, 255, L0 + dif); q0p[0] = (uint8_t)clip3(0, 255, R0 - dif); }
-        if (aq) q0p[st] = (uint8_t)(R1 + clip3(-c0, c0, (R2 + RL0 - (R1 << 1)) >> 1));
-      }
-    }
+  if (bS == 0) return;
+  int p[4], q[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { p[k] = e[-(k + 1) * st]; q[k] = e[k * st]; }
+  const int d0 = q[0] - p[0];
+  if (!(iabs_(d0) < alpha && iabs_(p[1] - p[0]) < beta && iabs_(q[1] - q[0]) < beta)) return;        // filterSamplesFlag (8-468)
+  const bool ap = iabs_(p[2] - p[0]) < beta, aq = iabs_(q[2] - q[0]) < beta;
+  int np[3] = {p[0], p[1], p[2]}, nq[3] = {q[0], q[1], q[2]};
+  if (bS < 4) {                                                 // 8.7.2.3
+    const int tc = tc0 + (int)ap + (int)aq;
+    const int delta = clip3(-tc, tc, ((d0 << 2) + (p[1] - q[1]) + 4) >> 3);
+    const int mid = (p[0] + q[0] + 1) >> 1;
+    np[0] = clip3(0, 255, p[0] + delta); nq[0] = clip3(0, 255, q[0] - delta);
+    if (ap) np[1] = p[1] + clip3(-tc0, tc0, (p[2] + mid - (p[1] << 1)) >> 1);
+    if (aq) nq[1] = q[1] + clip3(-tc0, tc0, (q[2] + mid - (q[1] << 1)) >> 1);
+  } else {                                                      // 8.7.2.4
+    const bool flat = iabs_(d0) < ((alpha >> 2) + 2);
+    const int s = p[0] + q[0];
+    if (ap && flat) {
+      np[0] = (p[2] + 2 * p[1] + 2 * s + q[1] + 4) >> 3;
+      np[1] = (p[2] + p[1] + s + 2) >> 2;
+      np[2] = (2 * p[3] + 3 * p[2] + p[1] + s + 4) >> 3;
+    } else np[0] = (2 * p[1] + p[0] + q[1] + 2) >> 2;
+    if (aq && flat) {
+      nq[0] = (q[2] + 2 * q[1] + 2 * s + p[1] + 4) >> 3;
+      nq[1] = (q[2] + q[1] + s + 2) >> 2;
+      nq[2] = (2 * q[3] + 3 * q[2] + q[1] + s + 4) >> 3;
+    } else nq[0] = (2 * q[1] + q[0] + p[1] + 2) >> 2;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (np[k] != p[k]) e[-(k + 1) * st] = (uint8_t)np[k];
+    if (nq[k] != q[k]) e[k * st] = (uint8_t)nq[k];
   }
 }
 
-static __device__ void chroma_line(uint8_t *q0p, int st, int bS, int alpha, int beta, int c0)
+static __device__ void filter_chroma_line(uint8_t *e, int st, int bS, int alpha, int beta, int tc0)
 {
-  const int L0 = q0p[-st], R0 = q0p[0], diff = R0 - L0;
-  if (bS == 0 || iabs_(diff) >= alpha) return;
-  const int R1 = q0p[st], L1 = q0p[-2 * st];
-  if (iabs_(R0 - R1) >= beta || iabs_(L0 - L1) >= beta) return;
-  if (bS == 4) {
-    q0p[-st] = (uint8_t)(((L1 << 1) + L0 + R1 + 2) >> 2);
-    q0p[0]   = (uint8_t)(((R1 << 1) + R0 + L1 + 2) >> 2);
-  } else {
-    const int tc = c0 + 1, dif = clip3(-tc, tc, ((diff << 2) + (L1 - R1) + 4) >> 3);
-    if (dif != 0) { q0p[-st] = (uint8_t)clip3(0, 255, L0 + dif); q0p[0] = (uint8_t)clip3(0, 255, R0 - dif); }
-  }
+  if (bS == 0) return;
+  const int p0 = e[-st], p1 = e[-2 * st], q0 = e[0], q1 = e[st], d0 = q0 - p0;
+  if (!(iabs_(d0) < alpha && iabs_(p1 - p0) < beta && iabs_(q1 - q0) < beta)) return;
+  int n0, m0;
+  if (bS < 4) {
+    const int tc = tc0 + 1, delta = clip3(-tc, tc, ((d0 << 2) + (p1 - q1) + 4) >> 3);
+    n0 = clip3(0, 255, p0 + delta); m0 = clip3(0, 255, q0 - delta);
+  } else { n0 = (2 * p1 + p0 + q1 + 2) >> 2; m0 = (2 * q1 + q0 + p1 + 2) >> 2; }
+  e[-st] = (uint8_t)n0; e[0] = (uint8_t)m0;
 }
 
 // boundary strength of one 4-sample segment (GetStrengthVer/Hor); dir 0 = vertical edge
