@@ -577,7 +577,8 @@ typedef struct {
   int32_t df_disable_idc, df_alpha_c0, df_beta;   /* Macroblock.DFDisableIdc, DFAlphaC0Offset, DFBetaOffset of the slice */
   int32_t num_slices;           /* 0 or 1: one slice.  n > 1: the call covers n consecutive slices of num_mb macroblocks each (the last one ends with the
                                    picture), same parameters, slice_nr counting up -- SliceMode 1 pictures: the slices' wavefronts run side by side */
-  int32_t reserved_[4];
+  int32_t symbol_mode;          /* currSlice->symbol_mode: 0 = CAVLC (levels clamped to CAVLC_LEVEL_LIMIT = 2063: quant4x4_normal.c:84, :160, :233, quantChroma_normal.c:69), 1 = CABAC (no clamp) */
+  int32_t reserved_[3];
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);

@@ -1264,7 +1264,6 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->slice_mode != NO_SLICES && p->slice_mode != FIXED_MB) why = "SliceMode > 1";
     else if (p->num_slice_groups_minus1 != 0) why = "FMO";
     else if (p->UseConstrainedIntraPred) why = "UseConstrainedIntraPred";
-    else if (p->symbol_mode != CAVLC) why = "CABAC";
     else if (p->RestrictRef || p->UseRDOQuant || p->ChromaMEEnable) why = "RestrictRefFrames / UseRDOQuant / ChromaMEEnable";
     else if (p->MEErrorMetric[F_PEL] != ERROR_SAD || p->MEErrorMetric[H_PEL] != ERROR_SATD || p->MEErrorMetric[Q_PEL] != ERROR_SATD || p->ModeDecisionMetric != ERROR_SATD) why = "distortion metrics other than SAD / SATD / SATD / SATD";
     else if (p->disthres != 0) why = "DisableThresholding";
@@ -1351,6 +1350,7 @@ static void pipe_run_slice(Macroblock *currMB)
           prm.q_chroma[uv][intra][j * 4 + i].OffsetComp = q->OffsetComp; prm.q_chroma[uv][intra][j * 4 + i].ScaleComp = q->ScaleComp; prm.q_chroma[uv][intra][j * 4 + i].InvScaleComp = q->InvScaleComp;
         }
       }
+  prm.symbol_mode = currSlice->symbol_mode == CABAC;        /* the entropy coder stays JM's; the quantiser clamps levels for CAVLC only */
   prm.df_disable_idc = currMB->DFDisableIdc; prm.df_alpha_c0 = currMB->DFAlphaC0Offset; prm.df_beta = currMB->DFBetaOffset;
   if (currMB->qp_scaled[0] != currMB->qp) { fprintf(stderr, "jmhip adapter: macroblock pipeline: luma QP scale\n"); exit(70); }
   /* SliceMode 1: every slice of the picture has the same parameters (no rate control here), so all of them are launched with the first one and

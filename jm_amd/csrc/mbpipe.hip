@@ -762,6 +762,9 @@ __device__ __forceinline__ int list0_cost(const Shared &S, const jmhip_slice_par
   return bm;
 }
 
+// the largest level the entropy coder takes: CAVLC_LEVEL_LIMIT with CAVLC (quant4x4_normal.c:84), none with CABAC
+__device__ __forceinline__ int lev_max_of(const jmhip_slice_params &P) { return P.symbol_mode == 0 ? 2063 : 0x7fffffff; }
+
 // ------------------------------------------------------------------ transform / quantisation of one 4x4 block in registers
 __device__ __forceinline__ void fwd4_(int &a, int &b, int &c, int &d) { int e0 = a + d, e1 = b + c, o0 = b - c, o1 = a - d; a = e0 + e1; b = (o1 << 1) + o0; c = e0 - e1; d = o1 - (o0 << 1); }
 __device__ __forceinline__ void inv4_(int &a, int &b, int &c, int &d) { int e0 = a + c, e1 = a - c, o0 = (b >> 1) - d, o1 = b + (d >> 1); a = e0 + o1; b = e1 + o0; c = e1 - o0; d = e0 - o1; }
@@ -782,7 +785,7 @@ __device__ __forceinline__ void inverse4x4(int (&m)[16])
 
 // quant_4x4_normal / quant_ac4x4_normal (quant4x4_normal.c:39 / :117) on the transformed block m (raster); first = 0 or 1 (AC only).
 // lev[16]: levels at their scan positions; m receives the dequantised coefficients.  Returns nonzero; cost accumulates the coefficient cost.
-__device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int qp_per, int first, int16_t *lev, int &cost)
+__device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int qp_per, int first, int16_t *lev, int &cost, int lev_max)
 {
   const int q_bits = 15 + qp_per;
   int run = 0, nz = 0;
@@ -798,7 +801,7 @@ __device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int
     if (cf != 0) {
       l = (iabs_(cf) * qs[idx] + qo[idx]) >> q_bits;
       if (l != 0) {
-        l = min(l, 2063);                                      // CAVLC_LEVEL_LIMIT
+        l = min(l, lev_max);                                   // CAVLC_LEVEL_LIMIT, or none (CABAC)
         cost += l > 1 ? 999999 : (run == 0 ? 3 : (run <= 2 ? 2 : (run <= 5 ? 1 : 0)));       // COEFF_COST4x4[0][run], block.c:72
         l = cf < 0 ? -l : l;
         m[idx] = (((l * qi[idx]) << qp_per) + 8) >> 4;
@@ -810,13 +813,13 @@ __device__ __forceinline__ int quant4x4(int (&m)[16], const jmhip_qparam *q, int
   return nz;
 }
 // residual_transform_quant_luma_4x4 (block.c:661-725): o, p = source and prediction rows; rec = reconstructed rows
-__device__ __forceinline__ int tq_luma4(const u32 (&o)[4], const u32 (&p)[4], const jmhip_qparam *q, int qp_per, int16_t *lev, int &cost, u32 (&rec)[4])
+__device__ __forceinline__ int tq_luma4(const u32 (&o)[4], const u32 (&p)[4], const jmhip_qparam *q, int qp_per, int16_t *lev, int &cost, u32 (&rec)[4], int lev_max)
 {
   int m[16], pr[16], any = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) { pr[k] = (p[k >> 2] >> (8 * (k & 3))) & 255; m[k] = (int)((o[k >> 2] >> (8 * (k & 3))) & 255) - pr[k]; any |= m[k]; }
   int nz = 0;
-  if (any) { forward4x4(m); nz = quant4x4(m, q, qp_per, 0, lev, cost); }
+  if (any) { forward4x4(m); nz = quant4x4(m, q, qp_per, 0, lev, cost, lev_max); }
   else {
 #pragma unroll
     for (int k = 0; k < 16; k++) lev[k] = 0;
@@ -840,7 +843,7 @@ __device__ __forceinline__ int tq_luma4(const u32 (&o)[4], const u32 (&p)[4], co
 // The same for a block that EVERY lane of the wave holds alike (the Intra4x4 chain: one block after the other): the sixteen coefficients are
 // quantised by sixteen lanes at once (lane = scan position) instead of a sixteen-step chain in every lane; the dequantised coefficients come
 // back to all lanes by wave shuffles.  lev: sixteen int16 in LDS (written by the sixteen lanes).  No coefficient cost (Intra4x4 does not use it).
-__device__ __forceinline__ int tq_luma4_wave(const u32 (&o)[4], const u32 (&p)[4], const jmhip_qparam *q, int qp_per, int lane, int16_t *lev, u32 (&rec)[4])
+__device__ __forceinline__ int tq_luma4_wave(const u32 (&o)[4], const u32 (&p)[4], const jmhip_qparam *q, int qp_per, int lane, int16_t *lev, u32 (&rec)[4], int lev_max)
 {
   constexpr int ZZ[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
   const int k = lane & 15;
@@ -856,7 +859,7 @@ __device__ __forceinline__ int tq_luma4_wave(const u32 (&o)[4], const u32 (&p)[4
 #pragma unroll
   for (int c = 0; c < 16; c++) cf = (c == zz) ? m[c] : cf;
   int l = (iabs_(cf) * qk.ScaleComp + qk.OffsetComp) >> (15 + qp_per);
-  l = min(l, 2063);                                            // CAVLC_LEVEL_LIMIT
+  l = min(l, lev_max);                                         // CAVLC_LEVEL_LIMIT, or none (CABAC)
   l = cf < 0 ? -l : l;
   const int dq = (((l * qk.InvScaleComp) << qp_per) + 8) >> 4;
   if (lane < 16) lev[k] = (int16_t)l;

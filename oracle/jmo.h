@@ -259,6 +259,7 @@ typedef struct {
   int32_t q_offset[2];          /* quantiser offset (of 2048) of inter / intra blocks in this slice type: 342 / 682 in I, 342 / 342 in P slices (q_offsets.c:633-711 with the default lists) */
   int32_t start_qp;             /* p_Vid->start_me_refinement_qp (mv_search.c:446); start_me_refinement_hp must be 0 */
   int32_t refbits[JMO_MAX_REF]; /* p_Vid->refbits, mv_search.c:376-385 */
+  int32_t cabac;                /* currSlice->symbol_mode == CABAC: levels are not clamped to CAVLC_LEVEL_LIMIT (quant4x4_normal.c:84) */
 } jmo_mbenc_cfg;
 
 /* What encode_one_macroblock_low leaves behind for write_macroblock (lencod/src/macroblock.c:2810), one record per macroblock. */

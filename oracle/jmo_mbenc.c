@@ -284,7 +284,7 @@ static int tq4x4(const enc *e, const jmo_pel *orig, int opitch, const jmo_pel *p
     if (any) {
       jmo_qparams_4x4(e->c->qp, intra, e->c->q_offset[intra ? 1 : 0], q);
       jmo_forward4x4(res, tb);
-      nz = jmo_quant_4x4_normal(tb, q, e->c->qp / 6, 1, &JMO_SNGL_SCAN[0][0], JMO_COEFF_COST4x4[0], level, run, coeff_cost);
+      nz = jmo_quant_4x4_normal(tb, q, e->c->qp / 6, !e->c->cabac, &JMO_SNGL_SCAN[0][0], JMO_COEFF_COST4x4[0], level, run, coeff_cost);
     }
     if (nz) {
       jmo_inverse4x4(tb, rr);
@@ -493,7 +493,7 @@ static void chroma_mb(enc *e, jmo_mb_record *o, int intra, int mode, const int8_
     for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) orig[j * 8 + i] = e->cur[1 + uv][(cy + j) * CW + cx + i];
     for (k = 0; k < 8; k++) ac_level[k][0] = 0;
     dc_level[0] = 0;
-    cr_cbp = jmo_rtq_chroma(1, uv, cr_cbp, &cbp_blk, q_ac, &q_dc, c->qpc / 6, c->qpc / 6, 1, 0, 0, 255, orig, pred, rec, dc_level, dc_run, ac_level, ac_run, fadj);
+    cr_cbp = jmo_rtq_chroma(1, uv, cr_cbp, &cbp_blk, q_ac, &q_dc, c->qpc / 6, c->qpc / 6, !c->cabac, 0, 0, 255, orig, pred, rec, dc_level, dc_run, ac_level, ac_run, fadj);
     for (pos = 0, k = 0; k < 4 && dc_level[k] != 0; k++) { pos += dc_run[k]; o->chroma_dc[uv][pos++] = (int16_t)dc_level[k]; }
     for (b4 = 0; b4 < 4; b4++)
       for (pos = 1, k = 0; k < 15 && ac_level[b4][k] != 0; k++) { pos += ac_run[b4][k]; o->chroma_ac[uv][b4][pos++] = (int16_t)ac_level[b4][k]; }
@@ -640,7 +640,7 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
       best_mode = 10; min_rdcost = rd_cost;
       jmo_qparams_4x4(c->qp, 1, c->q_offset[1], q);
       dc_level[0] = 0;
-      o->cbp = (int16_t)jmo_rtq_luma_16x16(e->orig, pred4[i16], q, c->qp / 6, 1, 0, 0, 255, dc_level, dc_run, ac_level, ac_run, rec, fadj);
+      o->cbp = (int16_t)jmo_rtq_luma_16x16(e->orig, pred4[i16], q, c->qp / 6, !c->cabac, 0, 0, 255, dc_level, dc_run, ac_level, ac_run, rec, fadj);
       memset(o->luma, 0, sizeof o->luma);
       for (pos = 0, k = 0; k < 16 && dc_level[k] != 0; k++) { pos += dc_run[k]; o->luma_dc[pos++] = (int16_t)dc_level[k]; }
       for (b = 0; b < 16; b++)

@@ -440,7 +440,7 @@ class MbEncCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("slice_type", C.c_int32), ("first_mb", C.c_int32), ("num_mb", C.c_int32),
                 ("qp", C.c_int32), ("qpc", C.c_int32), ("search_range", C.c_int32), ("num_ref", C.c_int32), ("lambda_mf", C.c_int32 * 3),
                 ("lambda_mdfp", C.c_int32), ("max_mvd", C.c_int32), ("mv_limit", C.c_int32 * 4), ("inter_valid", C.c_int32 * 8),
-                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF)]
+                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32)]
 
 
 MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("pad0", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
@@ -452,8 +452,9 @@ assert MB_RECORD.itemsize == 944
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
-              subpel=1):
+              subpel=1, cabac=0):
     c = MbEncCfg()
+    c.cabac = cabac
     c.width, c.height, c.slice_type, c.first_mb, c.num_mb = width, height, slice_type, first_mb, num_mb
     c.qp = qp
     c.qpc = qp if qp < 30 else [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39][qp - 30]

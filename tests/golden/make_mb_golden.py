@@ -33,6 +33,10 @@ CASES = {
     "q4r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", SliceMode="1", SliceArgument="33"), (176, 144), 3, False),
     "q4s": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", SliceMode="1", SliceArgument="40", NumberReferenceFrames="2", DFParametersFlag="1",
                  DFDisableRefISlice="2", DFDisableNRefISlice="2", DFDisableRefPSlice="2", DFDisableNRefPSlice="2"), (176, 144), 3, False),
+    # CABAC (Main profile): the quantiser no longer clamps levels to CAVLC_LEVEL_LIMIT; QP 0 is where levels beyond 2063 occur (Intra16x16 DC)
+    "q1c": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", SymbolMode="1", ProfileIDC="77"), (176, 144), 3, False),
+    "q0c": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", SymbolMode="1", ProfileIDC="77", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
+    "q0r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
     "g2r": (dict(RDO_OFF, **SYN1080), (1920, 1080), 2, True),                                          # SURVEY 8c G2r = BASELINE configs[1], RDO off
 }
 

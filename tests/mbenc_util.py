@@ -43,10 +43,11 @@ def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_
 class SeqEncoder:
     """IPPP with num_ref sliding-window references, RDOptimization = 0, AdaptiveRounding = 0 (the scope of jmo_mbenc.c)."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0):
         """lambdas[slice_type] = (lambda_mf[3], lambda_mdfp): JM's own tables (double arithmetic, never recomputed)."""
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
+        self.cabac = cabac     # SymbolMode: the quantiser clamps levels for CAVLC only
         self.refs = []         # most recent first: (RefPic, (u, v), picture id)
         self.npic = 0
 
@@ -64,7 +65,7 @@ class SeqEncoder:
         qpc = None
         for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv)
+            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac)
             qpc = cfg.qpc
             res = pyjmo.encode_slice(cfg, cur16, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], pic, debug=debug)
             if debug:

@@ -28,6 +28,7 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0):
     for k in ("slice_type", "first_mb", "num_mb", "qp", "qpc", "search_range", "num_ref", "lambda_mdfp", "max_mvd", "intra4_valid", "intra16_valid", "subpel", "start_qp"):
         p[k] = getattr(cfg, k)
     p["slice_nr"] = slice_nr
+    p["symbol_mode"] = cfg.cabac
     p["lambda_mf"] = list(cfg.lambda_mf)
     p["mv_limit"] = list(cfg.mv_limit)
     p["inter_valid"] = list(cfg.inter_valid)
@@ -46,7 +47,8 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0):
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0):
+        self.cabac = cabac
         import jm_amd.lib as L
         self.together = together      # all slices of a picture in one launch (num_slices), as the adapter does for SliceMode 1
         self.L = L
@@ -66,7 +68,7 @@ class DevSeqEncoder:
         slices = mbenc_util.slices_of(nmb, self.slice_mbs)
         for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv)
+            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc)
             if timing is not None:
                 J.enable_timing(True)
@@ -103,7 +105,7 @@ def load_case(tag):
     lam = {2: ([int(x) for x in z["lambda_i"][:3]], int(z["lambda_i"][3])), 0: ([int(x) for x in z["lambda_p"][:3]], int(z["lambda_p"][3]))}
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]],
-                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"])
+                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)))
 
 
 def clip_bytes(tag, c):
@@ -121,12 +123,12 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks)."""
     c = load_case(tag)
-    enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
+    enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     data = clip_bytes(tag, c)
     fs = c["sw"] * c["sh"] * 3 // 2
@@ -209,29 +211,36 @@ def hard_clip(kind, W, H, nfr, seed):
             y = 40 + 170 * (((xs + n) // 2) % 2) + 20 * (((ys + 2 * n) // 8) % 2)      # period 4 across, 16 down: whole families of equal SADs
         elif kind == "still":
             y = still
+        elif kind == "chroma_step":
+            y = still                                                       # luma predicts itself; the chroma planes jump by 240 (below)
         elif kind == "ramp":
             y = (3 * xs + 2 * ys + 7 * n) % 256                             # a gradient: SAD grows linearly with the displacement
         y = np.clip(y, 0, 255).astype(np.uint8)
         yd = y.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
         u = np.clip(np.rint(128 + 0.25 * (yd - 128)), 0, 255).astype(np.uint8)
         v = np.clip(np.rint(128 - 0.25 * (yd - 128)), 0, 255).astype(np.uint8)
+        if kind == "chroma_step":                                          # chroma DC levels beyond CAVLC's 2063 at QP 0: clamped (CAVLC) or not (CABAC)
+            u[:] = 250 if n == 0 else 10
+            v[:] = 250 if n == 0 else 10
         frames.append(np.concatenate([y.ravel(), u.ravel(), v.ravel()]))
     return frames
 
 
 @pytest.mark.parametrize("kind,R,num_ref,qp", [("flat", 32, 1, 44), ("flat", 16, 2, 28), ("noise", 32, 1, 12), ("noise", 16, 2, 40), ("stripes", 32, 2, 28),
-                                               ("stripes", 8, 1, 20), ("still", 32, 1, 36), ("still", 16, 2, 16), ("ramp", 32, 1, 28), ("ramp", 16, 1, 48)])
+                                               ("stripes", 8, 1, 20), ("still", 32, 1, 36), ("still", 16, 2, 16), ("ramp", 32, 1, 28), ("ramp", 16, 1, 48),
+                                               ("chroma_step", 16, 1, 0), ("chroma_step", 16, 1, -1), ("noise", 16, 1, -1)])   # qp -1: QP 0 with CABAC
 def test_encode_slice_vs_oracle_hard_content(kind, R, num_ref, qp):
     """The search skips candidates by JM's own cost bound (rows near the predictor, then only what the best cost so far leaves: mbpipe.hip fs_wave);
     the result must stay JM's whatever the content does to that bound: pictures where every candidate ties (flat, periodic stripes: the spiral
     order decides), where nothing matches (noise: the bound excludes nothing), where the distortion at the predictor is zero (a still picture:
     the bound excludes almost everything), and a gradient; lambda from very small to very large."""
     W, H = 96, 80
+    cabac, qp = int(qp < 0), max(qp, 0)
     f = max(1, int(192 * 2 ** ((qp - 28) / 6)))
     lam = {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
     frames = hard_clip(kind, W, H, 3 if num_ref == 1 else 4, 11)
-    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, 0)
-    ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, 0)
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, 0, cabac=cabac)
+    ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, 0, cabac=cabac)
     for n, raw in enumerate(frames):
         recs, pre, post = dev.encode(raw, W, H)
         orecs, _, opre, opost = ora.encode(pyjmo.load_frame(raw, W, H, W, H, 1))
@@ -239,6 +248,9 @@ def test_encode_slice_vs_oracle_hard_content(kind, R, num_ref, qp):
         assert d is None, (kind, n, d)
         for a, b in zip(post, opost):
             assert np.array_equal(a, b.astype(np.uint8)), (kind, n, "reconstruction after the loop filter")
+        if kind == "chroma_step" and n == 1:                               # the case is what it claims to be
+            big = int(np.abs(recs["chroma_dc"].astype(int)).max())
+            assert big == 2063 if not cabac else big > 2063, (kind, n, big, cabac)
 
 
 def test_sequences_side_by_side_on_their_own_streams():
