@@ -5,7 +5,7 @@ import collections, csv, json, shutil, sys
 O, tag, title = sys.argv[1], sys.argv[2], sys.argv[3]
 rows = list(csv.DictReader(open(f"{O}/stats/t_kernel_stats.csv")))
 out = [f"# {title} -- rocprofv3 --kernel-trace --stats", "",
-       "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end` (the I picture that makes the "
+       "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --streams 0` (the I picture that makes the "
        "reference, 12 steps incl. warm-up, 5 + 1 further launches for the per-launch time and the record check), 1x MI355X, configs[1]", "",
        "| kernel | calls | total us | avg us | % |", "|---|---|---|---|---|"]
 for r in rows:

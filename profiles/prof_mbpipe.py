@@ -53,6 +53,8 @@ for n in range(2):
         print("  first 4x4 search, the sliding part in detail: first rows %.2f, their minimum + the sub-pel fetch started %.2f, what remains decided %.2f, steps 1 %.2f, B1 + keys widened %.2f; step 2 %.2f, wave minimum %.2f us" % tuple(
             np.median(us(a, b)) for a, b in ((24, 27), (27, 28), (28, 29), (29, 30), (30, 7), (7, 23), (23, 20))))
     if n == 1 and MODE in ("1", "10"):
+        d = us(18, 22)
+        print("  first 4x4 search, whole: percentiles 10/50/90/99/max " + " ".join("%.2f" % np.percentile(d, q) for q in (10, 50, 90, 99, 100)) + "; its integer part: " + " ".join("%.2f" % np.percentile(us(19, 20), q) for q in (10, 50, 90, 99, 100)))
         print("  first 4x4 search of the macroblock (wave 3): predictor %.2f, integer search %.2f, half-pel stage %.2f, quarter-pel stage + clip %.2f us (medians)" % tuple(
             np.median(us(a, b)) for a, b in ((18, 19), (19, 20), (20, 21), (21, 22))))
     if n == 1:                                                 # the hand-over: from the last neighbour's flag store to this macroblock's start
