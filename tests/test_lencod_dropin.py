@@ -167,6 +167,36 @@ def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total
 
 
 @pytest.mark.gpu
+def test_lencod_macroblock_pipeline_leaves_a_real_trace_file_alone(tmp_path):
+    """The adapter drops JM's syntax-element trace inside the process only when the configuration sends it to /dev/null (part nulltrace).  With a
+    real TraceFile the drop-in encoder writes the same trace, byte for byte, as CPU JM (and the same bitstream)."""
+    import numpy as np
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    ref_exe = os.path.join(os.path.dirname(EXE), "lencod.exe")
+    z = np.load(os.path.join(G, "mb_low_q1r.npz"))
+    ov = dict(s.split("=") for s in z["overrides"])
+    ov["FramesToBeEncoded"] = "2"
+    sums = {}
+    for name, exe in (("hip", EXE), ("cpu", ref_exe)):
+        d = os.path.join(str(tmp_path), name)
+        os.makedirs(d)
+        for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
+            shutil.copyfile(os.path.join(G, f), os.path.join(d, f))
+        args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+        for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="trace.txt").items():
+            args += ["-p", f"{k}={v}"]
+        r = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (name, r.stderr.decode(errors="replace")[-800:])
+        if name == "hip":
+            rep = pipeline_report(r.stderr.decode(errors="replace"))
+            assert rep and rep["mbs"] == 2 * 99, rep
+        assert os.path.getsize(os.path.join(d, "trace.txt")) > 100000
+        sums[name] = (md5(os.path.join(d, "trace.txt")), md5(os.path.join(d, "o.264")))
+    assert sums["hip"] == sums["cpu"], sums
+
+
+@pytest.mark.gpu
 def test_lencod_macroblock_pipeline_configs1_full_size_1080p(tmp_path):
     """BASELINE.json configs[1] with RDOptimization = 0 end to end: .264 md5 04ce4cdee722defe8c3c7c0b249eda7e, zero
     per-block calls, and the P picture's wall time as lencod itself prints it."""
