@@ -78,6 +78,7 @@ struct Shared {
   u32 cur_y[64];                             // the source macroblock, 16 rows of 4 dwords
   u32 cur_c[2][16];                          // U, V: 8 rows of 2 dwords
   u64 nb[4][EDGE_WORDS];                     // edge records of A (left), B (up), C (up-right), D (up-left)
+  u32 ptab[8][16];                           // mv_predictor's neighbour table: per (block type, 4x4 position of the block) four codes A, B, C, D (once per launch)
   int avail[4];
   int ticket, addr, err;
   int allmv[JMHIP_MB_MAX_REF][8][16];        // currSlice->all_mv[LIST_0][ref][mode][4x4 raster], packed
@@ -177,26 +178,48 @@ __device__ __forceinline__ void mvinfo_get(const u64 *p, bool ok, int &mv, int &
   mv = ok ? rfl((int)(u32)w) : 0; ref = ok ? rfl((int)(int8_t)(w >> 32)) : -1;
 }
 
-// get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325); the four candidates are read at once
-__device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, int ref, int mb_x, int mb_y, int bsx, int bsy)
+// Where mv_predictor finds a block's neighbour: 0..15 = inside the macroblock (4x4 raster index in the chain's view), 16 + 8 n + k = word 9 + k of
+// neighbour n's edge record, 255 = never available.  (x4, y4) in [-1, 4] relative to the macroblock, as mvinfo_ptr.
+__device__ __forceinline__ u32 nb_code(int x4, int y4)
 {
-  int mv[3], rf[3], mD, rD;
-  bool av[3], avD;
-  const u64 *pA = mvinfo_ptr(S, view, avm, (mb_x - 1) >> 2, mb_y >> 2, av[0]);
-  const u64 *pB = mvinfo_ptr(S, view, avm, mb_x >> 2, (mb_y - 1) >> 2, av[1]);
-  const u64 *pC = mvinfo_ptr(S, view, avm, (mb_x + bsx) >> 2, (mb_y - 1) >> 2, av[2]);
-  const u64 *pD = mvinfo_ptr(S, view, avm, (mb_x - 1) >> 2, (mb_y - 1) >> 2, avD);
+  if (x4 < 0) return y4 < 0 ? 16u + 8u * 3u + 3u : (y4 < 4 ? 16u + 4u + (u32)y4 : 255u);
+  if (x4 < 4) return y4 < 0 ? 16u + 8u * 1u + (u32)x4 : (y4 < 4 ? (u32)(y4 * 4 + x4) : 255u);
+  return y4 < 0 ? 16u + 8u * 2u : 255u;
+}
+// the table entry of block type bt (1..7) at (mb_x, mb_y) (samples): get_neighbors (mv_search.c:268-307) incl. the cases where C is not yet coded
+__device__ __forceinline__ u32 ptab_entry(int bt, int mb_x, int mb_y)
+{
+  const int bsx = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
+  const u32 a = nb_code((mb_x - 1) >> 2, mb_y >> 2), b = nb_code(mb_x >> 2, (mb_y - 1) >> 2), d = nb_code((mb_x - 1) >> 2, (mb_y - 1) >> 2);
+  u32 c = nb_code((mb_x + bsx) >> 2, (mb_y - 1) >> 2);
   if (mb_y > 0) {
     if (mb_x < 8) {
-      if (mb_y == 8) { if (bsx == 16) av[2] = false; }
-      else if (mb_x + bsx == 8) av[2] = false;
-    } else if (mb_x + bsx == 16) av[2] = false;
+      if (mb_y == 8) { if (bsx == 16) c = 255u; }
+      else if (mb_x + bsx == 8) c = 255u;
+    } else if (mb_x + bsx == 16) c = 255u;
   }
-  mvinfo_get(pA, av[0], mv[0], rf[0]);
-  mvinfo_get(pB, av[1], mv[1], rf[1]);
-  mvinfo_get(pC, av[2], mv[2], rf[2]);
-  mvinfo_get(pD, avD, mD, rD);
-  if (!av[2]) { mv[2] = mD; rf[2] = rD; av[2] = avD; }
+  return a | (b << 8) | (c << 16) | (d << 24);
+}
+
+// get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325): one table read, then the four
+// candidates with one LDS read (a lane each)
+__device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, int ref, int mb_x, int mb_y, int bsx, int bsy, int lane)
+{
+  const int bt = bsx == 16 ? (bsy == 16 ? 1 : 2) : (bsx == 8 ? (bsy == 16 ? 3 : (bsy == 8 ? 4 : 5)) : (bsy == 8 ? 6 : 7));
+  const u32 codes = S.ptab[bt][(mb_y >> 2) * 4 + (mb_x >> 2)];
+  const u32 c = (codes >> (8 * (lane & 3))) & 255u;
+  const bool inside = c < 16u;
+  const int n = (int)(c - 16u) >> 3;
+  const bool ok = c != 255u && (inside || ((avm >> n) & 1));
+  const u64 *p = inside ? (const u64 *)&S.mvi[view][c][0] : &S.nb[n & 3][9 + ((c - 16u) & 7u)];
+  const u64 w = *p;
+  const int mvl = ok ? (int)(u32)w : 0, rfl_ = ok ? (int)(int8_t)(w >> 32) : -1;
+  const u32 okm = (u32)__ballot(ok) & 15u;
+  int mv[3], rf[3];
+  bool av[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { mv[k] = __builtin_amdgcn_readlane(mvl, k); rf[k] = __builtin_amdgcn_readlane(rfl_, k); av[k] = (okm >> k) & 1; }
+  if (!av[2]) { mv[2] = __builtin_amdgcn_readlane(mvl, 3); rf[2] = __builtin_amdgcn_readlane(rfl_, 3); av[2] = (okm >> 3) & 1; }
   int type = 0;
   if (rf[0] == ref && rf[1] != ref && rf[2] != ref) type = 1;
   else if (rf[0] != ref && rf[1] == ref && rf[2] != ref) type = 2;
@@ -216,7 +239,7 @@ __device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, 
 }
 
 // FindSkipModeMotionVector mv_search.c:1333-1405
-__device__ __forceinline__ int skip_vector(const Shared &S, int view, int avm)
+__device__ __forceinline__ int skip_vector(const Shared &S, int view, int avm, int lane)
 {
   int mA, rA, mB, rB;
   bool a, b;
@@ -224,7 +247,7 @@ __device__ __forceinline__ int skip_vector(const Shared &S, int view, int avm)
   mvinfo_get(pA, a, mA, rA); mvinfo_get(pB, b, mB, rB);
   const bool zl = !a || (rA == 0 && mA == 0), za = !b || (rB == 0 && mB == 0);
   if (za || zl) return 0;
-  return mv_predictor(S, view, avm, 0, 0, 0, 16, 16);
+  return mv_predictor(S, view, avm, 0, 0, 0, 16, 16, lane);
 }
 
 // ------------------------------------------------------------------ integer search of one block by one wave
@@ -639,7 +662,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
                      mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
-  const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH));
+  const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH, lane));
   BS_STAMP(19);
   int cx = ((mvx(pred) + 2) >> 2) * 4, cy = ((mvy(pred) + 2) >> 2) * 4;          // mv_search.c:931-932
   int min_x = -(R << 2), max_x = R << 2, min_y = min_x, max_y = max_x;
@@ -718,7 +741,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   mv = mvpack(clampi3(P.mv_limit[0], P.mv_limit[1], mvx(mv)), clampi3(P.mv_limit[2], P.mv_limit[3], mvy(mv)));   // :981
 
   if (bt == 1 && P.slice_type == 0) {                          // the skip vector against the 16x16 result: mv_search.c:983-998, GetSkipCostMB :1257
-    const int sv = rfl(skip_vector(S, view, avm));
+    const int sv = rfl(skip_vector(S, view, avm, lane));
     if (lane == 0) S.skip_mv = sv;
     const int qx = (mbx * 64) + mvx(sv), qy = (mby * 64) + mvy(sv);
     const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);     // one origin for the 16x16 block
