@@ -311,10 +311,12 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   const int t_y = c.pqy - c.cqy, t_x = c.pqx - c.cqx;           // the predictor relative to the search centre, quarter-pel
   const int ip = clampi3(i_lo, i_hi, Rs + ((t_y + 2) >> 2));   // the row nearest the predictor
   const bool prune = BW * BH <= 64 && !c.check00 && c.lambda > 0;
-  const int a_lo = prune ? max(i_lo, ip - 2) : i_lo, a_hi = prune ? min(i_hi, ip + 2) : i_hi;
+  constexpr int NBH = BH == 4 ? 3 : 2;                          // step 0: rows within NBH of the predictor's (a block four rows high pays little for two more, and is then mostly done)
+  const int a_lo = prune ? max(i_lo, ip - NBH) : i_lo, a_hi = prune ? min(i_hi, ip + NBH) : i_hi;
   const int bx_min = mvbits(t_x - 4 * clampi3(-Rs, Rs, (t_x + 2) >> 2));       // the cheapest column's bits
   int lo1 = i_lo, hi1 = i_hi;                                  // step 1's rows, set after step 0
   bool step1 = false;
+  int d_lo2 = 0, d_hi2 = -1, d_dqx2 = -1;                      // what the decision after step 0 found (step 2 uses it as it is when step 1 read nothing)
   int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read by the sliding lanes
   u32 bound = 0xffffffffu;                                     // the best cost so far
   const float rcp_lambda = __builtin_amdgcn_rcpf((float)(c.lambda > 0 ? c.lambda : 1));
@@ -353,7 +355,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         // step 0 as straight-line code: the (at most) five candidate rows and the BH - 1 window rows below them are read at once and summed side
         // by side (independent instructions: a lone wave issues a dependent one only every ~9 cycles); rows past the last candidate lie in the
         // window's slack rows
-        constexpr int NB = 5, NR = NB + BH - 1;
+        constexpr int NB = 2 * NBH + 1, NR = NB + BH - 1;
         const u8 *p = pbase + a_lo * WP;
         u32 bb[NR][BW / 4], ytv[NB];
 #pragma unroll
@@ -467,6 +469,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         if (a_hi + 1 <= hi2) byo2 = min(byo2, mvbits(4 * (a_hi + 1 - Rs) - t_y));
         const int dqx2 = bits_reach(kq - byo2);
         const int nc2 = dqx2 < 0 ? 0 : max(0, min(2 * Rs, Rs + ((t_x + dqx2) >> 2)) - max(0, Rs + ((t_x - dqx2 + 3) >> 2)) + 1);
+        d_lo2 = lo2; d_hi2 = hi2; d_dqx2 = dqx2;
         if ((max(0, a_lo - lo2) + max(0, hi2 - a_hi)) * nc2 <= 64) { lo1 = a_lo; hi1 = a_hi; }
         else {
           // the cheapest h, one lane per choice: sliding steps of step 1 (with their BH - 1 rows of lead-in) against passes of step 2
@@ -532,14 +535,17 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     }
   }
   if (prune) {                                                 // step 2: the rows beyond the hull, one lane per candidate
-    const int kq = (int)((float)bound * rcp_lambda) + 1;
-    const int dq = bits_reach(kq - bx_min);
-    const int r_lo = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), r_hi = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
+    int r_lo = d_lo2, r_hi = d_hi2, dqx = d_dqx2;
+    if (step1) {                                               // a tighter bound since: once more
+      const int kq = (int)((float)bound * rcp_lambda) + 1;
+      const int dq = bits_reach(kq - bx_min);
+      r_lo = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)); r_hi = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
+      int byo = 1 << 20;
+      if (ev_lo - r_lo > 0) byo = min(byo, mvbits(4 * (ev_lo - 1 - Rs) - t_y));
+      if (r_hi - ev_hi > 0) byo = min(byo, mvbits(4 * (ev_hi + 1 - Rs) - t_y));
+      dqx = bits_reach(kq - byo);
+    }
     const int n_up = max(0, ev_lo - r_lo), n_dn = max(0, r_hi - ev_hi), nr = n_up + n_dn;
-    int byo = 1 << 20;
-    if (n_up) byo = min(byo, mvbits(4 * (ev_lo - 1 - Rs) - t_y));
-    if (n_dn) byo = min(byo, mvbits(4 * (ev_hi + 1 - Rs) - t_y));
-    const int dqx = bits_reach(kq - byo);
     const int cl = max(0, Rs + ((t_x - dqx + 3) >> 2)), ch = min(2 * Rs, Rs + ((t_x + dqx) >> 2));
     const int total = (dqx < 0 || ch < cl) ? 0 : nr * (ch - cl + 1);
     const float inv = __builtin_amdgcn_rcpf((float)(nr > 0 ? nr : 1));
