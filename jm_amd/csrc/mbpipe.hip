@@ -657,12 +657,12 @@ __device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv
 
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
 // view: which chain's picture of the macroblock's vectors the predictor reads; wave: this wave's own scratch (row table, SATD sums).
-__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int &out_mv)
+__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int mbx, int mby, int &out_mv)
 {
   const jmhip_slice_params &P = A.p;
   const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
-  const int addr_ = rfl(S.addr), mbx = addr_ % A.wmb, mby = addr_ / A.wmb, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;
+  const int addr_ = mby * A.wmb + mbx, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;     // (the macroblock's position comes from the caller: a division per search otherwise)
   const int R = P.search_range;
   const bool prof_ = A.prof && (((A.prof_mode == 1 || A.prof_mode == 10) && mb_x == 0 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
                      mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
