@@ -622,7 +622,9 @@ __device__ __forceinline__ void subpel_satds(Shared &S, const PipeArgs &A, int w
   for (int base = 0; base < items; base += 64) {
     const int item = base + lane;
     const bool live = item < items;
-    const int it = live ? item : 0, cnd = it / nb4, b = it % nb4, sbx = (b % bw4) * 4, sby = (b / bw4) * 4;
+    // bw4, bh4 are 1, 2 or 4: shifts and masks, not divisions
+    const int lw = bw4 >> 1, lh = bh4 >> 1;                    // log2
+    const int it = live ? item : 0, cnd = it >> (lw + lh), b = it & (nb4 - 1), sbx = (b & (bw4 - 1)) * 4, sby = (b >> lw) * 4;
     const int qx = ((px + sbx) << 2) + mvx(mv) + sp9x(cnd) * step, qy = ((py + sby) << 2) + mvy(mv) + sp9y(cnd) * step;
     u32 r[4], o[4];
     ref_rows4(A, ref, qx, qy, r);
