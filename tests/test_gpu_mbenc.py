@@ -340,6 +340,11 @@ def test_encode_slice_rejects_what_it_does_not_cover():
     bad = prm.copy(); bad["search_range"] = 32
     with pytest.raises(L.JmHipError):
         J.encode_slice(bad)
+    bad = prm.copy(); bad["symbol_mode"] = 2
+    with pytest.raises(L.JmHipError):       # CAVLC or CABAC, nothing else
+        J.encode_slice(bad)
+    with pytest.raises(L.JmHipError):
+        J.set_pipeline_workgroups(-1)
     J4 = L.JmHip(64, 48, search_range=16, num_ref_slots=1, yuv_format=2)
     with pytest.raises(L.JmHipError):
         J4.encode_slice(prm)
