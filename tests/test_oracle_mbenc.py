@@ -30,7 +30,7 @@ def load_case(tag):
     didc = int(ov.get("DFDisableRefPSlice", 0))
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]], didc=didc,
-                nfr=len(z["slice_type"]), records=z["records"])
+                nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)))
 
 
 def source_frames(c, tag):
@@ -50,7 +50,7 @@ def source_frames(c, tag):
 
 def run_case(tag):
     c = load_case(tag)
-    enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
+    enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0))
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -66,7 +66,7 @@ def run_case(tag):
     return enc
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "q1c", "q0c", "q0r"])     # q1c / q0c: CABAC (Main profile) at QP 28 / 0; q0r: CAVLC at QP 0
 def test_oracle_macroblock_pipeline_equals_the_reference_encoder(tag):
     run_case(tag)
 
