@@ -166,6 +166,66 @@ def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total
     assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), (tag, "reconstruction differs from CPU JM", rep)
 
 
+def wild_clip(path, W, H, nfr, seed):
+    """CIF-sized synthetic clip made to leave the comfortable cases: global motion of up to 24 samples per picture in changing directions (long vectors,
+    search centres clamped to the range, windows over the picture edge), an object moving against it, a brightness ramp, a scene cut, coarse noise."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    def texture(s):
+        r = np.random.default_rng(s)
+        base = np.kron(r.integers(0, 256, (H // 8 + 16, W // 8 + 16)).astype(np.float64), np.ones((8, 8)))
+        k = 3
+        pad = np.pad(base, k, mode="edge")
+        return sum(pad[i:i + base.shape[0], j:j + base.shape[1]] for i in range(2 * k + 1) for j in range(2 * k + 1)) / (2 * k + 1) ** 2
+    tex, ox, oy = texture(seed), 64, 64
+    with open(path, "wb") as f:
+        for n in range(nfr):
+            if n == nfr // 2:
+                tex = texture(seed + 1)                                      # scene cut
+            ox = int(np.clip(ox + rng.integers(-24, 25), 0, 127)); oy = int(np.clip(oy + rng.integers(-24, 25), 0, 127))
+            y = tex[oy:oy + H, ox:ox + W].copy()
+            bx, by = (37 * n) % (W - 48), (23 * n) % (H - 48)
+            y[by:by + 48, bx:bx + 48] = 255 - y[by:by + 48, bx:bx + 48]       # an object moving against the background
+            y = y * (0.7 + 0.05 * n) + rng.normal(0, 3 + (n % 3) * 3, (H, W))  # brightness ramp, noise
+            y = np.clip(np.rint(y), 0, 255).astype(np.uint8)
+            c = y[::2, ::2].astype(np.float64)
+            f.write(y.tobytes()); f.write(np.clip(np.rint(128 + 0.3 * (c - 128)), 0, 255).astype(np.uint8).tobytes())
+            f.write(np.clip(np.rint(128 - 0.2 * (c - 128)), 0, 255).astype(np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ov", [dict(SearchRange="32", NumberReferenceFrames="2"), dict(SearchRange="16", NumberReferenceFrames="1", QPISlice="36", QPPSlice="38"),
+                                dict(SearchRange="8", NumberReferenceFrames="3", SliceMode="1", SliceArgument="100", SymbolMode="1", ProfileIDC="77", QPPSlice="22")],
+                         ids=["sr32_2ref", "sr16_qp38", "sr8_3ref_slices_cabac"])
+def test_lencod_macroblock_pipeline_side_by_side_on_a_wild_clip(tmp_path, ov):
+    """No golden file: CPU JM (oracle/_ref/lencod.exe) and the drop-in encoder run on the same generated CIF clip here on the GPU box (10 pictures:
+    large changing global motion, a moving object, brightness change, a scene cut, noise) and must write the same bitstream and reconstruction."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    ref_exe = os.path.join(os.path.dirname(EXE), "lencod.exe")
+    W, H, nfr = 352, 288, 10
+    sums = {}
+    for name, exe in (("hip", EXE), ("cpu", ref_exe)):
+        d = os.path.join(str(tmp_path), name)
+        os.makedirs(d)
+        shutil.copyfile(os.path.join(G, "q_offset.cfg"), os.path.join(d, "q_offset.cfg"))
+        wild_clip(os.path.join(d, "wild.yuv"), W, H, nfr, 77)
+        args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+        full = dict(RDOptimization="0", AdaptiveRounding="0", SearchMode="-1", InputFile="wild.yuv", SourceWidth=str(W), SourceHeight=str(H), OutputWidth=str(W),
+                    OutputHeight=str(H), FramesToBeEncoded=str(nfr), LevelIDC="40", OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null")
+        full.update(ov)
+        for k, v in full.items():
+            args += ["-p", f"{k}={v}"]
+        r = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        err = r.stderr.decode(errors="replace")
+        assert r.returncode == 0, (name, r.stdout.decode(errors="replace")[-800:], err[-800:])
+        if name == "hip":
+            rep = pipeline_report(err)
+            assert rep and rep["mbs"] == nfr * (W // 16) * (H // 16), (rep, err[-800:])
+        sums[name] = (md5(os.path.join(d, "o.264")), md5(os.path.join(d, "o_rec.yuv")))
+    assert sums["hip"] == sums["cpu"], sums
+
+
 @pytest.mark.gpu
 def test_lencod_macroblock_pipeline_leaves_a_real_trace_file_alone(tmp_path):
     """The adapter drops JM's syntax-element trace inside the process only when the configuration sends it to /dev/null (part nulltrace).  With a
