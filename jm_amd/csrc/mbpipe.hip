@@ -121,6 +121,16 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // hand-over between two waves of the workgroup through a sequence number in LDS (a wave's LDS operations execute in order)
 __device__ __forceinline__ void lds_signal(int *f, int seq, int lane) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) *(volatile int *)f = seq; }
+// the same for four flags at once (one LDS read per poll: lanes 0..3 read a flag each)
+__device__ __forceinline__ void lds_wait_ge4(const int *f, int seq, int lane)
+{
+  for (;;) {
+    const int v = lane < 4 ? *(const volatile int *)(f + lane) : seq;
+    if (__ballot(v < seq) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void lds_wait_ge(const int *f, int seq) { while (*(const volatile int *)f < seq) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 // Cross-lane steps inside a row of 16 lanes as DPP operands of the ALU (no trip through the LDS crossbar that __shfl_xor takes):
