@@ -615,9 +615,11 @@ __device__ __forceinline__ int satd4_rows(const u32 (&o)[4], const u32 (&r)[4])
 __device__ __forceinline__ void ref_rows4(const PipeArgs &A, int ref, int qx, int qy, u32 (&r)[4])
 {
   const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);
-  const u8 *p = A.ref_y[ref] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y) * A.ref_pitch + ix + JMHIP_PAD_X;
+  // (32-bit offsets: the sixteen planes of a 2160p picture are 140 MB)
+  const u32 off = (u32)((qy & 3) * 4 + (qx & 3)) * (u32)A.plane_stride + (u32)(iy + JMHIP_PAD_Y) * (u32)A.ref_pitch + (u32)(ix + JMHIP_PAD_X);
+  const u8 *p = A.ref_y[ref];
 #pragma unroll
-  for (int j = 0; j < 4; j++) r[j] = ldu32(p + (long)j * A.ref_pitch);
+  for (int j = 0; j < 4; j++) r[j] = ldu32(p + (off + (u32)j * (u32)A.ref_pitch));
 }
 
 // spiral positions 0..8 (mv_search.c:405-442): {0,0}, {0,-1}, {0,1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {1,1} as two packed constants (a table in
