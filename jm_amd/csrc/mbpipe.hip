@@ -367,17 +367,23 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         // window's slack rows
         constexpr int NB = 2 * NBH + 1, NR = NB + BH - 1;
         const u8 *p = pbase + a_lo * WP;
-        u32 bb[NR][BW / 4], ytv[NB];
+        u32 bb[NR][BW / 4], ytv[NB], aa[NR][BW / 4 + 1];
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
-          u32 a[BW / 4 + 1];
+        for (int r = 0; r < NR; r++)
 #pragma unroll
-          for (int k = 0; k <= BW / 4; k++) a[k] = ((const u32 *)(p + r * WP))[k];
-#pragma unroll
-          for (int k = 0; k < BW / 4; k++) bb[r][k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
-        }
+          for (int k = 0; k <= BW / 4; k++) aa[r][k] = ((const u32 *)(p + r * WP))[k];
 #pragma unroll
         for (int k = 0; k < NB; k++) ytv[k] = ytab[a_lo + k > 2 * Rs ? 2 * Rs : a_lo + k];
+        // every read above is on its way before the first value is used (left alone the compiler reuses two registers for all rows: a dozen LDS
+        // round trips one after the other)
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+          for (int k = 0; k <= BW / 4; k++) asm volatile("" : "+v"(aa[r][k]));
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+          for (int k = 0; k < BW / 4; k++) bb[r][k] = __builtin_amdgcn_alignbyte(aa[r][k + 1], aa[r][k], sh);
 #pragma unroll
         for (int k = 0; k < NB; k++) {
           u32 v = 0;
