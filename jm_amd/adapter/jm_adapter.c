@@ -79,7 +79,7 @@ static void pipe_report(void);
 static double now_s(void);
 static double T_slice, T_pad, T_deblock, T_interp;
 /* per picture (the first 64): when encode_one_slice was entered and left, and the time inside DeblockFrame / getSubImagesLuma (JMHIP_ADAPTER_TIMELINE=1 prints them) */
-static double TL_in[64], TL_out[64], TL_db[64], TL_ip[64], TL_begun[64], TL_first[64], TL_last[64], TL_ended[64], TL_wait[64];
+static double TL_in[64], TL_out[64], TL_db[64], TL_ip[64], TL_begun[64], TL_first[64], TL_last[64], TL_ended[64], TL_wait[64], TL_db_at[64], TL_ip_at[64];
 static int TL_n;
 static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV);
 static int pipe_reference(StorablePicture *s);
@@ -275,7 +275,7 @@ void __wrap_getSubImagesLuma(VideoParameters *p_Vid, StorablePicture *s)
 {
   int rc, k, j, i, y;
   const int Wp = s->size_x + 2 * JMHIP_PAD_X, Hp = s->size_y + 2 * JMHIP_PAD_Y;
-  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_reference(s)) { T_interp += now_s() - t0_; if (TL_n) TL_ip[TL_n - 1] += now_s() - t0_; return; } }   /* the macroblock pipeline's picture: the planes are made on the device and stay there */
+  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_reference(s)) { T_interp += now_s() - t0_; if (TL_n) { TL_ip[TL_n - 1] += now_s() - t0_; TL_ip_at[TL_n - 1] = t0_; } return; } }   /* the macroblock pipeline's picture: the planes are made on the device and stay there */
   if (!adapter_on(p_Vid) || !G.part_interp || s->size_x != G.W || s->size_y != G.H ||
       s->size_x_padded != Wp || s->size_y_padded != Hp) {
     G.n_passed++;
@@ -952,7 +952,7 @@ void __wrap_DeblockFrame(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
   StorablePicture *ids[64];
   int nids = 0, rc, x, y, l, k;
   unsigned i;
-  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) { T_deblock += now_s() - t0_; if (TL_n) TL_db[TL_n - 1] += now_s() - t0_; return; } }
+  { const double t0_ = now_s(); if (adapter_on(p_Vid) && pipe_deblock(p_Vid, imgY, imgUV)) { T_deblock += now_s() - t0_; if (TL_n) { TL_db[TL_n - 1] += now_s() - t0_; TL_db_at[TL_n - 1] = t0_; } return; } }
   if (!adapter_on(p_Vid) || !G.part_deblock || p_Vid->structure != FRAME || p_Vid->mb_aff_frame_flag ||
       (int)p_Vid->PicSizeInMbs != (G.W / 16) * (G.H / 16)) {
     G.n_passed++;
@@ -1466,8 +1466,9 @@ static void pipe_report(void)
   if (getenv("JMHIP_ADAPTER_TIMELINE")) {
     int i;
     for (i = 0; i < TL_n; i++)
-      fprintf(stderr, "jmhip adapter: picture %d: slices %.1f ms (after its start: launched %.1f, first record %.1f, last record %.1f, launch closed %.1f ms; waiting for records %.1f ms), DeblockFrame %.1f ms, getSubImagesLuma %.1f ms, everything else up to the next picture's first slice %.1f ms\n", i,
-              1e3 * (TL_out[i] - TL_in[i]), 1e3 * (TL_begun[i] - TL_in[i]), 1e3 * (TL_first[i] - TL_in[i]), 1e3 * (TL_last[i] - TL_in[i]), 1e3 * (TL_ended[i] - TL_in[i]), 1e3 * TL_wait[i], 1e3 * TL_db[i], 1e3 * TL_ip[i], i + 1 < TL_n ? 1e3 * (TL_in[i + 1] - TL_out[i] - TL_db[i] - TL_ip[i]) : 0.0);
+      fprintf(stderr, "jmhip adapter: picture %d: slices %.1f ms (after its start: launched %.1f, first record %.1f, last record %.1f, launch closed %.1f ms; waiting for records %.1f ms), DeblockFrame %.1f ms, getSubImagesLuma %.1f ms, everything else up to the next picture's first slice %.1f ms (slice end -> DeblockFrame %.1f, DeblockFrame -> getSubImagesLuma %.1f, getSubImagesLuma -> next slice %.1f)\n", i,
+              1e3 * (TL_out[i] - TL_in[i]), 1e3 * (TL_begun[i] - TL_in[i]), 1e3 * (TL_first[i] - TL_in[i]), 1e3 * (TL_last[i] - TL_in[i]), 1e3 * (TL_ended[i] - TL_in[i]), 1e3 * TL_wait[i], 1e3 * TL_db[i], 1e3 * TL_ip[i], i + 1 < TL_n ? 1e3 * (TL_in[i + 1] - TL_out[i] - TL_db[i] - TL_ip[i]) : 0.0,
+              1e3 * (TL_db_at[i] - TL_out[i]), 1e3 * (TL_ip_at[i] - TL_db_at[i] - TL_db[i]), i + 1 < TL_n ? 1e3 * (TL_in[i + 1] - TL_ip_at[i] - TL_ip[i]) : 0.0);
   }
 }
 
