@@ -282,6 +282,7 @@ __device__ __forceinline__ int bits_reach(int bits)
 struct FsCost {                              // what turns a SAD into JM's motion cost
   int lambda, cqx, cqy, pqx, pqy, Rs, R;     // lambda_factor[F_PEL], centre and predictor (quarter-pel), search range of this search and of the slice
   int check00;
+  int count;                                 // JMHIP_MB_PROF=11: count rows and candidates
 };
 __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, int bits_x)
 {
@@ -294,6 +295,45 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
 
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
+// NB candidate rows i0 .. i0 + NB - 1 (those beyond i_last do not count) of one column at once: every window row read before the first is used (left
+// alone the compiler funnels the reads through two registers, an LDS round trip each), SADs side by side, keys as in the sliding loop of fs_wave.
+// Returns min(bkey, the rows' keys).
+template <int BW, int BH, int NB>
+__device__ __forceinline__ u32 rows_at_once(const u8 *pbase, int WP, int sh, const u32 (&cb)[BH][BW / 4], const u32 *ytab, int Rs, int i0, int i_last, u32 rx7, int k1, int adx, u32 bkey)
+{
+  constexpr int NR = NB + BH - 1;
+  const u8 *p = pbase + i0 * WP;
+  u32 bb[NR][BW / 4], ytv[NB], aa[NR][BW / 4 + 1];
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+#pragma unroll
+    for (int k = 0; k <= BW / 4; k++) aa[r][k] = ((const u32 *)(p + r * WP))[k];
+#pragma unroll
+  for (int k = 0; k < NB; k++) ytv[k] = ytab[i0 + k > 2 * Rs ? 2 * Rs : i0 + k];
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+#pragma unroll
+    for (int k = 0; k <= BW / 4; k++) asm volatile("" : "+v"(aa[r][k]));
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+#pragma unroll
+    for (int k = 0; k < BW / 4; k++) bb[r][k] = __builtin_amdgcn_alignbyte(aa[r][k + 1], aa[r][k], sh);
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    u32 v = 0;
+#pragma unroll
+    for (int r = 0; r < BH; r++)
+#pragma unroll
+      for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(bb[k + r][q], cb[r][q], v);
+    const int i = i0 + k, dy = i - Rs, ady = dy < 0 ? -dy : dy;
+    const u32 kf = (v << 12) + rx7 + ytv[k];
+    const u32 kn = (kf & ~127u) | (u32)(i + k1);
+    const u32 key = (u32)ady <= (u32)adx ? kn : kf;
+    bkey = (i <= i_last && key < bkey) ? key : bkey;
+  }
+  return bkey;
+}
+
 // spec(mv): called (pruned searches only) with the best integer vector of the first rows -- most often the search's result -- so that the caller can
 // start fetching what its sub-pel stage will need.
 template <int BW, int BH, class Spec>
@@ -362,42 +402,19 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       const bool both = BH >= 8 && lo1 < a_lo && hi1 > a_hi;
       const int s_lo = seg == 0 ? a_lo : (seg == 1 ? lo1 : a_hi + 1), s_hi = seg == 0 ? a_hi : (seg == 1 ? (both ? hi1 : a_lo - 1) : (both ? a_hi : hi1));
       if (BW * BH <= 64 && seg == 0 && prune) {
-        // step 0 as straight-line code: the (at most) five candidate rows and the BH - 1 window rows below them are read at once and summed side
-        // by side (independent instructions: a lone wave issues a dependent one only every ~9 cycles); rows past the last candidate lie in the
-        // window's slack rows
-        constexpr int NB = 2 * NBH + 1, NR = NB + BH - 1;
-        const u8 *p = pbase + a_lo * WP;
-        u32 bb[NR][BW / 4], ytv[NB], aa[NR][BW / 4 + 1];
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-#pragma unroll
-          for (int k = 0; k <= BW / 4; k++) aa[r][k] = ((const u32 *)(p + r * WP))[k];
-#pragma unroll
-        for (int k = 0; k < NB; k++) ytv[k] = ytab[a_lo + k > 2 * Rs ? 2 * Rs : a_lo + k];
-        // every read above is on its way before the first value is used (left alone the compiler reuses two registers for all rows: a dozen LDS
-        // round trips one after the other)
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-#pragma unroll
-          for (int k = 0; k <= BW / 4; k++) asm volatile("" : "+v"(aa[r][k]));
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-#pragma unroll
-          for (int k = 0; k < BW / 4; k++) bb[r][k] = __builtin_amdgcn_alignbyte(aa[r][k + 1], aa[r][k], sh);
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-          u32 v = 0;
-#pragma unroll
-          for (int r = 0; r < BH; r++)
-#pragma unroll
-            for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(bb[k + r][q], cb[r][q], v);
-          const int i = a_lo + k, dy = i - Rs, ady = dy < 0 ? -dy : dy;
-          const u32 kf = (v << 12) + rx7 + ytv[k];
-          const u32 kn = (kf & ~127u) | (u32)(i + k1);
-          const u32 key = (u32)ady <= (u32)adx ? kn : kf;
-          bkey = (i <= a_hi && key < bkey) ? key : bkey;
+        // step 0 as straight-line code: the (at most) five or seven candidate rows and the BH - 1 window rows below them are read at once and
+        // summed side by side (independent instructions: a lone wave issues a dependent one only every ~9 cycles); rows past the last candidate
+        // lie in the window's slack rows
+        bkey = rows_at_once<BW, BH, 2 * NBH + 1>(pbase, WP, sh, cb, ytab, Rs, a_lo, a_hi, rx7, k1, adx, bkey);
+        dbg_steps += 2 * NBH + BH;
+      } else if (BW * BH <= 32 && prune && s_lo <= s_hi) {
+        // step 1 of the smallest blocks the same way, eight candidate rows at a time (twice as fast per row as the sliding loop below, although
+        // BH - 1 window rows are read again per chunk)
+        ev_lo = min(ev_lo, s_lo); ev_hi = max(ev_hi, s_hi);
+        for (int i0 = s_lo; i0 <= s_hi; i0 += 8) {
+          bkey = rows_at_once<BW, BH, 8>(pbase, WP, sh, cb, ytab, Rs, i0, s_hi, rx7, k1, adx, bkey);
+          dbg_steps += 8 + BH - 1;
         }
-        dbg_steps += NR;
       } else if (s_lo <= s_hi) {
         ev_lo = min(ev_lo, s_lo); ev_hi = max(ev_hi, s_hi);
         const int nrows = (s_hi - s_lo + 1) + BH - 1;
@@ -585,6 +602,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, mvbits(c.cqx + 4 * dx - c.pqx)); best = key < best ? key : best; }
     }
   }
+  if (c.count && lane == 0) { ytab_own[70] += (u32)dbg_steps; ytab_own[71] += (u32)dbg_items; }     // JMHIP_MB_PROF=11: per-wave totals (spare entries of the wave's row table)
   if (pf && lane == 0) { pf[23] = wall_clock64(); pf[26] = (unsigned long long)dbg_steps | ((unsigned long long)dbg_items << 16) | ((unsigned long long)(hi1 - lo1 + 1 > 0 ? hi1 - lo1 + 1 : 0) << 32); }
   const u32 hi = wave_min_u32((u32)(best >> 32));              // the smallest cost, then the earliest spiral index among the candidates that have it
   const u32 lo = wave_min_u32((u32)(best >> 32) == hi ? (u32)best : 0xffffffffu);
@@ -714,6 +732,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   c.lambda = P.lambda_mf[0]; c.cqx = cx; c.cqy = cy; c.pqx = mvx(pred); c.pqy = mvy(pred);
   c.Rs = min(max(min(max_x, max_y) >> 2, 0), R); c.R = R;
   c.check00 = bt == 1 && ref == 0;
+  c.count = A.prof != nullptr && A.prof_mode == 11;
   const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);

@@ -49,6 +49,13 @@ for n in range(2):
         w = st[:, 26]
         print("  ... that search: window rows read by the sliding lanes: median %d (mean %.1f); candidates of step 2: median %d (mean %.1f); rows of step 1: median %d (mean %.1f)" % (
             np.median(w & 0xffff), (w & 0xffff).mean(), np.median((w >> 16) & 0xffff), ((w >> 16) & 0xffff).mean(), np.median(w >> 32), (w >> 32).mean()))
+    if n == 1 and MODE == "11":                                # what makes a first 8x8 block slow: rows read by the sliding lanes / candidates of step 2, per wave
+        ph = us(2, 3)
+        slow, fast = ph >= np.percentile(ph, 90), ph <= np.percentile(ph, 50)
+        for w, nm in enumerate(("8x8", "8x4", "4x8", "4x4")):
+            v = st[:, 18 + w]; rows, items = v & 0xffffffff, v >> 32
+            tw = (st[:, 8 + w] - st[:, 2]) / 100.0
+            print("  wave %s: time fast half %.1f / slow tenth %.1f us; rows read %.0f / %.0f; step-2 candidates %.0f / %.0f" % (nm, tw[fast].mean(), tw[slow].mean(), rows[fast].mean(), rows[slow].mean(), items[fast].mean(), items[slow].mean()))
     if n == 1 and MODE == "10":
         print("  first 4x4 search, the sliding part in detail: first rows %.2f, their minimum + the sub-pel fetch started %.2f, what remains decided %.2f, steps 1 %.2f, B1 + keys widened %.2f; step 2 %.2f, wave minimum %.2f us" % tuple(
             np.median(us(a, b)) for a, b in ((24, 27), (27, 28), (28, 29), (29, 30), (30, 7), (7, 23), (23, 20))))
