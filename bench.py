@@ -41,7 +41,7 @@ G2R_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", 
 G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's .264 for two frames of the clip with these flags
 # HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
 # MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r02_v2_kernel_stats.md)
-PIPE_TRAFFIC_BYTES = 950860000             # mostly scratch memory: loop-invariant registers the compiler spills
+PIPE_TRAFFIC_BYTES = 1056860000            # mostly scratch memory: loop-invariant registers the compiler spills
 
 
 def synth_luma(n_frames, seed=1234):
