@@ -35,7 +35,7 @@ for n in range(2):
     if MODE == "1" and n == 1:
         print("  ... of the integer search: centre + source block %.2f, row table %.2f, column loop %.2f, column 64 %.2f, wave minimum %.2f us" % tuple(np.median(us(a, b)) for a, b in ((19, 25), (25, 24), (24, 7), (7, 23), (23, 20))))
     if MODE == "2":
-        print("  intra wave: Intra4x4 chain %.1f, Intra16x16 search %.1f, chroma decision %.1f us (medians)" % tuple(np.median(us(a, b)) for a, b in ((2, 7), (7, 23), (23, 15))))
+        print("  intra wave (7): the neighbours' samples + the Intra4x4 chain %.1f us (median)" % np.median(us(2, 7)))
     if MODE == "3":
         d = (st[:, 19] - st[:, 18]) / np.maximum(us(0, 17), 1e-9)
         print("  shader clock while the kernel runs (s_memtime ticks per microsecond of s_memrealtime): median %.0f MHz" % np.median(d))
