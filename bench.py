@@ -402,7 +402,7 @@ def main():
             "roofline": roof,
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and N == 1:                       # rank 0 at N = 1 only
             cpu = cpu_baseline()
             out["cpu_baseline"] = cpu
         if not args.no_end_to_end and N == 1:
