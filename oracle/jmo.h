@@ -260,7 +260,22 @@ typedef struct {
   int32_t start_qp;             /* p_Vid->start_me_refinement_qp (mv_search.c:446); start_me_refinement_hp must be 0 */
   int32_t refbits[JMO_MAX_REF]; /* p_Vid->refbits, mv_search.c:376-385 */
   int32_t cabac;                /* currSlice->symbol_mode == CABAC: levels are not clamped to CAVLC_LEVEL_LIMIT (quant4x4_normal.c:84) */
+  int32_t search_mode;          /* SearchMode: -1 (or 0 here: same thing) full search, 3 EPZS with EPZSSubPelGrid = 1 and EPZSSubPelME = 1 (needs a jmo_epzs_cfg) */
 } jmo_mbenc_cfg;
+
+/* EPZS (SearchMode = 3): the configuration's switches and what EPZSSliceInit (lencod/src/me_epzs_common.c:620) reads from the decoded picture buffer. */
+#define JMO_NO_REF (-(1 << 30))
+typedef struct {
+  int32_t pattern, dual, fixed, aggressive, temporal, spatial_mem, blocktype;   /* EPZSPattern, EPZSDualRefinement, EPZSFixedPredictors, EPZSAggressiveWindow, EPZSTemporal, EPZSSpatialMem, EPZSBlockType */
+  int32_t min_scale, med_scale, max_scale, sub_scale;                           /* EPZSMinThresScale, EPZSMedThresScale, EPZSMaxThresScale, EPZSSubPelThresScale */
+  int32_t poc_cur, poc_ref[JMO_MAX_REF];                                        /* enc_picture->poc, listX[LIST_0][r]->poc */
+  /* listX[LIST_0][0] and [1] as pictures with motion: per 4x4 block the LIST_0 vector (x, y) and the poc of the picture it refers to (JMO_NO_REF: none).
+   * [1] may be NULL when the list holds one picture. */
+  const int16_t *col_mv[2];
+  const int32_t *col_refpoc[2];
+  int64_t alias_hits;           /* out: candidates JM skipped only because its 16-bit EPZSMap stamp had wrapped round (BlkCount, me_epzs_int.c:80) */
+  int64_t searches;             /* out: EPZS searches run */
+} jmo_epzs_cfg;
 
 /* What encode_one_macroblock_low leaves behind for write_macroblock (lencod/src/macroblock.c:2810), one record per macroblock. */
 typedef struct {
@@ -292,6 +307,10 @@ typedef struct {                /* intermediate values, for localising a diverge
 int jmo_encode_slice(const jmo_mbenc_cfg *cfg, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
                      const jmo_refpic *refs, const jmo_pel *const *refc, jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v,
                      int16_t *mv, int8_t *ref_idx, int8_t *ipredmode, jmo_mb_record *out, jmo_mb_debug *dbg);
+/* the same with the EPZS inputs (ez may be NULL when cfg->search_mode != 3) */
+int jmo_encode_slice_ex(const jmo_mbenc_cfg *cfg, jmo_epzs_cfg *ez, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
+                        const jmo_refpic *refs, const jmo_pel *const *refc, jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v,
+                        int16_t *mv, int8_t *ref_idx, int8_t *ipredmode, jmo_mb_record *out, jmo_mb_debug *dbg);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ typedef struct {
   jmo_mv all_mv[JMO_MAX_REF][8][4][4];   /* currSlice->all_mv[LIST_0][ref][mode][by][bx] */
   jmo_dist motion_cost[8][JMO_MAX_REF][4];
   jmo_pel orig[256];
+  struct epzs_state *ez;                 /* SearchMode = 3: the slice's EPZS state (jmo_mbenc_epzs.inc) */
 } enc;
 
 static inline jmo_dist mv_cost(int lambda, int cx, int cy, int px, int py) { return (jmo_dist)lambda * (jmo_dist)(jmo_mvbits(cx - px) + jmo_mvbits(cy - py)); }
@@ -144,6 +145,67 @@ static jmo_dist satd_blocks(const jmo_pel *orig, int opitch, const jmo_pel *pred
   return c;
 }
 
+#include "jmo_mbenc_epzs.inc"
+
+/* BlockMotionSearch mv_search.c:857-1024 with SearchMode = 3 (EPZS, EPZSSubPelGrid = 1): the centre is the predictor itself (:924-927), the
+ * integer search EPZS_integer_motion_estimation or its sub-macroblock variant (mv_search.c:1634-1640, :1772-1788), the sub-pel search
+ * EPZS_sub_pel_motion_estimation unless a later reference already looks hopeless (:965) */
+static jmo_dist block_motion_search_epzs(enc *e, int ref, int blocktype, int mb_x, int mb_y, int bsx, int bsy, jmo_mv *out)
+{
+  const jmo_mbenc_cfg *c = e->c;
+  epzs_blk B;
+  nb b[4];
+  jmo_pel orig[256];
+  jmo_mv pred, mv, center;
+  int min_x = -(c->search_range << 2), max_x = c->search_range << 2, min_y = min_x, max_y = max_x;
+  jmo_dist min_mcost;
+  get_neighbors(e, b, mb_x, mb_y, bsx);
+  get_orig_block(e, mb_x, mb_y, bsx, bsy, orig);
+  pred = mv_predictor(e, b, ref, mb_x, mb_y, bsx, bsy);
+  mv = pred;
+  center = mv;
+  mv.x = (int16_t)iclip3(min_x, max_x, mv.x);
+  mv.y = (int16_t)iclip3(min_y, max_y, mv.y);
+  if (mv.x != center.x || mv.y != center.y) {            /* CheckSearchRange :822-849 */
+    const int lim = c->max_mvd - 2;
+    int left = mv.x + min_x, right = mv.x + max_x, top = mv.y + min_y, down = mv.y + max_y;
+    left = iclip3(center.x - lim, center.x + lim, left);   right = iclip3(center.x - lim, center.x + lim, right);
+    top = iclip3(center.y - lim, center.y + lim, top);     down = iclip3(center.y - lim, center.y + lim, down);
+    if (left < right && top < down) {
+      mv.x = (int16_t)((left + right) >> 1); mv.y = (int16_t)((top + down) >> 1);
+      max_x = imin_(mv.x - left, right - mv.x); max_y = imin_(mv.y - top, down - mv.y);
+    } else mv = center;
+  }
+  mv.x = (int16_t)iclip3(c->mv_limit[0], c->mv_limit[1], mv.x);
+  mv.y = (int16_t)iclip3(c->mv_limit[2], c->mv_limit[3], mv.y);
+  memset(&B, 0, sizeof B);
+  B.e = e; B.s = (epzs *)e->ez; B.rp = &e->ref[ref]; B.orig = orig; B.bt = blocktype; B.bsx = bsx; B.bsy = bsy; B.ref = ref; B.mb_x = mb_x; B.mb_y = mb_y;
+  B.pxp = (e->mbx * 16 + mb_x) << 2; B.pyp = (e->mby * 16 + mb_y) << 2; B.x4 = (e->mbx * 16 + mb_x) >> 2; B.y4 = (e->mby * 16 + mb_y) >> 2;
+  B.lambda = c->lambda_mf[0]; B.pred = pred; B.mv = mv; B.max_x = max_x; B.max_y = max_y; B.b = b;
+  min_mcost = epzs_integer(&B, blocktype > 4);
+  if (c->subpel) {
+    const jmo_dist prev = *epzs_prevsad(&B);
+    if (ref == 0 || 2 * min_mcost < 7 * prev) {             /* min_mcost < 3.5 * prevSad[pic_pix_x >> 2] */
+      min_mcost = epzs_subpel(&B, c->lambda_mf, c->start_qp, JMO_DIST_MAX);     /* start_me_refinement_hp = 0: the stage starts from DISTBLK_MAX (:969-972) */
+    }
+  }
+  mv = B.mv;
+  mv.x = (int16_t)iclip3(c->mv_limit[0], c->mv_limit[1], mv.x);
+  mv.y = (int16_t)iclip3(c->mv_limit[2], c->mv_limit[3], mv.y);
+  if (blocktype == 1 && c->slice_type == 0) {
+    jmo_mv s = skip_mv(e), z = {0, 0};
+    jmo_pel pr[256];
+    jmo_dist cost;
+    int j, i;
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s;
+    jmo_luma_pred(&e->ref[0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
+    cost = satd_blocks(e->orig, 16, pr, 16, 16, 16) - (jmo_dist)c->lambda_mf[2] * 8;
+    if (cost < min_mcost) { min_mcost = cost; mv = s; }
+  }
+  *out = mv;
+  return min_mcost;
+}
+
 /* BlockMotionSearch mv_search.c:857-1024 for one (block, reference), rdopt == 0, SearchMode = -1.  Returns min_mcost; *out = the vector. */
 static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, int mb_y, int bsx, int bsy, jmo_mv *out)
 {
@@ -157,6 +219,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
   jmo_dist min_mcost = JMO_DIST_MAX, mcost;
   int R, max_pos, pos, best_pos = 0, cx, cy, px, py, check00, check_position0;
 
+  if (c->search_mode == 3) return block_motion_search_epzs(e, ref, blocktype, mb_x, mb_y, bsx, bsy, out);
   get_neighbors(e, b, mb_x, mb_y, bsx);
   get_orig_block(e, mb_x, mb_y, bsx, bsy, orig);
   pred = mv_predictor(e, b, ref, mb_x, mb_y, bsx, bsy);
@@ -707,10 +770,22 @@ int jmo_encode_slice(const jmo_mbenc_cfg *cfg, const jmo_pel *cur_y, const jmo_p
                      const jmo_refpic *refs, const jmo_pel *const *refc, jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v,
                      int16_t *mv, int8_t *ref_idx, int8_t *ipredmode, jmo_mb_record *out, jmo_mb_debug *dbg)
 {
+  return jmo_encode_slice_ex(cfg, NULL, cur_y, cur_u, cur_v, refs, refc, rec_y, rec_u, rec_v, mv, ref_idx, ipredmode, out, dbg);
+}
+
+int jmo_encode_slice_ex(const jmo_mbenc_cfg *cfg, jmo_epzs_cfg *ez, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
+                        const jmo_refpic *refs, const jmo_pel *const *refc, jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v,
+                        int16_t *mv, int8_t *ref_idx, int8_t *ipredmode, jmo_mb_record *out, jmo_mb_debug *dbg)
+{
   enc *e = (enc *)calloc(1, sizeof(enc));
   int k, n4;
   if (!e) return -1;
   if (cfg->num_ref > JMO_MAX_REF || (cfg->slice_type != 0 && cfg->slice_type != 2)) { free(e); return -2; }
+  if (cfg->search_mode == 3 && cfg->slice_type == 0) {
+    if (!ez) { free(e); return -3; }
+    e->ez = (struct epzs_state *)epzs_new(cfg, ez);
+    if (!e->ez) { free(e); return -1; }
+  }
   e->c = cfg; e->wmb = cfg->width / 16; e->hmb = cfg->height / 16; e->w4 = cfg->width / 4;
   n4 = e->w4 * (cfg->height / 4);
   e->cur[0] = cur_y; e->cur[1] = cur_u; e->cur[2] = cur_v;
@@ -724,6 +799,7 @@ int jmo_encode_slice(const jmo_mbenc_cfg *cfg, const jmo_pel *cur_y, const jmo_p
     encode_mb(e, &out[k], dbg ? &dbg[k] : NULL);
   }
   for (k = 0; k < n4; k++) { mv[2 * k] = e->mi[k].mv.x; mv[2 * k + 1] = e->mi[k].mv.y; ref_idx[k] = e->mi[k].ref; }
+  epzs_free((epzs *)e->ez);
   free(e->spiral); free(e->mi); free(e);
   return 0;
 }

@@ -440,7 +440,21 @@ class MbEncCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("slice_type", C.c_int32), ("first_mb", C.c_int32), ("num_mb", C.c_int32),
                 ("qp", C.c_int32), ("qpc", C.c_int32), ("search_range", C.c_int32), ("num_ref", C.c_int32), ("lambda_mf", C.c_int32 * 3),
                 ("lambda_mdfp", C.c_int32), ("max_mvd", C.c_int32), ("mv_limit", C.c_int32 * 4), ("inter_valid", C.c_int32 * 8),
-                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32)]
+                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32)]
+
+
+NO_REF = -(1 << 30)
+
+
+class EpzsCfg(C.Structure):
+    """jmo_epzs_cfg: the configuration's EPZS switches + what EPZSSliceInit reads from the reference list"""
+    _fields_ = [("pattern", C.c_int32), ("dual", C.c_int32), ("fixed", C.c_int32), ("aggressive", C.c_int32), ("temporal", C.c_int32), ("spatial_mem", C.c_int32),
+                ("blocktype", C.c_int32), ("min_scale", C.c_int32), ("med_scale", C.c_int32), ("max_scale", C.c_int32), ("sub_scale", C.c_int32),
+                ("poc_cur", C.c_int32), ("poc_ref", C.c_int32 * MAX_REF), ("col_mv", C.c_void_p * 2), ("col_refpoc", C.c_void_p * 2),
+                ("alias_hits", C.c_int64), ("searches", C.c_int64)]
+
+
+EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2)   # the shipped .cfg files
 
 
 MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("pad0", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
@@ -452,9 +466,10 @@ assert MB_RECORD.itemsize == 944
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
-              subpel=1, cabac=0):
+              subpel=1, cabac=0, search_mode=-1):
     c = MbEncCfg()
     c.cabac = cabac
+    c.search_mode = search_mode
     c.width, c.height, c.slice_type, c.first_mb, c.num_mb = width, height, slice_type, first_mb, num_mb
     c.qp = qp
     c.qpc = qp if qp < 30 else [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39][qp - 30]
@@ -497,8 +512,10 @@ class Picture:
         self.ipredmode = np.full((height // 4, width // 4), 2, np.int8)
 
 
-def encode_slice(cfg, cur, refs, refc, pic, debug=False):
-    """cur: (y, u, v) uint16 planes at the coded size; refs: list of RefPic; refc: list of (u, v) uint16 chroma planes per reference."""
+def encode_slice(cfg, cur, refs, refc, pic, debug=False, epzs=None):
+    """cur: (y, u, v) uint16 planes at the coded size; refs: list of RefPic; refc: list of (u, v) uint16 chroma planes per reference.
+    epzs (SearchMode 3): dict(params=EPZS switches, poc_cur, poc_ref=[..], col=[(mv (h4, w4, 2) int16, refpoc (h4, w4) int32)] of references 0 and 1);
+    the EpzsCfg comes back in epzs["out"] (alias_hits, searches)."""
     cy, cu, cv = [np.ascontiguousarray(p, np.uint16) for p in cur]
     n = cfg.num_mb
     out = np.zeros(n, MB_RECORD)
@@ -508,7 +525,20 @@ def encode_slice(cfg, cur, refs, refc, pic, debug=False):
     keep = [np.ascontiguousarray(p, np.uint16) for pair in refc for p in pair]
     PA = C.c_void_p * max(1, len(keep))
     pa = PA(*[k.ctypes.data for k in keep]) if keep else PA()
-    r = L.jmo_encode_slice(C.byref(cfg), _p(cy), _p(cu), _p(cv), ra, pa, _p(pic.rec[0]), _p(pic.rec[1]), _p(pic.rec[2]),
-                           _p(pic.mv), _p(pic.ref_idx), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
+    ez, keep2 = None, []
+    if epzs is not None:
+        ez = EpzsCfg()
+        for k, v in dict(EPZS_DEFAULTS, **epzs.get("params", {})).items():
+            setattr(ez, k, v)
+        ez.poc_cur = epzs["poc_cur"]
+        for i, pc in enumerate(epzs["poc_ref"]):
+            ez.poc_ref[i] = pc
+        for i, (cmv, crp) in enumerate(epzs.get("col", [])[:2]):
+            a, b = np.ascontiguousarray(cmv, np.int16), np.ascontiguousarray(crp, np.int32)
+            keep2 += [a, b]
+            ez.col_mv[i], ez.col_refpoc[i] = a.ctypes.data, b.ctypes.data
+        epzs["out"] = ez
+    r = L.jmo_encode_slice_ex(C.byref(cfg), C.byref(ez) if ez is not None else None, _p(cy), _p(cu), _p(cv), ra, pa, _p(pic.rec[0]), _p(pic.rec[1]), _p(pic.rec[2]),
+                              _p(pic.mv), _p(pic.ref_idx), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
     assert r == 0, r
     return (out, dbg) if debug else out

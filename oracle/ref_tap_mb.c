@@ -37,6 +37,8 @@ typedef struct {
   int32_t dc_level[3][18], dc_run[3][18];            /* cofDC[pl][0/1][k] */
   int32_t chroma_level[8][17], chroma_run[8][17];    /* cofAC[4 + uv*2.. ][b4] for 4:2:0: b8 = 4, 5 hold U, V? see make_mb_golden.py */
   uint8_t rec_y[256], rec_u[64], rec_v[64];
+  int32_t poc, ref_poc[16];                 /* enc_picture->poc, listX[LIST_0][r]->poc (EPZS scales its predictors by picture distances) */
+  int64_t motion_cost_ref[8][4][4];         /* p_Vid->motion_cost[mode][LIST_0][ref 1..4][block] */
 } MBREC;
 #pragma pack(pop)
 
@@ -89,6 +91,13 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
           r.all_mv[m][j * 4 + i][1] = currSlice->all_mv[LIST_0][0][m][j][i].mv_y;
         }
     }
+  }
+  r.poc = p_Vid->enc_picture->poc;
+  if (currSlice->slice_type != I_SLICE) {
+    for (i = 0; i < 16 && i < currSlice->listXsize[LIST_0]; i++) r.ref_poc[i] = currSlice->listX[LIST_0][i]->poc;
+    for (m = 1; m < 8; m++)
+      for (i = 1; i < 5 && i < currSlice->listXsize[LIST_0]; i++)
+        for (k = 0; k < 4; k++) r.motion_cost_ref[m][i - 1][k] = p_Vid->motion_cost[m][LIST_0][i][k];
   }
   for (b8 = 0; b8 < 4; b8++)
     for (b4 = 0; b4 < 4; b4++)

@@ -38,6 +38,14 @@ CASES = {
     "q0c": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", SymbolMode="1", ProfileIDC="77", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
     "q0r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
     "g2r": (dict(RDO_OFF, **SYN1080), (1920, 1080), 2, True),                                          # SURVEY 8c G2r = BASELINE configs[1], RDO off
+    # EPZS (SearchMode = 3) with the shipped EPZS switches (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid, EPZS sub-pel search)
+    "q1e": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="1"), (176, 144), 3, False),          # the reference's own clip
+    "m5e": (dict(RDO_OFF, SearchMode="3", SearchRange="32", FramesToBeEncoded="6"), (208, 160), 6, "motion:11"),         # five references: the ref > 0 exits, scaled predictors
+    "m2c": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", SymbolMode="1", ProfileIDC="77", SliceMode="1", SliceArgument="40", FramesToBeEncoded="4"), (176, 144), 4, "motion:12"),   # CABAC, slices that start mid-row
+    "m3p": (dict(RDO_OFF, SearchMode="3", SearchRange="8", NumberReferenceFrames="3", EPZSPattern="4", EPZSDualRefinement="6", EPZSFixedPredictors="3", EPZSAggressiveWindow="1",
+                 EPZSMinThresScale="1", EPZSSubPelThresScale="1", FramesToBeEncoded="4", QPISlice="36", QPPSlice="36"), (176, 144), 4, "motion:13"),    # the other patterns / window set
+    "m2t": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", EPZSPattern="0", EPZSDualRefinement="0", EPZSFixedPredictors="0", EPZSTemporal="0",
+                 EPZSSpatialMem="0", EPZSBlockType="0", FramesToBeEncoded="4"), (192, 128), 4, "motion:14"),                                            # every optional predictor set off
 }
 
 
@@ -52,9 +60,16 @@ def run(tag):
     try:
         for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
             shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
-        if syn:
+        clip_md5 = ""
+        if syn is True:
             import bench
             bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), nfr)
+        elif syn:                                            # "motion:<seed>": tests/golden/synth_motion.py at the case's size
+            import synth_motion
+            data = np.concatenate(synth_motion.motion_clip(sw, sh, nfr, int(syn.split(":")[1])))
+            data.tofile(os.path.join(tmp, "motion.yuv"))
+            clip_md5 = md5(data.tobytes())
+            ov = dict(ov, InputFile="motion.yuv", SourceWidth=str(sw), SourceHeight=str(sh), OutputWidth=str(sw), OutputHeight=str(sh))
         args = [EXE, "-d", os.path.join(G, "jm_baseline.cfg")]
         for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
             args += ["-p", f"{k}={v}"]
@@ -76,9 +91,11 @@ def run(tag):
                             lambda_i=np.array(lam.get(2, [0, 0, 0, 0]), np.int32), lambda_p=np.array(lam.get(0, [0, 0, 0, 0]), np.int32),
                             qp=int(t0["qp"]), qpc=int(t0["qpc"]), search_range=int(t0["search_range"]), max_mvd=int(t0["max_mvd"]),
                             mv_limit=t0["mv_limit"].astype(np.int32), num_ref=int(tap["num_ref"].max()), size=np.array([sw, sh, W, H], np.int32),
-                            motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if tag != "g2r" else np.zeros(0, np.int64),
+                            poc=tap["poc"][::nmb].astype(np.int32), ref_poc=tap["ref_poc"][::nmb].astype(np.int32),
+                            motion_cost_ref=tap["motion_cost_ref"][:, 1:, :, :].astype(np.int64) if ov.get("SearchMode") == "3" else np.zeros(0, np.int64),
+                            motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if sw * sh < 200000 else np.zeros(0, np.int64),
                             md5_264=md5(open(os.path.join(tmp, "o.264"), "rb").read()), md5_recon=md5(open(os.path.join(tmp, "o_rec.yuv"), "rb").read()),
-                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())))
+                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5)
         print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

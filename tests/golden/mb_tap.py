@@ -14,7 +14,8 @@ TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), 
                 ("motion_cost", "<i8", (8, 4)), ("all_mv", "<i2", (8, 16, 2)),
                 ("luma_level", "<i4", (16, 17)), ("luma_run", "<i4", (16, 17)), ("dc_level", "<i4", (3, 18)), ("dc_run", "<i4", (3, 18)),
                 ("chroma_level", "<i4", (8, 17)), ("chroma_run", "<i4", (8, 17)),
-                ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,))])
+                ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,)),
+                ("poc", "<i4"), ("ref_poc", "<i4", (16,)), ("motion_cost_ref", "<i8", (8, 4, 4))])
 
 
 def read(path):

@@ -43,13 +43,16 @@ def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_
 class SeqEncoder:
     """IPPP with num_ref sliding-window references, RDOptimization = 0, AdaptiveRounding = 0 (the scope of jmo_mbenc.c)."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0):
-        """lambdas[slice_type] = (lambda_mf[3], lambda_mdfp): JM's own tables (double arithmetic, never recomputed)."""
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0, search_mode=-1, epzs=None):
+        """lambdas[slice_type] = (lambda_mf[3], lambda_mdfp): JM's own tables (double arithmetic, never recomputed).
+        search_mode 3 = EPZS with the switches in `epzs` (defaults: the shipped .cfg files', pyjmo.EPZS_DEFAULTS)."""
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
         self.cabac = cabac     # SymbolMode: the quantiser clamps levels for CAVLC only
-        self.refs = []         # most recent first: (RefPic, (u, v), picture id)
+        self.search_mode, self.epzs = search_mode, dict(epzs or {})
+        self.refs = []         # most recent first: (RefPic, (u, v), picture id, (mv, refpoc) per 4x4 block of the stored picture)
         self.npic = 0
+        self.epzs_stats = []   # per P slice: (searches, alias_hits) of the oracle's EPZS
 
     def encode(self, cur, debug=False):
         """cur = (y, u, v) at the coded size.  Returns (records, debug records or None, reconstruction before the loop filter, after it)."""
@@ -65,9 +68,14 @@ class SeqEncoder:
         qpc = None
         for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac)
+            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode)
             qpc = cfg.qpc
-            res = pyjmo.encode_slice(cfg, cur16, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], pic, debug=debug)
+            ez = None
+            if self.search_mode == 3 and st == 0:       # picture order counts: 2 per frame (IPPP, PicOrderCntType 0)
+                ez = dict(params=self.epzs, poc_cur=2 * self.npic, poc_ref=[2 * r[2] for r in self.refs[:nref]], col=[r[3] for r in self.refs[:min(nref, 2)]])
+            res = pyjmo.encode_slice(cfg, cur16, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], pic, debug=debug, epzs=ez)
+            if ez is not None:
+                self.epzs_stats.append((int(ez["out"].searches), int(ez["out"].alias_hits)))
             if debug:
                 recs[first:first + num], dbg[first:first + num] = res
             else:
@@ -76,7 +84,10 @@ class SeqEncoder:
         pre = [p.copy() for p in pic.rec]
         mbs, mot = db_side_info(recs, slice_nr, st, self.qp, qpc, W, H, [r[2] for r in self.refs[:nref]] or [0], self.disable_idc)
         y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], 1, mbs, mot)
-        self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic))
+        refpoc = np.full(pic.ref_idx.shape, pyjmo.NO_REF, np.int32)     # the stored picture's motion, as EPZSSliceInit of later pictures reads it
+        for k, r in enumerate(self.refs[:nref]):
+            refpoc[pic.ref_idx == k] = 2 * r[2]
+        self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic, (pic.mv.copy(), refpoc)))
         self.refs = self.refs[:self.num_ref]
         self.npic += 1
         return recs, dbg, pre, (y, u, v)

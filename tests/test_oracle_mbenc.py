@@ -22,6 +22,11 @@ import mbenc_util  # noqa: E402
 from oracle import pyjmo  # noqa: E402
 
 
+EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFixedPredictors", aggressive="EPZSAggressiveWindow", temporal="EPZSTemporal",
+                 spatial_mem="EPZSSpatialMem", blocktype="EPZSBlockType", min_scale="EPZSMinThresScale", med_scale="EPZSMedThresScale", max_scale="EPZSMaxThresScale",
+                 sub_scale="EPZSSubPelThresScale")
+
+
 def load_case(tag):
     z = np.load(os.path.join(G, f"mb_low_{tag}.npz"))
     ov = dict(s.split("=") for s in z["overrides"])
@@ -30,10 +35,17 @@ def load_case(tag):
     didc = int(ov.get("DFDisableRefPSlice", 0))
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]], didc=didc,
-                nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)))
+                nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)), search_mode=int(ov.get("SearchMode", -1)),
+                epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov})
 
 
 def source_frames(c, tag):
+    clip = str(c["z"]["clip"]) if "clip" in c["z"].files else ""
+    if clip.startswith("motion:"):
+        import synth_motion
+        fr = synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1]))
+        assert hashlib.md5(np.concatenate(fr).tobytes()).hexdigest() == str(c["z"]["clip_md5"]), "the generated clip is not the one the golden records were made from"
+        return [pyjmo.load_frame(f, c["sw"], c["sh"], c["W"], c["H"], 1) for f in fr]
     if tag == "g2r":
         import bench
         data = bench.synthetic_frames(c["nfr"]) if hasattr(bench, "synthetic_frames") else None
@@ -50,7 +62,8 @@ def source_frames(c, tag):
 
 def run_case(tag):
     c = load_case(tag)
-    enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0))
+    enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
+                                search_mode=c["search_mode"], epzs=c["epzs"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -69,6 +82,15 @@ def run_case(tag):
 @pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "q1c", "q0c", "q0r"])     # q1c / q0c: CABAC (Main profile) at QP 28 / 0; q0r: CAVLC at QP 0
 def test_oracle_macroblock_pipeline_equals_the_reference_encoder(tag):
     run_case(tag)
+
+
+# EPZS (SearchMode = 3; oracle/jmo_mbenc_epzs.inc): the reference's clip with the shipped switches (q1e); on tests/golden/synth_motion.py's clips five
+# references (m5e), CABAC + slices that start mid-row (m2c), the other patterns / the aggressive window set / other thresholds (m3p), every optional
+# predictor set off (m2t)
+@pytest.mark.parametrize("tag", ["q1e", "m5e", "m2c", "m3p", "m2t"])
+def test_oracle_epzs_pipeline_equals_the_reference_encoder(tag):
+    enc = run_case(tag)
+    assert enc.epzs_stats and all(a == 0 for _, a in enc.epzs_stats)        # no search count near 65535 here: JM's 16-bit map stamp cannot alias
 
 
 def test_oracle_macroblock_pipeline_configs1_full_size():
