@@ -39,6 +39,8 @@ CASES = {
     "q0r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
     "g2r": (dict(RDO_OFF, **SYN1080), (1920, 1080), 2, True),                                          # SURVEY 8c G2r = BASELINE configs[1], RDO off
     # EPZS (SearchMode = 3) with the shipped EPZS switches (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid, EPZS sub-pel search)
+    # BASELINE configs[2] without its 8x8 transform and B pictures: 1080p, Main profile, CABAC, EPZS, five references configured (two exist by the third picture)
+    "g3e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 3, True),
     "q1e": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="1"), (176, 144), 3, False),          # the reference's own clip
     "m5e": (dict(RDO_OFF, SearchMode="3", SearchRange="32", FramesToBeEncoded="6"), (208, 160), 6, "motion:11"),         # five references: the ref > 0 exits, scaled predictors
     "m2c": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", SymbolMode="1", ProfileIDC="77", SliceMode="1", SliceArgument="40", FramesToBeEncoded="4"), (176, 144), 4, "motion:12"),   # CABAC, slices that start mid-row

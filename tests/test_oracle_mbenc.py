@@ -46,7 +46,7 @@ def source_frames(c, tag):
         fr = synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1]))
         assert hashlib.md5(np.concatenate(fr).tobytes()).hexdigest() == str(c["z"]["clip_md5"]), "the generated clip is not the one the golden records were made from"
         return [pyjmo.load_frame(f, c["sw"], c["sh"], c["W"], c["H"], 1) for f in fr]
-    if tag == "g2r":
+    if tag == "g2r" or clip == "True":
         import bench
         data = bench.synthetic_frames(c["nfr"]) if hasattr(bench, "synthetic_frames") else None
         if data is None:
@@ -96,6 +96,13 @@ def test_oracle_epzs_pipeline_equals_the_reference_encoder(tag):
 def test_oracle_macroblock_pipeline_configs1_full_size():
     """BASELINE configs[1] with RDOptimization = 0 (G2r): I + P picture of the synthetic 1080p clip, 16 320 macroblocks (about half a minute)."""
     run_case("g2r")
+
+
+def test_oracle_epzs_configs2_full_size():
+    """BASELINE configs[2] as far as the pipeline goes (1080p, Main profile, CABAC, EPZS, RDO off, P pictures only, 4x4 transform): I + 2 P pictures, 24 480 macroblocks,
+    a million EPZS searches; the stamp of JM's visited map wraps round ten times per picture without a single aliased candidate on this clip."""
+    enc = run_case("g3e")
+    assert [s for s, _ in enc.epzs_stats] == [334560, 669120] and all(a == 0 for _, a in enc.epzs_stats)
 
 
 def test_record_layout():
