@@ -526,7 +526,7 @@ int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pitchY, uint8_
  * chroma_residual_coding (macroblock.c:1439), the skip test (md_low.c:658).  What the call leaves behind per macroblock is what
  * write_macroblock (macroblock.c:2810) and DeblockFrame read: one jmhip_mb_record.  The host keeps the entropy coder.
  *
- * Scope: frame macroblocks, 4:2:0, 8 bit, 4x4 transform, no adaptive rounding / weighted prediction / rate control, SearchMode -1,
+ * Scope: frame macroblocks, 4:2:0, 8 bit, 4x4 transform, no adaptive rounding / weighted prediction / rate control, SearchMode -1 or 3 (EPZS),
  * unconstrained intra prediction, num_ref * window bytes within the LDS (5 references at SearchRange 32, 16 at 16); anything else
  * returns JMHIP_EUNSUPPORTED and the caller keeps JM's own function.
  * The source picture is the one jmhip_set_current_frame loaded; the references are slots filled by jmhip_set_reference[_chroma] or
@@ -578,7 +578,18 @@ typedef struct {
   int32_t num_slices;           /* 0 or 1: one slice.  n > 1: the call covers n consecutive slices of num_mb macroblocks each (the last one ends with the
                                    picture), same parameters, slice_nr counting up -- SliceMode 1 pictures: the slices' wavefronts run side by side */
   int32_t symbol_mode;          /* currSlice->symbol_mode: 0 = CAVLC (levels clamped to CAVLC_LEVEL_LIMIT = 2063: quant4x4_normal.c:84, :160, :233, quantChroma_normal.c:69), 1 = CABAC (no clamp) */
-  int32_t reserved_[3];
+  int32_t search_mode;          /* 0: full_search_motion_estimation (JM's SearchMode -1); 3: EPZS (SearchMode 3) with EPZSSubPelGrid = 1 and EPZSSubPelME = 1,
+                                   the shipped settings: EPZS_integer_motion_estimation lencod/src/me_epzs_int.c:42, its sub-macroblock variant :437,
+                                   EPZS_sub_pel_motion_estimation me_epzs_sub.c:30 (start_qp must be 1) */
+  int32_t reserved_[2];
+  /* EPZS only (me_epzs_common.c:423 EPZSStructInit, :620 EPZSSliceInit); ignored with search_mode 0 */
+  int32_t epzs_pattern, epzs_dual, epzs_fixed, epzs_aggressive, epzs_temporal, epzs_spatial_mem, epzs_blocktype;   /* EPZSPattern (0..5), EPZSDualRefinement (0..6),
+                                   EPZSFixedPredictors (0..3), EPZSAggressiveWindow, EPZSTemporal, EPZSSpatialMem, EPZSBlockType */
+  int32_t epzs_min_scale, epzs_med_scale, epzs_max_scale, epzs_sub_scale;   /* EPZSMinThresScale, EPZSMedThresScale, EPZSMaxThresScale, EPZSSubPelThresScale */
+  int32_t epzs_reserved_;
+  int32_t poc_cur;              /* enc_picture->poc */
+  int32_t poc_ref[JMHIP_MB_MAX_REF];   /* listX[LIST_0][r]->poc: EPZS scales its predictors by picture distances; the temporal predictors are the vectors
+                                   jmhip_reference_from_recon kept with slots ref_slot[0] / [1] (a slot loaded by jmhip_set_reference has none: zero vectors) */
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);

@@ -137,14 +137,15 @@ extern int __real_putc(int, FILE *);
 extern int __real_fputc(int, FILE *);
 extern int __real_fflush(FILE *);
 extern int __vfprintf_chk(FILE *, int, const char *, va_list);
-int __wrap_putc(int c, FILE *f) { return f == null_sink ? c : __real_putc(c, f); }
-int __wrap_fputc(int c, FILE *f) { return f == null_sink ? c : __real_fputc(c, f); }
-int __wrap_fflush(FILE *f) { return (f && f == null_sink) ? 0 : __real_fflush(f); }
+#define IS_SINK(f) (null_sink && (f) == null_sink)            /* a NULL FILE (or any other) reaches libc while no sink exists */
+int __wrap_putc(int c, FILE *f) { return IS_SINK(f) ? c : __real_putc(c, f); }
+int __wrap_fputc(int c, FILE *f) { return IS_SINK(f) ? c : __real_fputc(c, f); }
+int __wrap_fflush(FILE *f) { return IS_SINK(f) ? 0 : __real_fflush(f); }
 int __wrap_fprintf(FILE *f, const char *fmt, ...)             /* a build without _FORTIFY_SOURCE calls fprintf itself */
 {
   va_list ap;
   int r;
-  if (f == null_sink) return 0;
+  if (IS_SINK(f)) return 0;
   va_start(ap, fmt);
   r = vfprintf(f, fmt, ap);
   va_end(ap);
@@ -154,7 +155,7 @@ int __wrap___fprintf_chk(FILE *f, int flag, const char *fmt, ...)
 {
   va_list ap;
   int r;
-  if (f == null_sink) return 0;
+  if (IS_SINK(f)) return 0;
   va_start(ap, fmt);
   r = __vfprintf_chk(f, flag, fmt, ap);
   va_end(ap);
@@ -1256,7 +1257,12 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     if (!G.part_mbpipe) why = "part mbpipe not selected";
     else if (p->rdopt != 0) why = "RDOptimization != 0";
     else if (p_Vid->yuv_format != YUV420) why = "not 4:2:0";
-    else if (p->SearchMode[0] != FULL_SEARCH) why = "SearchMode != -1";
+    else if (p->SearchMode[0] != FULL_SEARCH && p->SearchMode[0] != EPZS) why = "SearchMode other than -1 (full search) and 3 (EPZS)";
+    else if (p->SearchMode[0] == EPZS && (!p->EPZSSubPelGrid || p->EPZSSubPelME != 1 || p->HMEEnable)) why = "EPZS without EPZSSubPelGrid = 1 / EPZSSubPelME = 1, or with HME";
+    else if (p->DisableMEPrediction) why = "DisableMEPrediction";
+    else if (p->SkipDeBlockNonRef || p->DisposableP) why = "SkipDeBlockNonRef / DisposableP (pictures that are not deblocked stay on the device)";
+    else if (p->RDPictureDeblocking || p->RDPictureDecision) why = "RDPictureDecision / RDPictureDeblocking";
+    else if (p->redundant_pic_flag) why = "UseRedundantPicture";
     else if (p->Transform8x8Mode != 0) why = "Transform8x8Mode";
     else if (p->AdaptiveRounding != 0) why = "AdaptiveRounding";
     else if (p->WeightedPrediction || p->WeightedBiprediction) why = "weighted prediction";
@@ -1277,7 +1283,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->HierarchicalCoding || p->PicInterlace != FRAME_CODING || p->MbInterlace != FRAME_CODING) why = "hierarchical / interlaced coding";
     else if (R < 1 || R > 32) why = "SearchRange outside 1..32";
     else if (p_Vid->max_num_references > JMHIP_MB_MAX_REF) why = "more than 16 references";
-    else if ((size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
+    else if (p->SearchMode[0] == FULL_SEARCH && (size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
     else if (p_Vid->bitdepth_chroma_qp_scale != 0) why = "chroma QP scale";
     P.ok = why == NULL;
     if (!P.ok && G.part_mbpipe && p->rdopt == 0)
@@ -1351,6 +1357,15 @@ static void pipe_run_slice(Macroblock *currMB)
         }
       }
   prm.symbol_mode = currSlice->symbol_mode == CABAC;        /* the entropy coder stays JM's; the quantiser clamps levels for CAVLC only */
+  if (p_Inp->SearchMode[0] == EPZS) {                       /* EPZSStructInit / EPZSSliceInit read these (me_epzs_common.c:423, :620) */
+    prm.search_mode = 3;
+    prm.epzs_pattern = p_Inp->EPZSPattern; prm.epzs_dual = p_Inp->EPZSDual; prm.epzs_fixed = p_Inp->EPZSFixed; prm.epzs_aggressive = p_Inp->EPZSAggressiveWindow;
+    prm.epzs_temporal = p_Inp->EPZSTemporal[0]; prm.epzs_spatial_mem = p_Inp->EPZSSpatialMem; prm.epzs_blocktype = p_Inp->EPZSBlockType;
+    prm.epzs_min_scale = p_Inp->EPZSMinThresScale[0]; prm.epzs_med_scale = p_Inp->EPZSMedThresScale[0]; prm.epzs_max_scale = p_Inp->EPZSMaxThresScale[0];
+    prm.epzs_sub_scale = p_Inp->EPZSSubPelThresScale[0];
+    prm.poc_cur = p_Vid->enc_picture->poc;
+    for (r = 0; r < prm.num_ref; r++) prm.poc_ref[r] = currSlice->listX[LIST_0][r]->poc;
+  }
   prm.df_disable_idc = currMB->DFDisableIdc; prm.df_alpha_c0 = currMB->DFAlphaC0Offset; prm.df_beta = currMB->DFBetaOffset;
   if (currMB->qp_scaled[0] != currMB->qp) { fprintf(stderr, "jmhip adapter: macroblock pipeline: luma QP scale\n"); exit(70); }
   /* SliceMode 1: every slice of the picture has the same parameters (no rate control here), so all of them are launched with the first one and

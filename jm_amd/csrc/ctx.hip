@@ -189,6 +189,7 @@ extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int r = jmhip_check_job_error(ctx);
   if (r) return r;
+  if ((r = jmhip_check_mb_error(ctx))) return r;
   return jmhip_check_deblock_error(ctx);
 }
 
@@ -252,6 +253,7 @@ extern "C" int jmhip_set_reference_dev(jmhip_ctx *ctx, int32_t slot, const uint8
 {
   if (!ctx || !d_luma || slot < 0 || slot >= ctx->cfg.num_ref_slots || pitch_bytes < ctx->W)
     return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_dev: bad argument") : JMHIP_EINVAL;
+  jmhip_mb_slot_motion_reset(ctx, slot);
   return jmhip_launch_subplanes(ctx, d_luma, pitch_bytes, ctx->d_sub[slot]);
 }
 
@@ -261,6 +263,7 @@ extern "C" int jmhip_set_reference(jmhip_ctx *ctx, int32_t slot, const uint16_t 
     return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference: bad argument") : JMHIP_EINVAL;
   int r = upload_u16_as_u8(ctx, luma, pitch_samples, ctx->W, ctx->H, ctx->d_stage, ctx->cur_pitch);
   if (r) return r;
+  jmhip_mb_slot_motion_reset(ctx, slot);
   r = jmhip_launch_subplanes(ctx, ctx->d_stage, ctx->cur_pitch, ctx->d_sub[slot]);
   if (r) return r;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -46,6 +46,7 @@ struct jmhip_ctx {
   int *d_mb_order;       // wavefront order of the slice's macroblocks
   int mb_order_first, mb_order_num, mb_order_per;
   unsigned mb_epoch;
+  int mb_launched;       // a pipeline launch has happened since its error word was last read
   int mb_grid;           // jmhip_set_pipeline_workgroups (0: 256)
   void *d_mb_records;    // jmhip_mb_record per macroblock of the picture
   void *d_mb_dbmb, *d_mb_dbmo;   // loop-filter side information written by the pipeline
@@ -54,6 +55,11 @@ struct jmhip_ctx {
   void *d_h_mb_records; unsigned *d_h_mb_flags;   // the device's addresses of the two
   int mb_streaming, mb_stream_first, mb_stream_num;
   void *d_mb_prof;       // JMHIP_MB_PROF=1: time stamps per macroblock
+  // EPZS inside the pipeline (search_mode 3), allocated on its first use
+  int *d_ez_state;       // per macroblock: its columns of p_EPZS->distortion / p_motion (28 + 112 x 16 ints)
+  int *d_ez_col;         // co-located vectors of the running launch, per 4x4 block
+  void *d_mot;           // the current picture's motion per 4x4 block {packed vector, poc referred to}: what jmhip_reference_from_recon keeps with the slot
+  void **d_slot_mot;     // [num_ref_slots] the same of the pictures in the slots ({0, none} after jmhip_set_reference*)
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];
@@ -77,6 +83,8 @@ int jmhip_check_job_error(jmhip_ctx *ctx);      // me_fullsearch.hip: device-sid
 void jmhip_launch_check_me_jobs(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, int n);
 void jmhip_launch_check_subpel_jobs(jmhip_ctx *ctx, const jmhip_subpel_job *d_jobs, int n);
 void jmhip_mb_free(jmhip_ctx *ctx);   // mbpipe.hip
+int jmhip_check_mb_error(jmhip_ctx *ctx);   // mbpipe.hip: the pipeline's sticky error word, read and cleared
+void jmhip_mb_slot_motion_reset(jmhip_ctx *ctx, int slot);   // mbpipe.hip: a slot loaded from outside the pipeline carries no motion
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);
 int jmhip_launch_deblock_rows(jmhip_ctx *ctx, uint8_t *d_Y, int pitchY, uint8_t *d_U, uint8_t *d_V, int pitchC,
                               const jmhip_db_mb *d_mbs, const jmhip_db_motion *d_motion, int direct8x8);

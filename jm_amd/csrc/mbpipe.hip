@@ -21,6 +21,7 @@
 //   * Sub-pel refinement: (candidate, 4x4 sub-block) items over the lanes, Hadamard SATD from the 16 quarter-pel planes in HBM/L2 with JM's
 //     per-sub-block origin clamp (UMVLine4X), JM's strict-'<' scan replayed on the nine sums.
 // No MFMA: the path is byte / integer add, sub, shift, abs, min.
+#include <mutex>
 #include "jmhip_internal.h"
 #include "me_common.h"
 
@@ -29,9 +30,6 @@ typedef uint32_t u32;
 typedef uint8_t u8;
 
 #define MB_THREADS 512
-// 1: in the 8x8 blocks 1-3 every sub-mode search is shared by two waves (candidate rows split, hand-over through LDS).  Measured on the MI355X it is
-// no faster than one wave per search (38.5 vs 39.5 us per block: a row costs each of the two waves 1.5x what it costs a lone wave, and the hand-over
-// adds 1.3 us per search), so it is off; the parity tests pass either way.
 #define MAXC 0x7fffffff
 #define EDGE_WORDS 17                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
                                             // 6/7 right U/V columns, 8 ipredmode (bytes 0-3 bottom row, 4-7 right column), 9-12 / 13-16 mv_info of the
@@ -46,7 +44,7 @@ __device__ __forceinline__ int mvy(int p) { return p >> 16; }
 __device__ __forceinline__ int mvpack(int x, int y) { return (x & 0xffff) | (y << 16); }
 __device__ __forceinline__ int median3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
-static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 1492, "record sizes of include/jmhip.h");
+static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 1608, "record sizes of include/jmhip.h");
 
 struct PipeArgs {
   jmhip_slice_params p;
@@ -70,6 +68,11 @@ struct PipeArgs {
   jmhip_mb_record *hrecords;                 // streaming to the host (jmhip_encode_slice_begin): pinned, device-visible copies of the records
   unsigned *hflags;                          // ... and per macroblock the epoch of the launch whose record is complete there; null otherwise
   int prof_mode;                             // JMHIP_MB_PROF value: 1 = a 4x4 search's parts in stamps 18..22, 2 = an Intra4x4 block's parts there
+  // EPZS (search_mode 3)
+  const int *col;                            // [H / 4][W / 4] co-located vectors scaled to this picture (k_epzs_coloc), or null (EPZSTemporal = 0)
+  int *ez_state;                             // per macroblock: its four columns of p_EPZS->distortion [7][4] and p_EPZS->p_motion [num_ref][7][4][4] when it was done
+  int ez_words;                              // ints per macroblock there: 28 + 112 num_ref
+  u64 *mot_out;                              // per 4x4 block of the picture {packed vector, poc of the picture referred to}: later pictures' temporal predictors
   unsigned long long *prof;                  // profiling aid (JMHIP_MB_PROF=1): 24 time stamps (100 MHz) per macroblock, or null
 };
 
@@ -1036,4 +1039,5 @@ __device__ __forceinline__ void ihadamard4x4_jm(int (&m)[16])
 
 #include "mbpipe_intra.inc"
 #include "mbpipe_final.inc"
+#include "mbpipe_epzs.inc"
 #include "mbpipe_kernel.inc"

@@ -22,9 +22,17 @@ from oracle import pyjmo  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0):
-    """jmhip_slice_params from the oracle's configuration record (same meaning field by field) plus JM's quantiser tables"""
+def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None, poc_cur=0):
+    """jmhip_slice_params from the oracle's configuration record (same meaning field by field) plus JM's quantiser tables.
+    epzs: the EPZS switches (dict, pyjmo.EPZS_DEFAULTS' keys) when cfg.search_mode is 3; picture order counts are 2 x the picture ids."""
     p = np.zeros(1, L.SLICE_PARAMS)
+    if cfg.search_mode == 3:
+        p["search_mode"] = 3
+        for k, v in dict(pyjmo.EPZS_DEFAULTS, **(epzs or {})).items():
+            p["epzs_" + k] = v
+        p["poc_cur"] = poc_cur
+        for r, i in enumerate(ref_ids):
+            p["poc_ref"][0, r] = 2 * i
     for k in ("slice_type", "first_mb", "num_mb", "qp", "qpc", "search_range", "num_ref", "lambda_mdfp", "max_mvd", "intra4_valid", "intra16_valid", "subpel", "start_qp"):
         p[k] = getattr(cfg, k)
     p["slice_nr"] = slice_nr
@@ -47,8 +55,9 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0):
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None):
         self.cabac = cabac
+        self.search_mode, self.epzs = search_mode, dict(epzs or {})
         import jm_amd.lib as L
         self.together = together      # all slices of a picture in one launch (num_slices), as the adapter does for SliceMode 1
         self.L = L
@@ -68,8 +77,8 @@ class DevSeqEncoder:
         slices = mbenc_util.slices_of(nmb, self.slice_mbs)
         for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac)
-            prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc)
+            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode)
+            prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc, self.epzs, 2 * self.npic)
             if timing is not None:
                 J.enable_timing(True)
             if self.together and len(slices) > 1:
@@ -105,11 +114,23 @@ def load_case(tag):
     lam = {2: ([int(x) for x in z["lambda_i"][:3]], int(z["lambda_i"][3])), 0: ([int(x) for x in z["lambda_p"][:3]], int(z["lambda_p"][3]))}
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]],
-                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)))
+                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)),
+                search_mode=int(ov.get("SearchMode", -1)), epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov})
+
+
+EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFixedPredictors", aggressive="EPZSAggressiveWindow", temporal="EPZSTemporal",
+                 spatial_mem="EPZSSpatialMem", blocktype="EPZSBlockType", min_scale="EPZSMinThresScale", med_scale="EPZSMedThresScale", max_scale="EPZSMaxThresScale",
+                 sub_scale="EPZSSubPelThresScale")
 
 
 def clip_bytes(tag, c):
-    if tag == "g2r":
+    clip = str(c["z"]["clip"]) if "clip" in c["z"].files else ""
+    if clip.startswith("motion:"):
+        import synth_motion
+        data = np.concatenate(synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1])))
+        assert hashlib.md5(data.tobytes()).hexdigest() == str(c["z"]["clip_md5"]), "the generated clip is not the one the golden records were made from"
+        return data
+    if tag == "g2r" or clip == "True":
         import tempfile
         import bench
         with tempfile.TemporaryDirectory() as t:
@@ -123,12 +144,15 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
-    mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks)."""
+    mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
+    EPZS (SearchMode 3): the reference's clip (q1e), five references (m5e), CABAC + slices that start mid-row (m2c), the other patterns and window set
+    (m3p), every optional predictor set off (m2t), and BASELINE configs[2]'s search at 1920x1080 (g3e: Main profile, CABAC, 24 480 macroblocks)."""
     c = load_case(tag)
-    enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"])
+    enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
+                        search_mode=c["search_mode"], epzs=c["epzs"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     data = clip_bytes(tag, c)
     fs = c["sw"] * c["sh"] * 3 // 2

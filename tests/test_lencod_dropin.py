@@ -119,11 +119,20 @@ def run_rdo_off_case(tag, tmp, exe=EXE, env_extra=None, frames=None):
         ov["FramesToBeEncoded"] = str(frames)
     for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
         shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
-    if tag == "g2r":
+    clip = str(z["clip"]) if "clip" in z.files else ""
+    if tag == "g2r" or clip == "True":
         import sys
         sys.path.insert(0, ROOT)
         import bench
         bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), int(ov["FramesToBeEncoded"]))
+    elif clip.startswith("motion:"):                       # tests/golden/synth_motion.py at the case's size (the overrides name the file)
+        import sys
+        sys.path.insert(0, G)
+        import synth_motion
+        sw, sh = int(z["size"][0]), int(z["size"][1])
+        data = np.concatenate(synth_motion.motion_clip(sw, sh, int(ov["FramesToBeEncoded"]), int(clip.split(":")[1])))
+        assert frames or hashlib.md5(data.tobytes()).hexdigest() == str(z["clip_md5"])
+        data.tofile(os.path.join(tmp, "motion.yuv"))
     args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
     for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
         args += ["-p", f"{k}={v}"]
@@ -147,7 +156,8 @@ def frame_times(stdout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,nmb_total", [("q1r", 297), ("q5r", 297), ("q4r", 297), ("q4s", 297), ("q1c", 297), ("q0c", 297), ("q0r", 297)])
+@pytest.mark.parametrize("tag,nmb_total", [("q1r", 297), ("q5r", 297), ("q4r", 297), ("q4s", 297), ("q1c", 297), ("q0c", 297), ("q0r", 297),
+                                           ("q1e", 297), ("m5e", 780), ("m2c", 396), ("m3p", 396), ("m2t", 384)])     # the last five: EPZS (SearchMode 3)
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction
@@ -161,7 +171,7 @@ def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total
     rep = pipeline_report(err)
     c = counters(err)
     assert rep and rep["mbs"] == nmb_total, (rep, err[-1500:])
-    assert c["passed"] == 0 and c["fs"] == 0 and c["subpel"] == 0 and c["tq4"] == 0, c        # nothing per block, nothing on the host
+    assert c["passed"] == 0 and c["fs"] == 0 and c["subpel"] == 0 and c["tq4"] == 0 and c["eval"] == 0, c        # nothing per block (no jmhip_me_eval either), nothing on the host
     assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), (tag, "bitstream differs from CPU JM", rep)
     assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), (tag, "reconstruction differs from CPU JM", rep)
 
@@ -195,8 +205,10 @@ def wild_clip(path, W, H, nfr, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ov", [dict(SearchRange="32", NumberReferenceFrames="2"), dict(SearchRange="16", NumberReferenceFrames="1", QPISlice="36", QPPSlice="38"),
-                                dict(SearchRange="8", NumberReferenceFrames="3", SliceMode="1", SliceArgument="100", SymbolMode="1", ProfileIDC="77", QPPSlice="22")],
-                         ids=["sr32_2ref", "sr16_qp38", "sr8_3ref_slices_cabac"])
+                                dict(SearchRange="8", NumberReferenceFrames="3", SliceMode="1", SliceArgument="100", SymbolMode="1", ProfileIDC="77", QPPSlice="22"),
+                                dict(SearchMode="3", SearchRange="32", NumberReferenceFrames="4", SymbolMode="1", ProfileIDC="77"),
+                                dict(SearchMode="3", SearchRange="16", NumberReferenceFrames="2", SliceMode="1", SliceArgument="150", QPISlice="34", QPPSlice="36", EPZSPattern="5", EPZSDualRefinement="2")],
+                         ids=["sr32_2ref", "sr16_qp38", "sr8_3ref_slices_cabac", "epzs_4ref_cabac", "epzs_2ref_slices_pmvfast"])
 def test_lencod_macroblock_pipeline_side_by_side_on_a_wild_clip(tmp_path, ov):
     """No golden file: CPU JM (oracle/_ref/lencod.exe) and the drop-in encoder run on the same generated CIF clip here on the GPU box (10 pictures:
     large changing global motion, a moving object, brightness change, a scene cut, noise) and must write the same bitstream and reconstruction."""
@@ -273,6 +285,25 @@ def test_lencod_macroblock_pipeline_configs1_full_size_1080p(tmp_path):
     assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
     assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
     print(f"configs[1], RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
+
+
+@pytest.mark.gpu
+def test_lencod_macroblock_pipeline_configs2_epzs_1080p(tmp_path):
+    """BASELINE.json configs[2]'s search end to end at full size with RDOptimization = 0 (g3e: 1080p, Main profile, CABAC, EPZS with the shipped switches,
+    five references configured, I + 2 P pictures): every EPZS search runs inside the device's macroblock pipeline -- zero jmhip_me_eval calls, zero calls
+    passed to JM -- and the bitstream and the reconstruction equal CPU JM's."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, z = run_rdo_off_case("g3e", str(tmp_path))
+    err, out = r.stderr.decode(errors="replace"), r.stdout.decode(errors="replace")
+    assert r.returncode == 0, (out[-1500:], err[-1500:])
+    rep = pipeline_report(err)
+    c = counters(err)
+    assert rep and rep["mbs"] == 3 * 8160 and rep["slices"] == 3, (rep, err[-1500:])
+    assert c["passed"] == 0 and c["eval"] == 0 and c["evalp"] == 0 and c["fs"] == 0 and c["subpel"] == 0, c
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
+    print(f"configs[2] (EPZS, CABAC), RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
 
 
 def run_2160p(tag, tmp, env_extra=None):
