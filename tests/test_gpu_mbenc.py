@@ -198,11 +198,14 @@ LAMBDAS = {2: ([192, 192, 192], 192), 0: ([192, 192, 192], 192)}     # JM's tabl
     (320, 192, 32, 3, 50, 36, 3),     # slices that start mid-row, three references, coarse quantiser
     (208, 160, 8, 1, 13, 20, 4),      # one slice per macroblock row, fine quantiser
     (16, 16, 16, 1, 0, 28, 5),        # a single macroblock
+    (240, 176, 8, 5, 0, 28, 8),       # five references at SearchRange 8 ...
+    (240, 176, 16, 5, 0, 32, 9),      # ... and 16, beyond QCIF
+    (192, 128, 32, 4, 0, 24, 10),     # four references at SearchRange 32
 ])
 def test_encode_slice_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed):
     f = int(192 * 2 ** ((qp - 28) / 6))          # any positive factors serve: they are inputs of both sides
     lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
-    nfr = 3 if num_ref < 3 else 4
+    nfr = 3 if num_ref < 3 else (4 if num_ref < 4 else num_ref + 1)
     frames = synthetic_clip(W, H, nfr, seed)
     together, slice_mbs = slice_mbs < 0, abs(slice_mbs)
     dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, together=together)
@@ -275,6 +278,53 @@ def test_encode_slice_vs_oracle_hard_content(kind, R, num_ref, qp):
         if kind == "chroma_step" and n == 1:                               # the case is what it claims to be
             big = int(np.abs(recs["chroma_dc"].astype(int)).max())
             assert big == 2063 if not cabac else big > 2063, (kind, n, big, cabac)
+
+
+@pytest.mark.parametrize("lam_f,kind", [(13999, "noise"), (14000, "ramp"), (60000, "noise"), (60000, "stripes"), (60000, "still")])
+def test_encode_slice_key_limits(lam_f, kind):
+    """jmhip_encode_slice takes lambda factors up to 60000; the searches' 32-bit (cost << 7 | rank) keys and the sub-pel scans' (cost << 4 | position)
+    keys must hold them: cost < 2^25 resp. 2^27 (SAD << 5 < 2^21, rate = lambda x at most 46 bits).  13999 / 14000 is where the per-call kernels hand
+    over to their 64-bit path; the pipeline has one path, pinned here against the oracle at the largest factors it accepts."""
+    W, H, R = 96, 80, 32
+    lam = {2: ([lam_f] * 3, lam_f), 0: ([lam_f, lam_f - 1, lam_f], lam_f)}
+    frames = hard_clip(kind, W, H, 3, 5)
+    dev = DevSeqEncoder(W, H, 40, R, 2, lam, 0)
+    ora = mbenc_util.SeqEncoder(W, H, 40, R, 2, lam, 0)
+    for n, raw in enumerate(frames):
+        recs, pre, post = dev.encode(raw, W, H)
+        orecs, _, opre, opost = ora.encode(pyjmo.load_frame(raw, W, H, W, H, 1))
+        d = first_difference(mb_tap.canonical(orecs), mb_tap.canonical(as_oracle_records(recs)))
+        assert d is None, (lam_f, kind, n, d)
+
+
+@pytest.mark.parametrize("W,H,R,num_ref,slice_mbs,qp,seed,epzs", [
+    (208, 160, 32, 3, 0, 28, 31, {}),                                   # the shipped switches
+    (208, 160, 16, 2, 26, 34, 32, dict(pattern=1, dual=1)),             # square / small diamond, slices of two macroblock rows
+    (64, 48, 32, 2, 0, 28, 33, dict(pattern=3, dual=4, fixed=1)),       # a picture smaller than the search range: every range check bites
+    (176, 144, 8, 5, -33, 22, 34, dict(pattern=5, dual=5, aggressive=1)),   # five references, the extended window set (95 predictors), slices in one launch
+    (16, 16, 16, 1, 0, 28, 35, {}),                                     # a single macroblock
+    (320, 64, 32, 1, 0, 40, 36, dict(temporal=0, blocktype=0)),
+])
+def test_encode_slice_epzs_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed, epzs):
+    """EPZS inside the pipeline (k_mb_pipe_epzs) against the oracle's restatement (pinned to the real encoder by the m* / q1e / g3e records) on
+    tests/golden/synth_motion.py's clips: objects with their own velocities, so predictor sets, early exits, both refinement rounds and several
+    references all get used."""
+    import synth_motion
+    f = int(192 * 2 ** ((qp - 28) / 6))
+    lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    nfr = max(4, num_ref + 2)
+    frames = synth_motion.motion_clip(W, H, nfr, seed) if W >= 64 and H >= 48 else synthetic_clip(W, H, nfr, seed)
+    together, slice_mbs = slice_mbs < 0, abs(slice_mbs)
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, together=together, search_mode=3, epzs=epzs)
+    ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, search_mode=3, epzs=epzs)
+    for n, raw in enumerate(frames):
+        recs, pre, post = dev.encode(raw, W, H)
+        orecs, _, opre, opost = ora.encode(pyjmo.load_frame(raw, W, H, W, H, 1))
+        d = first_difference(mb_tap.canonical(orecs), mb_tap.canonical(as_oracle_records(recs)))
+        assert d is None, (n, d)
+        for a, b in zip(post, opost):
+            assert np.array_equal(a, b.astype(np.uint8)), (n, "reconstruction after the loop filter")
+    assert all(a == 0 for _, a in ora.epzs_stats)
 
 
 def test_sequences_side_by_side_on_their_own_streams():
