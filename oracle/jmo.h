@@ -261,6 +261,10 @@ typedef struct {
   int32_t refbits[JMO_MAX_REF]; /* p_Vid->refbits, mv_search.c:376-385 */
   int32_t cabac;                /* currSlice->symbol_mode == CABAC: levels are not clamped to CAVLC_LEVEL_LIMIT (quant4x4_normal.c:84) */
   int32_t search_mode;          /* SearchMode: -1 (or 0 here: same thing) full search, 3 EPZS with EPZSSubPelGrid = 1 and EPZSSubPelME = 1 (needs a jmo_epzs_cfg) */
+  int32_t transform8x8;         /* Transform8x8Mode: 0, or 1 = the 8x8 transform beside the 4x4 one (High profile): transform_decision for 16x16 / 16x8 / 8x16, the P8x8
+                                   pass with 8x8 blocks only, Intra8x8, 8x8 Hadamard SATD in the sub-pel search of blocks of 8x8 samples and more */
+  int32_t q_offset8[2];         /* quantiser offsets of the 8x8 transform, inter / intra (as q_offset) */
+  int32_t intra8_valid;         /* enc_mb.valid[I8MB] (mode_decision.c:127) */
 } jmo_mbenc_cfg;
 
 /* EPZS (SearchMode = 3): the configuration's switches and what EPZSSliceInit (lencod/src/me_epzs_common.c:620) reads from the decoded picture buffer. */
@@ -279,10 +283,11 @@ typedef struct {
 
 /* What encode_one_macroblock_low leaves behind for write_macroblock (lencod/src/macroblock.c:2810), one record per macroblock. */
 typedef struct {
-  int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB (MBModeTypes) */
+  int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB, 13 I8MB (MBModeTypes) */
   int8_t   i16mode;             /* currMB->i16mode as find_sad_16x16 left it */
   int8_t   c_ipred_mode;        /* currMB->c_ipred_mode as rdo_low_intra_chroma_decision left it (written for intra macroblocks only) */
-  int8_t   pad0;
+  int8_t   transform8x8;        /* currMB->luma_transform_size_8x8_flag.  With it the 64 levels of 8x8 block b8 lie in the frame zig-zag order of the 8x8 scan at
+                                   luma[4 * b8 + (s >> 4)][s & 15] (JM's CAVLC lists are that order de-interleaved: list s & 3, place s >> 2) */
   int16_t  cbp;                 /* currMB->cbp */
   int16_t  pad1;
   uint64_t cbp_blk;             /* currMB->cbp_blk */

@@ -131,6 +131,20 @@ static void get_orig_block(const enc *e, int bx, int by, int bsx, int bsy, jmo_p
   for (j = 0; j < bsy; j++) for (i = 0; i < bsx; i++) o[j * bsx + i] = e->orig[(by + j) * 16 + bx + i];
 }
 
+/* the same with 8x8 Hadamard blocks (p_Vid->distortion8x8 = distortion8x8SATD) */
+static jmo_dist satd_blocks8(const jmo_pel *orig, int opitch, const jmo_pel *pred, int ppitch, int w, int h)
+{
+  jmo_dist c = 0;
+  int by, bx, j, i;
+  int16_t d[64];
+  for (by = 0; by < h; by += 8)
+    for (bx = 0; bx < w; bx += 8) {
+      for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) d[j * 8 + i] = (int16_t)((int)orig[(by + j) * opitch + bx + i] - (int)pred[(by + j) * ppitch + bx + i]);
+      c += ((jmo_dist)jmo_hadamard_sad8x8(d)) << JMO_LAMBDA_BITS;
+    }
+  return c;
+}
+
 /* SATD of the macroblock against a 16x16 prediction, sixteen 4x4 blocks (p_Vid->distortion4x4 = distortion4x4SATD, MDDistortion = 2) */
 static jmo_dist satd_blocks(const jmo_pel *orig, int opitch, const jmo_pel *pred, int ppitch, int w, int h)
 {
@@ -199,7 +213,7 @@ static jmo_dist block_motion_search_epzs(enc *e, int ref, int blocktype, int mb_
     int j, i;
     for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s;
     jmo_luma_pred(&e->ref[0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
-    cost = satd_blocks(e->orig, 16, pr, 16, 16, 16) - (jmo_dist)c->lambda_mf[2] * 8;
+    cost = (c->transform8x8 ? satd_blocks8(e->orig, 16, pr, 16, 16, 16) : satd_blocks(e->orig, 16, pr, 16, 16, 16)) - (jmo_dist)c->lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = s; }
   }
   *out = mv;
@@ -266,6 +280,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
    * half- and quarter-pel metrics are the same, mv_search.c:445-446: the quarter-pel stage then keeps the half-pel minimum and skips position 0) ---- */
   if (c->subpel) {
     jmo_mv sp[9];
+    const int test8x8 = c->transform8x8 && blocktype <= 4;      /* mv_block.test8x8: mv_search.c:1624 (Transform8x8Mode), :1768 (... && blocktype == 4) */
     jmo_spiral(1, sp);
     check_position0 = (c->slice_type != 1 && ref == 0 && blocktype == 1 && mv.x == 0 && mv.y == 0);
     min_mcost = JMO_DIST_MAX;                                 /* mv_search.c:971-974 */
@@ -273,7 +288,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
       const int qx = mv.x + (sp[pos].x << 1), qy = mv.y + (sp[pos].y << 1);
       mcost = mv_cost(c->lambda_mf[1], qx, qy, pred.x, pred.y);
       if (mcost >= min_mcost) continue;
-      mcost += jmo_compute_satd(rp, orig, bsx, bsy, 0, min_mcost - mcost, qx + pxp, qy + pyp);
+      mcost += jmo_compute_satd(rp, orig, bsx, bsy, test8x8, min_mcost - mcost, qx + pxp, qy + pyp);
       if (pos == 0 && check_position0) mcost -= (jmo_dist)c->lambda_mf[1] * 16;
       if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
     }
@@ -283,7 +298,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
       const int qx = mv.x + sp[pos].x, qy = mv.y + sp[pos].y;
       mcost = mv_cost(c->lambda_mf[2], qx, qy, pred.x, pred.y);
       if (mcost >= min_mcost) continue;
-      mcost += jmo_compute_satd(rp, orig, bsx, bsy, 0, min_mcost - mcost, qx + pxp, qy + pyp);
+      mcost += jmo_compute_satd(rp, orig, bsx, bsy, test8x8, min_mcost - mcost, qx + pxp, qy + pyp);
       if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
     }
     if (best_pos) { mv.x = (int16_t)(mv.x + sp[best_pos].x); mv.y = (int16_t)(mv.y + sp[best_pos].y); }
@@ -299,7 +314,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
     int j, i;
     for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s;
     jmo_luma_pred(&e->ref[0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
-    cost = satd_blocks(e->orig, 16, pr, 16, 16, 16) - (jmo_dist)c->lambda_mf[2] * 8;
+    cost = (c->transform8x8 ? satd_blocks8(e->orig, 16, pr, 16, 16, 16) : satd_blocks(e->orig, 16, pr, 16, 16, 16)) - (jmo_dist)c->lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = s; }
   }
   *out = mv;
@@ -361,6 +376,33 @@ static int tq4x4(const enc *e, const jmo_pel *orig, int opitch, const jmo_pel *p
   return nz;
 }
 
+/* one 8x8 luma block through residual_transform_quant_luma_8x8 / _cavlc (transform8x8.c:522 / :604); the 64 levels into lev[4][16] in the frame zig-zag
+ * order of the 8x8 scan: lev[s >> 4][s & 15] */
+static int tq8x8(const enc *e, const jmo_pel *orig, int opitch, const jmo_pel *pred, int ppitch, int intra, int16_t lev[4][16], int *coeff_cost,
+                 jmo_pel *rec, int rpitch)
+{
+  jmo_pel o[64], p[64], r[64];
+  jmo_qparam q[64];
+  int level[68], run[68], fadj[64], j, i, nz, k, l;
+  const int cavlc = !e->c->cabac;
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) { o[j * 8 + i] = orig[j * opitch + i]; p[j * 8 + i] = pred[j * ppitch + i]; }
+  jmo_qparams_8x8(e->c->qp, intra, e->c->q_offset8[intra ? 1 : 0], q);
+  level[0] = level[17] = level[34] = level[51] = 0;
+  nz = jmo_rtq_luma_8x8(o, p, q, e->c->qp / 6, cavlc, 0, 0, 255, level, run, coeff_cost, r, fadj, NULL);
+  memset(lev, 0, 64 * sizeof(int16_t));
+  if (cavlc) {
+    for (l = 0; l < 4; l++) {
+      int pos = 0;
+      for (k = 0; k < 16 && level[17 * l + k] != 0; k++) { const int sidx = 4 * (pos + run[17 * l + k]) + l; pos += run[17 * l + k] + 1; lev[sidx >> 4][sidx & 15] = (int16_t)level[17 * l + k]; }
+    }
+  } else {
+    int pos = 0;
+    for (k = 0; k < 64 && level[k] != 0; k++) { pos += run[k]; lev[pos >> 4][pos & 15] = (int16_t)level[k]; pos++; }
+  }
+  for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) rec[j * rpitch + i] = r[j * 8 + i];
+  return nz;
+}
+
 typedef struct {
   jmo_pel pred[256], rec[256];
   int16_t lev[16][16];            /* block index 4*b8 + b4 */
@@ -368,11 +410,20 @@ typedef struct {
 } luma_result;
 
 /* luma_residual_coding_8x8 macroblock.c:919-1018 for one 8x8 block, 4x4 transform, P slice */
-static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref)
+static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref, int t8)
 {
   const int mb_y = (b8 >> 1) << 3, mb_x = (b8 & 1) << 3;
   jmo_mv z = {0, 0};
   int coeff_cost = 0, by, bx, j, i;
+  if (t8) {                                                    /* luma_transform_size_8x8_flag: one 8x8 prediction, one 8x8 transform (:991-1011) */
+    jmo_pel p[64];
+    jmo_luma_pred(&e->ref[ref], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mv[ref][mode][mb_y >> 2][mb_x >> 2], z, p);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) L->pred[(mb_y + j) * 16 + mb_x + i] = p[j * 8 + i];
+    if (tq8x8(e, e->orig + mb_y * 16 + mb_x, 16, L->pred + mb_y * 16 + mb_x, 16, 0, &L->lev[b8 * 4], &coeff_cost, L->rec + mb_y * 16 + mb_x, 16)) {
+      L->cbp_blk |= (int64_t)51 << (4 * b8 - 2 * (b8 & 1));
+      L->cbp |= 1 << b8;
+    }
+  } else {
   if (mode < 5) {
     jmo_pel p[64];
     jmo_luma_pred(&e->ref[ref], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mv[ref][mode][mb_y >> 2][mb_x >> 2], z, p);
@@ -391,6 +442,7 @@ static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref)
         L->cbp |= 1 << b8;
       }
     }
+  }
   if (coeff_cost <= 4) {                                       /* _LUMA_COEFF_COST_, reset_block macroblock.c:806-829 */
     L->cbp &= 63 - (1 << b8);
     L->cbp_blk &= ~((int64_t)51 << (4 * b8 - 2 * (b8 & 1)));
@@ -402,7 +454,7 @@ static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref)
 }
 
 /* luma_residual_coding macroblock.c:1182-1257 for mb_type 1, 2, 3 */
-static void luma_rc_mb(enc *e, luma_result *L, int mode, const int ref8[4])
+static void luma_rc_mb(enc *e, luma_result *L, int mode, const int ref8[4], int t8)
 {
   int sum = 0, b8, j, i;
   jmo_mv z = {0, 0};
@@ -412,6 +464,12 @@ static void luma_rc_mb(enc *e, luma_result *L, int mode, const int ref8[4])
     for (b8 = 0; b8 < 4; b8++) {                               /* luma_residual_coding_16x16 :841-908 */
       const int mb_y = (b8 >> 1) << 3, mb_x = (b8 & 1) << 3;
       int coeff_cost = 0, by, bx;
+      if (t8) {
+        if (tq8x8(e, e->orig + mb_y * 16 + mb_x, 16, L->pred + mb_y * 16 + mb_x, 16, 0, &L->lev[b8 * 4], &coeff_cost, L->rec + mb_y * 16 + mb_x, 16)) {
+          L->cbp_blk |= (int64_t)51 << (4 * b8 - 2 * (b8 & 1));
+          L->cbp |= 1 << b8;
+        }
+      } else
       for (by = mb_y; by < mb_y + 8; by += 4)
         for (bx = mb_x; bx < mb_x + 8; bx += 4) {
           const int b4 = ((by >> 2) & 1) * 2 + ((bx >> 2) & 1);
@@ -430,7 +488,7 @@ static void luma_rc_mb(enc *e, luma_result *L, int mode, const int ref8[4])
       sum += coeff_cost;
     }
   } else
-    for (b8 = 0; b8 < 4; b8++) sum += luma_rc_8x8(e, L, b8, mode, ref8[b8]);
+    for (b8 = 0; b8 < 4; b8++) sum += luma_rc_8x8(e, L, b8, mode, ref8[b8], t8);
   if (sum <= 5) {                                              /* _LUMA_MB_COEFF_COST_ :1248-1255 (the coefficient lists stay; cbp hides them) */
     L->cbp &= 0xfffff0; L->cbp_blk &= 0xff0000;
     memcpy(L->rec, L->pred, sizeof L->rec);
@@ -566,6 +624,106 @@ static void chroma_mb(enc *e, jmo_mb_record *o, int intra, int mode, const int8_
   o->cbp_blk |= (uint64_t)cbp_blk;
 }
 
+/* the 4x4-Hadamard and the 8x8-Hadamard SATD of a 16x16 prediction, 8x8 block by 8x8 block (transform_decision macroblock.c:1347, get_best_transform_8x8 md_low.c:43) */
+static void satd_4_and_8(const enc *e, const jmo_pel *pred4, const jmo_pel *pred8, jmo_dist *c4, jmo_dist *c8)
+{
+  *c4 = satd_blocks(e->orig, 16, pred4, 16, 16, 16);
+  *c8 = satd_blocks8(e->orig, 16, pred8, 16, 16, 16);
+}
+
+/* transform_decision (macroblock.c:1347-1425, block_check = -1) for mode 1..3: the prediction is made 8x8 block by 8x8 block */
+static int transform_decision(enc *e, int mode, const int ref8[4], jmo_dist *cost)
+{
+  jmo_pel pr[256], p[64];
+  jmo_mv z = {0, 0};
+  jmo_dist c4, c8;
+  int b8, j, i;
+  for (b8 = 0; b8 < 4; b8++) {
+    const int mb_y = (b8 >> 1) << 3, mb_x = (b8 & 1) << 3;
+    jmo_luma_pred(&e->ref[ref8[b8]], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mv[ref8[b8]][mode][mb_y >> 2][mb_x >> 2], z, p);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) pr[(mb_y + j) * 16 + mb_x + i] = p[j * 8 + i];
+  }
+  satd_4_and_8(e, pr, pr, &c4, &c8);
+  if (c8 < c4) return 1;
+  *cost += c4 - c8;
+  return 0;
+}
+
+/* set_intrapred_8x8 intra8x8.c:497-601 with LowPassForIntra8x8Pred :85-140: the 25 predictor samples Z, A..P, Q..X of 8x8 block (bx, by) */
+static void intra8_neighbours(const enc *e, int bx, int by, jmo_pel pp[25], int *left, int *up, int *all)
+{
+  const int W = e->c->width, X = e->mbx * 16 + bx, Y = e->mby * 16 + by;
+  nb a = neighbour4(e, bx - 1, by), b = neighbour4(e, bx, by - 1), c = neighbour4(e, bx + 8, by - 1), d = neighbour4(e, bx - 1, by - 1);
+  const jmo_pel *r = e->rec[0];
+  jmo_pel P[25], L[25];
+  int k;
+  if (bx == 8 && by == 8) c.avail = 0;
+  *left = a.avail; *up = b.avail; *all = b.avail && a.avail && d.avail;
+  for (k = 0; k < 8; k++) P[1 + k] = b.avail ? r[(Y - 1) * W + X + k] : 128;
+  for (k = 0; k < 8; k++) P[9 + k] = c.avail ? r[(Y - 1) * W + X + 8 + k] : P[8];
+  for (k = 0; k < 8; k++) P[17 + k] = a.avail ? r[(Y + k) * W + X - 1] : 128;
+  P[0] = d.avail ? r[(Y - 1) * W + X - 1] : 128;
+  memcpy(L, P, sizeof P);
+  if (b.avail) {
+    L[1] = (jmo_pel)(((d.avail ? P[0] : P[1]) + 2 * P[1] + P[2] + 2) >> 2);
+    for (k = 2; k < 16; k++) L[k] = (jmo_pel)((P[k - 1] + 2 * P[k] + P[k + 1] + 2) >> 2);
+    L[16] = (jmo_pel)((P[15] + 3 * P[16] + 2) >> 2);
+  }
+  if (d.avail) {
+    if (b.avail && a.avail) L[0] = (jmo_pel)((2 * P[0] + P[1] + P[17] + 2) >> 2);
+    else if (b.avail) L[0] = (jmo_pel)((3 * P[0] + P[1] + 2) >> 2);
+    else if (a.avail) L[0] = (jmo_pel)((3 * P[0] + P[17] + 2) >> 2);
+  }
+  if (a.avail) {
+    L[17] = (jmo_pel)(((d.avail ? P[0] : P[17]) + 2 * P[17] + P[18] + 2) >> 2);
+    for (k = 18; k < 24; k++) L[k] = (jmo_pel)((P[k - 1] + 2 * P[k] + P[k + 1] + 2) >> 2);
+    L[24] = (jmo_pel)((P[23] + 3 * P[24] + 2) >> 2);
+  }
+  memcpy(pp, L, sizeof L);
+}
+
+/* mode_decision_for_I8x8_MB transform8x8.c:241 -> mode_decision_for_I8x8_blocks_JM_Low rd_intra_jm_low.c:162.  Writes the macroblock's reconstruction as it goes
+ * (later blocks predict from it); ipm8 = p_Vid->ipredmode8x8 of the macroblock (4x4 raster). */
+static jmo_dist intra8x8_mb(enc *e, jmo_mb_record *o, int8_t ipm8[16], int *cbp_out)
+{
+  const int lambda = e->c->lambda_mdfp, W = e->c->width;
+  jmo_dist cost = (jmo_dist)lambda * 6;
+  int cbp = 0, b8;
+  for (b8 = 0; b8 < 4; b8++) {
+    const int bx = (b8 & 1) << 3, by = (b8 >> 1) << 3, X = e->mbx * 16 + bx, Y = e->mby * 16 + by;
+    nb lb = neighbour4(e, bx - 1, by), tb = neighbour4(e, bx, by - 1);
+    int upm, lm, mpm, left, up, all, m, best = 0, j, i, k, dummy = 0;
+    jmo_pel pp[25], pr[64], best_pr[64], ob[64];
+    jmo_dist min_cost = JMO_DIST_MAX, c;
+    int16_t d[64];
+    if (b8 >> 1) upm = tb.avail ? ipm8[((by >> 2) - 1) * 4 + (bx >> 2)] : -1;
+    else upm = tb.avail ? e->ipm[tb.y4 * e->w4 + tb.x4] : -1;
+    if (b8 & 1) lm = lb.avail ? ipm8[(by >> 2) * 4 + (bx >> 2) - 1] : -1;
+    else lm = lb.avail ? e->ipm[lb.y4 * e->w4 + lb.x4] : -1;
+    mpm = (upm < 0 || lm < 0) ? 2 : (upm < lm ? upm : lm);
+    intra8_neighbours(e, bx, by, pp, &left, &up, &all);
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) ob[j * 8 + i] = e->orig[(by + j) * 16 + bx + i];
+    memset(best_pr, 0, sizeof best_pr);
+    for (k = -1; k < 9; k++) {                                 /* the most probable mode first, then the others in ascending order */
+      m = k < 0 ? mpm : k;
+      if (k >= 0 && m == mpm) continue;
+      if (!(m == 2 || ((m == 0 || m == 7 || m == 3) && up) || ((m == 1 || m == 8) && left) || all)) continue;
+      jmo_intrapred_8x8(pp, m, left, up, pr);
+      c = (jmo_dist)lambda * (k < 0 ? 1 : 4);
+      if (k >= 0 && !(c < min_cost)) continue;
+      for (j = 0; j < 64; j++) d[j] = (int16_t)((int)ob[j] - (int)pr[j]);
+      c += ((jmo_dist)jmo_hadamard_sad8x8(d)) << JMO_LAMBDA_BITS;                  /* compute_satd8x8_cost transform8x8.c:880 */
+      if (k < 0 || c < min_cost) { best = m; min_cost = c; memcpy(best_pr, pr, sizeof pr); }
+    }
+    for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) { ipm8[((by >> 2) + j) * 4 + (bx >> 2) + i] = (int8_t)best; o->ipredmode[((by >> 2) + j) * 4 + (bx >> 2) + i] = (int8_t)best; }
+    o->ipred_syntax[4 * b8] = (int8_t)(mpm == best ? -1 : (best < mpm ? best : best - 1));
+    if (tq8x8(e, ob, 8, best_pr, 8, 1, &o->luma[4 * b8], &dummy, e->rec[0] + Y * W + X, W)) cbp |= 1 << b8;
+    cost += min_cost;
+  }
+  *cbp_out = cbp;
+  return cost;
+}
+
 static void store_luma(enc *e, const jmo_pel *src)
 {
   const int W = e->c->width;
@@ -581,11 +739,16 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
   jmo_dist min_cost = JMO_DIST_MAX, min_rdcost, rd_cost;
   int best_mode = 10, mode, block, ref, j, i, k;
   int best_ref[8][4];                      /* b8x8info->best[mode][b8].ref[LIST_0] */
-  int8_t p8mode[4] = {0, 0, 0, 0};
-  int p8ref[4] = {0, 0, 0, 0};
-  jmo_dist p8cost = 0;
-  luma_result P8, L;
-  int p8_valid = 0;
+  int8_t p8mode[4] = {0, 0, 0, 0}, p8tmode[4] = {0, 0, 0, 0};
+  int p8ref[4] = {0, 0, 0, 0}, p8tref[4] = {0, 0, 0, 0};
+  jmo_mv p8tmv[16];
+  jmo_dist p8cost = 0, p8tcost = 0;
+  luma_result P8, P8T, L;
+  int p8_valid = 0, p8_t8 = 0;
+  int cur_t8 = 0, best_transform_flag = 0;      /* currMB->luma_transform_size_8x8_flag as md_low.c carries it, and the flag of the best of modes 1..3 */
+  int8_t ipm8[16];
+  jmo_pel i8rec[256];
+  int tmp8 = 0;
 
   memset(o, 0, sizeof *o);
   e->availA = e->mbx > 0 && e->addr - 1 >= first;
@@ -620,60 +783,100 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
         else { best_ref[3][block] = bref; best_ref[3][block + 2] = bref; }
         if (mode > 1 && block == 0) set_me_parameters(e, e->all_mv[bref][mode][0][0], bref, 0, 0, bw / 4, bh / 4);   /* set_ref_and_motion_vectors_P_slice */
       }
-      if (cost < min_cost) { best_mode = mode; min_cost = cost; }
+      cur_t8 = 0;
+      if (c->transform8x8) cur_t8 = transform_decision(e, mode, best_ref[mode], &cost);      /* md_low.c:244-249 */
+      if (cost < min_cost) { best_mode = mode; min_cost = cost; best_transform_flag = cur_t8; }
     }
-    /* ---- P8x8: md_low.c:265-354, submacroblock_mode_decision_low mode_decision_P8x8.c:681 ---- */
+    /* ---- P8x8: md_low.c:265-354, submacroblock_mode_decision_low mode_decision_P8x8.c:681.  With Transform8x8Mode = 1 the four blocks are first decided with
+     * 8x8 partitions only and the 8x8 transform (tr8x8), then with all sub-modes and the 4x4 transform (tr4x4); both passes search again ---- */
     if (c->inter_valid[4] || c->inter_valid[5] || c->inter_valid[6] || c->inter_valid[7]) {
-      memset(&P8, 0, sizeof P8);
+      int pass;
       p8_valid = 1;
-      for (block = 0; block < 4; block++) {
-        const int x0 = (block & 1) * 8, y0 = (block >> 1) * 8;
-        jmo_dist min8 = JMO_DIST_MAX;
-        int any = 0;
-        for (mode = 4; mode < 8; mode++) {
-          jmo_dist cost;
-          int bref = 0;
-          const int bw = PART_W[mode], bh = PART_H[mode];
-          if (!c->inter_valid[mode]) continue;
-          any = 1;
-          for (ref = 0; ref < c->num_ref; ref++) {                              /* SubPartitionMotionSearch mv_search.c:1796-1830 */
-            int v, h;
-            e->motion_cost[mode][ref][block] = 0;
-            for (v = y0; v < y0 + 8; v += bh)
-              for (h = x0; h < x0 + 8; h += bw) {
-                jmo_mv mv;
-                e->motion_cost[mode][ref][block] += block_motion_search(e, ref, mode, h, v, bw, bh, &mv);
-                for (j = 0; j < bh / 4; j++) for (i = 0; i < bw / 4; i++) e->all_mv[ref][mode][v / 4 + j][h / 4 + i] = mv;
-                set_me_parameters(e, mv, ref, h / 4, v / 4, bw / 4, bh / 4);
-              }
+      for (pass = c->transform8x8 ? 1 : 0; pass >= 0; pass--) {                   /* pass 1: tr8x8, pass 0: tr4x4 */
+        luma_result *PR = pass ? &P8T : &P8;
+        jmo_dist pcost = 0;
+        memset(PR, 0, sizeof *PR);
+        for (block = 0; block < 4; block++) {
+          const int x0 = (block & 1) * 8, y0 = (block >> 1) * 8;
+          jmo_dist min8 = JMO_DIST_MAX;
+          int any = 0, bm = 0, br = 0;
+          for (mode = 4; mode < (pass ? 5 : 8); mode++) {
+            jmo_dist cost;
+            int bref = 0;
+            const int bw = PART_W[mode], bh = PART_H[mode];
+            if (!c->inter_valid[mode]) continue;
+            any = 1;
+            for (ref = 0; ref < c->num_ref; ref++) {                              /* SubPartitionMotionSearch mv_search.c:1796-1830 */
+              int v, h;
+              e->motion_cost[mode][ref][block] = 0;
+              for (v = y0; v < y0 + 8; v += bh)
+                for (h = x0; h < x0 + 8; h += bw) {
+                  jmo_mv mv;
+                  e->motion_cost[mode][ref][block] += block_motion_search(e, ref, mode, h, v, bw, bh, &mv);
+                  for (j = 0; j < bh / 4; j++) for (i = 0; i < bw / 4; i++) e->all_mv[ref][mode][v / 4 + j][h / 4 + i] = mv;
+                  set_me_parameters(e, mv, ref, h / 4, v / 4, bw / 4, bh / 4);
+                }
+            }
+            cost = list0_cost(e, mode, block, &bref);
+            for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) e->mi[(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i].ref = (int8_t)bref;   /* :847-854 */
+            if (cost != JMO_DIST_MAX) cost += (c->num_ref <= 1 ? 0 : (jmo_dist)c->lambda_mf[2] * c->refbits[mode - 4]) - 1;    /* :898-900: ref_cost(.., B8Mode2Value = mode - 4, ..) - 1 */
+            if (cost < min8) { min8 = cost; bm = mode; br = bref; }
           }
-          cost = list0_cost(e, mode, block, &bref);
-          for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) e->mi[(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i].ref = (int8_t)bref;   /* :847-854 */
-          if (cost != JMO_DIST_MAX) cost += (c->num_ref <= 1 ? 0 : (jmo_dist)c->lambda_mf[2] * c->refbits[mode - 4]) - 1;    /* :898-900: ref_cost(.., B8Mode2Value = mode - 4, ..) - 1 */
-          if (cost < min8) { min8 = cost; p8mode[block] = (int8_t)mode; p8ref[block] = bref; }
-        }
-        if (!any) continue;
-        if (min8 != JMO_DIST_MAX && p8cost != JMO_DIST_MAX) p8cost += min8; else p8cost = JMO_DIST_MAX;
-        {
-          const int cnt = luma_rc_8x8(e, &P8, block, p8mode[block], p8ref[block]);
-          if (cnt) { P8.cnt_nonz += cnt; }
-          /* cbp8x8: the block's bit when the returned coefficient cost is non-zero (:1010-1014); luma_rc_8x8 set L->cbp from the blocks' nonzero flags,
-           * which is the same condition unless the cost is 0 with coefficients present -- impossible: every kept level costs >= 0 and a block
-           * survives reset_block only with cost > 4.  Kept as JM writes it: */
-          if (!cnt) P8.cbp &= ~(1 << block);
-        }
-        for (j = 0; j < 2; j++)                                                  /* set_ref_and_motion_vectors_P_slice rdopt.c:2885, 8x8 region */
-          for (i = 0; i < 2; i++) {
-            mvinfo *m = &e->mi[(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i];
-            m->mv = e->all_mv[p8ref[block]][p8mode[block]][y0 / 4 + j][x0 / 4 + i]; m->ref = (int8_t)p8ref[block];
+          if (!any) continue;
+          if (pass) { p8tmode[block] = (int8_t)bm; p8tref[block] = br; } else { p8mode[block] = (int8_t)bm; p8ref[block] = br; }
+          if (min8 != JMO_DIST_MAX && pcost != JMO_DIST_MAX) pcost += min8; else pcost = JMO_DIST_MAX;
+          {
+            const int cnt = luma_rc_8x8(e, PR, block, bm, br, pass);
+            if (cnt) { PR->cnt_nonz += cnt; }
+            /* cbp8x8: the block's bit when the returned coefficient cost is non-zero (:1010-1014); luma_rc_8x8 set the cbp from the blocks' nonzero flags,
+             * which is the same condition unless the cost is 0 with coefficients present -- impossible: every kept level costs >= 0 and a block
+             * survives reset_block only with cost > 4.  Kept as JM writes it: */
+            if (!cnt) PR->cbp &= ~(1 << block);
           }
+          if (pass) for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) p8tmv[(y0 / 4 + j) * 4 + x0 / 4 + i] = e->all_mv[br][bm][y0 / 4 + j][x0 / 4 + i];    /* store_8x8_motion_vectors */
+          for (j = 0; j < 2; j++)                                                  /* set_ref_and_motion_vectors_P_slice rdopt.c:2885, 8x8 region */
+            for (i = 0; i < 2; i++) {
+              mvinfo *m = &e->mi[(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i];
+              m->mv = e->all_mv[br][bm][y0 / 4 + j][x0 / 4 + i]; m->ref = (int8_t)br;
+            }
+        }
+        if (pass) p8tcost = pcost; else p8cost = pcost;
       }
-      if (p8cost < min_cost) { best_mode = 8; min_cost = p8cost; }
+      if (c->transform8x8) cur_t8 = 0;                                            /* md_low.c:289 */
+      if (p8cost < min_cost || (c->transform8x8 && p8tcost < min_cost)) {         /* md_low.c:312-348 */
+        best_mode = 8;
+        if (c->transform8x8) {
+          if (p8tcost < p8cost) { min_cost = p8tcost; p8_t8 = 1; }
+          else if (p8cost < p8tcost) { min_cost = p8cost; p8_t8 = 0; }
+          else {                                                                  /* get_best_transform_8x8 md_low.c:43 */
+            jmo_dist c4, c8;
+            satd_4_and_8(e, P8.pred, P8T.pred, &c4, &c8);
+            p8_t8 = c8 < c4;
+            min_cost = p8_t8 ? p8tcost : p8cost;
+          }
+        } else { min_cost = p8cost; p8_t8 = 0; }
+        cur_t8 = p8_t8;
+      }
     }
     { jmo_mv s = skip_mv(e); for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s; }        /* md_low.c:357-358 */
   }
   min_rdcost = min_cost;
 
+  /* ---- Intra8x8: md_low.c:432-486 (enc_mb.valid[I8MB] = Transform8x8Mode wherever Intra4x4 is allowed) ---- */
+  tmp8 = cur_t8;                                                  /* tmp_8x8_flag md_low.c:368 */
+  if (c->transform8x8 && c->intra8_valid) {
+    jmo_mb_record t;
+    int cbp8 = 0;
+    memset(&t, 0, sizeof t);
+    memset(ipm8, 2, sizeof ipm8);
+    rd_cost = intra8x8_mb(e, &t, ipm8, &cbp8);
+    if (rd_cost <= min_rdcost) {
+      min_rdcost = rd_cost; best_mode = 13; cur_t8 = 1; tmp8 = 1;
+      memcpy(o->luma, t.luma, sizeof o->luma); memcpy(o->ipredmode, t.ipredmode, 16); memcpy(o->ipred_syntax, t.ipred_syntax, 16);
+      o->cbp = (int16_t)cbp8;
+      for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) i8rec[j * 16 + i] = e->rec[0][(e->mby * 16 + j) * W + e->mbx * 16 + i];      /* temp_img */
+    } else cur_t8 = tmp8;
+  }
   /* ---- Intra4x4: md_low.c:489-521 ---- */
   {
     jmo_mb_record t;
@@ -682,10 +885,11 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
       memset(&t, 0, sizeof t);
       rd_cost = intra4x4_mb(e, &t, &cbp4);
       if (rd_cost <= min_rdcost) {
+        cur_t8 = 0; tmp8 = 0;
         min_rdcost = rd_cost; best_mode = 9;
         memcpy(o->luma, t.luma, sizeof o->luma); memcpy(o->ipredmode, t.ipredmode, 16); memcpy(o->ipred_syntax, t.ipred_syntax, 16);
         o->cbp = (int16_t)cbp4;
-      }
+      } else cur_t8 = tmp8;
     }
   }
   /* ---- Intra16x16: md_low.c:522-556 ---- */
@@ -694,6 +898,7 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
     int left, up, upleft, mask, i16 = 2;
     intra16_neighbours(e, ee, &left, &up, &upleft);
     mask = (up ? 1 : 0) | (left ? 2 : 0) | 4 | ((left && up && upleft) ? 8 : 0);
+    cur_t8 = 0;                                                  /* find_best_mode_I16x16_MB rd_intra_jm.c:423 */
     rd_cost = (int)jmo_intra16_search(ee, left, up, mask, 2, 255, e->orig, pred4, &i16);
     o->i16mode = (int8_t)i16;
     if (rd_cost < min_rdcost) {
@@ -709,7 +914,7 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
       for (b = 0; b < 16; b++)
         for (pos = 1, k = 0; k < 15 && ac_level[b][k] != 0; k++) { pos += ac_run[b][k]; o->luma[b][pos++] = (int16_t)ac_level[b][k]; }
       store_luma(e, rec);
-    }
+    } else cur_t8 = tmp8;                                        /* md_low.c:553 */
   }
 
   /* ---- final parameters: md_low.c:560-669 ---- */
@@ -717,21 +922,36 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
   o->min_rdcost = min_rdcost;
   {
     int ref8[4] = {0, 0, 0, 0};
-    if (best_mode == 8) {                                        /* set_coeff_and_recon_8x8_p_slice rdopt.c:1460-1545 */
+    if (best_mode == 8) {                                        /* set_coeff_and_recon_8x8_p_slice rdopt.c:1326-1545 */
+      if (cur_t8 && P8T.cbp == 0) cur_t8 = 0;                    /* md_low.c:568-569: then the tr4x4 data are used */
+      if (cur_t8) {
+        for (k = 0; k < 4; k++) { o->b8mode[k] = p8tmode[k]; ref8[k] = p8tref[k]; }
+        for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[ref8[(j >> 1) * 2 + (i >> 1)]][4][j][i] = p8tmv[j * 4 + i];      /* RestoreMV8x8 */
+        memcpy(o->luma, P8T.lev, sizeof o->luma);
+        if (P8T.cnt_nonz <= 5) { o->cbp = 0; o->cbp_blk = 0; store_luma(e, P8T.pred); }       /* _LUMA_8x8_COEFF_COST_ */
+        else { o->cbp = (int16_t)P8T.cbp; o->cbp_blk = (uint64_t)P8T.cbp_blk; store_luma(e, P8T.rec); }
+      } else {
       for (k = 0; k < 4; k++) { o->b8mode[k] = p8mode[k]; ref8[k] = p8ref[k]; }
       memcpy(o->luma, P8.lev, sizeof o->luma);
       if (P8.cnt_nonz <= 5) { o->cbp = 0; o->cbp_blk = 0; store_luma(e, P8.pred); }
       else { o->cbp = (int16_t)P8.cbp; o->cbp_blk = (uint64_t)P8.cbp_blk; store_luma(e, P8.rec); }
+      }
     } else if (best_mode >= 1 && best_mode <= 3) {
       for (k = 0; k < 4; k++) { o->b8mode[k] = (int8_t)best_mode; ref8[k] = best_ref[best_mode][k]; }
-      luma_rc_mb(e, &L, best_mode, ref8);
+      cur_t8 = best_transform_flag;                              /* md_low.c:607-608 */
+      luma_rc_mb(e, &L, best_mode, ref8, cur_t8);
       memcpy(o->luma, L.lev, sizeof o->luma);
       o->cbp = (int16_t)L.cbp; o->cbp_blk = (uint64_t)L.cbp_blk;
       store_luma(e, L.rec);
     } else if (best_mode == 9) {
       for (k = 0; k < 4; k++) o->b8mode[k] = 11;               /* IBLOCK */
+    } else if (best_mode == 13) {
+      for (k = 0; k < 4; k++) o->b8mode[k] = 13;               /* I8MB (set_modes_and_refs_for_blocks) */
+      store_luma(e, i8rec);                                     /* md_low.c:585 */
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->ipm[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i] = ipm8[j * 4 + i];
     }
-    if (best_mode != 9) { memset(o->ipredmode, 2, 16); memset(o->ipred_syntax, 2, 16); for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->ipm[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i] = 2; }
+    if (best_mode != 9 && best_mode != 13) { memset(o->ipredmode, 2, 16); memset(o->ipred_syntax, 2, 16); for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->ipm[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i] = 2; }
+    if ((o->cbp & 15) == 0 && best_mode != 9 && best_mode != 13) cur_t8 = 0;      /* md_low.c:627-628 */
     for (k = 0; k < 4; k++) o->b8ref[k] = (int8_t)(best_mode >= 9 ? -1 : ref8[k]);
     chroma_mb(e, o, best_mode >= 9, best_mode, o->b8mode, ref8);
     /* SetMotionVectorsMBPSlice md_common.c:172 + the reference indices of set_modes_and_refs_for_blocks_p_slice rdopt.c:1041-1130 */
@@ -745,8 +965,9 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
     /* the skip test md_low.c:658-665 */
     if (pslice && best_mode == 1 && o->cbp == 0 && ref8[0] == 0) {
       const mvinfo *m = &e->mi[(e->mby * 4) * e->w4 + e->mbx * 4];
-      if (m->mv.x == e->all_mv[0][0][0][0].x && m->mv.y == e->all_mv[0][0][0][0].y) { o->mb_type = 0; memset(o->b8mode, 0, 4); }
+      if (m->mv.x == e->all_mv[0][0][0][0].x && m->mv.y == e->all_mv[0][0][0][0].y) { o->mb_type = 0; memset(o->b8mode, 0, 4); cur_t8 = 0; }
     }
+    o->transform8x8 = (int8_t)cur_t8;
     if (best_mode == 10) { /* i16offset is derived by the caller: I16Offset(cbp, i16mode) rdopt.c:868 */ }
     for (j = 0; j < 4; j++)
       for (i = 0; i < 4; i++) { const mvinfo *m = &e->mi[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i]; o->mv[j * 4 + i][0] = m->mv.x; o->mv[j * 4 + i][1] = m->mv.y; }

@@ -440,7 +440,7 @@ class MbEncCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("slice_type", C.c_int32), ("first_mb", C.c_int32), ("num_mb", C.c_int32),
                 ("qp", C.c_int32), ("qpc", C.c_int32), ("search_range", C.c_int32), ("num_ref", C.c_int32), ("lambda_mf", C.c_int32 * 3),
                 ("lambda_mdfp", C.c_int32), ("max_mvd", C.c_int32), ("mv_limit", C.c_int32 * 4), ("inter_valid", C.c_int32 * 8),
-                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32)]
+                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32), ("transform8x8", C.c_int32), ("q_offset8", C.c_int32 * 2), ("intra8_valid", C.c_int32)]
 
 
 NO_REF = -(1 << 30)
@@ -457,7 +457,7 @@ class EpzsCfg(C.Structure):
 EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2)   # the shipped .cfg files
 
 
-MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("pad0", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
+MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("transform8x8", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
                       ("chroma_dc", "<i2", (2, 4)), ("chroma_ac", "<i2", (2, 4, 16))])
@@ -466,10 +466,14 @@ assert MB_RECORD.itemsize == 944
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
-              subpel=1, cabac=0, search_mode=-1):
+              subpel=1, cabac=0, search_mode=-1, transform8x8=0):
     c = MbEncCfg()
     c.cabac = cabac
     c.search_mode = search_mode
+    c.transform8x8 = transform8x8
+    c.q_offset8[0] = 342
+    c.q_offset8[1] = 682 if slice_type == 2 else 342
+    c.intra8_valid = 1 if transform8x8 else 0
     c.width, c.height, c.slice_type, c.first_mb, c.num_mb = width, height, slice_type, first_mb, num_mb
     c.qp = qp
     c.qpc = qp if qp < 30 else [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39][qp - 30]

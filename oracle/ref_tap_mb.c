@@ -39,6 +39,7 @@ typedef struct {
   uint8_t rec_y[256], rec_u[64], rec_v[64];
   int32_t poc, ref_poc[16];                 /* enc_picture->poc, listX[LIST_0][r]->poc (EPZS scales its predictors by picture distances) */
   int64_t motion_cost_ref[8][4][4];         /* p_Vid->motion_cost[mode][LIST_0][ref 1..4][block] */
+  int32_t luma8_level[4][65], luma8_run[4][65];      /* cofAC[b8][0][0/1][k]: the 64-entry list of an 8x8 transform block with CABAC (CAVLC: four lists of 16 in luma_level) */
 } MBREC;
 #pragma pack(pop)
 
@@ -105,6 +106,8 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
         r.luma_level[b8 * 4 + b4][k] = currSlice->cofAC[b8][b4][0][k];
         r.luma_run[b8 * 4 + b4][k] = currSlice->cofAC[b8][b4][1][k];
       }
+  for (b8 = 0; b8 < 4; b8++)
+    for (k = 0; k < 65; k++) { r.luma8_level[b8][k] = currSlice->cofAC[b8][0][0][k]; r.luma8_run[b8][k] = currSlice->cofAC[b8][0][1][k]; }
   for (m = 0; m < 3; m++)
     for (k = 0; k < 18; k++) { r.dc_level[m][k] = currSlice->cofDC[m][0][k]; r.dc_run[m][k] = currSlice->cofDC[m][1][k]; }
   if (p_Vid->yuv_format == YUV420)

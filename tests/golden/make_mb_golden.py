@@ -41,6 +41,13 @@ CASES = {
     # EPZS (SearchMode = 3) with the shipped EPZS switches (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid, EPZS sub-pel search)
     # BASELINE configs[2] without its 8x8 transform and B pictures: 1080p, Main profile, CABAC, EPZS, five references configured (two exist by the third picture)
     "g3e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 3, True),
+    # High profile: the 8x8 transform beside the 4x4 one (Transform8x8Mode = 1): transform_decision, the tr8x8 pass of P8x8, Intra8x8
+    "q1h": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", Transform8x8Mode="1", ProfileIDC="100"), (176, 144), 3, False),     # CAVLC
+    "q2hc": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1"), (176, 144), 3, False),   # CABAC
+    "m3h": (dict(RDO_OFF, SearchMode="-1", SearchRange="32", NumberReferenceFrames="3", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", SliceMode="1", SliceArgument="45",
+                 FramesToBeEncoded="5", QPISlice="24", QPPSlice="24"), (208, 160), 5, "motion:21"),
+    "m2he": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", FramesToBeEncoded="4"), (176, 144), 4, "motion:22"),   # EPZS + 8x8: configs[2]
+    "m1hq": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="1", Transform8x8Mode="1", ProfileIDC="100", FramesToBeEncoded="3", QPISlice="40", QPPSlice="40"), (176, 144), 3, "motion:23"),   # CAVLC, coarse
     "q1e": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="1"), (176, 144), 3, False),          # the reference's own clip
     "m5e": (dict(RDO_OFF, SearchMode="3", SearchRange="32", FramesToBeEncoded="6"), (208, 160), 6, "motion:11"),         # five references: the ref > 0 exits, scaled predictors
     "m2c": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", SymbolMode="1", ProfileIDC="77", SliceMode="1", SliceArgument="40", FramesToBeEncoded="4"), (176, 144), 4, "motion:12"),   # CABAC, slices that start mid-row
@@ -89,7 +96,7 @@ def run(tag):
         t0 = tap[0]
         lam = {int(t["slice_type"]): list(t["lambda_mf"]) + [int(t["lambda_mdfp"])] for t in tap[::nmb]}
         np.savez_compressed(os.path.join(G, f"mb_low_{tag}.npz"),
-                            records=mb_tap.tap_to_records(tap), slice_type=tap["slice_type"][::nmb].astype(np.int32), slice_nr=tap["slice_nr"].astype(np.int16),
+                            records=mb_tap.tap_to_records(tap, int(ov.get("SymbolMode", 0))), slice_type=tap["slice_type"][::nmb].astype(np.int32), slice_nr=tap["slice_nr"].astype(np.int16),
                             lambda_i=np.array(lam.get(2, [0, 0, 0, 0]), np.int32), lambda_p=np.array(lam.get(0, [0, 0, 0, 0]), np.int32),
                             qp=int(t0["qp"]), qpc=int(t0["qpc"]), search_range=int(t0["search_range"]), max_mvd=int(t0["max_mvd"]),
                             mv_limit=t0["mv_limit"].astype(np.int32), num_ref=int(tap["num_ref"].max()), size=np.array([sw, sh, W, H], np.int32),

@@ -15,7 +15,8 @@ TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), 
                 ("luma_level", "<i4", (16, 17)), ("luma_run", "<i4", (16, 17)), ("dc_level", "<i4", (3, 18)), ("dc_run", "<i4", (3, 18)),
                 ("chroma_level", "<i4", (8, 17)), ("chroma_run", "<i4", (8, 17)),
                 ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,)),
-                ("poc", "<i4"), ("ref_poc", "<i4", (16,)), ("motion_cost_ref", "<i8", (8, 4, 4))])
+                ("poc", "<i4"), ("ref_poc", "<i4", (16,)), ("motion_cost_ref", "<i8", (8, 4, 4)),
+                ("luma8_level", "<i4", (4, 65)), ("luma8_run", "<i4", (4, 65))])
 
 
 def read(path):
@@ -35,18 +36,29 @@ def dense(level, run, start, n=16):
     return out
 
 
-def expected_coeffs(t):
-    """The coefficient arrays write_macroblock would read for tap record t, in the record layout; blocks the coded block pattern hides are zero."""
+def expected_coeffs(t, cabac=0):
+    """The coefficient arrays write_macroblock would read for tap record t, in the record layout; blocks the coded block pattern hides are zero.
+    An 8x8 transform block's 64 levels lie in the 8x8 scan's zig-zag order at luma[4 * b8 + (s >> 4)][s & 15]: JM keeps them as one list (CABAC) or as four
+    lists of every fourth position (CAVLC: list s & 3, place s >> 2)."""
     luma = np.zeros((16, 16), np.int16)
     luma_dc = np.zeros(16, np.int16)
     cdc = np.zeros((2, 4), np.int16)
     cac = np.zeros((2, 4, 16), np.int16)
     mbt, cbp = int(t["mb_type"]), int(t["cbp"])
+    t8 = int(t["transform8x8"]) and mbt not in (9, 10)
     if mbt == 10:
         luma_dc = dense(t["dc_level"][0], t["dc_run"][0], 0)
     for b8 in range(4):
         if cbp & (1 << b8):
-            for b4 in range(4):
+            if t8 and cabac:
+                luma[4 * b8:4 * b8 + 4] = dense(t["luma8_level"][b8], t["luma8_run"][b8], 0, 64).reshape(4, 16)
+            elif t8:
+                z = np.zeros(64, np.int16)
+                for l in range(4):
+                    z[l::4] = dense(t["luma_level"][4 * b8 + l], t["luma_run"][4 * b8 + l], 0)
+                luma[4 * b8:4 * b8 + 4] = z.reshape(4, 16)
+            else:
+              for b4 in range(4):
                 luma[4 * b8 + b4] = dense(t["luma_level"][4 * b8 + b4], t["luma_run"][4 * b8 + b4], 1 if mbt == 10 else 0)
     if cbp > 15:
         for uv in range(2):
@@ -124,7 +136,6 @@ def canonical(recs):
     out = np.array(recs, copy=True)
     for r in out:
         mbt, cbp = int(r["mb_type"]), int(r["cbp"])
-        r["pad0"] = 0
         r["pad1"] = 0
         luma, luma_dc, cdc, cac = visible_coeffs(r)
         r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = luma, luma_dc, cdc, cac
@@ -137,29 +148,36 @@ def canonical(recs):
             r["cbp_blk"] = int(r["cbp_blk"]) & 0xFFFF
         if mbt != 10:
             r["i16mode"] = 0
-        if mbt != 9:
+        if mbt == 13:                            # Intra8x8: one syntax element per 8x8 block, at [4 * b8]
+            syn = np.array(r["ipred_syntax"]).copy()
+            keep = syn[0::4].copy()
+            syn[:] = 2
+            syn[0::4] = keep
+            r["ipred_syntax"] = syn
+        elif mbt != 9:
             r["ipred_syntax"] = 2
             r["ipredmode"] = 2
         if mbt != 8:
-            r["b8mode"] = 11 if mbt == 9 else (0 if mbt in (0, 10) else mbt)
+            r["b8mode"] = 11 if mbt == 9 else (13 if mbt == 13 else (0 if mbt in (0, 10) else mbt))
         if mbt == 0:
             r["b8ref"] = 0
         (cbp)
     return out
 
 
-def tap_to_records(tap):
+def tap_to_records(tap, cabac=0):
     """The reference encoder's dump as canonical records."""
     out = np.zeros(len(tap), _record_dtype())
     for t, r in zip(tap, out):
         mbt = int(t["mb_type"])
+        r["transform8x8"] = int(t["transform8x8"])
         r["mb_type"], r["cbp"], r["min_rdcost"] = mbt, int(t["cbp"]), int(t["min_rdcost"])
         r["i16mode"], r["c_ipred_mode"] = int(t["i16mode"]), int(t["c_ipred_mode"])
         r["cbp_blk"] = int(t["cbp_blk"]) & 0xFFFFFFFFFFFFFFFF
         r["b8mode"] = t["b8mode"]
         r["b8ref"] = [int(t["ref_idx"][j * 8 + i * 2]) for j in range(2) for i in range(2)]
         r["ipredmode"], r["ipred_syntax"], r["mv"] = t["ipredmode"], t["ipred_syntax"], t["mv"]
-        r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = expected_coeffs(t)
+        r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = expected_coeffs(t, cabac)
     return canonical(out)
 
 

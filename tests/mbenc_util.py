@@ -29,7 +29,7 @@ def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_
     mot[:, :, :, 2] = -1
     for k in range(nmb):
         r = records[k]
-        mbs[k] = [int(r["mb_type"]), slice_type, qp, qpc, qpc, int(r["cbp"]), int(r["cbp_blk"]) & 0xFFFF, int(slice_nr[k]), disable_idc, 0, 0, 0]
+        mbs[k] = [int(r["mb_type"]), slice_type, qp, qpc, qpc, int(r["cbp"]), int(r["cbp_blk"]) & 0xFFFF, int(slice_nr[k]), disable_idc, 0, 0, int(r["transform8x8"])]
         mbx, mby = k % wmb, k // wmb
         if int(r["mb_type"]) < 9:
             mv = np.array(r["mv"]).reshape(4, 4, 2)
@@ -43,13 +43,14 @@ def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_
 class SeqEncoder:
     """IPPP with num_ref sliding-window references, RDOptimization = 0, AdaptiveRounding = 0 (the scope of jmo_mbenc.c)."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0, search_mode=-1, epzs=None):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0, search_mode=-1, epzs=None, transform8x8=0):
         """lambdas[slice_type] = (lambda_mf[3], lambda_mdfp): JM's own tables (double arithmetic, never recomputed).
         search_mode 3 = EPZS with the switches in `epzs` (defaults: the shipped .cfg files', pyjmo.EPZS_DEFAULTS)."""
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
         self.cabac = cabac     # SymbolMode: the quantiser clamps levels for CAVLC only
         self.search_mode, self.epzs = search_mode, dict(epzs or {})
+        self.transform8x8 = transform8x8     # Transform8x8Mode (0 / 1)
         self.refs = []         # most recent first: (RefPic, (u, v), picture id, (mv, refpoc) per 4x4 block of the stored picture)
         self.npic = 0
         self.epzs_stats = []   # per P slice: (searches, alias_hits) of the oracle's EPZS
@@ -68,7 +69,7 @@ class SeqEncoder:
         qpc = None
         for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode)
+            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8)
             qpc = cfg.qpc
             ez = None
             if self.search_mode == 3 and st == 0:       # picture order counts: 2 per frame (IPPP, PicOrderCntType 0)

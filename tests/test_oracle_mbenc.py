@@ -36,7 +36,7 @@ def load_case(tag):
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]], didc=didc,
                 nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)), search_mode=int(ov.get("SearchMode", -1)),
-                epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov})
+                epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
 
 
 def source_frames(c, tag):
@@ -63,7 +63,7 @@ def source_frames(c, tag):
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
-                                search_mode=c["search_mode"], epzs=c["epzs"])
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -96,6 +96,13 @@ def test_oracle_epzs_pipeline_equals_the_reference_encoder(tag):
 def test_oracle_macroblock_pipeline_configs1_full_size():
     """BASELINE configs[1] with RDOptimization = 0 (G2r): I + P picture of the synthetic 1080p clip, 16 320 macroblocks (about half a minute)."""
     run_case("g2r")
+
+
+# High profile, Transform8x8Mode = 1: transform_decision for 16x16 / 16x8 / 8x16, the tr8x8 and tr4x4 passes of P8x8, Intra8x8, 8x8 Hadamard SATD in the sub-pel
+# searches, residual_transform_quant_luma_8x8 with CAVLC (q1h, m1hq) and CABAC (q2hc, m3h: three references, slices that start mid-row), with EPZS (m2he, m1hq)
+@pytest.mark.parametrize("tag", ["q1h", "q2hc", "m3h", "m2he", "m1hq"])
+def test_oracle_high_profile_pipeline_equals_the_reference_encoder(tag):
+    run_case(tag)
 
 
 def test_oracle_epzs_configs2_full_size():
