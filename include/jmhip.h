@@ -535,10 +535,12 @@ int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pitchY, uint8_
  * ------------------------------------------------------------------------------------------ */
 #define JMHIP_MB_MAX_REF 16
 typedef struct {
-  int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB (MBModeTypes, lcommon/inc/types.h) */
+  int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB, 13 I8MB (MBModeTypes, lencod/inc/defines.h:170-185) */
   int8_t   i16mode;             /* currMB->i16mode as find_sad_16x16 left it */
   int8_t   c_ipred_mode;        /* currMB->c_ipred_mode as rdo_low_intra_chroma_decision left it (written for intra macroblocks) */
-  int8_t   reserved0_;
+  int8_t   transform8x8;        /* currMB->luma_transform_size_8x8_flag.  With it the 64 levels of 8x8 block b8 lie in the 8x8 scan's zig-zag order at
+                                   luma[4 * b8 + (s >> 4)][s & 15]: JM keeps them as one 64-entry list (CABAC, cofAC[b8][0]) or de-interleaved into four lists
+                                   (CAVLC, quant_8x8cavlc_normal: list s & 3, place s >> 2); Intra8x8: ipredmode per 4x4 block, ipred_syntax at [4 * b8] */
   int16_t  cbp;                 /* currMB->cbp */
   int16_t  reserved1_;
   uint64_t cbp_blk;             /* currMB->cbp_blk */
@@ -590,6 +592,12 @@ typedef struct {
   int32_t poc_cur;              /* enc_picture->poc */
   int32_t poc_ref[JMHIP_MB_MAX_REF];   /* listX[LIST_0][r]->poc: EPZS scales its predictors by picture distances; the temporal predictors are the vectors
                                    jmhip_reference_from_recon kept with slots ref_slot[0] / [1] (a slot loaded by jmhip_set_reference has none: zero vectors) */
+  /* High profile (ignored with transform8x8 0) */
+  int32_t transform8x8;         /* p_Inp->Transform8x8Mode: 0, or 1 = the 8x8 transform beside the 4x4 one: transform_decision (macroblock.c:1347) for 16x16 / 16x8 / 8x16,
+                                   the tr8x8 pass of P8x8 (mode_decision_P8x8.c:681), Intra8x8 (transform8x8.c:241), 8x8 Hadamard SATD in the sub-pel search of
+                                   blocks of 8x8 samples and more (mv_search.c:1624, :1768); needs inter_valid[4] in P slices */
+  int32_t intra8_valid;         /* enc_mb.valid[I8MB] (mode_decision.c:127) */
+  jmhip_qparam q_luma8[2][64];  /* p_Quant->q_params_8x8[0][intra][qp][j][i] at [intra][j * 8 + i] */
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);

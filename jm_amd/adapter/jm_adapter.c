@@ -1263,7 +1263,8 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->SkipDeBlockNonRef || p->DisposableP) why = "SkipDeBlockNonRef / DisposableP (pictures that are not deblocked stay on the device)";
     else if (p->RDPictureDeblocking || p->RDPictureDecision) why = "RDPictureDecision / RDPictureDeblocking";
     else if (p->redundant_pic_flag) why = "UseRedundantPicture";
-    else if (p->Transform8x8Mode != 0) why = "Transform8x8Mode";
+    else if (p->Transform8x8Mode != 0 && p->Transform8x8Mode != 1) why = "Transform8x8Mode 2 (8x8 transform only)";
+    else if (p->Transform8x8Mode == 1 && (p->ScalingMatrixPresentFlag || p->RDOQ_CP_MV || !p->InterSearch[0][0][4])) why = "Transform8x8Mode with scaling matrices / RDOQ_CP_MV / without the 8x8 partition";
     else if (p->AdaptiveRounding != 0) why = "AdaptiveRounding";
     else if (p->WeightedPrediction || p->WeightedBiprediction) why = "weighted prediction";
     else if (p->RCEnable) why = "rate control";
@@ -1357,6 +1358,16 @@ static void pipe_run_slice(Macroblock *currMB)
         }
       }
   prm.symbol_mode = currSlice->symbol_mode == CABAC;        /* the entropy coder stays JM's; the quantiser clamps levels for CAVLC only */
+  if (p_Inp->Transform8x8Mode == 1) {                       /* High profile: the 8x8 transform beside the 4x4 one, Intra8x8 */
+    prm.transform8x8 = 1;
+    prm.intra8_valid = enc_mb.valid[I8MB];
+    for (intra = 0; intra < 2; intra++)
+      for (j = 0; j < 8; j++)
+        for (i = 0; i < 8; i++) {
+          const LevelQuantParams *q = &p_Quant->q_params_8x8[0][intra][currMB->qp_scaled[0]][j][i];
+          prm.q_luma8[intra][j * 8 + i].OffsetComp = q->OffsetComp; prm.q_luma8[intra][j * 8 + i].ScaleComp = q->ScaleComp; prm.q_luma8[intra][j * 8 + i].InvScaleComp = q->InvScaleComp;
+        }
+  }
   if (p_Inp->SearchMode[0] == EPZS) {                       /* EPZSStructInit / EPZSSliceInit read these (me_epzs_common.c:423, :620) */
     prm.search_mode = 3;
     prm.epzs_pattern = p_Inp->EPZSPattern; prm.epzs_dual = p_Inp->EPZSDual; prm.epzs_fixed = p_Inp->EPZSFixed; prm.epzs_aggressive = p_Inp->EPZSAggressiveWindow;
@@ -1390,7 +1401,7 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
   currMB->best_mode = (short)(mbt == 0 ? 1 : mbt);
   currMB->ar_mode = currMB->best_mode;
   currMB->cbp = r->cbp; currMB->cbp_blk = (int64)r->cbp_blk;
-  currMB->luma_transform_size_8x8_flag = FALSE;
+  currMB->luma_transform_size_8x8_flag = (byte)(r->transform8x8 != 0);
   currMB->i16mode = r->i16mode;
   currMB->i16offset = mbt == I16MB ? I16Offset(r->cbp, r->i16mode) : 0;
   currMB->c_ipred_mode = intra ? r->c_ipred_mode : DC_PRED_8;
@@ -1400,6 +1411,7 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
     currMB->b8x8[k].ref[LIST_0] = r->b8ref[k]; currMB->b8x8[k].ref[LIST_1] = -1; currMB->b8x8[k].bipred = 0;
   }
   memcpy(currMB->intra_pred_modes, r->ipred_syntax, 16);
+  if (mbt == I8MB) memcpy(currMB->intra_pred_modes8x8, r->ipred_syntax, 16);       /* writeIntra8x8Modes (macroblock.c:1817) reads these, at [4 * b8] */
   for (j = 0; j < 4; j++)
     for (i = 0; i < 4; i++) {
       PicMotionParams *mp = &motion[currMB->block_y + j][currMB->block_x + i];
@@ -1409,6 +1421,22 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
       mp->ref_idx[LIST_0] = (char)ref; mp->ref_pic[LIST_0] = ref < 0 ? NULL : currSlice->listX[LIST_0][ref];
       mp->mv[LIST_1].mv_x = mp->mv[LIST_1].mv_y = 0; mp->ref_idx[LIST_1] = -1; mp->ref_pic[LIST_1] = NULL;
     }
+  if (r->transform8x8 && mbt != I4MB && mbt != I16MB) {
+    /* an 8x8 transform block: the record holds its 64 levels in zig-zag order; JM's writers read one 64-entry list (CABAC, residual_transform_quant_luma_8x8
+     * transform8x8.c:522) or four lists of every fourth position (CAVLC, residual_transform_quant_luma_8x8_cavlc :604) */
+    for (k = 0; k < 4; k++) {
+      const int16_t *z = &r->luma[4 * k][0];
+      if (currSlice->symbol_mode == CABAC) {
+        list_from_dense(z, 0, 64, currSlice->cofAC[k][0][0], currSlice->cofAC[k][0][1]);
+        for (j = 1; j < 4; j++) { currSlice->cofAC[k][j][0][0] = 0; currSlice->cofAC[k][j][1][0] = 0; }
+      } else
+        for (j = 0; j < 4; j++) {
+          int16_t d16[16];
+          for (i = 0; i < 16; i++) d16[i] = z[4 * i + j];
+          list_from_dense(d16, 0, 16, currSlice->cofAC[k][j][0], currSlice->cofAC[k][j][1]);
+        }
+    }
+  } else
   for (k = 0; k < 16; k++) list_from_dense(r->luma[k], mbt == I16MB ? 1 : 0, 16, currSlice->cofAC[k >> 2][k & 3][0], currSlice->cofAC[k >> 2][k & 3][1]);
   list_from_dense(r->luma_dc, 0, mbt == I16MB ? 16 : 0, currSlice->cofDC[0][0], currSlice->cofDC[0][1]);
   for (uv = 0; uv < 2; uv++) {

@@ -44,7 +44,7 @@ __device__ __forceinline__ int mvy(int p) { return p >> 16; }
 __device__ __forceinline__ int mvpack(int x, int y) { return (x & 0xffff) | (y << 16); }
 __device__ __forceinline__ int median3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
-static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 1608, "record sizes of include/jmhip.h");
+static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 3152, "record sizes of include/jmhip.h");
 
 struct PipeArgs {
   jmhip_slice_params p;
@@ -114,6 +114,19 @@ struct Shared {
   u32 ytab4[4][72];                          // the same for the four usual offsets of the predictor from the search centre (-2 .. 1 quarter-pels), full range: once per launch
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
+  // High profile (Transform8x8Mode 1)
+  jmhip_qparam q8[2][64];                    // the slice's 8x8 quantiser tables
+  int t8buf[64];                             // scratch of tq8_wave
+  int i8_cost, i8_cbp;                       // Intra8x8
+  int8_t i8_ipm[16], i8_syn[4];
+  int16_t i8_lev[16][16];
+  u8 i8_rec[256], i8p[28], i8f[28];
+  int m_t8[4];                               // transform_decision of modes 1..3
+  int p8t_ref[4], p8t_total, p8t_cnt, p8t_cbp, p8t_nonz;   // the tr8x8 pass of P8x8: references, cost, blocks decided, cbp8x8, cnt_nonz_8x8
+  u64 p8t_cbp_blk;
+  int16_t t8_lev[16][16];
+  u8 t8_rec[256], t8_pred[256];
+  int fin_t8;                                // the macroblock's final luma_transform_size_8x8_flag (loop-filter side information)
   int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
   u64 fl_cbp_blk, fc_bits;
   u32 fin_cbp_blk;
@@ -696,8 +709,11 @@ __device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv
   return (int)(key & 15u);
 }
 
+#include "mbpipe_had8.inc"
+
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
 // view: which chain's picture of the macroblock's vectors the predictor reads; wave: this wave's own scratch (row table, SATD sums).
+template <bool T8>
 __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int mbx, int mby, int &out_mv)
 {
   const jmhip_slice_params &P = A.p;
@@ -770,6 +786,9 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     const int check0 = ref == 0 && bt == 1 && mv == 0;
     const bool grid = bt == 7;
     const int mv0 = mv;
+    const bool had8 = T8 && bt <= 4;                           // mv_block.test8x8 (mv_search.c:1624, :1768): 8x8 Hadamard sub-blocks in computeSATD
+    auto sx9 = [](int k) { return sp9x(k); };
+    auto sy9 = [](int k) { return sp9y(k); };
     if (grid) {                                               // subpel_grid49 with the rows fetched ahead, if the guess held
       if (mv != spec_mv) ref_rows4(A, ref, (px << 2) + mvx(mv) + g_ox, (py << 2) + mvy(mv) + g_oy, sr);
       u32 o[4];
@@ -778,11 +797,13 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
       if (lane < 49) S.red[wave][lane] = satd4_rows(o, sr);
       wave_sync();
     }
+    else if (had8) subpel_satds8(S, A, S.red[wave], lane, ref, px, py, mb_x, mb_y, BW / 8, BH / 8, mv, 2, sx9, sy9);
     else subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
     int best = scan9(S, wave, lane, mv, 2, P.lambda_mf[1], c.pqx, c.pqy, check0 ? P.lambda_mf[1] * 16 : 0, 0, 0, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + 2 * sp9x(best), mvy(mv) + 2 * sp9y(best));
     BS_STAMP(21);
-    if (!grid) subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
+    if (had8) subpel_satds8(S, A, S.red[wave], lane, ref, px, py, mb_x, mb_y, BW / 8, BH / 8, mv, 1, sx9, sy9);
+    else if (!grid) subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
     best = scan9(S, wave, lane, mv, 1, P.lambda_mf[2], c.pqx, c.pqy, 0, min_mcost, P.start_qp, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + sp9x(best), mvy(mv) + sp9y(best));
   }
@@ -800,6 +821,19 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     for (int j = 0; j < 4; j++) { r[j] = ldu32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
     int v = lane < 16 ? satd4_rows(o, r) : 0;
     v = rfl(group_sum(v, 16));
+    if (T8) {                                                  // GetSkipCostMB with Transform8x8Mode: distortion8x8 of the four 8x8 blocks of the 16x16 prediction (one origin)
+      int d[64];
+      const int b8 = lane & 3, x8 = (b8 & 1) * 8, y8 = (b8 >> 1) * 8;
+      const u8 *p8 = A.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + y8) * A.ref_pitch + ix + JMHIP_PAD_X + x8;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const u32 r0 = ldu32(p8 + (long)j * A.ref_pitch), r1 = ldu32(p8 + (long)j * A.ref_pitch + 4), o0 = S.cur_y[(y8 + j) * 4 + (x8 >> 2)], o1 = S.cur_y[(y8 + j) * 4 + (x8 >> 2) + 1];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { d[8 * j + i] = (int)((o0 >> (8 * i)) & 255) - (int)((r0 >> (8 * i)) & 255); d[8 * j + 4 + i] = (int)((o1 >> (8 * i)) & 255) - (int)((r1 >> (8 * i)) & 255); }
+      }
+      int v8 = lane < 4 ? hadamard8(d) : 0;
+      v = rfl(group_sum(v8, 4));
+    }
     const int cost = (v << 5) - P.lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = sv; }
   }
@@ -1038,6 +1072,7 @@ __device__ __forceinline__ void ihadamard4x4_jm(int (&m)[16])
 }
 
 #include "mbpipe_intra.inc"
+#include "mbpipe_t8.inc"
 #include "mbpipe_final.inc"
 #include "mbpipe_epzs.inc"
 #include "mbpipe_kernel.inc"

@@ -77,7 +77,7 @@ IC_MB = np.dtype([("up", "u1", (2, 8)), ("left", "u1", (2, 16)), ("corner", "u1"
                   ("reserved_", "u1", (3,))])
 assert IP4_BLK.itemsize == 16 and I16_MB.itemsize == 40 and I16_OUT.itemsize == 1040 and IC_MB.itemsize == 56
 MB_MAX_REF = 16
-MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("reserved0_", "i1"), ("cbp", "<i2"), ("reserved1_", "<i2"),
+MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("transform8x8", "i1"), ("cbp", "<i2"), ("reserved1_", "<i2"),
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
                       ("chroma_dc", "<i2", (2, 4)), ("chroma_ac", "<i2", (2, 4, 16))])
@@ -89,8 +89,9 @@ SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", 
                          ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("num_slices", "<i4"), ("symbol_mode", "<i4"), ("search_mode", "<i4"), ("reserved_", "<i4", (2,)),
                          ("epzs_pattern", "<i4"), ("epzs_dual", "<i4"), ("epzs_fixed", "<i4"), ("epzs_aggressive", "<i4"), ("epzs_temporal", "<i4"), ("epzs_spatial_mem", "<i4"),
                          ("epzs_blocktype", "<i4"), ("epzs_min_scale", "<i4"), ("epzs_med_scale", "<i4"), ("epzs_max_scale", "<i4"), ("epzs_sub_scale", "<i4"), ("epzs_reserved_", "<i4"),
-                         ("poc_cur", "<i4"), ("poc_ref", "<i4", (MB_MAX_REF,))])
-assert MB_RECORD.itemsize == 944 and SLICE_PARAMS.itemsize == 1608
+                         ("poc_cur", "<i4"), ("poc_ref", "<i4", (MB_MAX_REF,)),
+                         ("transform8x8", "<i4"), ("intra8_valid", "<i4"), ("q_luma8", "<i4", (2, 64, 3))])
+assert MB_RECORD.itemsize == 944 and SLICE_PARAMS.itemsize == 3152
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 

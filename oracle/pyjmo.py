@@ -274,6 +274,12 @@ def qparams_4x4(qp, intra, offset):
     return q
 
 
+def qparams_8x8(qp, intra, offset):
+    q = np.zeros((64, 3), np.int32)
+    L.jmo_qparams_8x8(qp, intra, offset, _p(q))
+    return q
+
+
 def deblock_frame(y, u, v, fmt, mbs, mot, maxy=255, maxc=255, d8=1):
     """y,u,v uint8/uint16 planes (copied); mbs (N,12) int array in ref_tap order; mot (H/4,W/4,2,3)."""
     Y = np.ascontiguousarray(y, np.uint16).copy()

@@ -44,6 +44,10 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
     for r, (s, i) in enumerate(zip(ref_slots, ref_ids)):
         p["ref_slot"][0, r] = s
         p["ref_id"][0, r] = i
+    if cfg.transform8x8:
+        p["transform8x8"], p["intra8_valid"] = cfg.transform8x8, cfg.intra8_valid
+        for intra in range(2):
+            p["q_luma8"][0, intra] = pyjmo.qparams_8x8(cfg.qp, intra, cfg.q_offset8[intra])
     for intra in range(2):
         p["q_luma"][0, intra] = pyjmo.qparams_4x4(cfg.qp, intra, cfg.q_offset[intra])
         for uv in range(2):
@@ -55,9 +59,10 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0):
         self.cabac = cabac
         self.search_mode, self.epzs = search_mode, dict(epzs or {})
+        self.transform8x8 = transform8x8
         import jm_amd.lib as L
         self.together = together      # all slices of a picture in one launch (num_slices), as the adapter does for SliceMode 1
         self.L = L
@@ -77,7 +82,7 @@ class DevSeqEncoder:
         slices = mbenc_util.slices_of(nmb, self.slice_mbs)
         for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode)
+            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc, self.epzs, 2 * self.npic)
             if timing is not None:
                 J.enable_timing(True)
@@ -115,7 +120,7 @@ def load_case(tag):
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]],
                 didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)),
-                search_mode=int(ov.get("SearchMode", -1)), epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov})
+                search_mode=int(ov.get("SearchMode", -1)), epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
 
 
 EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFixedPredictors", aggressive="EPZSAggressiveWindow", temporal="EPZSTemporal",
@@ -144,15 +149,16 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
     EPZS (SearchMode 3): the reference's clip (q1e), five references (m5e), CABAC + slices that start mid-row (m2c), the other patterns and window set
-    (m3p), every optional predictor set off (m2t), and BASELINE configs[2]'s search at 1920x1080 (g3e: Main profile, CABAC, 24 480 macroblocks)."""
+    (m3p), every optional predictor set off (m2t), and BASELINE configs[2]'s search at 1920x1080 (g3e: Main profile, CABAC, 24 480 macroblocks).
+    High profile (Transform8x8Mode 1: transform decisions, the tr8x8 pass of P8x8, Intra8x8): CAVLC (q1h, m1hq), CABAC (q2hc, m3h), with EPZS (m2he, m1hq)."""
     c = load_case(tag)
     enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
-                        search_mode=c["search_mode"], epzs=c["epzs"])
+                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     data = clip_bytes(tag, c)
     fs = c["sw"] * c["sh"] * 3 // 2
