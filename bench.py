@@ -40,8 +40,8 @@ G2R_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", 
              "NumberReferenceFrames=1", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
 G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's .264 for two frames of the clip with these flags
 # HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
-# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r02_v2_kernel_stats.md)
-PIPE_TRAFFIC_BYTES = 1056860000            # mostly scratch memory: loop-invariant registers the compiler spills
+# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v2_kernel_stats.md)
+PIPE_TRAFFIC_BYTES = 995994624            # mostly scratch memory: loop-invariant registers the compiler spills
 
 
 def synth_luma(n_frames, seed=1234):
@@ -92,8 +92,8 @@ def yuv_frames(n_frames, seed=1234):
 
 
 G3E_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", "OutputWidth=1920", "OutputHeight=1080", "SearchMode=3", "SearchRange=32",
-             "NumberReferenceFrames=5", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "SymbolMode=1", "ProfileIDC=77", "OutputFile=o.264", "ReconFile=o_rec.yuv",
-             "TraceFile=/dev/null")        # tests/golden/mb_low_g3e.npz: BASELINE configs[2]'s search (Main profile, CABAC, EPZS), P pictures only, 4x4 transform
+             "NumberReferenceFrames=5", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "SymbolMode=1", "ProfileIDC=100", "Transform8x8Mode=1", "OutputFile=o.264",
+             "ReconFile=o_rec.yuv", "TraceFile=/dev/null")        # tests/golden/mb_low_g3h.npz: BASELINE configs[2] as stated (CABAC, 8x8 transform on, EPZS), P pictures only
 
 
 def run_lencod(exe, frames, timeout, flags=None, clip=None):
@@ -192,10 +192,10 @@ def configs2_end_to_end(max_seconds=300):
         return {"available": False, "why": "timeout"}
     if not c or not h:
         return {"available": False, "why": "an encoder failed"}
-    gold = str(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3e.npz"))["md5_264"])
+    gold = str(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["md5_264"])
     return {"available": True, "p_frame_ms_cpu_jm": c[0].get("P"), "p_frame_ms_hip": h[0].get("P"), "wall_s_cpu_jm": round(c[3], 2), "wall_s_hip": round(h[3], 2),
-            "speedup_p_frames": round(sum(c[0]["P"]) / max(1, sum(h[0]["P"])), 2), "md5_equal": c[1] == h[1], "md5_is_g3e": h[1] == gold, "adapter": h[2],
-            "config": "lencod -d jm_baseline.cfg " + " ".join("-p " + f for f in G3E_FLAGS[:13]) + " -p FramesToBeEncoded=3"}
+            "speedup_p_frames": round(sum(c[0]["P"]) / max(1, sum(h[0]["P"])), 2), "md5_equal": c[1] == h[1], "md5_is_g3h": h[1] == gold, "adapter": h[2],
+            "config": "lencod -d jm_baseline.cfg " + " ".join("-p " + f for f in G3E_FLAGS[:14]) + " -p FramesToBeEncoded=3"}
 
 
 def configs3_end_to_end(max_seconds=400):
@@ -426,6 +426,27 @@ def main():
         def epzs_prm(slice_type, num_ref, poc_cur):
             q = slice_prm(slice_type, 0, nmb, 0, num_ref)
             q["search_mode"], q["symbol_mode"] = 3, 1
+            q["transform8x8"], q["intra8_valid"] = 1, 1                  # High profile: q_params_8x8 at QP 28 (qp % 6 == 4 rows of quant_coef8 / dequant_coef8, q_matrix.c:38-167)
+            s8, d8 = [8192, 7346, 13159, 7740, 10486, 9777], [32, 28, 51, 30, 40, 38]
+
+            def cls8(j, i):
+                i4, j4 = i & 3, j & 3
+                if i4 == 0 and j4 == 0:
+                    return 0
+                if (i & 1) and (j & 1):
+                    return 1
+                if i4 == 2 and j4 == 2:
+                    return 2
+                if (i4 == 0 and (j & 1)) or ((i & 1) and j4 == 0):
+                    return 3
+                if (i4 == 0 and j4 == 2) or (i4 == 2 and j4 == 0):
+                    return 4
+                return 5
+            for intra in range(2):
+                off = 682 if (intra and slice_type == 2) else 342
+                for j in range(8):
+                    for i in range(8):
+                        q["q_luma8"][0, intra, j * 8 + i] = (off << (16 + QP // 6 - 11), s8[cls8(j, i)], d8[cls8(j, i)] << 4)
             for k, v in dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2).items():
                 q["epzs_" + k] = v                                        # the shipped .cfg files' switches
             q["poc_cur"] = poc_cur
@@ -445,10 +466,10 @@ def main():
         erecs = ctx.encode_slice(pe)
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import mb_tap
-        g3 = np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3e.npz"))["records"][nmb:2 * nmb]
+        g3 = np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"][nmb:2 * nmb]
         mine = np.frombuffer(erecs.tobytes(), g3.dtype).copy()
-        configs2_device = {"workload": "configs[2]'s search: 1080p, Main profile (CABAC), EPZS (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid), "
-                                       "RDO off, P picture with one reference, 4x4 transform", "kernel": "k_mb_pipe_epzs",
+        configs2_device = {"workload": "configs[2]: 1080p, High profile (CABAC, 8x8 transform on: Transform8x8Mode 1, Intra8x8), EPZS (pattern 2, dual 3, fixed 2, temporal, "
+                                       "spatial memory, block type, sub-pel grid), RDO off, P picture with one reference", "kernel": "k_mb_pipe_epzs_t8",
                            "avg_kernel_ms": round(float(np.mean(ems[1:])), 3), "macroblocks_per_s": round(nmb / (float(np.mean(ems[1:])) * 1e-3), 1),
                            "records_equal_jm": bool(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), g3)))}
 
@@ -461,7 +482,7 @@ def main():
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
-                "traffic_source": "profiles/r02_v2_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
+                "traffic_source": "profiles/r03_v2_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
                 "abs_diff_per_s_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 148.4e12, 5),
                 "critical_path": {"steps": W // 16 + 2 * (H // 16 - 1), "us_per_step": round(pipe_ms * 1e3 / (W // 16 + 2 * (H // 16 - 1)), 1),
                                   "note": "a macroblock waits for its left and upper-right neighbours' vectors: the picture is a chain of mb_w + 2 (mb_h - 1) "

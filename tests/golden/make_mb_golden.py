@@ -48,6 +48,8 @@ CASES = {
                  FramesToBeEncoded="5", QPISlice="24", QPPSlice="24"), (208, 160), 5, "motion:21"),
     "m2he": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", FramesToBeEncoded="4"), (176, 144), 4, "motion:22"),   # EPZS + 8x8: configs[2]
     "m1hq": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="1", Transform8x8Mode="1", ProfileIDC="100", FramesToBeEncoded="3", QPISlice="40", QPPSlice="40"), (176, 144), 3, "motion:23"),   # CAVLC, coarse
+    # BASELINE configs[2] as stated (High profile so that the 8x8 transform exists: CABAC, 8x8 transform on, EPZS), P pictures only, RDO off
+    "g3h": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="100", Transform8x8Mode="1")), (1920, 1080), 3, True),
     "q1e": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="1"), (176, 144), 3, False),          # the reference's own clip
     "m5e": (dict(RDO_OFF, SearchMode="3", SearchRange="32", FramesToBeEncoded="6"), (208, 160), 6, "motion:11"),         # five references: the ref > 0 exits, scaled predictors
     "m2c": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", SymbolMode="1", ProfileIDC="77", SliceMode="1", SliceArgument="40", FramesToBeEncoded="4"), (176, 144), 4, "motion:12"),   # CABAC, slices that start mid-row

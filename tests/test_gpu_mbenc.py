@@ -149,13 +149,14 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
     EPZS (SearchMode 3): the reference's clip (q1e), five references (m5e), CABAC + slices that start mid-row (m2c), the other patterns and window set
     (m3p), every optional predictor set off (m2t), and BASELINE configs[2]'s search at 1920x1080 (g3e: Main profile, CABAC, 24 480 macroblocks).
-    High profile (Transform8x8Mode 1: transform decisions, the tr8x8 pass of P8x8, Intra8x8): CAVLC (q1h, m1hq), CABAC (q2hc, m3h), with EPZS (m2he, m1hq)."""
+    High profile (Transform8x8Mode 1: transform decisions, the tr8x8 pass of P8x8, Intra8x8): CAVLC (q1h, m1hq), CABAC (q2hc, m3h), with EPZS (m2he, m1hq),
+    and BASELINE configs[2] as stated at 1920x1080 (g3h: CABAC, 8x8 transform on, EPZS)."""
     c = load_case(tag)
     enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
                         search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"])

@@ -289,13 +289,14 @@ def test_lencod_macroblock_pipeline_configs1_full_size_1080p(tmp_path):
 
 
 @pytest.mark.gpu
-def test_lencod_macroblock_pipeline_configs2_epzs_1080p(tmp_path):
-    """BASELINE.json configs[2]'s search end to end at full size with RDOptimization = 0 (g3e: 1080p, Main profile, CABAC, EPZS with the shipped switches,
-    five references configured, I + 2 P pictures): every EPZS search runs inside the device's macroblock pipeline -- zero jmhip_me_eval calls, zero calls
-    passed to JM -- and the bitstream and the reconstruction equal CPU JM's."""
+@pytest.mark.parametrize("tag", ["g3e", "g3h"])
+def test_lencod_macroblock_pipeline_configs2_epzs_1080p(tmp_path, tag):
+    """BASELINE.json configs[2] end to end at full size with RDOptimization = 0 and P pictures only: g3e = Main profile (CABAC, EPZS with the shipped switches,
+    five references configured, I + 2 P pictures), g3h = the same in High profile with the 8x8 transform on (configs[2] as stated).  Every EPZS search runs
+    inside the device's macroblock pipeline -- zero jmhip_me_eval calls, zero calls passed to JM -- and the bitstream and the reconstruction equal CPU JM's."""
     if not os.path.exists(EXE):
         pytest.fail("oracle/_ref/lencod_hip.exe missing")
-    r, z = run_rdo_off_case("g3e", str(tmp_path))
+    r, z = run_rdo_off_case(tag, str(tmp_path))
     err, out = r.stderr.decode(errors="replace"), r.stdout.decode(errors="replace")
     assert r.returncode == 0, (out[-1500:], err[-1500:])
     rep = pipeline_report(err)
@@ -304,7 +305,7 @@ def test_lencod_macroblock_pipeline_configs2_epzs_1080p(tmp_path):
     assert c["passed"] == 0 and c["eval"] == 0 and c["evalp"] == 0 and c["fs"] == 0 and c["subpel"] == 0, c
     assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
     assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
-    print(f"configs[2] (EPZS, CABAC), RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
+    print(f"configs[2] ({tag}: EPZS, CABAC), RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
 
 
 def run_2160p(tag, tmp, env_extra=None):

@@ -112,5 +112,11 @@ def test_oracle_epzs_configs2_full_size():
     assert [s for s, _ in enc.epzs_stats] == [334560, 669120] and all(a == 0 for _, a in enc.epzs_stats)
 
 
+def test_oracle_configs2_as_stated_full_size():
+    """BASELINE configs[2] as stated -- 1080p, CABAC, 8x8 transform on (High profile), EPZS -- with RDO off and P pictures only (g3h): 24 480 macroblocks."""
+    enc = run_case("g3h")
+    assert all(a == 0 for _, a in enc.epzs_stats)
+
+
 def test_record_layout():
     assert pyjmo.MB_RECORD.itemsize == 944
