@@ -580,7 +580,8 @@ typedef struct {
   int32_t num_slices;           /* 0 or 1: one slice.  n > 1: the call covers n consecutive slices of num_mb macroblocks each (the last one ends with the
                                    picture), same parameters, slice_nr counting up -- SliceMode 1 pictures: the slices' wavefronts run side by side */
   int32_t symbol_mode;          /* currSlice->symbol_mode: 0 = CAVLC (levels clamped to CAVLC_LEVEL_LIMIT = 2063: quant4x4_normal.c:84, :160, :233, quantChroma_normal.c:69), 1 = CABAC (no clamp) */
-  int32_t search_mode;          /* 0: full_search_motion_estimation (JM's SearchMode -1); 3: EPZS (SearchMode 3) with EPZSSubPelGrid = 1 and EPZSSubPelME = 1,
+  int32_t search_mode;          /* 0: full_search_motion_estimation (JM's SearchMode -1); 1: fast_full_search_motion_estimation (SearchMode 0, me_fullfast.c:618: one search
+                                   centre per macroblock and reference, the (0,0) vector first; RestrictSearchRange 2); 3: EPZS (SearchMode 3) with EPZSSubPelGrid = 1 and EPZSSubPelME = 1,
                                    the shipped settings: EPZS_integer_motion_estimation lencod/src/me_epzs_int.c:42, its sub-macroblock variant :437,
                                    EPZS_sub_pel_motion_estimation me_epzs_sub.c:30 (start_qp must be 1) */
   int32_t reserved_[2];

@@ -1257,7 +1257,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     if (!G.part_mbpipe) why = "part mbpipe not selected";
     else if (p->rdopt != 0) why = "RDOptimization != 0";
     else if (p_Vid->yuv_format != YUV420) why = "not 4:2:0";
-    else if (p->SearchMode[0] != FULL_SEARCH && p->SearchMode[0] != EPZS) why = "SearchMode other than -1 (full search) and 3 (EPZS)";
+    else if (p->SearchMode[0] != FULL_SEARCH && p->SearchMode[0] != FAST_FULL_SEARCH && p->SearchMode[0] != EPZS) why = "SearchMode other than -1 (full search), 0 (fast full search) and 3 (EPZS)";
     else if (p->SearchMode[0] == EPZS && (!p->EPZSSubPelGrid || p->EPZSSubPelME != 1 || p->HMEEnable)) why = "EPZS without EPZSSubPelGrid = 1 / EPZSSubPelME = 1, or with HME";
     else if (p->DisableMEPrediction) why = "DisableMEPrediction";
     else if (p->SkipDeBlockNonRef || p->DisposableP) why = "SkipDeBlockNonRef / DisposableP (pictures that are not deblocked stay on the device)";
@@ -1284,7 +1284,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->HierarchicalCoding || p->PicInterlace != FRAME_CODING || p->MbInterlace != FRAME_CODING) why = "hierarchical / interlaced coding";
     else if (R < 1 || R > 32) why = "SearchRange outside 1..32";
     else if (p_Vid->max_num_references > JMHIP_MB_MAX_REF) why = "more than 16 references";
-    else if (p->SearchMode[0] == FULL_SEARCH && (size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
+    else if (p->SearchMode[0] != EPZS && (size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
     else if (p_Vid->bitdepth_chroma_qp_scale != 0) why = "chroma QP scale";
     P.ok = why == NULL;
     if (!P.ok && G.part_mbpipe && p->rdopt == 0)
@@ -1368,6 +1368,7 @@ static void pipe_run_slice(Macroblock *currMB)
           prm.q_luma8[intra][j * 8 + i].OffsetComp = q->OffsetComp; prm.q_luma8[intra][j * 8 + i].ScaleComp = q->ScaleComp; prm.q_luma8[intra][j * 8 + i].InvScaleComp = q->InvScaleComp;
         }
   }
+  if (p_Inp->SearchMode[0] == FAST_FULL_SEARCH) prm.search_mode = 1;
   if (p_Inp->SearchMode[0] == EPZS) {                       /* EPZSStructInit / EPZSSliceInit read these (me_epzs_common.c:423, :620) */
     prm.search_mode = 3;
     prm.epzs_pattern = p_Inp->EPZSPattern; prm.epzs_dual = p_Inp->EPZSDual; prm.epzs_fixed = p_Inp->EPZSFixed; prm.epzs_aggressive = p_Inp->EPZSAggressiveWindow;

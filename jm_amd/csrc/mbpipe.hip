@@ -116,7 +116,7 @@ struct Shared {
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
   // High profile (Transform8x8Mode 1)
   jmhip_qparam q8[2][64];                    // the slice's 8x8 quantiser tables
-  int t8buf[64];                             // scratch of tq8_wave
+  int t8buf[2][64];                          // scratch of tq8_wave: [0] the inter side (the tr8x8 pass, the final stage), [1] the Intra8x8 chain -- they run side by side
   int i8_cost, i8_cbp;                       // Intra8x8
   int8_t i8_ipm[16], i8_syn[4];
   int16_t i8_lev[16][16];
@@ -751,6 +751,16 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   c.lambda = P.lambda_mf[0]; c.cqx = cx; c.cqy = cy; c.pqx = mvx(pred); c.pqy = mvy(pred);
   c.Rs = min(max(min(max_x, max_y) >> 2, 0), R); c.R = R;
   c.check00 = bt == 1 && ref == 0;
+  const bool ffs = P.search_mode == 1;
+  if (ffs) {
+    // fast_full_search_motion_estimation (me_fullfast.c:618-689, rdopt == 0): every block of the macroblock is searched around ONE centre per reference, the
+    // rounded 16x16 predictor (setup_fast_full_search :310-328; its neighbours lie outside the macroblock, so any chain's view gives it), over
+    // imax(max_x, max_y) >> 2 rings (:633); the (0,0) vector is tried first (below); the max_mvd guard (:638, :671) cannot fire (checked by the host)
+    const int p16 = rfl(mv_predictor(S, view, avm, ref, 0, 0, 16, 16, lane));
+    cx = clampi3(-(R << 2), R << 2, ((mvx(p16) + 2) >> 2) * 4); cy = clampi3(-(R << 2), R << 2, ((mvy(p16) + 2) >> 2) * 4);
+    cx = clampi3(P.mv_limit[0] + (R << 2), P.mv_limit[1] - (R << 2), cx); cy = clampi3(P.mv_limit[2] + (R << 2), P.mv_limit[3] - (R << 2), cy);
+    c.cqx = cx; c.cqy = cy; c.Rs = min(max(max(max_x, max_y) >> 2, 0), R); c.check00 = 0;
+  }
   c.count = A.prof != nullptr && A.prof_mode == 11;
   const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
@@ -781,6 +791,16 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   BS_STAMP(20);
   int mv = mvpack(cx + 4 * ((klo & 255) - 128), cy + 4 * (((klo >> 8) & 255) - 128));
   int min_mcost = khi;
+  if (ffs) {                                                   // the (0,0) vector first (me_fullfast.c:650-657): it holds the minimum against any later equal cost
+    const u8 *p00 = win + (size_t)(mb_y + 2 * R) * A.win_p + mb_x + A.win_ox;       // the block's own position in the window
+    u32 v = 0;
+    if (lane < BH) {
+      for (int k = 0; k < BW / 4; k++) v = __builtin_amdgcn_sad_u8(ldu32(p00 + lane * A.win_p + 4 * k), cur[lane * 4 + k], v);
+    }
+    const int sad00 = rfl(group_sum((int)v, 16));
+    const int cost00 = (sad00 << 5) + c.lambda * (mvbits(0 - c.pqx) + mvbits(0 - c.pqy));
+    if (cost00 <= min_mcost) { min_mcost = cost00; mv = 0; }
+  }
 
   if (P.subpel) {                                             // sub_pel_motion_estimation me_fullsearch.c:186-289 (start_me_refinement_hp = 0)
     const int check0 = ref == 0 && bt == 1 && mv == 0;

@@ -257,6 +257,42 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
   mv.y = (int16_t)iclip3(c->mv_limit[2], c->mv_limit[3], mv.y);
   (void)min_x; (void)min_y;
 
+  if (c->search_mode == 1) {
+    /* ---- fast_full_search_motion_estimation me_fullfast.c:618-689 (rdopt == 0): every block of the macroblock is searched around ONE centre per reference,
+     * the rounded 16x16 predictor (setup_fast_full_search :310-328), the (0,0) vector first (:650-657), the max_mvd guard (:638, :671) ---- */
+    nb b16[4];
+    jmo_mv p16, ctr;
+    const int rq = c->search_range << 2, guard = c->max_mvd - 1;
+    int pos00 = -1;
+    get_neighbors(e, b16, 0, 0, 16);
+    p16 = mv_predictor(e, b16, ref, 0, 0, 16, 16);
+    ctr.x = (int16_t)iclip3(-rq, rq, ((p16.x + 2) >> 2) * 4);
+    ctr.y = (int16_t)iclip3(-rq, rq, ((p16.y + 2) >> 2) * 4);
+    ctr.x = (int16_t)iclip3(c->mv_limit[0] + rq, c->mv_limit[1] - rq, ctr.x);
+    ctr.y = (int16_t)iclip3(c->mv_limit[2] + rq, c->mv_limit[3] - rq, ctr.y);
+    R = imax_(max_x, max_y) >> 2;                              /* :633 (imax) */
+    max_pos = (2 * R + 1) * (2 * R + 1);
+    if (e->spiral_R < c->search_range) { free(e->spiral); e->spiral = (jmo_mv *)malloc(sizeof(jmo_mv) * (size_t)imax_(9, (2 * c->search_range + 1) * (2 * c->search_range + 1))); jmo_spiral(c->search_range, e->spiral); e->spiral_R = c->search_range; }
+    cx = pxp + ctr.x; cy = pyp + ctr.y;
+    if (imax_(iabs_(0 - pred.x), iabs_(0 - pred.y)) < guard) {
+      min_mcost = jmo_compute_sad(rp, orig, bsx, bsy, JMO_DIST_MAX, pxp, pyp) + mv_cost(c->lambda_mf[0], 0, 0, pred.x, pred.y);
+      pos00 = 0;                                               /* marks "the (0,0) vector holds the minimum" */
+    }
+    best_pos = -1;
+    for (pos = 0; pos < max_pos; pos++) {
+      const int vx = ctr.x + (e->spiral[pos].x << 2), vy = ctr.y + (e->spiral[pos].y << 2);
+      if (imax_(iabs_(vx - pred.x), iabs_(vy - pred.y)) >= guard) continue;
+      mcost = jmo_compute_sad(rp, orig, bsx, bsy, JMO_DIST_MAX, pxp + vx, pyp + vy);
+      if (mcost >= min_mcost) continue;
+      mcost += mv_cost(c->lambda_mf[0], vx, vy, pred.x, pred.y);
+      if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
+    }
+    if (best_pos >= 0) { mv.x = (int16_t)(ctr.x + (e->spiral[best_pos].x << 2)); mv.y = (int16_t)(ctr.y + (e->spiral[best_pos].y << 2)); }
+    else if (pos00 == 0) { mv.x = 0; mv.y = 0; }
+    else { mv = ctr; }                                         /* best_pos = 0 without any candidate: the centre */
+    (void)cx; (void)cy;
+    best_pos = 0;
+  } else {
   /* ---- full_search_motion_estimation me_fullsearch.c:39-103 ---- */
   R = imin_(max_x, max_y) >> 2;
   max_pos = (2 * R + 1) * (2 * R + 1);
@@ -275,6 +311,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
     if (mcost < min_mcost) { best_pos = pos; min_mcost = mcost; }
   }
   if (best_pos) { mv.x = (int16_t)(mv.x + (e->spiral[best_pos].x << 2)); mv.y = (int16_t)(mv.y + (e->spiral[best_pos].y << 2)); }
+  }
 
   /* ---- sub_pel_motion_estimation me_fullsearch.c:186-289; start_me_refinement_hp = 0 (SAD then SATD), start_me_refinement_qp = cfg (1 when the
    * half- and quarter-pel metrics are the same, mv_search.c:445-446: the quarter-pel stage then keeps the half-pel minimum and skips position 0) ---- */

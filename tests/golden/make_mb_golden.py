@@ -41,6 +41,10 @@ CASES = {
     # EPZS (SearchMode = 3) with the shipped EPZS switches (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid, EPZS sub-pel search)
     # BASELINE configs[2] without its 8x8 transform and B pictures: 1080p, Main profile, CABAC, EPZS, five references configured (two exist by the third picture)
     "g3e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 3, True),
+    # fast full search (SearchMode = 0, encoder_baseline.cfg's own): one search centre per macroblock and reference, the (0,0) vector first
+    "q5f": (dict(RDO_OFF, SearchMode="0", SearchRange="32"), (176, 144), 3, False),                                   # encoder_baseline.cfg as shipped but for RDO / adaptive rounding
+    "m5f": (dict(RDO_OFF, SearchMode="0", SearchRange="16", FramesToBeEncoded="6", SliceMode="1", SliceArgument="50"), (208, 160), 6, "motion:31"),     # five references, slices mid-row
+    "m3fh": (dict(RDO_OFF, SearchMode="0", SearchRange="32", NumberReferenceFrames="3", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", FramesToBeEncoded="4", QPISlice="32", QPPSlice="32"), (176, 144), 4, "motion:32"),
     # High profile: the 8x8 transform beside the 4x4 one (Transform8x8Mode = 1): transform_decision, the tr8x8 pass of P8x8, Intra8x8
     "q1h": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", Transform8x8Mode="1", ProfileIDC="100"), (176, 144), 3, False),     # CAVLC
     "q2hc": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1"), (176, 144), 3, False),   # CABAC

@@ -26,6 +26,8 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
     """jmhip_slice_params from the oracle's configuration record (same meaning field by field) plus JM's quantiser tables.
     epzs: the EPZS switches (dict, pyjmo.EPZS_DEFAULTS' keys) when cfg.search_mode is 3; picture order counts are 2 x the picture ids."""
     p = np.zeros(1, L.SLICE_PARAMS)
+    if cfg.search_mode == 1:
+        p["search_mode"] = 1
     if cfg.search_mode == 3:
         p["search_mode"] = 3
         for k, v in dict(pyjmo.EPZS_DEFAULTS, **(epzs or {})).items():
@@ -120,7 +122,7 @@ def load_case(tag):
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]],
                 didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)),
-                search_mode=int(ov.get("SearchMode", -1)), epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
+                search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))], epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
 
 
 EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFixedPredictors", aggressive="EPZSAggressiveWindow", temporal="EPZSTemporal",
@@ -149,7 +151,7 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).

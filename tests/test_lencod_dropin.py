@@ -158,7 +158,8 @@ def frame_times(stdout):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,nmb_total", [("q1r", 297), ("q5r", 297), ("q4r", 297), ("q4s", 297), ("q1c", 297), ("q0c", 297), ("q0r", 297),
                                            ("q1e", 297), ("m5e", 780), ("m2c", 396), ("m3p", 396), ("m2t", 384),      # EPZS (SearchMode 3)
-                                           ("q1h", 297), ("q2hc", 297), ("m3h", 650), ("m2he", 396), ("m1hq", 297)])  # High profile: the 8x8 transform, Intra8x8
+                                           ("q1h", 297), ("q2hc", 297), ("m3h", 650), ("m2he", 396), ("m1hq", 297),   # High profile: the 8x8 transform, Intra8x8
+                                           ("q5f", 297), ("m5f", 780), ("m3fh", 396)])                                 # fast full search (SearchMode 0)
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction

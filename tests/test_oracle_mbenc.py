@@ -35,7 +35,7 @@ def load_case(tag):
     didc = int(ov.get("DFDisableRefPSlice", 0))
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]], didc=didc,
-                nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)), search_mode=int(ov.get("SearchMode", -1)),
+                nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)), search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))],
                 epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
 
 
