@@ -15,8 +15,8 @@ with the REAL reference encoder's (tests/golden/mb_low_g2r.npz): `records_equal_
 (`cpu_baseline`, oracle/_ref/lencod.exe, one thread) -- both print their own per-picture times; the .264 md5s are compared.
 
 python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, one rank per GPU)
-N > 1: one picture of N 1080p bands, one slice (band) per GPU, DFDisableIdc = 2; every GPU holds the whole reference, each step ends with
-ONE RCCL all-gather of the reconstructed bands (luma + chroma) -- weak scaling.  Prints ONE JSON line on rank 0.
+N > 1: BASELINE configs[3] with RDO off -- one 2160p picture, 8 slices dealt to the N GPUs (multi_gpu_configs3 below): strong scaling of one sequence,
+with the N-independent-sequences figure beside it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -260,10 +260,202 @@ def concurrent_streams(S, raw0, raw1, src_h, slice_prm, device, steps):
             "note": "S sequences side by side on one MI355X, one context + HIP stream each (GPU_MAX_HW_QUEUES raised from its default 4 so that the streams get a hardware queue each); the same step as `value` per sequence; not the BASELINE metric (one sequence)"}
 
 
+def slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref, num_slices=0):
+    """jmhip_slice_params with JM's own values for configs[1] / configs[3] with RDO off (tests/golden/mb_low_g2r.npz holds what the encoder used)"""
+    p = np.zeros(1, SLICE_PARAMS)
+    p["slice_type"], p["first_mb"], p["num_mb"], p["slice_nr"], p["qp"], p["qpc"] = slice_type, first, num, slice_nr, QP, QP
+    p["search_range"], p["num_ref"], p["num_slices"] = R, num_ref, num_slices
+    p["lambda_mf"], p["lambda_mdfp"] = [192, 192, 192], 192               # lambda_mf / LAMBDA_FACTOR(lambda_md) at QP 28 with RDOptimization = 0
+    p["max_mvd"] = 1023                                                  # mv_search.c:327 at SearchRange 32
+    p["mv_limit"] = [-8192, 8191, -2048, 2047]                           # level 5.1
+    p["inter_valid"], p["intra4_valid"], p["intra16_valid"], p["subpel"], p["start_qp"] = 1, 1, 1, 1, 1
+    bits = [1, 3, 3] + [5] * 4 + [7] * 8 + [9]
+    p["refbits"] = bits
+    sc, ds = {0: 8192, 1: 3355, 2: 5243}, {0: 16, 1: 25, 2: 20}          # qp % 6 == 4 rows of quant_coef / dequant_coef (q_matrix.c:20-36)
+    for intra in range(2):
+        off = 682 if (intra and slice_type == 2) else 342                # q_offsets.c:135-162 default offsets
+        for j in range(4):
+            for i in range(4):
+                c = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 and j % 2) else 2)
+                q = (off << (15 + QP // 6 - 11), sc[c], ds[c] << 4)
+                p["q_luma"][0, intra, j * 4 + i] = q
+                p["q_chroma"][0, :, intra, j * 4 + i] = q
+    p["df_disable_idc"] = 0                                              # DeblockFrame filters across slice edges (the .cfg files' DFDisableIdc = 0)
+    return p
+
+
 class _DevMem:
     """device memory of the library as a torch tensor (for the collective)"""
     def __init__(self, ptr, nbytes):
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def multi_gpu_configs3(args, world, rank, local, dev, one_gpu):
+    """N > 1: BASELINE configs[3] with RDO off -- ONE 3840x2160 picture in 8 slices of 4080 macroblocks (SliceMode 1: bands of 17 ... 17, 16
+    macroblock rows), the slices dealt to the N GPUs in order (8 / N each, their wavefronts side by side in one launch), DFDisableIdc = 0 as the .cfg files
+    ship it: DeblockFrame filters across slice edges, so the picture is deblocked AFTER the exchange.  A step:
+      jmhip_encode_slice_dev       this rank's slices (k_mb_pipe), reconstruction and loop filter side information left in the rank's picture buffers
+      ONE all-gather (RCCL)        every rank's un-deblocked rows of Y / U / V + its rows of jmhip_db_mb / jmhip_db_motion (jm_amd.shard.BandGather)
+      jmhip_deblock_picture_dev    the whole picture, on every rank (redundant by design: 0.3 ms against a halo protocol)
+      jmhip_reference_from_recon   getSubImagesLuma of the whole picture: every rank holds the whole reference for the next picture's searches
+    Total work is fixed as N grows ("strong").  After the timed region rank 0 hashes the I and the P picture's reconstruction: it must be the md5 CPU JM's
+    -o file has for this clip and these flags (tests/golden/md5.json G4r), or the number is void.  `independent_sequences` is the other way to use N GPUs --
+    one 1080p sequence (configs[1]'s step) per GPU, no collective at all -- measured in the same run."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from jm_amd import JmHip, shard
+    from jm_amd.lib import SLICE_PARAMS
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synclip
+    W4, H4 = 3840, 2160
+    mbw, mbh = W4 // 16, H4 // 16
+    nmb = mbw * mbh
+    n_slices = 8 if 8 % world == 0 else world
+    rows = -(-mbh // n_slices)                              # 17 macroblock rows per slice: SliceArgument = 4080
+    per = shard.slice_argument(mbh, mbw, n_slices)
+    spr = n_slices // world                                 # slices per rank
+    k = rows * spr                                          # macroblock rows per rank (the last rank's band is one row short)
+    first = rank * spr * per
+    mine = min(spr * per, nmb - first)
+
+    stream = torch.cuda.current_stream()
+    ctx = JmHip(W4, H4, search_range=R, num_ref_slots=2, yuv_format=1, device=local, stream=stream.cuda_stream)
+    with tempfile.TemporaryDirectory() as tmp:
+        synclip.syn2160p(os.path.join(tmp, "s.yuv"), 2)
+        data = np.fromfile(os.path.join(tmp, "s.yuv"), np.uint8)
+    fs = W4 * H4 * 3 // 2
+    raw0, raw1 = data[:fs].copy(), data[fs:2 * fs].copy()
+
+    def flat(planes):
+        return b"".join(np.ascontiguousarray(p).astype(np.uint8).tobytes() for p in planes)
+
+    # the reference: the I picture, all eight slices on every rank (setup, untimed)
+    ctx.set_current_frame(raw0, W4, H4)
+    ctx.encode_slice_dev(slice_params(SLICE_PARAMS, 2, 0, per, 0, 0, num_slices=n_slices))
+    ctx.deblock_picture_dev(1)
+    rec_i = flat(ctx.get_recon()) if rank == 0 else None
+    ctx.reference_from_recon(0)
+    ctx.set_current_frame(raw1, W4, H4)
+    ctx.synchronize()
+    prm = slice_params(SLICE_PARAMS, 0, first, per if spr > 1 else mine, rank * spr, 1, num_slices=spr)
+    prm["ref_slot"][0, 0] = 0
+
+    py, pitch, pu, pv, pc = ctx.recon_planes_dev()
+    pm, nm, po, no = ctx.deblock_side_info_dev()
+    planes = [(torch.as_tensor(_DevMem(py, pitch * H4), device=dev).view(H4, pitch), 16 * k),
+              (torch.as_tensor(_DevMem(pu, pc * H4 // 2), device=dev).view(H4 // 2, pc), 8 * k),
+              (torch.as_tensor(_DevMem(pv, pc * H4 // 2), device=dev).view(H4 // 2, pc), 8 * k),
+              (torch.as_tensor(_DevMem(pm, nm), device=dev).view(mbh, nm // mbh), k),                 # jmhip_db_mb: one row per macroblock row
+              (torch.as_tensor(_DevMem(po, no), device=dev).view(4 * mbh, no // (4 * mbh)), 4 * k)]   # jmhip_db_motion: four rows per macroblock row
+    if one_gpu:
+        host = [(t.cpu(), kk) for t, kk in planes]
+        gather = shard.BandGather(host, world, rank)
+    else:
+        gather = shard.BandGather(planes, world, rank)
+    exchanged_bytes = int(gather.all.numel())
+
+    def exchange():
+        if one_gpu:
+            for (h, _), (t, _) in zip(host, planes):
+                h.copy_(t)
+            gather()
+            for (h, _), (t, _) in zip(host, planes):
+                t.copy_(h)
+        else:
+            gather()
+
+    def step():
+        ctx.encode_slice_dev(prm)
+        exchange()
+        ctx.deblock_picture_dev(1)
+        ctx.reference_from_recon(1)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ctx.enable_timing(True)
+    for i in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    ctx.synchronize()
+    ms = []
+    for i in range(3):
+        ctx.encode_slice_dev(prm)
+        ctx.synchronize()
+        ms.append(ctx.last_kernel_ms(5))
+    pipe_ms = max_over_ranks(float(np.mean(ms)))
+    step()                                                   # the picture buffers hold a whole deblocked P picture again
+    ctx.synchronize()
+    md5_ok = None
+    if rank == 0:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "md5.json")))["G4r"]["md5_recon"]
+        md5_ok = hashlib.md5(rec_i + flat(ctx.get_recon())).hexdigest() == gold
+    ctx.close()
+
+    # ---------------- the other use of N GPUs: one independent 1080p sequence per GPU (configs[1]'s step), no collective
+    c1 = JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1, device=local, stream=stream.cuda_stream)
+    f0, f1 = yuv_frames(2, seed=1234 + rank)
+    n1 = (W // 16) * (H // 16)
+    c1.set_current_frame(f0, W, H_SRC)
+    c1.encode_slice_dev(slice_params(SLICE_PARAMS, 2, 0, n1, 0, 0))
+    c1.deblock_picture_dev(1)
+    c1.reference_from_recon(0)
+    c1.set_current_frame(f1, W, H_SRC)
+    p1 = slice_params(SLICE_PARAMS, 0, 0, n1, 0, 1)
+    p1["ref_slot"][0, 0] = 0
+
+    def step1():
+        c1.encode_slice_dev(p1)
+        c1.deblock_picture_dev(1)
+        c1.reference_from_recon(1)
+    for i in range(args.warmup):
+        step1()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step1()
+    barrier()
+    dt1 = max_over_ranks(time.perf_counter() - t0)
+    c1.synchronize()
+    c1.close()
+
+    if rank == 0:
+        alg_mb = 6656 + 328 + 128 + 2900 + 944 + 384       # as at N = 1 (DESIGN.md section 3)
+        alg = alg_mb * mine
+        out = {
+            "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
+            "value": round(nmb * args.steps / dt, 1), "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"configs[3] with RDO off (G4r): ONE 3840x2160 4:2:0 synthetic picture ({nmb} MB) in {n_slices} slices of {per} macroblocks (SliceMode 1), "
+                                   "Baseline IPPP, FullSearch SR=32, 1 ref, QP 28, DFDisableIdc = 0; P picture through the RDO-off macroblock pipeline + DeblockFrame + getSubImagesLuma",
+                       "macroblocks_per_step": nmb, "macroblocks_per_step_rank0": mine, "search_range": R,
+                       "parallelism": f"{spr} slice(s) per GPU on {world} GPUs; per step ONE all-gather of {exchanged_bytes} bytes (un-deblocked Y/U/V rows + loop filter side information), "
+                                      "then every GPU deblocks and interpolates the whole picture and keeps the whole reference"
+                                      + (" [UNMEASURED debugging path: all ranks on one GPU, exchange over gloo on host copies]" if one_gpu else ""),
+                       "recon_md5_equals_cpu_jm": md5_ok,
+                       "note": "one GPU already runs all eight slices side by side (configs3 object of the N = 1 line): a slice is a chain of 240 + 2 x 16 dependent macroblocks "
+                               "whatever the number of GPUs, so the split cannot go below one slice's chain plus the exchange; N GPUs pay off for N sequences (independent_sequences)"},
+            "roofline": {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": None, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
+                         "note": "the slowest rank's launch over its own slices"},
+            "independent_sequences": {"workload": "configs[1]'s step (1080p P picture, 8160 MB) on every GPU, one sequence each, no collective", "scaling": "weak",
+                                      "macroblocks_per_s": round(n1 * world * args.steps / dt1, 1), "ms_per_step": round(dt1 / args.steps * 1e3, 4)},
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()
 
 
 def main():
@@ -297,75 +489,30 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_gpu else "nccl", **({} if one_gpu else {"device_id": dev}))
-    N = world
-    HP = H * N                                           # N > 1: one picture of N 1080p bands
+    if world > 1:
+        return multi_gpu_configs3(args, world, rank, local, dev, one_gpu)
+    N, HP = 1, H
     mbw, mbh = W // 16, H // 16
     nmb = mbw * mbh
 
     stream = torch.cuda.current_stream()
     ctx = JmHip(W, HP, search_range=R, num_ref_slots=2, yuv_format=1, device=local, stream=stream.cuda_stream)
 
-    # ---------------- inputs: the clip's first two pictures; N > 1: every band is the same 1080p picture pair with its own noise seed
-    def tall(frame_idx):
-        parts = [yuv_frames(2, seed=1234 + r)[frame_idx] for r in range(N)]
-        if N == 1:
-            return parts[0], H_SRC
-        ys = [np.concatenate([p[:W * H_SRC].reshape(H_SRC, W), np.repeat(p[:W * H_SRC].reshape(H_SRC, W)[-1:], H - H_SRC, 0)]) for p in parts]
-        cs = []
-        for k in range(2):
-            o = W * H_SRC + k * (W // 2) * (H_SRC // 2)
-            cs.append([np.concatenate([p[o:o + (W // 2) * (H_SRC // 2)].reshape(H_SRC // 2, W // 2),
-                                       np.repeat(p[o:o + (W // 2) * (H_SRC // 2)].reshape(H_SRC // 2, W // 2)[-1:], (H - H_SRC) // 2, 0)]) for p in parts])
-        return np.concatenate([np.concatenate(ys).ravel(), np.concatenate(cs[0]).ravel(), np.concatenate(cs[1]).ravel()]), HP
-
     def slice_prm(slice_type, first, num, slice_nr, num_ref):
-        """jmhip_slice_params with JM's own values for this configuration (tests/golden/mb_low_g2r.npz holds what the encoder used)"""
-        p = np.zeros(1, SLICE_PARAMS)
-        p["slice_type"], p["first_mb"], p["num_mb"], p["slice_nr"], p["qp"], p["qpc"] = slice_type, first, num, slice_nr, QP, QP
-        p["search_range"], p["num_ref"] = R, num_ref
-        p["lambda_mf"], p["lambda_mdfp"] = [192, 192, 192], 192               # lambda_mf / LAMBDA_FACTOR(lambda_md) at QP 28 with RDOptimization = 0
-        p["max_mvd"] = 1023                                                  # mv_search.c:327 at SearchRange 32
-        p["mv_limit"] = [-8192, 8191, -2048, 2047]                           # level 5.1
-        p["inter_valid"], p["intra4_valid"], p["intra16_valid"], p["subpel"], p["start_qp"] = 1, 1, 1, 1, 1
-        bits = [1, 3, 3] + [5] * 4 + [7] * 8 + [9]
-        p["refbits"] = bits
-        sc, ds = {0: 8192, 1: 3355, 2: 5243}, {0: 16, 1: 25, 2: 20}          # qp % 6 == 4 rows of quant_coef / dequant_coef (q_matrix.c:20-36)
-        for intra in range(2):
-            off = 682 if (intra and slice_type == 2) else 342                # q_offsets.c:135-162 default offsets
-            for j in range(4):
-                for i in range(4):
-                    c = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 and j % 2) else 2)
-                    q = (off << (15 + QP // 6 - 11), sc[c], ds[c] << 4)
-                    p["q_luma"][0, intra, j * 4 + i] = q
-                    p["q_chroma"][0, :, intra, j * 4 + i] = q
-        p["df_disable_idc"] = 2 if N > 1 else 0
-        return p
+        return slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref)
 
-    raw0, src_h = tall(0)
-    raw1, _ = tall(1)
-    first = rank * nmb
-    # the reference: the I picture through the same pipeline (every rank codes all bands of it: setup, untimed)
+    # ---------------- inputs: the clip's first two pictures
+    raw0, raw1 = yuv_frames(2)
+    src_h = H_SRC
+    # the reference: the I picture through the same pipeline (setup, untimed)
     ctx.set_current_frame(raw0, W, src_h)
-    for r in range(N):
-        ctx.encode_slice_dev(slice_prm(2, r * nmb, nmb, r, 0))
+    ctx.encode_slice_dev(slice_prm(2, 0, nmb, 0, 0))
     ctx.deblock_picture_dev(1)
     ctx.reference_from_recon(0)
     ctx.set_current_frame(raw1, W, src_h)                               # the P picture's source stays resident
     ctx.synchronize()
-    prm = slice_prm(0, first, nmb, rank, 1)
+    prm = slice_prm(0, 0, nmb, 0, 1)
     prm["ref_slot"][0, 0] = 0
-
-    gather = None
-    if N > 1:
-        py, pitch, pu, pv, pc = ctx.recon_planes_dev()
-        ty = torch.as_tensor(_DevMem(py, pitch * HP), device=dev).view(HP, pitch)
-        tu = torch.as_tensor(_DevMem(pu, pc * HP // 2), device=dev).view(HP // 2, pc)
-        tv = torch.as_tensor(_DevMem(pv, pc * HP // 2), device=dev).view(HP // 2, pc)
-        if one_gpu:
-            hy, hu, hv = ty.cpu(), tu.cpu(), tv.cpu()
-            gather = shard.PictureGather(hy, hu, hv, N, rank)
-        else:
-            gather = shard.PictureGather(ty, tu, tv, N, rank)
 
     ctx.enable_timing(True)
     kernel_ms = []
@@ -373,18 +520,11 @@ def main():
     def step(timed):
         ctx.encode_slice_dev(prm)                                       # k_mb_pipe
         ctx.deblock_picture_dev(1)                                      # K9/K10
-        if N > 1:                                                       # the one collective: every rank gets every band's reconstruction
-            if one_gpu:
-                hy.copy_(ty); hu.copy_(tu); hv.copy_(tv); gather(); ty.copy_(hy); tu.copy_(hu); tv.copy_(hv)
-            else:
-                gather()
         ctx.reference_from_recon(1)                                     # K5 + chroma planes: the next picture's reference
         if timed:
             kernel_ms.append(None)
 
     def barrier():
-        if N > 1:
-            dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -396,11 +536,6 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.synchronize()                                                    # reads the device-side error words: the pipeline's is sticky (a launch that finds it set does nothing), so an incomplete picture cannot go unnoticed
-    pipe_ms = ctx.last_kernel_ms(5)                                      # HIP events on the launch stream around the last k_mb_pipe launch
-    if N > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     # per-launch duration of the dominant kernel over a few more (untimed) launches, events around each
     ms = []
     for i in range(5):
@@ -502,8 +637,7 @@ def main():
                                    "(encode_one_macroblock_low on the device: FullSearch SR=32 at every block's own centre, 1 ref, QP 28, mode decision, transform/quant, "
                                    "reconstruction) + DeblockFrame + getSubImagesLuma; entropy coding is the host's and is outside the step (see end_to_end)",
                        "macroblocks_per_step_per_gpu": nmb, "search_range": R,
-                       "parallelism": "1 GPU" if N == 1 else f"{N} slices (1080p bands of one {W}x{HP} picture) one per GPU, DFDisableIdc=2, one RCCL all-gather of the reconstructed bands per step; "
-                                                              "every GPU keeps the whole reference" + (" [UNMEASURED debugging path: all ranks on one GPU, gloo]" if one_gpu else ""),
+                       "parallelism": "1 GPU",
                        "records_equal_jm": equal, "mb_types_pskip_16x16_16x8_8x16_p8x8_i4_i16": [int(types[k]) for k in (0, 1, 2, 3, 8, 9, 10)]},
             "roofline": roof,
         }
@@ -519,8 +653,6 @@ def main():
         if args.streams > 1 and N == 1:
             out["concurrent_streams"] = concurrent_streams(args.streams, raw0, raw1, src_h, slice_prm, local, min(args.steps, 20))
         print(json.dumps(out))
-    if N > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

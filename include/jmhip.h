@@ -617,6 +617,11 @@ int jmhip_encode_slice_end(jmhip_ctx *ctx);
 /* the reconstruction the slices of the current picture left on the device (before / after jmhip_deblock_picture_dev) */
 int jmhip_recon_planes_dev(jmhip_ctx *ctx, uint8_t **d_y, int32_t *pitch_y, uint8_t **d_u, uint8_t **d_v, int32_t *pitch_c);
 int jmhip_get_recon(jmhip_ctx *ctx, uint16_t *y, int32_t pitch_y, uint16_t *u, uint16_t *v, int32_t pitch_c);   /* as imgpel, pitches in samples */
+/* The loop filter's side information the slices of the current picture left on the device: one jmhip_db_mb per macroblock (raster) and one
+ * jmhip_db_motion per 4x4 block (raster over the picture's 4x4 grid, PicWidthInMbs * 4 per row).  A host that splits a picture's slices over
+ * several devices exchanges these rows together with the reconstruction's before the picture is deblocked (DeblockFrame filters across slice
+ * edges unless DFDisableIdc = 2: lencod/src/loopFilter.c:159-165 reads the neighbouring slice's macroblocks). */
+int jmhip_deblock_side_info_dev(jmhip_ctx *ctx, jmhip_db_mb **d_mbs, jmhip_db_motion **d_motion);
 /* DeblockFrame on that reconstruction with the side information the slices' macroblocks left on the device */
 int jmhip_deblock_picture_dev(jmhip_ctx *ctx, int32_t direct_8x8_inference);
 /* getSubImagesLuma (+ the integer chroma planes) of the reconstruction into a reference slot, without leaving the device */

@@ -103,7 +103,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
-           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups"]
+           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups"]
 
 
 class JmHipError(RuntimeError):
@@ -580,6 +580,13 @@ class JmHip:
         a, b = C.c_int32(), C.c_int32()
         self._ck(self.lib.jmhip_recon_planes_dev(self.h, C.byref(py), C.byref(a), C.byref(pu), C.byref(pv), C.byref(b)))
         return py.value, a.value, pu.value, pv.value, b.value
+
+    def deblock_side_info_dev(self):
+        """(pointer, bytes) of the per-macroblock and of the per-4x4-block loop filter side information of the current picture on the device"""
+        pm, po = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.jmhip_deblock_side_info_dev(self.h, C.byref(pm), C.byref(po)))
+        nmb = (self.W // 16) * (self.H // 16)
+        return pm.value, nmb * 28, po.value, nmb * 16 * 16
 
     def get_recon(self):
         """(y, u, v) uint8: the reconstruction on the device (before or after deblock_picture_dev)"""

@@ -116,27 +116,46 @@ class YuvExchange:
         return self.out_y, self.out_c[:, : self.width // 2], self.out_c[:, self.width // 2:]
 
 
-class PictureGather:
-    """Every rank holds the whole reconstruction: all-gather of equal bands of a 4:2:0 picture's three planes, one collective per picture.
+class BandGather:
+    """Every rank ends up with every band: one all-gather of bands of rows of several row-major planes, the last band possibly shorter
+    (JM's SliceArgument partitioning: 2160p in 8 slices of 4080 macroblocks is 7 bands of 17 macroblock rows and one of 16).
 
-    The planes are (rows, pitch) uint8 tensors that may alias library memory (the macroblock pipeline's reconstruction); rank r owns
-    luma rows [r * band_rows, (r + 1) * band_rows) and chroma rows [r * band_rows / 2, ...).  pack -> all_gather_into_tensor -> three
-    strided copies back into the planes (the packed buffer keeps the collective's input and output from aliasing)."""
+    planes: [(tensor (rows, pitch) uint8, rows_per_band)], rank r owns rows [r * k, min((r + 1) * k, rows)) of each.  The tensors may alias library
+    memory (the pipeline's reconstruction and loop filter side information).  pack -> all_gather_into_tensor -> strided copies back; the packed
+    buffer keeps the collective's input and output from aliasing and pads the short band, so a picture costs exactly one collective."""
 
-    def __init__(self, y, u, v, world, rank, group=None):
-        self.y, self.u, self.v, self.world, self.rank, self.group = y, u, v, world, rank, group
-        assert y.shape[0] % world == 0 and u.shape[0] % world == 0 and v.shape == u.shape, (y.shape, u.shape, v.shape, world)
-        self.ny = (y.shape[0] // world) * y.shape[1]
-        self.nc = (u.shape[0] // world) * u.shape[1]
-        self.own = torch.empty(self.ny + 2 * self.nc, dtype=torch.uint8, device=y.device)
-        self.all = torch.empty((world, self.ny + 2 * self.nc), dtype=torch.uint8, device=y.device)
+    def __init__(self, planes, world, rank, group=None):
+        self.planes, self.world, self.rank, self.group = planes, world, rank, group
+        self.off, n = [], 0
+        for t, k in planes:
+            assert t.dim() == 2 and t.dtype == torch.uint8 and k > 0 and (world - 1) * k < t.shape[0] <= world * k, (t.shape, k, world)
+            self.off.append(n)
+            n += k * t.shape[1]
+        dev = planes[0][0].device
+        self.own = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.all = torch.empty((world, n), dtype=torch.uint8, device=dev)
 
     def __call__(self):
-        r, ny, nc = self.rank, self.ny, self.nc
-        self.own[:ny].copy_(self.y.view(self.world, ny)[r])
-        self.own[ny:ny + nc].copy_(self.u.view(self.world, nc)[r])
-        self.own[ny + nc:].copy_(self.v.view(self.world, nc)[r])
+        r = self.rank
+        for (t, k), o in zip(self.planes, self.off):
+            mine = t[r * k:(r + 1) * k]
+            self.own[o:o + mine.numel()].view(mine.shape).copy_(mine)
         dist.all_gather_into_tensor(self.all.view(-1), self.own, group=self.group)
-        self.y.view(self.world, ny).copy_(self.all[:, :ny])
-        self.u.view(self.world, nc).copy_(self.all[:, ny:ny + nc])
-        self.v.view(self.world, nc).copy_(self.all[:, ny + nc:])
+        for (t, k), o in zip(self.planes, self.off):
+            rows, pitch = t.shape
+            full = rows // k
+            t[:full * k].view(full, k * pitch).copy_(self.all[:full, o:o + k * pitch])
+            if rows > full * k:
+                t[full * k:].copy_(self.all[full, o:o + (rows - full * k) * pitch].view(rows - full * k, pitch))
+
+
+class PictureGather(BandGather):
+    """BandGather of a 4:2:0 picture's three planes: rank r owns luma rows [r * band_rows, (r + 1) * band_rows) and chroma rows
+    [r * band_rows / 2, ...); band_rows defaults to equal bands."""
+
+    def __init__(self, y, u, v, world, rank, group=None, band_rows=None):
+        if band_rows is None:
+            assert y.shape[0] % world == 0 and u.shape[0] % world == 0, (y.shape, u.shape, world)
+            band_rows = y.shape[0] // world
+        assert v.shape == u.shape and band_rows % 2 == 0
+        super().__init__([(y, band_rows), (u, band_rows // 2), (v, band_rows // 2)], world, rank, group)

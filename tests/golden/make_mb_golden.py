@@ -42,6 +42,8 @@ CASES = {
     # BASELINE configs[2] without its 8x8 transform and B pictures: 1080p, Main profile, CABAC, EPZS, five references configured (two exist by the third picture)
     "g3e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 3, True),
     # fast full search (SearchMode = 0, encoder_baseline.cfg's own): one search centre per macroblock and reference, the (0,0) vector first
+    # encoder_baseline.cfg as north_star names it (fast full search, SearchRange 32, five references) at 1080p, but for RDO / adaptive rounding: four pictures
+    "g5f": (dict(RDO_OFF, **dict(SYN1080, SearchMode="0", NumberReferenceFrames="5", FramesToBeEncoded="4")), (1920, 1080), 4, True),
     "q5f": (dict(RDO_OFF, SearchMode="0", SearchRange="32"), (176, 144), 3, False),                                   # encoder_baseline.cfg as shipped but for RDO / adaptive rounding
     "m5f": (dict(RDO_OFF, SearchMode="0", SearchRange="16", FramesToBeEncoded="6", SliceMode="1", SliceArgument="50"), (208, 160), 6, "motion:31"),     # five references, slices mid-row
     "m3fh": (dict(RDO_OFF, SearchMode="0", SearchRange="32", NumberReferenceFrames="3", Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", FramesToBeEncoded="4", QPISlice="32", QPPSlice="32"), (176, 144), 4, "motion:32"),

@@ -151,14 +151,16 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
     EPZS (SearchMode 3): the reference's clip (q1e), five references (m5e), CABAC + slices that start mid-row (m2c), the other patterns and window set
     (m3p), every optional predictor set off (m2t), and BASELINE configs[2]'s search at 1920x1080 (g3e: Main profile, CABAC, 24 480 macroblocks).
     High profile (Transform8x8Mode 1: transform decisions, the tr8x8 pass of P8x8, Intra8x8): CAVLC (q1h, m1hq), CABAC (q2hc, m3h), with EPZS (m2he, m1hq),
-    and BASELINE configs[2] as stated at 1920x1080 (g3h: CABAC, 8x8 transform on, EPZS)."""
+    and BASELINE configs[2] as stated at 1920x1080 (g3h: CABAC, 8x8 transform on, EPZS).
+    Fast full search (SearchMode 0, encoder_baseline.cfg's): QCIF with five references (q5f), the motion clip (m5f), High profile (m3fh), and 1920x1080 with
+    up to three references (g5f: 32 640 macroblocks)."""
     c = load_case(tag)
     enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
                         search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"])
@@ -379,6 +381,89 @@ def test_sequences_side_by_side_on_their_own_streams():
             e.refs = [(slot, n)]
     for e in encs:
         e.J.close()
+
+
+@pytest.mark.parametrize("W,H,n_slices,world,seed", [(640, 368, 8, 2, 41), (320, 240, 4, 4, 42), (3840, 2160, 8, 8, 43)])
+def test_slices_dealt_to_ranks_equal_the_one_launch_picture(W, H, n_slices, world, seed):
+    """bench.py's N > 1 leg (BASELINE configs[3]: 2160p, 8 slices of 4080 macroblocks = bands of 17 ... 17, 16 rows; DFDisableIdc 0) without the collective:
+    every "rank" is a context of its own that codes only its slices of the P picture; its records, its rows of the un-deblocked reconstruction and its rows
+    of the loop filter's side information must equal the ones of the launch that codes all slices at once, and the picture assembled from the ranks' rows
+    (what jm_amd.shard.BandGather leaves in every rank's buffers) must deblock to the same picture."""
+    import torch
+    import bench
+    from jm_amd import shard
+    R, qp = 16 if W < 3840 else 32, 28
+    mbw, mbh = W // 16, H // 16
+    nmb = mbw * mbh
+    per = shard.slice_argument(mbh, mbw, n_slices)
+    spr = n_slices // world
+    k = -(-mbh // n_slices) * spr                            # macroblock rows per rank
+    if W == 3840:
+        import synclip
+        import tempfile
+        with tempfile.TemporaryDirectory() as t:
+            synclip.syn2160p(os.path.join(t, "s.yuv"), 2)
+            data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+        clip = [data[:W * H * 3 // 2], data[W * H * 3 // 2:]]
+    else:
+        clip = synthetic_clip(W, H, 2, seed)
+
+    def planes_of(J):
+        py, pitch, pu, pv, pc = J.recon_planes_dev()
+        pm, nm, po, no = J.deblock_side_info_dev()
+        dev = torch.device("cuda", 0)
+        return [(torch.as_tensor(bench._DevMem(py, pitch * H), device=dev).view(H, pitch), 16 * k),
+                (torch.as_tensor(bench._DevMem(pu, pc * H // 2), device=dev).view(H // 2, pc), 8 * k),
+                (torch.as_tensor(bench._DevMem(pv, pc * H // 2), device=dev).view(H // 2, pc), 8 * k),
+                (torch.as_tensor(bench._DevMem(pm, nm), device=dev).view(mbh, nm // mbh), k),
+                (torch.as_tensor(bench._DevMem(po, no), device=dev).view(4 * mbh, no // (4 * mbh)), 4 * k)]
+
+    def coded(first, num, num_slices, slice_nr):
+        """a fresh context: the I picture in all its slices, then the P picture's macroblocks [first, ...) only; (context, records)"""
+        J = L.JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1)
+        J.set_current_frame(clip[0], W, H)
+        cfg = pyjmo.mbenc_cfg(W, H, 2, 0, per, qp, R, 0, *LAMBDAS[2])
+        prm = slice_params(L, cfg, 0, [], [])
+        prm["num_slices"] = n_slices
+        J.encode_slice_dev(prm)
+        J.deblock_picture_dev(1)
+        J.reference_from_recon(0)
+        J.set_current_frame(clip[1], W, H)
+        cfg = pyjmo.mbenc_cfg(W, H, 0, first, num, qp, R, 1, *LAMBDAS[0])
+        prm = slice_params(L, cfg, slice_nr, [0], [0])
+        prm["num_slices"] = num_slices
+        recs = J.encode_slice(prm)
+        J.synchronize()
+        return J, recs
+
+    import jm_amd.lib as L
+    J, all_recs = coded(0, per, n_slices, 0)
+    want = [t.cpu() for t, _ in planes_of(J)]                # un-deblocked reconstruction + side information of the one-launch picture
+    J.deblock_picture_dev(1)
+    post = J.get_recon()
+    J.close()
+    assert len(all_recs) == nmb
+    got = [torch.full_like(t, 0xEE) for t in want]
+    for r in range(world):
+        first = r * spr * per
+        mine = min(spr * per, nmb - first)
+        Jr, recs = coded(first, per if spr > 1 else mine, spr, r * spr)
+        assert len(recs) == mine and recs.tobytes() == all_recs[first:first + mine].tobytes(), ("records of rank", r)
+        pl = planes_of(Jr)
+        for (t, kk), w, g in zip(pl, want, got):
+            assert torch.equal(t[r * kk:(r + 1) * kk].cpu(), w[r * kk:(r + 1) * kk]), ("rows of rank", r, kk)
+            g[r * kk:(r + 1) * kk] = t[r * kk:(r + 1) * kk].cpu()
+        if r < world - 1:
+            Jr.close()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)                                 # every row has exactly one owner
+    for (t, _), g in zip(pl, got):                               # the last rank's buffers after the exchange
+        t.copy_(g)
+    torch.cuda.synchronize()
+    Jr.deblock_picture_dev(1)
+    for a, b in zip(Jr.get_recon(), post):
+        assert np.array_equal(a, b)
+    Jr.close()
 
 
 def test_streamed_records_equal_the_blocking_call():

@@ -309,6 +309,25 @@ def test_lencod_macroblock_pipeline_configs2_epzs_1080p(tmp_path, tag):
     print(f"configs[2] ({tag}: EPZS, CABAC), RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
 
 
+@pytest.mark.gpu
+def test_lencod_macroblock_pipeline_fast_full_search_1080p(tmp_path):
+    """encoder_baseline.cfg's search as it ships -- SearchMode 0 (fast full search), SearchRange 32, five references configured -- at 1920x1080 with
+    RDOptimization = 0 (g5f): I + 3 P pictures searching 1, 2 and 3 references, 32 640 macroblocks through the pipeline, bitstream and reconstruction
+    equal to CPU JM's."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, z = run_rdo_off_case("g5f", str(tmp_path))
+    err, out = r.stderr.decode(errors="replace"), r.stdout.decode(errors="replace")
+    assert r.returncode == 0, (out[-1500:], err[-1500:])
+    rep = pipeline_report(err)
+    c = counters(err)
+    assert rep and rep["mbs"] == 4 * 8160 and rep["slices"] == 4, (rep, err[-1500:])
+    assert c["passed"] == 0 and c["eval"] == 0 and c["fs"] == 0 and c["subpel"] == 0, c
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
+    print(f"1080p fast full search, up to three references, RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
+
+
 def run_2160p(tag, tmp, env_extra=None):
     """lencod_hip.exe on BASELINE configs[3] at its own size: synthetic 2160p, 8 slices of 4080 macroblocks, two pictures (tests/golden/make_g4.py)"""
     import sys

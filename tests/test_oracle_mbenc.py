@@ -118,5 +118,11 @@ def test_oracle_configs2_as_stated_full_size():
     assert all(a == 0 for _, a in enc.epzs_stats)
 
 
+@pytest.mark.skipif(os.environ.get("JMO_LONG") != "1", reason="six minutes of oracle full searches: set JMO_LONG=1 (q5f / m5f / m3fh pin the same search at small sizes)")
+def test_oracle_fast_full_search_1080p_full_size():
+    """encoder_baseline.cfg's search as shipped (SearchMode 0, five references configured) at 1080p, RDO off: I + 3 P pictures with 1, 2 and 3 references (g5f)."""
+    run_case("g5f")
+
+
 def test_record_layout():
     assert pyjmo.MB_RECORD.itemsize == 944

@@ -155,3 +155,42 @@ def test_picture_gather_gloo(world):
     for p in ps:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def _uneven_worker(rank, world, port, mb_rows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # configs[3]'s exchange in small: bands of k macroblock rows with a shorter last band; luma, two chroma planes, one row of loop filter
+        # side information per macroblock row (28 bytes per macroblock) and four rows of per-4x4 motion per macroblock row
+        wmb, pitch, cw = 5, 96, 40
+        k = -(-mb_rows // world)
+        shapes = [(16 * mb_rows, pitch, 16 * k), (8 * mb_rows, cw, 8 * k), (8 * mb_rows, cw, 8 * k), (mb_rows, wmb * 28, k), (4 * mb_rows, wmb * 4 * 16, 4 * k)]
+        full = [_full_picture(r, p, 20 + i) for i, (r, p, _) in enumerate(shapes)]
+        mine = [torch.full(p.shape, 0xEE, dtype=torch.uint8) for p in full]
+        for p, m, (_, _, kk) in zip(full, mine, shapes):
+            m[rank * kk:(rank + 1) * kk] = torch.from_numpy(p[rank * kk:(rank + 1) * kk])
+        g = shard.BandGather([(m, kk) for m, (_, _, kk) in zip(mine, shapes)], world, rank)
+        ok = True
+        for rep in range(2):
+            g()
+            ok &= all(bool((m.numpy() == p).all()) for p, m in zip(full, mine))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mb_rows", [(2, 7), (3, 8), (2, 8)])
+def test_band_gather_uneven_gloo(world, mb_rows):
+    """The N > 1 leg of bench.py on configs[3]: the last band is shorter (17 ... 17, 16 macroblock rows); every rank must end up with every
+    plane complete -- the un-deblocked reconstruction and the loop filter's side information -- after ONE collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_uneven_worker, args=(r, world, port, mb_rows, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
