@@ -432,7 +432,7 @@ def multi_gpu_configs3(args, world, rank, local, dev, one_gpu):
     c1.close()
 
     if rank == 0:
-        alg_mb = 6656 + 328 + 128 + 2900 + 944 + 384       # as at N = 1
+        alg_mb = 6656 + 328 + 128 + 2900 + 1216 + 384       # as at N = 1
         alg = alg_mb * mine
         out = {
             "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
@@ -551,7 +551,7 @@ def main():
     if N == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import mb_tap
-        gold = np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g2r.npz"))["records"][nmb:2 * nmb]
+        gold = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g2r.npz"))["records"][nmb:2 * nmb])
         mine = np.frombuffer(recs.tobytes(), gold.dtype).copy()
         equal = bool(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), gold)))
 
@@ -601,7 +601,7 @@ def main():
         erecs = ctx.encode_slice(pe)
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import mb_tap
-        g3 = np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"][nmb:2 * nmb]
+        g3 = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"][nmb:2 * nmb])
         mine = np.frombuffer(erecs.tobytes(), g3.dtype).copy()
         configs2_device = {"workload": "configs[2]: 1080p, High profile (CABAC, 8x8 transform on: Transform8x8Mode 1, Intra8x8), EPZS (pattern 2, dual 3, fixed 2, temporal, "
                                        "spatial memory, block type, sub-pel grid), RDO off, P picture with one reference", "kernel": "k_mb_pipe_epzs_t8",
@@ -611,8 +611,8 @@ def main():
     if rank == 0:
         total_mb = nmb * N * args.steps
         # algorithmic bytes per macroblock: SURVEY 8d's 6656 + 328 B per macroblock-reference for the search, the source
-        # macroblock's chroma (128 B), ~2.9 KB of transform/quant traffic for the coded mode, the 944-byte record, 384 B of reconstruction
-        alg_mb = 6656 + 328 + 128 + 2900 + 944 + 384
+        # macroblock's chroma (128 B), ~2.9 KB of transform/quant traffic for the coded mode, the 1216-byte record, 384 B of reconstruction
+        alg_mb = 6656 + 328 + 128 + 2900 + 1216 + 384
         alg = alg_mb * nmb
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",

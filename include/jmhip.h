@@ -526,7 +526,8 @@ int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pitchY, uint8_
  * chroma_residual_coding (macroblock.c:1439), the skip test (md_low.c:658).  What the call leaves behind per macroblock is what
  * write_macroblock (macroblock.c:2810) and DeblockFrame read: one jmhip_mb_record.  The host keeps the entropy coder.
  *
- * Scope: frame macroblocks, 4:2:0, 8 bit, 4x4 transform, no adaptive rounding / weighted prediction / rate control, SearchMode -1 or 3 (EPZS),
+ * Scope: frame macroblocks, 4:2:0 or 4:2:2 (the context's yuv_format), 8 bit, 4x4 and 8x8 transform, no adaptive rounding / weighted prediction / rate control,
+ * SearchMode -1, 0 or 3 (EPZS),
  * unconstrained intra prediction, num_ref * window bytes within the LDS (5 references at SearchRange 32, 16 at 16); anything else
  * returns JMHIP_EUNSUPPORTED and the caller keeps JM's own function.
  * The source picture is the one jmhip_set_current_frame loaded; the references are slots filled by jmhip_set_reference[_chroma] or
@@ -552,9 +553,9 @@ typedef struct {
   int16_t  mv[16][2];           /* enc_picture->mv_info[..].mv[LIST_0], 4x4 raster */
   int16_t  luma[16][16];        /* quantised levels in zig-zag scan order, block 4 * b8 + b4 (cofAC order); Intra16x16: AC levels at [1..15] */
   int16_t  luma_dc[16];         /* Intra16x16 DC levels (cofDC[0]), scan order */
-  int16_t  chroma_dc[2][4];     /* cofDC[1 + uv] */
-  int16_t  chroma_ac[2][4][16]; /* cofAC[4 + uv][b4], levels at [1..15] */
-} jmhip_mb_record;              /* 944 bytes */
+  int16_t  chroma_dc[2][8];     /* cofDC[1 + uv] at the levels' scan positions: four with 4:2:0, eight with 4:2:2 (SCAN_YUV422, block.c:88) */
+  int16_t  chroma_ac[2][8][16]; /* levels at [1..15] of the plane's 4x4 blocks in raster order: 4:2:0 cofAC[4 + uv][k] (k < 4), 4:2:2 cofAC[4 + 2 uv + (k >> 2)][k & 3] (k < 8) */
+} jmhip_mb_record;              /* 1216 bytes */
 
 typedef struct {
   int32_t slice_type;           /* 0 P, 2 I */
@@ -599,6 +600,8 @@ typedef struct {
                                    blocks of 8x8 samples and more (mv_search.c:1624, :1768); needs inter_valid[4] in P slices */
   int32_t intra8_valid;         /* enc_mb.valid[I8MB] (mode_decision.c:127) */
   jmhip_qparam q_luma8[2][64];  /* p_Quant->q_params_8x8[0][intra][qp][j][i] at [intra][j * 8 + i] */
+  /* 4:2:2 (a context with yuv_format 2; ignored otherwise) */
+  jmhip_qparam q_chroma_dc[2][2];   /* p_Quant->q_params_4x4[1 + uv][intra][qpc + 3][0][0] at [uv][intra]: the 2x4 chroma DC transform is quantised with qpc + 3 (block.c:1059-1072) */
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);

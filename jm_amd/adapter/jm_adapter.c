@@ -1256,7 +1256,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     P.checked = 1;
     if (!G.part_mbpipe) why = "part mbpipe not selected";
     else if (p->rdopt != 0) why = "RDOptimization != 0";
-    else if (p_Vid->yuv_format != YUV420) why = "not 4:2:0";
+    else if (p_Vid->yuv_format != YUV420 && p_Vid->yuv_format != YUV422) why = "neither 4:2:0 nor 4:2:2";
     else if (p->SearchMode[0] != FULL_SEARCH && p->SearchMode[0] != FAST_FULL_SEARCH && p->SearchMode[0] != EPZS) why = "SearchMode other than -1 (full search), 0 (fast full search) and 3 (EPZS)";
     else if (p->SearchMode[0] == EPZS && (!p->EPZSSubPelGrid || p->EPZSSubPelME != 1 || p->HMEEnable)) why = "EPZS without EPZSSubPelGrid = 1 / EPZSSubPelME = 1, or with HME";
     else if (p->DisableMEPrediction) why = "DisableMEPrediction";
@@ -1357,6 +1357,12 @@ static void pipe_run_slice(Macroblock *currMB)
           prm.q_chroma[uv][intra][j * 4 + i].OffsetComp = q->OffsetComp; prm.q_chroma[uv][intra][j * 4 + i].ScaleComp = q->ScaleComp; prm.q_chroma[uv][intra][j * 4 + i].InvScaleComp = q->InvScaleComp;
         }
       }
+  if (p_Vid->yuv_format == YUV422)                          /* the 2x4 chroma DC transform is quantised with the parameters of qpc + 3 (block.c:1059-1063) */
+    for (intra = 0; intra < 2; intra++)
+      for (uv = 0; uv < 2; uv++) {
+        const LevelQuantParams *q = &p_Quant->q_params_4x4[uv + 1][intra][currMB->qpc[uv] + 3 + currSlice->bitdepth_chroma_qp_scale][0][0];
+        prm.q_chroma_dc[uv][intra].OffsetComp = q->OffsetComp; prm.q_chroma_dc[uv][intra].ScaleComp = q->ScaleComp; prm.q_chroma_dc[uv][intra].InvScaleComp = q->InvScaleComp;
+      }
   prm.symbol_mode = currSlice->symbol_mode == CABAC;        /* the entropy coder stays JM's; the quantiser clamps levels for CAVLC only */
   if (p_Inp->Transform8x8Mode == 1) {                       /* High profile: the 8x8 transform beside the 4x4 one, Intra8x8 */
     prm.transform8x8 = 1;
@@ -1441,6 +1447,11 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
   for (k = 0; k < 16; k++) list_from_dense(r->luma[k], mbt == I16MB ? 1 : 0, 16, currSlice->cofAC[k >> 2][k & 3][0], currSlice->cofAC[k >> 2][k & 3][1]);
   list_from_dense(r->luma_dc, 0, mbt == I16MB ? 16 : 0, currSlice->cofDC[0][0], currSlice->cofDC[0][1]);
   for (uv = 0; uv < 2; uv++) {
+    if (p_Vid->yuv_format == YUV422) {                       /* eight DC levels in SCAN_YUV422 order; the plane's eight blocks live in cofAC[4 + 2 uv] and [5 + 2 uv] (block.c:1096-1105) */
+      list_from_dense(r->chroma_dc[uv], 0, 8, currSlice->cofDC[uv + 1][0], currSlice->cofDC[uv + 1][1]);
+      for (k = 0; k < 8; k++) list_from_dense(r->chroma_ac[uv][k], 1, 16, currSlice->cofAC[4 + 2 * uv + (k >> 2)][k & 3][0], currSlice->cofAC[4 + 2 * uv + (k >> 2)][k & 3][1]);
+      continue;
+    }
     list_from_dense(r->chroma_dc[uv], 0, 4, currSlice->cofDC[uv + 1][0], currSlice->cofDC[uv + 1][1]);
     for (k = 0; k < 4; k++) list_from_dense(r->chroma_ac[uv][k], 1, 16, currSlice->cofAC[4 + uv][k][0], currSlice->cofAC[4 + uv][k][1]);
   }

@@ -31,9 +31,10 @@ typedef uint8_t u8;
 
 #define MB_THREADS 512
 #define MAXC 0x7fffffff
-#define EDGE_WORDS 17                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
+#define EDGE_WORDS 19                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
                                             // 6/7 right U/V columns, 8 ipredmode (bytes 0-3 bottom row, 4-7 right column), 9-12 / 13-16 mv_info of the
-                                            // bottom row / right column {packed vector, reference index}
+                                            // bottom row / right column {packed vector, reference index}; 4:2:2: 17/18 rows 8..15 of the right U/V columns
+#define EDGE_MV_END 17                      // words 9 .. 16 are the tagged vectors
 #define SPIN_LIMIT (1u << 26)
 
 struct __attribute__((packed)) U32un { u32 v; };
@@ -44,11 +45,12 @@ __device__ __forceinline__ int mvy(int p) { return p >> 16; }
 __device__ __forceinline__ int mvpack(int x, int y) { return (x & 0xffff) | (y << 16); }
 __device__ __forceinline__ int median3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
-static_assert(sizeof(jmhip_mb_record) == 944 && sizeof(jmhip_slice_params) == 3152, "record sizes of include/jmhip.h");
+static_assert(sizeof(jmhip_mb_record) == 1216 && sizeof(jmhip_slice_params) == 3200, "record sizes of include/jmhip.h");
 
 struct PipeArgs {
   jmhip_slice_params p;
   int W, H, wmb, hmb, cw, ch;
+  int c422;                                  // 4:2:2: chroma planes cw x H, 8 x 16 samples per macroblock (ch = H); else 4:2:0
   int total_mb;                              // macroblocks of the launch (num_slices slices of p.num_mb, cut at the end of the picture)
   int cur_pitch, ref_pitch, rec_pitch;       // luma pitches (bytes); chroma planes are cw wide
   long plane_stride;
@@ -79,7 +81,7 @@ struct PipeArgs {
 // per-workgroup state in LDS
 struct Shared {
   u32 cur_y[64];                             // the source macroblock, 16 rows of 4 dwords
-  u32 cur_c[2][16];                          // U, V: 8 rows of 2 dwords
+  u32 cur_c[2][32];                          // U, V: 8 (4:2:0) or 16 (4:2:2) rows of 2 dwords
   u64 nb[4][EDGE_WORDS];                     // edge records of A (left), B (up), C (up-right), D (up-left)
   u32 ptab[8][16];                           // mv_predictor's neighbour table: per (block type, 4x4 position of the block) four codes A, B, C, D (once per launch)
   int avail[4];
@@ -101,12 +103,12 @@ struct Shared {
   jmhip_qparam q_luma[2][16], q_chroma[2][2][16];   // the slice's quantiser tables (out of the kernel arguments once per workgroup: LDS reads can be batched)
   int i16_cost, i16_mode;
   u8 e16[36];
-  u8 ec[2][20];                              // chroma predictor samples: [0] corner, [1..8] up, [9..16] left
+  u8 ec[2][28];                              // chroma predictor samples: [0] corner, [1..8] up, [9..16] left (4:2:2: [9..24])
   int c_ipred;
-  u8 icpred[2][4][64];
+  u8 icpred[2][4][128];                      // [plane][mode][row * 8 + column]
   // final coding
   u8 pred[256], rec[256];
-  u8 predc[2][64], recc[2][64];
+  u8 predc[2][128], recc[2][128];
   int16_t dcbuf[16];
   int red[8][80];
   int nbflag;                                // the neighbours' samples are in nb (running count over the launch)

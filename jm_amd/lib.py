@@ -80,7 +80,7 @@ MB_MAX_REF = 16
 MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("transform8x8", "i1"), ("cbp", "<i2"), ("reserved1_", "<i2"),
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
-                      ("chroma_dc", "<i2", (2, 4)), ("chroma_ac", "<i2", (2, 4, 16))])
+                      ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16))])
 SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", "<i4"), ("slice_nr", "<i4"), ("qp", "<i4"), ("qpc", "<i4"),
                          ("search_range", "<i4"), ("num_ref", "<i4"), ("ref_slot", "<i4", (MB_MAX_REF,)), ("ref_id", "<i4", (MB_MAX_REF,)),
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
@@ -90,8 +90,8 @@ SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", 
                          ("epzs_pattern", "<i4"), ("epzs_dual", "<i4"), ("epzs_fixed", "<i4"), ("epzs_aggressive", "<i4"), ("epzs_temporal", "<i4"), ("epzs_spatial_mem", "<i4"),
                          ("epzs_blocktype", "<i4"), ("epzs_min_scale", "<i4"), ("epzs_med_scale", "<i4"), ("epzs_max_scale", "<i4"), ("epzs_sub_scale", "<i4"), ("epzs_reserved_", "<i4"),
                          ("poc_cur", "<i4"), ("poc_ref", "<i4", (MB_MAX_REF,)),
-                         ("transform8x8", "<i4"), ("intra8_valid", "<i4"), ("q_luma8", "<i4", (2, 64, 3))])
-assert MB_RECORD.itemsize == 944 and SLICE_PARAMS.itemsize == 3152
+                         ("transform8x8", "<i4"), ("intra8_valid", "<i4"), ("q_luma8", "<i4", (2, 64, 3)), ("q_chroma_dc", "<i4", (2, 2, 3))])
+assert MB_RECORD.itemsize == 1216 and SLICE_PARAMS.itemsize == 3200
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
@@ -591,8 +591,9 @@ class JmHip:
     def get_recon(self):
         """(y, u, v) uint8: the reconstruction on the device (before or after deblock_picture_dev)"""
         y = np.zeros((self.H, self.W), np.uint16)
-        u = np.zeros((self.H // 2, self.W // 2), np.uint16)
-        v = np.zeros((self.H // 2, self.W // 2), np.uint16)
+        ch = self.H if self.yuv_format == 2 else self.H // 2
+        u = np.zeros((ch, self.W // 2), np.uint16)
+        v = np.zeros((ch, self.W // 2), np.uint16)
         self._ck(self.lib.jmhip_get_recon(self.h, _vp(y), self.W, _vp(u), _vp(v), self.W // 2))
         return y.astype(np.uint8), u.astype(np.uint8), v.astype(np.uint8)
 

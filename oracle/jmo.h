@@ -131,6 +131,8 @@ void jmo_inverse8x8(const int in[64], int out[64]);          /* :450-547 */
 typedef struct { int OffsetComp, ScaleComp, InvScaleComp; } jmo_qparam;   /* LevelQuantParams quant_params.h:17-21 */
 /* q_matrix.c:20-37 flat-matrix tables, q_offsets.c defaults */
 void jmo_qparams_4x4(int qp, int intra, int offset_bits_val, jmo_qparam out[16]);  /* [j*4+i] */
+void jmo_qparams_4x4_m(int qp, const int16_t off[16], jmo_qparam out[16]);     /* per-position offsets (update_q_offset4x4 q_offsets.c:238) */
+void jmo_qparams_8x8_m(int qp, const int16_t off[64], jmo_qparam out[64]);     /* update_q_offset8x8 q_offsets.c:251 */
 void jmo_qparams_8x8(int qp, int intra, int offset_bits_val, jmo_qparam out[64]);
 /* quant_4x4_normal quant4x4_normal.c:39-115 (symbol_mode CAVLC => level clamp 2063).
  * tblock: 16 coeffs row-major [j][i], overwritten with the dequantised values.
@@ -256,15 +258,18 @@ typedef struct {
   int32_t inter_valid[8];       /* InterSearch[0][0][mode] */
   int32_t intra4_valid, intra16_valid;   /* enc_mb.valid[I4MB], [I16MB] (mode_decision.c:127-131) */
   int32_t subpel;               /* !DisableSubpelME */
-  int32_t q_offset[2];          /* quantiser offset (of 2048) of inter / intra blocks in this slice type: 342 / 682 in I, 342 / 342 in P slices (q_offsets.c:633-711 with the default lists) */
+  int16_t off4[3][2][16];       /* quantiser offsets (of 2048) of the 4x4 transform's coefficients, [Y, U, V][inter, intra][j * 4 + i], as this slice type uses them (CalculateOffset4x4Param
+                                   q_offsets.c:633-711): the default lists are flat -- 342 inter, intra 682 in I and 342 in P slices --, a q_offset.cfg (OffsetMatrixPresentFlag) gives every
+                                   position its own (the shipped file: luma intra DC 1024, intra 742 in I / 400 in P slices) */
   int32_t start_qp;             /* p_Vid->start_me_refinement_qp (mv_search.c:446); start_me_refinement_hp must be 0 */
   int32_t refbits[JMO_MAX_REF]; /* p_Vid->refbits, mv_search.c:376-385 */
   int32_t cabac;                /* currSlice->symbol_mode == CABAC: levels are not clamped to CAVLC_LEVEL_LIMIT (quant4x4_normal.c:84) */
   int32_t search_mode;          /* SearchMode: -1 (or 0 here: same thing) full search, 3 EPZS with EPZSSubPelGrid = 1 and EPZSSubPelME = 1 (needs a jmo_epzs_cfg) */
   int32_t transform8x8;         /* Transform8x8Mode: 0, or 1 = the 8x8 transform beside the 4x4 one (High profile): transform_decision for 16x16 / 16x8 / 8x16, the P8x8
                                    pass with 8x8 blocks only, Intra8x8, 8x8 Hadamard SATD in the sub-pel search of blocks of 8x8 samples and more */
-  int32_t q_offset8[2];         /* quantiser offsets of the 8x8 transform, inter / intra (as q_offset) */
+  int16_t off8[2][64];          /* the same for the luma 8x8 transform, [inter, intra][j * 8 + i] (CalculateOffset8x8Param q_offsets.c:720) */
   int32_t intra8_valid;         /* enc_mb.valid[I8MB] (mode_decision.c:127) */
+  int32_t yuv_format;           /* 0 or 1: 4:2:0; 2: 4:2:2 (chroma planes width / 2 x height: 8 x 16 samples per macroblock, the 2x4 DC transform, DC quantiser of qpc + 3) */
 } jmo_mbenc_cfg;
 
 /* EPZS (SearchMode = 3): the configuration's switches and what EPZSSliceInit (lencod/src/me_epzs_common.c:620) reads from the decoded picture buffer. */
@@ -299,9 +304,9 @@ typedef struct {
   int16_t  mv[16][2];           /* enc_picture->mv_info[..].mv[LIST_0], 4x4 raster */
   int16_t  luma[16][16];        /* quantised levels in zig-zag scan order, block 4 * b8 + b4 (cofAC order); Intra16x16: AC levels at [1..15] */
   int16_t  luma_dc[16];         /* Intra16x16 DC levels, scan order */
-  int16_t  chroma_dc[2][4];
-  int16_t  chroma_ac[2][4][16]; /* [uv][b4][1..15] */
-} jmo_mb_record;                /* 944 bytes */
+  int16_t  chroma_dc[2][8];     /* [uv][scan position]: four levels with 4:2:0, eight (SCAN_YUV422 order, block.c:88) with 4:2:2 */
+  int16_t  chroma_ac[2][8][16]; /* [uv][4x4 block in raster order of the plane: four (4:2:0) or eight (4:2:2: cofAC[4 + 2 uv + (k >> 2)][k & 3])][1..15] */
+} jmo_mb_record;                /* 1216 bytes */
 
 typedef struct {                /* intermediate values, for localising a divergence (tests only) */
   int64_t motion_cost[8][4];    /* p_Vid->motion_cost[mode][LIST_0][0][block] */

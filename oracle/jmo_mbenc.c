@@ -397,7 +397,7 @@ static int tq4x4(const enc *e, const jmo_pel *orig, int opitch, const jmo_pel *p
     for (k = 0; k < 16; k++) { res[k] = (int)o[k] - (int)p[k]; any |= res[k]; }
     nz = 0;
     if (any) {
-      jmo_qparams_4x4(e->c->qp, intra, e->c->q_offset[intra ? 1 : 0], q);
+      jmo_qparams_4x4_m(e->c->qp, e->c->off4[0][intra ? 1 : 0], q);
       jmo_forward4x4(res, tb);
       nz = jmo_quant_4x4_normal(tb, q, e->c->qp / 6, !e->c->cabac, &JMO_SNGL_SCAN[0][0], JMO_COEFF_COST4x4[0], level, run, coeff_cost);
     }
@@ -423,7 +423,7 @@ static int tq8x8(const enc *e, const jmo_pel *orig, int opitch, const jmo_pel *p
   int level[68], run[68], fadj[64], j, i, nz, k, l;
   const int cavlc = !e->c->cabac;
   for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) { o[j * 8 + i] = orig[j * opitch + i]; p[j * 8 + i] = pred[j * ppitch + i]; }
-  jmo_qparams_8x8(e->c->qp, intra, e->c->q_offset8[intra ? 1 : 0], q);
+  jmo_qparams_8x8_m(e->c->qp, e->c->off8[intra ? 1 : 0], q);
   level[0] = level[17] = level[34] = level[51] = 0;
   nz = jmo_rtq_luma_8x8(o, p, q, e->c->qp / 6, cavlc, 0, 0, 255, level, run, coeff_cost, r, fadj, NULL);
   memset(lev, 0, 64 * sizeof(int16_t));
@@ -603,59 +603,65 @@ static void intra16_neighbours(const enc *e, jmo_pel ee[33], int *left, int *up,
   ee[0] = e->availD ? r[(Y - 1) * W + X - 1] : 128;
 }
 
-/* chroma: intra_chroma_prediction intra_chroma.c:530 + rdo_low_intra_chroma_decision :460, then chroma_residual_coding macroblock.c:1439 */
+/* chroma: intra_chroma_prediction intra_chroma.c:530 + rdo_low_intra_chroma_decision :460, then chroma_residual_coding macroblock.c:1439.
+ * 4:2:0: 8 x 8 samples per plane and macroblock; 4:2:2 (yuv_format 2): 8 x 16 -- eight 4x4 blocks, the vector of the luma block at the same row,
+ * the 2x4 DC transform with the quantiser of qpc + 3 (block.c:1056-1093). */
 static void chroma_mb(enc *e, jmo_mb_record *o, int intra, int mode, const int8_t b8mode[4], const int ref8[4])
 {
   const jmo_mbenc_cfg *c = e->c;
-  const int CW = c->width >> 1, cx = e->mbx * 8, cy = e->mby * 8;
+  const int y422 = c->yuv_format == 2, RH = y422 ? 16 : 8, nblk = y422 ? 8 : 4;
+  const int CW = c->width >> 1, CH = y422 ? c->height : c->height >> 1, cx = e->mbx * 8, cy = e->mby * RH;
   jmo_pel ipred[2][4][128];
   int uv, m, j, i, cr_cbp = 0, mask = 0;
   int64_t cbp_blk = 0;
-  jmo_qparam q_ac[16], q_dc;
+  jmo_qparam q_ac[16], q_dcs[16], q_dc;
   {                                                              /* the decision runs for every macroblock; only intra ones keep it */
     jmo_dist min_cost = JMO_DIST_MAX;
     int best = 0;
     for (uv = 0; uv < 2; uv++) {
-      jmo_pel up[8], left[8];
+      jmo_pel up[8], left[16];
       const jmo_pel *r = e->rec[1 + uv];
-      for (i = 0; i < 8; i++) { up[i] = e->availB ? r[(cy - 1) * CW + cx + i] : 0; left[i] = e->availA ? r[(cy + i) * CW + cx - 1] : 0; }
-      mask = jmo_intra_chroma_pred(up, left, e->availD ? r[(cy - 1) * CW + cx - 1] : 0, e->availB, e->availA, e->availD, 8, 255, ipred[uv]);
+      for (i = 0; i < 8; i++) up[i] = e->availB ? r[(cy - 1) * CW + cx + i] : 0;
+      for (i = 0; i < RH; i++) left[i] = e->availA ? r[(cy + i) * CW + cx - 1] : 0;
+      mask = jmo_intra_chroma_pred(up, left, e->availD ? r[(cy - 1) * CW + cx - 1] : 0, e->availB, e->availA, e->availD, RH, 255, ipred[uv]);
     }
     for (m = 0; m < 4; m++) {
       jmo_dist cost = 0;
       if ((m == 2 && !e->availB) || (m == 1 && !e->availA) || (m == 3 && (!e->availA || !e->availB || !e->availD))) continue;
       (void)mask;
-      for (uv = 0; uv < 2; uv++) cost += satd_blocks(e->cur[1 + uv] + cy * CW + cx, CW, ipred[uv][m], 8, 8, 8);
+      for (uv = 0; uv < 2; uv++) cost += satd_blocks(e->cur[1 + uv] + cy * CW + cx, CW, ipred[uv][m], 8, 8, RH);
       if (cost < min_cost) { best = m; min_cost = cost; }
     }
     o->c_ipred_mode = (int8_t)best;
   }
-  jmo_qparams_4x4(c->qpc, intra, c->q_offset[intra ? 1 : 0], q_ac);
-  q_dc = q_ac[0];
   for (uv = 0; uv < 2; uv++) {
-    jmo_pel pred[64], orig[64], rec[64];
+    jmo_pel pred[128], orig[128], rec[128];
     int dc_level[9], dc_run[9], ac_level[8][16], ac_run[8][16], fadj[128], b4, pos, k;
+    jmo_qparams_4x4_m(c->qpc, c->off4[1 + uv][intra ? 1 : 0], q_ac);
+    q_dc = q_ac[0];
+    if (y422) { jmo_qparams_4x4_m(c->qpc + 3, c->off4[1 + uv][intra ? 1 : 0], q_dcs); q_dc = q_dcs[0]; }
     if (intra) memcpy(pred, ipred[uv][o->c_ipred_mode], sizeof pred);
     else
-      for (j = 0; j < 8; j += 4)
+      for (j = 0; j < RH; j += 4)
         for (i = 0; i < 8; i += 4) {
-          const int b8 = (j >> 2) * 2 + (i >> 2), md = mode == 8 ? b8mode[b8] : mode, ref = ref8[b8];
+          const int b8 = (y422 ? j >> 3 : j >> 2) * 2 + (i >> 2), md = mode == 8 ? b8mode[b8] : mode, ref = ref8[b8];
           jmo_mv mv0[4][2], mv1[4][2];
           jmo_pel out[16];
           int jj, h;
           memset(mv1, 0, sizeof mv1);
-          for (jj = 0; jj < 4; jj++) for (h = 0; h < 2; h++) mv0[jj][h] = e->all_mv[ref][md][(j + jj) >> 1][(i + 2 * h) >> 1];
-          jmo_chroma_pred4x4(e->refc[ref * 2 + uv], NULL, CW, CW, c->height >> 1, 1, 0, cx + i, cy + j, mv0, mv1, out);
+          for (jj = 0; jj < 4; jj++) for (h = 0; h < 2; h++) mv0[jj][h] = e->all_mv[ref][md][y422 ? (j + jj) >> 2 : (j + jj) >> 1][(i + 2 * h) >> 1];
+          jmo_chroma_pred4x4(e->refc[ref * 2 + uv], NULL, CW, CW, CH, y422 ? 2 : 1, 0, cx + i, cy + j, mv0, mv1, out);
           for (jj = 0; jj < 4; jj++) for (h = 0; h < 4; h++) pred[(j + jj) * 8 + i + h] = out[jj * 4 + h];
         }
-    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) orig[j * 8 + i] = e->cur[1 + uv][(cy + j) * CW + cx + i];
+    for (j = 0; j < RH; j++) for (i = 0; i < 8; i++) orig[j * 8 + i] = e->cur[1 + uv][(cy + j) * CW + cx + i];
     for (k = 0; k < 8; k++) ac_level[k][0] = 0;
     dc_level[0] = 0;
-    cr_cbp = jmo_rtq_chroma(1, uv, cr_cbp, &cbp_blk, q_ac, &q_dc, c->qpc / 6, c->qpc / 6, !c->cabac, 0, 0, 255, orig, pred, rec, dc_level, dc_run, ac_level, ac_run, fadj);
-    for (pos = 0, k = 0; k < 4 && dc_level[k] != 0; k++) { pos += dc_run[k]; o->chroma_dc[uv][pos++] = (int16_t)dc_level[k]; }
-    for (b4 = 0; b4 < 4; b4++)
+    cr_cbp = jmo_rtq_chroma(y422 ? 2 : 1, uv, cr_cbp, &cbp_blk, q_ac, &q_dc, c->qpc / 6, y422 ? (c->qpc + 3) / 6 : c->qpc / 6, !c->cabac, 0, 0, 255, orig, pred, rec,
+                            dc_level, dc_run, ac_level, ac_run, fadj);
+    for (pos = 0, k = 0; k < nblk && dc_level[k] != 0; k++) { pos += dc_run[k]; o->chroma_dc[uv][pos++] = (int16_t)dc_level[k]; }
+    for (b4 = 0; b4 < nblk; b4++)
       for (pos = 1, k = 0; k < 15 && ac_level[b4][k] != 0; k++) { pos += ac_run[b4][k]; o->chroma_ac[uv][b4][pos++] = (int16_t)ac_level[b4][k]; }
-    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) e->rec[1 + uv][(cy + j) * CW + cx + i] = rec[j * 8 + i];
+    for (j = 0; j < RH; j++) for (i = 0; i < 8; i++) e->rec[1 + uv][(cy + j) * CW + cx + i] = rec[j * 8 + i];
   }
   o->cbp = (int16_t)(o->cbp + (cr_cbp << 4));
   o->cbp_blk |= (uint64_t)cbp_blk;
@@ -943,7 +949,7 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
       int dc_level[17], dc_run[17], ac_level[16][16], ac_run[16][16], fadj[64], pos, b;
       jmo_pel rec[256];
       best_mode = 10; min_rdcost = rd_cost;
-      jmo_qparams_4x4(c->qp, 1, c->q_offset[1], q);
+      jmo_qparams_4x4_m(c->qp, c->off4[0][1], q);
       dc_level[0] = 0;
       o->cbp = (int16_t)jmo_rtq_luma_16x16(e->orig, pred4[i16], q, c->qp / 6, !c->cabac, 0, 0, 255, dc_level, dc_run, ac_level, ac_run, rec, fadj);
       memset(o->luma, 0, sizeof o->luma);

@@ -220,6 +220,18 @@ void jmo_qparams_8x8(int qp, int intra, int offset_val, jmo_qparam out[64])
     out[j * 8 + i].OffsetComp   = offset_val << (16 + per - 11);    /* q_offsets.c CalculateOffset8x8Param: Q_BITS_8 */
   }
 }
+void jmo_qparams_4x4_m(int qp, const int16_t off[16], jmo_qparam out[16])
+{
+  int k;
+  jmo_qparams_4x4(qp, 0, 0, out);
+  for (k = 0; k < 16; k++) out[k].OffsetComp = (int)off[k] << (15 + qp / 6 - 11);
+}
+void jmo_qparams_8x8_m(int qp, const int16_t off[64], jmo_qparam out[64])
+{
+  int k;
+  jmo_qparams_8x8(qp, 0, 0, out);
+  for (k = 0; k < 64; k++) out[k].OffsetComp = (int)off[k] << (16 + qp / 6 - 11);
+}
 
 /* quant_4x4_normal quant4x4_normal.c:39-115 / quant_4x4_around quant4x4_around.c:40-127 */
 static int quant4x4_core(int tb[16], const jmo_qparam q[16], int qp_per, int cavlc,

@@ -269,14 +269,23 @@ def rtq_chroma(yuv, uv, cr_cbp, cbp_blk, q_ac, q_dc, qp_per_ac, qp_per_dc, cavlc
 
 
 def qparams_4x4(qp, intra, offset):
+    """offset: one value for all sixteen positions, or sixteen values (a q_offset.cfg list)"""
     q = np.zeros((16, 3), np.int32)
-    L.jmo_qparams_4x4(qp, intra, offset, _p(q))
+    if np.ndim(offset):
+        o = np.ascontiguousarray(offset, np.int16)
+        L.jmo_qparams_4x4_m(qp, _p(o), _p(q))
+    else:
+        L.jmo_qparams_4x4(qp, intra, offset, _p(q))
     return q
 
 
 def qparams_8x8(qp, intra, offset):
     q = np.zeros((64, 3), np.int32)
-    L.jmo_qparams_8x8(qp, intra, offset, _p(q))
+    if np.ndim(offset):
+        o = np.ascontiguousarray(offset, np.int16)
+        L.jmo_qparams_8x8_m(qp, _p(o), _p(q))
+    else:
+        L.jmo_qparams_8x8(qp, intra, offset, _p(q))
     return q
 
 
@@ -446,7 +455,7 @@ class MbEncCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("slice_type", C.c_int32), ("first_mb", C.c_int32), ("num_mb", C.c_int32),
                 ("qp", C.c_int32), ("qpc", C.c_int32), ("search_range", C.c_int32), ("num_ref", C.c_int32), ("lambda_mf", C.c_int32 * 3),
                 ("lambda_mdfp", C.c_int32), ("max_mvd", C.c_int32), ("mv_limit", C.c_int32 * 4), ("inter_valid", C.c_int32 * 8),
-                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("q_offset", C.c_int32 * 2), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32), ("transform8x8", C.c_int32), ("q_offset8", C.c_int32 * 2), ("intra8_valid", C.c_int32)]
+                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("off4", C.c_int16 * 16 * 2 * 3), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32), ("transform8x8", C.c_int32), ("off8", C.c_int16 * 64 * 2), ("intra8_valid", C.c_int32), ("yuv_format", C.c_int32)]
 
 
 NO_REF = -(1 << 30)
@@ -466,19 +475,27 @@ EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spati
 MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("transform8x8", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
-                      ("chroma_dc", "<i2", (2, 4)), ("chroma_ac", "<i2", (2, 4, 16))])
+                      ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16))])
 MB_DEBUG = np.dtype([("motion_cost", "<i8", (8, 4)), ("all_mv", "<i2", (8, 16, 2)), ("best_mode", "<i4"), ("pad", "<i4")])
-assert MB_RECORD.itemsize == 944
+assert MB_RECORD.itemsize == 1216
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
-              subpel=1, cabac=0, search_mode=-1, transform8x8=0):
+              subpel=1, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, offsets=None):
+    """offsets: None = JM's default quantiser offsets, or the lists of a q_offset.cfg (load_q_offsets) when the sequence has OffsetMatrixPresentFlag = 1"""
     c = MbEncCfg()
+    o4, o8 = slice_offsets(slice_type, offsets)
+    for pl in range(3):
+        for intra in range(2):
+            for k in range(16):
+                c.off4[pl][intra][k] = int(o4[pl][intra][k])
+    for intra in range(2):
+        for k in range(64):
+            c.off8[intra][k] = int(o8[intra][k])
+    c.yuv_format = yuv_format
     c.cabac = cabac
     c.search_mode = search_mode
     c.transform8x8 = transform8x8
-    c.q_offset8[0] = 342
-    c.q_offset8[1] = 682 if slice_type == 2 else 342
     c.intra8_valid = 1 if transform8x8 else 0
     c.width, c.height, c.slice_type, c.first_mb, c.num_mb = width, height, slice_type, first_mb, num_mb
     c.qp = qp
@@ -496,8 +513,6 @@ def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambd
     c.intra4_valid = c.intra16_valid = 1
     c.subpel = subpel
     c.start_qp = 1
-    c.q_offset[0] = 342
-    c.q_offset[1] = 682 if slice_type == 2 else 342
     c.refbits[0] = 1
     bits = 3
     while True:
@@ -511,12 +526,33 @@ def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambd
     return c
 
 
+def load_q_offsets(path):
+    """the lists of a q_offset.cfg (lencod/src/q_offsets.c:300-420 parses `NAME = v, v, ...`) as {name: [values]}"""
+    import re
+    txt = re.sub(r"#[^\n]*", "", open(path).read())
+    out = {}
+    for m in re.finditer(r"([A-Z0-9_]+)\s*=\s*([-0-9,\s]+)", txt):
+        out[m.group(1)] = [int(v) for v in m.group(2).replace(",", " ").split()]
+    return out
+
+
+def slice_offsets(slice_type, offsets=None):
+    """(off4[plane][inter, intra][16], off8[inter, intra][64]) as CalculateOffset4x4Param / 8x8Param (q_offsets.c:633, :720) pick them for an I (2) or a P (0) slice"""
+    if offsets is None:
+        intra = 682 if slice_type == 2 else 342                      # Offset_intra_default_intra / _inter, Offset_inter_default (q_offsets.c:135-162)
+        return [[[342] * 16, [intra] * 16] for _ in range(3)], [[342] * 64, [intra] * 64]
+    sfx = "INTRA" if slice_type == 2 else "INTERP"
+    o4 = [[offsets[f"INTER4X4_{pl}_INTERP"], offsets[f"INTRA4X4_{pl}_{sfx}"]] for pl in ("LUMA", "CHROMAU", "CHROMAV")]
+    return o4, [offsets["INTER8X8_LUMA_INTERP"], offsets[f"INTRA8X8_LUMA_{sfx}"]]
+
+
 class Picture:
     """Per-picture state the slices of a picture share: reconstruction, mv_info, ipredmode."""
 
-    def __init__(self, width, height):
+    def __init__(self, width, height, yuv_format=1):
         self.w, self.h = width, height
-        self.rec = [np.zeros((height, width), np.uint16), np.zeros((height // 2, width // 2), np.uint16), np.zeros((height // 2, width // 2), np.uint16)]
+        ch = height if yuv_format == 2 else height // 2
+        self.rec = [np.zeros((height, width), np.uint16), np.zeros((ch, width // 2), np.uint16), np.zeros((ch, width // 2), np.uint16)]
         self.mv = np.zeros((height // 4, width // 4, 2), np.int16)
         self.ref_idx = np.full((height // 4, width // 4), -1, np.int8)
         self.ipredmode = np.full((height // 4, width // 4), 2, np.int8)

@@ -40,6 +40,11 @@ typedef struct {
   int32_t poc, ref_poc[16];                 /* enc_picture->poc, listX[LIST_0][r]->poc (EPZS scales its predictors by picture distances) */
   int64_t motion_cost_ref[8][4][4];         /* p_Vid->motion_cost[mode][LIST_0][ref 1..4][block] */
   int32_t luma8_level[4][65], luma8_run[4][65];      /* cofAC[b8][0][0/1][k]: the 64-entry list of an 8x8 transform block with CABAC (CAVLC: four lists of 16 in luma_level) */
+  /* 4:2:2: chroma_level / _run [uv * 4 + b4] = cofAC[4 + 2 uv][b4] (the plane's blocks 0..3), chroma2_* [uv * 4 + b4] = cofAC[5 + 2 uv][b4] (blocks 4..7, block.c:1096-1105);
+   * rec_u / rec_v rows 0..7, rec_u2 / rec_v2 rows 8..15 */
+  int32_t chroma2_level[8][17], chroma2_run[8][17];
+  uint8_t rec_u2[64], rec_v2[64];
+  int32_t yuv_format;
 } MBREC;
 #pragma pack(pop)
 
@@ -117,6 +122,16 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
           r.chroma_level[(b8 - 4) * 4 + b4][k] = currSlice->cofAC[b8][b4][0][k];
           r.chroma_run[(b8 - 4) * 4 + b4][k] = currSlice->cofAC[b8][b4][1][k];
         }
+  if (p_Vid->yuv_format == YUV422)
+    for (m = 0; m < 2; m++)                      /* plane */
+      for (b4 = 0; b4 < 4; b4++)
+        for (k = 0; k < 17; k++) {
+          r.chroma_level[m * 4 + b4][k] = currSlice->cofAC[4 + 2 * m][b4][0][k];
+          r.chroma_run[m * 4 + b4][k] = currSlice->cofAC[4 + 2 * m][b4][1][k];
+          r.chroma2_level[m * 4 + b4][k] = currSlice->cofAC[5 + 2 * m][b4][0][k];
+          r.chroma2_run[m * 4 + b4][k] = currSlice->cofAC[5 + 2 * m][b4][1][k];
+        }
+  r.yuv_format = p_Vid->yuv_format;
   for (j = 0; j < 16; j++)
     for (i = 0; i < 16; i++) r.rec_y[j * 16 + i] = (uint8_t)p_Vid->enc_picture->imgY[currMB->pix_y + j][currMB->pix_x + i];
   if (p_Vid->yuv_format == YUV420)
@@ -124,6 +139,14 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
       for (i = 0; i < 8; i++) {
         r.rec_u[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[0][currMB->pix_c_y + j][currMB->pix_c_x + i];
         r.rec_v[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[1][currMB->pix_c_y + j][currMB->pix_c_x + i];
+      }
+  if (p_Vid->yuv_format == YUV422)
+    for (j = 0; j < 8; j++)
+      for (i = 0; i < 8; i++) {
+        r.rec_u[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[0][currMB->pix_c_y + j][currMB->pix_c_x + i];
+        r.rec_v[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[1][currMB->pix_c_y + j][currMB->pix_c_x + i];
+        r.rec_u2[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[0][currMB->pix_c_y + 8 + j][currMB->pix_c_x + i];
+        r.rec_v2[j * 8 + i] = (uint8_t)p_Vid->enc_picture->imgUV[1][currMB->pix_c_y + 8 + j][currMB->pix_c_x + i];
       }
   fwrite(&r, sizeof r, 1, f);
   fflush(f);

@@ -27,7 +27,7 @@ RDO_OFF = {"RDOptimization": "0", "AdaptiveRounding": "0"}
 SYN1080 = {"InputFile": "syn1080p.yuv", "SourceWidth": "1920", "SourceHeight": "1080", "OutputWidth": "1920", "OutputHeight": "1080",
            "FramesToBeEncoded": "2", "SearchMode": "-1", "SearchRange": "32", "NumberReferenceFrames": "1", "LevelIDC": "51"}
 CASES = {
-    # tag: (overrides on tests/golden/jm_baseline.cfg, source size, frames, synthetic clip?)
+    # tag: (overrides on tests/golden/jm_baseline.cfg -- or on the .cfg named as a fifth element --, source size, frames, synthetic clip?)
     "q1r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1"), (176, 144), 3, False),
     "q5r": (dict(RDO_OFF, SearchMode="-1", SearchRange="32"), (176, 144), 3, False),                      # five references
     "q4r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", SliceMode="1", SliceArgument="33"), (176, 144), 3, False),
@@ -63,6 +63,17 @@ CASES = {
                  EPZSMinThresScale="1", EPZSSubPelThresScale="1", FramesToBeEncoded="4", QPISlice="36", QPPSlice="36"), (176, 144), 4, "motion:13"),    # the other patterns / window set
     "m2t": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", EPZSPattern="0", EPZSDualRefinement="0", EPZSFixedPredictors="0", EPZSTemporal="0",
                  EPZSSpatialMem="0", EPZSBlockType="0", FramesToBeEncoded="4"), (192, 128), 4, "motion:14"),                                            # every optional predictor set off
+    # 4:2:2 (High 4:2:2 profile): 8 x 16 chroma samples per macroblock, the 2x4 chroma DC transform with the quantiser of qpc + 3, vectors of the luma block at the same row
+    # BASELINE configs[4] = encoder_yuv422.cfg (CABAC, 8x8 transform on, fast full search SR 32, five references) on its own clip, but for RDO / adaptive rounding / B pictures
+    "q5y": (dict(RDO_OFF, NumberBFrames="0"), (176, 144), 3, False, "jm_yuv422.cfg"),
+    "q2yv": (dict(RDO_OFF, YUVFormat="2", ProfileIDC="122", InputFile="foreman_part_qcif_422.yuv", SearchMode="-1", SearchRange="16", NumberReferenceFrames="2"), (176, 144), 3, False),   # CAVLC, 4x4 transform only
+    "m3y": (dict(RDO_OFF, NumberBFrames="0", SearchMode="3", NumberReferenceFrames="3", SliceMode="1", SliceArgument="45", FramesToBeEncoded="5", QPISlice="36", QPPSlice="36"),
+            (208, 160), 5, "motion422:41", "jm_yuv422.cfg"),                                                                                 # EPZS, qpc != qp, slices that start mid-row
+    "m2yq": (dict(RDO_OFF, NumberBFrames="0", SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", QPISlice="12", QPPSlice="12", SymbolMode="0"),
+             (176, 144), 4, "motion422:42", "jm_yuv422.cfg"),                                                                                # fine quantiser, CAVLC
+    # BASELINE configs[4] at its own size: 1080p 4:2:2 synthetic, encoder_yuv422.cfg but for RDO / adaptive rounding / B pictures (and the level: five references of 1080p need 5.1)
+    "g4y": (dict(RDO_OFF, NumberBFrames="0", InputFile="syn1080p422.yuv", SourceWidth="1920", SourceHeight="1080", OutputWidth="1920", OutputHeight="1080", FramesToBeEncoded="3", LevelIDC="51"),
+            (1920, 1080), 3, "syn422", "jm_yuv422.cfg"),
 }
 
 
@@ -71,23 +82,39 @@ def md5(b):
 
 
 def run(tag):
-    ov, (sw, sh), nfr, syn = CASES[tag]
+    ov, (sw, sh), nfr, syn = CASES[tag][:4]
+    cfg = CASES[tag][4] if len(CASES[tag]) > 4 else "jm_baseline.cfg"
     W, H = (sw + 15) // 16 * 16, (sh + 15) // 16 * 16
+    if cfg != "jm_baseline.cfg":                             # the tests read a case's settings from its overrides: spell out the ones this .cfg sets differently
+        base = {}
+        for name in ("jm_baseline.cfg", cfg):
+            for line in open(os.path.join(G, name)):
+                kv = line.split("#")[0].split("=")
+                if len(kv) == 2:
+                    base.setdefault(name, {})[kv[0].strip()] = kv[1].strip().strip('"')
+        for k in ("SymbolMode", "SearchMode", "SearchRange", "Transform8x8Mode", "NumberReferenceFrames", "ProfileIDC", "LevelIDC", "YUVFormat", "InputFile", "FramesToBeEncoded",
+                  "SliceMode", "SliceArgument", "QPISlice", "QPPSlice", "DFDisableRefPSlice", "OffsetMatrixPresentFlag"):
+            if k in base[cfg] and k not in ov:
+                ov = dict(ov, **{k: base[cfg][k]})
     tmp = tempfile.mkdtemp(prefix="mbgold_")
     try:
-        for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
+        for f in ("foreman_part_qcif.yuv", "foreman_part_qcif_422.yuv", "q_offset.cfg"):
             shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
         clip_md5 = ""
         if syn is True:
             import bench
             bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), nfr)
-        elif syn:                                            # "motion:<seed>": tests/golden/synth_motion.py at the case's size
+        elif syn == "syn422":
+            import synclip
+            synclip.syn1080p422(os.path.join(tmp, "syn1080p422.yuv"), nfr)
+            clip_md5 = md5(open(os.path.join(tmp, "syn1080p422.yuv"), "rb").read())
+        elif syn:                                            # "motion:<seed>" / "motion422:<seed>": tests/golden/synth_motion.py at the case's size
             import synth_motion
-            data = np.concatenate(synth_motion.motion_clip(sw, sh, nfr, int(syn.split(":")[1])))
+            data = np.concatenate(synth_motion.motion_clip(sw, sh, nfr, int(syn.split(":")[1]), yuv422=syn.startswith("motion422")))
             data.tofile(os.path.join(tmp, "motion.yuv"))
             clip_md5 = md5(data.tobytes())
             ov = dict(ov, InputFile="motion.yuv", SourceWidth=str(sw), SourceHeight=str(sh), OutputWidth=str(sw), OutputHeight=str(sh))
-        args = [EXE, "-d", os.path.join(G, "jm_baseline.cfg")]
+        args = [EXE, "-d", os.path.join(G, cfg)]
         for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
             args += ["-p", f"{k}={v}"]
         subprocess.run(args, cwd=tmp, env=dict(os.environ, JM_TAP_DIR=tmp), check=True, stdout=subprocess.DEVNULL)
@@ -98,8 +125,12 @@ def run(tag):
         for n in range(nfr):
             T = tap[n * nmb:(n + 1) * nmb]
             y = T["rec_y"].reshape(H // 16, W // 16, 16, 16).transpose(0, 2, 1, 3).reshape(H, W)
-            u = T["rec_u"].reshape(H // 16, W // 16, 8, 8).transpose(0, 2, 1, 3).reshape(H // 2, W // 2)
-            v = T["rec_v"].reshape(H // 16, W // 16, 8, 8).transpose(0, 2, 1, 3).reshape(H // 2, W // 2)
+            if int(T["yuv_format"][0]) == 2:
+                u = np.concatenate([T["rec_u"], T["rec_u2"]], axis=1).reshape(H // 16, W // 16, 16, 8).transpose(0, 2, 1, 3).reshape(H, W // 2)
+                v = np.concatenate([T["rec_v"], T["rec_v2"]], axis=1).reshape(H // 16, W // 16, 16, 8).transpose(0, 2, 1, 3).reshape(H, W // 2)
+            else:
+                u = T["rec_u"].reshape(H // 16, W // 16, 8, 8).transpose(0, 2, 1, 3).reshape(H // 2, W // 2)
+                v = T["rec_v"].reshape(H // 16, W // 16, 8, 8).transpose(0, 2, 1, 3).reshape(H // 2, W // 2)
             pre.append([md5(np.ascontiguousarray(p).tobytes()) for p in (y, u, v)])
         t0 = tap[0]
         lam = {int(t["slice_type"]): list(t["lambda_mf"]) + [int(t["lambda_mdfp"])] for t in tap[::nmb]}
@@ -112,7 +143,7 @@ def run(tag):
                             motion_cost_ref=tap["motion_cost_ref"][:, 1:, :, :].astype(np.int64) if ov.get("SearchMode") == "3" else np.zeros(0, np.int64),
                             motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if sw * sh < 200000 else np.zeros(0, np.int64),
                             md5_264=md5(open(os.path.join(tmp, "o.264"), "rb").read()), md5_recon=md5(open(os.path.join(tmp, "o_rec.yuv"), "rb").read()),
-                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5)
+                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]))
         print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

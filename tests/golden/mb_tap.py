@@ -1,7 +1,7 @@
 """Reader of oracle/ref_tap_mb.c's dump (mb_low.bin) and helpers shared by make_mb_golden.py and the tests: TEST INFRASTRUCTURE.
 
 The dump is what the REAL reference encoder's encode_one_macroblock_low left behind per macroblock; `to_records` turns it into the
-record layout of the product ABI / the oracle (jmhip_mb_record = jmo_mb_record, 944 bytes) so the three can be compared field by field."""
+record layout of the product ABI / the oracle (jmhip_mb_record = jmo_mb_record, 1216 bytes) so the three can be compared field by field."""
 import numpy as np
 
 TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), ("slice_nr", "<i4"),
@@ -16,7 +16,8 @@ TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), 
                 ("chroma_level", "<i4", (8, 17)), ("chroma_run", "<i4", (8, 17)),
                 ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,)),
                 ("poc", "<i4"), ("ref_poc", "<i4", (16,)), ("motion_cost_ref", "<i8", (8, 4, 4)),
-                ("luma8_level", "<i4", (4, 65)), ("luma8_run", "<i4", (4, 65))])
+                ("luma8_level", "<i4", (4, 65)), ("luma8_run", "<i4", (4, 65)),
+                ("chroma2_level", "<i4", (8, 17)), ("chroma2_run", "<i4", (8, 17)), ("rec_u2", "u1", (64,)), ("rec_v2", "u1", (64,)), ("yuv_format", "<i4")])
 
 
 def read(path):
@@ -42,9 +43,10 @@ def expected_coeffs(t, cabac=0):
     lists of every fourth position (CAVLC: list s & 3, place s >> 2)."""
     luma = np.zeros((16, 16), np.int16)
     luma_dc = np.zeros(16, np.int16)
-    cdc = np.zeros((2, 4), np.int16)
-    cac = np.zeros((2, 4, 16), np.int16)
+    cdc = np.zeros((2, 8), np.int16)
+    cac = np.zeros((2, 8, 16), np.int16)
     mbt, cbp = int(t["mb_type"]), int(t["cbp"])
+    y422 = int(t["yuv_format"]) == 2
     t8 = int(t["transform8x8"]) and mbt not in (9, 10)
     if mbt == 10:
         luma_dc = dense(t["dc_level"][0], t["dc_run"][0], 0)
@@ -62,11 +64,14 @@ def expected_coeffs(t, cabac=0):
                 luma[4 * b8 + b4] = dense(t["luma_level"][4 * b8 + b4], t["luma_run"][4 * b8 + b4], 1 if mbt == 10 else 0)
     if cbp > 15:
         for uv in range(2):
-            cdc[uv] = dense(t["dc_level"][1 + uv], t["dc_run"][1 + uv], 0, 4)
+            n = 8 if y422 else 4
+            cdc[uv][:n] = dense(t["dc_level"][1 + uv], t["dc_run"][1 + uv], 0, n)
     if cbp >> 4 == 2:
         for uv in range(2):
             for b4 in range(4):
                 cac[uv][b4] = dense(t["chroma_level"][4 * uv + b4], t["chroma_run"][4 * uv + b4], 1)
+                if y422:                         # the plane's blocks 4..7: cofAC[5 + 2 uv][b4]
+                    cac[uv][4 + b4] = dense(t["chroma2_level"][4 * uv + b4], t["chroma2_run"][4 * uv + b4], 1)
     return luma, luma_dc, cdc, cac
 
 
@@ -115,7 +120,10 @@ def compare(t, r, rec_mb=None):
             if not np.array_equal(a, b):
                 d.append((name, a.tolist(), b.tolist()))
     if rec_mb is not None:
-        for name, a, b in zip(("rec_y", "rec_u", "rec_v"), (t["rec_y"].reshape(16, 16), t["rec_u"].reshape(8, 8), t["rec_v"].reshape(8, 8)), rec_mb):
+        ru, rv = t["rec_u"].reshape(8, 8), t["rec_v"].reshape(8, 8)
+        if int(t["yuv_format"]) == 2:
+            ru, rv = np.concatenate([ru, t["rec_u2"].reshape(8, 8)]), np.concatenate([rv, t["rec_v2"].reshape(8, 8)])
+        for name, a, b in zip(("rec_y", "rec_u", "rec_v"), (t["rec_y"].reshape(16, 16), ru, rv), rec_mb):
             if not np.array_equal(a, b):
                 d.append((name, int(np.abs(a.astype(int) - b.astype(int)).max())))
     return d
@@ -179,6 +187,18 @@ def tap_to_records(tap, cabac=0):
         r["ipredmode"], r["ipred_syntax"], r["mv"] = t["ipredmode"], t["ipred_syntax"], t["mv"]
         r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = expected_coeffs(t, cabac)
     return canonical(out)
+
+
+def widen(recs):
+    """Records stored with an earlier, narrower layout (the 944-byte record of the 4:2:0-only pipeline: chroma_dc[2][4], chroma_ac[2][4][16]) in today's layout."""
+    dt = _record_dtype()
+    if recs.dtype == dt:
+        return recs
+    out = np.zeros(recs.shape, dt)
+    for old, new in zip(recs.dtype.names, dt.names):          # same fields in the same order (one was renamed when it got a meaning)
+        a = recs[old]
+        out[new][tuple([slice(None)] + [slice(0, k) for k in a.shape[1:]])] = a
+    return out
 
 
 def diff_fields(a, b):

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: a small synthetic clip with a non-trivial motion field (own generator, seed-pinned): a textured background that drifts by a
 fractional number of samples per picture, rectangles with their own textures and velocities on top of it, one of them appearing late, sensor noise.
 EPZS (predictor sets, early exits, pattern walks, several references) is pinned on this clip; the reference's own sample clip has three pictures only.
-planar 4:2:0 bytes per frame."""
+planar 4:2:0 (or, on request, 4:2:2) bytes per frame."""
 import numpy as np
 
 
@@ -20,7 +20,7 @@ def _shifted(tex, y, x, h, w):
     return (1 - fy) * ((1 - fx) * a[:h, :w] + fx * a[:h, 1:w + 1]) + fy * ((1 - fx) * a[1:h + 1, :w] + fx * a[1:h + 1, 1:w + 1])
 
 
-def motion_clip(W, H, nfr, seed):
+def motion_clip(W, H, nfr, seed, yuv422=False):
     rng = np.random.default_rng(seed)
     bg = _texture(rng, H + 96, W + 96, 8, 5)
     objs = []
@@ -41,7 +41,7 @@ def motion_clip(W, H, nfr, seed):
             patch = _shifted(o["tex"], 20 + (ya - y0), 20 + (xa - x0) + o["tx"] * n, yb - ya, xb - xa)
             y[ya:yb, xa:xb] = patch
         y = np.clip(np.rint(y + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
-        yd = y.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
+        yd = y.reshape(H, W // 2, 2).mean(axis=2) if yuv422 else y.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))     # 4:2:2: chroma planes W / 2 x H
         u = np.clip(np.rint(128 + 0.3 * (yd - 128)), 0, 255).astype(np.uint8)
         v = np.clip(np.rint(128 - 0.2 * (yd - 128)), 0, 255).astype(np.uint8)
         frames.append(np.concatenate([y.ravel(), u.ravel(), v.ravel()]))

@@ -49,11 +49,12 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
     if cfg.transform8x8:
         p["transform8x8"], p["intra8_valid"] = cfg.transform8x8, cfg.intra8_valid
         for intra in range(2):
-            p["q_luma8"][0, intra] = pyjmo.qparams_8x8(cfg.qp, intra, cfg.q_offset8[intra])
+            p["q_luma8"][0, intra] = pyjmo.qparams_8x8(cfg.qp, intra, list(cfg.off8[intra]))
     for intra in range(2):
-        p["q_luma"][0, intra] = pyjmo.qparams_4x4(cfg.qp, intra, cfg.q_offset[intra])
+        p["q_luma"][0, intra] = pyjmo.qparams_4x4(cfg.qp, intra, list(cfg.off4[0][intra]))
         for uv in range(2):
-            p["q_chroma"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc, intra, cfg.q_offset[intra])
+            p["q_chroma"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc, intra, list(cfg.off4[1 + uv][intra]))
+            p["q_chroma_dc"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc + 3, intra, list(cfg.off4[1 + uv][intra]))[0]     # 4:2:2: the chroma DC quantiser (qpc + 3)
     p["df_disable_idc"] = disable_idc
     return p
 
@@ -61,8 +62,9 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None):
         self.cabac = cabac
+        self.yuv_format, self.offsets = yuv_format, offsets
         self.search_mode, self.epzs = search_mode, dict(epzs or {})
         self.transform8x8 = transform8x8
         import jm_amd.lib as L
@@ -70,7 +72,7 @@ class DevSeqEncoder:
         self.L = L
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
-        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=num_ref + 1, yuv_format=1)
+        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=num_ref + 1, yuv_format=yuv_format)
         self.refs = []          # most recent first: (slot, picture id)
         self.npic = 0
 
@@ -84,7 +86,8 @@ class DevSeqEncoder:
         slices = mbenc_util.slices_of(nmb, self.slice_mbs)
         for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8)
+            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
+                                  yuv_format=self.yuv_format, offsets=self.offsets)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc, self.epzs, 2 * self.npic)
             if timing is not None:
                 J.enable_timing(True)
@@ -121,8 +124,10 @@ def load_case(tag):
     lam = {2: ([int(x) for x in z["lambda_i"][:3]], int(z["lambda_i"][3])), 0: ([int(x) for x in z["lambda_p"][:3]], int(z["lambda_p"][3]))}
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]],
-                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)),
-                search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))], epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
+                didc=int(ov.get("DFDisableRefPSlice", 0)), nfr=len(z["slice_type"]), records=mb_tap.widen(z["records"]), cabac=int(ov.get("SymbolMode", 0)),
+                search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))], epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)),
+                yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
+                offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None)
 
 
 EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFixedPredictors", aggressive="EPZSAggressiveWindow", temporal="EPZSTemporal",
@@ -132,9 +137,17 @@ EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFi
 
 def clip_bytes(tag, c):
     clip = str(c["z"]["clip"]) if "clip" in c["z"].files else ""
-    if clip.startswith("motion:"):
+    if clip == "syn422":
+        import synclip
+        import tempfile
+        with tempfile.TemporaryDirectory() as t:
+            synclip.syn1080p422(os.path.join(t, "s.yuv"), c["nfr"])
+            data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+        assert hashlib.md5(data.tobytes()).hexdigest() == str(c["z"]["clip_md5"])
+        return data
+    if clip.startswith("motion"):
         import synth_motion
-        data = np.concatenate(synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1])))
+        data = np.concatenate(synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1]), yuv422=clip.startswith("motion422")))
         assert hashlib.md5(data.tobytes()).hexdigest() == str(c["z"]["clip_md5"]), "the generated clip is not the one the golden records were made from"
         return data
     if tag == "g2r" or clip == "True":
@@ -143,7 +156,7 @@ def clip_bytes(tag, c):
         with tempfile.TemporaryDirectory() as t:
             bench.write_yuv(os.path.join(t, "s.yuv"), c["nfr"])
             return np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
-    return np.fromfile(os.path.join(G, "foreman_part_qcif.yuv"), np.uint8)
+    return np.fromfile(os.path.join(G, "foreman_part_qcif_422.yuv" if c["yuv"] == 2 else "foreman_part_qcif.yuv"), np.uint8)
 
 
 def first_difference(want, got):
@@ -151,7 +164,7 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
@@ -160,13 +173,16 @@ def test_encode_slice_equals_the_reference_encoder(tag):
     High profile (Transform8x8Mode 1: transform decisions, the tr8x8 pass of P8x8, Intra8x8): CAVLC (q1h, m1hq), CABAC (q2hc, m3h), with EPZS (m2he, m1hq),
     and BASELINE configs[2] as stated at 1920x1080 (g3h: CABAC, 8x8 transform on, EPZS).
     Fast full search (SearchMode 0, encoder_baseline.cfg's): QCIF with five references (q5f), the motion clip (m5f), High profile (m3fh), and 1920x1080 with
-    up to three references (g5f: 32 640 macroblocks)."""
+    up to three references (g5f: 32 640 macroblocks).
+    4:2:2 (High 4:2:2 profile; 8 x 16 chroma samples per macroblock, the 2x4 DC transform, q_offset.cfg's quantiser offsets): BASELINE configs[4] but for RDO / adaptive
+    rounding / B pictures on the reference's clip (q5y) and at 1920x1080 (g4y: 24 480 macroblocks), CAVLC with the 4x4 transform only (q2yv), EPZS at QP 36 with
+    slices that start mid-row (m3y), QP 12 (m2yq)."""
     c = load_case(tag)
     enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
-                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"])
+                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     data = clip_bytes(tag, c)
-    fs = c["sw"] * c["sh"] * 3 // 2
+    fs = c["sw"] * c["sh"] * (4 if c["yuv"] == 2 else 3) // 2
     z = c["z"]
     for n in range(c["nfr"]):
         recs, pre, post = enc.encode(data[n * fs:(n + 1) * fs], c["sw"], c["sh"])

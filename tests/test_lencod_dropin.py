@@ -117,23 +117,29 @@ def run_rdo_off_case(tag, tmp, exe=EXE, env_extra=None, frames=None):
     ov = dict(s.split("=") for s in z["overrides"])
     if frames:
         ov["FramesToBeEncoded"] = str(frames)
-    for f in ("foreman_part_qcif.yuv", "q_offset.cfg"):
+    for f in ("foreman_part_qcif.yuv", "foreman_part_qcif_422.yuv", "q_offset.cfg"):
         shutil.copyfile(os.path.join(G, f), os.path.join(tmp, f))
     clip = str(z["clip"]) if "clip" in z.files else ""
-    if tag == "g2r" or clip == "True":
+    cfg = str(z["cfg"]) if "cfg" in z.files else "jm_baseline.cfg"
+    if clip == "syn422":                                   # BASELINE configs[4]'s input at its own size (tests/golden/synclip.py)
+        import sys
+        sys.path.insert(0, G)
+        import synclip
+        synclip.syn1080p422(os.path.join(tmp, "syn1080p422.yuv"), int(ov["FramesToBeEncoded"]))
+    elif tag == "g2r" or clip == "True":
         import sys
         sys.path.insert(0, ROOT)
         import bench
         bench.write_yuv(os.path.join(tmp, "syn1080p.yuv"), int(ov["FramesToBeEncoded"]))
-    elif clip.startswith("motion:"):                       # tests/golden/synth_motion.py at the case's size (the overrides name the file)
+    elif clip.startswith("motion"):                        # tests/golden/synth_motion.py at the case's size (the overrides name the file)
         import sys
         sys.path.insert(0, G)
         import synth_motion
         sw, sh = int(z["size"][0]), int(z["size"][1])
-        data = np.concatenate(synth_motion.motion_clip(sw, sh, int(ov["FramesToBeEncoded"]), int(clip.split(":")[1])))
+        data = np.concatenate(synth_motion.motion_clip(sw, sh, int(ov["FramesToBeEncoded"]), int(clip.split(":")[1]), yuv422=clip.startswith("motion422")))
         assert frames or hashlib.md5(data.tobytes()).hexdigest() == str(z["clip_md5"])
         data.tofile(os.path.join(tmp, "motion.yuv"))
-    args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+    args = [exe, "-d", os.path.join(G, cfg)]
     for k, v in dict(ov, OutputFile="o.264", ReconFile="o_rec.yuv", TraceFile="/dev/null").items():
         args += ["-p", f"{k}={v}"]
     env = dict(os.environ)
@@ -159,7 +165,8 @@ def frame_times(stdout):
 @pytest.mark.parametrize("tag,nmb_total", [("q1r", 297), ("q5r", 297), ("q4r", 297), ("q4s", 297), ("q1c", 297), ("q0c", 297), ("q0r", 297),
                                            ("q1e", 297), ("m5e", 780), ("m2c", 396), ("m3p", 396), ("m2t", 384),      # EPZS (SearchMode 3)
                                            ("q1h", 297), ("q2hc", 297), ("m3h", 650), ("m2he", 396), ("m1hq", 297),   # High profile: the 8x8 transform, Intra8x8
-                                           ("q5f", 297), ("m5f", 780), ("m3fh", 396)])                                 # fast full search (SearchMode 0)
+                                           ("q5f", 297), ("m5f", 780), ("m3fh", 396),                                  # fast full search (SearchMode 0)
+                                           ("q5y", 297), ("q2yv", 297), ("m3y", 650), ("m2yq", 396)])                  # 4:2:2 (encoder_yuv422.cfg: BASELINE configs[4] with RDO off, P pictures only)
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction
@@ -326,6 +333,25 @@ def test_lencod_macroblock_pipeline_fast_full_search_1080p(tmp_path):
     assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
     assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
     print(f"1080p fast full search, up to three references, RDO off, macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
+
+
+@pytest.mark.gpu
+def test_lencod_macroblock_pipeline_configs4_yuv422_1080p(tmp_path):
+    """BASELINE.json configs[4] at its own size with RDOptimization = 0 and P pictures only (g4y): encoder_yuv422.cfg -- High 4:2:2 profile, CABAC, 8x8 transform on, fast
+    full search SR 32, five references configured, q_offset.cfg's quantiser offsets -- on 1920x1080 4:2:2 synthetic input, I + 2 P pictures: every macroblock through
+    the device's pipeline, bitstream and reconstruction equal to CPU JM's."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, z = run_rdo_off_case("g4y", str(tmp_path))
+    err, out = r.stderr.decode(errors="replace"), r.stdout.decode(errors="replace")
+    assert r.returncode == 0, (out[-1500:], err[-1500:])
+    rep = pipeline_report(err)
+    c = counters(err)
+    assert rep and rep["mbs"] == 3 * 8160 and rep["slices"] == 3, (rep, err[-1500:])
+    assert c["passed"] == 0 and c["eval"] == 0 and c["fs"] == 0 and c["subpel"] == 0, c
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]), ("bitstream differs from CPU JM", rep)
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("reconstruction differs from CPU JM", rep)
+    print(f"configs[4] (1080p 4:2:2, CABAC, 8x8 transform, fast full search, RDO off), macroblock pipeline: frame times (ms) {frame_times(out)}, adapter {rep}")
 
 
 def run_2160p(tag, tmp, env_extra=None):

@@ -35,18 +35,28 @@ def load_case(tag):
     didc = int(ov.get("DFDisableRefPSlice", 0))
     return dict(z=z, sw=sw, sh=sh, W=W, H=H, lam=lam, qp=int(z["qp"]), R=int(z["search_range"]), num_ref=int(z["num_ref"]),
                 slice_mbs=int(ov.get("SliceArgument", 0)) if ov.get("SliceMode", "0") == "1" else 0, mv_limit=[int(x) for x in z["mv_limit"]], didc=didc,
-                nfr=len(z["slice_type"]), records=z["records"], cabac=int(ov.get("SymbolMode", 0)), search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))],
-                epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)))
+                nfr=len(z["slice_type"]), records=mb_tap.widen(z["records"]), cabac=int(ov.get("SymbolMode", 0)), search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))],
+                epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)),
+                yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
+                offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None)
 
 
 def source_frames(c, tag):
     clip = str(c["z"]["clip"]) if "clip" in c["z"].files else ""
-    if clip.startswith("motion:"):
+    yuv = c["yuv"]
+    if clip.startswith("motion"):
         import synth_motion
-        fr = synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1]))
+        fr = synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1]), yuv422=clip.startswith("motion422"))
         assert hashlib.md5(np.concatenate(fr).tobytes()).hexdigest() == str(c["z"]["clip_md5"]), "the generated clip is not the one the golden records were made from"
-        return [pyjmo.load_frame(f, c["sw"], c["sh"], c["W"], c["H"], 1) for f in fr]
-    if tag == "g2r" or clip == "True":
+        return [pyjmo.load_frame(f, c["sw"], c["sh"], c["W"], c["H"], yuv) for f in fr]
+    if clip == "syn422":
+        import synclip
+        import tempfile
+        with tempfile.TemporaryDirectory() as t:
+            synclip.syn1080p422(os.path.join(t, "s.yuv"), c["nfr"])
+            data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+        assert hashlib.md5(data.tobytes()).hexdigest() == str(c["z"]["clip_md5"])
+    elif tag == "g2r" or clip == "True":
         import bench
         data = bench.synthetic_frames(c["nfr"]) if hasattr(bench, "synthetic_frames") else None
         if data is None:
@@ -55,15 +65,15 @@ def source_frames(c, tag):
                 bench.write_yuv(os.path.join(t, "s.yuv"), c["nfr"])
                 data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
     else:
-        data = np.fromfile(os.path.join(G, "foreman_part_qcif.yuv"), np.uint8)
-    fs = c["sw"] * c["sh"] * 3 // 2
-    return [pyjmo.load_frame(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], c["W"], c["H"], 1) for n in range(c["nfr"])]
+        data = np.fromfile(os.path.join(G, "foreman_part_qcif_422.yuv" if yuv == 2 else "foreman_part_qcif.yuv"), np.uint8)
+    fs = c["sw"] * c["sh"] * (2 if yuv == 2 else 3) // (1 if yuv == 2 else 2)
+    return [pyjmo.load_frame(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], c["W"], c["H"], yuv) for n in range(c["nfr"])]
 
 
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
-                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"])
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -118,6 +128,21 @@ def test_oracle_configs2_as_stated_full_size():
     assert all(a == 0 for _, a in enc.epzs_stats)
 
 
+# 4:2:2 (High 4:2:2 profile, encoder_yuv422.cfg): 8 x 16 chroma samples per macroblock -- eight 4x4 blocks per plane, the 2x4 DC transform with the quantiser of qpc + 3,
+# the vector of the luma block at the same row -- and the quantiser offsets of q_offset.cfg (OffsetMatrixPresentFlag 1).  q5y = BASELINE configs[4] on its own clip but for
+# RDO / adaptive rounding / B pictures (CABAC, 8x8 transform, fast full search SR 32, five references); q2yv CAVLC, 4x4 transform only, default offsets; m3y EPZS, QP 36 (qpc != qp),
+# slices that start mid-row; m2yq QP 12, CAVLC
+@pytest.mark.parametrize("tag", ["q5y", "q2yv", "m3y", "m2yq"])
+def test_oracle_yuv422_pipeline_equals_the_reference_encoder(tag):
+    run_case(tag)
+
+
+@pytest.mark.skipif(os.environ.get("JMO_LONG") != "1", reason="ten minutes of oracle searches: set JMO_LONG=1 (q5y pins the same configuration at QCIF)")
+def test_oracle_configs4_1080p_full_size():
+    """BASELINE configs[4] at its own size: 1080p 4:2:2 synthetic, encoder_yuv422.cfg but for RDO / adaptive rounding / B pictures (g4y): I + 2 P pictures."""
+    run_case("g4y")
+
+
 @pytest.mark.skipif(os.environ.get("JMO_LONG") != "1", reason="six minutes of oracle full searches: set JMO_LONG=1 (q5f / m5f / m3fh pin the same search at small sizes)")
 def test_oracle_fast_full_search_1080p_full_size():
     """encoder_baseline.cfg's search as shipped (SearchMode 0, five references configured) at 1080p, RDO off: I + 3 P pictures with 1, 2 and 3 references (g5f)."""
@@ -125,4 +150,4 @@ def test_oracle_fast_full_search_1080p_full_size():
 
 
 def test_record_layout():
-    assert pyjmo.MB_RECORD.itemsize == 944
+    assert pyjmo.MB_RECORD.itemsize == 1216
