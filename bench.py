@@ -96,11 +96,13 @@ G3E_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", 
              "ReconFile=o_rec.yuv", "TraceFile=/dev/null")        # tests/golden/mb_low_g3h.npz: BASELINE configs[2] as stated (CABAC, 8x8 transform on, EPZS), P pictures only
 
 
-def run_lencod(exe, frames, timeout, flags=None, clip=None):
+def run_lencod(exe, frames, timeout, flags=None, clip=None, cfg_name="jm_baseline.cfg"):
     """(per-frame {type: [ms]}, md5 of the .264, adapter report line or None, wall seconds) of one encoder run on the clip with the G2r flags (or `flags`)"""
     import hashlib
-    cfg = os.path.join(ROOT, "tests", "golden", "jm_baseline.cfg")
+    import shutil
+    cfg = os.path.join(ROOT, "tests", "golden", cfg_name)
     with tempfile.TemporaryDirectory() as tmp:
+        shutil.copyfile(os.path.join(ROOT, "tests", "golden", "q_offset.cfg"), os.path.join(tmp, "q_offset.cfg"))      # read when a .cfg sets OffsetMatrixPresentFlag
         if clip:
             clip(tmp)
         else:
@@ -196,6 +198,30 @@ def configs2_end_to_end(max_seconds=300):
     return {"available": True, "p_frame_ms_cpu_jm": c[0].get("P"), "p_frame_ms_hip": h[0].get("P"), "wall_s_cpu_jm": round(c[3], 2), "wall_s_hip": round(h[3], 2),
             "speedup_p_frames": round(sum(c[0]["P"]) / max(1, sum(h[0]["P"])), 2), "md5_equal": c[1] == h[1], "md5_is_g3h": h[1] == gold, "adapter": h[2],
             "config": "lencod -d jm_baseline.cfg " + " ".join("-p " + f for f in G3E_FLAGS[:14]) + " -p FramesToBeEncoded=3"}
+
+
+def configs4_end_to_end(max_seconds=400):
+    """BASELINE configs[4] at its own size with RDO off and P pictures only (tests/golden/mb_low_g4y.npz): encoder_yuv422.cfg -- High 4:2:2, CABAC, 8x8 transform on, fast full
+    search SR 32, five references configured, q_offset.cfg -- on 1920x1080 4:2:2 synthetic input, I + 2 P pictures; CPU JM and the drop-in encoder side by side."""
+    cpu_exe, hip_exe = os.path.join(ROOT, "oracle", "_ref", "lencod.exe"), os.path.join(ROOT, "oracle", "_ref", "lencod_hip.exe")
+    if not all(os.path.exists(e) and os.access(e, os.X_OK) for e in (cpu_exe, hip_exe)):
+        return {"available": False, "why": "oracle/_ref/lencod.exe / lencod_hip.exe did not travel"}
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synclip
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g4y.npz"))
+    flags = tuple(str(f) for f in z["overrides"] if not str(f).startswith("FramesToBeEncoded")) + ("OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
+    clip = lambda tmp: synclip.syn1080p422(os.path.join(tmp, "syn1080p422.yuv"), 3)
+    try:
+        c = run_lencod(cpu_exe, 3, max_seconds, flags, clip=clip, cfg_name=str(z["cfg"]))
+        h = run_lencod(hip_exe, 3, max_seconds, flags, clip=clip, cfg_name=str(z["cfg"]))
+    except subprocess.TimeoutExpired:
+        return {"available": False, "why": "timeout"}
+    if not c or not h:
+        return {"available": False, "why": "an encoder failed"}
+    return {"available": True, "workload": "configs[4]: 1080p 4:2:2 (High 4:2:2 profile), CABAC, 8x8 transform on, fast full search SR 32, five references configured (1 and 2 exist), RDO off, "
+                                           "P pictures only, q_offset.cfg's quantiser offsets", "kernel": "k_mb_pipe_t8",
+            "p_frame_ms_cpu_jm": c[0].get("P"), "p_frame_ms_hip": h[0].get("P"), "wall_s_cpu_jm": round(c[3], 2), "wall_s_hip": round(h[3], 2),
+            "speedup_p_frames": round(sum(c[0]["P"]) / max(1, sum(h[0]["P"])), 2), "md5_equal": c[1] == h[1], "md5_is_g4y": h[1] == str(z["md5_264"]), "adapter": h[2]}
 
 
 def configs3_end_to_end(max_seconds=400):
@@ -650,6 +676,7 @@ def main():
         if not args.no_end_to_end and N == 1:
             out["configs2"] = dict(configs2_device, end_to_end=configs2_end_to_end())
             out["configs3"] = configs3_end_to_end()
+            out["configs4"] = configs4_end_to_end()
         if args.streams > 1 and N == 1:
             out["concurrent_streams"] = concurrent_streams(args.streams, raw0, raw1, src_h, slice_prm, local, min(args.steps, 20))
         print(json.dumps(out))
