@@ -605,7 +605,7 @@ typedef struct {
 } jmhip_slice_params;
 
 int jmhip_encode_slice(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_record *out /* host, num_mb records */);
-/* How many workgroups (= compute units) a slice's launch may occupy; 0 = the default (256, the whole MI355X).  A slice is a dependency chain: at
+/* How many workgroups (= compute units) a slice's launch may occupy; 0 = the default: a third more than the slice's widest wavefront, between 64 and 256 (80 for a 1080p slice).  A slice is a dependency chain: at
  * 1080p at most 60 macroblocks can be in flight, 27 on average, so one stream leaves most of the chip idle.  A server that encodes several
  * sequences at once (one context and one HIP stream each -- JM itself has no such mode: one lencod process per sequence) gives each context its
  * share, e.g. 32 for eight 1080p streams; the records are the same for any value (tests/test_gpu_mbenc.py). */
