@@ -81,6 +81,22 @@ int jmhip_set_current_dev(jmhip_ctx *ctx, const uint8_t *d_luma, int32_t pitch_b
  * jmhip_get_current_planes copies them out as imgpel (tight pitches W and W / 2: what p_Vid->pImgOrg[0..2] hold). */
 int jmhip_set_current_frame(jmhip_ctx *ctx, const uint8_t *raw, int32_t src_w, int32_t src_h);
 int jmhip_set_current_frame_dev(jmhip_ctx *ctx, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
+/* The general reader: any of read_one_frame's planar cases -- 4:0:0 / 4:2:0 / 4:2:2 / 4:4:4, 8 .. 14 (16) bit samples in one or two bytes (little endian),
+ * source bit depth == / > / < the coded one (buf2img_basic lcommon/src/input.c:552, buf2img_bitshift :440 with rshift_rnd, chosen as initInput :41-53 does), a file frame larger
+ * or smaller than the picture (cropped / centred, :609-650), pad_borders (:880-925) -- into imgpel (uint16_t) planes of the coded size with tight pitches (coded_w; chroma by
+ * yuv_format), independent of the context's own picture size and bit depth (the context supplies device and stream).  Bit-identical to the reference including its one oddity:
+ * imgpel-sized samples of an equal-sized picture are copied with ONE memcpy (:568-570), so a two-byte picture whose width is not a multiple of 16 arrives sheared in the coded-width
+ * planes -- that is what JM encodes, and what this returns.  Interleaved / RGB / TIFF input stays the host's (deinterleave :102, ReadTIFFImage). */
+typedef struct {
+  int32_t yuv_format;                   /* 0 4:0:0, 1 4:2:0, 2 4:2:2, 3 4:4:4 */
+  int32_t src_w, src_h;                 /* source->width[0], height[0]: the frame in the file */
+  int32_t out_w, out_h;                 /* output->width[0], height[0]: the picture to code */
+  int32_t coded_w, coded_h;             /* p_Vid->width, height: out size rounded up to whole macroblocks (pad_borders' target) */
+  int32_t symbol_bytes;                 /* source->pic_unit_size_shift3: 1 or 2 */
+  int32_t src_depth[3], out_depth[3];   /* source->bit_depth[k], output->bit_depth[k] */
+} jmhip_frame_format;
+int jmhip_load_frame(jmhip_ctx *ctx, const jmhip_frame_format *f, const uint8_t *raw, uint16_t *y, uint16_t *u, uint16_t *v);           /* host frame in, host planes out */
+int jmhip_load_frame_dev(jmhip_ctx *ctx, const jmhip_frame_format *f, const uint8_t *d_raw, uint16_t *d_y, uint16_t *d_u, uint16_t *d_v);   /* device to device, asynchronous */
 /* the same from imgpel planes that already have the coded size (p_Vid->pCurImg, p_Vid->pImgOrg[1], [2] after pad_borders, lcommon/src/input.c:880);
  * asynchronous on the context's stream (the samples are copied into pinned staging before the call returns) */
 int jmhip_set_current_planes(jmhip_ctx *ctx, const uint16_t *y, int32_t pitch_y, const uint16_t *u, const uint16_t *v, int32_t pitch_c);

@@ -117,3 +117,104 @@ extern "C" int jmhip_get_current_planes(jmhip_ctx *ctx, uint16_t *y, uint16_t *u
   if (v) for (size_t i = 0; i < nc; i++) v[i] = st[ny + nc + i];
   return JMHIP_OK;
 }
+
+// ------------------------------------------------------------------ the general reader (jmhip_load_frame): every planar case of read_one_frame
+// One thread per sample of the coded planes (a copy with a little arithmetic: HBM-bound, symbol_bytes read + 2 written per sample).
+struct LoadPlane { long src_off, dst_off; int w, h, ow, oh, cw, ch, shift; };
+struct LoadArgs { LoadPlane pl[3]; int nplanes, sb, bitshift_fn; long total; };
+
+__global__ __launch_bounds__(256) void k_load_frame_ex(const uint8_t *__restrict__ raw, LoadArgs a, uint16_t *__restrict__ y, uint16_t *__restrict__ u, uint16_t *__restrict__ v)
+{
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.total) return;
+  int k = 0;
+  if (a.nplanes > 1 && i >= a.pl[1].dst_off) k = i >= a.pl[2].dst_off ? 2 : 1;
+  const LoadPlane p = a.pl[k];
+  const long e = i - p.dst_off;
+  const int r = (int)(e / p.cw), c = (int)(e - (long)r * p.cw);
+  const int rr = min(r, p.oh - 1), cc = min(c, p.ow - 1);          // pad_borders: right of / below the picture repeats the last column / row
+  const bool same = p.w == p.ow && p.h == p.oh;
+  long si = -1;                                                   // index of the file sample that lands at (rr, cc), or none
+  if (!a.bitshift_fn && a.sb == 2 && same) {                      // buf2img_basic's single memcpy: w * h samples back to back in rows that are cw apart
+    const long f = (long)rr * p.cw + cc;
+    if (f < (long)p.w * p.h) si = f;
+  } else {
+    const int iw = min(p.w, p.ow), ih = min(p.h, p.oh);
+    const int dx = (!same && p.ow >= p.w) ? (p.ow - p.w) >> 1 : 0, dy = (!same && p.oh >= p.h) ? (p.oh - p.h) >> 1 : 0;
+    if (rr >= dy && rr < dy + ih && cc >= dx && cc < dx + iw) si = (long)(rr - dy) * p.w + (cc - dx);
+  }
+  int val = 0;
+  if (si >= 0) {
+    const uint8_t *s = raw + p.src_off + si * a.sb;
+    val = a.sb == 1 ? s[0] : (int)s[0] | ((int)s[1] << 8);
+    if (a.bitshift_fn) val = p.shift > 0 ? (val + (1 << (p.shift - 1))) >> p.shift : val << (-p.shift);       // rshift_rnd
+  }
+  (k == 0 ? y : (k == 1 ? u : v))[e] = (uint16_t)val;
+}
+
+static int load_args(jmhip_ctx *ctx, const char *who, const jmhip_frame_format *f, LoadArgs &a, size_t &raw_bytes, size_t (&n)[3])
+{
+  if (!f) return jmhip_fail(ctx, JMHIP_EINVAL, "%s: null format", who);
+  if (f->yuv_format < 0 || f->yuv_format > 3 || (f->symbol_bytes != 1 && f->symbol_bytes != 2) || f->src_w < 1 || f->src_h < 1 || f->out_w < 1 || f->out_h < 1 ||
+      f->coded_w < f->out_w || f->coded_h < f->out_h || (f->coded_w & 15) || (f->coded_h & 15) || f->coded_w - f->out_w >= 16 || f->coded_h - f->out_h >= 16)
+    return jmhip_fail(ctx, JMHIP_EINVAL, "%s: format %d, %dx%d -> %dx%d in %dx%d, %d byte(s) per sample", who, f->yuv_format, f->src_w, f->src_h, f->out_w, f->out_h, f->coded_w, f->coded_h, f->symbol_bytes);
+  const int sx = (f->yuv_format == 1 || f->yuv_format == 2) ? 1 : 0, sy = f->yuv_format == 1 ? 1 : 0;
+  if (sx && ((f->src_w | f->out_w) & 1)) return jmhip_fail(ctx, JMHIP_EINVAL, "%s: odd width with sub-sampled chroma", who);
+  if (sy && ((f->src_h | f->out_h) & 1)) return jmhip_fail(ctx, JMHIP_EINVAL, "%s: odd height with 4:2:0", who);
+  a.nplanes = f->yuv_format ? 3 : 1; a.sb = f->symbol_bytes;
+  a.bitshift_fn = !(f->src_depth[0] == f->out_depth[0] && f->src_depth[1] == f->out_depth[1]);     // initInput lcommon/src/input.c:41-53
+  long so = 0, dof = 0;
+  for (int k = 0; k < 3; k++) {
+    const int c = k ? 1 : 0;
+    LoadPlane &p = a.pl[k];
+    p.w = c ? f->src_w >> sx : f->src_w; p.h = c ? f->src_h >> sy : f->src_h;
+    p.ow = c ? f->out_w >> sx : f->out_w; p.oh = c ? f->out_h >> sy : f->out_h;
+    p.cw = c ? f->coded_w >> sx : f->coded_w; p.ch = c ? f->coded_h >> sy : f->coded_h;
+    p.shift = f->src_depth[k] - f->out_depth[k];
+    if (k < a.nplanes && (f->src_depth[k] < 1 || f->src_depth[k] > 8 * f->symbol_bytes || f->out_depth[k] < 1 || f->out_depth[k] > 16 || (a.bitshift_fn && 8 * f->symbol_bytes - p.shift > 16)))
+      return jmhip_fail(ctx, JMHIP_EUNSUPPORTED, "%s: %d-bit samples in %d byte(s) to %d bits (input.c:440-443: would not fit imgpel)", who, f->src_depth[k], f->symbol_bytes, f->out_depth[k]);
+    if (k >= a.nplanes) { p.src_off = so; p.dst_off = dof; n[k] = 0; continue; }
+    p.src_off = so; p.dst_off = dof;
+    so += (long)p.w * p.h * f->symbol_bytes;
+    n[k] = (size_t)p.cw * p.ch;
+    dof += (long)n[k];
+  }
+  a.total = dof; raw_bytes = (size_t)so;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_load_frame_dev(jmhip_ctx *ctx, const jmhip_frame_format *f, const uint8_t *d_raw, uint16_t *d_y, uint16_t *d_u, uint16_t *d_v)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  LoadArgs a; size_t rb, n[3];
+  int r = load_args(ctx, "jmhip_load_frame_dev", f, a, rb, n);
+  if (r) return r;
+  if (!d_raw || !d_y || (a.nplanes == 3 && (!d_u || !d_v))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_load_frame_dev: null plane");
+  // the kernel indexes each plane from its own base
+  LoadArgs b = a;
+  hipLaunchKernelGGL(k_load_frame_ex, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, ctx->stream, d_raw, b, d_y, d_u, d_v);
+  HIPCHK(ctx, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_load_frame(jmhip_ctx *ctx, const jmhip_frame_format *f, const uint8_t *raw, uint16_t *y, uint16_t *u, uint16_t *v)
+{
+  if (!ctx) return JMHIP_EINVAL;
+  LoadArgs a; size_t rb, n[3];
+  int r = load_args(ctx, "jmhip_load_frame", f, a, rb, n);
+  if (r) return r;
+  if (!raw || !y || (a.nplanes == 3 && (!u || !v))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_load_frame: null plane");
+  uint8_t *d_raw = nullptr; uint16_t *d_out = nullptr;
+  const size_t tot = n[0] + n[1] + n[2];
+  HIPCHK(ctx, hipMalloc((void **)&d_raw, rb));
+  if (hipMalloc((void **)&d_out, tot * 2) != hipSuccess) { (void)hipFree(d_raw); return jmhip_fail(ctx, JMHIP_ENOMEM, "jmhip_load_frame: %zu bytes of device memory", tot * 2); }
+  hipError_t e = hipMemcpyAsync(d_raw, raw, rb, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) { r = jmhip_load_frame_dev(ctx, f, d_raw, d_out, d_out + n[0], d_out + n[0] + n[1]); if (r) { (void)hipFree(d_raw); (void)hipFree(d_out); return r; } }
+  if (e == hipSuccess) e = hipMemcpyAsync(y, d_out, n[0] * 2, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && a.nplanes == 3) e = hipMemcpyAsync(u, d_out + n[0], n[1] * 2, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && a.nplanes == 3) e = hipMemcpyAsync(v, d_out + n[0] + n[1], n[2] * 2, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_raw); (void)hipFree(d_out);
+  HIPCHK(ctx, e);
+  return JMHIP_OK;
+}

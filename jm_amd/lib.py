@@ -81,6 +81,8 @@ MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
                       ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16))])
+FRAME_FORMAT = np.dtype([("yuv_format", "<i4"), ("src_w", "<i4"), ("src_h", "<i4"), ("out_w", "<i4"), ("out_h", "<i4"), ("coded_w", "<i4"), ("coded_h", "<i4"),
+                         ("symbol_bytes", "<i4"), ("src_depth", "<i4", (3,)), ("out_depth", "<i4", (3,))])
 SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", "<i4"), ("slice_nr", "<i4"), ("qp", "<i4"), ("qpc", "<i4"),
                          ("search_range", "<i4"), ("num_ref", "<i4"), ("ref_slot", "<i4", (MB_MAX_REF,)), ("ref_id", "<i4", (MB_MAX_REF,)),
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
@@ -96,7 +98,7 @@ assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.items
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
 EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchronize", "jmhip_set_stream", "jmhip_plane_geometry",
-           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_current_frame", "jmhip_set_current_frame_dev", "jmhip_set_current_planes", "jmhip_current_planes_dev", "jmhip_get_current_planes", "jmhip_set_reference", "jmhip_set_reference_dev",
+           "jmhip_set_current", "jmhip_set_current_dev", "jmhip_set_current_frame", "jmhip_set_current_frame_dev", "jmhip_load_frame", "jmhip_load_frame_dev", "jmhip_set_current_planes", "jmhip_current_planes_dev", "jmhip_get_current_planes", "jmhip_set_reference", "jmhip_set_reference_dev",
            "jmhip_get_subplanes", "jmhip_subplanes_dev", "jmhip_me_fullsearch", "jmhip_me_fullsearch_dev",
            "jmhip_me_sad_tables", "jmhip_me_eval", "jmhip_me_eval_pred", "jmhip_me_eval_pred_dev", "jmhip_me_subpel", "jmhip_me_subpel_dev", "jmhip_me_refine_dev", "jmhip_tq_luma4x4",
            "jmhip_tq_luma4x4_dev", "jmhip_forward4x4", "jmhip_inverse4x4", "jmhip_forward8x8", "jmhip_inverse8x8",
@@ -221,6 +223,20 @@ class JmHip:
 
     def set_current_frame_dev(self, d_raw, src_w, src_h):
         self._ck(self.lib.jmhip_set_current_frame_dev(self.h, _vp(d_raw), src_w, src_h))
+
+    def load_frame(self, raw, yuv, src_w, src_h, out_w, out_h, symbol_bytes, src_depth, out_depth):
+        """jmhip_load_frame: the general reader; (y, u, v) uint16 planes of the coded size (u, v None at 4:0:0)"""
+        raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
+        W, H = (int(out_w) + 15) // 16 * 16, (int(out_h) + 15) // 16 * 16
+        f = np.zeros(1, FRAME_FORMAT)
+        f["yuv_format"], f["src_w"], f["src_h"], f["out_w"], f["out_h"], f["coded_w"], f["coded_h"], f["symbol_bytes"] = yuv, src_w, src_h, out_w, out_h, W, H, symbol_bytes
+        f["src_depth"], f["out_depth"] = src_depth, out_depth
+        sx, sy = (1 if yuv in (1, 2) else 0), (1 if yuv == 1 else 0)
+        y = np.zeros((H, W), np.uint16)
+        u = np.zeros((H >> sy, W >> sx), np.uint16) if yuv else None
+        v = np.zeros_like(u) if yuv else None
+        self._ck(self.lib.jmhip_load_frame(self.h, _vp(f), _vp(raw), _vp(y), _vp(u) if yuv else None, _vp(v) if yuv else None))
+        return y, u, v
 
     def get_current_planes(self):
         """(y, u, v) uint8 planes of the coded size as jmhip_set_current_frame left them (u, v None at 4:0:0)"""

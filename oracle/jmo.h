@@ -197,6 +197,9 @@ int jmo_intra_chroma_pred(const jmo_pel *up, const jmo_pel *left, int corner, in
 
 /* ---- source frame -> coded-size planes: buf2img_basic + pad_borders, lcommon/src/input.c:552-600, :880-925 (see jmo_interp.c) ---- */
 void jmo_load_frame(const uint8_t *raw, int src_w, int src_h, int W, int H, int yuv, jmo_pel *y, jmo_pel *u, jmo_pel *v);
+/* the general reader: 4:0:0 .. 4:4:4, one or two bytes per sample (little endian), bit depth conversion (buf2img_bitshift :440), source size != picture size (centred / cropped) */
+void jmo_load_frame_ex(const uint8_t *raw, int yuv, int src_w, int src_h, int out_w, int out_h, int W, int H, int symbol_bytes,
+                       const int src_depth[3], const int out_depth[3], jmo_pel *y, jmo_pel *u, jmo_pel *v);
 
 /* ---- motion-compensated prediction, un-weighted (lencod/src/mc_prediction.c; see jmo_mc.c) ---- */
 void jmo_luma_pred(const jmo_refpic *r0, const jmo_refpic *r1, int p_dir, int x, int y, int bsx, int bsy, jmo_mv mv0, jmo_mv mv1, jmo_pel *out);

@@ -10,6 +10,7 @@
  * reproduces them all.
  */
 #include <stdlib.h>
+#include <string.h>
 #include "jmo.h"
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -102,5 +103,44 @@ void jmo_load_frame(const uint8_t *raw, int src_w, int src_h, int W, int H, int 
   if (yuv == 1 || yuv == 2) {
     load_plane(raw + (long)src_w * src_h, scw, sch, cw, ch, u);
     load_plane(raw + (long)src_w * src_h + (long)scw * sch, scw, sch, cw, ch, v);
+  }
+}
+
+/* ---- the general source picture reader: read_one_frame's buf2img calls (lcommon/src/input.c:822-853, planar Y, U, V) with buf2img_basic (:552-650) when the
+ * source and output bit depths agree and buf2img_bitshift (:440-540, rshift_rnd: rounding shift down, plain shift up) otherwise (initInput :41-53), little endian
+ * samples of one or two bytes, the centred / cropped copy when the file's size differs from the picture's, then pad_borders (:880-925).
+ * Planes: tight, coded size (W x H luma; chroma by yuv: 0 none, 1 4:2:0, 2 4:2:2, 3 4:4:4); what the copy does not reach stays 0, as in freshly allocated planes. */
+static void load_plane_ex(const uint8_t *buf, int w, int h, int ow, int oh, int cw, int ch, int sb, int shift, int bitshift_fn, jmo_pel *out)
+{
+  const int same = w == ow && h == oh;
+  const int iw = same ? ow : (w < ow ? w : ow), ih = same ? oh : (h < oh ? h : oh);
+  const int dx = (!same && ow >= w) ? (ow - w) >> 1 : 0, dy = (!same && oh >= h) ? (oh - h) >> 1 : 0;
+  int x, y;
+  memset(out, 0, (size_t)cw * ch * sizeof(jmo_pel));
+  if (!bitshift_fn && sb == (int)sizeof(uint16_t) && same) {
+    /* buf2img_basic :568-570: imgpel-sized samples of an equal-sized picture are copied with ONE memcpy into &imgX[0][0] -- w * h samples back to back, although
+     * the plane's rows are the CODED width apart: a picture whose width is not a multiple of 16 arrives sheared.  That is what the reference encodes. */
+    for (x = 0; x < w * h; x++) out[x] = (jmo_pel)(buf[2 * x] | (buf[2 * x + 1] << 8));
+  } else
+  for (y = 0; y < ih; y++)
+    for (x = 0; x < iw; x++) {
+      const uint8_t *p = buf + ((long)y * w + x) * sb;
+      int v = sb == 1 ? p[0] : p[0] | (p[1] << 8);
+      if (bitshift_fn) v = shift > 0 ? (v + (1 << (shift - 1))) >> shift : v << (-shift);
+      out[(long)(y + dy) * cw + x + dx] = (jmo_pel)v;
+    }
+  for (y = 0; y < oh; y++) for (x = ow; x < cw; x++) out[(long)y * cw + x] = out[(long)y * cw + x - 1];
+  for (y = oh; y < ch; y++) for (x = 0; x < cw; x++) out[(long)y * cw + x] = out[(long)(y - 1) * cw + x];
+}
+void jmo_load_frame_ex(const uint8_t *raw, int yuv, int src_w, int src_h, int out_w, int out_h, int W, int H, int symbol_bytes,
+                       const int src_depth[3], const int out_depth[3], jmo_pel *y, jmo_pel *u, jmo_pel *v)
+{
+  const int sx = (yuv == 1 || yuv == 2) ? 1 : 0, sy = yuv == 1 ? 1 : 0;
+  const int fn = !(src_depth[0] == out_depth[0] && src_depth[1] == out_depth[1]);
+  const long by = (long)src_w * src_h * symbol_bytes, bc = (long)(src_w >> sx) * (src_h >> sy) * symbol_bytes;
+  load_plane_ex(raw, src_w, src_h, out_w, out_h, W, H, symbol_bytes, src_depth[0] - out_depth[0], fn, y);
+  if (yuv) {
+    load_plane_ex(raw + by, src_w >> sx, src_h >> sy, out_w >> sx, out_h >> sy, W >> sx, H >> sy, symbol_bytes, src_depth[1] - out_depth[1], fn, u);
+    load_plane_ex(raw + by + bc, src_w >> sx, src_h >> sy, out_w >> sx, out_h >> sy, W >> sx, H >> sy, symbol_bytes, src_depth[2] - out_depth[2], fn, v);
   }
 }

@@ -333,6 +333,19 @@ def load_frame(raw, src_w, src_h, w, h, yuv):
     return y.astype(np.uint8), (u.astype(np.uint8) if yuv else None), (v.astype(np.uint8) if yuv else None)
 
 
+def load_frame_ex(raw, yuv, src_w, src_h, out_w, out_h, symbol_bytes, src_depth, out_depth):
+    """the general reader (jmo_load_frame_ex): (y, u, v) uint16 planes of the coded size, chroma by yuv (0: none)"""
+    raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
+    W, H = int(out_w + 15) // 16 * 16, int(out_h + 15) // 16 * 16
+    sx, sy = (1 if yuv in (1, 2) else 0), (1 if yuv == 1 else 0)
+    y = np.zeros((H, W), np.uint16)
+    u = np.zeros((H >> sy, W >> sx) if yuv else (1, 1), np.uint16)
+    v = np.zeros_like(u)
+    I3 = C.c_int * 3
+    L.jmo_load_frame_ex(_p(raw), int(yuv), int(src_w), int(src_h), int(out_w), int(out_h), W, H, int(symbol_bytes), I3(*[int(src_depth)] * 3), I3(*[int(out_depth)] * 3), _p(y), _p(u), _p(v))
+    return y, u, v
+
+
 # ---- motion-compensated prediction (jmo_mc.c)
 def luma_pred(r0, r1, p_dir, x, y, bsx, bsy, mv0, mv1):
     """luma_prediction, un-weighted: r0 / r1 RefPic of list 0 / 1 (either may be None when unused); returns (bsy, bsx) uint8"""

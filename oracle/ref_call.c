@@ -107,3 +107,41 @@ long long refcall_pred_dist(int pred, int metric, int W, int H, const unsigned s
   undress_picture(&r1); undress_picture(&r2);
   return (long long)d;
 }
+
+/* ---- the source picture reader: read_one_frame's buf2img calls (lcommon/src/input.c:822-853, non-RGB order) with the function initInput (:41-53) selects,
+ * then pad_borders (:880-925).  buf = one frame as ReadFrameSeparate leaves it in p_Vid->buf (planar Y, U, V; symbol_bytes per sample, little endian).
+ * y / u / v: tight planes of the coded size (coded_w x coded_h, chroma per yuv), zero-filled by the caller like freshly allocated imgpel planes. */
+#include "input.h"
+void buf2img_basic(imgpel **imgX, unsigned char *buf, int size_x, int size_y, int o_size_x, int o_size_y, int symbol_size_in_bytes, int bitshift);
+void buf2img_bitshift(imgpel **imgX, unsigned char *buf, int size_x, int size_y, int o_size_x, int o_size_y, int symbol_size_in_bytes, int bitshift);
+int refcall_load_frame(unsigned char *buf, int yuv, int src_w, int src_h, int out_w, int out_h, int coded_w, int coded_h, int symbol_bytes,
+                       const int src_depth[3], const int out_depth[3], imgpel *y, imgpel *u, imgpel *v)
+{
+  const int sx = (yuv == YUV420 || yuv == YUV422) ? 1 : 0, sy = yuv == YUV420 ? 1 : 0;
+  const int w[2] = {src_w, yuv == YUV400 ? 0 : src_w >> sx}, h[2] = {src_h, yuv == YUV400 ? 0 : src_h >> sy};
+  const int ow[2] = {out_w, yuv == YUV400 ? 0 : out_w >> sx}, oh[2] = {out_h, yuv == YUV400 ? 0 : out_h >> sy};
+  const int cw[2] = {coded_w, yuv == YUV400 ? 0 : coded_w >> sx}, ch[2] = {coded_h, yuv == YUV400 ? 0 : coded_h >> sy};
+  imgpel *planes[3] = {y, u, v};
+  imgpel **rows[3];
+  void (*b2i)(imgpel **, unsigned char *, int, int, int, int, int, int) =
+      (src_depth[0] == out_depth[0] && src_depth[1] == out_depth[1]) ? buf2img_basic : buf2img_bitshift;
+  const long bytes_y = (long)w[0] * h[0] * symbol_bytes, bytes_uv = (long)w[1] * h[1] * symbol_bytes;
+  FrameFormat out;
+  int k, j;
+  for (k = 0; k < 3; k++) {
+    const int c = k ? 1 : 0;
+    rows[k] = (imgpel **)malloc((size_t)(ch[c] > 0 ? ch[c] : 1) * sizeof(imgpel *));
+    for (j = 0; j < ch[c]; j++) rows[k][j] = planes[k] + (size_t)j * cw[c];
+  }
+  b2i(rows[0], buf, w[0], h[0], ow[0], oh[0], symbol_bytes, src_depth[0] - out_depth[0]);
+  if (yuv != YUV400) {
+    b2i(rows[1], buf + bytes_y, w[1], h[1], ow[1], oh[1], symbol_bytes, src_depth[1] - out_depth[1]);
+    b2i(rows[2], buf + bytes_y + bytes_uv, w[1], h[1], ow[1], oh[1], symbol_bytes, src_depth[2] - out_depth[2]);
+  }
+  memset(&out, 0, sizeof out);
+  out.yuv_format = (ColorFormat)yuv;
+  out.width[0] = ow[0]; out.height[0] = oh[0]; out.width[1] = out.width[2] = ow[1]; out.height[1] = out.height[2] = oh[1];
+  pad_borders(out, cw[0], ch[0], cw[1], ch[1], rows);
+  for (k = 0; k < 3; k++) free(rows[k]);
+  return 0;
+}

@@ -1427,6 +1427,37 @@ def test_eval_pred_vs_oracle_and_plain_eval(J, seed):
     ctx.close()
 
 
+# ---------------------------------------------------------------- the general source picture reader
+def test_load_frame_equals_the_reference_reader(J):
+    """jmhip_load_frame (k_load_frame_ex) against the REAL reference's buf2img_* + pad_borders outputs (tests/golden/load_frame.npz) and against the oracle on larger seeded
+    frames: 4:0:0 .. 4:4:4, 8 .. 14 bit, one / two bytes per sample, depth conversion, padded and mismatching sizes, 1080p 4:4:4 10 bit."""
+    from jm_amd.lib import JmHipError
+    g = np.load(os.path.join(G, "load_frame.npz"))
+    ctx = make_ctx(64, 48)                                  # the reader does not depend on the context's own picture size
+    for k, (yuv, sw, sh, ow, oh, sb, sd, od) in enumerate(g["cases"]):
+        y, u, v = ctx.load_frame(g[f"raw{k}"], int(yuv), int(sw), int(sh), int(ow), int(oh), int(sb), int(sd), int(od))
+        assert np.array_equal(y, g[f"y{k}"]), k
+        if yuv:
+            assert np.array_equal(u, g[f"u{k}"]) and np.array_equal(v, g[f"v{k}"]), k
+    rng = np.random.default_rng(99)
+    for (yuv, sw, sh, ow, oh, sb, sd, od) in [(3, 1920, 1080, 1920, 1080, 2, 10, 10), (2, 1918, 1078, 1918, 1078, 2, 14, 12), (1, 722, 578, 704, 576, 1, 8, 8),
+                                               (3, 350, 290, 352, 300, 1, 8, 9), (0, 1280, 720, 1280, 720, 2, 12, 12)]:
+        sx, sy = (1 if yuv in (1, 2) else 0), (1 if yuv == 1 else 0)
+        n = sw * sh + (2 * (sw >> sx) * (sh >> sy) if yuv else 0)
+        smp = rng.integers(0, 1 << sd, n).astype(np.uint16)
+        raw = np.frombuffer(smp.astype(np.uint8).tobytes() if sb == 1 else smp.astype("<u2").tobytes(), np.uint8)
+        y, u, v = ctx.load_frame(raw, yuv, sw, sh, ow, oh, sb, sd, od)
+        oy, ou, ov = J.load_frame_ex(raw, yuv, sw, sh, ow, oh, sb, sd, od)
+        assert np.array_equal(y, oy), (yuv, sw, sh)
+        if yuv:
+            assert np.array_equal(u, ou) and np.array_equal(v, ov), (yuv, sw, sh)
+    with pytest.raises(JmHipError):                        # two-byte samples cannot be scaled up (lcommon/src/input.c:440-443)
+        ctx.load_frame(np.zeros(2 * 16 * 16 * 3, np.uint8), 3, 16, 16, 16, 16, 2, 10, 12)
+    with pytest.raises(JmHipError):
+        ctx.load_frame(np.zeros(16 * 16, np.uint8), 0, 16, 16, 16, 16, 3, 8, 8)
+    ctx.close()
+
+
 # ---------------------------------------------------------------- the source picture: file bytes -> coded-size planes
 @pytest.mark.parametrize("sw,sh,fmt", [(168, 136, 1), (176, 144, 1), (170, 130, 2), (1920, 1080, 1), (1906, 1074, 0), (162, 144, 2)])
 def test_set_current_frame_vs_oracle_and_reference_digests(J, sw, sh, fmt):

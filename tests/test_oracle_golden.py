@@ -494,6 +494,23 @@ def test_oracle_source_frame_padding_matches_the_reference():
     assert [hashlib.sha256(p.tobytes()).hexdigest() for p in (y, u, v)] == [str(s_) for s_ in want]
 
 
+def test_oracle_general_frame_reader_matches_the_reference():
+    """jmo_load_frame_ex == read_one_frame's buf2img calls + pad_borders on the REAL reference's outputs (tests/golden/load_frame.npz, made by calling buf2img_basic /
+    buf2img_bitshift / pad_borders of the unmodified lencod objects: tests/golden/make_load_frame.py): 4:0:0 .. 4:4:4, 8 .. 14 bit in one or two bytes, depth conversion up and
+    down, padded sizes, a file frame larger / smaller than the picture -- and the sheared planes JM makes of two-byte pictures whose width is not a multiple of 16."""
+    g = np.load(os.path.join(G, "load_frame.npz"))
+    assert len(g["cases"]) >= 12
+    for k, (yuv, sw, sh, ow, oh, sb, sd, od) in enumerate(g["cases"]):
+        y, u, v = J.load_frame_ex(g[f"raw{k}"], yuv, sw, sh, ow, oh, sb, sd, od)
+        assert np.array_equal(y, g[f"y{k}"]), k
+        if yuv:
+            assert np.array_equal(u, g[f"u{k}"]) and np.array_equal(v, g[f"v{k}"]), k
+    # the 8-bit reader of the pipeline is the special case
+    k = [i for i, c in enumerate(g["cases"]) if tuple(c[:5]) == (1, 176, 144, 176, 144)][0]
+    y8, u8, v8 = J.load_frame(g[f"raw{k}"], 176, 144, 176, 144, 1)
+    assert np.array_equal(y8, g[f"y{k}"]) and np.array_equal(u8, g[f"u{k}"]) and np.array_equal(v8, g[f"v{k}"])
+
+
 @pytest.mark.parametrize("tag", ["a", "c", "e"])
 def test_oracle_intra_chroma_prediction_matches_the_reference(tag):
     """jmo_intra_chroma_pred == intra_chroma_prediction (intra_chroma.c:530): DC / horizontal / vertical / plane of both planes on the
