@@ -40,8 +40,8 @@ G2R_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", 
              "NumberReferenceFrames=1", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
 G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's .264 for two frames of the clip with these flags
 # HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
-# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v5_kernel_stats.md)
-PIPE_TRAFFIC_BYTES = 319443003            # 3.4 x the algorithmic bytes: the references' windows re-read per macroblock and what is left of the scratch traffic (DESIGN.md section 0 "Scratch")
+# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v6_kernel_stats.md)
+PIPE_TRAFFIC_BYTES = 165844805            # 1.75 x the algorithmic bytes (DESIGN.md section 0 "Scratch and traffic")
 
 
 def synth_luma(n_frames, seed=1234):
@@ -242,6 +242,46 @@ def configs3_end_to_end(max_seconds=400):
         return {"available": False, "why": "lencod_hip.exe failed"}
     return {"available": True, "macroblocks_per_picture": 32400, "slices": 8, "p_frame_ms_hip": h[0].get("P"), "i_frame_ms_hip": h[0].get("I"), "wall_s_hip": round(h[3], 2),
             "macroblocks_per_s_p_frame": round(32400 / (h[0]["P"][0] / 1000.0), 1) if h[0].get("P") else None, "md5_is_g4r": h[1] == e["md5_264"], "adapter": h[2]}
+
+
+def configs3_device(device):
+    """BASELINE configs[3]'s P picture on ONE GPU, device-resident: 3840x2160, 8 slices of 4080 macroblocks side by side in one launch of k_mb_pipe (HIP events), and the whole
+    step (+ DeblockFrame + getSubImagesLuma)."""
+    import torch
+    from jm_amd import JmHip
+    from jm_amd.lib import SLICE_PARAMS
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synclip
+    W4, H4, per, ns = 3840, 2160, 4080, 8
+    with tempfile.TemporaryDirectory() as t:
+        synclip.syn2160p(os.path.join(t, "s.yuv"), 2)
+        data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+    fs = W4 * H4 * 3 // 2
+    ctx = JmHip(W4, H4, search_range=R, num_ref_slots=2, yuv_format=1, device=device, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.set_current_frame(data[:fs].copy(), W4, H4)
+    ctx.encode_slice_dev(slice_params(SLICE_PARAMS, 2, 0, per, 0, 0, num_slices=ns))
+    ctx.deblock_picture_dev(1)
+    ctx.reference_from_recon(0)
+    ctx.set_current_frame(data[fs:2 * fs].copy(), W4, H4)
+    prm = slice_params(SLICE_PARAMS, 0, 0, per, 0, 1, num_slices=ns)
+    prm["ref_slot"][0, 0] = 0
+    ctx.enable_timing(True)
+    ms = []
+    for i in range(4):
+        ctx.encode_slice_dev(prm)
+        ctx.synchronize()
+        ms.append(ctx.last_kernel_ms(5))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(5):
+        ctx.encode_slice_dev(prm)
+        ctx.deblock_picture_dev(1)
+        ctx.reference_from_recon(1)
+    ctx.synchronize()
+    step = (time.perf_counter() - t0) / 5
+    ctx.close()
+    k = float(np.mean(ms[1:]))
+    return {"kernel": "k_mb_pipe", "slices_in_one_launch": ns, "avg_kernel_ms": round(k, 3), "ms_per_step": round(step * 1e3, 3), "macroblocks_per_s_step": round(32400 / step, 1)}
 
 
 def concurrent_streams(S, raw0, raw1, src_h, slice_prm, device, steps):
@@ -643,7 +683,7 @@ def main():
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
-                "traffic_source": "profiles/r03_v5_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
+                "traffic_source": "profiles/r03_v6_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
                 "abs_diff_per_s_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 148.4e12, 5),
                 "critical_path": {"steps": W // 16 + 2 * (H // 16 - 1), "us_per_step": round(pipe_ms * 1e3 / (W // 16 + 2 * (H // 16 - 1)), 1),
                                   "note": "a macroblock waits for its left and upper-right neighbours' vectors: the picture is a chain of mb_w + 2 (mb_h - 1) "
@@ -652,8 +692,8 @@ def main():
                 "note": "a dependency (latency) bound wavefront (x + 2y: at most 60 of 8160 macroblocks in flight at 1080p, 27 on average), not an HBM stream: frac prices the "
                         "algorithmic bytes against 8 TB/s as the contract asks; valu_frac_jm_equivalent counts every candidate JM's full search visits -- the device "
                         "skips the ones JM's own cost bound excludes, so the abs-diffs really issued are fewer (profiles/prof_mbpipe.py mode 11 counts them) -- over the "
-                        "measured v_sad_u8 peak of 148.4 T/s (profiles/r01_valu_rates.txt); traffic is 3.4 times the algorithmic bytes (window re-reads + the remaining scratch; it was 10.5 times with 256 workgroups and "
-                        "768 B of scratch per lane).  DESIGN.md sections 0, 4"}
+                        "measured v_sad_u8 peak of 148.4 T/s (profiles/r01_valu_rates.txt); traffic is 1.75 times the algorithmic bytes (it was 10.5 times with 256 workgroups, 768 B of scratch per lane and every XCD "
+                        "reading every row of the sub-pel planes).  DESIGN.md sections 0, 4"}
         out = {
             "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
             "value": round(total_mb / dt, 1), "unit": "macroblocks/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -675,7 +715,7 @@ def main():
             out["end_to_end"] = end_to_end(cpu)
         if not args.no_end_to_end and N == 1:
             out["configs2"] = dict(configs2_device, end_to_end=configs2_end_to_end())
-            out["configs3"] = configs3_end_to_end()
+            out["configs3"] = dict(configs3_end_to_end(), device=configs3_device(local))
             out["configs4"] = configs4_end_to_end()
         if args.streams > 1 and N == 1:
             out["concurrent_streams"] = concurrent_streams(args.streams, raw0, raw1, src_h, slice_prm, local, min(args.steps, 20))

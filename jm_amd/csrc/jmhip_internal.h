@@ -42,9 +42,10 @@ struct jmhip_ctx {
   uint8_t *d_rec;        // reconstruction of the current picture: Y (cur_pitch x H), then U, V (cw x ch, pitch cw)
   void *d_mb_edge;       // per macroblock: the samples / vectors / modes its right and lower neighbours read (136 bytes, write-through)
   unsigned *d_mb_done;   // per macroblock: epoch of the launch that finished it
-  unsigned *d_mb_sync;   // [0] ticket, [1] error word
+  unsigned *d_mb_sync;   // [0] ticket, [1] error word, [2..9] the bands' tickets
   int *d_mb_order;       // wavefront order of the slice's macroblocks
-  int mb_order_first, mb_order_num, mb_order_per;
+  int mb_order_first, mb_order_num, mb_order_per, mb_order_bands;
+  int mb_band_start[9];
   unsigned mb_epoch;
   int mb_launched;       // a pipeline launch has happened since its error word was last read
   int mb_grid;           // jmhip_set_pipeline_workgroups (0: 256)

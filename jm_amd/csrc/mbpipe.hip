@@ -22,6 +22,8 @@
 //     per-sub-block origin clamp (UMVLine4X), JM's strict-'<' scan replayed on the nine sums.
 // No MFMA: the path is byte / integer add, sub, shift, abs, min.
 #include <mutex>
+#include <cstdlib>
+#include <cstring>
 #include "jmhip_internal.h"
 #include "me_common.h"
 
@@ -52,6 +54,9 @@ struct PipeArgs {
   int W, H, wmb, hmb, cw, ch;
   int c422;                                  // 4:2:2: chroma planes cw x H, 8 x 16 samples per macroblock (ch = H); else 4:2:0
   int total_mb;                              // macroblocks of the launch (num_slices slices of p.num_mb, cut at the end of the picture)
+  int nbands, band_start[9];                 // 8 (or 1): the ticket order is cut into bands of macroblock rows, tickets band_start[b] .. band_start[b + 1] - 1 belong to band b, and
+                                             // workgroup g draws from band g % 8 first -- block g is observed to run on XCD g % 8, so an XCD's L2 then only ever sees its band's
+                                             // rows of the references' planes (speed only: any workgroup may take any ticket)
   int cur_pitch, ref_pitch, rec_pitch;       // luma pitches (bytes); chroma planes are cw wide
   long plane_stride;
   int win_h, win_p, win_ox;                  // LDS window of a reference: (16 + 4R) rows of win_p bytes; the macroblock's column 0 sits at byte win_ox

@@ -11,16 +11,28 @@ import bench
 from jm_amd import JmHip
 from jm_amd.lib import SLICE_PARAMS
 
-W, H, HS = bench.W, bench.H, bench.H_SRC
+if os.environ.get("SWEEP_2160P") == "1":                 # configs[3]: 3840x2160, 8 slices of 4080 macroblocks in one launch
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synclip
+    W, H, HS, per, ns = 3840, 2160, 2160, 4080, 8
+    with tempfile.TemporaryDirectory() as t:
+        synclip.syn2160p(os.path.join(t, "s.yuv"), 2)
+        data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8)
+    fs = W * H * 3 // 2
+    raw0, raw1 = data[:fs].copy(), data[fs:].copy()
+else:
+    W, H, HS = bench.W, bench.H, bench.H_SRC
+    per, ns = (W // 16) * (H // 16), 0
+    raw0, raw1 = bench.yuv_frames(2)
 nmb = (W // 16) * (H // 16)
 ctx = JmHip(W, H, search_range=bench.R, num_ref_slots=2, yuv_format=1)
-raw0, raw1 = bench.yuv_frames(2)
 ctx.set_current_frame(raw0, W, HS)
-ctx.encode_slice_dev(bench.slice_params(SLICE_PARAMS, 2, 0, nmb, 0, 0))
+ctx.encode_slice_dev(bench.slice_params(SLICE_PARAMS, 2, 0, per, 0, 0, num_slices=ns))
 ctx.deblock_picture_dev(1)
 ctx.reference_from_recon(0)
 ctx.set_current_frame(raw1, W, HS)
-prm = bench.slice_params(SLICE_PARAMS, 0, 0, nmb, 0, 1)
+prm = bench.slice_params(SLICE_PARAMS, 0, 0, per, 0, 1, num_slices=ns)
 prm["ref_slot"][0, 0] = 0
 ctx.enable_timing(True)
 ref = None
