@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the macroblock pipeline (GPU box): jmhip_encode_slice against the oracle's restatement (itself pinned to the real encoder by the
+tests/golden/mb_low_* records) on seeded random configurations -- picture size, search range and mode (full search / fast full search / EPZS with random switches),
+references, QP, slices (separate launches or side by side in one), CAVLC / CABAC, 8x8 transform, 4:2:0 / 4:2:2, default or q_offset.cfg quantiser offsets, clips with
+a motion field or adversarial content.  Every macroblock record and the reconstruction before and after the loop filter must be identical.
+TEST INFRASTRUCTURE (uses oracle/).   usage: python profiles/fuzz_mbenc.py <seconds> [first seed]"""
+import os
+import sys
+import time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, d)
+import mb_tap, mbenc_util, synth_motion
+import test_gpu_mbenc as T
+from oracle import pyjmo
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+offsets = pyjmo.load_q_offsets(os.path.join(ROOT, "tests", "golden", "q_offset.cfg"))
+t0, done, by_mode = time.time(), 0, {0: 0, 1: 0, 3: 0}
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed)
+    sm = int(rng.choice([0, 0, 1, 3, 3]))                     # pyjmo search_mode: 0 / -1 full search, 1 fast full search, 3 EPZS
+    R = int(rng.choice([4, 8, 16, 32]))
+    big = R == 32 and sm != 3
+    W = 16 * int(rng.integers(2, 9 if big else 17)); H = 16 * int(rng.integers(2, 7 if big else 12))
+    num_ref = int(rng.integers(1, 5 if R == 32 else 6))
+    qp = int(rng.integers(8, 46))
+    t8, yuv, cabac = int(rng.integers(0, 2)), int(rng.choice([1, 1, 2])), int(rng.integers(0, 2))
+    nmb = (W // 16) * (H // 16)
+    sl = int(rng.choice([0, 0, 1, 2]))
+    slice_mbs = 0 if sl == 0 or nmb < 4 else int(rng.integers(2, nmb))
+    together = bool(sl == 2 and slice_mbs)
+    offs = offsets if rng.integers(0, 3) == 0 else None
+    epzs = None
+    if sm == 3:
+        epzs = dict(pattern=int(rng.integers(0, 6)), dual=int(rng.integers(0, 7)), fixed=int(rng.integers(0, 4)), aggressive=int(rng.integers(0, 2)), temporal=int(rng.integers(0, 2)),
+                    spatial_mem=int(rng.integers(0, 2)), blocktype=int(rng.integers(0, 2)), min_scale=int(rng.integers(0, 3)), med_scale=int(rng.integers(0, 3)), max_scale=int(rng.integers(1, 4)),
+                    sub_scale=int(rng.integers(0, 3)))
+    nfr = min(num_ref + 1, 4) if num_ref > 1 else 3
+    kind = str(rng.choice(["motion", "motion", "motion", "flat", "noise", "stripes", "still", "ramp"]))
+    if kind == "motion" or yuv == 2:
+        frames = synth_motion.motion_clip(W, H, nfr, seed, yuv422=yuv == 2) if W >= 48 and H >= 48 else None
+    else:
+        frames = T.hard_clip(kind, W, H, nfr, seed)
+    if frames is None:
+        frames = T.synthetic_clip(W, H, nfr, seed) if yuv == 1 else None
+    if frames is None:
+        seed += 1
+        continue
+    f = int(192 * 2 ** ((qp - 28) / 6))
+    lam = {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    desc = dict(seed=seed, W=W, H=H, R=R, refs=num_ref, qp=qp, mode=sm, t8=t8, yuv=yuv, cabac=cabac, slice_mbs=slice_mbs, together=together, offsets=offs is not None, clip=kind, epzs=epzs)
+    try:
+        dev = T.DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, together=together, cabac=cabac, search_mode=sm, epzs=epzs, transform8x8=t8, yuv_format=yuv, offsets=offs)
+    except Exception as e:                                   # a configuration the library turns away (LDS budget): say so and go on
+        print("skipped", desc, str(e)[:120]); seed += 1; continue
+    ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, cabac=cabac, search_mode=sm, epzs=epzs, transform8x8=t8, yuv_format=yuv, offsets=offs)
+    try:
+        for n, raw in enumerate(frames):
+            recs, pre, post = dev.encode(raw, W, H)
+            orecs, _, opre, opost = ora.encode(pyjmo.load_frame(raw, W, H, W, H, yuv))
+            d = T.first_difference(mb_tap.canonical(orecs), mb_tap.canonical(T.as_oracle_records(recs)))
+            assert d is None, ("records", n, d[:3])
+            assert all(np.array_equal(a, b.astype(np.uint8)) for a, b in zip(pre, opre)), ("reconstruction before the loop filter", n)
+            assert all(np.array_equal(a, b.astype(np.uint8)) for a, b in zip(post, opost)), ("reconstruction after the loop filter", n)
+    except Exception as e:
+        print("FAILED", desc, repr(e)[:600])
+        sys.exit(1)
+    finally:
+        dev.J.close()
+    done += 1; by_mode[sm] += 1; seed += 1
+print(f"fuzz_mbenc: {done} random configurations identical to the oracle in {time.time() - t0:.0f} s (full search {by_mode[0]}, fast full search {by_mode[1]}, EPZS {by_mode[3]}); next seed {seed}")

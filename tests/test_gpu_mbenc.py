@@ -532,3 +532,12 @@ def test_encode_slice_rejects_what_it_does_not_cover():
     J4 = L.JmHip(64, 48, search_range=16, num_ref_slots=1, yuv_format=2)
     with pytest.raises(L.JmHipError):
         J4.encode_slice(prm)
+
+
+def test_random_configurations_vs_oracle():
+    """Thirty seconds of profiles/fuzz_mbenc.py: seeded random configurations (size, search mode and range, references, QP, slices, entropy mode, 8x8 transform, 4:2:0 / 4:2:2,
+    quantiser offsets, clip kind) through jmhip_encode_slice and the oracle; records and reconstructions identical.  (A ten-minute run of the same script: profiles/r03_fuzz.txt.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_mbenc.py"), "30", "424242"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "identical to the oracle" in out, out[-2000:]
