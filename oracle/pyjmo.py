@@ -494,8 +494,8 @@ assert MB_RECORD.itemsize == 1216
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
-              subpel=1, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, offsets=None):
-    """offsets: None = JM's default quantiser offsets, or the lists of a q_offset.cfg (load_q_offsets) when the sequence has OffsetMatrixPresentFlag = 1"""
+              subpel=1, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None):
+    """inter_valid: enc_mb.valid[0..7] of a P slice (PSliceSkip, PSliceSearch16x16 .. 4x4; default all on).  offsets: None = JM's default quantiser offsets, or the lists of a q_offset.cfg (load_q_offsets) when the sequence has OffsetMatrixPresentFlag = 1"""
     c = MbEncCfg()
     o4, o8 = slice_offsets(slice_type, offsets)
     for pl in range(3):
@@ -522,7 +522,7 @@ def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambd
     for i in range(4):
         c.mv_limit[i] = level_mv[i]
     for m in range(8):
-        c.inter_valid[m] = 1
+        c.inter_valid[m] = 1 if inter_valid is None else int(inter_valid[m])
     c.intra4_valid = c.intra16_valid = 1
     c.subpel = subpel
     c.start_qp = 1

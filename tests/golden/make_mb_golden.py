@@ -63,6 +63,11 @@ CASES = {
                  EPZSMinThresScale="1", EPZSSubPelThresScale="1", FramesToBeEncoded="4", QPISlice="36", QPPSlice="36"), (176, 144), 4, "motion:13"),    # the other patterns / window set
     "m2t": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", EPZSPattern="0", EPZSDualRefinement="0", EPZSFixedPredictors="0", EPZSTemporal="0",
                  EPZSSpatialMem="0", EPZSBlockType="0", FramesToBeEncoded="4"), (192, 128), 4, "motion:14"),                                            # every optional predictor set off
+    # partitions switched off (PSliceSearch*): a mode that is never searched leaves currSlice->all_mv at the zeros it was allocated with, and EPZS's block-type predictors read them
+    "m2pd": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", PSliceSearch16x8="0", PSliceSearch8x4="0"), (176, 144), 4, "motion:51"),
+    "m3pe": (dict(RDO_OFF, SearchMode="3", SearchRange="8", NumberReferenceFrames="3", FramesToBeEncoded="5", PSliceSearch16x8="0", PSliceSearch8x16="0", PSliceSearch8x4="0", PSliceSearch4x8="0",
+                  Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", SliceMode="1", SliceArgument="27", QPISlice="26", QPPSlice="26"), (160, 96), 5, "motion:52"),
+    "q1pd": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", PSliceSearch8x16="0", PSliceSearch4x8="0", PSliceSearch4x4="0"), (176, 144), 3, False),
     # 4:2:2 (High 4:2:2 profile): 8 x 16 chroma samples per macroblock, the 2x4 chroma DC transform with the quantiser of qpc + 3, vectors of the luma block at the same row
     # BASELINE configs[4] = encoder_yuv422.cfg (CABAC, 8x8 transform on, fast full search SR 32, five references) on its own clip, but for RDO / adaptive rounding / B pictures
     "q5y": (dict(RDO_OFF, NumberBFrames="0"), (176, 144), 3, False, "jm_yuv422.cfg"),

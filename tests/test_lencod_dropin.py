@@ -166,7 +166,8 @@ def frame_times(stdout):
                                            ("q1e", 297), ("m5e", 780), ("m2c", 396), ("m3p", 396), ("m2t", 384),      # EPZS (SearchMode 3)
                                            ("q1h", 297), ("q2hc", 297), ("m3h", 650), ("m2he", 396), ("m1hq", 297),   # High profile: the 8x8 transform, Intra8x8
                                            ("q5f", 297), ("m5f", 780), ("m3fh", 396),                                  # fast full search (SearchMode 0)
-                                           ("q5y", 297), ("q2yv", 297), ("m3y", 650), ("m2yq", 396)])                  # 4:2:2 (encoder_yuv422.cfg: BASELINE configs[4] with RDO off, P pictures only)
+                                           ("q5y", 297), ("q2yv", 297), ("m3y", 650), ("m2yq", 396),                   # 4:2:2 (encoder_yuv422.cfg: BASELINE configs[4] with RDO off, P pictures only)
+                                           ("m2pd", 396), ("m3pe", 300), ("q1pd", 297)])                              # partitions switched off (PSliceSearch*)
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction
@@ -422,3 +423,16 @@ def test_adapter_off_is_plain_jm(tmp_path):
     r, out264, rec = run_lencod(EXE, "G1_1ref_2frames", str(tmp_path), {"JMHIP_ADAPTER": "off"})
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-1500:]
     assert md5(out264) == MD5["G1_1ref_2frames"]["md5_264"]
+
+
+@pytest.mark.gpu
+def test_random_rdo_off_configurations_equal_cpu_jm():
+    """Forty seconds of profiles/fuzz_dropin.py: seeded random RDO-off configurations (search mode and range, references, QPs of I and P slices, chroma QP offset, entropy coder, 8x8
+    transform, 4:2:0 / 4:2:2, slices, loop filter parameters, partition switches, intra period, cropped picture sizes, EPZS switches) through lencod_hip.exe and CPU JM: .264 and
+    reconstruction byte-identical.  (Twelve minutes of the same script: profiles/r03_fuzz_dropin.txt; it is what found the stale block-type predictors of switched-off partitions.)"""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_dropin.py"), "40", "777000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and " 0 NOT byte-identical" in out, out[-3000:]

@@ -22,6 +22,7 @@ import mbenc_util  # noqa: E402
 from oracle import pyjmo  # noqa: E402
 
 
+PSLICE_KEYS = ("PSliceSkip", "PSliceSearch16x16", "PSliceSearch16x8", "PSliceSearch8x16", "PSliceSearch8x8", "PSliceSearch8x4", "PSliceSearch4x8", "PSliceSearch4x4")
 EPZS_KEYS = dict(pattern="EPZSPattern", dual="EPZSDualRefinement", fixed="EPZSFixedPredictors", aggressive="EPZSAggressiveWindow", temporal="EPZSTemporal",
                  spatial_mem="EPZSSpatialMem", blocktype="EPZSBlockType", min_scale="EPZSMinThresScale", med_scale="EPZSMedThresScale", max_scale="EPZSMaxThresScale",
                  sub_scale="EPZSSubPelThresScale")
@@ -38,7 +39,8 @@ def load_case(tag):
                 nfr=len(z["slice_type"]), records=mb_tap.widen(z["records"]), cabac=int(ov.get("SymbolMode", 0)), search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))],
                 epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)),
                 yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
-                offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None)
+                offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None,
+                inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None)
 
 
 def source_frames(c, tag):
@@ -73,7 +75,7 @@ def source_frames(c, tag):
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
-                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"])
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -134,6 +136,12 @@ def test_oracle_configs2_as_stated_full_size():
 # slices that start mid-row; m2yq QP 12, CAVLC
 @pytest.mark.parametrize("tag", ["q5y", "q2yv", "m3y", "m2yq"])
 def test_oracle_yuv422_pipeline_equals_the_reference_encoder(tag):
+    run_case(tag)
+
+
+# partitions switched off (PSliceSearch*): EPZS's block-type predictors read currSlice->all_mv of types that are never searched -- the zeros it was allocated with
+@pytest.mark.parametrize("tag", ["m2pd", "m3pe", "q1pd"])
+def test_oracle_with_partitions_switched_off(tag):
     run_case(tag)
 
 
