@@ -601,7 +601,8 @@ typedef struct {
                                    centre per macroblock and reference, the (0,0) vector first; RestrictSearchRange 2); 3: EPZS (SearchMode 3) with EPZSSubPelGrid = 1 and EPZSSubPelME = 1,
                                    the shipped settings: EPZS_integer_motion_estimation lencod/src/me_epzs_int.c:42, its sub-macroblock variant :437,
                                    EPZS_sub_pel_motion_estimation me_epzs_sub.c:30 (start_qp must be 1) */
-  int32_t reserved_[2];
+  int32_t qpc_cr_delta;         /* currMB->qpc[1] - currMB->qpc[0]: not 0 when CrQPOffset != CbQPOffset (High profiles); q_chroma[1] / q_chroma_dc[1] are the Cr tables at that QP */
+  int32_t reserved_[1];
   /* EPZS only (me_epzs_common.c:423 EPZSStructInit, :620 EPZSSliceInit); ignored with search_mode 0 */
   int32_t epzs_pattern, epzs_dual, epzs_fixed, epzs_aggressive, epzs_temporal, epzs_spatial_mem, epzs_blocktype;   /* EPZSPattern (0..5), EPZSDualRefinement (0..6),
                                    EPZSFixedPredictors (0..3), EPZSAggressiveWindow, EPZSTemporal, EPZSSpatialMem, EPZSBlockType */

@@ -1330,7 +1330,7 @@ static void pipe_run_slice(Macroblock *currMB)
   prm.num_mb = p_Inp->slice_mode == FIXED_MB ? imin(p_Inp->slice_argument, left) : left;
   prm.slice_nr = currMB->slice_nr;
   prm.qp = currMB->qp; prm.qpc = currMB->qpc[0];
-  if (currMB->qpc[0] != currMB->qpc[1]) { fprintf(stderr, "jmhip adapter: macroblock pipeline: different chroma QPs\n"); exit(70); }
+  prm.qpc_cr_delta = currMB->qpc[1] - currMB->qpc[0];        /* CbQPOffset != CrQPOffset (High profiles) */
   prm.search_range = p_Vid->searchRange.max_x >> 2;
   prm.num_ref = currSlice->slice_type == I_SLICE ? 0 : currSlice->listXsize[LIST_0];
   for (r = 0; r < prm.num_ref; r++) {

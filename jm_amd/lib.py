@@ -88,7 +88,7 @@ SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", 
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
                          ("inter_valid", "<i4", (8,)), ("intra4_valid", "<i4"), ("intra16_valid", "<i4"), ("subpel", "<i4"), ("start_qp", "<i4"),
                          ("refbits", "<i4", (MB_MAX_REF,)), ("q_luma", "<i4", (2, 16, 3)), ("q_chroma", "<i4", (2, 2, 16, 3)),
-                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("num_slices", "<i4"), ("symbol_mode", "<i4"), ("search_mode", "<i4"), ("reserved_", "<i4", (2,)),
+                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("num_slices", "<i4"), ("symbol_mode", "<i4"), ("search_mode", "<i4"), ("qpc_cr_delta", "<i4"), ("reserved_", "<i4", (1,)),
                          ("epzs_pattern", "<i4"), ("epzs_dual", "<i4"), ("epzs_fixed", "<i4"), ("epzs_aggressive", "<i4"), ("epzs_temporal", "<i4"), ("epzs_spatial_mem", "<i4"),
                          ("epzs_blocktype", "<i4"), ("epzs_min_scale", "<i4"), ("epzs_med_scale", "<i4"), ("epzs_max_scale", "<i4"), ("epzs_sub_scale", "<i4"), ("epzs_reserved_", "<i4"),
                          ("poc_cur", "<i4"), ("poc_ref", "<i4", (MB_MAX_REF,)),

@@ -272,6 +272,7 @@ typedef struct {
                                    pass with 8x8 blocks only, Intra8x8, 8x8 Hadamard SATD in the sub-pel search of blocks of 8x8 samples and more */
   int16_t off8[2][64];          /* the same for the luma 8x8 transform, [inter, intra][j * 8 + i] (CalculateOffset8x8Param q_offsets.c:720) */
   int32_t intra8_valid;         /* enc_mb.valid[I8MB] (mode_decision.c:127) */
+  int32_t qpc_cr_delta;         /* currMB->qpc[1] - currMB->qpc[0] (CrQPOffset != CbQPOffset in the High profiles), normally 0 */
   int32_t yuv_format;           /* 0 or 1: 4:2:0; 2: 4:2:2 (chroma planes width / 2 x height: 8 x 16 samples per macroblock, the 2x4 DC transform, DC quantiser of qpc + 3) */
 } jmo_mbenc_cfg;
 

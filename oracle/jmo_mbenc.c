@@ -637,9 +637,10 @@ static void chroma_mb(enc *e, jmo_mb_record *o, int intra, int mode, const int8_
   for (uv = 0; uv < 2; uv++) {
     jmo_pel pred[128], orig[128], rec[128];
     int dc_level[9], dc_run[9], ac_level[8][16], ac_run[8][16], fadj[128], b4, pos, k;
-    jmo_qparams_4x4_m(c->qpc, c->off4[1 + uv][intra ? 1 : 0], q_ac);
+    const int qpc = c->qpc + uv * c->qpc_cr_delta;
+    jmo_qparams_4x4_m(qpc, c->off4[1 + uv][intra ? 1 : 0], q_ac);
     q_dc = q_ac[0];
-    if (y422) { jmo_qparams_4x4_m(c->qpc + 3, c->off4[1 + uv][intra ? 1 : 0], q_dcs); q_dc = q_dcs[0]; }
+    if (y422) { jmo_qparams_4x4_m(qpc + 3, c->off4[1 + uv][intra ? 1 : 0], q_dcs); q_dc = q_dcs[0]; }
     if (intra) memcpy(pred, ipred[uv][o->c_ipred_mode], sizeof pred);
     else
       for (j = 0; j < RH; j += 4)
@@ -656,7 +657,7 @@ static void chroma_mb(enc *e, jmo_mb_record *o, int intra, int mode, const int8_
     for (j = 0; j < RH; j++) for (i = 0; i < 8; i++) orig[j * 8 + i] = e->cur[1 + uv][(cy + j) * CW + cx + i];
     for (k = 0; k < 8; k++) ac_level[k][0] = 0;
     dc_level[0] = 0;
-    cr_cbp = jmo_rtq_chroma(y422 ? 2 : 1, uv, cr_cbp, &cbp_blk, q_ac, &q_dc, c->qpc / 6, y422 ? (c->qpc + 3) / 6 : c->qpc / 6, !c->cabac, 0, 0, 255, orig, pred, rec,
+    cr_cbp = jmo_rtq_chroma(y422 ? 2 : 1, uv, cr_cbp, &cbp_blk, q_ac, &q_dc, qpc / 6, y422 ? (qpc + 3) / 6 : qpc / 6, !c->cabac, 0, 0, 255, orig, pred, rec,
                             dc_level, dc_run, ac_level, ac_run, fadj);
     for (pos = 0, k = 0; k < nblk && dc_level[k] != 0; k++) { pos += dc_run[k]; o->chroma_dc[uv][pos++] = (int16_t)dc_level[k]; }
     for (b4 = 0; b4 < nblk; b4++)

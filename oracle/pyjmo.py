@@ -468,7 +468,7 @@ class MbEncCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("slice_type", C.c_int32), ("first_mb", C.c_int32), ("num_mb", C.c_int32),
                 ("qp", C.c_int32), ("qpc", C.c_int32), ("search_range", C.c_int32), ("num_ref", C.c_int32), ("lambda_mf", C.c_int32 * 3),
                 ("lambda_mdfp", C.c_int32), ("max_mvd", C.c_int32), ("mv_limit", C.c_int32 * 4), ("inter_valid", C.c_int32 * 8),
-                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("off4", C.c_int16 * 16 * 2 * 3), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32), ("transform8x8", C.c_int32), ("off8", C.c_int16 * 64 * 2), ("intra8_valid", C.c_int32), ("yuv_format", C.c_int32)]
+                ("intra4_valid", C.c_int32), ("intra16_valid", C.c_int32), ("subpel", C.c_int32), ("off4", C.c_int16 * 16 * 2 * 3), ("start_qp", C.c_int32), ("refbits", C.c_int32 * MAX_REF), ("cabac", C.c_int32), ("search_mode", C.c_int32), ("transform8x8", C.c_int32), ("off8", C.c_int16 * 64 * 2), ("intra8_valid", C.c_int32), ("qpc_cr_delta", C.c_int32), ("yuv_format", C.c_int32)]
 
 
 NO_REF = -(1 << 30)
@@ -494,8 +494,8 @@ assert MB_RECORD.itemsize == 1216
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
-              subpel=1, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None):
-    """inter_valid: enc_mb.valid[0..7] of a P slice (PSliceSkip, PSliceSearch16x16 .. 4x4; default all on).  offsets: None = JM's default quantiser offsets, or the lists of a q_offset.cfg (load_q_offsets) when the sequence has OffsetMatrixPresentFlag = 1"""
+              subpel=1, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0):
+    """qpc: currMB->qpc[0] when the chroma QP offsets are not 0 (default: the table value of qp); qpc_cr_delta: qpc[1] - qpc[0].  inter_valid: enc_mb.valid[0..7] of a P slice (PSliceSkip, PSliceSearch16x16 .. 4x4; default all on).  offsets: None = JM's default quantiser offsets, or the lists of a q_offset.cfg (load_q_offsets) when the sequence has OffsetMatrixPresentFlag = 1"""
     c = MbEncCfg()
     o4, o8 = slice_offsets(slice_type, offsets)
     for pl in range(3):
@@ -513,6 +513,9 @@ def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambd
     c.width, c.height, c.slice_type, c.first_mb, c.num_mb = width, height, slice_type, first_mb, num_mb
     c.qp = qp
     c.qpc = qp if qp < 30 else [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39][qp - 30]
+    if qpc is not None:
+        c.qpc = int(qpc)
+    c.qpc_cr_delta = int(qpc_cr_delta)
     c.search_range, c.num_ref = R, num_ref
     for i in range(3):
         c.lambda_mf[i] = lambda_mf[i]

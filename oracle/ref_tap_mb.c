@@ -45,6 +45,7 @@ typedef struct {
   int32_t chroma2_level[8][17], chroma2_run[8][17];
   uint8_t rec_u2[64], rec_v2[64];
   int32_t yuv_format;
+  int32_t qpc_v;                            /* currMB->qpc[1] (qpc above is qpc[0]) */
 } MBREC;
 #pragma pack(pop)
 
@@ -131,7 +132,7 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
           r.chroma2_level[m * 4 + b4][k] = currSlice->cofAC[5 + 2 * m][b4][0][k];
           r.chroma2_run[m * 4 + b4][k] = currSlice->cofAC[5 + 2 * m][b4][1][k];
         }
-  r.yuv_format = p_Vid->yuv_format;
+  r.yuv_format = p_Vid->yuv_format; r.qpc_v = currMB->qpc[1];
   for (j = 0; j < 16; j++)
     for (i = 0; i < 16; i++) r.rec_y[j * 16 + i] = (uint8_t)p_Vid->enc_picture->imgY[currMB->pix_y + j][currMB->pix_x + i];
   if (p_Vid->yuv_format == YUV420)

@@ -52,6 +52,12 @@ while time.time() - t0 < budget:
                   EPZSSpatialMem=int(rng.integers(0, 2)), EPZSBlockType=int(rng.integers(0, 2)), EPZSAggressiveWindow=int(rng.integers(0, 2)))
     if yuv == 2 and rng.integers(0, 2):
         ov.update(OffsetMatrixPresentFlag=1)
+    if prof >= 100 and rng.integers(0, 3) == 0:               # the High profiles' separate chroma offsets
+        ov.update(CbQPOffset=int(rng.integers(-6, 7)), CrQPOffset=int(rng.integers(-6, 7)))
+    if rng.integers(0, 4) == 0:                               # smaller levels: tighter vertical vector limits (conformance.c:604-631)
+        ov.update(LevelIDC=int(rng.choice([11, 20, 30])))
+    if rng.integers(0, 8) == 0:
+        ov.update(QPISlice=int(rng.choice([0, 1, 50, 51])), QPPSlice=int(rng.choice([0, 2, 49, 51])))
     tmp = tempfile.mkdtemp(prefix="fz_")
     try:
         np.concatenate(synth_motion.motion_clip(sw, sh, nfr, seed, yuv422=yuv == 2)).tofile(os.path.join(tmp, "clip.yuv"))

@@ -68,6 +68,11 @@ CASES = {
     "m3pe": (dict(RDO_OFF, SearchMode="3", SearchRange="8", NumberReferenceFrames="3", FramesToBeEncoded="5", PSliceSearch16x8="0", PSliceSearch8x16="0", PSliceSearch8x4="0", PSliceSearch4x8="0",
                   Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", SliceMode="1", SliceArgument="27", QPISlice="26", QPPSlice="26"), (160, 96), 5, "motion:52"),
     "q1pd": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", PSliceSearch8x16="0", PSliceSearch4x8="0", PSliceSearch4x4="0"), (176, 144), 3, False),
+    # different chroma QP offsets for Cb and Cr (High profile): qpc[0] != qpc[1]
+    "m2cq": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", ProfileIDC="100", Transform8x8Mode="1", SymbolMode="1", CbQPOffset="3", CrQPOffset="-4",
+                  QPISlice="33", QPPSlice="33"), (176, 144), 4, "motion:61"),
+    "m2yc": (dict(RDO_OFF, NumberBFrames="0", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", CbQPOffset="-5", CrQPOffset="2", QPISlice="31", QPPSlice="31"),
+             (176, 144), 4, "motion422:62", "jm_yuv422.cfg"),
     # 4:2:2 (High 4:2:2 profile): 8 x 16 chroma samples per macroblock, the 2x4 chroma DC transform with the quantiser of qpc + 3, vectors of the luma block at the same row
     # BASELINE configs[4] = encoder_yuv422.cfg (CABAC, 8x8 transform on, fast full search SR 32, five references) on its own clip, but for RDO / adaptive rounding / B pictures
     "q5y": (dict(RDO_OFF, NumberBFrames="0"), (176, 144), 3, False, "jm_yuv422.cfg"),
@@ -148,7 +153,7 @@ def run(tag):
                             motion_cost_ref=tap["motion_cost_ref"][:, 1:, :, :].astype(np.int64) if ov.get("SearchMode") == "3" else np.zeros(0, np.int64),
                             motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if sw * sh < 200000 else np.zeros(0, np.int64),
                             md5_264=md5(open(os.path.join(tmp, "o.264"), "rb").read()), md5_recon=md5(open(os.path.join(tmp, "o_rec.yuv"), "rb").read()),
-                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]))
+                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]), qpc_v=int(t0["qpc_v"]))
         print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

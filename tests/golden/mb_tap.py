@@ -17,7 +17,7 @@ TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), 
                 ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,)),
                 ("poc", "<i4"), ("ref_poc", "<i4", (16,)), ("motion_cost_ref", "<i8", (8, 4, 4)),
                 ("luma8_level", "<i4", (4, 65)), ("luma8_run", "<i4", (4, 65)),
-                ("chroma2_level", "<i4", (8, 17)), ("chroma2_run", "<i4", (8, 17)), ("rec_u2", "u1", (64,)), ("rec_v2", "u1", (64,)), ("yuv_format", "<i4")])
+                ("chroma2_level", "<i4", (8, 17)), ("chroma2_run", "<i4", (8, 17)), ("rec_u2", "u1", (64,)), ("rec_v2", "u1", (64,)), ("yuv_format", "<i4"), ("qpc_v", "<i4")])
 
 
 def read(path):

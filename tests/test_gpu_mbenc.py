@@ -53,8 +53,9 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
     for intra in range(2):
         p["q_luma"][0, intra] = pyjmo.qparams_4x4(cfg.qp, intra, list(cfg.off4[0][intra]))
         for uv in range(2):
-            p["q_chroma"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc, intra, list(cfg.off4[1 + uv][intra]))
-            p["q_chroma_dc"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc + 3, intra, list(cfg.off4[1 + uv][intra]))[0]     # 4:2:2: the chroma DC quantiser (qpc + 3)
+            p["q_chroma"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc + uv * cfg.qpc_cr_delta, intra, list(cfg.off4[1 + uv][intra]))
+            p["q_chroma_dc"][0, uv, intra] = pyjmo.qparams_4x4(cfg.qpc + uv * cfg.qpc_cr_delta + 3, intra, list(cfg.off4[1 + uv][intra]))[0]     # 4:2:2: the chroma DC quantiser (qpc + 3)
+    p["qpc_cr_delta"] = cfg.qpc_cr_delta
     p["df_disable_idc"] = disable_idc
     return p
 
@@ -62,9 +63,9 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0):
         self.cabac = cabac
-        self.yuv_format, self.offsets, self.inter_valid = yuv_format, offsets, inter_valid
+        self.yuv_format, self.offsets, self.inter_valid, self.qpc, self.qpc_cr_delta = yuv_format, offsets, inter_valid, qpc, qpc_cr_delta
         self.search_mode, self.epzs = search_mode, dict(epzs or {})
         self.transform8x8 = transform8x8
         import jm_amd.lib as L
@@ -87,7 +88,7 @@ class DevSeqEncoder:
         for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
             cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
-                                  yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=self.inter_valid)
+                                  yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=self.inter_valid, qpc=self.qpc, qpc_cr_delta=self.qpc_cr_delta)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc, self.epzs, 2 * self.npic)
             if timing is not None:
                 J.enable_timing(True)
@@ -128,7 +129,8 @@ def load_case(tag):
                 search_mode={-1: 0, 0: 1, 3: 3}[int(ov.get("SearchMode", -1))], epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)),
                 yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
                 offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None,
-                inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None)
+                inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None,
+                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0)
 
 
 PSLICE_KEYS = ("PSliceSkip", "PSliceSearch16x16", "PSliceSearch16x8", "PSliceSearch8x16", "PSliceSearch8x8", "PSliceSearch8x4", "PSliceSearch4x8", "PSliceSearch4x4")
@@ -166,7 +168,7 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y", "m2pd", "q1pd", "m3pe"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y", "m2pd", "q1pd", "m3pe", "m2cq", "m2yc"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
@@ -181,7 +183,7 @@ def test_encode_slice_equals_the_reference_encoder(tag):
     slices that start mid-row (m3y), QP 12 (m2yq)."""
     c = load_case(tag)
     enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
-                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"])
+                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"], qpc_cr_delta=c["qpc_cr_delta"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     data = clip_bytes(tag, c)
     fs = c["sw"] * c["sh"] * (4 if c["yuv"] == 2 else 3) // 2

@@ -40,7 +40,8 @@ def load_case(tag):
                 epzs={k: int(ov[n]) for k, n in EPZS_KEYS.items() if n in ov}, t8=int(ov.get("Transform8x8Mode", 0)),
                 yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
                 offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None,
-                inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None)
+                inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None,
+                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0)
 
 
 def source_frames(c, tag):
@@ -75,7 +76,7 @@ def source_frames(c, tag):
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
-                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"])
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"], qpc_cr_delta=c["qpc_cr_delta"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -142,6 +143,12 @@ def test_oracle_yuv422_pipeline_equals_the_reference_encoder(tag):
 # partitions switched off (PSliceSearch*): EPZS's block-type predictors read currSlice->all_mv of types that are never searched -- the zeros it was allocated with
 @pytest.mark.parametrize("tag", ["m2pd", "m3pe", "q1pd"])
 def test_oracle_with_partitions_switched_off(tag):
+    run_case(tag)
+
+
+# CbQPOffset != CrQPOffset (High profiles): the two chroma planes are quantised (and loop-filtered) with different QPs; 4:2:0 (m2cq) and 4:2:2 (m2yc)
+@pytest.mark.parametrize("tag", ["m2cq", "m2yc"])
+def test_oracle_with_different_chroma_qps(tag):
     run_case(tag)
 
 
