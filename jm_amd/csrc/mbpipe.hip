@@ -52,6 +52,8 @@ static_assert(sizeof(jmhip_mb_record) == 1216 && sizeof(jmhip_slice_params) == 3
 struct PipeArgs {
   jmhip_slice_params p;
   int W, H, wmb, hmb, cw, ch;
+  unsigned role_perm;                        // role of hardware wave w = nibble w: which chain a wave runs (0-3 the P8x8 sub-modes, 4 16x16 + Intra16x16 + chroma decision, 5 16x8,
+                                             // 6 8x16, 7 the Intra4x4 chain).  Waves w and w + 4 share a SIMD: the pairing decides who competes with the 4x4 chain for issue slots
   int c422;                                  // 4:2:2: chroma planes cw x H, 8 x 16 samples per macroblock (ch = H); else 4:2:0
   int total_mb;                              // macroblocks of the launch (num_slices slices of p.num_mb, cut at the end of the picture)
   int nbands, band_start[9];                 // 8 (or 1): the ticket order is cut into bands of macroblock rows, tickets band_start[b] .. band_start[b + 1] - 1 belong to band b, and

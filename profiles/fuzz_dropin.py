@@ -29,7 +29,9 @@ while time.time() - t0 < budget:
     cabac = int(rng.integers(0, 2))
     prof = 122 if yuv == 2 else (100 if t8 else (77 if cabac else 66))
     sw, sh = 16 * int(rng.integers(3, 12)) - int(rng.choice([0, 0, 2, 8])), 16 * int(rng.integers(3, 9)) - int(rng.choice([0, 0, 2, 6]))
-    nfr = int(rng.integers(3, 6))
+    if rng.integers(0, 12) == 0:                              # now and then a CIF-sized picture
+        sw, sh = 16 * int(rng.integers(16, 23)), 16 * int(rng.integers(12, 19))
+    nfr = int(rng.integers(3, 6)) if rng.integers(0, 10) else int(rng.integers(6, 10))
     sm = int(rng.choice([-1, -1, 0, 3]))
     ov = dict(RDOptimization=0, AdaptiveRounding=0, InputFile="clip.yuv", SourceWidth=sw, SourceHeight=sh, OutputWidth=sw, OutputHeight=sh, FramesToBeEncoded=nfr, YUVFormat=yuv,
               ProfileIDC=prof, LevelIDC=40, SymbolMode=cabac, Transform8x8Mode=t8, SearchMode=sm, SearchRange=int(rng.choice([4, 8, 16, 32])), NumberReferenceFrames=int(rng.integers(1, 6)),
