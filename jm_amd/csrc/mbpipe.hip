@@ -106,7 +106,8 @@ struct Shared {
   int8_t i4_ipm[16], i4_syn[16];
   int16_t i4_lev[16][16];
   u8 i4_rec[256];
-  u8 i4p[16], i4val[44], i4tab[144];
+  u8 i4p[2][16], i4val[2][44], i4tab[144];   // i4p / i4val: per wave of the Intra4x4 chain (two in I slices)
+  int i4prog[2], i4_t1, i4_c1;               // I slices: blocks each of the two Intra4x4 waves has finished (running counts over the launch), the second wave's cost and cbp
   jmhip_qparam q_luma[2][16], q_chroma[2][2][16];   // the slice's quantiser tables (out of the kernel arguments once per workgroup: LDS reads can be batched)
   int i16_cost, i16_mode;
   u8 e16[36];
