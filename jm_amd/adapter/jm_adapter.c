@@ -54,6 +54,7 @@
 #include "intra4x4.h"
 #include "intra8x8.h"
 #include "me_epzs_common.h"
+#include "conformance.h"
 #include "jmhip.h"
 
 #define MAX_SLOTS 20
@@ -1254,11 +1255,15 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     const int R = imax(p->search_range[0], p->search_range[1]);
     const int ox = (2 * R + 3) & ~3;
     P.checked = 1;
+    if (p_Vid->active_sps && p->PicInterlace == FRAME_CODING && p->MbInterlace == FRAME_CODING) update_mv_limits(p_Vid, FALSE);   /* the level's vector limits (conformance.c:604): JM sets them per picture
+                                                                    (image.c:1635), later than the first question about this sequence; frame pictures always get these values */
     if (!G.part_mbpipe) why = "part mbpipe not selected";
     else if (p->rdopt != 0) why = "RDOptimization != 0";
     else if (p_Vid->yuv_format != YUV420 && p_Vid->yuv_format != YUV422) why = "neither 4:2:0 nor 4:2:2";
     else if (p->SearchMode[0] != FULL_SEARCH && p->SearchMode[0] != FAST_FULL_SEARCH && p->SearchMode[0] != EPZS) why = "SearchMode other than -1 (full search), 0 (fast full search) and 3 (EPZS)";
     else if (p->SearchMode[0] == EPZS && (!p->EPZSSubPelGrid || p->EPZSSubPelME != 1 || p->HMEEnable)) why = "EPZS without EPZSSubPelGrid = 1 / EPZSSubPelME = 1, or with HME";
+    else if (p->SearchMode[0] == FAST_FULL_SEARCH && (p_Vid->MaxVmvR[5] - 4 * R < 4 * R || p_Vid->MaxVmvR[4] + 4 * R > -4 * R || p_Vid->MaxHmvR[5] - 4 * R < 4 * R || p_Vid->MaxHmvR[4] + 4 * R > -4 * R))
+      why = "fast full search with a level whose vector limit cuts into the search range (the search centre can leave the sample grid: me_fullfast.c:325-326, and JM then reads a stale pos_00)";
     else if (p->DisableMEPrediction) why = "DisableMEPrediction";
     else if (p->SkipDeBlockNonRef || p->DisposableP) why = "SkipDeBlockNonRef / DisposableP (pictures that are not deblocked stay on the device)";
     else if (p->RDPictureDeblocking || p->RDPictureDecision) why = "RDPictureDecision / RDPictureDeblocking";

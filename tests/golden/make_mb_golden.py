@@ -68,6 +68,11 @@ CASES = {
     "m3pe": (dict(RDO_OFF, SearchMode="3", SearchRange="8", NumberReferenceFrames="3", FramesToBeEncoded="5", PSliceSearch16x8="0", PSliceSearch8x16="0", PSliceSearch8x4="0", PSliceSearch4x8="0",
                   Transform8x8Mode="1", ProfileIDC="100", SymbolMode="1", SliceMode="1", SliceArgument="27", QPISlice="26", QPPSlice="26"), (160, 96), 5, "motion:52"),
     "q1pd": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", PSliceSearch8x16="0", PSliceSearch4x8="0", PSliceSearch4x4="0"), (176, 144), 3, False),
+    # a small level: the vertical vector limit (level 1.1: -256 .. 255 quarter-pels) cuts into the search range; fast full search clips its centre to limit -+ range, which need not be a whole sample
+    "m3fl": (dict(RDO_OFF, SearchMode="0", SearchRange="32", NumberReferenceFrames="3", FramesToBeEncoded="5", LevelIDC="11", QPISlice="27", QPPSlice="27"), (72, 112), 5, "motion:71"),
+    "m3fm": (dict(RDO_OFF, SearchMode="0", SearchRange="16", NumberReferenceFrames="3", FramesToBeEncoded="5", LevelIDC="11", QPISlice="27", QPPSlice="27"), (72, 112), 5, "motion:74"),
+    "m2sl": (dict(RDO_OFF, SearchMode="-1", SearchRange="32", NumberReferenceFrames="2", FramesToBeEncoded="4", LevelIDC="11"), (120, 96), 4, "motion:72"),
+    "m2el": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", FramesToBeEncoded="4", LevelIDC="11"), (120, 96), 4, "motion:73"),
     # different chroma QP offsets for Cb and Cr (High profile): qpc[0] != qpc[1]
     "m2cq": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", ProfileIDC="100", Transform8x8Mode="1", SymbolMode="1", CbQPOffset="3", CrQPOffset="-4",
                   QPISlice="33", QPPSlice="33"), (176, 144), 4, "motion:61"),
@@ -153,7 +158,8 @@ def run(tag):
                             motion_cost_ref=tap["motion_cost_ref"][:, 1:, :, :].astype(np.int64) if ov.get("SearchMode") == "3" else np.zeros(0, np.int64),
                             motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if sw * sh < 200000 else np.zeros(0, np.int64),
                             md5_264=md5(open(os.path.join(tmp, "o.264"), "rb").read()), md5_recon=md5(open(os.path.join(tmp, "o_rec.yuv"), "rb").read()),
-                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]), qpc_v=int(t0["qpc_v"]))
+                            md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]), qpc_v=int(t0["qpc_v"]),
+                            qp_p=int(([int(t["qp"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qp"])])[0]))
         print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

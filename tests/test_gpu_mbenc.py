@@ -63,8 +63,9 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0, qp_p=None):
         self.cabac = cabac
+        self.qp_p = qp if qp_p is None else qp_p
         self.yuv_format, self.offsets, self.inter_valid, self.qpc, self.qpc_cr_delta = yuv_format, offsets, inter_valid, qpc, qpc_cr_delta
         self.search_mode, self.epzs = search_mode, dict(epzs or {})
         self.transform8x8 = transform8x8
@@ -87,7 +88,7 @@ class DevSeqEncoder:
         slices = mbenc_util.slices_of(nmb, self.slice_mbs)
         for sn, (first, num) in enumerate(slices):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
+            cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp if st == 2 else self.qp_p, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
                                   yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=self.inter_valid, qpc=self.qpc, qpc_cr_delta=self.qpc_cr_delta)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc, self.epzs, 2 * self.npic)
             if timing is not None:
@@ -130,7 +131,7 @@ def load_case(tag):
                 yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
                 offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None,
                 inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None,
-                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0)
+                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0, qp_p=int(z["qp_p"]) if "qp_p" in z.files else None)
 
 
 PSLICE_KEYS = ("PSliceSkip", "PSliceSearch16x16", "PSliceSearch16x8", "PSliceSearch8x16", "PSliceSearch8x8", "PSliceSearch8x4", "PSliceSearch4x8", "PSliceSearch4x4")
@@ -168,7 +169,7 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y", "m2pd", "q1pd", "m3pe", "m2cq", "m2yc"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y", "m2pd", "q1pd", "m3pe", "m2cq", "m2yc", "m3fl", "m3fm", "m2sl", "m2el"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).
@@ -183,7 +184,7 @@ def test_encode_slice_equals_the_reference_encoder(tag):
     slices that start mid-row (m3y), QP 12 (m2yq)."""
     c = load_case(tag)
     enc = DevSeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c["cabac"],
-                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"], qpc_cr_delta=c["qpc_cr_delta"])
+                        search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"] if c["qp_p"] in (None, c["qp"]) else None, qpc_cr_delta=c["qpc_cr_delta"], qp_p=c["qp_p"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     data = clip_bytes(tag, c)
     fs = c["sw"] * c["sh"] * (4 if c["yuv"] == 2 else 3) // 2
@@ -536,6 +537,28 @@ def test_encode_slice_rejects_what_it_does_not_cover():
     J4 = L.JmHip(64, 48, search_range=16, num_ref_slots=1, yuv_format=2)
     with pytest.raises(L.JmHipError):
         J4.encode_slice(prm)
+
+
+def test_fast_full_search_is_refused_when_the_level_cuts_into_the_range():
+    """me_fullfast.c:318-326 clips the search centre to limit -+ range after making sure (0,0) is inside; with a vertical limit of 255 quarter-pels (levels 1 / 1b; JM also maps
+    level_idc 11 of the High profiles there) and SearchRange 32 the centre can become 127 -- off the sample grid --, the (0,0) position is then not found (:354-365) and JM uses the
+    pos_00 an EARLIER macroblock left: raster-order state the wavefront cannot reproduce, so the call is refused and the adapter turns such sequences away (found by
+    profiles/fuzz_dropin.py: 3 of 2051 configurations).  SearchRange 16 with the same limits, and level 1.1's own limits (goldens m3fl, m3fm), are served."""
+    import jm_amd.lib as L
+    W, H, tight = 80, 112, (-8192, 8191, -256, 255)
+    clip = synthetic_clip(W, H, 2, 77)
+    J = L.JmHip(W, H, search_range=32, num_ref_slots=2, yuv_format=1)
+    J.set_current_frame(clip[0], W, H)
+    nmb = (W // 16) * (H // 16)
+    J.encode_slice_dev(slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 32, 0, *LAMBDAS[2], level_mv=tight, search_mode=1), 0, [], []))
+    J.deblock_picture_dev(1); J.reference_from_recon(0)
+    J.set_current_frame(clip[1], W, H)
+    with pytest.raises(L.JmHipError, match="cuts into the search range"):
+        J.encode_slice_dev(slice_params(L, pyjmo.mbenc_cfg(W, H, 0, 0, nmb, 28, 32, 1, *LAMBDAS[0], level_mv=tight, search_mode=1), 0, [0], [0]))
+    for R, mode in ((16, 1), (32, 0), (32, 3)):                  # the same limits with SearchRange 16, and with full search / EPZS, are served
+        J.encode_slice_dev(slice_params(L, pyjmo.mbenc_cfg(W, H, 0, 0, nmb, 28, R, 1, *LAMBDAS[0], level_mv=tight, search_mode=mode), 0, [0], [0]))
+    J.synchronize()
+    J.close()
 
 
 def test_random_configurations_vs_oracle():

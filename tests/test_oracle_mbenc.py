@@ -41,7 +41,7 @@ def load_case(tag):
                 yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
                 offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None,
                 inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None,
-                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0)
+                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0, qp_p=int(z["qp_p"]) if "qp_p" in z.files else None)
 
 
 def source_frames(c, tag):
@@ -76,7 +76,7 @@ def source_frames(c, tag):
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
-                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"], qpc_cr_delta=c["qpc_cr_delta"])
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"] if c["qp_p"] in (None, c["qp"]) else None, qpc_cr_delta=c["qpc_cr_delta"], qp_p=c["qp_p"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -143,6 +143,12 @@ def test_oracle_yuv422_pipeline_equals_the_reference_encoder(tag):
 # partitions switched off (PSliceSearch*): EPZS's block-type predictors read currSlice->all_mv of types that are never searched -- the zeros it was allocated with
 @pytest.mark.parametrize("tag", ["m2pd", "m3pe", "q1pd"])
 def test_oracle_with_partitions_switched_off(tag):
+    run_case(tag)
+
+
+# level 1.1: the vertical vector limit (-256 .. 255 quarter-pels) cuts into SearchRange 32 -- full search, fast full search, EPZS
+@pytest.mark.parametrize("tag", ["m3fl", "m3fm", "m2sl", "m2el"])
+def test_oracle_at_a_small_level(tag):
     run_case(tag)
 
 
