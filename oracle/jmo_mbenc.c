@@ -259,7 +259,10 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
 
   if (c->search_mode == 1) {
     /* ---- fast_full_search_motion_estimation me_fullfast.c:618-689 (rdopt == 0): every block of the macroblock is searched around ONE centre per reference,
-     * the rounded 16x16 predictor (setup_fast_full_search :310-328), the (0,0) vector first (:650-657), the max_mvd guard (:638, :671) ---- */
+     * the rounded 16x16 predictor (setup_fast_full_search :310-328), the (0,0) vector first (:650-657), the max_mvd guard (:638, :671).
+     * SCOPE: the centre stays on the sample grid with (0,0) inside the window, i.e. mv_limit[2] + 4 R <= -4 R and mv_limit[3] - 4 R >= 4 R (the same horizontally).  With the limits
+     * of levels 1 / 1b and R = 32 the second clip (:326-327) can leave the centre at 127; JM then finds no (0,0) position (:354-365) and prices the (0,0) vector with the pos_00
+     * an earlier macroblock left behind -- raster-order state this restatement (and the device) does not carry: jmo_encode_slice refuses such a configuration. ---- */
     nb b16[4];
     jmo_mv p16, ctr;
     const int rq = c->search_range << 2, guard = c->max_mvd - 1;
@@ -1046,6 +1049,10 @@ int jmo_encode_slice_ex(const jmo_mbenc_cfg *cfg, jmo_epzs_cfg *ez, const jmo_pe
   int k, n4;
   if (!e) return -1;
   if (cfg->num_ref > JMO_MAX_REF || (cfg->slice_type != 0 && cfg->slice_type != 2)) { free(e); return -2; }
+  if (cfg->search_mode == 1 && cfg->slice_type == 0) {          /* fast full search: see the scope note in block_motion_search */
+    const int rq = cfg->search_range << 2;
+    if (cfg->mv_limit[3] - rq < rq || cfg->mv_limit[2] + rq > -rq || cfg->mv_limit[1] - rq < rq || cfg->mv_limit[0] + rq > -rq) { free(e); return -4; }
+  }
   if (cfg->search_mode == 3 && cfg->slice_type == 0) {
     if (!ez) { free(e); return -3; }
     e->ez = (struct epzs_state *)epzs_new(cfg, ez);

@@ -60,9 +60,16 @@ while time.time() - t0 < budget:
         ov.update(LevelIDC=int(rng.choice([11, 20, 30])))
     if rng.integers(0, 8) == 0:
         ov.update(QPISlice=int(rng.choice([0, 1, 50, 51])), QPPSlice=int(rng.choice([0, 2, 49, 51])))
+    if rng.integers(0, 3) == 0:                               # any search range, more references with the smaller ones, skipped source frames (picture order count distances)
+        ov.update(SearchRange=int(rng.integers(2, 33)))
+    if ov["SearchRange"] <= 16 and rng.integers(0, 4) == 0:
+        ov.update(NumberReferenceFrames=int(rng.integers(5, 9)), FramesToBeEncoded=int(rng.integers(6, 10)))
+    if rng.integers(0, 5) == 0:
+        ov.update(FrameSkip=int(rng.integers(1, 3)))
     tmp = tempfile.mkdtemp(prefix="fz_")
     try:
-        np.concatenate(synth_motion.motion_clip(sw, sh, nfr, seed, yuv422=yuv == 2)).tofile(os.path.join(tmp, "clip.yuv"))
+        nsrc = (int(ov["FramesToBeEncoded"]) - 1) * (1 + int(ov.get("FrameSkip", 0))) + 1
+        np.concatenate(synth_motion.motion_clip(sw, sh, nsrc, seed, yuv422=yuv == 2)).tofile(os.path.join(tmp, "clip.yuv"))
         shutil.copyfile(os.path.join(G, "q_offset.cfg"), os.path.join(tmp, "q_offset.cfg"))
         res = []
         for exe, tag in ((CPU, "c"), (HIP, "h")):
