@@ -598,7 +598,8 @@ typedef struct {
                                    picture), same parameters, slice_nr counting up -- SliceMode 1 pictures: the slices' wavefronts run side by side */
   int32_t symbol_mode;          /* currSlice->symbol_mode: 0 = CAVLC (levels clamped to CAVLC_LEVEL_LIMIT = 2063: quant4x4_normal.c:84, :160, :233, quantChroma_normal.c:69), 1 = CABAC (no clamp) */
   int32_t search_mode;          /* 0: full_search_motion_estimation (JM's SearchMode -1); 1: fast_full_search_motion_estimation (SearchMode 0, me_fullfast.c:618: one search
-                                   centre per macroblock and reference, the (0,0) vector first; RestrictSearchRange 2); 3: EPZS (SearchMode 3) with EPZSSubPelGrid = 1 and EPZSSubPelME = 1,
+                                   centre per macroblock and reference, the (0,0) vector first; RestrictSearchRange 2; refused when mv_limit cuts into the range -- mv_limit[3] - 4 R < 4 R etc.: JM's
+                                   centre then leaves the sample grid and it reads the pos_00 an earlier macroblock left, me_fullfast.c:326-327, :354-365); 3: EPZS (SearchMode 3) with EPZSSubPelGrid = 1 and EPZSSubPelME = 1,
                                    the shipped settings: EPZS_integer_motion_estimation lencod/src/me_epzs_int.c:42, its sub-macroblock variant :437,
                                    EPZS_sub_pel_motion_estimation me_epzs_sub.c:30 (start_qp must be 1) */
   int32_t qpc_cr_delta;         /* currMB->qpc[1] - currMB->qpc[0]: not 0 when CrQPOffset != CbQPOffset (High profiles); q_chroma[1] / q_chroma_dc[1] are the Cr tables at that QP */
