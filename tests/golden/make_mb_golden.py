@@ -73,6 +73,10 @@ CASES = {
     "m3fm": (dict(RDO_OFF, SearchMode="0", SearchRange="16", NumberReferenceFrames="3", FramesToBeEncoded="5", LevelIDC="11", QPISlice="27", QPPSlice="27"), (72, 112), 5, "motion:74"),
     "m2sl": (dict(RDO_OFF, SearchMode="-1", SearchRange="32", NumberReferenceFrames="2", FramesToBeEncoded="4", LevelIDC="11"), (120, 96), 4, "motion:72"),
     "m2el": (dict(RDO_OFF, SearchMode="3", SearchRange="32", NumberReferenceFrames="2", FramesToBeEncoded="4", LevelIDC="11"), (120, 96), 4, "motion:73"),
+    # EPZS at SearchRange 2: EPZSWindowPredictorInit has no level to fill, searchPoints stays -1, and EPZSWindowPredictors -- adding it to the count -- drops the predictor before it
+    "m2es": (dict(RDO_OFF, SearchMode="3", SearchRange="2", NumberReferenceFrames="2", FramesToBeEncoded="4"), (176, 144), 4, "motion:81"),
+    "m5es": (dict(RDO_OFF, SearchMode="3", SearchRange="2", NumberReferenceFrames="5", FramesToBeEncoded="6", EPZSPattern="4", EPZSDualRefinement="2", EPZSAggressiveWindow="1",
+                  QPISlice="30", QPPSlice="30"), (128, 64), 6, "motion:82"),
     # different chroma QP offsets for Cb and Cr (High profile): qpc[0] != qpc[1]
     "m2cq": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", ProfileIDC="100", Transform8x8Mode="1", SymbolMode="1", CbQPOffset="3", CrQPOffset="-4",
                   QPISlice="33", QPPSlice="33"), (176, 144), 4, "motion:61"),

@@ -169,7 +169,8 @@ def frame_times(stdout):
                                            ("q5y", 297), ("q2yv", 297), ("m3y", 650), ("m2yq", 396),                   # 4:2:2 (encoder_yuv422.cfg: BASELINE configs[4] with RDO off, P pictures only)
                                            ("m2pd", 396), ("m3pe", 300), ("q1pd", 297),                               # partitions switched off (PSliceSearch*)
                                            ("m2cq", 396), ("m2yc", 396),                                               # CbQPOffset != CrQPOffset
-                                           ("m3fl", 175), ("m3fm", 175), ("m2sl", 192), ("m2el", 192)])                              # level 1.1
+                                           ("m3fl", 175), ("m3fm", 175), ("m2sl", 192), ("m2el", 192),                               # level 1.1
+                                           ("m2es", 396), ("m5es", 192)])                                              # EPZS at SearchRange 2
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction

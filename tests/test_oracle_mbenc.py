@@ -152,6 +152,12 @@ def test_oracle_at_a_small_level(tag):
     run_case(tag)
 
 
+# EPZS at SearchRange 2: the window predictor set is empty and its searchPoints of -1 takes the last predictor before it off the list (me_epzs_common.c:343-414, :1661-1673)
+@pytest.mark.parametrize("tag", ["m2es", "m5es"])
+def test_oracle_epzs_at_search_range_two(tag):
+    run_case(tag)
+
+
 # CbQPOffset != CrQPOffset (High profiles): the two chroma planes are quantised (and loop-filtered) with different QPs; 4:2:0 (m2cq) and 4:2:2 (m2yc)
 @pytest.mark.parametrize("tag", ["m2cq", "m2yc"])
 def test_oracle_with_different_chroma_qps(tag):
