@@ -1264,6 +1264,8 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->SearchMode[0] == EPZS && (!p->EPZSSubPelGrid || p->EPZSSubPelME != 1 || p->HMEEnable)) why = "EPZS without EPZSSubPelGrid = 1 / EPZSSubPelME = 1, or with HME";
     else if (p->SearchMode[0] == FAST_FULL_SEARCH && (p_Vid->MaxVmvR[5] - 4 * R < 4 * R || p_Vid->MaxVmvR[4] + 4 * R > -4 * R || p_Vid->MaxHmvR[5] - 4 * R < 4 * R || p_Vid->MaxHmvR[4] + 4 * R > -4 * R))
       why = "fast full search with a level whose vector limit cuts into the search range (the search centre can leave the sample grid: me_fullfast.c:325-326, and JM then reads a stale pos_00)";
+    else if (p_Vid->MaxVmvR[4] > -4 * R || p_Vid->MaxVmvR[5] < 4 * R || p_Vid->MaxHmvR[4] > -4 * R || p_Vid->MaxHmvR[5] < 4 * R)
+      why = "vector limits (UseMVLimits / the level) narrower than the search range";      /* jmhip_encode_slice refuses such a slice */
     else if (p->DisableMEPrediction) why = "DisableMEPrediction";
     else if (p->SkipDeBlockNonRef || p->DisposableP) why = "SkipDeBlockNonRef / DisposableP (pictures that are not deblocked stay on the device)";
     else if (p->RDPictureDeblocking || p->RDPictureDecision) why = "RDPictureDecision / RDPictureDeblocking";
