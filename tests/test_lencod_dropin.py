@@ -439,3 +439,31 @@ def test_random_rdo_off_configurations_equal_cpu_jm():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_dropin.py"), "40", "777000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and " 0 NOT byte-identical" in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_vector_limits_below_the_search_range_go_to_jms_own_function(tmp_path):
+    """UseMVLimits with SetMVXLimit 8 under SearchRange 32 (conformance.c:615-630): jmhip_encode_slice refuses limits narrower than the search range, so the adapter must turn the
+    sequence away BEFORE the first slice (pipe_config_ok) -- JM's own encode_one_macroblock_low runs, the output equals CPU JM's.  (The drop-in used to exit here: found by
+    profiles/fuzz_dropin.py's seed 500000.)"""
+    import sys
+    import numpy as np
+    sys.path.insert(0, G)
+    import synth_motion
+    cpu = os.path.join(ROOT, "oracle", "_ref", "lencod.exe")
+    if not os.path.exists(EXE) or not os.path.exists(cpu):
+        pytest.fail("oracle/_ref/lencod_hip.exe / lencod.exe missing")
+    sw, sh = 96, 80
+    np.concatenate(synth_motion.motion_clip(sw, sh, 3, 500000)).tofile(str(tmp_path / "clip.yuv"))
+    ov = dict(RDOptimization=0, AdaptiveRounding=0, InputFile="clip.yuv", SourceWidth=sw, SourceHeight=sh, OutputWidth=sw, OutputHeight=sh, FramesToBeEncoded=3, SearchMode=-1, SearchRange=32,
+              NumberReferenceFrames=2, NumberBFrames=0, UseMVLimits=1, SetMVXLimit=8, SetMVYLimit=512)
+    out = {}
+    for exe, tag in ((cpu, "c"), (EXE, "h")):
+        args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+        for k, v in dict(ov, OutputFile=f"{tag}.264", ReconFile=f"{tag}.yuv", TraceFile="/dev/null").items():
+            args += ["-p", f"{k}={v}"]
+        r = subprocess.run(args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+        out[tag] = (md5(str(tmp_path / f"{tag}.264")), md5(str(tmp_path / f"{tag}.yuv")), r.stderr.decode(errors="replace"))
+    assert out["c"][:2] == out["h"][:2]
+    assert "macroblock pipeline not used (vector limits" in out["h"][2], out["h"][2][-1500:]
