@@ -23,9 +23,11 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     sm = int(rng.choice([0, 0, 1, 3, 3]))                     # pyjmo search_mode: 0 / -1 full search, 1 fast full search, 3 EPZS
     R = int(rng.choice([4, 8, 16, 32]))
-    big = R == 32 and sm != 3
+    if seed >= 600000 and rng.integers(0, 3) == 0:           # any range (2 is where EPZS's window predictor set is empty: searchPoints -1)
+        R = int(rng.integers(2, 33))
+    big = R > 16 and sm != 3
     W = 16 * int(rng.integers(2, 9 if big else 17)); H = 16 * int(rng.integers(2, 7 if big else 12))
-    num_ref = int(rng.integers(1, 5 if R == 32 else 6))
+    num_ref = int(rng.integers(1, 5 if R > 16 else 6))
     qp = int(rng.integers(8, 46))
     t8, yuv, cabac = int(rng.integers(0, 2)), int(rng.choice([1, 1, 2])), int(rng.integers(0, 2))
     nmb = (W // 16) * (H // 16)
