@@ -80,6 +80,9 @@ CASES = {
     # different chroma QP offsets for Cb and Cr (High profile): qpc[0] != qpc[1]
     "m2cq": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", ProfileIDC="100", Transform8x8Mode="1", SymbolMode="1", CbQPOffset="3", CrQPOffset="-4",
                   QPISlice="33", QPPSlice="33"), (176, 144), 4, "motion:61"),
+    # ... with QPPSlice != QPISlice as well: the P pictures' chroma QPs are not the I picture's (the harness takes both from the tap: qpc_p / qpc_v_p)
+    "m2cp": (dict(RDO_OFF, SearchMode="-1", SearchRange="8", NumberReferenceFrames="2", FramesToBeEncoded="4", ProfileIDC="100", Transform8x8Mode="1", SymbolMode="0", CbQPOffset="5", CrQPOffset="-3",
+                  QPISlice="27", QPPSlice="34"), (176, 144), 4, "motion:63"),
     "m2yc": (dict(RDO_OFF, NumberBFrames="0", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="4", CbQPOffset="-5", CrQPOffset="2", QPISlice="31", QPPSlice="31"),
              (176, 144), 4, "motion422:62", "jm_yuv422.cfg"),
     # 4:2:2 (High 4:2:2 profile): 8 x 16 chroma samples per macroblock, the 2x4 chroma DC transform with the quantiser of qpc + 3, vectors of the luma block at the same row
@@ -163,7 +166,9 @@ def run(tag):
                             motion_cost=tap["motion_cost"][:, 1:, :].astype(np.int64) if sw * sh < 200000 else np.zeros(0, np.int64),
                             md5_264=md5(open(os.path.join(tmp, "o.264"), "rb").read()), md5_recon=md5(open(os.path.join(tmp, "o_rec.yuv"), "rb").read()),
                             md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]), qpc_v=int(t0["qpc_v"]),
-                            qp_p=int(([int(t["qp"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qp"])])[0]))
+                            qp_p=int(([int(t["qp"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qp"])])[0]),
+                            qpc_p=int(([int(t["qpc"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qpc"])])[0]),      # the P pictures' chroma QPs (QPPSlice != QPISlice with chroma offsets)
+                            qpc_v_p=int(([int(t["qpc_v"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qpc_v"])])[0]))
         print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

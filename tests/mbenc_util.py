@@ -44,7 +44,7 @@ def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_
 class SeqEncoder:
     """IPPP with num_ref sliding-window references, RDOptimization = 0, AdaptiveRounding = 0 (the scope of jmo_mbenc.c)."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0, qp_p=None):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0, qp_p=None, qpc_p=None, qpc_cr_delta_p=None):
         """lambdas[slice_type] = (lambda_mf[3], lambda_mdfp): JM's own tables (double arithmetic, never recomputed).
         search_mode 3 = EPZS with the switches in `epzs` (defaults: the shipped .cfg files', pyjmo.EPZS_DEFAULTS)."""
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
@@ -55,6 +55,7 @@ class SeqEncoder:
         self.yuv_format = yuv_format         # 1: 4:2:0, 2: 4:2:2
         self.qp_p = qp if qp_p is None else qp_p             # QPPSlice when it differs from QPISlice
         self.qpc, self.qpc_cr_delta = qpc, qpc_cr_delta     # chroma QPs when CbQPOffset / CrQPOffset are not 0
+        self.qpc_p, self.qpc_cr_delta_p = (qpc, qpc_cr_delta) if qpc_p is None else (qpc_p, qpc_cr_delta_p)      # ... of the P pictures, when QPPSlice differs from QPISlice as well
         self.inter_valid = inter_valid       # enc_mb.valid[0..7] of P slices (None: all on)
         self.offsets = offsets               # None, or pyjmo.load_q_offsets(q_offset.cfg) with OffsetMatrixPresentFlag = 1
         self.refs = []         # most recent first: (RefPic, (u, v), picture id, (mv, refpoc) per 4x4 block of the stored picture)
@@ -75,7 +76,7 @@ class SeqEncoder:
         qpc = None
         for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
             lam_mf, lam_md = self.lambdas[st]
-            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp if st == 2 else self.qp_p, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8, yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=self.inter_valid, qpc=self.qpc, qpc_cr_delta=self.qpc_cr_delta)
+            cfg = pyjmo.mbenc_cfg(W, H, st, first, num, self.qp if st == 2 else self.qp_p, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8, yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=self.inter_valid, qpc=self.qpc if st == 2 else self.qpc_p, qpc_cr_delta=self.qpc_cr_delta if st == 2 else self.qpc_cr_delta_p)
             qpc = cfg.qpc
             ez = None
             if self.search_mode == 3 and st == 0:       # picture order counts: 2 per frame (IPPP, PicOrderCntType 0)
@@ -89,7 +90,7 @@ class SeqEncoder:
                 recs[first:first + num] = res
             slice_nr[first:first + num] = sn
         pre = [p.copy() for p in pic.rec]
-        mbs, mot = db_side_info(recs, slice_nr, st, self.qp if st == 2 else self.qp_p, (qpc, qpc + self.qpc_cr_delta), W, H, [r[2] for r in self.refs[:nref]] or [0], self.disable_idc)
+        mbs, mot = db_side_info(recs, slice_nr, st, self.qp if st == 2 else self.qp_p, (qpc, qpc + (self.qpc_cr_delta if st == 2 else self.qpc_cr_delta_p)), W, H, [r[2] for r in self.refs[:nref]] or [0], self.disable_idc)
         y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], self.yuv_format, mbs, mot)
         refpoc = np.full(pic.ref_idx.shape, pyjmo.NO_REF, np.int32)     # the stored picture's motion, as EPZSSliceInit of later pictures reads it
         for k, r in enumerate(self.refs[:nref]):

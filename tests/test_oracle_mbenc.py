@@ -41,7 +41,8 @@ def load_case(tag):
                 yuv=int(z["yuv_format"]) if "yuv_format" in z.files else 1,
                 offsets=pyjmo.load_q_offsets(os.path.join(G, "q_offset.cfg")) if ov.get("OffsetMatrixPresentFlag", "0") == "1" else None,
                 inter_valid=[int(ov.get(k, 1)) for k in PSLICE_KEYS] if any(k in ov for k in PSLICE_KEYS) else None,
-                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0, qp_p=int(z["qp_p"]) if "qp_p" in z.files else None)
+                qpc=int(z["qpc"]), qpc_cr_delta=(int(z["qpc_v"]) - int(z["qpc"])) if "qpc_v" in z.files else 0, qp_p=int(z["qp_p"]) if "qp_p" in z.files else None,
+                qpc_p=int(z["qpc_p"]) if "qpc_p" in z.files else None, qpc_cr_delta_p=(int(z["qpc_v_p"]) - int(z["qpc_p"])) if "qpc_p" in z.files else None)
 
 
 def source_frames(c, tag):
@@ -76,7 +77,7 @@ def source_frames(c, tag):
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
-                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"] if c["qp_p"] in (None, c["qp"]) else None, qpc_cr_delta=c["qpc_cr_delta"], qp_p=c["qp_p"])
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"], qpc=c["qpc"] if c["qp_p"] in (None, c["qp"]) or c["qpc_p"] is not None else None, qpc_cr_delta=c["qpc_cr_delta"], qp_p=c["qp_p"], qpc_p=c["qpc_p"], qpc_cr_delta_p=c["qpc_cr_delta_p"])
     nmb = (c["W"] // 16) * (c["H"] // 16)
     z = c["z"]
     for n, cur in enumerate(source_frames(c, tag)):
@@ -159,7 +160,7 @@ def test_oracle_epzs_at_search_range_two(tag):
 
 
 # CbQPOffset != CrQPOffset (High profiles): the two chroma planes are quantised (and loop-filtered) with different QPs; 4:2:0 (m2cq) and 4:2:2 (m2yc)
-@pytest.mark.parametrize("tag", ["m2cq", "m2yc"])
+@pytest.mark.parametrize("tag", ["m2cq", "m2yc", "m2cp"])
 def test_oracle_with_different_chroma_qps(tag):
     run_case(tag)
 
