@@ -40,8 +40,8 @@ G2R_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", 
              "NumberReferenceFrames=1", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
 G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's .264 for two frames of the clip with these flags
 # HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
-# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v7_kernel_stats.md)
-PIPE_TRAFFIC_BYTES = 135303883            # 1.43 x the algorithmic bytes (DESIGN.md section 0 "Scratch and traffic")
+# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v8_kernel_stats.md)
+PIPE_TRAFFIC_BYTES = 140176272            # 1.48 x the algorithmic bytes (DESIGN.md section 0 "Scratch and traffic")
 
 
 def synth_luma(n_frames, seed=1234):
@@ -683,7 +683,7 @@ def main():
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
-                "traffic_source": "profiles/r03_v7_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
+                "traffic_source": "profiles/r03_v8_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
                 "abs_diff_per_s_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 148.4e12, 5),
                 "critical_path": {"steps": W // 16 + 2 * (H // 16 - 1), "us_per_step": round(pipe_ms * 1e3 / (W // 16 + 2 * (H // 16 - 1)), 1),
                                   "note": "a macroblock waits for its left and upper-right neighbours' vectors: the picture is a chain of mb_w + 2 (mb_h - 1) "
@@ -692,7 +692,7 @@ def main():
                 "note": "a dependency (latency) bound wavefront (x + 2y: at most 60 of 8160 macroblocks in flight at 1080p, 27 on average), not an HBM stream: frac prices the "
                         "algorithmic bytes against 8 TB/s as the contract asks; valu_frac_jm_equivalent counts every candidate JM's full search visits -- the device "
                         "skips the ones JM's own cost bound excludes, so the abs-diffs really issued are fewer (profiles/prof_mbpipe.py mode 11 counts them) -- over the "
-                        "measured v_sad_u8 peak of 148.4 T/s (profiles/r01_valu_rates.txt); traffic is 1.43 times the algorithmic bytes (it was 10.5 times with 256 workgroups, 768 B of scratch per lane and every XCD "
+                        "measured v_sad_u8 peak of 148.4 T/s (profiles/r01_valu_rates.txt); traffic is 1.48 times the algorithmic bytes (it was 10.5 times with 256 workgroups, 768 B of scratch per lane and every XCD "
                         "reading every row of the sub-pel planes).  DESIGN.md sections 0, 4"}
         out = {
             "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",

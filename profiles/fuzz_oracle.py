@@ -21,6 +21,11 @@ def config(seed):
     prof = 122 if yuv == 2 else (100 if t8 else (77 if cabac else 66))
     sw, sh = 16 * int(rng.integers(3, 12)) - int(rng.choice([0, 0, 2, 8])), 16 * int(rng.integers(3, 9)) - int(rng.choice([0, 0, 2, 6]))
     nfr = int(rng.integers(3, 6))
+    if seed >= 800000 and rng.integers(0, 5) == 0:           # now and then a CIF-sized picture or a longer sequence (all five references in use)
+        if rng.integers(0, 2):
+            sw, sh = 16 * int(rng.integers(16, 23)), 16 * int(rng.integers(12, 19))
+        else:
+            nfr = int(rng.integers(6, 10))
     sm = int(rng.choice([-1, -1, 0, 3, 3]))
     R = int(rng.choice([4, 8, 16, 32])) if rng.integers(0, 3) else int(rng.integers(2, 33))
     qp = int(rng.integers(10, 45))
