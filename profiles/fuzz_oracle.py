@@ -44,6 +44,9 @@ def config(seed):
         ov.update(CbQPOffset=int(rng.integers(-6, 7)), CrQPOffset=int(rng.integers(-6, 7)))
     if sm != 0 and rng.integers(0, 4) == 0:
         ov.update(LevelIDC=int(rng.choice([11, 20, 30])))
+    if seed >= 900000 and rng.integers(0, 3) == 0:           # the loop filter switched off / kept inside the slices (as golden q4s)
+        d = int(rng.choice([1, 2]))
+        ov.update(DFParametersFlag=1, DFDisableRefISlice=d, DFDisableNRefISlice=d, DFDisableRefPSlice=d, DFDisableNRefPSlice=d)
     clip = ("motion422:" if yuv == 2 else "motion:") + str(seed)
     case = ({k: str(v) for k, v in ov.items()}, (sw, sh), nfr, clip)
     return case + (("jm_yuv422.cfg",) if yuv == 2 else ())
