@@ -31,6 +31,13 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
+// The four kernel instances are compiled as separate translation units (jm_amd/build.py: -DMBPIPE_PART=0..3, a kernel each; part 4 = the host side, which
+// only declares them): one hipcc process per kernel instead of one for all four -- minutes of build time, nothing else.  Without the macro: one unit.
+#ifndef MBPIPE_PART
+#define MBPIPE_PART -1
+#endif
+#define MBPIPE_HOST (MBPIPE_PART == -1 || MBPIPE_PART == 4)
+
 #define MB_THREADS 512
 #define MAXC 0x7fffffff
 #define EDGE_WORDS 19                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
