@@ -48,6 +48,16 @@ typedef uint8_t u8;
 
 struct __attribute__((packed)) U32un { u32 v; };
 __device__ __forceinline__ u32 ldu32(const u8 *p) { return ((const U32un *)p)->v; }
+// Samples of a reference picture (the sixteen quarter-pel planes, the chroma planes).  With pictures in flight side by side (jmhip_seq_*) another workgroup of another
+// launch may have written them microseconds ago, write-through: they are read with sc1 loads (served by the L2 but never by this compute unit's L1, and coherent with
+// the other XCDs' write-through stores -- MI355X guide, inter-workgroup visibility), the same form the edge records use.  Any byte alignment, like ldu32.
+#ifdef JMHIP_REF_PLAIN                                           // A/B aid: plain loads (valid only when every reference is complete before the launch)
+__device__ __forceinline__ u32 ldref32(const u8 *p) { return ((const U32un *)p)->v; }
+__device__ __forceinline__ u32 ldref8(const u8 *p) { return *p; }
+#else
+__device__ __forceinline__ u32 ldref32(const u8 *p) { return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 ldref8(const u8 *p) { return (u32)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 __device__ __forceinline__ int clampi3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int mvx(int p) { return (int)(int16_t)(p & 0xffff); }
 __device__ __forceinline__ int mvy(int p) { return p >> 16; }
@@ -676,7 +686,7 @@ __device__ __forceinline__ void ref_rows4(const PipeArgs &A, int ref, int qx, in
   const u32 off = (u32)((qy & 3) * 4 + (qx & 3)) * (u32)A.plane_stride + (u32)(iy + JMHIP_PAD_Y) * (u32)A.ref_pitch + (u32)(ix + JMHIP_PAD_X);
   const u8 *p = A.ref_y[ref];
 #pragma unroll
-  for (int j = 0; j < 4; j++) r[j] = ldu32(p + (off + (u32)j * (u32)A.ref_pitch));
+  for (int j = 0; j < 4; j++) r[j] = ldref32(p + (off + (u32)j * (u32)A.ref_pitch));
 }
 
 // spiral positions 0..8 (mv_search.c:405-442): {0,0}, {0,-1}, {0,1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {1,1} as two packed constants (a table in
@@ -855,7 +865,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     const u8 *p = A.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + by) * A.ref_pitch + ix + JMHIP_PAD_X + bx;
     u32 r[4], o[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { r[j] = ldu32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
+    for (int j = 0; j < 4; j++) { r[j] = ldref32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
     int v = lane < 16 ? satd4_rows(o, r) : 0;
     v = rfl(group_sum(v, 16));
     if (T8) {                                                  // GetSkipCostMB with Transform8x8Mode: distortion8x8 of the four 8x8 blocks of the 16x16 prediction (one origin)
@@ -864,7 +874,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
       const u8 *p8 = A.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + y8) * A.ref_pitch + ix + JMHIP_PAD_X + x8;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const u32 r0 = ldu32(p8 + (long)j * A.ref_pitch), r1 = ldu32(p8 + (long)j * A.ref_pitch + 4), o0 = S.cur_y[(y8 + j) * 4 + (x8 >> 2)], o1 = S.cur_y[(y8 + j) * 4 + (x8 >> 2) + 1];
+        const u32 r0 = ldref32(p8 + (long)j * A.ref_pitch), r1 = ldref32(p8 + (long)j * A.ref_pitch + 4), o0 = S.cur_y[(y8 + j) * 4 + (x8 >> 2)], o1 = S.cur_y[(y8 + j) * 4 + (x8 >> 2) + 1];
 #pragma unroll
         for (int i = 0; i < 4; i++) { d[8 * j + i] = (int)((o0 >> (8 * i)) & 255) - (int)((r0 >> (8 * i)) & 255); d[8 * j + 4 + i] = (int)((o1 >> (8 * i)) & 255) - (int)((r1 >> (8 * i)) & 255); }
       }
