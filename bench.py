@@ -73,7 +73,8 @@ def write_yuv(path, n_frames, seed=1234):
     sm = sm[:H_SRC + 64, :W + 64]
     with open(path, "wb") as f:
         for n in range(n_frames):
-            dx, dy = 3 * n, 2 * n
+            m = n % 42 if n % 42 <= 21 else 42 - n % 42            # Appendix A's pan for the first 22 frames (all that G2 / G4 and the goldens use); longer clips pan back and forth
+            dx, dy = 3 * m, 2 * m
             y = sm[dy:dy + H_SRC, dx:dx + W] + rng.normal(0, 2, size=(H_SRC, W))
             y = np.clip(np.rint(y), 0, 255).astype(np.uint8)
             u = np.clip(np.rint(128 + 0.25 * (y[::2, ::2].astype(np.float32) - 128)), 0, 255).astype(np.uint8)

@@ -649,6 +649,44 @@ int jmhip_deblock_picture_dev(jmhip_ctx *ctx, int32_t direct_8x8_inference);
 int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
 
 /* ------------------------------------------------------------------------------------------
+ * Consecutive pictures of ONE sequence in flight side by side
+ *
+ * JM codes a sequence picture after picture on one thread: code_a_picture (lencod/src/image.c:1183), then DeblockFrame over the whole picture (:236), then
+ * UnifiedOneForthPix (:2187, getSubImagesLuma) when the picture enters the DPB, then the next picture.  What picture n + 1 needs of picture n is local: macroblock
+ * (X, r) reads reference samples within 2 SearchRange (+ the sub-pel taps) of itself, and DeblockMb / the six-tap stencil of a macroblock are final as soon as its
+ * right and lower neighbours are filtered.  So with IPPP coding, RDOptimization 0 and no rate control -- where nothing but the reference picture flows from one
+ * picture to the next -- the pictures can follow each other at a distance of a few macroblock diagonals instead of a whole picture, every record and every sample
+ * as JM leaves them.  (JM itself has no such mode; the hand-over is jm_amd/csrc/mbpipe_post.inc.)
+ *
+ * jmhip_seq_open gives the context `depth` entries (1 .. 8): a source picture, records, loop-filter side information and a HIP stream each.  A picture is
+ *   jmhip_seq_set_frame[_dev](entry, ...)      the source picture, as jmhip_set_current_frame[_dev]
+ *   jmhip_seq_encode(entry, prm, out_slot, ..) the launch: jmhip_encode_slice_dev + jmhip_deblock_picture_dev + jmhip_reference_from_recon(out_slot) in one, asynchronous;
+ *                                              a reference slot (prm->ref_slot[]) that an earlier jmhip_seq_encode is still writing is followed macroblock by macroblock
+ *   jmhip_seq_record(entry, mb_addr, &rec)     (to_host != 0) the record of one macroblock as soon as it is complete in pinned host memory, as jmhip_slice_record
+ *   jmhip_seq_wait(entry)                      the picture is done: records (jmhip_seq_records[_dev]), the filtered reconstruction and the sub-pel planes of out_slot
+ *                                              (jmhip_seq_recon_dev / jmhip_seq_get_recon, jmhip_subplanes_dev); reports the launch's errors
+ * The caller deals the pictures to the entries in turn (picture k -> entry k % depth) and the reconstructions to slots that no picture in flight refers to
+ * (num_ref + depth slots in turn always do; a conflicting launch is simply held back until the readers are done).  An entry's buffers -- its records among them --
+ * are reused by the entry's next jmhip_seq_set_frame / jmhip_seq_encode.
+ * Scope: what jmhip_encode_slice_dev accepts with search_mode 0 or 1 (the full searches: their reach is bounded by 2 SearchRange), one slice covering the
+ * whole picture.  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
+ * after jmhip_seq_wait of the entry that wrote them, or after jmhip_synchronize).
+ * ------------------------------------------------------------------------------------------ */
+int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture /* 0: 256 / depth, at most 80; always cut to 248 / (depth - 1), so that the oldest picture in flight can never be
+                   kept off the chip by the workgroups of later ones waiting for it.  HIP serves a process's streams from GPU_MAX_HW_QUEUES hardware queues (default 4): with
+                   more pictures in flight than that, set GPU_MAX_HW_QUEUES = 2 * depth in the environment before HIP starts, or the launches take turns */);
+int jmhip_seq_close(jmhip_ctx *ctx);
+int jmhip_seq_set_frame(jmhip_ctx *ctx, int32_t entry, const uint8_t *raw, int32_t src_w, int32_t src_h);
+int jmhip_seq_set_frame_dev(jmhip_ctx *ctx, int32_t entry, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
+int jmhip_seq_encode(jmhip_ctx *ctx, int32_t entry, const jmhip_slice_params *prm, int32_t out_slot, int32_t direct_8x8_inference, int32_t to_host);
+int jmhip_seq_record(jmhip_ctx *ctx, int32_t entry, int32_t mb_addr, const jmhip_mb_record **rec);
+int jmhip_seq_wait(jmhip_ctx *ctx, int32_t entry);
+int jmhip_seq_records(jmhip_ctx *ctx, int32_t entry, jmhip_mb_record *out /* host, the launch's num_mb records */);
+int jmhip_seq_records_dev(jmhip_ctx *ctx, int32_t entry, jmhip_mb_record **d_records);
+int jmhip_seq_recon_dev(jmhip_ctx *ctx, int32_t slot, uint8_t **d_y, int32_t *pitch_y, uint8_t **d_u, uint8_t **d_v, int32_t *pitch_c);
+int jmhip_seq_get_recon(jmhip_ctx *ctx, int32_t slot, uint16_t *y, int32_t pitch_y, uint16_t *u, uint16_t *v, int32_t pitch_c);   /* as imgpel, after jmhip_seq_wait */
+
+/* ------------------------------------------------------------------------------------------
  * Timing helper: elapsed milliseconds of the last `_dev` launch of each kind, measured with
  * hipEvents on the context's stream (bench.py uses it for the roofline object).
  * kind: 0 subplanes, 1 me_fullsearch, 2 me_subpel, 3 tq, 4 deblock, 5 encode_slice.

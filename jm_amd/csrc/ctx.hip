@@ -187,7 +187,9 @@ extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
 {
   if (!ctx) return JMHIP_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  int r = jmhip_check_job_error(ctx);
+  int r = jmhip_seq_sync_all(ctx);
+  if (r) return r;
+  r = jmhip_check_job_error(ctx);
   if (r) return r;
   if ((r = jmhip_check_mb_error(ctx))) return r;
   return jmhip_check_deblock_error(ctx);
@@ -253,6 +255,7 @@ extern "C" int jmhip_set_reference_dev(jmhip_ctx *ctx, int32_t slot, const uint8
 {
   if (!ctx || !d_luma || slot < 0 || slot >= ctx->cfg.num_ref_slots || pitch_bytes < ctx->W)
     return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_dev: bad argument") : JMHIP_EINVAL;
+  if (ctx->seq) { (void)jmhip_seq_sync_all(ctx); ctx->slot_entry[slot] = -1; }      // no picture in flight reads or writes the slot any more
   jmhip_mb_slot_motion_reset(ctx, slot);
   return jmhip_launch_subplanes(ctx, d_luma, pitch_bytes, ctx->d_sub[slot]);
 }
@@ -263,6 +266,7 @@ extern "C" int jmhip_set_reference(jmhip_ctx *ctx, int32_t slot, const uint16_t 
     return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference: bad argument") : JMHIP_EINVAL;
   int r = upload_u16_as_u8(ctx, luma, pitch_samples, ctx->W, ctx->H, ctx->d_stage, ctx->cur_pitch);
   if (r) return r;
+  if (ctx->seq) { (void)jmhip_seq_sync_all(ctx); ctx->slot_entry[slot] = -1; }
   jmhip_mb_slot_motion_reset(ctx, slot);
   r = jmhip_launch_subplanes(ctx, ctx->d_stage, ctx->cur_pitch, ctx->d_sub[slot]);
   if (r) return r;

@@ -20,7 +20,9 @@ static __device__ __constant__ int8_t c_chroma_edge[2][4][4] = {
   {{-4, 0, 0, 0}, {-4, -4, 4, 4},  {-4, 4, 8, 8}, {-4, -4, 12, 12}}
 };
 
+#ifndef JMHIP_HAVE_IABS                                         // me_common.h has the same (mbpipe.hip includes both)
 static __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
+#endif
 static __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 static __device__ __forceinline__ bool is_intra(int t) { return t == 9 || t == 13 || t == 10 || t == 14; }
 static __device__ __forceinline__ int cmp_mv(const int16_t a[2], const int16_t b[2]) { return (int)(iabs_(a[0] - b[0]) >= 4) | (int)(iabs_(a[1] - b[1]) >= 4); }

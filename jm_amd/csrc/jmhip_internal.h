@@ -8,6 +8,22 @@
 
 #define JMHIP_NKINDS 6
 
+// A picture in flight (jmhip_seq_*, mbpipe_host.inc): everything one launch of the macroblock pipeline owns, so that launches of consecutive pictures can run side by side
+struct jmhip_seq_entry {
+  hipStream_t stream;
+  hipEvent_t done;       // recorded behind the entry's launch
+  uint8_t *d_raw;        // the source picture as the file holds it (jmhip_seq_set_frame)
+  uint8_t *d_cur, *d_cur_c;   // source planes (as jmhip_ctx::d_cur / d_cur_c)
+  void *d_edge; unsigned *d_done, *d_sync;
+  void *d_records, *d_dbmb, *d_dbmo;
+  void *h_records; unsigned *h_flags; void *d_h_records; unsigned *d_h_flags;
+  unsigned epoch;
+  int first_mb, num_mb;  // macroblocks of the launch (streamed records)
+  int out_slot, num_ref, refs[JMHIP_MB_MAX_REF];
+  int in_flight;         // launched and not yet waited for (jmhip_seq_wait)
+  int streaming;
+};
+
 struct jmhip_ctx {
   jmhip_config cfg;
   hipStream_t stream;
@@ -61,6 +77,14 @@ struct jmhip_ctx {
   int *d_ez_col;         // co-located vectors of the running launch, per 4x4 block
   void *d_mot;           // the current picture's motion per 4x4 block {packed vector, poc referred to}: what jmhip_reference_from_recon keeps with the slot
   void **d_slot_mot;     // [num_ref_slots] the same of the pictures in the slots ({0, none} after jmhip_set_reference*)
+  // pictures in flight (jmhip_seq_open)
+  int seq_depth, seq_grid;
+  jmhip_seq_entry *seq;
+  uint8_t **d_slot_recy; // [num_ref_slots] the slot's picture before interpolation: luma, pitch cur_pitch (its chroma is d_refc[slot]); filtered in place
+  unsigned **d_slot_post;// [num_ref_slots] per macroblock: slot_tag once the macroblock is filtered and interpolated
+  unsigned *slot_tag;    // [num_ref_slots] tag of the slot's current / last picture made by a sequence launch
+  int *slot_entry;       // [num_ref_slots] entry that makes / made the slot's picture, -1: filled by jmhip_set_reference* / jmhip_reference_from_recon
+  hipEvent_t seq_ev;     // orders the context's own stream before an entry's
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];
@@ -84,6 +108,7 @@ int jmhip_check_job_error(jmhip_ctx *ctx);      // me_fullsearch.hip: device-sid
 void jmhip_launch_check_me_jobs(jmhip_ctx *ctx, const jmhip_me_job *d_jobs, int n);
 void jmhip_launch_check_subpel_jobs(jmhip_ctx *ctx, const jmhip_subpel_job *d_jobs, int n);
 void jmhip_mb_free(jmhip_ctx *ctx);   // mbpipe.hip
+int jmhip_seq_sync_all(jmhip_ctx *ctx);   // mbpipe.hip: every picture in flight is done (their error words are left for jmhip_seq_wait)
 int jmhip_check_mb_error(jmhip_ctx *ctx);   // mbpipe.hip: the pipeline's sticky error word, read and cleared
 void jmhip_mb_slot_motion_reset(jmhip_ctx *ctx, int slot);   // mbpipe.hip: a slot loaded from outside the pipeline carries no motion
 int jmhip_launch_subplanes(jmhip_ctx *ctx, const uint8_t *d_luma, int pitch, uint8_t *d_planes);

@@ -26,6 +26,7 @@
 #include <cstring>
 #include "jmhip_internal.h"
 #include "me_common.h"
+#include "deblock_common.h"
 
 typedef unsigned long long u64;
 typedef uint32_t u32;
@@ -45,6 +46,7 @@ typedef uint8_t u8;
                                             // bottom row / right column {packed vector, reference index}; 4:2:2: 17/18 rows 8..15 of the right U/V columns
 #define EDGE_MV_END 17                      // words 9 .. 16 are the tagged vectors
 #define SPIN_LIMIT (1u << 26)
+#define JMHIP_SEQ_MAX_FLIGHT 8              // references of a picture that may still be in the making when its launch starts (the most recent ones)
 
 struct __attribute__((packed)) U32un { u32 v; };
 __device__ __forceinline__ u32 ldu32(const u8 *p) { return ((const U32un *)p)->v; }
@@ -100,6 +102,29 @@ struct PipeArgs {
   int ez_words;                              // ints per macroblock there: 28 + 112 num_ref
   u64 *mot_out;                              // per 4x4 block of the picture {packed vector, poc of the picture referred to}: later pictures' temporal predictors
   unsigned long long *prof;                  // profiling aid (JMHIP_MB_PROF=1): 24 time stamps (100 MHz) per macroblock, or null
+  // Pictures in flight side by side (jmhip_seq_encode, mbpipe_post.inc): the macroblock's share of the loop filter and of the quarter-pel planes follows its coding
+  // inside the launch, rec_y / rec_u / rec_v are the planes of the slot the picture goes to (filtered in place), and the references may still be in the making
+  int fused;
+  int direct8x8;                             // active_sps->direct_8x8_inference_flag (DeblockMb's skip rule for B_Skip: never met in P / I pictures)
+  u8 *out_planes;                            // the sixteen quarter-pel planes of that slot
+  u32 *post;                                 // per macroblock of that slot: post_tag once the macroblock is filtered and its share of the planes is written
+  u32 post_tag;
+  int reach_x, reach_y;                      // macroblock (X, r) reads reference samples that macroblocks up to (X + reach_x, r + reach_y) of the reference produce
+  const u32 *ref_post[JMHIP_SEQ_MAX_FLIGHT]; // the post flags of reference r's slot, or null (complete before the launch); references beyond are always complete
+  u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
+};
+static_assert(sizeof(PipeArgs) <= 4096, "kernel arguments: 4 KB");
+
+// scratch of the post stage (mbpipe_post.inc)
+struct PostShared {
+  jmhip_db_motion own[16], mo[2][4];         // the macroblock's 4x4 blocks; the left neighbour's right column, the upper neighbour's bottom row
+  jmhip_db_mb q, nb[2];                      // the macroblock, its left and its upper neighbour
+  u8 str[2][4][4];                           // [dir][edge][segment] boundary strengths
+  __attribute__((aligned(8))) u8 y[20 * LP]; // luma rows -4 .. 15, columns -4 .. 15 at [(r + 4) * LP + c + 4]
+  __attribute__((aligned(8))) u8 c[2][18 * CP];   // chroma rows -2 .. 15, columns -4 .. 7 at [(r + 2) * CP + c + 4]
+  __attribute__((aligned(8))) u8 src[21][24];     // interpolation: source rows y0 - 2 .. y0 + 18, columns x0 - 4 .. x0 + 19
+  int16_t h[21][16];                         // unclipped horizontal six-tap sums
+  u8 v[16][20];                              // vertical half-pel samples (17 columns used)
 };
 
 // per-workgroup state in LDS
@@ -158,6 +183,7 @@ struct Shared {
   u64 fl_cbp_blk, fc_bits;
   u32 fin_cbp_blk;
   jmhip_mb_record out;
+  PostShared post;
 };
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value every lane of the wave holds alike, moved to a scalar register (loop bounds, addresses and branches on it become scalar)
@@ -1122,4 +1148,5 @@ __device__ __forceinline__ void ihadamard4x4_jm(int (&m)[16])
 #include "mbpipe_t8.inc"
 #include "mbpipe_final.inc"
 #include "mbpipe_epzs.inc"
+#include "mbpipe_post.inc"
 #include "mbpipe_kernel.inc"

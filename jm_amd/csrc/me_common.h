@@ -4,6 +4,7 @@
 
 #define NP JMHIP_NPART
 
+#define JMHIP_HAVE_IABS 1
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 // mvbits LUT of lencod/src/mv_search.c:366-374 in closed form

@@ -105,7 +105,9 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_tq_luma8x8", "jmhip_tq_luma8x8_dev", "jmhip_tq_luma16x16", "jmhip_tq_luma16x16_dev", "jmhip_dc_transform", "jmhip_quant_dc4x4", "jmhip_tq_chroma",
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
-           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups"]
+           "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
+           "jmhip_seq_open", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
+           "jmhip_seq_recon_dev", "jmhip_seq_get_recon"]
 
 
 class JmHipError(RuntimeError):
@@ -618,6 +620,52 @@ class JmHip:
 
     def reference_from_recon(self, slot):
         self._ck(self.lib.jmhip_reference_from_recon(self.h, slot))
+
+    # ---- consecutive pictures of one sequence in flight side by side (include/jmhip.h: jmhip_seq_*)
+    def seq_open(self, depth, workgroups=0):
+        self._ck(self.lib.jmhip_seq_open(self.h, int(depth), int(workgroups)))
+
+    def seq_close(self):
+        self._ck(self.lib.jmhip_seq_close(self.h))
+
+    def seq_set_frame(self, entry, raw, src_w, src_h):
+        a = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
+        cw, chh = src_w // 2, (src_h // 2 if self.yuv_format == 1 else src_h)
+        assert a.size == src_w * src_h + (2 * cw * chh if self.yuv_format else 0), (a.size, src_w, src_h)
+        self._ck(self.lib.jmhip_seq_set_frame(self.h, int(entry), _vp(a), src_w, src_h))
+
+    def seq_set_frame_dev(self, entry, d_raw, src_w, src_h):
+        self._ck(self.lib.jmhip_seq_set_frame_dev(self.h, int(entry), _vp(d_raw), src_w, src_h))
+
+    def seq_encode(self, entry, prm, out_slot, direct8x8=1, to_host=False):
+        prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
+        self._ck(self.lib.jmhip_seq_encode(self.h, int(entry), _vp(prm), int(out_slot), int(direct8x8), int(bool(to_host))))
+
+    def seq_wait(self, entry):
+        self._ck(self.lib.jmhip_seq_wait(self.h, int(entry)))
+
+    def seq_records(self, entry, num_mb=None):
+        out = np.zeros((self.W // 16) * (self.H // 16) if num_mb is None else num_mb, MB_RECORD)
+        self._ck(self.lib.jmhip_seq_records(self.h, int(entry), _vp(out)))
+        return out
+
+    def seq_records_streamed(self, entry, first, num):
+        """the records of a picture launched with to_host, read in raster order while the device is still encoding"""
+        out = np.zeros(num, MB_RECORD)
+        p = C.c_void_p()
+        for k in range(num):
+            self._ck(self.lib.jmhip_seq_record(self.h, int(entry), first + k, C.byref(p)))
+            out[k] = np.frombuffer((C.c_char * MB_RECORD.itemsize).from_address(p.value), MB_RECORD)[0]
+        return out
+
+    def seq_get_recon(self, slot):
+        """(y, u, v) uint8: the filtered reconstruction a sequence launch left in `slot`"""
+        y = np.zeros((self.H, self.W), np.uint16)
+        ch = self.H if self.yuv_format == 2 else self.H // 2
+        u = np.zeros((ch, self.W // 2), np.uint16)
+        v = np.zeros((ch, self.W // 2), np.uint16)
+        self._ck(self.lib.jmhip_seq_get_recon(self.h, int(slot), _vp(y), self.W, _vp(u), _vp(v), self.W // 2))
+        return y.astype(np.uint8), u.astype(np.uint8), v.astype(np.uint8)
 
 
 def db_arrays_from_tap(mbs12, mot):

@@ -1,0 +1,47 @@
+"""Measurement aid: configs[1] (1080p, SR 32, one reference, QP 28, G2r's flags) as a real IPPP sequence with `depth` pictures in flight (jmhip_seq_*).
+usage: python profiles/seq_probe.py [pictures] [depth,depth,...] [workgroups]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from jm_amd import JmHip  # noqa: E402
+from jm_amd.lib import SLICE_PARAMS  # noqa: E402
+
+npic = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+depths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+wg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+W, H = 1920, 1088
+nmb = (W // 16) * (H // 16)
+frames = bench.yuv_frames(npic)
+for depth in depths:
+    nslots = depth + 2
+    ctx = JmHip(W, H, search_range=32, num_ref_slots=nslots, yuv_format=1)
+    ctx.seq_open(depth, wg)
+
+    def prm(k):
+        p = bench.slice_params(SLICE_PARAMS, 2 if k == 0 else 0, 0, nmb, 0, 0 if k == 0 else 1)
+        if k:
+            p["ref_slot"][0, 0] = (k - 1) % nslots
+            p["ref_id"][0, 0] = k - 1
+        return p
+    # all source pictures resident before the clock starts: one context entry per picture would be the product's ring; here the frames are re-uploaded per entry, untimed first pass
+    for rep in range(2):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(npic):
+            e = k % depth
+            if k >= depth:
+                ctx.seq_wait(e)
+            ctx.seq_set_frame(e, frames[k], 1920, 1080)
+            ctx.seq_encode(e, prm(k), k % nslots, 1, False)
+        for k in range(max(0, npic - depth), npic):
+            ctx.seq_wait(k % depth)
+        dt = time.perf_counter() - t0
+    print(f"depth {depth} workgroups/picture {wg or 224 // depth}: {npic} pictures in {dt * 1e3:.1f} ms = {dt / npic * 1e3:.2f} ms per picture = {nmb * npic / dt / 1e3:.0f} k macroblocks/s", flush=True)
+    ctx.close()

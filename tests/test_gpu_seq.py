@@ -1,0 +1,200 @@
+"""gpu: consecutive pictures of one sequence in flight side by side (jmhip_seq_*, jm_amd/csrc/mbpipe_post.inc) through the C ABI.
+
+What is checked: a sequence coded with several pictures in flight -- the loop filter and the quarter-pel interpolation of a macroblock following its coding inside
+the launch, the next picture's macroblocks starting as soon as THEIR part of the reference is there -- leaves exactly what the picture-after-picture path
+(jmhip_encode_slice -> jmhip_deblock_picture_dev -> jmhip_reference_from_recon) leaves: every macroblock record, every filtered picture, all sixteen sub-pel planes
+with their padding.  That path is pinned to the real encoder and to the oracle by tests/test_gpu_mbenc.py; the 1080p case here is compared with the real
+encoder's records directly (tests/golden/mb_low_g2r.npz) and with the oracle's loop filter and interpolation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, G)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mb_tap  # noqa: E402
+import mbenc_util  # noqa: E402
+from oracle import pyjmo  # noqa: E402
+from test_gpu_mbenc import DevSeqEncoder, LAMBDAS, slice_params, synthetic_clip, hard_clip, as_oracle_records, first_difference  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+class FlightEncoder:
+    """IPPP with `depth` pictures in flight: picture k goes to entry k % depth and to slot k % (num_ref + depth + 1)."""
+
+    def __init__(self, W, H, qp, R, num_ref, lambdas, depth, workgroups=0, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, stream_records=False):
+        import jm_amd.lib as L
+        self.L = L
+        self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas, self.depth = W, H, qp, R, num_ref, lambdas, depth
+        self.cabac, self.search_mode, self.transform8x8, self.yuv_format = cabac, search_mode, transform8x8, yuv_format
+        self.nslots = num_ref + depth + 1
+        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=self.nslots, yuv_format=yuv_format)
+        self.J.seq_open(depth, workgroups)
+        self.stream_records = stream_records
+        self.npic = 0
+        self.results = {}
+
+    def collect(self, k):
+        J = self.J
+        nmb = (self.W // 16) * (self.H // 16)
+        if self.stream_records:
+            recs = J.seq_records_streamed(k % self.depth, 0, nmb)
+            J.seq_wait(k % self.depth)
+        else:
+            J.seq_wait(k % self.depth)
+            recs = J.seq_records(k % self.depth)
+        self.results[k] = (recs, J.seq_get_recon(k % self.nslots), J.get_subplanes(k % self.nslots))
+
+    def submit(self, raw, sw, sh):
+        k, L, J = self.npic, self.L, self.J
+        if k >= self.depth:
+            self.collect(k - self.depth)                     # the entry's previous picture, before its buffers are reused
+        nmb = (self.W // 16) * (self.H // 16)
+        st = 2 if k == 0 else 0
+        nref = min(self.num_ref, k) if st == 0 else 0
+        lam_mf, lam_md = self.lambdas[st]
+        cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, nmb, self.qp, self.R, nref, lam_mf, lam_md, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8, yuv_format=self.yuv_format)
+        prm = slice_params(L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)])
+        J.seq_set_frame(k % self.depth, raw, sw, sh)
+        J.seq_encode(k % self.depth, prm, k % self.nslots, 1, self.stream_records)
+        self.npic += 1
+
+    def finish(self):
+        for k in range(max(0, self.npic - self.depth), self.npic):
+            self.collect(k)
+        self.J.synchronize()
+        return [self.results[k] for k in range(self.npic)]
+
+
+def classic(W, H, qp, R, num_ref, lam, frames, sw=None, sh=None, **kw):
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, 0, **kw)
+    out = []
+    for raw in frames:
+        recs, pre, post = dev.encode(raw, sw or W, sh or H)
+        out.append((recs, post, dev.J.get_subplanes(dev.refs[0][0])))
+    dev.J.close()
+    return out
+
+
+def compare(want, got, what):
+    assert len(want) == len(got)
+    for n, (a, b) in enumerate(zip(want, got)):
+        d = first_difference(mb_tap.canonical(as_oracle_records(a[0])), mb_tap.canonical(as_oracle_records(b[0])))
+        assert d is None, (what, "picture", n, "record", d)
+        for p, (x, y) in enumerate(zip(a[1], b[1])):
+            if not np.array_equal(x, y):
+                bad = np.argwhere(x != y)
+                raise AssertionError((what, "picture", n, "filtered plane", p, "first differences (row, column)", bad[:8].tolist(), len(bad)))
+        if not np.array_equal(a[2], b[2]):
+            bad = np.argwhere(a[2] != b[2])
+            raise AssertionError((what, "picture", n, "sub-pel planes: first differences (plane, row, column)", bad[:8].tolist(), len(bad)))
+
+
+@pytest.mark.parametrize("W,H,R,num_ref,qp,depth,wg,seed,kw", [
+    (176, 144, 16, 1, 28, 2, 0, 1, {}),
+    (176, 144, 16, 1, 28, 8, 0, 1, {}),
+    (320, 192, 32, 1, 28, 4, 0, 2, {}),
+    (320, 192, 32, 3, 36, 4, 0, 3, {}),                      # three references, all of them possibly still in the making
+    (640, 368, 32, 1, 28, 4, 0, 4, {}),
+    (640, 368, 8, 2, 20, 8, 12, 5, {}),                      # a short reach: pictures three diagonals apart; few workgroups per picture
+    (64, 48, 32, 2, 28, 4, 0, 6, {}),                        # smaller than the search window: every macroblock waits for the reference's last one
+    (16, 16, 16, 1, 28, 3, 0, 7, {}),                        # a single macroblock: all four borders of the planes from one workgroup
+    (208, 160, 16, 1, 28, 1, 0, 8, {}),                      # depth 1: the launch alone (filter + interpolation inside it)
+    (320, 192, 16, 2, 28, 4, 0, 9, {"cabac": 1}),
+    (320, 192, 16, 1, 28, 4, 0, 10, {"transform8x8": 1, "cabac": 1}),
+    (320, 192, 32, 2, 28, 4, 0, 11, {"search_mode": 1}),      # fast full search
+    (320, 192, 16, 1, 28, 4, 0, 12, {"yuv_format": 2}),
+    (320, 192, 32, 2, 32, 3, 5, 13, {"yuv_format": 2, "transform8x8": 1, "cabac": 1, "search_mode": 1}),
+])
+def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, depth, wg, seed, kw):
+    f = int(192 * 2 ** ((qp - 28) / 6))
+    lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    nfr = max(7, depth + 3)
+    if kw.get("yuv_format") == 2:
+        frames = [np.concatenate([fr[:W * H], np.repeat(fr[W * H:].reshape(2, H // 2, W // 2), 2, axis=1).ravel()]) for fr in synthetic_clip(W, H, nfr, seed)]
+    else:
+        frames = synthetic_clip(W, H, nfr, seed)
+    want = classic(W, H, qp, R, num_ref, lam, frames, **kw)
+    fl = FlightEncoder(W, H, qp, R, num_ref, lam, depth, wg, **kw)
+    for raw in frames:
+        fl.submit(raw, W, H)
+    got = fl.finish()
+    fl.J.close()
+    compare(want, got, (W, H, R, num_ref, depth))
+
+
+@pytest.mark.parametrize("kind,R,num_ref,qp", [("flat", 32, 1, 44), ("noise", 16, 2, 12), ("stripes", 32, 2, 28), ("still", 32, 1, 30)])
+def test_pictures_in_flight_hard_content(kind, R, num_ref, qp):
+    """content that makes every edge filter (noise, coarse quantiser) or none (still), and vectors at the limit of the reach (stripes)"""
+    W, H = 256, 160
+    f = int(192 * 2 ** ((qp - 28) / 6))
+    lam = {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    frames = hard_clip(kind, W, H, 6, 77)
+    want = classic(W, H, qp, R, num_ref, lam, frames)
+    fl = FlightEncoder(W, H, qp, R, num_ref, lam, 4)
+    for raw in frames:
+        fl.submit(raw, W, H)
+    compare(want, fl.finish(), kind)
+    fl.J.close()
+
+
+def test_pictures_in_flight_streamed_records_and_repeated_runs():
+    """records read macroblock by macroblock from pinned memory while pictures are in flight; the same sequence five times over gives the same bytes"""
+    W, H, R = 320, 192, 16
+    frames = synthetic_clip(W, H, 9, 31)
+    want = classic(W, H, 28, R, 1, LAMBDAS, frames)
+    for rep in range(5):
+        fl = FlightEncoder(W, H, 28, R, 1, LAMBDAS, 4, stream_records=(rep & 1) == 0)
+        for raw in frames:
+            fl.submit(raw, W, H)
+        compare(want, fl.finish(), ("repetition", rep))
+        fl.J.close()
+
+
+def test_seq_refuses_what_it_does_not_cover():
+    import jm_amd.lib as L
+    W, H = 176, 144
+    nmb = (W // 16) * (H // 16)
+    J = L.JmHip(W, H, search_range=16, num_ref_slots=4, yuv_format=1)
+    with pytest.raises(L.JmHipError):
+        J.seq_encode(0, slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2]), 0, [], []), 0)       # no jmhip_seq_open
+    J.seq_open(2)
+    raw = synthetic_clip(W, H, 1, 1)[0]
+    J.seq_set_frame(0, raw, W, H)
+    cfg = pyjmo.mbenc_cfg(W, H, 2, 0, nmb // 2, 28, 16, 0, *LAMBDAS[2])
+    with pytest.raises(L.JmHipError, match="one slice covering the picture"):
+        J.seq_encode(0, slice_params(L, cfg, 0, [], []), 0)
+    cfg = pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2], search_mode=3)
+    with pytest.raises(L.JmHipError, match="EPZS"):
+        J.seq_encode(0, slice_params(L, cfg, 0, [], []), 0)
+    with pytest.raises(L.JmHipError):
+        J.seq_encode(2, slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2]), 0, [], []), 0)       # entry out of range
+    with pytest.raises(L.JmHipError):
+        J.seq_encode(0, slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2]), 0, [], []), 9)       # slot out of range
+    J.close()
+
+
+def test_1080p_sequence_in_flight_equals_the_reference_encoder():
+    """configs[1] at its own size: the clip of SURVEY Appendix A, G2r's flags, eight pictures in flight; the I and the P picture's records against the REAL
+    encoder's (tests/golden/mb_low_g2r.npz), the later P pictures and every filtered picture / plane against the picture-after-picture path"""
+    import bench
+    from test_gpu_mbenc import load_case
+    c = load_case("g2r")
+    W, H, R = c["W"], c["H"], c["R"]
+    nmb = (W // 16) * (H // 16)
+    frames = bench.yuv_frames(10)
+    want = classic(W, H, c["qp"], R, 1, c["lam"], frames[:4], c["sw"], c["sh"])
+    fl = FlightEncoder(W, H, c["qp"], R, 1, c["lam"], 8)
+    for raw in frames:
+        fl.submit(raw, c["sw"], c["sh"])
+    got = fl.finish()
+    fl.J.close()
+    compare(want, got[:4], "1080p")
+    for n in range(c["nfr"]):
+        d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(got[n][0])))
+        assert d is None, ("against the reference encoder, picture", n, d)
