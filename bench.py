@@ -31,7 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # before the HIP runtime starts: one hardware queue per stream for the concurrent_streams figure
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")         # before the HIP runtime starts: a hardware queue per stream (the pictures in flight; the concurrent_streams figure); the default is 4
 
 W, H_SRC, H = 1920, 1080, 1088
 R = 32
@@ -42,6 +42,7 @@ G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's 
 # HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
 # MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v8_kernel_stats.md)
 PIPE_TRAFFIC_BYTES = 140176272            # 1.48 x the algorithmic bytes (DESIGN.md section 0 "Scratch and traffic")
+PIPE_TRAFFIC_SOURCE = "profiles/r03_v8_kernel_stats.md (separate rocprofv3 --pmc passes; the round-3 kernel without the loop filter and interpolation inside: not re-measured in this run)"
 
 
 def synth_luma(n_frames, seed=1234):
@@ -532,6 +533,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--flight", type=int, default=8, help="pictures of the sequence in flight side by side (jmhip_seq_open; 1 = one launch at a time)")
+    ap.add_argument("--workgroups", type=int, default=0, help="workgroups per picture in flight (0: 256 / flight)")
     ap.add_argument("--streams", type=int, default=8, help="sequences encoded side by side for the extra concurrent_streams figure (0: skip)")
     args = ap.parse_args()
 
@@ -561,66 +564,87 @@ def main():
     N, HP = 1, H
     mbw, mbh = W // 16, H // 16
     nmb = mbw * mbh
+    depth = max(1, min(8, args.flight))
+    nslots = depth + 2                                                     # one reference + the pictures in flight + one: no launch ever waits for a slot
+    nseq = 1 + args.warmup + args.steps                                    # the I picture, the warm-up and the timed P pictures: one IPPP sequence
 
     stream = torch.cuda.current_stream()
-    ctx = JmHip(W, HP, search_range=R, num_ref_slots=2, yuv_format=1, device=local, stream=stream.cuda_stream)
+    ctx = JmHip(W, HP, search_range=R, num_ref_slots=nslots, yuv_format=1, device=local, stream=stream.cuda_stream)
+    ctx.seq_open(depth, args.workgroups)
 
     def slice_prm(slice_type, first, num, slice_nr, num_ref):
         return slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref)
 
-    # ---------------- inputs: the clip's first two pictures
-    raw0, raw1 = yuv_frames(2)
+    def seq_prm(k):
+        q = slice_prm(2 if k == 0 else 0, 0, nmb, 0, 0 if k == 0 else 1)
+        if k:
+            q["ref_slot"][0, 0], q["ref_id"][0, 0] = (k - 1) % nslots, k - 1
+        return q
+
+    # ---------------- inputs: the clip (continued), every source picture resident in HBM as the file holds it before the clock starts
     src_h = H_SRC
-    # the reference: the I picture through the same pipeline (setup, untimed)
-    ctx.set_current_frame(raw0, W, src_h)
-    ctx.encode_slice_dev(slice_prm(2, 0, nmb, 0, 0))
-    ctx.deblock_picture_dev(1)
-    ctx.reference_from_recon(0)
-    ctx.set_current_frame(raw1, W, src_h)                               # the P picture's source stays resident
-    ctx.synchronize()
-    prm = slice_prm(0, 0, nmb, 0, 1)
-    prm["ref_slot"][0, 0] = 0
-
+    frames = yuv_frames(nseq)
+    raw0, raw1 = frames[0], frames[1]
+    d_raw = torch.from_numpy(np.stack(frames)).to(dev)
+    d_recs = torch.zeros((nseq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)      # every picture's records (the entries' own are reused)
     ctx.enable_timing(True)
-    kernel_ms = []
 
-    def step(timed):
-        ctx.encode_slice_dev(prm)                                       # k_mb_pipe
-        ctx.deblock_picture_dev(1)                                      # K9/K10
-        ctx.reference_from_recon(1)                                     # K5 + chroma planes: the next picture's reference
-        if timed:
-            kernel_ms.append(None)
+    def step(k):
+        """picture k of the sequence: read_one_frame / pad_borders -> encode_one_macroblock_low of every macroblock, DeblockMb and the sixteen sub-pel planes behind
+        each of them (k_load_frame, k_mb_pipe); asynchronous -- up to `depth` pictures are in flight"""
+        e = k % depth
+        ctx.seq_set_frame_dev(e, d_raw[k].data_ptr(), W, src_h)
+        ctx.seq_encode(e, seq_prm(k), k % nslots, 1, False, d_recs[k].data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(False)
+    for k in range(1 + args.warmup):                                       # the I picture and the warm-up P pictures
+        step(k)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(True)
+    for k in range(1 + args.warmup, nseq):
+        step(k)
     barrier()
     dt = time.perf_counter() - t0
-    ctx.synchronize()                                                    # reads the device-side error words: the pipeline's is sticky (a launch that finds it set does nothing), so an incomplete picture cannot go unnoticed
-    # per-launch duration of the dominant kernel over a few more (untimed) launches, events around each
-    ms = []
-    for i in range(5):
-        ctx.encode_slice_dev(prm)
-        ctx.synchronize()
-        ms.append(ctx.last_kernel_ms(5))
-    pipe_ms = float(np.mean(ms))
+    kernel_ms = [ctx.seq_kernel_ms(e) for e in range(min(depth, args.steps))]      # the last launches, in flight together
+    for e in range(depth):
+        ctx.seq_wait(e)                                                    # reads the device-side error words: the pipeline's is sticky (a launch that finds it set does nothing), so an incomplete picture cannot go unnoticed
+    ctx.synchronize()
+    pipe_ms = float(np.mean(kernel_ms))
+    recs_all = d_recs.cpu().numpy().view(MB_RECORD).reshape(nseq, nmb)
 
-    # ---------------- the records of the last step against the real encoder's (N = 1: the whole P picture of G2r)
-    recs = ctx.encode_slice(prm)
-    types = np.bincount(recs["mb_type"].astype(int), minlength=11)
-    equal = None
-    if N == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        import mb_tap
-        gold = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g2r.npz"))["records"][nmb:2 * nmb])
-        mine = np.frombuffer(recs.tobytes(), gold.dtype).copy()
-        equal = bool(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), gold)))
+    # ---------------- the same sequence picture after picture (k_mb_pipe, then DeblockFrame, then getSubImagesLuma, each waiting for the one before): the round-3 step.
+    # Every picture's records must be the same bytes; the launch alone gives the kernel's solo time.
+    ctx.seq_close()
+    ctx.enable_timing(True)
+    solo_ms, same = [], True
+    t1 = time.perf_counter()
+    for k in range(nseq):
+        ctx.set_current_frame(frames[k], W, src_h)
+        q = seq_prm(k)
+        if k:
+            q["ref_slot"][0, 0] = (k - 1) & 1
+        recs = ctx.encode_slice(q)
+        if k:
+            solo_ms.append(ctx.last_kernel_ms(5))
+        same = same and recs.tobytes() == recs_all[k].tobytes()
+        ctx.deblock_picture_dev(1)
+        ctx.reference_from_recon(k & 1)
+    ctx.synchronize()
+    classic_s = time.perf_counter() - t1
+
+    # ---------------- the records against the real encoder's (the pictures the committed dumps hold)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import mb_tap
+    gname = "mb_low_g6r.npz" if os.path.exists(os.path.join(ROOT, "tests", "golden", "mb_low_g6r.npz")) else "mb_low_g2r.npz"
+    gold = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", gname))["records"])
+    ngold = min(len(gold) // nmb, nseq)
+    equal = True
+    for k in range(ngold):
+        mine = np.frombuffer(recs_all[k].tobytes(), gold.dtype).copy()
+        equal = equal and all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), gold[k * nmb:(k + 1) * nmb]))
+    types = np.bincount(recs_all[1 + args.warmup:]["mb_type"].astype(int).ravel(), minlength=14)
 
     # ---------------- configs[2]'s search on the same pictures: the P picture through k_mb_pipe_epzs (EPZS, CABAC), records against the real encoder's (g3e)
     configs2_device = {}
@@ -677,35 +701,46 @@ def main():
 
     if rank == 0:
         total_mb = nmb * N * args.steps
+        steps_chain = W // 16 + 2 * (H // 16 - 1)
         # algorithmic bytes per macroblock: SURVEY 8d's 6656 + 328 B per macroblock-reference for the search, the source
-        # macroblock's chroma (128 B), ~2.9 KB of transform/quant traffic for the coded mode, the 1216-byte record, 384 B of reconstruction
-        alg_mb = 6656 + 328 + 128 + 2900 + 1216 + 384
+        # macroblock's chroma (128 B), ~2.9 KB of transform/quant traffic for the coded mode, the 1216-byte record, 384 B of reconstruction; with the
+        # loop filter and the interpolation inside the launch also the filtered macroblock read back with its halo (21 x 24 B) and its share of the sixteen planes (4096 B)
+        alg_mb = 6656 + 328 + 128 + 2900 + 1216 + 384 + 504 + 4096
         alg = alg_mb * nmb
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
-        roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
-                "traffic_source": "profiles/r03_v8_kernel_stats.md (separate rocprofv3 --pmc passes over this command; not re-measured in this run)", "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
-                "abs_diff_per_s_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops / (pipe_ms * 1e-3) / 148.4e12, 5),
-                "critical_path": {"steps": W // 16 + 2 * (H // 16 - 1), "us_per_step": round(pipe_ms * 1e3 / (W // 16 + 2 * (H // 16 - 1)), 1),
-                                  "note": "a macroblock waits for its left and upper-right neighbours' vectors: the picture is a chain of mb_w + 2 (mb_h - 1) "
-                                          "macroblocks, one after the other, whatever the chip's width; the kernel's time is that chain "
-                                          "(profiles/prof_mbpipe.py follows it macroblock by macroblock)"},
-                "note": "a dependency (latency) bound wavefront (x + 2y: at most 60 of 8160 macroblocks in flight at 1080p, 27 on average), not an HBM stream: frac prices the "
-                        "algorithmic bytes against 8 TB/s as the contract asks; valu_frac_jm_equivalent counts every candidate JM's full search visits -- the device "
-                        "skips the ones JM's own cost bound excludes, so the abs-diffs really issued are fewer (profiles/prof_mbpipe.py mode 11 counts them) -- over the "
-                        "measured v_sad_u8 peak of 148.4 T/s (profiles/r01_valu_rates.txt); traffic is 1.48 times the algorithmic bytes (it was 10.5 times with 256 workgroups, 768 B of scratch per lane and every XCD "
-                        "reading every row of the sub-pel planes).  DESIGN.md sections 0, 4"}
+        conc = pipe_ms * 1e-3 * args.steps / dt                            # launches in flight at a time, on average over the timed region
+        solo = float(np.mean(solo_ms)) if solo_ms else None
+        roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg * args.steps / dt / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(alg * args.steps / dt / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
+                "traffic_source": PIPE_TRAFFIC_SOURCE, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
+                "launches_in_flight": round(conc, 2),
+                "per_launch": {"achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "avg_kernel_ms_alone": round(solo, 3) if solo else None,
+                               "note": "one launch = one picture; `depth` launches overlap, each slower than alone because they share the chip -- achieved / frac above are the "
+                                       "timed region's: algorithmic bytes of its launches over its wall time"},
+                "abs_diff_per_s_jm_equivalent": round(sad_ops * args.steps / dt / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops * args.steps / dt / 148.4e12, 5),
+                "critical_path": {"steps": steps_chain, "us_per_step_alone": round(solo * 1e3 / steps_chain, 1) if solo else None,
+                                  "note": "a macroblock waits for its left and upper-right neighbours' vectors: one picture is a chain of mb_w + 2 (mb_h - 1) macroblocks whatever the "
+                                          "chip's width, with 27 of 8160 macroblocks in flight on average.  What fills the chip is the NEXT pictures: macroblock (X, r) of picture n + 1 "
+                                          "only needs picture n filtered and interpolated up to macroblock (X + 5, r + 5), so consecutive pictures follow each other 16 diagonals apart "
+                                          "(jm_amd/csrc/mbpipe_post.inc)"},
+                "note": "dependency (latency) bound wavefronts, not an HBM stream: frac prices the algorithmic bytes against 8 TB/s as the contract asks; valu_frac_jm_equivalent counts every "
+                        "candidate JM's full search visits -- the device skips the ones JM's own cost bound excludes -- over the measured v_sad_u8 peak of 148.4 T/s "
+                        "(profiles/r01_valu_rates.txt).  DESIGN.md sections 0, 4"}
         out = {
             "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
             "value": round(total_mb / dt, 1), "unit": "macroblocks/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP, P picture through the RDO-off macroblock pipeline "
-                                   "(encode_one_macroblock_low on the device: FullSearch SR=32 at every block's own centre, 1 ref, QP 28, mode decision, transform/quant, "
-                                   "reconstruction) + DeblockFrame + getSubImagesLuma; entropy coding is the host's and is outside the step (see end_to_end)",
-                       "macroblocks_per_step_per_gpu": nmb, "search_range": R,
+            "config": {"workload": "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP, one sequence: a step is the next P picture of it -- read_one_frame / pad_borders from the "
+                                   "file's bytes in HBM, encode_one_macroblock_low of every macroblock on the device (FullSearch SR=32 at every block's own centre, 1 ref = the picture before, QP 28, "
+                                   "mode decision, transform/quant, reconstruction), DeblockFrame, getSubImagesLuma -- with up to `pictures_in_flight` consecutive pictures in flight; the timed region "
+                                   "starts and ends with an idle device (pipeline fill and drain are inside it); entropy coding is the host's and is outside the step (see end_to_end)",
+                       "macroblocks_per_step_per_gpu": nmb, "search_range": R, "pictures_in_flight": depth, "workgroups_per_picture": args.workgroups or min(80, 256 // depth),
                        "parallelism": "1 GPU",
-                       "records_equal_jm": equal, "mb_types_pskip_16x16_16x8_8x16_p8x8_i4_i16": [int(types[k]) for k in (0, 1, 2, 3, 8, 9, 10)]},
+                       "records_equal_jm": bool(equal), "pictures_checked_against_jm": ngold,
+                       "records_equal_picture_after_picture": bool(same), "pictures_checked_against_picture_after_picture": nseq,
+                       "picture_after_picture_ms_per_picture": round(classic_s / nseq * 1e3, 2),
+                       "mb_types_pskip_16x16_16x8_8x16_p8x8_i4_i16": [int(types[k]) for k in (0, 1, 2, 3, 8, 9, 10)]},
             "roofline": roof,
         }
         cpu = None

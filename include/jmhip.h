@@ -678,7 +678,10 @@ int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture
 int jmhip_seq_close(jmhip_ctx *ctx);
 int jmhip_seq_set_frame(jmhip_ctx *ctx, int32_t entry, const uint8_t *raw, int32_t src_w, int32_t src_h);
 int jmhip_seq_set_frame_dev(jmhip_ctx *ctx, int32_t entry, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
-int jmhip_seq_encode(jmhip_ctx *ctx, int32_t entry, const jmhip_slice_params *prm, int32_t out_slot, int32_t direct_8x8_inference, int32_t to_host);
+int jmhip_seq_encode(jmhip_ctx *ctx, int32_t entry, const jmhip_slice_params *prm, int32_t out_slot, int32_t direct_8x8_inference, int32_t to_host,
+                     jmhip_mb_record *d_out /* device: a copy of the picture's records queued behind the launch (the entry's own are overwritten by its next picture), or NULL */);
+/* with jmhip_enable_timing: milliseconds of the entry's last launch (HIP events on the entry's stream around k_mb_pipe); waits for it */
+int jmhip_seq_kernel_ms(jmhip_ctx *ctx, int32_t entry, float *ms);
 int jmhip_seq_record(jmhip_ctx *ctx, int32_t entry, int32_t mb_addr, const jmhip_mb_record **rec);
 int jmhip_seq_wait(jmhip_ctx *ctx, int32_t entry);
 int jmhip_seq_records(jmhip_ctx *ctx, int32_t entry, jmhip_mb_record *out /* host, the launch's num_mb records */);

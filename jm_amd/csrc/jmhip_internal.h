@@ -12,6 +12,8 @@
 struct jmhip_seq_entry {
   hipStream_t stream;
   hipEvent_t done;       // recorded behind the entry's launch
+  hipEvent_t t0, t1;     // jmhip_enable_timing: around the launch
+  int timed;
   uint8_t *d_raw;        // the source picture as the file holds it (jmhip_seq_set_frame)
   uint8_t *d_cur, *d_cur_c;   // source planes (as jmhip_ctx::d_cur / d_cur_c)
   void *d_edge; unsigned *d_done, *d_sync;

@@ -107,7 +107,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
            "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
            "jmhip_seq_open", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
-           "jmhip_seq_recon_dev", "jmhip_seq_get_recon"]
+           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms"]
 
 
 class JmHipError(RuntimeError):
@@ -637,9 +637,14 @@ class JmHip:
     def seq_set_frame_dev(self, entry, d_raw, src_w, src_h):
         self._ck(self.lib.jmhip_seq_set_frame_dev(self.h, int(entry), _vp(d_raw), src_w, src_h))
 
-    def seq_encode(self, entry, prm, out_slot, direct8x8=1, to_host=False):
+    def seq_encode(self, entry, prm, out_slot, direct8x8=1, to_host=False, d_out=None):
         prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
-        self._ck(self.lib.jmhip_seq_encode(self.h, int(entry), _vp(prm), int(out_slot), int(direct8x8), int(bool(to_host))))
+        self._ck(self.lib.jmhip_seq_encode(self.h, int(entry), _vp(prm), int(out_slot), int(direct8x8), int(bool(to_host)), _vp(d_out)))
+
+    def seq_kernel_ms(self, entry):
+        ms = C.c_float()
+        self._ck(self.lib.jmhip_seq_kernel_ms(self.h, int(entry), C.byref(ms)))
+        return ms.value
 
     def seq_wait(self, entry):
         self._ck(self.lib.jmhip_seq_wait(self.h, int(entry)))
