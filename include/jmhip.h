@@ -678,6 +678,7 @@ int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture
 int jmhip_seq_close(jmhip_ctx *ctx);
 int jmhip_seq_set_frame(jmhip_ctx *ctx, int32_t entry, const uint8_t *raw, int32_t src_w, int32_t src_h);
 int jmhip_seq_set_frame_dev(jmhip_ctx *ctx, int32_t entry, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
+int jmhip_seq_set_planes(jmhip_ctx *ctx, int32_t entry, const uint16_t *y, int32_t pitch_y, const uint16_t *u, const uint16_t *v, int32_t pitch_c);   /* as jmhip_set_current_planes */
 int jmhip_seq_encode(jmhip_ctx *ctx, int32_t entry, const jmhip_slice_params *prm, int32_t out_slot, int32_t direct_8x8_inference, int32_t to_host,
                      jmhip_mb_record *d_out /* device: a copy of the picture's records queued behind the launch (the entry's own are overwritten by its next picture), or NULL */);
 /* with jmhip_enable_timing: milliseconds of the entry's last launch (HIP events on the entry's stream around k_mb_pipe); waits for it */

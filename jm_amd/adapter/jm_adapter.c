@@ -35,6 +35,7 @@
 #include <string.h>
 #include <time.h>
 #include <sys/types.h>
+#include <unistd.h>
 #include "global.h"
 #include "image.h"
 #include "mbuffer.h"
@@ -57,7 +58,7 @@
 #include "conformance.h"
 #include "jmhip.h"
 
-#define MAX_SLOTS 20
+#define MAX_SLOTS 32
 
 static struct {
   int         init_done, off;
@@ -86,6 +87,28 @@ static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV);
 static int pipe_reference(StorablePicture *s);
 static int pipe_config_ok(VideoParameters *p_Vid);
 static int pipe_active(void);
+static void flight_begin(VideoParameters *p_Vid);
+static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm);
+
+/* Pictures in flight (jmhip_seq_*).  JM codes picture after picture; with IPPP, RDOptimization 0 and no rate control nothing but the reference picture
+ * flows from one picture to the next, and everything else a picture's launch needs is known beforehand: its source frame lies in the input file, its parameters are those
+ * of the last picture of its type.  So while JM entropy-codes picture k the adapter has the next pictures launched already -- each follows its reference a few macroblock
+ * diagonals behind, inside the device (mbpipe_post.inc) -- and when JM arrives at picture k + 1 its records are waiting.  Nothing is taken on trust: at the picture's
+ * first macroblock the parameters JM really has are built as always and compared byte for byte with the ones the launch was given, and the source planes JM really holds
+ * are compared with the frame that was sent; any difference voids the pictures in flight and the picture is launched the ordinary way. */
+#define FL_MAX 8
+static struct {
+  int depth, nring;                   /* entries of jmhip_seq_open; device slots used in turn */
+  int on;
+  int fd, have_file, src_w, src_h, cur_frame_no, frame_step;
+  long header, frame_bytes, start_frame;
+  long pic, total;                    /* pictures of the sequence met so far; pictures it will have */
+  struct { long pic; int valid, slot; jmhip_slice_params prm; uint8_t *raw; } sub[FL_MAX];      /* by entry: the launch it holds */
+  jmhip_slice_params tmpl[3];         /* by slice type: what the last picture of that type was launched with */
+  int have_tmpl[3], nref_prev;
+  int cur_entry, cur_slot;
+  long n_ahead, n_hit, n_void;
+} F;
 
 static void adapter_report(void)
 {
@@ -221,6 +244,18 @@ static int adapter_on(VideoParameters *p_Vid)
     if (G.R > JMHIP_MAX_SEARCH_RANGE) { G.part_fs = G.part_ffs = 0; G.R = JMHIP_MAX_SEARCH_RANGE; }
     if (G.R < 1) G.R = 1;
     G.nslots = imin(MAX_SLOTS, p_Vid->max_num_references + 2);
+    {                                                       /* pictures in flight: JMHIP_ADAPTER_FLIGHT = 2 .. 8 entries (default 4; 0 or 1: off) */
+      const char *fl = getenv("JMHIP_ADAPTER_FLIGHT");
+      F.depth = fl ? atoi(fl) : 4;
+      if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || p_Inp->slice_mode != NO_SLICES || p_Inp->NumberBFrames != 0 ||
+          (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH)) F.depth = 0;
+      if (F.depth > FL_MAX) F.depth = FL_MAX;
+      if (F.depth) {
+        F.nring = imin(MAX_SLOTS, p_Vid->max_num_references + F.depth + 1);
+        G.nslots = F.nring;
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);             /* before HIP starts: a hardware queue per picture in flight (the runtime's default is 4) */
+      }
+    }
     memset(&cfg, 0, sizeof cfg);
     cfg.device = getenv("JMHIP_DEVICE") ? atoi(getenv("JMHIP_DEVICE")) : 0;
     cfg.width = G.W; cfg.height = G.H; cfg.yuv_format = G.fmt; cfg.bit_depth = 8; cfg.search_range = G.R; cfg.num_ref_slots = G.nslots;
@@ -1311,6 +1346,110 @@ static void list_from_dense(const int16_t *dense, int first, int n, int *level, 
   level[c] = 0; run[c] = 0;
 }
 
+/* ---- pictures in flight: see the note at struct F */
+extern int __real_read_one_frame(VideoParameters *, VideoDataFile *, int, int, FrameFormat *, FrameFormat *, imgpel **[3]);
+int __wrap_read_one_frame(VideoParameters *p_Vid, VideoDataFile *input_file, int FrameNoInFile, int HeaderSize, FrameFormat *source, FrameFormat *output, imgpel **pImage[3])
+{
+  /* where JM finds its frames (ReadFrameConcatenated lcommon/src/io_raw.c:103: one file, frame n at HeaderSize + frame bytes x (n + start_frame)): the pictures launched
+   * ahead of time are read from the same descriptor with pread; what they read is checked against JM's own planes when JM gets there */
+  InputParameters *p_Inp = p_Vid->p_Inp;
+  const int fmt = (int)source->yuv_format;
+  F.have_file = input_file == &p_Inp->input_file1 && input_file->is_concatenated && !input_file->is_interleaved && input_file->vdtype == VIDEO_YUV && input_file->f_num >= 0 &&
+                source->pic_unit_size_shift3 == 1 && source->bit_depth[0] == 8 && output->bit_depth[0] == 8 && (fmt == YUV420 || fmt == YUV422) &&
+                source->width[0] == output->width[0] && source->height[0] == output->height[0] && source->color_model != CM_RGB && p_Inp->ProcessInput == 0;
+  if (F.have_file) {
+    F.fd = input_file->f_num; F.header = HeaderSize; F.start_frame = p_Inp->start_frame; F.cur_frame_no = FrameNoInFile; F.frame_step = 1 + p_Inp->frame_skip;
+    F.src_w = source->width[0]; F.src_h = source->height[0];
+    F.frame_bytes = (long)source->size_cmp[0] + 2 * (long)source->size_cmp[1];
+  }
+  return __real_read_one_frame(p_Vid, input_file, FrameNoInFile, HeaderSize, source, output, pImage);
+}
+
+static void flight_begin(VideoParameters *p_Vid)
+{
+  int rc, k;
+  if (F.on || !F.depth || P.n_slices) return;               /* decided at the sequence's first picture */
+  F.total = p_Vid->p_Inp->no_frames;
+  if ((rc = jmhip_seq_open(G.ctx, F.depth, 0))) adapter_die("jmhip_seq_open", rc);
+  for (k = 0; k < F.depth; k++) F.sub[k].valid = 0;
+  F.on = 1;
+}
+
+/* do JM's source planes hold exactly the frame that was sent ahead of time? */
+static int flight_source_equal(VideoParameters *p_Vid, const uint8_t *raw)
+{
+  const int cw = F.src_w / 2, chh = p_Vid->yuv_format == YUV422 ? F.src_h : F.src_h / 2;
+  int y, x, uv;
+  if (!raw) return 0;
+  for (y = 0; y < F.src_h; y++) {
+    const imgpel *row = p_Vid->pCurImg[y];
+    const uint8_t *q = raw + (size_t)y * F.src_w;
+    int bad = 0;
+    for (x = 0; x < F.src_w; x++) bad |= row[x] ^ q[x];
+    if (bad) return 0;
+  }
+  for (uv = 0; uv < 2; uv++)
+    for (y = 0; y < chh; y++) {
+      const imgpel *row = p_Vid->pImgOrg[1 + uv][y];
+      const uint8_t *q = raw + (size_t)F.src_w * F.src_h + (size_t)uv * cw * chh + (size_t)y * cw;
+      int bad = 0;
+      for (x = 0; x < cw; x++) bad |= row[x] ^ q[x];
+      if (bad) return 0;
+    }
+  return 1;
+}
+
+/* picture F.pic with the parameters JM really has: take the launch made ahead of time if it was given exactly these, else launch now; then launch ahead */
+static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
+{
+  InputParameters *p_Inp = p_Vid->p_Inp;
+  const long k = F.pic;
+  const int e = F.cur_entry, d8 = p_Vid->active_sps->direct_8x8_inference_flag;
+  int rc, j, hit;
+  hit = F.sub[e].valid && F.sub[e].pic == k && F.sub[e].slot == F.cur_slot && !memcmp(&F.sub[e].prm, prm, sizeof *prm) && flight_source_equal(p_Vid, F.sub[e].raw);
+  if (hit) F.n_hit++;
+  else {
+    for (j = 0; j < F.depth; j++)                           /* whatever is in flight was built on a picture that is not this one */
+      if (F.sub[j].valid && F.sub[j].pic >= k) { (void)jmhip_seq_wait(G.ctx, j); F.sub[j].valid = 0; F.n_void++; }
+    rc = jmhip_seq_set_planes(G.ctx, e, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
+                              p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0]));
+    if (rc) adapter_die("jmhip_seq_set_planes", rc);
+    G.n_cur++;
+    if ((rc = jmhip_seq_encode(G.ctx, e, prm, F.cur_slot, d8, 1, NULL))) adapter_die("jmhip_seq_encode", rc);
+    F.sub[e].valid = 1; F.sub[e].pic = k; F.sub[e].slot = F.cur_slot; F.sub[e].prm = *prm;
+  }
+  F.tmpl[prm->slice_type] = *prm; F.have_tmpl[prm->slice_type] = 1;
+  /* ---- the next pictures: the frame from the file, the parameters of the last picture of the type the picture will have (IntraPeriod / IDRPeriod as
+   * get_idr_flag / set_slice_type apply them without B pictures; a wrong guess is found out above and costs the launch, never a byte) */
+  for (j = 1; j < F.depth && F.have_file; j++) {
+    const long n = k + j;
+    const int en = (int)(n % F.depth), sl = (int)(n % F.nring);
+    const int intra = (p_Inp->intra_period > 0 && n % p_Inp->intra_period == 0) || (p_Inp->idr_period > 0 && n % p_Inp->idr_period == 0);
+    jmhip_slice_params q;
+    int r, nref;
+    if (n >= F.total) break;
+    if (F.sub[en].valid && F.sub[en].pic == n) continue;    /* launched already */
+    if (!F.have_tmpl[intra ? I_SLICE : P_SLICE]) break;
+    q = F.tmpl[intra ? I_SLICE : P_SLICE];
+    if (!intra) {
+      /* list 0 of a P picture in a sliding window: the pictures before it, most recent first, as many as the last P picture had -- one more per picture while the window fills */
+      const int cap = p_Inp->P_List0_refs[0] ? imin(p_Inp->P_List0_refs[0], p_Vid->max_num_references) : p_Vid->max_num_references;
+      nref = imin(cap, (prm->slice_type == P_SLICE ? prm->num_ref : 0) + j);
+      if (p_Inp->idr_period > 0) nref = imin(nref, (int)(n % p_Inp->idr_period));
+      if (nref < 1) break;
+      q.num_ref = nref;
+      for (r = 0; r < JMHIP_MB_MAX_REF; r++) { q.ref_slot[r] = r < nref ? (int)((n - 1 - r) % F.nring) : 0; q.ref_id[r] = q.ref_slot[r]; }
+    }
+    if (!F.sub[en].raw && !(F.sub[en].raw = (uint8_t *)malloc((size_t)F.frame_bytes))) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+    if (pread(F.fd, F.sub[en].raw, (size_t)F.frame_bytes, (off_t)(F.header + F.frame_bytes * ((long)F.cur_frame_no + (long)j * F.frame_step + F.start_frame))) != (ssize_t)F.frame_bytes) break;
+    if ((rc = jmhip_seq_set_frame(G.ctx, en, F.sub[en].raw, F.src_w, F.src_h))) adapter_die("jmhip_seq_set_frame", rc);
+    if ((rc = jmhip_seq_encode(G.ctx, en, &q, sl, d8, 1, NULL))) adapter_die("jmhip_seq_encode (ahead of time)", rc);
+    F.sub[en].valid = 1; F.sub[en].pic = n; F.sub[en].slot = sl; F.sub[en].prm = q;
+    F.n_ahead++;
+  }
+  F.pic++;
+}
+
 static void pipe_run_slice(Macroblock *currMB)
 {
   Slice *currSlice = currMB->p_Slice;
@@ -1325,10 +1464,18 @@ static void pipe_run_slice(Macroblock *currMB)
   if (P.pic == p_Vid->enc_picture && first > 0 && first <= P.slice_last) { P.n_slices++; return; }      /* launched together with the picture's first slice */
   if (P.pic != p_Vid->enc_picture || first == 0) {          /* a new picture: its source planes go up once */
     P.pic = p_Vid->enc_picture; P.mbs = 0; P.deblocked = 0;
-    rc = jmhip_set_current_planes(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
-                                  p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0]));
-    if (rc) adapter_die("jmhip_set_current_planes", rc);
-    G.n_cur++;
+    flight_begin(p_Vid);
+    if (F.on) {                                             /* the picture's place in the ring of slots; its source goes up in flight_launch (or went up ahead of time) */
+      int s;
+      F.cur_entry = (int)(F.pic % F.depth); F.cur_slot = (int)(F.pic % F.nring);
+      for (s = 0; s < G.nslots; s++) if (G.slot_pic[s] == p_Vid->enc_picture) G.slot_pic[s] = NULL;
+      G.slot_pic[F.cur_slot] = p_Vid->enc_picture; G.slot_tick[F.cur_slot] = ++G.tick; G.slot_chroma[F.cur_slot] = 2;
+    } else {
+      rc = jmhip_set_current_planes(G.ctx, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
+                                    p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0]));
+      if (rc) adapter_die("jmhip_set_current_planes", rc);
+      G.n_cur++;
+    }
   }
   memset(&prm, 0, sizeof prm);
   init_enc_mb_params(currMB, &enc_mb, currSlice->slice_type == I_SLICE);
@@ -1341,7 +1488,8 @@ static void pipe_run_slice(Macroblock *currMB)
   prm.search_range = p_Vid->searchRange.max_x >> 2;
   prm.num_ref = currSlice->slice_type == I_SLICE ? 0 : currSlice->listXsize[LIST_0];
   for (r = 0; r < prm.num_ref; r++) {
-    prm.ref_slot[r] = slot_with_chroma(currSlice->listX[LIST_0][r]);
+    prm.ref_slot[r] = F.on ? slot_find(currSlice->listX[LIST_0][r]) : slot_with_chroma(currSlice->listX[LIST_0][r]);
+    if (prm.ref_slot[r] < 0) { fprintf(stderr, "jmhip adapter: pictures in flight: reference %d of picture %ld is not a picture the device holds\n", r, F.pic); exit(70); }
     prm.ref_id[r] = prm.ref_slot[r];
   }
   for (m = 0; m < 3; m++) prm.lambda_mf[m] = enc_mb.lambda_mf[m];
@@ -1396,7 +1544,8 @@ static void pipe_run_slice(Macroblock *currMB)
   /* SliceMode 1: every slice of the picture has the same parameters (no rate control here), so all of them are launched with the first one and
    * their wavefronts run side by side on the device; JM still codes them one after the other */
   if (p_Inp->slice_mode == FIXED_MB && first == 0 && prm.num_mb < left) prm.num_slices = (left + prm.num_mb - 1) / prm.num_mb;
-  if ((rc = jmhip_encode_slice_begin(G.ctx, &prm))) adapter_die("jmhip_encode_slice_begin", rc);
+  if (F.on) flight_launch(p_Vid, &prm);
+  else if ((rc = jmhip_encode_slice_begin(G.ctx, &prm))) adapter_die("jmhip_encode_slice_begin", rc);
   P.slice_last = prm.num_slices > 1 ? (int)p_Vid->PicSizeInMbs - 1 : first + prm.num_mb - 1;
   P.n_slices++; P.n_refs += prm.num_ref;
   P.t_dev += now_s() - t0;
@@ -1482,13 +1631,14 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
     const jmhip_mb_record *rec;
     int rc;
     t0 = now_s();
-    if ((rc = jmhip_slice_record(G.ctx, currMB->mbAddrX, &rec))) adapter_die("jmhip_slice_record", rc);     /* waits while the device is behind */
+    if (F.on) { if ((rc = jmhip_seq_record(G.ctx, F.cur_entry, currMB->mbAddrX, &rec))) adapter_die("jmhip_seq_record", rc); }
+    else if ((rc = jmhip_slice_record(G.ctx, currMB->mbAddrX, &rec))) adapter_die("jmhip_slice_record", rc);     /* waits while the device is behind */
     P.t_wait += now_s() - t0;
     if (TL_n) { TL_wait[TL_n - 1] += now_s() - t0; if (currMB->mbAddrX == 0) TL_first[TL_n - 1] = now_s(); if (currMB->mbAddrX == (int)p_Vid->PicSizeInMbs - 1) TL_last[TL_n - 1] = now_s(); }
     t0 = now_s();
     mb_from_record(currMB, rec);
     P.t_fill += now_s() - t0;
-    if (currMB->mbAddrX == P.slice_last && (rc = jmhip_encode_slice_end(G.ctx))) adapter_die("jmhip_encode_slice_end", rc);
+    if (!F.on && currMB->mbAddrX == P.slice_last && (rc = jmhip_encode_slice_end(G.ctx))) adapter_die("jmhip_encode_slice_end", rc);
     if (TL_n && currMB->mbAddrX == P.slice_last) TL_ended[TL_n - 1] = now_s();
   }
   P.mbs++; P.n_mbs++;
@@ -1500,6 +1650,12 @@ static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
   int rc;
   double t0 = now_s();
   if (!P.ok || P.pic != p_Vid->enc_picture || imgY != p_Vid->enc_picture->imgY || P.mbs != (int)p_Vid->PicSizeInMbs) return 0;
+  if (F.on) {                                               /* filtered (and interpolated) inside the picture's launch: wait for it, read its errors, fetch the picture */
+    if ((rc = jmhip_seq_wait(G.ctx, F.cur_entry))) adapter_die("jmhip_seq_wait", rc);
+    if ((rc = jmhip_seq_get_recon(G.ctx, F.cur_slot, imgY[0], (int)(imgY[1] - imgY[0]), imgUV[0][0], imgUV[1][0], (int)(imgUV[0][1] - imgUV[0][0])))) adapter_die("jmhip_seq_get_recon", rc);
+    P.deblocked = 1; G.n_deblock++; P.t_dev += now_s() - t0;
+    return 1;
+  }
   if ((rc = jmhip_deblock_picture_dev(G.ctx, p_Vid->active_sps->direct_8x8_inference_flag))) adapter_die("jmhip_deblock_picture_dev", rc);
   if ((rc = jmhip_get_recon(G.ctx, imgY[0], (int)(imgY[1] - imgY[0]), imgUV[0][0], imgUV[1][0], (int)(imgUV[0][1] - imgUV[0][0])))) adapter_die("jmhip_get_recon", rc);
   P.deblocked = 1;
@@ -1512,6 +1668,7 @@ static int pipe_reference(StorablePicture *s)
   int k, rc;
   double t0 = now_s();
   if (!P.ok || P.pic != s || !P.deblocked) return 0;
+  if (F.on) { G.n_interp++; return 1; }                     /* the planes are in the picture's slot already (flight_launch registered it) */
   k = slot_take(s);
   if ((rc = jmhip_reference_from_recon(G.ctx, k))) adapter_die("jmhip_reference_from_recon", rc);
   G.slot_chroma[k] = 2;                                     /* on the device, and nobody on the host needs the sub-images */
@@ -1521,6 +1678,7 @@ static int pipe_reference(StorablePicture *s)
 }
 static void pipe_report(void)
 {
+  if (F.on) fprintf(stderr, "jmhip adapter: pictures in flight: %ld pictures, %ld launched ahead of time (up to %d in flight), %ld of them served as launched, %ld voided\n", F.pic, F.n_ahead, F.depth, F.n_hit, F.n_void);
   if (P.n_slices)
     fprintf(stderr, "jmhip adapter: macroblock pipeline: %ld slices, %ld macroblocks encoded on the MI355X (encode_one_macroblock_low never ran on the host); "
                     "device calls %.3f s, waiting for records %.3f s, unpacking them %.3f s; wall time inside encode_one_slice %.3f s, pad_borders %.3f s, DeblockFrame %.3f s, getSubImagesLuma %.3f s\n",

@@ -38,6 +38,10 @@ CASES = {
     "q0c": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", SymbolMode="1", ProfileIDC="77", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
     "q0r": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="1", QPISlice="0", QPPSlice="0"), (176, 144), 3, False),
     "g2r": (dict(RDO_OFF, **SYN1080), (1920, 1080), 2, True),                                          # SURVEY 8c G2r = BASELINE configs[1], RDO off
+    # the same, six pictures: what a sequence with consecutive pictures in flight (jmhip_seq_*) must leave, picture by picture (bench.py checks its timed sequence against it)
+    "g6r": (dict(RDO_OFF, **dict(SYN1080, FramesToBeEncoded="6")), (1920, 1080), 6, True),
+    # six pictures of configs[2]'s search (EPZS, five references configured, CABAC): the temporal predictors and spatial memory over a longer chain (a million searches a picture)
+    "g6e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="6", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 6, True),
     # EPZS (SearchMode = 3) with the shipped EPZS switches (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid, EPZS sub-pel search)
     # BASELINE configs[2] without its 8x8 transform and B pictures: 1080p, Main profile, CABAC, EPZS, five references configured (two exist by the third picture)
     "g3e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 3, True),
