@@ -155,7 +155,7 @@ def clip_bytes(tag, c):
         data = np.concatenate(synth_motion.motion_clip(c["sw"], c["sh"], c["nfr"], int(clip.split(":")[1]), yuv422=clip.startswith("motion422")))
         assert hashlib.md5(data.tobytes()).hexdigest() == str(c["z"]["clip_md5"]), "the generated clip is not the one the golden records were made from"
         return data
-    if tag == "g2r" or clip == "True":
+    if tag in ("g2r", "g6r", "g6e") or clip == "True":
         import tempfile
         import bench
         with tempfile.TemporaryDirectory() as t:
@@ -169,7 +169,7 @@ def first_difference(want, got):
     return (len(bad), bad[:6], mb_tap.diff_fields(want[bad[0]], got[bad[0]]), want[bad[0]], got[bad[0]]) if bad else None
 
 
-@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y", "m2pd", "q1pd", "m3pe", "m2cq", "m2yc", "m3fl", "m3fm", "m2sl", "m2el", "m2es", "m5es"])
+@pytest.mark.parametrize("tag", ["q1r", "q5r", "q4r", "q4s", "g2r", "g6r", "g6e", "q1c", "q0c", "q0r", "q1e", "m5e", "m2c", "m3p", "m2t", "g3e", "q1h", "q2hc", "m3h", "m2he", "m1hq", "g3h", "q5f", "m5f", "m3fh", "g5f", "q5y", "q2yv", "m3y", "m2yq", "g4y", "m2pd", "q1pd", "m3pe", "m2cq", "m2yc", "m3fl", "m3fm", "m2sl", "m2el", "m2es", "m5es"])
 def test_encode_slice_equals_the_reference_encoder(tag):
     """The device against what JM's own encode_one_macroblock_low left behind: QCIF with one / five references, three slices, slices that start
     mid-row with two references and DFDisableIdc = 2, and BASELINE configs[1] with RDO off at 1920x1080 (SURVEY 8c G2r, 16 320 macroblocks).

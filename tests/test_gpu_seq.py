@@ -180,11 +180,11 @@ def test_seq_refuses_what_it_does_not_cover():
 
 
 def test_1080p_sequence_in_flight_equals_the_reference_encoder():
-    """configs[1] at its own size: the clip of SURVEY Appendix A, G2r's flags, eight pictures in flight; the I and the P picture's records against the REAL
-    encoder's (tests/golden/mb_low_g2r.npz), the later P pictures and every filtered picture / plane against the picture-after-picture path"""
+    """configs[1] at its own size: the clip of SURVEY Appendix A, G2r's flags, eight pictures in flight; the first six pictures' records against the REAL
+    encoder's (tests/golden/mb_low_g6r.npz: the tapped lencod, six pictures), the later ones and every filtered picture / plane against the picture-after-picture path"""
     import bench
     from test_gpu_mbenc import load_case
-    c = load_case("g2r")
+    c = load_case("g6r")
     W, H, R = c["W"], c["H"], c["R"]
     nmb = (W // 16) * (H // 16)
     frames = bench.yuv_frames(10)

@@ -126,6 +126,19 @@ def test_oracle_epzs_configs2_full_size():
     assert [s for s, _ in enc.epzs_stats] == [334560, 669120] and all(a == 0 for _, a in enc.epzs_stats)
 
 
+def test_oracle_epzs_six_pictures_full_size():
+    """Six pictures of the same search (g6e): five P pictures with up to five references -- the temporal predictors, the spatial memory and JM's 16-bit visited-map stamp
+    over a chain of 4.7 million searches (the stamp wraps round seventy times) without a single aliased candidate."""
+    enc = run_case("g6e")
+    assert len(enc.epzs_stats) == 5 and sum(s for s, _ in enc.epzs_stats) > 4000000 and all(s > 65535 for s, _ in enc.epzs_stats) and all(a == 0 for _, a in enc.epzs_stats)
+
+
+@pytest.mark.skipif(os.environ.get("JMO_LONG") != "1", reason="three minutes of oracle full searches: set JMO_LONG=1 (g2r pins the first two pictures of the same sequence)")
+def test_oracle_macroblock_pipeline_configs1_six_pictures():
+    """BASELINE configs[1] with RDOptimization = 0, six pictures (g6r): what the device's pictures in flight are checked against (tests/test_gpu_seq.py, bench.py)."""
+    run_case("g6r")
+
+
 def test_oracle_configs2_as_stated_full_size():
     """BASELINE configs[2] as stated -- 1080p, CABAC, 8x8 transform on (High profile), EPZS -- with RDO off and P pictures only (g3h): 24 480 macroblocks."""
     enc = run_case("g3h")
