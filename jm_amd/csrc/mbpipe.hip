@@ -125,6 +125,7 @@ struct PostShared {
   __attribute__((aligned(8))) u8 src[21][24];     // interpolation: source rows y0 - 2 .. y0 + 18, columns x0 - 4 .. x0 + 19
   int16_t h[21][16];                         // unclipped horizontal six-tap sums
   u8 v[16][20];                              // vertical half-pel samples (17 columns used)
+  __attribute__((aligned(16))) u8 outp[16][16][16];   // the block's sixteen planes [plane][row][column]: gathered here so that they leave as 16-byte write-through stores
 };
 
 // per-workgroup state in LDS
