@@ -551,6 +551,7 @@ int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pitchY, uint8_
  * side information (jmhip_deblock_picture[_dev]).
  * ------------------------------------------------------------------------------------------ */
 #define JMHIP_MB_MAX_REF 16
+#define JMHIP_SEQ_MAX_DEPTH 16        /* pictures in flight at most (jmhip_seq_open) */
 typedef struct {
   int8_t   mb_type;             /* 0 PSKIP, 1 P16x16, 2 P16x8, 3 P8x16, 8 P8x8, 9 I4MB, 10 I16MB, 13 I8MB (MBModeTypes, lencod/inc/defines.h:170-185) */
   int8_t   i16mode;             /* currMB->i16mode as find_sad_16x16 left it */
@@ -658,7 +659,7 @@ int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
  * picture to the next -- the pictures can follow each other at a distance of a few macroblock diagonals instead of a whole picture, every record and every sample
  * as JM leaves them.  (JM itself has no such mode; the hand-over is jm_amd/csrc/mbpipe_post.inc.)
  *
- * jmhip_seq_open gives the context `depth` entries (1 .. 8): a source picture, records, loop-filter side information and a HIP stream each.  A picture is
+ * jmhip_seq_open gives the context `depth` entries (1 .. JMHIP_SEQ_MAX_DEPTH): a source picture, records, loop-filter side information and a HIP stream each.  A picture is
  *   jmhip_seq_set_frame[_dev](entry, ...)      the source picture, as jmhip_set_current_frame[_dev]
  *   jmhip_seq_encode(entry, prm, out_slot, ..) the launch: jmhip_encode_slice_dev + jmhip_deblock_picture_dev + jmhip_reference_from_recon(out_slot) in one, asynchronous;
  *                                              a reference slot (prm->ref_slot[]) that an earlier jmhip_seq_encode is still writing is followed macroblock by macroblock

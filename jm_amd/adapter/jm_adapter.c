@@ -185,6 +185,69 @@ int __wrap___fprintf_chk(FILE *f, int flag, const char *fmt, ...)
   va_end(ap);
   return r;
 }
+/* part "lazyzero": JM's padded picture planes (get_mem2Dpel_pad .. get_mem5Dpel_pad, lcommon/src/memalloc.c:881-1022) are malloc + memset (mem_calloc, memalloc.h:204).
+ * alloc_storable_picture (mbuffer.c:438-456) makes 16 luma and 128 chroma sub-image planes that way for EVERY stored picture -- 0.84 GB of memset and a quarter of a million
+ * page faults per 2160p picture (0.21 GB at 1080p) -- and with the macroblock pipeline nobody on the host ever reads them (the device keeps its own).  The same
+ * pointer structures with calloc for the samples: the memory is as zero as JM makes it, but a plane nobody touches costs an mmap and a munmap instead of being written
+ * (M_MMAP_THRESHOLD is pinned so that every plane of a megabyte or more is mapped afresh).  JM's own free_mem*_pad free them: same layout, same allocator. */
+#include <malloc.h>
+static int lz_on(void)
+{
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("JMHIP_ADAPTER"), *parts = getenv("JMHIP_ADAPTER_PARTS"), *p;
+    on = !(e && !strcmp(e, "off"));
+    if (on && parts) { on = 0; for (p = parts; (p = strstr(p, "lazyzero")); p += 8) if ((p == parts || p[-1] == ',') && (p[8] == 0 || p[8] == ',')) on = 1; }
+    if (on) mallopt(M_MMAP_THRESHOLD, 1 << 20);
+  }
+  return on;
+}
+static void lz_nomem(void) { fprintf(stderr, "jmhip adapter: out of memory (picture planes)\n"); exit(70); }
+static int lz_2d(imgpel ***a, int d0, int d1, int py, int px)
+{
+  const int h = d0 + 2 * py, w = d1 + 2 * px;
+  imgpel *cur;
+  int i;
+  if (!(*a = (imgpel **)malloc((size_t)h * sizeof(imgpel *)))) lz_nomem();
+  if (!((*a)[0] = (imgpel *)calloc((size_t)h * w, sizeof(imgpel)))) lz_nomem();
+  (*a)[0] += px;
+  cur = (*a)[0];
+  for (i = 1; i < h; i++) { cur += w; (*a)[i] = cur; }
+  *a = &(*a)[py];
+  return h * (int)(sizeof(imgpel *) + w * sizeof(imgpel));
+}
+static int lz_3d(imgpel ****a, int d0, int d1, int d2, int py, int px)
+{
+  int i, n = d0 * (int)sizeof(imgpel **);
+  if (!(*a = (imgpel ***)malloc((size_t)d0 * sizeof(imgpel **)))) lz_nomem();
+  for (i = 0; i < d0; i++) n += lz_2d((*a) + i, d1, d2, py, px);
+  return n;
+}
+static int lz_4d(imgpel *****a, int d0, int d1, int d2, int d3, int py, int px)
+{
+  int i, n = d0 * (int)sizeof(imgpel ***);
+  if (!(*a = (imgpel ****)malloc((size_t)d0 * sizeof(imgpel ***)))) lz_nomem();
+  n += lz_3d(*a, d0 * d1, d2, d3, py, px);
+  for (i = 1; i < d0; i++) (*a)[i] = (*a)[i - 1] + d1;
+  return n;
+}
+extern int __real_get_mem2Dpel_pad(imgpel ***, int, int, int, int);
+extern int __real_get_mem3Dpel_pad(imgpel ****, int, int, int, int, int);
+extern int __real_get_mem4Dpel_pad(imgpel *****, int, int, int, int, int, int);
+extern int __real_get_mem5Dpel_pad(imgpel ******, int, int, int, int, int, int, int);
+int __wrap_get_mem2Dpel_pad(imgpel ***a, int d0, int d1, int py, int px) { return lz_on() ? lz_2d(a, d0, d1, py, px) : __real_get_mem2Dpel_pad(a, d0, d1, py, px); }
+int __wrap_get_mem3Dpel_pad(imgpel ****a, int d0, int d1, int d2, int py, int px) { return lz_on() ? lz_3d(a, d0, d1, d2, py, px) : __real_get_mem3Dpel_pad(a, d0, d1, d2, py, px); }
+int __wrap_get_mem4Dpel_pad(imgpel *****a, int d0, int d1, int d2, int d3, int py, int px) { return lz_on() ? lz_4d(a, d0, d1, d2, d3, py, px) : __real_get_mem4Dpel_pad(a, d0, d1, d2, d3, py, px); }
+int __wrap_get_mem5Dpel_pad(imgpel ******a, int d0, int d1, int d2, int d3, int d4, int py, int px)
+{
+  int i, n = d0 * (int)sizeof(imgpel ****);
+  if (!lz_on()) return __real_get_mem5Dpel_pad(a, d0, d1, d2, d3, d4, py, px);
+  if (!(*a = (imgpel *****)malloc((size_t)d0 * sizeof(imgpel ****)))) lz_nomem();
+  n += lz_4d(*a, d0 * d1, d2, d3, d4, py, px);
+  for (i = 1; i < d0; i++) (*a)[i] = (*a)[i - 1] + d1;
+  return n;
+}
+
 /* part "readframe": buf2img_basic (lcommon/src/input.c:552) widens the file's bytes to imgpel one memcpy at a time (12 ms per 1080p picture); the same
  * assignment as a plain loop the compiler vectorises, for the case JM's first branch of the 8-bit path covers (equal sizes); everything else is JM's. */
 extern void buf2img_basic(imgpel **imgX, unsigned char *buf, int size_x, int size_y, int o_size_x, int o_size_y, int symbol_size_in_bytes, int bitshift);
