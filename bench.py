@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- encoded macroblocks/sec of the MI355X hot path on synthetic 1080p (BASELINE.json configs[1]).
 
-One "step" = one P picture of configs[1] (1920x1080 coded as 1920x1088 = 8160 macroblocks, Baseline IPPP, FullSearch SR = 32, one reference,
-QP 28, RDOptimization = 0 / AdaptiveRounding = 0: the configuration whose output the tests prove bit-identical to CPU JM) through
-the device-resident macroblock pipeline, inputs already in HBM:
-  jmhip_encode_slice_dev     encode_one_macroblock_low of every macroblock on the x + 2y wavefront: MV prediction, 41 full searches at each
-                             block's own centre, sub-pel refinement, mode decision (inter / P8x8 / Intra4x4 / Intra16x16), transform / quantisation /
-                             reconstruction of the winner, the macroblock records the host's entropy coder reads            (kernel k_mb_pipe)
-  jmhip_deblock_picture_dev  DeblockFrame on the reconstruction, side information straight from the pipeline
-  jmhip_reference_from_recon getSubImagesLuma + the chroma planes: the next picture's reference, without leaving the device
-The reference the P picture searches is the clip's I picture as the same pipeline coded it.  After the timed region the records are compared
-with the REAL reference encoder's (tests/golden/mb_low_g2r.npz): `records_equal_jm` must be true or the number is void.
+One "step" = the next P picture of ONE IPPP sequence of configs[1] (1920x1080 coded as 1920x1088 = 8160 macroblocks, Baseline, FullSearch SR = 32, one reference = the
+picture before, QP 28, RDOptimization = 0 / AdaptiveRounding = 0: the configuration whose output the tests prove bit-identical to CPU JM), inputs already in HBM:
+  jmhip_seq_set_frame_dev    read_one_frame + pad_borders from the file's bytes (k_load_frame)
+  jmhip_seq_encode           ONE launch of k_mb_pipe: encode_one_macroblock_low of every macroblock on the x + 2y wavefront -- MV prediction, 41 full searches at each block's own
+                             centre, sub-pel refinement, mode decision, transform / quantisation / reconstruction, the record JM's entropy coder reads -- and, behind each
+                             macroblock, its DeblockMb and its share of getSubImagesLuma's sixteen planes (jm_amd/csrc/mbpipe_post.inc)
+Up to --flight (8) consecutive pictures are in flight side by side: a macroblock of picture n + 1 starts as soon as picture n is filtered and interpolated five macroblocks to its
+right and below.  The timed region starts and ends with an idle device.  After it every picture's records are compared with the REAL reference encoder's
+(tests/golden/mb_low_g6r.npz, six pictures) and with the same sequence coded picture after picture: `records_equal_jm` and `records_equal_picture_after_picture` must be true or
+the number is void.
 `end_to_end` is the unmodified lencod with this path linked in (oracle/_ref/lencod_hip.exe) on the same clip and flags, next to CPU JM
 (`cpu_baseline`, oracle/_ref/lencod.exe, one thread) -- both print their own per-picture times; the .264 md5s are compared.
 
 python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, one rank per GPU)
-N > 1: BASELINE configs[3] with RDO off -- one 2160p picture, 8 slices dealt to the N GPUs (multi_gpu_configs3 below): strong scaling of one sequence,
-with the N-independent-sequences figure beside it.  Prints ONE JSON line on rank 0.
+N > 1: the same step on every GPU, one closed GOP (I + P pictures) per GPU, no collective on the data path: weak scaling, `value` = all GPUs' macroblocks / the slowest
+rank's time.  BASELINE configs[3] with RDO off -- one 2160p picture, 8 slices dealt to the N GPUs with one RCCL all-gather per picture (multi_gpu_configs3 below: strong scaling
+of one picture) -- is measured in the same run (`configs3_slice_split`).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -472,38 +473,11 @@ def multi_gpu_configs3(args, world, rank, local, dev, one_gpu):
         md5_ok = hashlib.md5(rec_i + flat(ctx.get_recon())).hexdigest() == gold
     ctx.close()
 
-    # ---------------- the other use of N GPUs: one independent 1080p sequence per GPU (configs[1]'s step), no collective
-    c1 = JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1, device=local, stream=stream.cuda_stream)
-    f0, f1 = yuv_frames(2, seed=1234 + rank)
-    n1 = (W // 16) * (H // 16)
-    c1.set_current_frame(f0, W, H_SRC)
-    c1.encode_slice_dev(slice_params(SLICE_PARAMS, 2, 0, n1, 0, 0))
-    c1.deblock_picture_dev(1)
-    c1.reference_from_recon(0)
-    c1.set_current_frame(f1, W, H_SRC)
-    p1 = slice_params(SLICE_PARAMS, 0, 0, n1, 0, 1)
-    p1["ref_slot"][0, 0] = 0
-
-    def step1():
-        c1.encode_slice_dev(p1)
-        c1.deblock_picture_dev(1)
-        c1.reference_from_recon(1)
-    for i in range(args.warmup):
-        step1()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step1()
-    barrier()
-    dt1 = max_over_ranks(time.perf_counter() - t0)
-    c1.synchronize()
-    c1.close()
-
     if rank == 0:
         alg_mb = 6656 + 328 + 128 + 2900 + 1216 + 384       # as at N = 1
         alg = alg_mb * mine
         out = {
-            "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), 1080p IPPP SR=32",
+            "metric": "encoded macroblocks/sec (bit-exact vs CPU JM), ONE 2160p picture's 8 slices dealt to the GPUs, SR=32 (BASELINE configs[3], strong scaling)",
             "value": round(nmb * args.steps / dt, 1), "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -515,15 +489,13 @@ def multi_gpu_configs3(args, world, rank, local, dev, one_gpu):
                                       + (" [UNMEASURED debugging path: all ranks on one GPU, exchange over gloo on host copies]" if one_gpu else ""),
                        "recon_md5_equals_cpu_jm": md5_ok,
                        "note": "one GPU already runs all eight slices side by side (configs3 object of the N = 1 line): a slice is a chain of 240 + 2 x 16 dependent macroblocks "
-                               "whatever the number of GPUs, so the split cannot go below one slice's chain plus the exchange; N GPUs pay off for N sequences (independent_sequences)"},
+                               "whatever the number of GPUs, so the split cannot go below one slice's chain plus the exchange; N GPUs pay off for N closed GOPs (this line's `value`)"},
             "roofline": {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "traffic": None, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
                          "note": "the slowest rank's launch over its own slices"},
-            "independent_sequences": {"workload": "configs[1]'s step (1080p P picture, 8160 MB) on every GPU, one sequence each, no collective", "scaling": "weak",
-                                      "macroblocks_per_s": round(n1 * world * args.steps / dt1, 1), "ms_per_step": round(dt1 / args.steps * 1e3, 4)},
         }
-        print(json.dumps(out))
-    dist.destroy_process_group()
+        return out
+    return None
 
 
 def main():
@@ -559,12 +531,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_gpu else "nccl", **({} if one_gpu else {"device_id": dev}))
-    if world > 1:
-        return multi_gpu_configs3(args, world, rank, local, dev, one_gpu)
-    N, HP = 1, H
+    # N > 1: the SAME step on every GPU -- each rank codes its own closed GOP (an I picture and its P pictures: what JM writes with IDRPeriod = the GOP's length needs nothing
+    # of the GOP before it), no collective on the data path (weak scaling); the slice split of configs[3] with its all-gather is measured beside it (configs3_slice_split)
+    N, HP = world, H
     mbw, mbh = W // 16, H // 16
     nmb = mbw * mbh
     depth = max(1, min(8, args.flight))
+    if one_gpu and world > 1:
+        depth = max(1, 4 // world)                                        # the ranks share one GPU: the launches in flight of ALL of them must leave room for each rank's oldest picture
     nslots = depth + 2                                                     # one reference + the pictures in flight + one: no launch ever waits for a slot
     nseq = 1 + args.warmup + args.steps                                    # the I picture, the warm-up and the timed P pictures: one IPPP sequence
 
@@ -583,7 +557,7 @@ def main():
 
     # ---------------- inputs: the clip (continued), every source picture resident in HBM as the file holds it before the clock starts
     src_h = H_SRC
-    frames = yuv_frames(nseq)
+    frames = yuv_frames(nseq, seed=1234 + rank)                          # rank 0: the clip the golden records were made from
     raw0, raw1 = frames[0], frames[1]
     d_raw = torch.from_numpy(np.stack(frames)).to(dev)
     d_recs = torch.zeros((nseq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)      # every picture's records (the entries' own are reused)
@@ -597,7 +571,16 @@ def main():
         ctx.seq_encode(e, seq_prm(k), k % nslots, 1, False, d_recs[k].data_ptr())
 
     def barrier():
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
+
+    def over_ranks(x, op):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
     for k in range(1 + args.warmup):                                       # the I picture and the warm-up P pictures
         step(k)
@@ -606,12 +589,12 @@ def main():
     for k in range(1 + args.warmup, nseq):
         step(k)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)
     kernel_ms = [ctx.seq_kernel_ms(e) for e in range(min(depth, args.steps))]      # the last launches, in flight together
     for e in range(depth):
         ctx.seq_wait(e)                                                    # reads the device-side error words: the pipeline's is sticky (a launch that finds it set does nothing), so an incomplete picture cannot go unnoticed
     ctx.synchronize()
-    pipe_ms = float(np.mean(kernel_ms))
+    pipe_ms = over_ranks(float(np.mean(kernel_ms)), dist.ReduceOp.MAX)
     recs_all = d_recs.cpu().numpy().view(MB_RECORD).reshape(nseq, nmb)
 
     # ---------------- the same sequence picture after picture (k_mb_pipe, then DeblockFrame, then getSubImagesLuma, each waiting for the one before): the round-3 step.
@@ -633,13 +616,14 @@ def main():
         ctx.reference_from_recon(k & 1)
     ctx.synchronize()
     classic_s = time.perf_counter() - t1
+    same = over_ranks(1.0 if same else 0.0, dist.ReduceOp.MIN) == 1.0    # every rank's GOP
 
     # ---------------- the records against the real encoder's (the pictures the committed dumps hold)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import mb_tap
     gname = "mb_low_g6r.npz" if os.path.exists(os.path.join(ROOT, "tests", "golden", "mb_low_g6r.npz")) else "mb_low_g2r.npz"
     gold = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", gname))["records"])
-    ngold = min(len(gold) // nmb, nseq)
+    ngold = min(len(gold) // nmb, nseq) if rank == 0 else 0              # the golden records are of rank 0's clip
     equal = True
     for k in range(ngold):
         mine = np.frombuffer(recs_all[k].tobytes(), gold.dtype).copy()
@@ -647,6 +631,10 @@ def main():
     types = np.bincount(recs_all[1 + args.warmup:]["mb_type"].astype(int).ravel(), minlength=14)
 
     # ---------------- configs[2]'s search on the same pictures: the P picture through k_mb_pipe_epzs (EPZS, CABAC), records against the real encoder's (g3e)
+    slice_split = None
+    if world > 1:
+        ctx.close()
+        slice_split = multi_gpu_configs3(args, world, rank, local, dev, one_gpu)
     configs2_device = {}
     if N == 1 and rank == 0:
         def epzs_prm(slice_type, num_ref, poc_cur):
@@ -731,18 +719,21 @@ def main():
             "value": round(total_mb / dt, 1), "unit": "macroblocks/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP, one sequence: a step is the next P picture of it -- read_one_frame / pad_borders from the "
+            "config": {"workload": ("" if N == 1 else f"{N} GPUs, one closed GOP of the workload below per GPU (no collective on the data path; a step = one picture on EVERY GPU).  ") +
+                                   "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP, one sequence: a step is the next P picture of it -- read_one_frame / pad_borders from the "
                                    "file's bytes in HBM, encode_one_macroblock_low of every macroblock on the device (FullSearch SR=32 at every block's own centre, 1 ref = the picture before, QP 28, "
                                    "mode decision, transform/quant, reconstruction), DeblockFrame, getSubImagesLuma -- with up to `pictures_in_flight` consecutive pictures in flight; the timed region "
                                    "starts and ends with an idle device (pipeline fill and drain are inside it); entropy coding is the host's and is outside the step (see end_to_end)",
                        "macroblocks_per_step_per_gpu": nmb, "search_range": R, "pictures_in_flight": depth, "workgroups_per_picture": args.workgroups or min(80, 256 // depth),
-                       "parallelism": "1 GPU",
+                       "parallelism": "1 GPU" if N == 1 else f"{N} GPUs x one GOP each (JM with IDRPeriod = GOP length codes the same pictures: closed GOPs are independent)",
                        "records_equal_jm": bool(equal), "pictures_checked_against_jm": ngold,
                        "records_equal_picture_after_picture": bool(same), "pictures_checked_against_picture_after_picture": nseq,
                        "picture_after_picture_ms_per_picture": round(classic_s / nseq * 1e3, 2),
                        "mb_types_pskip_16x16_16x8_8x16_p8x8_i4_i16": [int(types[k]) for k in (0, 1, 2, 3, 8, 9, 10)]},
             "roofline": roof,
         }
+        if slice_split is not None:
+            out["configs3_slice_split"] = slice_split
         cpu = None
         if not args.no_cpu_baseline and N == 1:                       # rank 0 at N = 1 only
             cpu = cpu_baseline()
@@ -756,6 +747,8 @@ def main():
         if args.streams > 1 and N == 1:
             out["concurrent_streams"] = concurrent_streams(args.streams, raw0, raw1, src_h, slice_prm, local, min(args.steps, 20))
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -612,7 +612,9 @@ typedef struct {
   int32_t epzs_reserved_;
   int32_t poc_cur;              /* enc_picture->poc */
   int32_t poc_ref[JMHIP_MB_MAX_REF];   /* listX[LIST_0][r]->poc: EPZS scales its predictors by picture distances; the temporal predictors are the vectors
-                                   jmhip_reference_from_recon kept with slots ref_slot[0] / [1] (a slot loaded by jmhip_set_reference has none: zero vectors) */
+                                   jmhip_reference_from_recon kept with slots ref_slot[0] / [1] (a slot loaded by jmhip_set_reference has none: zero vectors).  Every picture of
+                                   an EPZS sequence -- its I pictures too -- is launched with search_mode 3 and its picture order counts: a picture launched otherwise leaves
+                                   "no motion" with its slot, not JM's mv_info */
   /* High profile (ignored with transform8x8 0) */
   int32_t transform8x8;         /* p_Inp->Transform8x8Mode: 0, or 1 = the 8x8 transform beside the 4x4 one: transform_decision (macroblock.c:1347) for 16x16 / 16x8 / 8x16,
                                    the tr8x8 pass of P8x8 (mode_decision_P8x8.c:681), Intra8x8 (transform8x8.c:241), 8x8 Hadamard SATD in the sub-pel search of

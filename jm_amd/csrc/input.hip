@@ -135,17 +135,22 @@ __global__ __launch_bounds__(256) void k_load_frame_ex(const uint8_t *__restrict
   const int rr = min(r, p.oh - 1), cc = min(c, p.ow - 1);          // pad_borders: right of / below the picture repeats the last column / row
   const bool same = p.w == p.ow && p.h == p.oh;
   long si = -1;                                                   // index of the file sample that lands at (rr, cc), or none
+  long sbyte = -1;                                                // ... or its byte offset where JM itself counts in bytes
   if (!a.bitshift_fn && a.sb == 2 && same) {                      // buf2img_basic's single memcpy: w * h samples back to back in rows that are cw apart
     const long f = (long)rr * p.cw + cc;
     if (f < (long)p.w * p.h) si = f;
   } else {
     const int iw = min(p.w, p.ow), ih = min(p.h, p.oh);
     const int dx = (!same && p.ow >= p.w) ? (p.ow - p.w) >> 1 : 0, dy = (!same && p.oh >= p.h) ? (p.oh - p.h) >> 1 : 0;
-    if (rr >= dy && rr < dy + ih && cc >= dx && cc < dx + iw) si = (long)(rr - dy) * p.w + (cc - dx);
+    if (rr >= dy && rr < dy + ih && cc >= dx && cc < dx + iw) {
+      si = (long)(rr - dy) * p.w + (cc - dx);
+      // buf2img_basic :586-588 (imgpel-sized samples, sizes differ): the row is taken at temp_buf[row * size_x], an unsigned char pointer -- row * size_x BYTES into the plane
+      if (!a.bitshift_fn && a.sb == 2) sbyte = (long)(rr - dy) * p.w + 2 * (cc - dx);
+    }
   }
   int val = 0;
   if (si >= 0) {
-    const uint8_t *s = raw + p.src_off + si * a.sb;
+    const uint8_t *s = raw + p.src_off + (sbyte >= 0 ? sbyte : si * a.sb);
     val = a.sb == 1 ? s[0] : (int)s[0] | ((int)s[1] << 8);
     if (a.bitshift_fn) val = p.shift > 0 ? (val + (1 << (p.shift - 1))) >> p.shift : val << (-p.shift);       // rshift_rnd
   }

@@ -229,6 +229,10 @@ class JmHip:
     def load_frame(self, raw, yuv, src_w, src_h, out_w, out_h, symbol_bytes, src_depth, out_depth):
         """jmhip_load_frame: the general reader; (y, u, v) uint16 planes of the coded size (u, v None at 4:0:0)"""
         raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
+        sx, sy = (1 if yuv in (1, 2) else 0), (1 if yuv == 1 else 0)
+        need = (src_w * src_h + (2 * (src_w >> sx) * (src_h >> sy) if yuv else 0)) * symbol_bytes
+        if raw.size < need:                                   # the library copies `need` bytes from this buffer
+            raise ValueError(f"load_frame: {raw.size} bytes for a {src_w}x{src_h} frame of format {yuv} with {symbol_bytes}-byte samples ({need} needed)")
         W, H = (int(out_w) + 15) // 16 * 16, (int(out_h) + 15) // 16 * 16
         f = np.zeros(1, FRAME_FORMAT)
         f["yuv_format"], f["src_w"], f["src_h"], f["out_w"], f["out_h"], f["coded_w"], f["coded_h"], f["symbol_bytes"] = yuv, src_w, src_h, out_w, out_h, W, H, symbol_bytes

@@ -124,7 +124,9 @@ static void load_plane_ex(const uint8_t *buf, int w, int h, int ow, int oh, int 
   } else
   for (y = 0; y < ih; y++)
     for (x = 0; x < iw; x++) {
-      const uint8_t *p = buf + ((long)y * w + x) * sb;
+      /* buf2img_basic :586-588 (imgpel-sized samples, sizes differ): row y is taken at temp_buf[y * size_x] -- an unsigned char pointer, so the row starts y * size_x BYTES
+       * into the plane, not y * size_x samples; that, too, is what the reference encodes */
+      const uint8_t *p = (!bitshift_fn && sb == 2) ? buf + (long)y * w + 2 * x : buf + ((long)y * w + x) * sb;
       int v = sb == 1 ? p[0] : p[0] | (p[1] << 8);
       if (bitshift_fn) v = shift > 0 ? (v + (1 << (shift - 1))) >> shift : v << (-shift);
       out[(long)(y + dy) * cw + x + dx] = (jmo_pel)v;

@@ -30,6 +30,10 @@ CASES = [
     (2, 38, 22, 38, 22, 2, 9, 9),       # 4:2:2, 9 bit
     (1, 176, 144, 176, 144, 1, 8, 8),   # QCIF, the common case
     (3, 20, 20, 24, 20, 1, 8, 12),      # 4:4:4, wider output, 8 -> 12 bit (two-byte samples may not be scaled up: input.c:440-443)
+    # two-byte samples at equal depth with a size mismatch: buf2img_basic takes row i at BYTE offset i * size_x (input.c:586-588), i.e. half way into the sample row
+    (1, 40, 24, 48, 32, 2, 10, 10),     # centred
+    (1, 52, 40, 48, 32, 2, 10, 10),     # cropped
+    (3, 20, 20, 24, 20, 2, 12, 12),     # 4:4:4, wider output
 ]
 
 
