@@ -646,6 +646,14 @@ int jmhip_get_recon(jmhip_ctx *ctx, uint16_t *y, int32_t pitch_y, uint16_t *u, u
  * several devices exchanges these rows together with the reconstruction's before the picture is deblocked (DeblockFrame filters across slice
  * edges unless DFDisableIdc = 2: lencod/src/loopFilter.c:159-165 reads the neighbouring slice's macroblocks). */
 int jmhip_deblock_side_info_dev(jmhip_ctx *ctx, jmhip_db_mb **d_mbs, jmhip_db_motion **d_motion);
+/* One picture's slices dealt to several devices (SURVEY.md 8e / 8b viii: JM shards a picture only by slice, lencod/src/slice.c:431; BASELINE configs[3]): one process, n
+ * contexts of the same picture size -- one per device (or several on one) --, context r has coded the slices that make up macroblock rows [r * band_mb_rows,
+ * (r + 1) * band_mb_rows) of the current picture (jmhip_encode_slice[_dev / _begin]; the last band may be shorter).  The call gives EVERY context every band: the rows of
+ * the un-deblocked reconstruction (Y, U, V) and of the loop filter's side information (jmhip_db_mb, jmhip_db_motion), so that each can run jmhip_deblock_picture_dev
+ * (DeblockFrame filters across slice edges unless DFDisableIdc = 2: loopFilter.c:159-165) and jmhip_reference_from_recon on the whole picture -- the next picture's
+ * search windows reach into the neighbouring bands.  Peer-to-peer copies (hipMemcpyPeerAsync over xGMI between devices), each destination's copies on its own stream behind
+ * an event of the source's stream; asynchronous like the launches around it.  (One process per GPU: the same exchange is one RCCL all-gather, jm_amd/shard.py BandGather.) */
+int jmhip_allgather_bands(jmhip_ctx *const *ctx, int32_t n, int32_t band_mb_rows);
 /* DeblockFrame on that reconstruction with the side information the slices' macroblocks left on the device */
 int jmhip_deblock_picture_dev(jmhip_ctx *ctx, int32_t direct_8x8_inference);
 /* getSubImagesLuma (+ the integer chroma planes) of the reconstruction into a reference slot, without leaving the device */

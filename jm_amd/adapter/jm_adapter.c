@@ -65,6 +65,8 @@ static struct {
   int         part_interp, part_fs, part_subpel, part_ffs, part_deblock, part_tq4, part_tq8, part_tqc, part_tq16, part_mcl, part_mcc, part_eval, part_ip4, part_i16, part_interpc, part_evalp, part_load, part_ic, part_ip8, part_mbpipe, part_evalbatch;
   int         in_real_me;             /* inside one of JM's own search functions: its computeSAD / computeSATD calls stay on the host */
   jmhip_ctx  *ctx;
+  jmhip_ctx  *ctxs[8];                /* JMHIP_DEVICES=d0,d1,...: one context per entry (ctxs[0] = ctx); a SliceMode 1 picture's slices are dealt to them */
+  int         nctx;
   int         W, H, fmt, R, nslots;
   StorablePicture *slot_pic[MAX_SLOTS];
   unsigned    slot_tick[MAX_SLOTS], tick;
@@ -123,6 +125,7 @@ static void adapter_report(void)
                   "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld; chroma intra predictions on the MI355X: %ld macroblocks; Intra8x8 predictions on the MI355X: %ld blocks\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
           G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load, G.n_ic, G.n_ip8);
+  { int k_; for (k_ = 1; k_ < G.nctx; k_++) if (G.ctxs[k_]) jmhip_destroy(G.ctxs[k_]); }
   if (G.ctx) jmhip_destroy(G.ctx);
   G.ctx = NULL;
 }
@@ -322,10 +325,24 @@ static int adapter_on(VideoParameters *p_Vid)
     memset(&cfg, 0, sizeof cfg);
     cfg.device = getenv("JMHIP_DEVICE") ? atoi(getenv("JMHIP_DEVICE")) : 0;
     cfg.width = G.W; cfg.height = G.H; cfg.yuv_format = G.fmt; cfg.bit_depth = 8; cfg.search_range = G.R; cfg.num_ref_slots = G.nslots;
-    rc = jmhip_create(&G.ctx, &cfg);
-    if (rc != JMHIP_OK) {                                /* the library has no CPU fallback; say so and stop */
-      fprintf(stderr, "jmhip adapter: jmhip_create failed (%d): %s\n", rc, jmhip_last_error(NULL));
-      exit(70);
+    {
+      /* JMHIP_DEVICES=0,1,...: a context per listed device (a device may be listed more than once); used when a picture comes in slices (SliceMode 1) */
+      const char *dl = getenv("JMHIP_DEVICES");
+      int devs[8], nd = 0, k;
+      if (dl && G.part_mbpipe && p_Inp->rdopt == 0 && p_Inp->slice_mode == FIXED_MB)
+        while (*dl && nd < 8) { devs[nd++] = atoi(dl); dl = strchr(dl, ','); if (!dl) break; dl++; }
+      if (nd > 1) cfg.device = devs[0];
+      rc = jmhip_create(&G.ctx, &cfg);
+      if (rc != JMHIP_OK) {                                /* the library has no CPU fallback; say so and stop */
+        fprintf(stderr, "jmhip adapter: jmhip_create failed (%d): %s\n", rc, jmhip_last_error(NULL));
+        exit(70);
+      }
+      G.ctxs[0] = G.ctx; G.nctx = 1;
+      for (k = 1; k < nd; k++) {
+        cfg.device = devs[k];
+        if ((rc = jmhip_create(&G.ctxs[k], &cfg)) != JMHIP_OK) { fprintf(stderr, "jmhip adapter: jmhip_create on device %d failed (%d): %s\n", devs[k], rc, jmhip_last_error(NULL)); exit(70); }
+        G.nctx = k + 1;
+      }
     }
     G.planes = (uint16_t *)malloc((size_t)16 * (G.W + 2 * JMHIP_PAD_X) * (G.H + 2 * JMHIP_PAD_Y) * sizeof(uint16_t));
     G.tables = (uint16_t *)malloc((size_t)7 * 16 * (2 * G.R + 1) * (2 * G.R + 1) * sizeof(uint16_t));
@@ -1338,6 +1355,7 @@ static struct {
   int mbs;                            /* its macroblocks served so far */
   int deblocked;
   int slice_last;                     /* last macroblock the running launch covers (one slice, or every slice of the picture) */
+  int dealt, share_mbs, band_rows;    /* the picture's slices are dealt to G.nctx contexts: macroblocks / macroblock rows per context */
   long n_slices, n_mbs, n_refs;
   double t_dev, t_fill, t_wait;
 } P;
@@ -1607,7 +1625,26 @@ static void pipe_run_slice(Macroblock *currMB)
   /* SliceMode 1: every slice of the picture has the same parameters (no rate control here), so all of them are launched with the first one and
    * their wavefronts run side by side on the device; JM still codes them one after the other */
   if (p_Inp->slice_mode == FIXED_MB && first == 0 && prm.num_mb < left) prm.num_slices = (left + prm.num_mb - 1) / prm.num_mb;
-  if (F.on) flight_launch(p_Vid, &prm);
+  P.dealt = 0;
+  if (G.nctx > 1 && first == 0 && prm.num_slices > 1 && prm.num_slices % G.nctx == 0 && prm.num_mb % (int)p_Vid->PicWidthInMbs == 0) {
+    /* the slices dealt to the devices in order, num_slices / nctx each: every device gets the source picture and launches its share; the records come back from the
+     * device that owns the macroblock, the bands are exchanged before DeblockFrame (pipe_deblock), every device keeps the whole reference */
+    const int spr = prm.num_slices / G.nctx;
+    int c;
+    for (r = 0; r < prm.num_ref; r++)
+      if (slot_find(currSlice->listX[LIST_0][r]) != prm.ref_slot[r] || G.slot_chroma[prm.ref_slot[r]] != 2) { fprintf(stderr, "jmhip adapter: slices dealt to %d devices: reference %d is not a picture every device holds\n", G.nctx, r); exit(70); }
+    P.dealt = 1; P.share_mbs = spr * prm.num_mb; P.band_rows = P.share_mbs / (int)p_Vid->PicWidthInMbs;
+    for (c = 0; c < G.nctx; c++) {
+      jmhip_slice_params q = prm;
+      q.first_mb = c * P.share_mbs; q.num_slices = spr; q.slice_nr = prm.slice_nr + c * spr;
+      if (spr == 1) q.num_mb = imin(prm.num_mb, (int)p_Vid->PicSizeInMbs - q.first_mb);      /* the picture's last slice may be shorter */
+      if (c && (rc = jmhip_set_current_planes(G.ctxs[c], p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
+                                              p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0])))) adapter_die("jmhip_set_current_planes", rc);
+      if ((rc = jmhip_encode_slice_begin(G.ctxs[c], &q))) { fprintf(stderr, "jmhip adapter: device %d: %s\n", c, jmhip_last_error(G.ctxs[c])); adapter_die("jmhip_encode_slice_begin", rc); }
+    }
+  }
+  else if (G.nctx > 1) { fprintf(stderr, "jmhip adapter: JMHIP_DEVICES names %d contexts but this picture's %d slice(s) of %d macroblocks cannot be dealt to them (whole rows, a multiple of the contexts)\n", G.nctx, prm.num_slices > 1 ? prm.num_slices : 1, prm.num_mb); exit(70); }
+  else if (F.on) flight_launch(p_Vid, &prm);
   else if ((rc = jmhip_encode_slice_begin(G.ctx, &prm))) adapter_die("jmhip_encode_slice_begin", rc);
   P.slice_last = prm.num_slices > 1 ? (int)p_Vid->PicSizeInMbs - 1 : first + prm.num_mb - 1;
   P.n_slices++; P.n_refs += prm.num_ref;
@@ -1695,12 +1732,17 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
     int rc;
     t0 = now_s();
     if (F.on) { if ((rc = jmhip_seq_record(G.ctx, F.cur_entry, currMB->mbAddrX, &rec))) adapter_die("jmhip_seq_record", rc); }
+    else if (P.dealt) { if ((rc = jmhip_slice_record(G.ctxs[currMB->mbAddrX / P.share_mbs], currMB->mbAddrX, &rec))) adapter_die("jmhip_slice_record (dealt)", rc); }
     else if ((rc = jmhip_slice_record(G.ctx, currMB->mbAddrX, &rec))) adapter_die("jmhip_slice_record", rc);     /* waits while the device is behind */
     P.t_wait += now_s() - t0;
     if (TL_n) { TL_wait[TL_n - 1] += now_s() - t0; if (currMB->mbAddrX == 0) TL_first[TL_n - 1] = now_s(); if (currMB->mbAddrX == (int)p_Vid->PicSizeInMbs - 1) TL_last[TL_n - 1] = now_s(); }
     t0 = now_s();
     mb_from_record(currMB, rec);
     P.t_fill += now_s() - t0;
+    if (P.dealt) {
+      const int c = currMB->mbAddrX / P.share_mbs;
+      if ((currMB->mbAddrX == P.slice_last || (currMB->mbAddrX + 1) % P.share_mbs == 0) && (rc = jmhip_encode_slice_end(G.ctxs[c]))) adapter_die("jmhip_encode_slice_end (dealt)", rc);
+    } else
     if (!F.on && currMB->mbAddrX == P.slice_last && (rc = jmhip_encode_slice_end(G.ctx))) adapter_die("jmhip_encode_slice_end", rc);
     if (TL_n && currMB->mbAddrX == P.slice_last) TL_ended[TL_n - 1] = now_s();
   }
@@ -1719,6 +1761,11 @@ static int pipe_deblock(VideoParameters *p_Vid, imgpel **imgY, imgpel ***imgUV)
     P.deblocked = 1; G.n_deblock++; P.t_dev += now_s() - t0;
     return 1;
   }
+  if (P.dealt) {                                            /* every device gets every band, then filters the whole picture (it keeps the whole reference) */
+    int c;
+    if ((rc = jmhip_allgather_bands(G.ctxs, G.nctx, P.band_rows))) adapter_die("jmhip_allgather_bands", rc);
+    for (c = 1; c < G.nctx; c++) if ((rc = jmhip_deblock_picture_dev(G.ctxs[c], p_Vid->active_sps->direct_8x8_inference_flag))) adapter_die("jmhip_deblock_picture_dev (dealt)", rc);
+  }
   if ((rc = jmhip_deblock_picture_dev(G.ctx, p_Vid->active_sps->direct_8x8_inference_flag))) adapter_die("jmhip_deblock_picture_dev", rc);
   if ((rc = jmhip_get_recon(G.ctx, imgY[0], (int)(imgY[1] - imgY[0]), imgUV[0][0], imgUV[1][0], (int)(imgUV[0][1] - imgUV[0][0])))) adapter_die("jmhip_get_recon", rc);
   P.deblocked = 1;
@@ -1733,6 +1780,7 @@ static int pipe_reference(StorablePicture *s)
   if (!P.ok || P.pic != s || !P.deblocked) return 0;
   if (F.on) { G.n_interp++; return 1; }                     /* the planes are in the picture's slot already (flight_launch registered it) */
   k = slot_take(s);
+  if (G.nctx > 1) { int c; for (c = 1; c < G.nctx; c++) if ((rc = jmhip_reference_from_recon(G.ctxs[c], k))) adapter_die("jmhip_reference_from_recon (dealt)", rc); }
   if ((rc = jmhip_reference_from_recon(G.ctx, k))) adapter_die("jmhip_reference_from_recon", rc);
   G.slot_chroma[k] = 2;                                     /* on the device, and nobody on the host needs the sub-images */
   G.n_interp++;
@@ -1741,6 +1789,7 @@ static int pipe_reference(StorablePicture *s)
 }
 static void pipe_report(void)
 {
+  if (G.nctx > 1) fprintf(stderr, "jmhip adapter: %d contexts (JMHIP_DEVICES): the slices of a picture dealt to them, the bands exchanged with jmhip_allgather_bands\n", G.nctx);
   if (F.on) fprintf(stderr, "jmhip adapter: pictures in flight: %ld pictures, %ld launched ahead of time (up to %d in flight), %ld of them served as launched, %ld voided\n", F.pic, F.n_ahead, F.depth, F.n_hit, F.n_void);
   if (P.n_slices)
     fprintf(stderr, "jmhip adapter: macroblock pipeline: %ld slices, %ld macroblocks encoded on the MI355X (encode_one_macroblock_low never ran on the host); "

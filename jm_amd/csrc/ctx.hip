@@ -4,6 +4,7 @@
 #include "jmhip_internal.h"
 
 char g_jmhip_create_err[512] = "";
+int g_jmhip_multi_device = 0;      // a context on a device other than 0 has been created in this process
 
 int jmhip_fail(jmhip_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -82,6 +83,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   jmhip_ctx *c = (jmhip_ctx *)calloc(1, sizeof(jmhip_ctx));
   if (!c) return jmhip_fail(NULL, JMHIP_ENOMEM, "out of host memory");
   c->cfg = *cfg;
+  if (cfg->device != 0) g_jmhip_multi_device = 1;
   c->stream = (hipStream_t)cfg->stream;
   { const char *fg = getenv("JMHIP_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
   { const char *fg = getenv("JMHIP_DEBLOCK_DIAG"); c->force_db_diag = fg && fg[0] == '1'; }

@@ -74,6 +74,7 @@ extern "C" int jmhip_set_current_planes(jmhip_ctx *ctx, const uint16_t *y, int32
   if (!ctx) return JMHIP_EINVAL;
   const int fmt = ctx->cfg.yuv_format;
   if (!y || pitch_y < ctx->W || (fmt && (!u || !v || pitch_c < ctx->cw))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_current_planes: bad argument");
+  JMHIP_DEVICE(ctx);
   const size_t ny = (size_t)ctx->W * ctx->H, nc = (size_t)ctx->cw * ctx->ch;
   if (ny + 2 * nc > ctx->h_stage_bytes) return jmhip_fail(ctx, JMHIP_ENOMEM, "jmhip_set_current_planes: staging area too small");
   if (fmt && !ctx->d_cur_c) HIPCHK(ctx, hipMalloc((void **)&ctx->d_cur_c, 2 * nc));

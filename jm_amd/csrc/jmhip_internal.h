@@ -97,6 +97,9 @@ struct jmhip_ctx {
 extern char g_jmhip_create_err[512];
 
 int jmhip_fail(jmhip_ctx *ctx, int code, const char *fmt, ...);
+// a process may hold contexts on several devices (jmhip_allgather_bands): the entry points of the macroblock pipeline select theirs first
+#define JMHIP_DEVICE(ctx) do { if ((ctx)->cfg.device != 0 || g_jmhip_multi_device) (void)hipSetDevice((ctx)->cfg.device); } while (0)
+extern int g_jmhip_multi_device;
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return jmhip_fail(ctx, JMHIP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 

@@ -107,7 +107,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
            "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
            "jmhip_seq_open", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_planes", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
-           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms"]
+           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_allgather_bands"]
 
 
 class JmHipError(RuntimeError):
@@ -675,6 +675,15 @@ class JmHip:
         v = np.zeros((ch, self.W // 2), np.uint16)
         self._ck(self.lib.jmhip_seq_get_recon(self.h, int(slot), _vp(y), self.W, _vp(u), _vp(v), self.W // 2))
         return y.astype(np.uint8), u.astype(np.uint8), v.astype(np.uint8)
+
+
+def allgather_bands(contexts, band_mb_rows):
+    """jmhip_allgather_bands: every context of the list (one per device, or several on one) gets every band of the picture whose slices they coded"""
+    lib = load_library()
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = lib.jmhip_allgather_bands(arr, len(contexts), int(band_mb_rows))
+    if rc != 0:
+        raise JmHipError(f"libjmhip error {rc}: {lib.jmhip_last_error(contexts[0].h).decode()}")
 
 
 def db_arrays_from_tap(mbs12, mot):

@@ -487,6 +487,62 @@ def test_slices_dealt_to_ranks_equal_the_one_launch_picture(W, H, n_slices, worl
     Jr.close()
 
 
+@pytest.mark.parametrize("W,H,n_slices,world,seed", [(640, 368, 8, 2, 51), (320, 240, 4, 4, 52), (1920, 1088, 8, 8, 53)])
+def test_allgather_bands_through_the_c_abi(W, H, n_slices, world, seed):
+    """jmhip_allgather_bands (SURVEY 8b viii): one process, `world` contexts -- all of them on this box's one device, which is what a single GPU allows; between devices the
+    same calls are peer copies over xGMI --, each codes its share of a picture's slices, the call gives every context every band, and then EVERY context deblocks and
+    interpolates the whole picture: filtered planes and sub-pel planes equal the ones of the context that coded all slices itself.  Two pictures, so that the second
+    one's searches read a reference every context built from exchanged bands."""
+    import jm_amd.lib as L
+    from jm_amd import shard
+    R, qp = 16, 28
+    mbw, mbh = W // 16, H // 16
+    nmb = mbw * mbh
+    per = shard.slice_argument(mbh, mbw, n_slices)
+    spr = n_slices // world
+    band = -(-mbh // n_slices) * spr
+    clip = synthetic_clip(W, H, 3, seed)
+
+    def prm_for(st, first, num, num_slices, slice_nr, nref):
+        cfg = pyjmo.mbenc_cfg(W, H, st, first, num, qp, R, nref, *LAMBDAS[st])
+        q = slice_params(L, cfg, slice_nr, [n & 1 for n in range(nref)] if nref else [], [0] * nref)
+        q["num_slices"] = num_slices
+        return q
+    one = L.JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1)
+    ctxs = [L.JmHip(W, H, search_range=R, num_ref_slots=2, yuv_format=1) for _ in range(world)]
+    for n, raw in enumerate(clip):
+        st, nref = (2, 0) if n == 0 else (0, 1)
+        one.set_current_frame(raw, W, H)
+        q = prm_for(st, 0, per, n_slices, 0, nref)
+        if nref:
+            q["ref_slot"][0, 0] = (n - 1) & 1
+        all_recs = one.encode_slice(q)
+        one.deblock_picture_dev(1)
+        want_post = one.get_recon()
+        one.reference_from_recon(n & 1)
+        want_planes = one.get_subplanes(n & 1)
+        for r, J in enumerate(ctxs):
+            first = r * spr * per
+            mine = min(spr * per, nmb - first)
+            J.set_current_frame(raw, W, H)
+            q = prm_for(st, first, per if spr > 1 else mine, spr, r * spr, nref)
+            if nref:
+                q["ref_slot"][0, 0] = (n - 1) & 1
+            recs = J.encode_slice(q)
+            assert recs.tobytes() == all_recs[first:first + mine].tobytes(), ("picture", n, "records of context", r)
+        L.allgather_bands(ctxs, band)
+        for r, J in enumerate(ctxs):
+            J.deblock_picture_dev(1)
+            for a, b in zip(J.get_recon(), want_post):
+                assert np.array_equal(a, b), ("picture", n, "filtered picture of context", r)
+            J.reference_from_recon(n & 1)
+            assert np.array_equal(J.get_subplanes(n & 1), want_planes), ("picture", n, "sub-pel planes of context", r)
+    with pytest.raises(L.JmHipError):
+        L.allgather_bands(ctxs, band + 1 if world * (band + 1) - (band + 1) >= mbh else mbh + 1)      # bands that do not make up the picture
+    for J in ctxs + [one]:
+        J.close()
+
+
 def test_streamed_records_equal_the_blocking_call():
     """jmhip_encode_slice_begin / jmhip_slice_record / jmhip_encode_slice_end (what the adapter uses: JM's entropy coder reads each record in raster
     order while the device is still encoding) hands over the same records as jmhip_encode_slice, picture after picture, with mid-row slices."""

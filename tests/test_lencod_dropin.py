@@ -392,6 +392,65 @@ def test_lencod_macroblock_pipeline_configs3_2160p_8_slices(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,devices,nmb_total", [("q4r", "0,0,0", 297), ("G4r", "0,0", 64800), ("G4r", "0,0,0,0,0,0,0,0", 64800)])
+def test_lencod_slices_dealt_to_several_contexts(tmp_path, tag, devices, nmb_total):
+    """JMHIP_DEVICES: the slices of a picture dealt to several contexts of one process (here all on this box's one device; between devices the same calls are peer copies),
+    the bands exchanged with jmhip_allgather_bands before DeblockFrame, every context keeping the whole reference: QCIF in three slices on three contexts, BASELINE configs[3]
+    (2160p, 8 slices, RDO off) on two and on eight.  Bitstream and reconstruction equal CPU JM's."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    if tag == "G4r":
+        r, e = run_2160p(tag, str(tmp_path), {"JMHIP_DEVICES": devices})
+        want = (e["md5_264"], e["md5_recon"])
+    else:
+        r, z = run_rdo_off_case(tag, str(tmp_path), env_extra={"JMHIP_DEVICES": devices})
+        want = (str(z["md5_264"]), str(z["md5_recon"]))
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-1500:], err[-1500:])
+    assert f"{len(devices.split(','))} contexts (JMHIP_DEVICES)" in err, err[-1500:]
+    rep = pipeline_report(err)
+    assert rep and rep["mbs"] == nmb_total, (rep, err[-1500:])
+    assert md5(os.path.join(str(tmp_path), "o.264")) == want[0], (tag, devices, "bitstream differs from CPU JM")
+    assert md5(os.path.join(str(tmp_path), "o_rec.yuv")) == want[1], (tag, devices, "reconstruction differs from CPU JM")
+
+
+@pytest.mark.gpu
+def test_lencod_pictures_in_flight_are_verified_not_trusted(tmp_path):
+    """The adapter launches pictures ahead of time and uses such a launch only if JM's own parameters and source planes equal what it was given.
+    (a) the plain case: the third of three pictures is served as launched; (b) a QP that changes at the third picture (ChangeQPFrame): the launch made with the old QP is voided and
+    redone; (c) JMHIP_ADAPTER_FLIGHT=0: no launch ahead of time.  All three write CPU JM's bytes."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    import re as _re
+    cpu = os.path.join(ROOT, "oracle", "_ref", "lencod.exe")
+    for name, ov, env in (("plain", {}, {}), ("qp change", {"ChangeQPFrame": "1", "ChangeQPP": "6", "ChangeQPI": "6"}, {}), ("off", {}, {"JMHIP_ADAPTER_FLIGHT": "0"})):
+        outs = []
+        for exe in (cpu, EXE):
+            d = os.path.join(str(tmp_path), name.replace(" ", "_") + ("_cpu" if exe == cpu else "_hip"))
+            os.makedirs(d)
+            shutil.copyfile(os.path.join(G, "foreman_part_qcif.yuv"), os.path.join(d, "foreman_part_qcif.yuv"))
+            args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+            for k, v in dict({"RDOptimization": "0", "AdaptiveRounding": "0", "SearchMode": "-1", "SearchRange": "16", "NumberReferenceFrames": "2", "FramesToBeEncoded": "3", "FrameSkip": "0",
+                              "OutputFile": "o.264", "ReconFile": "o_rec.yuv", "TraceFile": "/dev/null"}, **ov).items():
+                args += ["-p", f"{k}={v}"]
+            r = subprocess.run(args, cwd=d, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert r.returncode == 0, (name, r.stderr.decode(errors="replace")[-1500:])
+            outs.append((md5(os.path.join(d, "o.264")), md5(os.path.join(d, "o_rec.yuv")), r.stderr.decode(errors="replace")))
+        assert outs[0][:2] == outs[1][:2], (name, "the drop-in encoder's bytes differ from CPU JM's")
+        m = _re.search(r"pictures in flight: (\d+) pictures, (\d+) launched ahead of time \(up to (\d+) in flight\), (\d+) of them served as launched, (\d+) voided", outs[1][2])
+        if name == "off":
+            assert m is None, outs[1][2][-800:]
+        else:
+            assert m, outs[1][2][-1500:]
+            pics, ahead, depth, hit, void = (int(x) for x in m.groups())
+            assert pics == 3 and ahead >= 1, (name, m.groups())
+            if name == "qp change":
+                assert void >= 1 and hit == 0, (name, m.groups())      # the third picture was launched with the second one's QP: found out, voided, launched again
+            else:
+                assert hit >= 1 and void == 0, (name, m.groups())
+
+
+@pytest.mark.gpu
 def test_lencod_configs3_full_size_2160p_per_call(tmp_path):
     """BASELINE.json configs[3] as SURVEY.md 8c states it (G4: RDO on, 2160p, 8 slices, md5 933ebd28...): the per-call path (every BlockMotionSearch of
     the P picture on the device one by one, sub-pel planes, deblocking), as the 1080p test does for configs[1].  Minutes, not seconds."""

@@ -1,6 +1,5 @@
-"""Multi-GPU path on CPU: world_size 2 and 3 over gloo.  Each rank owns one slice band of a picture; after the one
-collective (all-gather of reconstructed bands) every rank must hold exactly the rows of the full picture its search
-windows can reach, and the oracle's motion search on that local reference must equal the search on the full picture."""
+"""Multi-GPU path on CPU: world_size 2 and 3 over gloo.  Each rank owns one slice band of a picture; after the one collective (jm_amd.shard.BandGather: all-gather of
+the un-deblocked bands and their loop-filter side information) every rank must hold the whole picture; and the closed-GOP split of a sequence gives every picture one owner."""
 import os
 import socket
 
@@ -22,139 +21,25 @@ def _full_picture(h, w, seed):
     return rng.integers(0, 256, (h, w)).astype(np.uint8)
 
 
-def _worker(rank, world, port, h_mbs, w, halo, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        H = 16 * h_mbs
-        full = _full_picture(H, w, 11)
-        band = shard.band_of(rank, world, h_mbs)
-        own = np.zeros((16 * band.rows_per_band, w), np.uint8)
-        own[:band.height] = full[band.y0:band.y0 + band.height]          # each rank only ever holds its own band
-        for rep in range(2):                                             # buffers are reusable across pictures
-            local = shard.exchange_reference(torch.from_numpy(own), band, halo, H)
-            want = full[np.clip(np.arange(band.y0 - halo, band.y0 + band.height + halo), 0, H - 1)]
-            ok = local.shape == want.shape and bool((local.numpy() == want).all())
-            if not ok:
-                break
-        # motion search on the local reference == on the full picture (oracle; search windows stay inside band + halo)
-        from oracle import pyjmo as J
-        cur = np.roll(full, (-2, 3), (0, 1))
-        ref_full, ref_loc = J.RefPic(full), J.RefPic(local.numpy())
-        y_off = band.y0 - halo                                           # local row 0 = picture row y_off (before clamping)
-        same = True
-        for mby in range(band.first_mb_row, band.first_mb_row + band.mb_rows):
-            y = 16 * mby
-            if y - 8 - 4 < max(0, y_off) or y + 16 + 8 + 4 > min(H, band.y0 + band.height + halo):
-                continue                                                 # window would leave the rows this rank holds
-            a = J.full_search(ref_full, cur, 16, y, 16, 16, (0, 0), (0, 0), 8, 187)
-            cur_loc = np.zeros_like(local.numpy()); cur_loc[y - y_off:y - y_off + 16] = cur[y:y + 16]
-            b = J.full_search(ref_loc, cur_loc, 16, y - y_off, 16, 16, (0, 0), (0, 0), 8, 187)
-            same &= (a[0], a[1]) == (b[0], b[1])
-        q.put((rank, ok, same, band.first_mb_row, band.mb_rows))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,h_mbs", [(2, 8), (3, 8), (2, 5)])
-def test_band_exchange_gloo(world, h_mbs):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h_mbs, 64, 32, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert all(r[1] for r in res), res
-    assert all(r[2] for r in res), res
-    assert sum(r[4] for r in res) == h_mbs                               # the bands tile the picture
-    assert [r[3] for r in res] == [min(i * -(-h_mbs // world), h_mbs) for i in range(world)]
-
-
-def _worker_yuv(rank, world, port, h_mbs, w, halo, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        H = 16 * h_mbs
-        rng = np.random.default_rng(23)
-        Y, U, V = rng.integers(0, 256, (H, w)).astype(np.uint8), rng.integers(0, 256, (H // 2, w // 2)).astype(np.uint8), rng.integers(0, 256, (H // 2, w // 2)).astype(np.uint8)
-        band = shard.band_of(rank, world, h_mbs)
-        rows = 16 * band.rows_per_band
-        oy, ou, ov = np.zeros((rows, w), np.uint8), np.zeros((rows // 2, w // 2), np.uint8), np.zeros((rows // 2, w // 2), np.uint8)
-        oy[:band.height] = Y[band.y0:band.y0 + band.height]
-        ou[:band.height // 2] = U[band.y0 // 2:(band.y0 + band.height) // 2]; ov[:band.height // 2] = V[band.y0 // 2:(band.y0 + band.height) // 2]
-        ex = shard.YuvExchange(band, halo, H, w, world, "cpu")
-        ok = True
-        for rep in range(2):
-            ly, lu, lv = ex(shard.packed_band(torch.from_numpy(oy), torch.from_numpy(ou), torch.from_numpy(ov)))
-            wy = Y[np.clip(np.arange(band.y0 - halo, band.y0 + band.height + halo), 0, H - 1)]
-            cr = np.clip(np.arange((band.y0 - halo) // 2, (band.y0 + band.height + halo) // 2), 0, H // 2 - 1)
-            ok &= bool((ly.numpy() == wy).all()) and bool((lu.numpy() == U[cr]).all()) and bool((lv.numpy() == V[cr]).all())
-        q.put((rank, ok))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,h_mbs", [(2, 8), (3, 8), (2, 5)])
-def test_packed_yuv_exchange_gloo(world, h_mbs):
-    """luma and 4:2:0 chroma of the reconstructed bands in ONE all-gather; every rank ends up with its band + halo of all three planes"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_yuv, args=(r, world, port, h_mbs, 64, 32, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert all(r[1] for r in res), res
-
-
 def test_slice_argument_matches_jm_config():
     # configs[3]: 2160p = 240 x 135 macroblocks, 8 slices -> SliceArgument 4080 (17 rows each, the last band 16)
     assert shard.slice_argument(135, 240, 8) == 4080
     bands = [shard.band_of(r, 8, 135) for r in range(8)]
     assert [b.mb_rows for b in bands] == [17] * 7 + [16]
-    assert shard.halo_rows(32, 512) == 576
 
 
-def _gather_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        rows, pitch, cw = 32 * world, 64, 24
-        full = [_full_picture(rows, pitch, 3), _full_picture(rows // 2, cw, 4), _full_picture(rows // 2, cw, 5)]
-        mine = [torch.zeros(p.shape, dtype=torch.uint8) for p in full]
-        for p, m in zip(full, mine):                                     # each rank starts with its own band only
-            b = p.shape[0] // world
-            m[rank * b:(rank + 1) * b] = torch.from_numpy(p[rank * b:(rank + 1) * b])
-        g = shard.PictureGather(mine[0], mine[1], mine[2], world, rank)
-        ok = True
-        for rep in range(2):
-            g()
-            ok &= all(bool((m.numpy() == p).all()) for p, m in zip(full, mine))
-        q.put((rank, ok))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world", [2, 3])
-def test_picture_gather_gloo(world):
-    """bench.py's N > 1 exchange: after one collective every rank holds the whole reconstruction (all three planes)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=120) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-    assert all(ok for _, ok in res), res
+def test_closed_gops_are_dealt_whole():
+    # bench.py --gpus N: every picture has one owner, a GOP is never split, GOPs go to the ranks in turn
+    for world, n, period in ((8, 200, 24), (2, 7, 3), (4, 4, 10), (3, 30, 10)):
+        owner = {}
+        for r in range(world):
+            for first, cnt in shard.gop_of(r, world, n, period):
+                assert first % period == 0 and 0 < cnt <= period
+                for k in range(first, first + cnt):
+                    assert k not in owner
+                    owner[k] = r
+        assert sorted(owner) == list(range(n))
+        assert all(owner[k] == (k // period) % world for k in range(n))
 
 
 def _uneven_worker(rank, world, port, mb_rows, q):
