@@ -4,7 +4,7 @@ seeded random RDO-off configurations -- the .264 and the reconstruction file mus
 away (then JM's own function or the per-call kernels run).  Varied: search mode / range, references, QPs of I and P slices, chroma QP offset, entropy coder, 8x8 transform, 4:2:0 /
 4:2:2, slices, loop filter parameters and disable flags, partition switches, sub-pel on / off, intra period, picture size (cropped sources), EPZS switches; from seed 500000 on also
 intra modes switched off, PList0References, UseMVLimits, EPZS threshold scales, explicit lambda weights, reference reordering, PicOrderCntType 2, IDRPeriod, ChangeQPFrame.
-TEST INFRASTRUCTURE.   usage: python profiles/fuzz_dropin.py <seconds> [first seed]"""
+TEST INFRASTRUCTURE.   usage: python tests/fuzz_dropin.py <seconds> [first seed]"""
 import hashlib
 import os
 import shutil

@@ -2,8 +2,10 @@
 """Randomised parity run of the macroblock pipeline (GPU box): jmhip_encode_slice against the oracle's restatement (itself pinned to the real encoder by the
 tests/golden/mb_low_* records) on seeded random configurations -- picture size, search range and mode (full search / fast full search / EPZS with random switches),
 references, QP, slices (separate launches or side by side in one), CAVLC / CABAC, 8x8 transform, 4:2:0 / 4:2:2, default or q_offset.cfg quantiser offsets, clips with
-a motion field or adversarial content.  Every macroblock record and the reconstruction before and after the loop filter must be identical.
-TEST INFRASTRUCTURE (uses oracle/).   usage: python profiles/fuzz_mbenc.py <seconds> [first seed]"""
+a motion field or adversarial content.  Every macroblock record and the reconstruction before and after the loop filter must be identical.  Configurations the
+sequence entry points cover (full searches, one slice) are coded a second time with a random number of pictures in flight (jmhip_seq_*): records, filtered pictures and
+sub-pel planes must equal the picture-after-picture run's.
+TEST INFRASTRUCTURE (uses oracle/).   usage: python tests/fuzz_mbenc.py <seconds> [first seed]"""
 import os
 import sys
 import time
@@ -13,12 +15,13 @@ for d in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
     sys.path.insert(0, d)
 import mb_tap, mbenc_util, synth_motion
 import test_gpu_mbenc as T
+import test_gpu_seq as TS
 from oracle import pyjmo
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 offsets = pyjmo.load_q_offsets(os.path.join(ROOT, "tests", "golden", "q_offset.cfg"))
-t0, done, by_mode = time.time(), 0, {0: 0, 1: 0, 3: 0}
+t0, done, by_mode, flights = time.time(), 0, {0: 0, 1: 0, 3: 0}, 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     sm = int(rng.choice([0, 0, 1, 3, 3]))                     # pyjmo search_mode: 0 / -1 full search, 1 fast full search, 3 EPZS
@@ -59,9 +62,13 @@ while time.time() - t0 < budget:
     except Exception as e:                                   # a configuration the library turns away (LDS budget): say so and go on
         print("skipped", desc, str(e)[:120]); seed += 1; continue
     ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, cabac=cabac, search_mode=sm, epzs=epzs, transform8x8=t8, yuv_format=yuv, offsets=offs)
+    in_flight = sm != 3 and slice_mbs == 0 and offs is None
+    classic = []
     try:
         for n, raw in enumerate(frames):
             recs, pre, post = dev.encode(raw, W, H)
+            if in_flight:
+                classic.append((recs, post, dev.J.get_subplanes(dev.refs[0][0])))
             orecs, _, opre, opost = ora.encode(pyjmo.load_frame(raw, W, H, W, H, yuv))
             d = T.first_difference(mb_tap.canonical(orecs), mb_tap.canonical(T.as_oracle_records(recs)))
             assert d is None, ("records", n, d[:3])
@@ -72,5 +79,18 @@ while time.time() - t0 < budget:
         sys.exit(1)
     finally:
         dev.J.close()
+    if in_flight:
+        depth, wg = int(rng.integers(1, 9)), int(rng.choice([0, 0, 1, 3, 17]))
+        fl = TS.FlightEncoder(W, H, qp, R, num_ref, lam, depth, wg, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv, stream_records=bool(rng.integers(0, 2)))
+        try:
+            for raw in frames:
+                fl.submit(raw, W, H)
+            TS.compare(classic, fl.finish(), ("in flight", depth, wg))
+        except Exception as e:
+            print("FAILED (pictures in flight)", dict(desc, depth=depth, workgroups=wg), repr(e)[:600])
+            sys.exit(1)
+        finally:
+            fl.J.close()
+        flights += 1
     done += 1; by_mode[sm] += 1; seed += 1
-print(f"fuzz_mbenc: {done} random configurations identical to the oracle in {time.time() - t0:.0f} s (full search {by_mode[0]}, fast full search {by_mode[1]}, EPZS {by_mode[3]}); next seed {seed}")
+print(f"fuzz_mbenc: {done} random configurations identical to the oracle in {time.time() - t0:.0f} s (full search {by_mode[0]}, fast full search {by_mode[1]}, EPZS {by_mode[3]}; {flights} of them once more with pictures in flight); next seed {seed}")

@@ -2,7 +2,7 @@
 """Randomised pinning of the ORACLE (CPU only, needs /root/reference's build in oracle/_ref: the build container): seeded random RDO-off configurations through the tapped real
 encoder (tests/golden/make_mb_golden.py: oracle/_ref/lencod_tapmb.exe) and through oracle/jmo_mbenc.c (tests/test_oracle_mbenc.run_case) -- every macroblock's record, motion
 costs, reconstruction must be equal.  The committed goldens pin the oracle on fixed cases; this checks it on configurations nobody chose.  TEST INFRASTRUCTURE.
-usage: python profiles/fuzz_oracle.py <seconds> [first seed] [workers]"""
+usage: python tests/fuzz_oracle.py <seconds> [first seed] [workers]"""
 import multiprocessing as mp
 import os
 import subprocess

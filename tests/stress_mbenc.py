@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Determinism stress of the macroblock pipeline (GPU box): the same P picture encoded again and again with identical inputs must give identical records -- any difference
 is a race.  Several configurations (search modes, 8x8 transform, 4:2:2, slices of a few macroblocks in separate launches / side by side, streamed records).
-usage: python profiles/stress_mbenc.py <repeats per configuration>"""
+usage: python tests/stress_mbenc.py <repeats per configuration>"""
 import os
 import sys
 import numpy as np

@@ -599,7 +599,7 @@ def test_fast_full_search_is_refused_when_the_level_cuts_into_the_range():
     """me_fullfast.c:318-326 clips the search centre to limit -+ range after making sure (0,0) is inside; with a vertical limit of 255 quarter-pels (levels 1 / 1b; JM also maps
     level_idc 11 of the High profiles there) and SearchRange 32 the centre can become 127 -- off the sample grid --, the (0,0) position is then not found (:354-365) and JM uses the
     pos_00 an EARLIER macroblock left: raster-order state the wavefront cannot reproduce, so the call is refused and the adapter turns such sequences away (found by
-    profiles/fuzz_dropin.py: 3 of 2051 configurations).  SearchRange 16 with the same limits, and level 1.1's own limits (goldens m3fl, m3fm), are served."""
+    tests/fuzz_dropin.py: 3 of 2051 configurations).  SearchRange 16 with the same limits, and level 1.1's own limits (goldens m3fl, m3fm), are served."""
     import jm_amd.lib as L
     W, H, tight = 80, 112, (-8192, 8191, -256, 255)
     clip = synthetic_clip(W, H, 2, 77)
@@ -618,9 +618,9 @@ def test_fast_full_search_is_refused_when_the_level_cuts_into_the_range():
 
 
 def test_random_configurations_vs_oracle():
-    """Thirty seconds of profiles/fuzz_mbenc.py: seeded random configurations (size, search mode and range, references, QP, slices, entropy mode, 8x8 transform, 4:2:0 / 4:2:2,
+    """Thirty seconds of tests/fuzz_mbenc.py: seeded random configurations (size, search mode and range, references, QP, slices, entropy mode, 8x8 transform, 4:2:0 / 4:2:2,
     quantiser offsets, clip kind) through jmhip_encode_slice and the oracle; records and reconstructions identical.  (A ten-minute run of the same script: profiles/r03_fuzz.txt.)"""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_mbenc.py"), "30", "424242"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_mbenc.py"), "30", "424242"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "identical to the oracle" in out, out[-2000:]

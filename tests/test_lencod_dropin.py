@@ -489,13 +489,13 @@ def test_adapter_off_is_plain_jm(tmp_path):
 
 @pytest.mark.gpu
 def test_random_rdo_off_configurations_equal_cpu_jm():
-    """Forty seconds of profiles/fuzz_dropin.py: seeded random RDO-off configurations (search mode and range, references, QPs of I and P slices, chroma QP offset, entropy coder, 8x8
+    """Forty seconds of tests/fuzz_dropin.py: seeded random RDO-off configurations (search mode and range, references, QPs of I and P slices, chroma QP offset, entropy coder, 8x8
     transform, 4:2:0 / 4:2:2, slices, loop filter parameters, partition switches, intra period, cropped picture sizes, EPZS switches) through lencod_hip.exe and CPU JM: .264 and
     reconstruction byte-identical.  (Twelve minutes of the same script: profiles/r03_fuzz_dropin.txt; it is what found the stale block-type predictors of switched-off partitions.)"""
     if not os.path.exists(EXE):
         pytest.fail("oracle/_ref/lencod_hip.exe missing")
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_dropin.py"), "40", "777000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_dropin.py"), "40", "777000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and " 0 NOT byte-identical" in out, out[-3000:]
 
@@ -504,7 +504,7 @@ def test_random_rdo_off_configurations_equal_cpu_jm():
 def test_vector_limits_below_the_search_range_go_to_jms_own_function(tmp_path):
     """UseMVLimits with SetMVXLimit 8 under SearchRange 32 (conformance.c:615-630): jmhip_encode_slice refuses limits narrower than the search range, so the adapter must turn the
     sequence away BEFORE the first slice (pipe_config_ok) -- JM's own encode_one_macroblock_low runs, the output equals CPU JM's.  (The drop-in used to exit here: found by
-    profiles/fuzz_dropin.py's seed 500000.)"""
+    tests/fuzz_dropin.py's seed 500000.)"""
     import sys
     import numpy as np
     sys.path.insert(0, G)

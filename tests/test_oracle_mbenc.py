@@ -195,12 +195,12 @@ def test_record_layout():
 
 
 def test_oracle_equals_the_tapped_encoder_on_random_configurations():
-    """Twelve seconds of profiles/fuzz_oracle.py: seeded random RDO-off configurations through the tapped REAL encoder (oracle/_ref/lencod_tapmb.exe, built from /root/reference by
+    """Twelve seconds of tests/fuzz_oracle.py: seeded random RDO-off configurations through the tapped REAL encoder (oracle/_ref/lencod_tapmb.exe, built from /root/reference by
     oracle/Makefile.ref) and through the oracle -- records, motion costs, reconstructions equal.  Only where the reference's build exists (the build container); the committed goldens
     pin the same restatement everywhere else.  (35 minutes of the same script: profiles/r03_fuzz_oracle.txt.)"""
     import subprocess
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "lencod_tapmb.exe")):
         pytest.skip("needs oracle/_ref/lencod_tapmb.exe (the reference's build: /root/reference)")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_oracle.py"), "12", "950000", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_oracle.py"), "12", "950000", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and " 0 NOT equal" in out, out[-3000:]
