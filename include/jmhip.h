@@ -679,8 +679,10 @@ int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
  * The caller deals the pictures to the entries in turn (picture k -> entry k % depth) and the reconstructions to slots that no picture in flight refers to
  * (num_ref + depth slots in turn always do; a conflicting launch is simply held back until the readers are done).  An entry's buffers -- its records among them --
  * are reused by the entry's next jmhip_seq_set_frame / jmhip_seq_encode.
- * Scope: what jmhip_encode_slice_dev accepts with search_mode 0 or 1 (the full searches: their reach is bounded by 2 SearchRange), one slice covering the
- * whole picture.  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
+ * Scope: what jmhip_encode_slice_dev accepts, one slice covering the whole picture.  The full searches (search_mode 0, 1) reach 2 SearchRange into the reference, so a
+ * macroblock waits once, for the macroblock 5 to its right and 5 below it (SearchRange 32); an EPZS search (search_mode 3) goes wherever its predictor takes it inside the
+ * level's vector range, so every search asks for what it is about to read when its centre is known; the temporal predictors read the motion kept with the slots of
+ * references 0 / 1 directly (every picture of such a sequence, its I pictures too, is launched with search_mode 3 and its picture order counts).  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
  * after jmhip_seq_wait of the entry that wrote them, or after jmhip_synchronize).
  * ------------------------------------------------------------------------------------------ */
 int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture /* 0: 256 / depth, at most 80; always cut to 248 / (depth - 1), so that the oldest picture in flight can never be

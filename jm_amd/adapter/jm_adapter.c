@@ -108,6 +108,7 @@ static struct {
   struct { long pic; int valid, slot; jmhip_slice_params prm; uint8_t *raw; } sub[FL_MAX];      /* by entry: the launch it holds */
   jmhip_slice_params tmpl[3];         /* by slice type: what the last picture of that type was launched with */
   int have_tmpl[3], nref_prev;
+  int slot_poc[MAX_SLOTS], poc_last, poc_step;   /* EPZS: the picture order count of the picture in each slot of the ring; the last picture's and the step to the one before it */
   int cur_entry, cur_slot;
   long n_ahead, n_hit, n_void;
 } F;
@@ -314,7 +315,7 @@ static int adapter_on(VideoParameters *p_Vid)
       const char *fl = getenv("JMHIP_ADAPTER_FLIGHT");
       F.depth = fl ? atoi(fl) : 4;
       if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || p_Inp->slice_mode != NO_SLICES || p_Inp->NumberBFrames != 0 ||
-          (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH)) F.depth = 0;
+          (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH && p_Inp->SearchMode[0] != EPZS)) F.depth = 0;
       if (F.depth > FL_MAX) F.depth = FL_MAX;
       if (F.depth) {
         F.nring = imin(MAX_SLOTS, p_Vid->max_num_references + F.depth + 1);
@@ -1500,6 +1501,8 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
     F.sub[e].valid = 1; F.sub[e].pic = k; F.sub[e].slot = F.cur_slot; F.sub[e].prm = *prm;
   }
   F.tmpl[prm->slice_type] = *prm; F.have_tmpl[prm->slice_type] = 1;
+  F.poc_step = k ? prm->poc_cur - F.poc_last : 2 * (1 + p_Inp->frame_skip);
+  F.poc_last = prm->poc_cur; F.slot_poc[F.cur_slot] = prm->poc_cur;
   /* ---- the next pictures: the frame from the file, the parameters of the last picture of the type the picture will have (IntraPeriod / IDRPeriod as
    * get_idr_flag / set_slice_type apply them without B pictures; a wrong guess is found out above and costs the launch, never a byte) */
   for (j = 1; j < F.depth && F.have_file; j++) {
@@ -1520,6 +1523,11 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
       if (nref < 1) break;
       q.num_ref = nref;
       for (r = 0; r < JMHIP_MB_MAX_REF; r++) { q.ref_slot[r] = r < nref ? (int)((n - 1 - r) % F.nring) : 0; q.ref_id[r] = q.ref_slot[r]; }
+    }
+    if (q.search_mode == 3) {                               /* EPZS scales its predictors by picture distances: the picture's own count continues the last step, its references' are the ring's */
+      q.poc_cur = F.poc_last + j * F.poc_step;
+      for (r = 0; r < JMHIP_MB_MAX_REF; r++) q.poc_ref[r] = (!intra && r < q.num_ref) ? F.slot_poc[q.ref_slot[r]] : 0;
+      F.slot_poc[sl] = q.poc_cur;
     }
     if (!F.sub[en].raw && !(F.sub[en].raw = (uint8_t *)malloc((size_t)F.frame_bytes))) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
     if (pread(F.fd, F.sub[en].raw, (size_t)F.frame_bytes, (off_t)(F.header + F.frame_bytes * ((long)F.cur_frame_no + (long)j * F.frame_step + F.start_frame))) != (ssize_t)F.frame_bytes) break;

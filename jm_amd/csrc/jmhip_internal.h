@@ -18,6 +18,7 @@ struct jmhip_seq_entry {
   uint8_t *d_cur, *d_cur_c;   // source planes (as jmhip_ctx::d_cur / d_cur_c)
   void *d_edge; unsigned *d_done, *d_sync;
   void *d_records, *d_dbmb, *d_dbmo;
+  int *d_ez_state;       // EPZS: the macroblocks' state columns of the entry's picture (allocated on first use)
   void *h_records; unsigned *h_flags; void *d_h_records; unsigned *d_h_flags;
   unsigned epoch;
   int first_mb, num_mb;  // macroblocks of the launch (streamed records)

@@ -112,6 +112,8 @@ struct PipeArgs {
   int reach_x, reach_y;                      // macroblock (X, r) reads reference samples that macroblocks up to (X + reach_x, r + reach_y) of the reference produce
   const u32 *ref_post[JMHIP_SEQ_MAX_FLIGHT]; // the post flags of reference r's slot, or null (complete before the launch); references beyond are always complete
   u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
+  const u64 *mot_ref[2];                     // EPZS in flight: the motion kept with the slots of references 0 / 1 ({vector, poc referred to} per 4x4 block), read where k_epzs_coloc's
+                                             // whole-picture pass would have put the co-located vectors (the reference may still be in the making); null: no temporal predictors
 };
 static_assert(sizeof(PipeArgs) <= 4096, "kernel arguments: 4 KB");
 
@@ -162,6 +164,8 @@ struct Shared {
   u8 predc[2][128], recc[2][128];
   int16_t dcbuf[16];
   int red[8][80];
+  int ref_ok[3][JMHIP_SEQ_MAX_FLIGHT];       // EPZS in flight, per search chain and reference: the macroblock (column | row << 16) whose post flag the chain has seen (-1: none) --
+                                             // everything left of and above it is filtered and interpolated (mbpipe_post.inc)
   int nbflag;                                // the neighbours' samples are in nb (running count over the launch)
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
   u32 ytab4[4][72];                          // the same for the four usual offsets of the predictor from the search centre (-2 .. 1 quarter-pels), full range: once per launch
