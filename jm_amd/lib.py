@@ -231,7 +231,7 @@ class JmHip:
         raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw, np.uint8)
         sx, sy = (1 if yuv in (1, 2) else 0), (1 if yuv == 1 else 0)
         need = (src_w * src_h + (2 * (src_w >> sx) * (src_h >> sy) if yuv else 0)) * symbol_bytes
-        if raw.size < need:                                   # the library copies `need` bytes from this buffer
+        if symbol_bytes in (1, 2) and raw.size < need:        # the library copies `need` bytes from this buffer (a format it refuses is refused there)
             raise ValueError(f"load_frame: {raw.size} bytes for a {src_w}x{src_h} frame of format {yuv} with {symbol_bytes}-byte samples ({need} needed)")
         W, H = (int(out_w) + 15) // 16 * 16, (int(out_h) + 15) // 16 * 16
         f = np.zeros(1, FRAME_FORMAT)

@@ -16,19 +16,30 @@ from jm_amd.lib import SLICE_PARAMS  # noqa: E402
 npic = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 depths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 wg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+mode = sys.argv[4] if len(sys.argv) > 4 else "fs"           # fs | ffs | epzs (configs[2]'s switches, CABAC, 8x8 transform off) | ffs3 (three references)
 W, H = 1920, 1088
 nmb = (W // 16) * (H // 16)
 frames = bench.yuv_frames(npic)
 for depth in depths:
-    nslots = depth + 2
+    nslots = depth + (4 if mode == "ffs3" else 2)
     ctx = JmHip(W, H, search_range=32, num_ref_slots=nslots, yuv_format=1)
     ctx.seq_open(depth, wg)
+    ctx.enable_timing(True)
 
     def prm(k):
-        p = bench.slice_params(SLICE_PARAMS, 2 if k == 0 else 0, 0, nmb, 0, 0 if k == 0 else 1)
-        if k:
-            p["ref_slot"][0, 0] = (k - 1) % nslots
-            p["ref_id"][0, 0] = k - 1
+        nref = 0 if k == 0 else (min(k, 3) if mode == "ffs3" else 1)
+        p = bench.slice_params(SLICE_PARAMS, 2 if k == 0 else 0, 0, nmb, 0, nref)
+        for r in range(nref):
+            p["ref_slot"][0, r] = (k - 1 - r) % nslots
+            p["ref_id"][0, r] = k - 1 - r
+            p["poc_ref"][0, r] = 2 * (k - 1 - r)
+        p["poc_cur"] = 2 * k
+        if mode.startswith("ffs"):
+            p["search_mode"] = 1
+        if mode == "epzs":
+            p["search_mode"], p["symbol_mode"] = 3, 1
+            for kk, v in dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2).items():
+                p["epzs_" + kk] = v
         return p
     # all source pictures resident before the clock starts: one context entry per picture would be the product's ring; here the frames are re-uploaded per entry, untimed first pass
     for rep in range(2):
@@ -43,5 +54,7 @@ for depth in depths:
         for k in range(max(0, npic - depth), npic):
             ctx.seq_wait(k % depth)
         dt = time.perf_counter() - t0
-    print(f"depth {depth} workgroups/picture {wg or 224 // depth}: {npic} pictures in {dt * 1e3:.1f} ms = {dt / npic * 1e3:.2f} ms per picture = {nmb * npic / dt / 1e3:.0f} k macroblocks/s", flush=True)
+    kms = [ctx.seq_kernel_ms(e) for e in range(min(depth, npic))]
+    print(f"   launches' durations (HIP events, the last in each entry): {' '.join(f'{x:.1f}' for x in kms)} ms")
+    print(f"{mode} depth {depth} workgroups/picture {wg or min(80, 256 // depth)}: {npic} pictures in {dt * 1e3:.1f} ms = {dt / npic * 1e3:.2f} ms per picture = {nmb * npic / dt / 1e3:.0f} k macroblocks/s", flush=True)
     ctx.close()

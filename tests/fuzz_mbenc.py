@@ -62,7 +62,7 @@ while time.time() - t0 < budget:
     except Exception as e:                                   # a configuration the library turns away (LDS budget): say so and go on
         print("skipped", desc, str(e)[:120]); seed += 1; continue
     ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, cabac=cabac, search_mode=sm, epzs=epzs, transform8x8=t8, yuv_format=yuv, offsets=offs)
-    in_flight = sm != 3 and slice_mbs == 0 and offs is None
+    in_flight = slice_mbs == 0 and offs is None
     classic = []
     try:
         for n, raw in enumerate(frames):
@@ -81,7 +81,7 @@ while time.time() - t0 < budget:
         dev.J.close()
     if in_flight:
         depth, wg = int(rng.integers(1, 9)), int(rng.choice([0, 0, 1, 3, 17]))
-        fl = TS.FlightEncoder(W, H, qp, R, num_ref, lam, depth, wg, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv, stream_records=bool(rng.integers(0, 2)))
+        fl = TS.FlightEncoder(W, H, qp, R, num_ref, lam, depth, wg, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv, stream_records=bool(rng.integers(0, 2)), epzs=epzs)
         try:
             for raw in frames:
                 fl.submit(raw, W, H)

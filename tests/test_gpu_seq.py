@@ -202,3 +202,22 @@ def test_1080p_sequence_in_flight_equals_the_reference_encoder():
     for n in range(c["nfr"]):
         d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(got[n][0])))
         assert d is None, ("against the reference encoder, picture", n, d)
+
+
+def test_1080p_epzs_sequence_in_flight_equals_the_reference_encoder():
+    """configs[2]'s search at its own size with pictures in flight: six pictures of the 1080p clip, EPZS with the shipped switches, CABAC, up to five references -- every
+    record against the REAL encoder's (tests/golden/mb_low_g6e.npz)"""
+    import bench
+    from test_gpu_mbenc import load_case
+    c = load_case("g6e")
+    W, H = c["W"], c["H"]
+    nmb = (W // 16) * (H // 16)
+    frames = bench.yuv_frames(c["nfr"])
+    fl = FlightEncoder(W, H, c["qp"], c["R"], c["num_ref"], c["lam"], 6, cabac=c["cabac"], search_mode=3, epzs=c["epzs"])
+    for raw in frames:
+        fl.submit(raw, c["sw"], c["sh"])
+    got = fl.finish()
+    fl.J.close()
+    for n in range(c["nfr"]):
+        d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(got[n][0])))
+        assert d is None, ("against the reference encoder, picture", n, d)
