@@ -611,6 +611,8 @@ def main():
         recs = ctx.encode_slice(q)
         if k:
             solo_ms.append(ctx.last_kernel_ms(5))
+        else:
+            i_ms = ctx.last_kernel_ms(5)                                  # the I picture's launch (no searches: the Intra4x4 chains on two waves), alone
         same = same and recs.tobytes() == recs_all[k].tobytes()
         ctx.deblock_picture_dev(1)
         ctx.reference_from_recon(k & 1)
@@ -686,6 +688,33 @@ def main():
                                        "spatial memory, block type, sub-pel grid), RDO off, P picture with one reference", "kernel": "k_mb_pipe_epzs_t8",
                            "avg_kernel_ms": round(float(np.mean(ems[1:])), 3), "macroblocks_per_s": round(nmb / (float(np.mean(ems[1:])) * 1e-3), 1),
                            "records_equal_jm": bool(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), g3)))}
+        # ... and the same search as a sequence with pictures in flight (every search asks for what it reaches of a reference in the making): I + 16 P pictures of the clip, one
+        # reference; the first three pictures' records against the real encoder's (mb_low_g3h holds three: I, P with one reference, P with two -- the third differs by its reference count, so two are compared)
+        nq = min(17, nseq)
+        ctx.seq_open(depth, args.workgroups)
+        d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
+
+        def estep(k):
+            q = epzs_prm(2 if k == 0 else 0, 0 if k == 0 else 1, 2 * k)
+            if k:
+                q["ref_slot"][0, 0], q["ref_id"][0, 0], q["poc_ref"][0, 0] = (k - 1) % nslots, k - 1, 2 * (k - 1)
+            ctx.seq_set_frame_dev(k % depth, d_raw[k].data_ptr(), W, src_h)
+            ctx.seq_encode(k % depth, q, k % nslots, 1, False, d_r2[k].data_ptr())
+        estep(0)
+        barrier()
+        te = time.perf_counter()
+        for k in range(1, nq):
+            estep(k)
+        barrier()
+        te = time.perf_counter() - te
+        for e in range(depth):
+            ctx.seq_wait(e)
+        ctx.seq_close()
+        g3all = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"])
+        r2 = d_r2.cpu().numpy().view(MB_RECORD).reshape(nq, nmb)
+        eq2 = all(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(np.frombuffer(r2[k].tobytes(), g3all.dtype).copy()), g3all[k * nmb:(k + 1) * nmb])) for k in range(2))
+        configs2_device["in_flight"] = {"pictures": nq - 1, "pictures_in_flight": depth, "ms_per_picture": round(te / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / te, 1),
+                                        "records_equal_jm_first_two_pictures": bool(eq2)}
 
     if rank == 0:
         total_mb = nmb * N * args.steps
@@ -728,7 +757,7 @@ def main():
                        "parallelism": "1 GPU" if N == 1 else f"{N} GPUs x one GOP each (JM with IDRPeriod = GOP length codes the same pictures: closed GOPs are independent)",
                        "records_equal_jm": bool(equal), "pictures_checked_against_jm": ngold,
                        "records_equal_picture_after_picture": bool(same), "pictures_checked_against_picture_after_picture": nseq,
-                       "picture_after_picture_ms_per_picture": round(classic_s / nseq * 1e3, 2),
+                       "picture_after_picture_ms_per_picture": round(classic_s / nseq * 1e3, 2), "i_picture_kernel_ms_alone": round(i_ms, 3),
                        "mb_types_pskip_16x16_16x8_8x16_p8x8_i4_i16": [int(types[k]) for k in (0, 1, 2, 3, 8, 9, 10)]},
             "roofline": roof,
         }
