@@ -703,6 +703,28 @@ int jmhip_seq_records_dev(jmhip_ctx *ctx, int32_t entry, jmhip_mb_record **d_rec
 int jmhip_seq_recon_dev(jmhip_ctx *ctx, int32_t slot, uint8_t **d_y, int32_t *pitch_y, uint8_t **d_u, uint8_t **d_v, int32_t *pitch_c);
 int jmhip_seq_get_recon(jmhip_ctx *ctx, int32_t slot, uint16_t *y, int32_t pitch_y, uint16_t *u, uint16_t *v, int32_t pitch_c);   /* as imgpel, after jmhip_seq_wait */
 
+/* The same hand-over, n consecutive P pictures in ONE launch.  With a launch per picture (jmhip_seq_encode) every picture owns its share of the chip's compute units for as
+ * long as it runs, although a picture's wavefront is narrow at both ends and wide in the middle; here the launch's persistent workgroups draw the macroblocks of all n
+ * pictures from one queue, ordered by wavefront index + lag x position in the batch, so that every workgroup always finds the oldest macroblock that can run, whichever
+ * picture it belongs to (lag = reach_x + 2 reach_y + 1 = 16 wavefront steps at SearchRange 32: every macroblock's queue position is behind everything it waits for -- its
+ * neighbours, the macroblock 5 right / 5 below it in each reference, the pictures that still read the slot it overwrites --, which is what makes the launch deadlock-free).
+ * Picture k: its source in device memory in the file's layout (as jmhip_seq_set_frame_dev), the slot its filtered reconstruction and sub-pel planes go to, its references
+ * (slots an earlier picture of the batch goes to, or slots that were complete before the call: jmhip_set_reference*, jmhip_reference_from_recon, an earlier jmhip_seq_encode /
+ * jmhip_seq_batch), and device memory for its PicSizeInMbs records.  prm: the parameters every picture shares (JM: one P picture after another at one QP with
+ * RDOptimization 0 and no rate control differ in nothing but their references); its ref_slot / ref_id are not read.  A slot is reused inside the batch as with the entries:
+ * the picture that overwrites it starts once the last picture that read it is done, so num_ref + (pictures that overlap, PicHeightInMbs / 8 at 1080p) slots keep the
+ * queue dense.  Asynchronous on the context's stream: jmhip_synchronize (which reports the launch's errors), then the records, jmhip_seq_get_recon / jmhip_seq_recon_dev,
+ * jmhip_subplanes_dev.  Scope: the full searches (search_mode 0, 1), P slices, one slice per picture, num_ref <= 8, PicSizeInMbs < 65536, n <= 4096; needs jmhip_seq_open
+ * (any depth).  Anything else JMHIP_EUNSUPPORTED.  Results: those of coding the pictures one after another (tests/test_gpu_seq.py). */
+typedef struct {
+  const uint8_t *d_raw;         /* device: the source picture as it lies in the file (8 bit planar) */
+  int32_t src_w, src_h;         /* its size (<= the context's; padded as JM's reader pads: PadImage lencod/src/input.c:257) */
+  int32_t out_slot;
+  int32_t ref_slot[JMHIP_MB_MAX_REF], ref_id[JMHIP_MB_MAX_REF];   /* as jmhip_slice_params; the first prm->num_ref count */
+  jmhip_mb_record *d_records;   /* device: PicSizeInMbs records */
+} jmhip_seq_picture;
+int jmhip_seq_batch(jmhip_ctx *ctx, const jmhip_slice_params *prm, int32_t direct_8x8_inference, int32_t n, const jmhip_seq_picture *pics);
+
 /* ------------------------------------------------------------------------------------------
  * Timing helper: elapsed milliseconds of the last `_dev` launch of each kind, measured with
  * hipEvents on the context's stream (bench.py uses it for the roofline object).

@@ -88,6 +88,9 @@ struct jmhip_ctx {
   unsigned *slot_tag;    // [num_ref_slots] tag of the slot's current / last picture made by a sequence launch
   int *slot_entry;       // [num_ref_slots] entry that makes / made the slot's picture, -1: filled by jmhip_set_reference* / jmhip_reference_from_recon
   hipEvent_t seq_ev;     // orders the context's own stream before an entry's
+  // several pictures in ONE launch (jmhip_seq_batch): per picture a source picture, edge records, flags and loop-filter side information at a fixed stride; the
+  // pictures' descriptors and the ticket order of the last batch
+  uint8_t *d_batch; int batch_cap; void *d_batch_tab; size_t batch_tab_bytes; unsigned batch_epoch;
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)
   hipEvent_t ev0[JMHIP_NKINDS], ev1[JMHIP_NKINDS];

@@ -68,13 +68,45 @@ __device__ __forceinline__ int median3(int a, int b, int c) { return a > b ? (b 
 
 static_assert(sizeof(jmhip_mb_record) == 1216 && sizeof(jmhip_slice_params) == 3200, "record sizes of include/jmhip.h");
 
+// What one PICTURE of a launch is made of.  A launch of one picture (jmhip_encode_slice*, jmhip_seq_encode) carries it in its arguments (PipeArgs::v); a launch of several
+// consecutive pictures (jmhip_seq_batch) reads picture k's from PipeArgs::pics[k] when a workgroup draws a ticket of that picture.  Either way the workgroup works on its
+// copy in LDS (Shared::V, PV below).
+struct PicView {
+  const u8 *cur_y, *cur_u, *cur_v;           // source planes
+  const u8 *ref_y[JMHIP_MB_MAX_REF];         // 16 quarter-pel planes of each reference (plane (0,0) first)
+  const u8 *ref_u[JMHIP_MB_MAX_REF];         // the references' chroma: U, then V cw x ch bytes on (jmhip_ctx::d_refc)
+  u8 *rec_y, *rec_u, *rec_v;                 // reconstruction; with `fused` the planes of the slot the picture goes to (filtered in place)
+  u8 *out_planes;                            // fused: the sixteen quarter-pel planes of that slot
+  u64 *edge;
+  unsigned *done;
+  jmhip_mb_record *records;
+  jmhip_mb_record *hrecords;                 // streaming to the host (jmhip_encode_slice_begin): pinned, device-visible copies of the records
+  unsigned *hflags;                          // ... and per macroblock the epoch of the launch whose record is complete there; null otherwise
+  jmhip_db_mb *dbmb;
+  jmhip_db_motion *dbmo;
+  u32 *post;                                 // fused: per macroblock of the slot: post_tag once the macroblock is filtered and its share of the planes is written
+  const u32 *ref_post[JMHIP_SEQ_MAX_FLIGHT]; // the post flags of reference r's slot, or null (complete before the launch); references beyond are always complete
+  const u32 *war_post;                       // a launch of several pictures: the post flags of the picture that must be done before this one may write its slot, or null
+  const u32 *prev_post;                      // ... and of the picture before this one in the launch: pictures complete in launch order (this one's last macroblock waits for that one's), so
+                                             // "picture j is done" (war_post) says the same of every picture before j
+  int *ez_state;                             // EPZS: per macroblock its four columns of p_EPZS->distortion [7][4] and p_EPZS->p_motion [num_ref][7][4][4] when it was done
+  u64 *mot_out;                              // EPZS: per 4x4 block of the picture {packed vector, poc of the picture referred to}: later pictures' temporal predictors
+  const u64 *mot_ref[2];                     // EPZS in flight: the motion kept with the slots of references 0 / 1, read where k_epzs_coloc's whole-picture pass would have put the
+                                             // co-located vectors (the reference may still be in the making); null: no temporal predictors
+  u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
+  u32 post_tag, war_tag, prev_tag, pad_;
+  unsigned epoch;
+  int ref_id[JMHIP_MB_MAX_REF];              // identity of reference r for the loop filter's comparison (jmhip_slice_params::ref_id)
+};
+static_assert(sizeof(PicView) % 8 == 0, "copied as dwords, pointers first");
+
 struct PipeArgs {
   jmhip_slice_params p;
   int W, H, wmb, hmb, cw, ch;
   unsigned role_perm;                        // role of hardware wave w = nibble w: which chain a wave runs (0-3 the P8x8 sub-modes, 4 16x16 + Intra16x16 + chroma decision, 5 16x8,
                                              // 6 8x16, 7 the Intra4x4 chain).  Waves w and w + 4 share a SIMD: the pairing decides who competes with the 4x4 chain for issue slots
   int c422;                                  // 4:2:2: chroma planes cw x H, 8 x 16 samples per macroblock (ch = H); else 4:2:0
-  int total_mb;                              // macroblocks of the launch (num_slices slices of p.num_mb, cut at the end of the picture)
+  int total_mb;                              // tickets of the launch: macroblocks of num_slices slices of p.num_mb, cut at the end of the picture -- or of every picture of a batch
   int nbands, band_start[9];                 // 8 (or 1): the ticket order is cut into bands of macroblock rows, tickets band_start[b] .. band_start[b + 1] - 1 belong to band b, and
                                              // workgroup g draws from band g % 8 first -- block g is observed to run on XCD g % 8, so an XCD's L2 then only ever sees its band's
                                              // rows of the references' planes (speed only: any workgroup may take any ticket)
@@ -82,38 +114,21 @@ struct PipeArgs {
   long plane_stride;
   int win_h, win_p, win_ox;                  // LDS window of a reference: (16 + 4R) rows of win_p bytes; the macroblock's column 0 sits at byte win_ox
                                              // (2R rounded up to a multiple of 4, so picture dwords stay aligned)
-  const u8 *cur_y, *cur_u, *cur_v;
-  const u8 *ref_y[JMHIP_MB_MAX_REF];         // 16 quarter-pel planes of each reference (plane (0,0) first)
-  const u8 *ref_u[JMHIP_MB_MAX_REF], *ref_v[JMHIP_MB_MAX_REF];
-  u8 *rec_y, *rec_u, *rec_v;
-  u64 *edge;
-  unsigned *done, *sync;
-  const int *order;
-  unsigned epoch;
-  jmhip_mb_record *records;
-  jmhip_db_mb *dbmb;
-  jmhip_db_motion *dbmo;
-  jmhip_mb_record *hrecords;                 // streaming to the host (jmhip_encode_slice_begin): pinned, device-visible copies of the records
-  unsigned *hflags;                          // ... and per macroblock the epoch of the launch whose record is complete there; null otherwise
+  unsigned *sync;
+  const int *order;                          // ticket -> macroblock address (a batch: picture << 16 | address)
   int prof_mode;                             // JMHIP_MB_PROF value: 1 = a 4x4 search's parts in stamps 18..22, 2 = an Intra4x4 block's parts there
   // EPZS (search_mode 3)
   const int *col;                            // [H / 4][W / 4] co-located vectors scaled to this picture (k_epzs_coloc), or null (EPZSTemporal = 0)
-  int *ez_state;                             // per macroblock: its four columns of p_EPZS->distortion [7][4] and p_EPZS->p_motion [num_ref][7][4][4] when it was done
-  int ez_words;                              // ints per macroblock there: 28 + 112 num_ref
-  u64 *mot_out;                              // per 4x4 block of the picture {packed vector, poc of the picture referred to}: later pictures' temporal predictors
+  int ez_words;                              // ints per macroblock of PicView::ez_state: 28 + 112 num_ref
   unsigned long long *prof;                  // profiling aid (JMHIP_MB_PROF=1): 24 time stamps (100 MHz) per macroblock, or null
   // Pictures in flight side by side (jmhip_seq_encode, mbpipe_post.inc): the macroblock's share of the loop filter and of the quarter-pel planes follows its coding
-  // inside the launch, rec_y / rec_u / rec_v are the planes of the slot the picture goes to (filtered in place), and the references may still be in the making
+  // inside the launch, and the references may still be in the making
   int fused;
   int direct8x8;                             // active_sps->direct_8x8_inference_flag (DeblockMb's skip rule for B_Skip: never met in P / I pictures)
-  u8 *out_planes;                            // the sixteen quarter-pel planes of that slot
-  u32 *post;                                 // per macroblock of that slot: post_tag once the macroblock is filtered and its share of the planes is written
-  u32 post_tag;
   int reach_x, reach_y;                      // macroblock (X, r) reads reference samples that macroblocks up to (X + reach_x, r + reach_y) of the reference produce
-  const u32 *ref_post[JMHIP_SEQ_MAX_FLIGHT]; // the post flags of reference r's slot, or null (complete before the launch); references beyond are always complete
-  u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
-  const u64 *mot_ref[2];                     // EPZS in flight: the motion kept with the slots of references 0 / 1 ({vector, poc referred to} per 4x4 block), read where k_epzs_coloc's
-                                             // whole-picture pass would have put the co-located vectors (the reference may still be in the making); null: no temporal predictors
+  int npics;                                 // > 0: a launch of several consecutive pictures (jmhip_seq_batch): pics[0 .. npics), tickets ordered by wavefront index + lag x picture
+  const PicView *pics;
+  PicView v;                                 // the picture of a one-picture launch
 };
 static_assert(sizeof(PipeArgs) <= 4096, "kernel arguments: 4 KB");
 
@@ -138,6 +153,7 @@ struct Shared {
   u32 ptab[8][16];                           // mv_predictor's neighbour table: per (block type, 4x4 position of the block) four codes A, B, C, D (once per launch)
   int avail[4];
   int ticket, addr, err;
+  int vpic;                                  // a launch of several pictures: the picture V holds (-1: none yet)
   int allmv[JMHIP_MB_MAX_REF][8][16];        // currSlice->all_mv[LIST_0][ref][mode][4x4 raster], packed
   int mcost[8][JMHIP_MB_MAX_REF][4];         // p_Vid->motion_cost[mode][LIST_0][ref][block]
   int mvi[8][16][2];                         // per wave: the macroblock's mv_info as that wave's chain sees it {packed mv, ref_idx}
@@ -189,7 +205,10 @@ struct Shared {
   u32 fin_cbp_blk;
   jmhip_mb_record out;
   PostShared post;
+  PicView V;                                 // the picture the workgroup's current macroblock belongs to
 };
+extern __shared__ __attribute__((aligned(16))) u8 mb_smem[];
+#define PV (((Shared *)mb_smem)->V)
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value every lane of the wave holds alike, moved to a scalar register (loop bounds, addresses and branches on it become scalar)
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -715,7 +734,7 @@ __device__ __forceinline__ void ref_rows4(const PipeArgs &A, int ref, int qx, in
   const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);
   // (32-bit offsets: the sixteen planes of a 2160p picture are 140 MB)
   const u32 off = (u32)((qy & 3) * 4 + (qx & 3)) * (u32)A.plane_stride + (u32)(iy + JMHIP_PAD_Y) * (u32)A.ref_pitch + (u32)(ix + JMHIP_PAD_X);
-  const u8 *p = A.ref_y[ref];
+  const u8 *p = PV.ref_y[ref];
 #pragma unroll
   for (int j = 0; j < 4; j++) r[j] = ldref32(p + (off + (u32)j * (u32)A.ref_pitch));
 }
@@ -893,7 +912,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     const int qx = (mbx * 64) + mvx(sv), qy = (mby * 64) + mvy(sv);
     const int iy = clampi3(-JMHIP_PAD_Y, A.H + 3, qy >> 2), ix = clampi3(-JMHIP_PAD_X, A.W + 15, qx >> 2);     // one origin for the 16x16 block
     const int b = lane & 15, bx = (b & 3) * 4, by = (b >> 2) * 4;
-    const u8 *p = A.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + by) * A.ref_pitch + ix + JMHIP_PAD_X + bx;
+    const u8 *p = PV.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + by) * A.ref_pitch + ix + JMHIP_PAD_X + bx;
     u32 r[4], o[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { r[j] = ldref32(p + (long)j * A.ref_pitch); o[j] = S.cur_y[(by + j) * 4 + (bx >> 2)]; }
@@ -902,7 +921,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     if (T8) {                                                  // GetSkipCostMB with Transform8x8Mode: distortion8x8 of the four 8x8 blocks of the 16x16 prediction (one origin)
       int d[64];
       const int b8 = lane & 3, x8 = (b8 & 1) * 8, y8 = (b8 >> 1) * 8;
-      const u8 *p8 = A.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + y8) * A.ref_pitch + ix + JMHIP_PAD_X + x8;
+      const u8 *p8 = PV.ref_y[0] + (long)((qy & 3) * 4 + (qx & 3)) * A.plane_stride + (long)(iy + JMHIP_PAD_Y + y8) * A.ref_pitch + ix + JMHIP_PAD_X + x8;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const u32 r0 = ldref32(p8 + (long)j * A.ref_pitch), r1 = ldref32(p8 + (long)j * A.ref_pitch + 4), o0 = S.cur_y[(y8 + j) * 4 + (x8 >> 2)], o1 = S.cur_y[(y8 + j) * 4 + (x8 >> 2) + 1];

@@ -83,6 +83,10 @@ MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1
                       ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16))])
 FRAME_FORMAT = np.dtype([("yuv_format", "<i4"), ("src_w", "<i4"), ("src_h", "<i4"), ("out_w", "<i4"), ("out_h", "<i4"), ("coded_w", "<i4"), ("coded_h", "<i4"),
                          ("symbol_bytes", "<i4"), ("src_depth", "<i4", (3,)), ("out_depth", "<i4", (3,))])
+# jmhip_seq_picture (include/jmhip.h): 8-byte pointers, the record pointer aligned behind 35 ints
+SEQ_PICTURE = np.dtype({"names": ["d_raw", "src_w", "src_h", "out_slot", "ref_slot", "ref_id", "d_records"],
+                        "formats": ["<u8", "<i4", "<i4", "<i4", ("<i4", (16,)), ("<i4", (16,)), "<u8"],
+                        "offsets": [0, 8, 12, 16, 20, 84, 152], "itemsize": 160})
 SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", "<i4"), ("slice_nr", "<i4"), ("qp", "<i4"), ("qpc", "<i4"),
                          ("search_range", "<i4"), ("num_ref", "<i4"), ("ref_slot", "<i4", (MB_MAX_REF,)), ("ref_id", "<i4", (MB_MAX_REF,)),
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
@@ -107,7 +111,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
            "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
            "jmhip_seq_open", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_planes", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
-           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_allgather_bands"]
+           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_allgather_bands"]
 
 
 class JmHipError(RuntimeError):
@@ -666,6 +670,17 @@ class JmHip:
             self._ck(self.lib.jmhip_seq_record(self.h, int(entry), first + k, C.byref(p)))
             out[k] = np.frombuffer((C.c_char * MB_RECORD.itemsize).from_address(p.value), MB_RECORD)[0]
         return out
+
+    def seq_batch(self, prm, pictures, direct8x8=1):
+        """jmhip_seq_batch: consecutive P pictures in one launch.  pictures: dicts with d_raw, src_w, src_h, out_slot, ref_slot (list), ref_id (list), d_records
+        (device pointers as ints); asynchronous -- synchronize() reports the launch's errors"""
+        prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)
+        a = np.zeros(len(pictures), SEQ_PICTURE)
+        for k, q in enumerate(pictures):
+            a[k]["d_raw"], a[k]["src_w"], a[k]["src_h"], a[k]["out_slot"], a[k]["d_records"] = int(q["d_raw"]), q["src_w"], q["src_h"], q["out_slot"], int(q["d_records"])
+            a[k]["ref_slot"][:len(q["ref_slot"])] = q["ref_slot"]
+            a[k]["ref_id"][:len(q["ref_id"])] = q["ref_id"]
+        self._ck(self.lib.jmhip_seq_batch(self.h, _vp(prm), int(direct8x8), len(pictures), _vp(a)))
 
     def seq_get_recon(self, slot):
         """(y, u, v) uint8: the filtered reconstruction a sequence launch left in `slot`"""

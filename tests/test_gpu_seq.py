@@ -71,6 +71,63 @@ class FlightEncoder:
         return [self.results[k] for k in range(self.npic)]
 
 
+class BatchEncoder:
+    """IPPP with the P pictures in launches of several pictures each (jmhip_seq_batch): the I picture and the first P pictures (fewer references than num_ref) through
+    jmhip_seq_encode, then batches of `sizes` pictures in turn; picture k goes to slot k % nslots."""
+
+    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0):
+        import torch
+        import jm_amd.lib as L
+        self.L, self.torch = L, torch
+        self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas, self.sizes, self.nslots = W, H, qp, R, num_ref, lambdas, list(sizes), nslots
+        self.kw = dict(cabac=cabac, search_mode=search_mode, transform8x8=transform8x8, yuv_format=yuv_format)
+        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=nslots, yuv_format=yuv_format)
+        self.J.seq_open(1)
+        if workgroups:
+            self.J.set_pipeline_workgroups(workgroups)
+
+    def params(self, k, st, nref):
+        nmb = (self.W // 16) * (self.H // 16)
+        lam_mf, lam_md = self.lambdas[st]
+        cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, nmb, self.qp, self.R, nref, lam_mf, lam_md, **self.kw)
+        return slice_params(self.L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], 0, {}, 2 * k)
+
+    def run(self, frames, sw, sh):
+        J, torch, L = self.J, self.torch, self.L
+        nmb = (self.W // 16) * (self.H // 16)
+        out = {}
+
+        def keep(k, recs):
+            out[k] = (recs, J.seq_get_recon(k % self.nslots), J.get_subplanes(k % self.nslots))
+        k = 0
+        while k < len(frames) and k < self.num_ref:              # pictures with fewer references than the batch's
+            J.seq_set_frame(0, frames[k], sw, sh)
+            J.seq_encode(0, self.params(k, 2 if k == 0 else 0, min(self.num_ref, k)), k % self.nslots, 1, False)
+            J.seq_wait(0)
+            keep(k, J.seq_records(0))
+            k += 1
+        turn = 0
+        while k < len(frames):
+            n = min(self.sizes[turn % len(self.sizes)], len(frames) - k)
+            turn += 1
+            d_raw = [torch.from_numpy(np.ascontiguousarray(frames[k + i])).cuda() for i in range(n)]
+            d_rec = torch.zeros(n * nmb * L.MB_RECORD.itemsize, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            pics = [dict(d_raw=d_raw[i].data_ptr(), src_w=sw, src_h=sh, out_slot=(k + i) % self.nslots, ref_slot=[(k + i - 1 - r) % self.nslots for r in range(self.num_ref)],
+                         ref_id=[k + i - 1 - r for r in range(self.num_ref)], d_records=d_rec.data_ptr() + i * nmb * L.MB_RECORD.itemsize) for i in range(n)]
+            J.seq_batch(self.params(k, 0, self.num_ref), pics)
+            J.synchronize()
+            recs = np.frombuffer(d_rec.cpu().numpy().tobytes(), L.MB_RECORD).reshape(n, nmb)
+            # every picture's planes can only be read while its slot still holds it: the last nslots pictures of the batch
+            for i in range(n):
+                if i >= n - self.nslots:
+                    keep(k + i, recs[i].copy())
+                else:
+                    out[k + i] = (recs[i].copy(), None, None)
+            k += n
+        return [out[i] for i in range(len(frames))]
+
+
 def classic(W, H, qp, R, num_ref, lam, frames, sw=None, sh=None, **kw):
     dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, 0, **kw)
     out = []
@@ -86,6 +143,8 @@ def compare(want, got, what):
     for n, (a, b) in enumerate(zip(want, got)):
         d = first_difference(mb_tap.canonical(as_oracle_records(a[0])), mb_tap.canonical(as_oracle_records(b[0])))
         assert d is None, (what, "picture", n, "record", d)
+        if b[1] is None:                                      # a batch's picture whose slot a later picture of the batch took: the records say it all
+            continue
         for p, (x, y) in enumerate(zip(a[1], b[1])):
             if not np.array_equal(x, y):
                 bad = np.argwhere(x != y)
@@ -133,6 +192,62 @@ def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, de
     got = fl.finish()
     fl.J.close()
     compare(want, got, (W, H, R, num_ref, depth))
+
+
+@pytest.mark.parametrize("W,H,R,num_ref,qp,sizes,nslots,wg,seed,kw", [
+    (176, 144, 16, 1, 28, [3], 4, 0, 21, {}),
+    (320, 192, 32, 1, 28, [8], 10, 0, 22, {}),                # every picture its own slot
+    (320, 192, 32, 1, 28, [9], 3, 0, 23, {}),                 # three slots in turn: a picture starts when the one two before it is done
+    (320, 192, 32, 1, 28, [7], 2, 0, 24, {}),                 # two slots: one picture after the other, inside one launch
+    (320, 192, 32, 3, 36, [6], 6, 0, 25, {}),                 # three references
+    (640, 368, 32, 2, 28, [2, 5, 1], 5, 0, 26, {}),           # batch after batch: references from the batch before; a batch of one
+    (640, 368, 8, 2, 20, [8], 12, 0, 27, {}),                 # a short reach: pictures three diagonals apart
+    (64, 48, 32, 2, 28, [6], 5, 0, 28, {}),                   # smaller than the search window
+    (16, 16, 16, 1, 28, [5], 3, 0, 29, {}),                   # a single macroblock per picture
+    (320, 192, 16, 2, 28, [6], 8, 3, 30, {"cabac": 1, "transform8x8": 1}),     # three workgroups for everything
+    (320, 192, 32, 2, 28, [6], 8, 0, 31, {"search_mode": 1}),
+    (320, 192, 16, 1, 30, [6], 4, 0, 32, {"yuv_format": 2, "search_mode": 1, "transform8x8": 1}),
+])
+def test_pictures_in_one_launch_equal_picture_after_picture(W, H, R, num_ref, qp, sizes, nslots, wg, seed, kw):
+    """jmhip_seq_batch: the macroblocks of several consecutive pictures from one queue, ordered by wavefront index + lag x picture"""
+    f = int(192 * 2 ** ((qp - 28) / 6))
+    lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    nfr = num_ref + sum(sizes) + (1 if len(sizes) == 1 else 0)
+    if kw.get("yuv_format") == 2:
+        frames = [np.concatenate([fr[:W * H], np.repeat(fr[W * H:].reshape(2, H // 2, W // 2), 2, axis=1).ravel()]) for fr in synthetic_clip(W, H, nfr, seed)]
+    else:
+        frames = synthetic_clip(W, H, nfr, seed)
+    want = classic(W, H, qp, R, num_ref, lam, frames, **kw)
+    be = BatchEncoder(W, H, qp, R, num_ref, lam, sizes, nslots, workgroups=wg, **kw)
+    got = be.run(frames, W, H)
+    be.J.close()
+    compare(want, got, (W, H, R, num_ref, sizes, nslots))
+
+
+def test_batch_refuses_what_it_does_not_cover():
+    import torch
+    import jm_amd.lib as L
+    W, H = 176, 144
+    nmb = (W // 16) * (H // 16)
+    J = L.JmHip(W, H, search_range=16, num_ref_slots=4, yuv_format=1)
+    raw = torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda")
+    rec = torch.zeros(nmb * L.MB_RECORD.itemsize, dtype=torch.uint8, device="cuda")
+    pic = dict(d_raw=raw.data_ptr(), src_w=W, src_h=H, out_slot=1, ref_slot=[0], ref_id=[0], d_records=rec.data_ptr())
+    p = slice_params(L, pyjmo.mbenc_cfg(W, H, 0, 0, nmb, 28, 16, 1, *LAMBDAS[0]), 0, [0], [0])
+    with pytest.raises(L.JmHipError, match="jmhip_seq_open"):
+        J.seq_batch(p, [pic])
+    J.seq_open(1)
+    with pytest.raises(L.JmHipError, match="holds no picture"):
+        J.seq_batch(p, [pic])                                   # slot 0 was never filled
+    with pytest.raises(L.JmHipError, match="its reference"):
+        J.seq_batch(p, [dict(pic, out_slot=0)])
+    with pytest.raises(L.JmHipError, match="P pictures with a full search"):
+        J.seq_batch(slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2]), 0, [], []), [pic])
+    with pytest.raises(L.JmHipError, match="P pictures with a full search"):
+        J.seq_batch(slice_params(L, pyjmo.mbenc_cfg(W, H, 0, 0, nmb, 28, 16, 1, *LAMBDAS[0], search_mode=3), 0, [0], [0], 0, {}, 2), [pic])
+    with pytest.raises(L.JmHipError):
+        J.seq_batch(p, [dict(pic, d_records=0)])
+    J.close()
 
 
 @pytest.mark.parametrize("kind,R,num_ref,qp", [("flat", 32, 1, 44), ("noise", 16, 2, 12), ("stripes", 32, 2, 28), ("still", 32, 1, 30)])
