@@ -506,7 +506,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--flight", type=int, default=8, help="pictures of the sequence in flight side by side (jmhip_seq_open; 1 = one launch at a time)")
-    ap.add_argument("--workgroups", type=int, default=0, help="workgroups per picture in flight (0: 256 / flight)")
+    ap.add_argument("--workgroups", type=int, default=0, help="workgroups per picture in flight (0: 256 / flight); with --launch batch: workgroups of the launch (0: 256)")
+    ap.add_argument("--launch", choices=["batch", "pictures"], default="batch", help="batch: the timed P pictures in ONE launch, every picture's macroblocks from one queue (jmhip_seq_batch); "
+                    "pictures: a launch per picture, --flight of them side by side (jmhip_seq_encode)")
+    ap.add_argument("--slots", type=int, default=24, help="--launch batch: reference slots the pictures go to in turn (a picture starts once the last reader of its slot is done)")
     ap.add_argument("--streams", type=int, default=8, help="sequences encoded side by side for the extra concurrent_streams figure (0: skip)")
     args = ap.parse_args()
 
@@ -539,12 +542,13 @@ def main():
     depth = max(1, min(8, args.flight))
     if one_gpu and world > 1:
         depth = max(1, 4 // world)                                        # the ranks share one GPU: the launches in flight of ALL of them must leave room for each rank's oldest picture
-    nslots = depth + 2                                                     # one reference + the pictures in flight + one: no launch ever waits for a slot
+    batch = args.launch == "batch"
+    nslots = max(depth + 2, min(32, args.slots)) if batch else depth + 2   # one reference + the pictures in flight + one: no launch ever waits for a slot
     nseq = 1 + args.warmup + args.steps                                    # the I picture, the warm-up and the timed P pictures: one IPPP sequence
 
     stream = torch.cuda.current_stream()
     ctx = JmHip(W, HP, search_range=R, num_ref_slots=nslots, yuv_format=1, device=local, stream=stream.cuda_stream)
-    ctx.seq_open(depth, args.workgroups)
+    ctx.seq_open(1 if batch else depth, 0 if batch else args.workgroups)
 
     def slice_prm(slice_type, first, num, slice_nr, num_ref):
         return slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref)
@@ -582,18 +586,39 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
-    for k in range(1 + args.warmup):                                       # the I picture and the warm-up P pictures
-        step(k)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(1 + args.warmup, nseq):
-        step(k)
-    barrier()
-    dt = over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)
-    kernel_ms = [ctx.seq_kernel_ms(e) for e in range(min(depth, args.steps))]      # the last launches, in flight together
-    for e in range(depth):
-        ctx.seq_wait(e)                                                    # reads the device-side error words: the pipeline's is sticky (a launch that finds it set does nothing), so an incomplete picture cannot go unnoticed
-    ctx.synchronize()
+    def steps_in_one_launch(k0, k1):
+        """pictures k0 .. k1 - 1 of the sequence, the same work per picture, in ONE launch of k_mb_pipe: the launch's workgroups draw the macroblocks of all of them from one queue
+        ordered by wavefront index + 16 x picture (jmhip_seq_batch); asynchronous"""
+        ctx.seq_batch(seq_prm(k0), [dict(d_raw=d_raw[k].data_ptr(), src_w=W, src_h=src_h, out_slot=k % nslots, ref_slot=[(k - 1) % nslots], ref_id=[k - 1],
+                                         d_records=d_recs[k].data_ptr()) for k in range(k0, k1)])
+
+    if batch:
+        ctx.set_pipeline_workgroups(args.workgroups or (256 // world if one_gpu else 256))
+        step(0)                                                            # the I picture
+        if args.warmup:
+            steps_in_one_launch(1, 1 + args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        steps_in_one_launch(1 + args.warmup, nseq)
+        barrier()
+        dt = over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        kernel_ms = [ctx.last_kernel_ms(5)]                                # the timed launch
+        ctx.seq_wait(0)
+        ctx.synchronize()                                                  # reads the device-side error word (sticky: an incomplete picture cannot go unnoticed)
+        ctx.set_pipeline_workgroups(0)
+    else:
+        for k in range(1 + args.warmup):                                   # the I picture and the warm-up P pictures
+            step(k)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(1 + args.warmup, nseq):
+            step(k)
+        barrier()
+        dt = over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        kernel_ms = [ctx.seq_kernel_ms(e) for e in range(min(depth, args.steps))]      # the last launches, in flight together
+        for e in range(depth):
+            ctx.seq_wait(e)                                                # reads the device-side error words: the pipeline's is sticky (a launch that finds it set does nothing), so an incomplete picture cannot go unnoticed
+        ctx.synchronize()
     pipe_ms = over_ranks(float(np.mean(kernel_ms)), dist.ReduceOp.MAX)
     recs_all = d_recs.cpu().numpy().view(MB_RECORD).reshape(nseq, nmb)
 
@@ -691,7 +716,7 @@ def main():
         # ... and the same search as a sequence with pictures in flight (every search asks for what it reaches of a reference in the making): I + 16 P pictures of the clip, one
         # reference; the first three pictures' records against the real encoder's (mb_low_g3h holds three: I, P with one reference, P with two -- the third differs by its reference count, so two are compared)
         nq = min(17, nseq)
-        ctx.seq_open(depth, args.workgroups)
+        ctx.seq_open(depth, 0 if batch else args.workgroups)
         d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
 
         def estep(k):
@@ -725,15 +750,18 @@ def main():
         alg_mb = 6656 + 328 + 128 + 2900 + 1216 + 384 + 504 + 4096
         alg = alg_mb * nmb
         sad_ops = 7 * 256 * (2 * R + 1) ** 2 * nmb                       # seven block types x 256 samples x 4225 positions per macroblock-reference
-        conc = pipe_ms * 1e-3 * args.steps / dt                            # launches in flight at a time, on average over the timed region
+        per_launch = args.steps if batch else 1                          # pictures a launch codes
+        conc = pipe_ms * 1e-3 * (args.steps / per_launch) / dt           # launches in flight at a time, on average over the timed region
         solo = float(np.mean(solo_ms)) if solo_ms else None
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg * args.steps / dt / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(alg * args.steps / dt / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
-                "traffic_source": PIPE_TRAFFIC_SOURCE, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg,
-                "launches_in_flight": round(conc, 2),
-                "per_launch": {"achieved": round(alg / (pipe_ms * 1e-3) / 1e9, 3), "frac": round(alg / (pipe_ms * 1e-3) / 8e12, 6), "avg_kernel_ms_alone": round(solo, 3) if solo else None,
-                               "note": "one launch = one picture; `depth` launches overlap, each slower than alone because they share the chip -- achieved / frac above are the "
-                                       "timed region's: algorithmic bytes of its launches over its wall time"},
+                "traffic_source": PIPE_TRAFFIC_SOURCE, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg * per_launch,
+                "pictures_per_launch": per_launch, "launches_in_flight": round(conc, 2),
+                "per_launch": {"achieved": round(alg * per_launch / (pipe_ms * 1e-3) / 1e9, 3), "frac": round(alg * per_launch / (pipe_ms * 1e-3) / 8e12, 6),
+                               "one_picture_launch_alone_ms": round(solo, 3) if solo else None,
+                               "note": ("one launch = the timed region's pictures: every picture's macroblocks from one queue (jmhip_seq_batch)" if batch else
+                                        "one launch = one picture; `depth` launches overlap, each slower than alone because they share the chip") +
+                                       " -- achieved / frac above are the timed region's: algorithmic bytes of its launches over its wall time"},
                 "abs_diff_per_s_jm_equivalent": round(sad_ops * args.steps / dt / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops * args.steps / dt / 148.4e12, 5),
                 "critical_path": {"steps": steps_chain, "us_per_step_alone": round(solo * 1e3 / steps_chain, 1) if solo else None,
                                   "note": "a macroblock waits for its left and upper-right neighbours' vectors: one picture is a chain of mb_w + 2 (mb_h - 1) macroblocks whatever the "
@@ -751,9 +779,13 @@ def main():
             "config": {"workload": ("" if N == 1 else f"{N} GPUs, one closed GOP of the workload below per GPU (no collective on the data path; a step = one picture on EVERY GPU).  ") +
                                    "configs[1]: 1080p 4:2:0 synthetic (1920x1088 coded, 8160 MB), Baseline IPPP, one sequence: a step is the next P picture of it -- read_one_frame / pad_borders from the "
                                    "file's bytes in HBM, encode_one_macroblock_low of every macroblock on the device (FullSearch SR=32 at every block's own centre, 1 ref = the picture before, QP 28, "
-                                   "mode decision, transform/quant, reconstruction), DeblockFrame, getSubImagesLuma -- with up to `pictures_in_flight` consecutive pictures in flight; the timed region "
+                                   "mode decision, transform/quant, reconstruction), DeblockFrame, getSubImagesLuma -- " +
+                                   ("the timed P pictures in one launch whose workgroups draw every picture's macroblocks from one queue, a picture 16 wavefront steps behind the one it refers to" if batch else
+                                    "with up to `pictures_in_flight` consecutive pictures in flight, a launch each") + "; the timed region "
                                    "starts and ends with an idle device (pipeline fill and drain are inside it); entropy coding is the host's and is outside the step (see end_to_end)",
-                       "macroblocks_per_step_per_gpu": nmb, "search_range": R, "pictures_in_flight": depth, "workgroups_per_picture": args.workgroups or min(80, 256 // depth),
+                       "macroblocks_per_step_per_gpu": nmb, "search_range": R, "launch": args.launch,
+                       **({"pictures_per_launch": args.steps, "reference_slots": nslots, "workgroups": args.workgroups or 256} if batch else
+                          {"pictures_in_flight": depth, "workgroups_per_picture": args.workgroups or min(80, 256 // depth)}),
                        "parallelism": "1 GPU" if N == 1 else f"{N} GPUs x one GOP each (JM with IDRPeriod = GOP length codes the same pictures: closed GOPs are independent)",
                        "records_equal_jm": bool(equal), "pictures_checked_against_jm": ngold,
                        "records_equal_picture_after_picture": bool(same), "pictures_checked_against_picture_after_picture": nseq,

@@ -319,6 +319,25 @@ def test_1080p_sequence_in_flight_equals_the_reference_encoder():
         assert d is None, ("against the reference encoder, picture", n, d)
 
 
+def test_1080p_sequence_in_one_launch_equals_the_reference_encoder():
+    """configs[1] at its own size, the P pictures in one launch (jmhip_seq_batch, what bench.py times): the six pictures of tests/golden/mb_low_g6r.npz against the REAL encoder's
+    records, four more against the picture-after-picture path, with four slots in turn (pictures wait for their slot inside the launch)"""
+    import bench
+    from test_gpu_mbenc import load_case
+    c = load_case("g6r")
+    W, H, R = c["W"], c["H"], c["R"]
+    nmb = (W // 16) * (H // 16)
+    frames = bench.yuv_frames(10)
+    want = classic(W, H, c["qp"], R, 1, c["lam"], frames, c["sw"], c["sh"])
+    be = BatchEncoder(W, H, c["qp"], R, 1, c["lam"], [9], 4)
+    got = be.run(frames, c["sw"], c["sh"])
+    be.J.close()
+    compare(want, got, "1080p, one launch")
+    for n in range(c["nfr"]):
+        d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(got[n][0])))
+        assert d is None, ("against the reference encoder, picture", n, d)
+
+
 def test_1080p_epzs_sequence_in_flight_equals_the_reference_encoder():
     """configs[2]'s search at its own size with pictures in flight: six pictures of the 1080p clip, EPZS with the shipped switches, CABAC, up to five references -- every
     record against the REAL encoder's (tests/golden/mb_low_g6e.npz)"""
