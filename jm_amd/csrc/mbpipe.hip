@@ -696,6 +696,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     }
   }
   if (c.count && lane == 0) { ytab_own[70] += (u32)dbg_steps; ytab_own[71] += (u32)dbg_items; }     // JMHIP_MB_PROF=11: per-wave totals (spare entries of the wave's row table)
+  if (c.count && lane == 0) ytab_own[68] += (u32)(dbg_steps * 64 + dbg_items) * (u32)(BW * BH / 16);            // ... and the absolute differences issued, in units of 16 (a window row read by the 64 sliding lanes is BH rows of BW samples each)
   if (pf && lane == 0) { pf[23] = wall_clock64(); pf[26] = (unsigned long long)dbg_steps | ((unsigned long long)dbg_items << 16) | ((unsigned long long)(hi1 - lo1 + 1 > 0 ? hi1 - lo1 + 1 : 0) << 32); }
   const u32 hi = wave_min_u32((u32)(best >> 32));              // the smallest cost, then the earliest spiral index among the candidates that have it
   const u32 lo = wave_min_u32((u32)(best >> 32) == hi ? (u32)best : 0xffffffffu);
