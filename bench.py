@@ -40,10 +40,16 @@ QP = 28
 G2R_FLAGS = ("InputFile=syn1080p.yuv", "SourceWidth=1920", "SourceHeight=1080", "OutputWidth=1920", "OutputHeight=1080", "SearchMode=-1", "SearchRange=32",
              "NumberReferenceFrames=1", "LevelIDC=51", "RDOptimization=0", "AdaptiveRounding=0", "OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
 G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's .264 for two frames of the clip with these flags
-# HBM bytes of one k_mb_pipe launch on the P picture: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, corrected as
-# MI355X_MICROARCH.md prescribes (profiles/collect2.sh, profiles/r03_v8_kernel_stats.md)
-PIPE_TRAFFIC_BYTES = 140176272            # 1.48 x the algorithmic bytes (DESIGN.md section 0 "Scratch and traffic")
-PIPE_TRAFFIC_SOURCE = "profiles/r03_v8_kernel_stats.md (separate rocprofv3 --pmc passes; the round-3 kernel without the loop filter and interpolation inside: not re-measured in this run)"
+# HBM-side bytes of k_mb_pipe PER PICTURE: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command (--steps 20 --warmup 5), corrected as
+# MI355X_MICROARCH.md prescribes (profiles/collect5.sh, profiles/r04_v4_kernel_stats.md).  The counters sit between the L2s and the fabric: they also count what the 256 MB
+# Infinity Cache serves.  Most of it is by design: every reference sample is read with an sc1 load (past the XCD's L2 -- another XCD may have written it microseconds ago), 678 MB
+# of reads per picture; WRITE_SIZE counts 32-byte sectors (a 16-byte write-through store counts twice: profiles/r04_write_calib.txt).  DESIGN.md section 0a.
+PIPE_TRAFFIC_BYTES = {"batch": 1004052267, "pictures": 464000000}          # per picture: one launch for all timed pictures (r04_v4) / a launch per picture, eight in flight (r04_v1)
+# absolute differences the integer searches of one P picture of the clip ISSUE (the kernel's own counters, JMHIP_MB_PROF=11: profiles/batch_prof.py 25 fs 11): 81.5 % of the 61.78 G
+# JM's full search visits -- the cost bound of me_fullsearch.c:83 skips the rest for the small blocks
+VALU_ISSUED_PER_PICTURE = 50.366e9
+VALU_ISSUED_SOURCE = "profiles/r04_valu_issued.txt (the kernel's own counters over one picture of this clip; not re-measured in this run)"
+PIPE_TRAFFIC_SOURCE = "profiles/r04_v4_kernel_stats.md (--launch batch) / profiles/r04_v1_kernel_stats.md (--launch pictures): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, per picture x the pictures of a launch; not re-measured in this run"
 
 
 def synth_luma(n_frames, seed=1234):
@@ -754,7 +760,7 @@ def main():
         conc = pipe_ms * 1e-3 * (args.steps / per_launch) / dt           # launches in flight at a time, on average over the timed region
         solo = float(np.mean(solo_ms)) if solo_ms else None
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg * args.steps / dt / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(alg * args.steps / dt / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES if N == 1 else None,
+                "frac": round(alg * args.steps / dt / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES[args.launch] * per_launch if N == 1 else None,
                 "traffic_source": PIPE_TRAFFIC_SOURCE, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg * per_launch,
                 "pictures_per_launch": per_launch, "launches_in_flight": round(conc, 2),
                 "per_launch": {"achieved": round(alg * per_launch / (pipe_ms * 1e-3) / 1e9, 3), "frac": round(alg * per_launch / (pipe_ms * 1e-3) / 8e12, 6),
@@ -763,6 +769,7 @@ def main():
                                         "one launch = one picture; `depth` launches overlap, each slower than alone because they share the chip") +
                                        " -- achieved / frac above are the timed region's: algorithmic bytes of its launches over its wall time"},
                 "abs_diff_per_s_jm_equivalent": round(sad_ops * args.steps / dt / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops * args.steps / dt / 148.4e12, 5),
+                "valu_frac_issued": round(VALU_ISSUED_PER_PICTURE * args.steps / dt / 148.4e12, 5), "valu_issued_source": VALU_ISSUED_SOURCE,
                 "critical_path": {"steps": steps_chain, "us_per_step_alone": round(solo * 1e3 / steps_chain, 1) if solo else None,
                                   "note": "a macroblock waits for its left and upper-right neighbours' vectors: one picture is a chain of mb_w + 2 (mb_h - 1) macroblocks whatever the "
                                           "chip's width, with 27 of 8160 macroblocks in flight on average.  What fills the chip is the NEXT pictures: macroblock (X, r) of picture n + 1 "

@@ -3,8 +3,8 @@
 tests/golden/mb_low_* records) on seeded random configurations -- picture size, search range and mode (full search / fast full search / EPZS with random switches),
 references, QP, slices (separate launches or side by side in one), CAVLC / CABAC, 8x8 transform, 4:2:0 / 4:2:2, default or q_offset.cfg quantiser offsets, clips with
 a motion field or adversarial content.  Every macroblock record and the reconstruction before and after the loop filter must be identical.  Configurations the
-sequence entry points cover (full searches, one slice) are coded a second time with a random number of pictures in flight (jmhip_seq_*): records, filtered pictures and
-sub-pel planes must equal the picture-after-picture run's.
+sequence entry points cover (one slice) are coded a second time with a random number of pictures in flight (jmhip_seq_*) and, the full searches, a third time with the P pictures
+in launches of several pictures (jmhip_seq_batch): records, filtered pictures and sub-pel planes must equal the picture-after-picture run's.
 TEST INFRASTRUCTURE (uses oracle/).   usage: python tests/fuzz_mbenc.py <seconds> [first seed]"""
 import os
 import sys
@@ -21,7 +21,7 @@ from oracle import pyjmo
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 offsets = pyjmo.load_q_offsets(os.path.join(ROOT, "tests", "golden", "q_offset.cfg"))
-t0, done, by_mode, flights = time.time(), 0, {0: 0, 1: 0, 3: 0}, 0
+t0, done, by_mode, flights, batches = time.time(), 0, {0: 0, 1: 0, 3: 0}, 0, 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     sm = int(rng.choice([0, 0, 1, 3, 3]))                     # pyjmo search_mode: 0 / -1 full search, 1 fast full search, 3 EPZS
@@ -92,5 +92,17 @@ while time.time() - t0 < budget:
         finally:
             fl.J.close()
         flights += 1
+        if sm != 3 and num_ref <= 8 and len(frames) > num_ref:     # ... and once more with the P pictures in launches of several pictures (jmhip_seq_batch)
+            nslots = int(rng.integers(num_ref + 1, num_ref + 6))
+            be = TS.BatchEncoder(W, H, qp, R, num_ref, lam, [int(rng.integers(1, 4)), int(rng.integers(1, 4))], nslots, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv,
+                                 workgroups=int(rng.choice([0, 0, 2, 19])))
+            try:
+                TS.compare(classic, be.run(frames, W, H), ("one launch", nslots))
+            except Exception as e:
+                print("FAILED (pictures in one launch)", dict(desc, slots=nslots), repr(e)[:600])
+                sys.exit(1)
+            finally:
+                be.J.close()
+            batches += 1
     done += 1; by_mode[sm] += 1; seed += 1
-print(f"fuzz_mbenc: {done} random configurations identical to the oracle in {time.time() - t0:.0f} s (full search {by_mode[0]}, fast full search {by_mode[1]}, EPZS {by_mode[3]}; {flights} of them once more with pictures in flight); next seed {seed}")
+print(f"fuzz_mbenc: {done} random configurations identical to the oracle in {time.time() - t0:.0f} s (full search {by_mode[0]}, fast full search {by_mode[1]}, EPZS {by_mode[3]}; {flights} of them once more with pictures in flight, {batches} with the P pictures in launches of several); next seed {seed}")
