@@ -311,9 +311,11 @@ static int adapter_on(VideoParameters *p_Vid)
     if (G.R > JMHIP_MAX_SEARCH_RANGE) { G.part_fs = G.part_ffs = 0; G.R = JMHIP_MAX_SEARCH_RANGE; }
     if (G.R < 1) G.R = 1;
     G.nslots = imin(MAX_SLOTS, p_Vid->max_num_references + 2);
-    {                                                       /* pictures in flight: JMHIP_ADAPTER_FLIGHT = 2 .. 8 entries (default 4; 0 or 1: off) */
+    {                                                       /* pictures in flight: JMHIP_ADAPTER_FLIGHT = 2 .. 8 entries (0 or 1: off).  Default 4 for the full searches -- the host's
+                                                               entropy coder is what bounds such a sequence, and the first pictures of a run get more workgroups each -- and 8 for EPZS with
+                                                               its up to five references per picture, where the device is (nine 1080p pictures of configs[2]: 52 -> 19 ms per later P picture) */
       const char *fl = getenv("JMHIP_ADAPTER_FLIGHT");
-      F.depth = fl ? atoi(fl) : 4;
+      F.depth = fl ? atoi(fl) : (p_Inp->SearchMode[0] == EPZS ? 8 : 4);
       if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || p_Inp->slice_mode != NO_SLICES || p_Inp->NumberBFrames != 0 ||
           (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH && p_Inp->SearchMode[0] != EPZS)) F.depth = 0;
       if (F.depth > FL_MAX) F.depth = FL_MAX;
