@@ -206,9 +206,11 @@ struct Shared {
   jmhip_mb_record out;
   PostShared post;
   PicView V;                                 // the picture the workgroup's current macroblock belongs to
+  PicView Vp;                                // ... and the one its PREVIOUS macroblock belonged to: that macroblock's post stage runs beside this one's staging (mbpipe_kernel.inc)
 };
 extern __shared__ __attribute__((aligned(16))) u8 mb_smem[];
 #define PV (((Shared *)mb_smem)->V)
+#define PVP (((Shared *)mb_smem)->Vp)
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value every lane of the wave holds alike, moved to a scalar register (loop bounds, addresses and branches on it become scalar)
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
