@@ -301,7 +301,56 @@ def configs3_device(device):
     step = (time.perf_counter() - t0) / 5
     ctx.close()
     k = float(np.mean(ms[1:]))
-    return {"kernel": "k_mb_pipe", "slices_in_one_launch": ns, "avg_kernel_ms": round(k, 3), "ms_per_step": round(step * 1e3, 3), "macroblocks_per_s_step": round(32400 / step, 1)}
+    out = {"kernel": "k_mb_pipe", "slices_in_one_launch": ns, "avg_kernel_ms": round(k, 3), "ms_per_step": round(step * 1e3, 3), "macroblocks_per_s_step": round(32400 / step, 1)}
+    # ... and 2160p as ONE slice per picture, an IPPP sequence with its P pictures in one launch (jmhip_seq_batch): not configs[3] (eight slices), the same picture size with four times
+    # 1080p's macroblocks to run at a time; the first P pictures' records against the picture-after-picture path
+    from jm_amd.lib import MB_RECORD
+    nmb4, npic, nslots, ncheck = 32400, 13, 16, 3
+    with tempfile.TemporaryDirectory() as t:
+        synclip.syn2160p(os.path.join(t, "s.yuv"), npic)
+        data = np.fromfile(os.path.join(t, "s.yuv"), np.uint8).reshape(npic, fs)
+    dev = torch.device("cuda", device)
+    d_raw = torch.from_numpy(data).to(dev)
+    d_rec = torch.zeros((npic, nmb4 * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
+    ctx = JmHip(W4, H4, search_range=R, num_ref_slots=nslots, yuv_format=1, device=device, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.seq_open(1)
+
+    def prm1(kk):
+        q = slice_params(SLICE_PARAMS, 2 if kk == 0 else 0, 0, nmb4, 0, 0 if kk == 0 else 1)
+        if kk:
+            q["ref_slot"][0, 0], q["ref_id"][0, 0] = (kk - 1) % nslots, kk - 1
+        return q
+
+    def launch(k0, k1):
+        ctx.seq_batch(prm1(k0), [dict(d_raw=d_raw[kk].data_ptr(), src_w=W4, src_h=H4, out_slot=kk % nslots, ref_slot=[(kk - 1) % nslots], ref_id=[kk - 1],
+                                      d_records=d_rec[kk].data_ptr()) for kk in range(k0, k1)])
+    ctx.seq_set_frame_dev(0, d_raw[0].data_ptr(), W4, H4)
+    ctx.seq_encode(0, prm1(0), 0, 1, False, d_rec[0].data_ptr())
+    launch(1, 3)                                                          # warm-up
+    ctx.seq_wait(0)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    launch(3, npic)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recs = d_rec.cpu().numpy().view(MB_RECORD).reshape(npic, nmb4)
+    ctx.seq_close()
+    same = True
+    for kk in range(1 + ncheck):                                          # the same pictures one after the other
+        ctx.set_current_frame(data[kk], W4, H4)
+        q = prm1(kk)
+        if kk:
+            q["ref_slot"][0, 0] = (kk - 1) & 1
+        same = same and ctx.encode_slice(q).tobytes() == recs[kk].tobytes()
+        ctx.deblock_picture_dev(1)
+        ctx.reference_from_recon(kk & 1)
+    ctx.close()
+    out["one_slice_sequence_in_one_launch"] = {"pictures": npic - 3, "ms_per_picture": round(dt / (npic - 3) * 1e3, 3), "macroblocks_per_s": round(nmb4 * (npic - 3) / dt, 1),
+                                               "records_equal_picture_after_picture": bool(same), "pictures_checked": 1 + ncheck,
+                                               "note": "3840x2160 IPPP, one slice per picture, SR 32, one reference: the P pictures in one launch; not the BASELINE configuration (eight slices)"}
+    return out
 
 
 def concurrent_streams(S, raw0, raw1, src_h, slice_prm, device, steps):
