@@ -781,16 +781,18 @@ def main():
                            "records_equal_jm": bool(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), g3)))}
         # ... and the same search as a sequence with pictures in flight (every search asks for what it reaches of a reference in the making): I + 16 P pictures of the clip, one
         # reference; the first three pictures' records against the real encoder's (mb_low_g3h holds three: I, P with one reference, P with two -- the third differs by its reference count, so two are compared)
-        nq = min(17, nseq)
-        ctx.seq_open(depth, 0 if batch else args.workgroups)
+        # EPZS P pictures run as four-wave workgroups, two to a compute unit: sixteen pictures in flight x 2 x 16 workgroups fill the chip (profiles/r04_epzs_four_wave.txt)
+        nq = min(33, nseq)
+        depth_e = depth if (one_gpu and world > 1) else max(1, min(16, nslots - 2, 2 * args.flight))
+        ctx.seq_open(depth_e, 0 if batch else args.workgroups)
         d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
 
         def estep(k):
             q = epzs_prm(2 if k == 0 else 0, 0 if k == 0 else 1, 2 * k)
             if k:
                 q["ref_slot"][0, 0], q["ref_id"][0, 0], q["poc_ref"][0, 0] = (k - 1) % nslots, k - 1, 2 * (k - 1)
-            ctx.seq_set_frame_dev(k % depth, d_raw[k].data_ptr(), W, src_h)
-            ctx.seq_encode(k % depth, q, k % nslots, 1, False, d_r2[k].data_ptr())
+            ctx.seq_set_frame_dev(k % depth_e, d_raw[k].data_ptr(), W, src_h)
+            ctx.seq_encode(k % depth_e, q, k % nslots, 1, False, d_r2[k].data_ptr())
         estep(0)
         barrier()
         te = time.perf_counter()
@@ -798,13 +800,13 @@ def main():
             estep(k)
         barrier()
         te = time.perf_counter() - te
-        for e in range(depth):
+        for e in range(depth_e):
             ctx.seq_wait(e)
         ctx.seq_close()
         g3all = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"])
         r2 = d_r2.cpu().numpy().view(MB_RECORD).reshape(nq, nmb)
         eq2 = all(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(np.frombuffer(r2[k].tobytes(), g3all.dtype).copy()), g3all[k * nmb:(k + 1) * nmb])) for k in range(2))
-        configs2_device["in_flight"] = {"pictures": nq - 1, "pictures_in_flight": depth, "ms_per_picture": round(te / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / te, 1),
+        configs2_device["in_flight"] = {"pictures": nq - 1, "pictures_in_flight": depth_e, "kernel": "k_mb_pipe_epzs4_t8 (four waves per workgroup, two workgroups per compute unit)", "ms_per_picture": round(te / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / te, 1),
                                         "records_equal_jm_first_two_pictures": bool(eq2)}
 
     if rank == 0:

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libjmhip.so")
 SOURCES = ["ctx.hip", "input.hip", "interp.hip", "me_fullsearch.hip", "me_fast.hip", "me_subpel.hip", "me_refine.hip", "tq.hip", "tq8.hip", "tq16.hip", "tq_chroma.hip", "mc.hip", "intra.hip", "distortion.hip", "deblock.hip", "deblock_rows.hip", "deblock_sparse.hip"]
-# mbpipe.hip is compiled five times: -DMBPIPE_PART=0..3 one kernel instance each, 4 the host side (one unit takes six minutes, the parts two side by side)
-MBPIPE_PARTS = 5
+# mbpipe.hip is compiled seven times: -DMBPIPE_PART=0..3, 5, 6 one kernel instance each, 4 the host side (one unit takes six minutes, the parts two side by side)
+MBPIPE_PARTS = (3, 6, 1, 5, 2, 0, 4)                                 # the slowest first
 # The macroblock pipeline's units are compiled without machine-level loop-invariant code motion: in a kernel whose one loop body is 240 KB of code every value hoisted to the
 # top is a value spilled (k_mb_pipe: 304 -> 208 bytes of scratch per lane, 2 % faster; profiles/r04_kernel_resources.txt).  JMHIP_MBPIPE_FLAGS adds flags (measurement aid).
 MBPIPE_FLAGS = ["-mllvm", "-disable-machine-licm"] + os.environ.get("JMHIP_MBPIPE_FLAGS", "").split()
@@ -66,7 +66,7 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         return obj
 
-    jobs = [(os.path.join(CSRC, "mbpipe.hip"), k) for k in (3, 1, 2, 0, 4)][:MBPIPE_PARTS] + [(s, None) for s in srcs]      # the slowest first
+    jobs = [(os.path.join(CSRC, "mbpipe.hip"), k) for k in MBPIPE_PARTS] + [(s, None) for s in srcs]      # the slowest first
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         objs = list(ex.map(compile_one, jobs))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

@@ -22,6 +22,7 @@
 //     per-sub-block origin clamp (UMVLine4X), JM's strict-'<' scan replayed on the nine sums.
 // No MFMA: the path is byte / integer add, sub, shift, abs, min.
 #include <mutex>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include "jmhip_internal.h"
@@ -32,8 +33,8 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-// The four kernel instances are compiled as separate translation units (jm_amd/build.py: -DMBPIPE_PART=0..3, a kernel each; part 4 = the host side, which
-// only declares them): one hipcc process per kernel instead of one for all four -- minutes of build time, nothing else.  Without the macro: one unit.
+// The six kernel instances are compiled as separate translation units (jm_amd/build.py: -DMBPIPE_PART=0..3, 5, 6, a kernel each; part 4 = the host side, which
+// only declares them): one hipcc process per kernel instead of one for all -- minutes of build time, nothing else.  Without the macro: one unit.
 #ifndef MBPIPE_PART
 #define MBPIPE_PART -1
 #endif
@@ -155,7 +156,7 @@ struct Shared {
   int ticket, addr, err;
   int vpic;                                  // a launch of several pictures: the picture V holds (-1: none yet)
   int allmv[JMHIP_MB_MAX_REF][8][16];        // currSlice->all_mv[LIST_0][ref][mode][4x4 raster], packed
-  int mcost[8][JMHIP_MB_MAX_REF][4];         // p_Vid->motion_cost[mode][LIST_0][ref][block]
+  int mcost[4][JMHIP_MB_MAX_REF][4];         // p_Vid->motion_cost[mode][LIST_0][ref][block] of the modes 1..3 (a sub-mode sums its costs up as the references go by)
   int mvi[8][16][2];                         // per wave: the macroblock's mv_info as that wave's chain sees it {packed mv, ref_idx}
   int p8_cost[4][4], p8_bref[4][4];          // [block][mode - 4]
   int p8_cnt;

@@ -336,8 +336,13 @@ def test_encode_slice_key_limits(lam_f, kind):
     (176, 144, 8, 5, -33, 22, 34, dict(pattern=5, dual=5, aggressive=1)),   # five references, the extended window set (95 predictors), slices in one launch
     (16, 16, 16, 1, 0, 28, 35, {}),                                     # a single macroblock
     (320, 64, 32, 1, 0, 40, 36, dict(temporal=0, blocktype=0)),
+    (208, 160, 32, 3, 0, 28, 37, dict(waves=8)),                        # the eight-wave form of the P slices forced on (by default: four waves, two workgroups per compute unit)
+    (208, 160, 16, 6, 0, 28, 38, {}),                                   # six references: two workgroups' LDS no longer fit a compute unit -- the eight-wave form by itself
 ])
-def test_encode_slice_epzs_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed, epzs):
+def test_encode_slice_epzs_vs_oracle(W, H, R, num_ref, slice_mbs, qp, seed, epzs, monkeypatch):
+    epzs = dict(epzs)
+    if epzs.pop("waves", 0) == 8:
+        monkeypatch.setenv("JMHIP_EPZS_WAVES", "8")
     """EPZS inside the pipeline (k_mb_pipe_epzs) against the oracle's restatement (pinned to the real encoder by the m* / q1e / g3e records) on
     tests/golden/synth_motion.py's clips: objects with their own velocities, so predictor sets, early exits, both refinement rounds and several
     references all get used."""

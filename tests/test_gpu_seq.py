@@ -176,8 +176,17 @@ def compare(want, got, what):
     (208, 160, 8, 5, 24, 3, 7, 17, {"search_mode": 3, "epzs": dict(pattern=5, dual=6, fixed=3, aggressive=1, temporal=1, spatial_mem=1, blocktype=1)}),
     (320, 192, 16, 2, 28, 4, 0, 18, {"search_mode": 3, "yuv_format": 2, "epzs": dict(temporal=0, spatial_mem=0, blocktype=0)}),
     (64, 48, 32, 2, 28, 4, 0, 19, {"search_mode": 3}),
+    # EPZS P pictures run as four-wave workgroups, two to a compute unit (k_mb_pipe_epzs4*), where two workgroups' LDS fit one (up to five references): sixteen pictures in
+    # flight; the eight-wave form (what six references and more get) forced on; six references
+    (320, 192, 16, 1, 28, 16, 0, 40, {"search_mode": 3, "cabac": 1}),
+    (320, 192, 32, 2, 28, 4, 0, 41, {"search_mode": 3, "transform8x8": 1, "cabac": 1, "waves": 8}),
+    (320, 192, 16, 5, 32, 6, 0, 42, {"search_mode": 3}),
+    (208, 160, 16, 6, 28, 4, 0, 43, {"search_mode": 3}),
 ])
-def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, depth, wg, seed, kw):
+def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, depth, wg, seed, kw, monkeypatch):
+    kw = dict(kw)
+    if kw.pop("waves", 0) == 8:
+        monkeypatch.setenv("JMHIP_EPZS_WAVES", "8")
     f = int(192 * 2 ** ((qp - 28) / 6))
     lam = LAMBDAS if qp == 28 else {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
     nfr = max(7, depth + 3)
