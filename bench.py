@@ -395,6 +395,36 @@ def concurrent_streams(S, raw0, raw1, src_h, slice_prm, device, steps):
             "note": "S sequences side by side on one MI355X, one context + HIP stream each (GPU_MAX_HW_QUEUES raised from its default 4 so that the streams get a hardware queue each); the same step as `value` per sequence; not the BASELINE metric (one sequence)"}
 
 
+def configs2_params(q, slice_type, poc_cur):
+    """configs[2]'s switches on top of slice_params' record: EPZS as the .cfg files ship it, CABAC, High profile (8x8 transform, Intra8x8)"""
+    q["search_mode"], q["symbol_mode"] = 3, 1
+    q["transform8x8"], q["intra8_valid"] = 1, 1                  # High profile: q_params_8x8 at QP 28 (qp % 6 == 4 rows of quant_coef8 / dequant_coef8, q_matrix.c:38-167)
+    s8, d8 = [8192, 7346, 13159, 7740, 10486, 9777], [32, 28, 51, 30, 40, 38]
+
+    def cls8(j, i):
+        i4, j4 = i & 3, j & 3
+        if i4 == 0 and j4 == 0:
+            return 0
+        if (i & 1) and (j & 1):
+            return 1
+        if i4 == 2 and j4 == 2:
+            return 2
+        if (i4 == 0 and (j & 1)) or ((i & 1) and j4 == 0):
+            return 3
+        if (i4 == 0 and j4 == 2) or (i4 == 2 and j4 == 0):
+            return 4
+        return 5
+    for intra in range(2):
+        off = 682 if (intra and slice_type == 2) else 342
+        for j in range(8):
+            for i in range(8):
+                q["q_luma8"][0, intra, j * 8 + i] = (off << (16 + QP // 6 - 11), s8[cls8(j, i)], d8[cls8(j, i)] << 4)
+    for k, v in dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2).items():
+        q["epzs_" + k] = v                                        # the shipped .cfg files' switches
+    q["poc_cur"] = poc_cur
+    return q
+
+
 def slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref, num_slices=0):
     """jmhip_slice_params with JM's own values for configs[1] / configs[3] with RDO off (tests/golden/mb_low_g2r.npz holds what the encoder used)"""
     p = np.zeros(1, SLICE_PARAMS)
@@ -731,33 +761,7 @@ def main():
     configs2_device = {}
     if N == 1 and rank == 0:
         def epzs_prm(slice_type, num_ref, poc_cur):
-            q = slice_prm(slice_type, 0, nmb, 0, num_ref)
-            q["search_mode"], q["symbol_mode"] = 3, 1
-            q["transform8x8"], q["intra8_valid"] = 1, 1                  # High profile: q_params_8x8 at QP 28 (qp % 6 == 4 rows of quant_coef8 / dequant_coef8, q_matrix.c:38-167)
-            s8, d8 = [8192, 7346, 13159, 7740, 10486, 9777], [32, 28, 51, 30, 40, 38]
-
-            def cls8(j, i):
-                i4, j4 = i & 3, j & 3
-                if i4 == 0 and j4 == 0:
-                    return 0
-                if (i & 1) and (j & 1):
-                    return 1
-                if i4 == 2 and j4 == 2:
-                    return 2
-                if (i4 == 0 and (j & 1)) or ((i & 1) and j4 == 0):
-                    return 3
-                if (i4 == 0 and j4 == 2) or (i4 == 2 and j4 == 0):
-                    return 4
-                return 5
-            for intra in range(2):
-                off = 682 if (intra and slice_type == 2) else 342
-                for j in range(8):
-                    for i in range(8):
-                        q["q_luma8"][0, intra, j * 8 + i] = (off << (16 + QP // 6 - 11), s8[cls8(j, i)], d8[cls8(j, i)] << 4)
-            for k, v in dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2).items():
-                q["epzs_" + k] = v                                        # the shipped .cfg files' switches
-            q["poc_cur"] = poc_cur
-            return q
+            return configs2_params(slice_prm(slice_type, 0, nmb, 0, num_ref), slice_type, poc_cur)
         ctx.set_current_frame(raw0, W, src_h)
         ctx.encode_slice_dev(epzs_prm(2, 0, 0))
         ctx.deblock_picture_dev(1)
@@ -776,7 +780,7 @@ def main():
         g3 = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"][nmb:2 * nmb])
         mine = np.frombuffer(erecs.tobytes(), g3.dtype).copy()
         configs2_device = {"workload": "configs[2]: 1080p, High profile (CABAC, 8x8 transform on: Transform8x8Mode 1, Intra8x8), EPZS (pattern 2, dual 3, fixed 2, temporal, "
-                                       "spatial memory, block type, sub-pel grid), RDO off, P picture with one reference", "kernel": "k_mb_pipe_epzs_t8",
+                                       "spatial memory, block type, sub-pel grid), RDO off, P picture with one reference", "kernel": "k_mb_pipe_epzs4_t8 (a launch alone)",
                            "avg_kernel_ms": round(float(np.mean(ems[1:])), 3), "macroblocks_per_s": round(nmb / (float(np.mean(ems[1:])) * 1e-3), 1),
                            "records_equal_jm": bool(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(mine), g3)))}
         # ... and the same search as a sequence with pictures in flight (every search asks for what it reaches of a reference in the making): I + 16 P pictures of the clip, one

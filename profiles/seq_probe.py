@@ -16,7 +16,7 @@ from jm_amd.lib import SLICE_PARAMS  # noqa: E402
 npic = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 depths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 wg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-mode = sys.argv[4] if len(sys.argv) > 4 else "fs"           # fs | ffs | epzs (configs[2]'s switches, CABAC, 8x8 transform off) | ffs3 (three references)
+mode = sys.argv[4] if len(sys.argv) > 4 else "fs"           # fs | ffs | epzs (configs[2]'s switches, CABAC, 8x8 transform off) | epzs8 (configs[2]: 8x8 transform on) | ffs3 (three references)
 W, H = 1920, 1088
 nmb = (W // 16) * (H // 16)
 frames = bench.yuv_frames(npic)
@@ -40,6 +40,8 @@ for depth in depths:
             p["search_mode"], p["symbol_mode"] = 3, 1
             for kk, v in dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2).items():
                 p["epzs_" + kk] = v
+        if mode == "epzs8":
+            p = bench.configs2_params(p, 2 if k == 0 else 0, 2 * k)
         return p
     # all source pictures resident before the clock starts: one context entry per picture would be the product's ring; here the frames are re-uploaded per entry, untimed first pass
     for rep in range(2):
