@@ -312,44 +312,49 @@ def configs3_device(device):
     dev = torch.device("cuda", device)
     d_raw = torch.from_numpy(data).to(dev)
     d_rec = torch.zeros((npic, nmb4 * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
-    ctx = JmHip(W4, H4, search_range=R, num_ref_slots=nslots, yuv_format=1, device=device, stream=torch.cuda.current_stream().cuda_stream)
-    ctx.seq_open(1)
+    for key, per, note in (("one_slice_sequence_in_one_launch", nmb4, "3840x2160 IPPP, one slice per picture, SR 32, one reference: the P pictures in one launch; not the BASELINE configuration (eight slices)"),
+                           ("eight_slice_sequence_in_one_launch", 4080, "3840x2160 IPPP, configs[3]'s eight slices per picture (SliceArgument 4080), SR 32, one reference, the loop filter across the slices' "
+                            "edges: the P pictures in one launch, every picture in ITS wavefront order (the records against the slices' wavefronts side by side, picture after picture)")):
+        ctx = JmHip(W4, H4, search_range=R, num_ref_slots=nslots, yuv_format=1, device=device, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.seq_open(1)
 
-    def prm1(kk):
-        q = slice_params(SLICE_PARAMS, 2 if kk == 0 else 0, 0, nmb4, 0, 0 if kk == 0 else 1)
-        if kk:
-            q["ref_slot"][0, 0], q["ref_id"][0, 0] = (kk - 1) % nslots, kk - 1
-        return q
+        def prm1(kk):
+            q = slice_params(SLICE_PARAMS, 2 if kk == 0 else 0, 0, per, 0, 0 if kk == 0 else 1)
+            if per < nmb4:
+                q["num_slices"] = (nmb4 + per - 1) // per                   # the picture's slices in the one launch (SliceMode 1)
+            if kk:
+                q["ref_slot"][0, 0], q["ref_id"][0, 0] = (kk - 1) % nslots, kk - 1
+            return q
 
-    def launch(k0, k1):
-        ctx.seq_batch(prm1(k0), [dict(d_raw=d_raw[kk].data_ptr(), src_w=W4, src_h=H4, out_slot=kk % nslots, ref_slot=[(kk - 1) % nslots], ref_id=[kk - 1],
-                                      d_records=d_rec[kk].data_ptr()) for kk in range(k0, k1)])
-    ctx.seq_set_frame_dev(0, d_raw[0].data_ptr(), W4, H4)
-    ctx.seq_encode(0, prm1(0), 0, 1, False, d_rec[0].data_ptr())
-    launch(1, 3)                                                          # warm-up
-    ctx.seq_wait(0)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    launch(3, npic)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    recs = d_rec.cpu().numpy().view(MB_RECORD).reshape(npic, nmb4)
-    ctx.seq_close()
-    same = True
-    for kk in range(1 + ncheck):                                          # the same pictures one after the other
-        ctx.set_current_frame(data[kk], W4, H4)
-        q = prm1(kk)
-        if kk:
-            q["ref_slot"][0, 0] = (kk - 1) & 1
-        same = same and ctx.encode_slice(q).tobytes() == recs[kk].tobytes()
-        ctx.deblock_picture_dev(1)
-        ctx.reference_from_recon(kk & 1)
-    ctx.close()
-    out["one_slice_sequence_in_one_launch"] = {"pictures": npic - 3, "ms_per_picture": round(dt / (npic - 3) * 1e3, 3), "macroblocks_per_s": round(nmb4 * (npic - 3) / dt, 1),
-                                               "records_equal_picture_after_picture": bool(same), "pictures_checked": 1 + ncheck,
-                                               "note": "3840x2160 IPPP, one slice per picture, SR 32, one reference: the P pictures in one launch; not the BASELINE configuration (eight slices)"}
+        def launch(k0, k1):
+            ctx.seq_batch(prm1(k0), [dict(d_raw=d_raw[kk].data_ptr(), src_w=W4, src_h=H4, out_slot=kk % nslots, ref_slot=[(kk - 1) % nslots], ref_id=[kk - 1],
+                                          d_records=d_rec[kk].data_ptr()) for kk in range(k0, k1)])
+        ctx.seq_set_frame_dev(0, d_raw[0].data_ptr(), W4, H4)
+        ctx.seq_encode(0, prm1(0), 0, 1, False, d_rec[0].data_ptr())
+        launch(1, 3)                                                          # warm-up
+        ctx.seq_wait(0)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        launch(3, npic)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        recs = d_rec.cpu().numpy().view(MB_RECORD).reshape(npic, nmb4)
+        ctx.seq_close()
+        same = True
+        for kk in range(1 + ncheck):                                          # the same pictures one after the other
+            ctx.set_current_frame(data[kk], W4, H4)
+            q = prm1(kk)
+            if kk:
+                q["ref_slot"][0, 0] = (kk - 1) & 1
+            same = same and ctx.encode_slice(q).tobytes() == recs[kk].tobytes()
+            ctx.deblock_picture_dev(1)
+            ctx.reference_from_recon(kk & 1)
+        ctx.close()
+        out[key] = {"pictures": npic - 3, "ms_per_picture": round(dt / (npic - 3) * 1e3, 3), "macroblocks_per_s": round(nmb4 * (npic - 3) / dt, 1),
+                                                   "records_equal_picture_after_picture": bool(same), "pictures_checked": 1 + ncheck,
+                                                   "note": note}
     return out
 
 

@@ -679,7 +679,9 @@ int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
  * The caller deals the pictures to the entries in turn (picture k -> entry k % depth) and the reconstructions to slots that no picture in flight refers to
  * (num_ref + depth slots in turn always do; a conflicting launch is simply held back until the readers are done).  An entry's buffers -- its records among them --
  * are reused by the entry's next jmhip_seq_set_frame / jmhip_seq_encode.
- * Scope: what jmhip_encode_slice_dev accepts, one slice covering the whole picture.  The full searches (search_mode 0, 1) reach 2 SearchRange into the reference, so a
+ * Scope: what jmhip_encode_slice_dev accepts, the whole picture per launch: one slice, or its slices of num_mb macroblocks each (num_slices, SliceMode 1) -- coded in the
+ * PICTURE's wavefront order rather than with the slices' wavefronts side by side, because a macroblock's loop filter follows its left and upper neighbours' also across a
+ * slice's edge.  The full searches (search_mode 0, 1) reach 2 SearchRange into the reference, so a
  * macroblock waits once, for the macroblock 5 to its right and 5 below it (SearchRange 32); an EPZS search (search_mode 3) goes wherever its predictor takes it inside the
  * level's vector range, so every search asks for what it is about to read when its centre is known; the temporal predictors read the motion kept with the slots of
  * references 0 / 1 directly (every picture of such a sequence, its I pictures too, is launched with search_mode 3 and its picture order counts).  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
@@ -687,7 +689,10 @@ int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
  * ------------------------------------------------------------------------------------------ */
 int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture /* 0: 256 / depth, at most 80; always cut to 248 / (depth - 1), so that the oldest picture in flight can never be
                    kept off the chip by the workgroups of later ones waiting for it.  HIP serves a process's streams from GPU_MAX_HW_QUEUES hardware queues (default 4): with
-                   more pictures in flight than that, set GPU_MAX_HW_QUEUES = 2 * depth in the environment before HIP starts, or the launches take turns */);
+                   more pictures in flight than that, set GPU_MAX_HW_QUEUES = 2 * depth in the environment before HIP starts, or the launches take turns.
+                   The count is in workgroups that fill a compute unit (eight waves).  An EPZS P picture with up to five references is launched as four-wave workgroups, two
+                   to a compute unit (k_mb_pipe_epzs4*), and takes twice the count: sixteen such pictures in flight (depth 16, 2 x 16 workgroups each) are the fastest form
+                   measured, 5.4 ms per 1080p picture (profiles/r04_epzs_four_wave.txt) */);
 int jmhip_seq_close(jmhip_ctx *ctx);
 int jmhip_seq_set_frame(jmhip_ctx *ctx, int32_t entry, const uint8_t *raw, int32_t src_w, int32_t src_h);
 int jmhip_seq_set_frame_dev(jmhip_ctx *ctx, int32_t entry, const uint8_t *d_raw, int32_t src_w, int32_t src_h);
@@ -714,7 +719,7 @@ int jmhip_seq_get_recon(jmhip_ctx *ctx, int32_t slot, uint16_t *y, int32_t pitch
  * RDOptimization 0 and no rate control differ in nothing but their references); its ref_slot / ref_id are not read.  A slot is reused inside the batch as with the entries:
  * the picture that overwrites it starts once the last picture that read it is done, so num_ref + (pictures that overlap, PicHeightInMbs / 8 at 1080p) slots keep the
  * queue dense.  Asynchronous on the context's stream: jmhip_synchronize (which reports the launch's errors), then the records, jmhip_seq_get_recon / jmhip_seq_recon_dev,
- * jmhip_subplanes_dev.  Scope: the full searches (search_mode 0, 1), P slices, one slice per picture, num_ref <= 8, PicSizeInMbs < 65536, n <= 4096; needs jmhip_seq_open
+ * jmhip_subplanes_dev.  Scope: the full searches (search_mode 0, 1), P slices, the whole picture (one slice or num_slices of them), num_ref <= 8, PicSizeInMbs < 65536, n <= 4096; needs jmhip_seq_open
  * (any depth).  Anything else JMHIP_EUNSUPPORTED.  Results: those of coding the pictures one after another (tests/test_gpu_seq.py). */
 typedef struct {
   const uint8_t *d_raw;         /* device: the source picture as it lies in the file (8 bit planar) */

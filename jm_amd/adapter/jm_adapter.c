@@ -316,7 +316,9 @@ static int adapter_on(VideoParameters *p_Vid)
                                                                its up to five references per picture, where the device is (nine 1080p pictures of configs[2]: 52 -> 19 ms per later P picture) */
       const char *fl = getenv("JMHIP_ADAPTER_FLIGHT");
       F.depth = fl ? atoi(fl) : (p_Inp->SearchMode[0] == EPZS ? 8 : 4);
-      if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || p_Inp->slice_mode != NO_SLICES || p_Inp->NumberBFrames != 0 ||
+      /* (SliceMode 1: the picture's slices go up in one launch either way; with pictures in flight the launch runs in the picture's wavefront order -- not with JMHIP_DEVICES,
+         where the slices are dealt to several contexts) */
+      if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || (p_Inp->slice_mode != NO_SLICES && (p_Inp->slice_mode != FIXED_MB || getenv("JMHIP_DEVICES"))) || p_Inp->NumberBFrames != 0 ||
           (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH && p_Inp->SearchMode[0] != EPZS)) F.depth = 0;
       if (F.depth > FL_MAX) F.depth = FL_MAX;
       if (F.depth) {

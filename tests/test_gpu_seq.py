@@ -27,9 +27,10 @@ pytestmark = pytest.mark.gpu
 class FlightEncoder:
     """IPPP with `depth` pictures in flight: picture k goes to entry k % depth and to slot k % (num_ref + depth + 1)."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, depth, workgroups=0, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, stream_records=False, epzs=None):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, depth, workgroups=0, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, stream_records=False, epzs=None, slice_mbs=0, disable_idc=0):
         import jm_amd.lib as L
         self.L = L
+        self.slice_mbs, self.disable_idc = slice_mbs, disable_idc                      # slice_mbs > 0: the picture's slices of that many macroblocks in the one launch (num_slices)
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas, self.depth = W, H, qp, R, num_ref, lambdas, depth
         self.cabac, self.search_mode, self.transform8x8, self.yuv_format, self.epzs = cabac, search_mode, transform8x8, yuv_format, dict(epzs or {})
         self.nslots = num_ref + depth + 1
@@ -58,8 +59,11 @@ class FlightEncoder:
         st = 2 if k == 0 else 0
         nref = min(self.num_ref, k) if st == 0 else 0
         lam_mf, lam_md = self.lambdas[st]
-        cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, nmb, self.qp, self.R, nref, lam_mf, lam_md, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8, yuv_format=self.yuv_format)
-        prm = slice_params(L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], 0, self.epzs, 2 * k)
+        per = self.slice_mbs if 0 < self.slice_mbs < nmb else nmb
+        cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, per, self.qp, self.R, nref, lam_mf, lam_md, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8, yuv_format=self.yuv_format)
+        prm = slice_params(L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], self.disable_idc, self.epzs, 2 * k)
+        if per < nmb:
+            prm["num_slices"] = (nmb + per - 1) // per
         J.seq_set_frame(k % self.depth, raw, sw, sh)
         J.seq_encode(k % self.depth, prm, k % self.nslots, 1, self.stream_records)
         self.npic += 1
@@ -75,8 +79,9 @@ class BatchEncoder:
     """IPPP with the P pictures in launches of several pictures each (jmhip_seq_batch): the I picture and the first P pictures (fewer references than num_ref) through
     jmhip_seq_encode, then batches of `sizes` pictures in turn; picture k goes to slot k % nslots."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0, slice_mbs=0, disable_idc=0):
         import torch
+        self.slice_mbs, self.disable_idc = slice_mbs, disable_idc
         import jm_amd.lib as L
         self.L, self.torch = L, torch
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas, self.sizes, self.nslots = W, H, qp, R, num_ref, lambdas, list(sizes), nslots
@@ -89,8 +94,12 @@ class BatchEncoder:
     def params(self, k, st, nref):
         nmb = (self.W // 16) * (self.H // 16)
         lam_mf, lam_md = self.lambdas[st]
-        cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, nmb, self.qp, self.R, nref, lam_mf, lam_md, **self.kw)
-        return slice_params(self.L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], 0, {}, 2 * k)
+        per = self.slice_mbs if 0 < self.slice_mbs < nmb else nmb
+        cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, per, self.qp, self.R, nref, lam_mf, lam_md, **self.kw)
+        prm = slice_params(self.L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], self.disable_idc, {}, 2 * k)
+        if per < nmb:
+            prm["num_slices"] = (nmb + per - 1) // per
+        return prm
 
     def run(self, frames, sw, sh):
         J, torch, L = self.J, self.torch, self.L
@@ -128,8 +137,8 @@ class BatchEncoder:
         return [out[i] for i in range(len(frames))]
 
 
-def classic(W, H, qp, R, num_ref, lam, frames, sw=None, sh=None, **kw):
-    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, 0, **kw)
+def classic(W, H, qp, R, num_ref, lam, frames, sw=None, sh=None, slice_mbs=0, **kw):
+    dev = DevSeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, together=slice_mbs > 0, **kw)      # slices: the picture's slices in one launch, their wavefronts side by side
     out = []
     for raw in frames:
         recs, pre, post = dev.encode(raw, sw or W, sh or H)
@@ -182,6 +191,12 @@ def compare(want, got, what):
     (320, 192, 32, 2, 28, 4, 0, 41, {"search_mode": 3, "transform8x8": 1, "cabac": 1, "waves": 8}),
     (320, 192, 16, 5, 32, 6, 0, 42, {"search_mode": 3}),
     (208, 160, 16, 6, 28, 4, 0, 43, {"search_mode": 3}),
+    # pictures of several slices (SliceMode 1): one launch per picture in the picture's wavefront order; the loop filter across the slices' edges, or not (disable_idc 2)
+    (320, 192, 32, 1, 28, 4, 0, 44, {"slice_mbs": 60}),                  # four slices of three macroblock rows
+    (320, 192, 16, 2, 32, 4, 0, 45, {"slice_mbs": 50, "cabac": 1}),       # slices that start mid-row
+    (640, 368, 32, 1, 28, 8, 0, 46, {"slice_mbs": 120, "disable_idc": 2}),
+    (320, 192, 16, 2, 28, 4, 0, 47, {"slice_mbs": 70, "search_mode": 3}),
+    (320, 192, 16, 1, 28, 3, 0, 48, {"slice_mbs": 33, "transform8x8": 1, "cabac": 1, "search_mode": 1}),
 ])
 def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, depth, wg, seed, kw, monkeypatch):
     kw = dict(kw)
@@ -216,6 +231,8 @@ def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, de
     (320, 192, 16, 2, 28, [6], 8, 3, 30, {"cabac": 1, "transform8x8": 1}),     # three workgroups for everything
     (320, 192, 32, 2, 28, [6], 8, 0, 31, {"search_mode": 1}),
     (320, 192, 16, 1, 30, [6], 4, 0, 32, {"yuv_format": 2, "search_mode": 1, "transform8x8": 1}),
+    (320, 192, 32, 1, 28, [8], 10, 0, 33, {"slice_mbs": 60}),             # pictures of four slices
+    (640, 368, 32, 2, 28, [6], 8, 0, 34, {"slice_mbs": 130, "disable_idc": 2, "cabac": 1}),      # slices that start mid-row, no filtering across their edges
 ])
 def test_pictures_in_one_launch_equal_picture_after_picture(W, H, R, num_ref, qp, sizes, nslots, wg, seed, kw):
     """jmhip_seq_batch: the macroblocks of several consecutive pictures from one queue, ordered by wavefront index + lag x picture"""
@@ -298,7 +315,7 @@ def test_seq_refuses_what_it_does_not_cover():
     raw = synthetic_clip(W, H, 1, 1)[0]
     J.seq_set_frame(0, raw, W, H)
     cfg = pyjmo.mbenc_cfg(W, H, 2, 0, nmb // 2, 28, 16, 0, *LAMBDAS[2])
-    with pytest.raises(L.JmHipError, match="one slice covering the picture"):
+    with pytest.raises(L.JmHipError, match="slices that cover the picture"):                        # half a picture
         J.seq_encode(0, slice_params(L, cfg, 0, [], []), 0)
     with pytest.raises(L.JmHipError):
         J.seq_encode(2, slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2]), 0, [], []), 0)       # entry out of range
