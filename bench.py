@@ -764,7 +764,9 @@ def main():
         ctx.close()
         slice_split = multi_gpu_configs3(args, world, rank, local, dev, one_gpu)
     configs2_device = {}
-    if N == 1 and rank == 0:
+    # (with --no-end-to-end the configs[2..4] figures are not reported: the profiler's passes -- whose counter collection serialises the launches -- then see no pictures in
+    # flight launch by launch)
+    if N == 1 and rank == 0 and not args.no_end_to_end:
         def epzs_prm(slice_type, num_ref, poc_cur):
             return configs2_params(slice_prm(slice_type, 0, nmb, 0, num_ref), slice_type, poc_cur)
         ctx.set_current_frame(raw0, W, src_h)
@@ -791,7 +793,7 @@ def main():
         # ... and the same search as a sequence with pictures in flight (every search asks for what it reaches of a reference in the making): I + 16 P pictures of the clip, one
         # reference; the first three pictures' records against the real encoder's (mb_low_g3h holds three: I, P with one reference, P with two -- the third differs by its reference count, so two are compared)
         # EPZS P pictures run as four-wave workgroups, two to a compute unit: sixteen pictures in flight x 2 x 16 workgroups fill the chip (profiles/r04_epzs_four_wave.txt)
-        nq = min(33, nseq)
+        nq = 65                                                          # an I picture and 64 P pictures: the clip's pictures over and over (four fills of the sixteen entries; a launch takes ~20 x the steady state's time per picture)
         depth_e = depth if (one_gpu and world > 1) else max(1, min(16, nslots - 2, 2 * args.flight))
         ctx.seq_open(depth_e, 0 if batch else args.workgroups)
         d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
@@ -800,7 +802,7 @@ def main():
             q = epzs_prm(2 if k == 0 else 0, 0 if k == 0 else 1, 2 * k)
             if k:
                 q["ref_slot"][0, 0], q["ref_id"][0, 0], q["poc_ref"][0, 0] = (k - 1) % nslots, k - 1, 2 * (k - 1)
-            ctx.seq_set_frame_dev(k % depth_e, d_raw[k].data_ptr(), W, src_h)
+            ctx.seq_set_frame_dev(k % depth_e, d_raw[k % nseq].data_ptr(), W, src_h)
             ctx.seq_encode(k % depth_e, q, k % nslots, 1, False, d_r2[k].data_ptr())
         estep(0)
         barrier()
@@ -813,7 +815,7 @@ def main():
             ctx.seq_wait(e)
         ctx.seq_close()
         g3all = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"])
-        r2 = d_r2.cpu().numpy().view(MB_RECORD).reshape(nq, nmb)
+        r2 = d_r2[:2].cpu().numpy().view(MB_RECORD).reshape(2, nmb)
         eq2 = all(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(np.frombuffer(r2[k].tobytes(), g3all.dtype).copy()), g3all[k * nmb:(k + 1) * nmb])) for k in range(2))
         configs2_device["in_flight"] = {"pictures": nq - 1, "pictures_in_flight": depth_e, "kernel": "k_mb_pipe_epzs4_t8 (four waves per workgroup, two workgroups per compute unit)", "ms_per_picture": round(te / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / te, 1),
                                         "records_equal_jm_first_two_pictures": bool(eq2)}

@@ -3,7 +3,7 @@
 tests/golden/mb_low_* records) on seeded random configurations -- picture size, search range and mode (full search / fast full search / EPZS with random switches),
 references, QP, slices (separate launches or side by side in one), CAVLC / CABAC, 8x8 transform, 4:2:0 / 4:2:2, default or q_offset.cfg quantiser offsets, clips with
 a motion field or adversarial content.  Every macroblock record and the reconstruction before and after the loop filter must be identical.  Configurations the
-sequence entry points cover (one slice) are coded a second time with a random number of pictures in flight (jmhip_seq_*) and, the full searches, a third time with the P pictures
+sequence entry points cover are coded a second time with a random number of pictures in flight (jmhip_seq_*) and, the full searches, a third time with the P pictures
 in launches of several pictures (jmhip_seq_batch): records, filtered pictures and sub-pel planes must equal the picture-after-picture run's.
 TEST INFRASTRUCTURE (uses oracle/).   usage: python tests/fuzz_mbenc.py <seconds> [first seed]"""
 import os
@@ -62,7 +62,7 @@ while time.time() - t0 < budget:
     except Exception as e:                                   # a configuration the library turns away (LDS budget): say so and go on
         print("skipped", desc, str(e)[:120]); seed += 1; continue
     ora = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, cabac=cabac, search_mode=sm, epzs=epzs, transform8x8=t8, yuv_format=yuv, offsets=offs)
-    in_flight = slice_mbs == 0 and offs is None
+    in_flight = offs is None                                  # (pictures of several slices too: one launch per picture in the picture's wavefront order)
     classic = []
     try:
         for n, raw in enumerate(frames):
@@ -81,7 +81,7 @@ while time.time() - t0 < budget:
         dev.J.close()
     if in_flight:
         depth, wg = int(rng.integers(1, 9)), int(rng.choice([0, 0, 1, 3, 17]))
-        fl = TS.FlightEncoder(W, H, qp, R, num_ref, lam, depth, wg, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv, stream_records=bool(rng.integers(0, 2)), epzs=epzs)
+        fl = TS.FlightEncoder(W, H, qp, R, num_ref, lam, depth, wg, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv, stream_records=bool(rng.integers(0, 2)), epzs=epzs, slice_mbs=slice_mbs)
         try:
             for raw in frames:
                 fl.submit(raw, W, H)
@@ -95,7 +95,7 @@ while time.time() - t0 < budget:
         if sm != 3 and num_ref <= 8 and len(frames) > num_ref:     # ... and once more with the P pictures in launches of several pictures (jmhip_seq_batch)
             nslots = int(rng.integers(num_ref + 1, num_ref + 6))
             be = TS.BatchEncoder(W, H, qp, R, num_ref, lam, [int(rng.integers(1, 4)), int(rng.integers(1, 4))], nslots, cabac=cabac, search_mode=sm, transform8x8=t8, yuv_format=yuv,
-                                 workgroups=int(rng.choice([0, 0, 2, 19])))
+                                 workgroups=int(rng.choice([0, 0, 2, 19])), slice_mbs=slice_mbs)
             try:
                 TS.compare(classic, be.run(frames, W, H), ("one launch", nslots))
             except Exception as e:
