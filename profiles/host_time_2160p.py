@@ -16,6 +16,8 @@ with tempfile.TemporaryDirectory() as t:
     t0 = time.time()
     p = subprocess.run(args, cwd=t, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     wall = time.time() - t0
+    import hashlib
+    print("md5 of the .264:", hashlib.md5(open(os.path.join(t, "o.264"), "rb").read()).hexdigest())
     r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     for line in p.stdout.decode(errors="replace").splitlines():
         if line.strip()[:5].isdigit() and "(" in line:
