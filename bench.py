@@ -260,8 +260,19 @@ def configs3_end_to_end(max_seconds=400):
         return {"available": False, "why": "timeout"}
     if not h:
         return {"available": False, "why": "lencod_hip.exe failed"}
-    return {"available": True, "macroblocks_per_picture": 32400, "slices": 8, "p_frame_ms_hip": h[0].get("P"), "i_frame_ms_hip": h[0].get("I"), "wall_s_hip": round(h[3], 2),
-            "macroblocks_per_s_p_frame": round(32400 / (h[0]["P"][0] / 1000.0), 1) if h[0].get("P") else None, "md5_is_g4r": h[1] == e["md5_264"], "adapter": h[2]}
+    out = {"available": True, "macroblocks_per_picture": 32400, "slices": 8, "p_frame_ms_hip": h[0].get("P"), "i_frame_ms_hip": h[0].get("I"), "wall_s_hip": round(h[3], 2),
+           "macroblocks_per_s_p_frame": round(32400 / (h[0]["P"][0] / 1000.0), 1) if h[0].get("P") else None, "md5_is_g4r": h[1] == e["md5_264"], "adapter": h[2]}
+    # ... and eight pictures of the same sequence: the adapter launches the next pictures ahead of time (SliceMode 1 pictures too since round 4: one launch per picture in the
+    # picture's wavefront order), JM entropy-codes picture k while the device is pictures ahead; no CPU JM beside it (a minute per picture)
+    try:
+        h8 = run_lencod(hip_exe, 8, max_seconds, flags, clip=lambda tmp: synclip.syn2160p(os.path.join(tmp, "syn2160p.yuv"), 8))
+        if h8 and h8[0].get("P"):
+            later = sorted(h8[0]["P"][1:])
+            out["eight_pictures"] = {"p_frame_ms_hip": h8[0]["P"], "p_frame_ms_later_median": later[len(later) // 2], "wall_s_hip": round(h8[3], 2),
+                                     "macroblocks_per_s_later_p_frames": round(32400 / (later[len(later) // 2] / 1000.0), 1)}
+    except subprocess.TimeoutExpired:
+        pass
+    return out
 
 
 def configs3_device(device):
