@@ -1,4 +1,7 @@
-# measurement aid (round 4): configs[3] end to end (lencod_hip.exe, 2160p, 8 slices) with the pictures launched ahead of time and without
+# measurement aid (round 4): EPZS with five references in flight, both forms (two four-wave workgroups' LDS: 81 120 B each); one reference again; the sequence tests; smoke
 mkdir -p gpurun_out/r4z
-( for n in 2 8; do for f in "" "JMHIP_ADAPTER_FLIGHT=0"; do echo "--- $n pictures $f"; timeout 300 python profiles/host_time_2160p.py $n $f 2>&1 | grep -E "^0|md5|wall|flight"; done; done ) > gpurun_out/r4z/e2e_2160p_flight.txt 2>&1
-cat gpurun_out/r4z/e2e_2160p_flight.txt
+export GPU_MAX_HW_QUEUES=24
+( timeout 200 python profiles/seq_probe.py 64 16 0 epzs5; JMHIP_EPZS_WAVES=8 timeout 200 python profiles/seq_probe.py 64 8 0 epzs5; timeout 200 python profiles/seq_probe.py 96 16 0 epzs ) 2>&1 | grep -E "depth|rror" > gpurun_out/r4z/probe_epzs5.txt; cat gpurun_out/r4z/probe_epzs5.txt
+unset GPU_MAX_HW_QUEUES
+timeout 600 python -m pytest tests/test_gpu_seq.py -x -q -m gpu > gpurun_out/r4z/pytest_seq.txt 2>&1; tail -3 gpurun_out/r4z/pytest_seq.txt
+timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -2

@@ -16,18 +16,18 @@ from jm_amd.lib import SLICE_PARAMS  # noqa: E402
 npic = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 depths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 wg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-mode = sys.argv[4] if len(sys.argv) > 4 else "fs"           # fs | ffs | epzs (configs[2]'s switches, CABAC, 8x8 transform off) | epzs8 (configs[2]: 8x8 transform on) | ffs3 (three references)
+mode = sys.argv[4] if len(sys.argv) > 4 else "fs"           # fs | ffs | epzs (configs[2]'s switches, CABAC, 8x8 transform off) | epzs5 (the same with five references) | epzs8 (configs[2]: 8x8 transform on) | ffs3 (three references)
 W, H = 1920, 1088
 nmb = (W // 16) * (H // 16)
 frames = bench.yuv_frames(npic)
 for depth in depths:
-    nslots = depth + (4 if mode == "ffs3" else 2)
+    nslots = depth + (4 if mode == "ffs3" else (6 if mode == "epzs5" else 2))
     ctx = JmHip(W, H, search_range=32, num_ref_slots=nslots, yuv_format=1)
     ctx.seq_open(depth, wg)
     ctx.enable_timing(True)
 
     def prm(k):
-        nref = 0 if k == 0 else (min(k, 3) if mode == "ffs3" else 1)
+        nref = 0 if k == 0 else (min(k, 3) if mode == "ffs3" else (min(k, 5) if mode == "epzs5" else 1))
         p = bench.slice_params(SLICE_PARAMS, 2 if k == 0 else 0, 0, nmb, 0, nref)
         for r in range(nref):
             p["ref_slot"][0, r] = (k - 1 - r) % nslots
@@ -36,7 +36,7 @@ for depth in depths:
         p["poc_cur"] = 2 * k
         if mode.startswith("ffs"):
             p["search_mode"] = 1
-        if mode == "epzs":
+        if mode in ("epzs", "epzs5"):
             p["search_mode"], p["symbol_mode"] = 3, 1
             for kk, v in dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spatial_mem=1, blocktype=1, min_scale=0, med_scale=1, max_scale=2, sub_scale=2).items():
                 p["epzs_" + kk] = v
