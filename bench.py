@@ -706,6 +706,7 @@ def main():
 
     if batch:
         ctx.set_pipeline_workgroups(args.workgroups or (256 // world if one_gpu else 256))
+        ctx.seq_batch_reserve(max(args.steps, args.warmup, 1))           # the launches' scratch (per-picture edge records, flags, side information) allocated before the clock starts, as JM allocates per sequence
         step(0)                                                            # the I picture
         if args.warmup:
             steps_in_one_launch(1, 1 + args.warmup)

@@ -729,6 +729,10 @@ typedef struct {
   jmhip_mb_record *d_records;   /* device: PicSizeInMbs records */
 } jmhip_seq_picture;
 int jmhip_seq_batch(jmhip_ctx *ctx, const jmhip_slice_params *prm, int32_t direct_8x8_inference, int32_t n, const jmhip_seq_picture *pics);
+/* The device memory a launch of n pictures needs beside the slots (per picture: the source picture, edge records, flags, loop-filter side information; the launch's descriptors
+ * and ticket table) is kept from launch to launch and grows with the first launch that needs more: a caller that knows its run length reserves it once, after jmhip_seq_open,
+ * instead of paying a hipMalloc inside its first long launch (JM: the counterpart of init_global_buffers, lencod.c, which allocates per sequence, not per picture). */
+int jmhip_seq_batch_reserve(jmhip_ctx *ctx, int32_t n);
 
 /* ------------------------------------------------------------------------------------------
  * Timing helper: elapsed milliseconds of the last `_dev` launch of each kind, measured with

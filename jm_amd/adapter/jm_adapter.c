@@ -98,7 +98,7 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
  * diagonals behind, inside the device (mbpipe_post.inc) -- and when JM arrives at picture k + 1 its records are waiting.  Nothing is taken on trust: at the picture's
  * first macroblock the parameters JM really has are built as always and compared byte for byte with the ones the launch was given, and the source planes JM really holds
  * are compared with the frame that was sent; any difference voids the pictures in flight and the picture is launched the ordinary way. */
-#define FL_MAX 8
+#define FL_MAX 16
 static struct {
   int depth, nring;                   /* entries of jmhip_seq_open; device slots used in turn */
   int on;
@@ -311,11 +311,13 @@ static int adapter_on(VideoParameters *p_Vid)
     if (G.R > JMHIP_MAX_SEARCH_RANGE) { G.part_fs = G.part_ffs = 0; G.R = JMHIP_MAX_SEARCH_RANGE; }
     if (G.R < 1) G.R = 1;
     G.nslots = imin(MAX_SLOTS, p_Vid->max_num_references + 2);
-    {                                                       /* pictures in flight: JMHIP_ADAPTER_FLIGHT = 2 .. 8 entries (0 or 1: off).  Default 4 for the full searches -- the host's
-                                                               entropy coder is what bounds such a sequence, and the first pictures of a run get more workgroups each -- and 8 for EPZS with
-                                                               its up to five references per picture, where the device is (nine 1080p pictures of configs[2]: 52 -> 19 ms per later P picture) */
+    {                                                       /* pictures in flight: JMHIP_ADAPTER_FLIGHT = 2 .. 16 entries (0 or 1: off).  Default 4 for the full searches -- the host's
+                                                               entropy coder is what bounds such a sequence, and the first pictures of a run get more workgroups each -- and 16 for EPZS with
+                                                               its up to five references per picture, where the device is: its P pictures run as four-wave workgroups, two to a compute unit, and
+                                                               sixteen of them fill the chip (24 1080p pictures of configs[2]: 16 - 58 ms per later P picture with eight in flight, the device
+                                                               running dry again and again; 17 - 23 ms with sixteen: profiles/r04_e2e_configs2_flight.txt) */
       const char *fl = getenv("JMHIP_ADAPTER_FLIGHT");
-      F.depth = fl ? atoi(fl) : (p_Inp->SearchMode[0] == EPZS ? 8 : 4);
+      F.depth = fl ? atoi(fl) : (p_Inp->SearchMode[0] == EPZS ? 16 : 4);
       /* (SliceMode 1: the picture's slices go up in one launch either way; with pictures in flight the launch runs in the picture's wavefront order -- not with JMHIP_DEVICES,
          where the slices are dealt to several contexts) */
       if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || (p_Inp->slice_mode != NO_SLICES && (p_Inp->slice_mode != FIXED_MB || getenv("JMHIP_DEVICES"))) || p_Inp->NumberBFrames != 0 ||
@@ -324,7 +326,7 @@ static int adapter_on(VideoParameters *p_Vid)
       if (F.depth) {
         F.nring = imin(MAX_SLOTS, p_Vid->max_num_references + F.depth + 1);
         G.nslots = F.nring;
-        setenv("GPU_MAX_HW_QUEUES", "16", 0);             /* before HIP starts: a hardware queue per picture in flight (the runtime's default is 4) */
+        setenv("GPU_MAX_HW_QUEUES", F.depth > 8 ? "24" : "16", 0);       /* before HIP starts: a hardware queue per picture in flight (the runtime's default is 4) */
       }
     }
     memset(&cfg, 0, sizeof cfg);

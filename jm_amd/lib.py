@@ -111,7 +111,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
            "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
            "jmhip_seq_open", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_planes", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
-           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_allgather_bands"]
+           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_seq_batch_reserve", "jmhip_allgather_bands"]
 
 
 class JmHipError(RuntimeError):
@@ -681,6 +681,10 @@ class JmHip:
             a[k]["ref_slot"][:len(q["ref_slot"])] = q["ref_slot"]
             a[k]["ref_id"][:len(q["ref_id"])] = q["ref_id"]
         self._ck(self.lib.jmhip_seq_batch(self.h, _vp(prm), int(direct8x8), len(pictures), _vp(a)))
+
+    def seq_batch_reserve(self, n):
+        """device memory for launches of up to n pictures (jmhip_seq_batch), ahead of the first one"""
+        self._ck(self.lib.jmhip_seq_batch_reserve(self.h, int(n)))
 
     def seq_get_recon(self, slot):
         """(y, u, v) uint8: the filtered reconstruction a sequence launch left in `slot`"""
