@@ -79,7 +79,7 @@ class BatchEncoder:
     """IPPP with the P pictures in launches of several pictures each (jmhip_seq_batch): the I picture and the first P pictures (fewer references than num_ref) through
     jmhip_seq_encode, then batches of `sizes` pictures in turn; picture k goes to slot k % nslots."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0, slice_mbs=0, disable_idc=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0, slice_mbs=0, disable_idc=0, reserve=0):
         import torch
         self.slice_mbs, self.disable_idc = slice_mbs, disable_idc
         import jm_amd.lib as L
@@ -90,6 +90,8 @@ class BatchEncoder:
         self.J.seq_open(1)
         if workgroups:
             self.J.set_pipeline_workgroups(workgroups)
+        if reserve:
+            self.J.seq_batch_reserve(reserve)                 # the launches' scratch ahead of the first launch (fewer pictures than the later launches have: it grows again)
 
     def params(self, k, st, nref):
         nmb = (self.W // 16) * (self.H // 16)
@@ -224,7 +226,7 @@ def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, de
     (320, 192, 32, 1, 28, [9], 3, 0, 23, {}),                 # three slots in turn: a picture starts when the one two before it is done
     (320, 192, 32, 1, 28, [7], 2, 0, 24, {}),                 # two slots: one picture after the other, inside one launch
     (320, 192, 32, 3, 36, [6], 6, 0, 25, {}),                 # three references
-    (640, 368, 32, 2, 28, [2, 5, 1], 5, 0, 26, {}),           # batch after batch: references from the batch before; a batch of one
+    (640, 368, 32, 2, 28, [2, 5, 1], 5, 0, 26, {"reserve": 3}),   # batch after batch: references from the batch before; a batch of one; scratch reserved for three pictures, then five come
     (640, 368, 8, 2, 20, [8], 12, 0, 27, {}),                 # a short reach: pictures three diagonals apart
     (64, 48, 32, 2, 28, [6], 5, 0, 28, {}),                   # smaller than the search window
     (16, 16, 16, 1, 28, [5], 3, 0, 29, {}),                   # a single macroblock per picture
@@ -243,7 +245,7 @@ def test_pictures_in_one_launch_equal_picture_after_picture(W, H, R, num_ref, qp
         frames = [np.concatenate([fr[:W * H], np.repeat(fr[W * H:].reshape(2, H // 2, W // 2), 2, axis=1).ravel()]) for fr in synthetic_clip(W, H, nfr, seed)]
     else:
         frames = synthetic_clip(W, H, nfr, seed)
-    want = classic(W, H, qp, R, num_ref, lam, frames, **kw)
+    want = classic(W, H, qp, R, num_ref, lam, frames, **{k: v for k, v in kw.items() if k != "reserve"})
     be = BatchEncoder(W, H, qp, R, num_ref, lam, sizes, nslots, workgroups=wg, **kw)
     got = be.run(frames, W, H)
     be.J.close()
