@@ -1,5 +1,3 @@
 mkdir -p gpurun_out/r4z
-timeout 600 python -m pytest tests/test_gpu_seq.py -x -q -m gpu 2>&1 | tail -2
-for a in "" "--steps 20 --warmup 5"; do timeout 300 python bench.py $a --no-cpu-baseline --no-end-to-end --streams 0 2>/dev/null | python -c "
-import sys, json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$a:', d['value'], d['ms_per_step'], d['roofline']['avg_kernel_ms'])"; done
-timeout 300 python -m pytest tests/test_lencod_dropin.py -x -q -m gpu -k "epzs or g3e or g3h or g6e or configs2" 2>&1 | tail -2
+JMHIP_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 2 > gpurun_out/r4z/bench_n2.json 2> gpurun_out/r4z/bench_n2.err
+tail -c 1500 gpurun_out/r4z/bench_n2.json; tail -3 gpurun_out/r4z/bench_n2.err
