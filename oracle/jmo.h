@@ -329,4 +329,9 @@ int jmo_encode_slice_ex(const jmo_mbenc_cfg *cfg, jmo_epzs_cfg *ez, const jmo_pe
 #ifdef __cplusplus
 }
 #endif
+/* ---- B slices: spatial direct mode (jmo_direct.c; lencod/src/mv_direct.c:522 Get_Direct_MV_Spatial_Normal) ---- */
+void jmo_direct_spatial(const int8_t avail[3], const int8_t nref[3][2], const int16_t nmv[3][2][2], int col_long_term,
+                        const int8_t col_ref[16][2], const int16_t col_mv[16][2][2],
+                        int8_t ref_out[16][2], int8_t pdir_out[16], int16_t mv_out[16][2][2]);
+
 #endif

@@ -604,3 +604,14 @@ def encode_slice(cfg, cur, refs, refc, pic, debug=False, epzs=None):
                               _p(pic.mv), _p(pic.ref_idx), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
     assert r == 0, r
     return (out, dbg) if debug else out
+
+
+def direct_spatial(nb_avail, nb_ref, nb_mv, col_long_term, col_ref, col_mv):
+    """jmo_direct_spatial (oracle/jmo_direct.c; Get_Direct_MV_Spatial_Normal lencod/src/mv_direct.c:522): the neighbours A, B, C and the co-located picture's motion of one
+    macroblock of a B slice -> (direct_ref_idx [16][2], direct_pdir [16], vectors [16][2][2])"""
+    av = np.ascontiguousarray(np.asarray(nb_avail)[:3], np.int8)
+    nr, nm = np.ascontiguousarray(nb_ref, np.int8), np.ascontiguousarray(nb_mv, np.int16)
+    cr, cm = np.ascontiguousarray(col_ref, np.int8), np.ascontiguousarray(col_mv, np.int16)
+    ro, po, mo = np.zeros((16, 2), np.int8), np.zeros(16, np.int8), np.zeros((16, 2, 2), np.int16)
+    L.jmo_direct_spatial(_p(av), _p(nr), _p(nm), int(col_long_term), _p(cr), _p(cm), _p(ro), _p(po), _p(mo))
+    return ro, po, mo

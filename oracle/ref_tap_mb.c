@@ -49,6 +49,69 @@ typedef struct {
 } MBREC;
 #pragma pack(pop)
 
+/* B slices: what Get_Direct_MV_Spatial_Normal (lencod/src/mv_direct.c:522) read and what it left -- $JM_TAP_DIR/mb_low_b.bin, one record per macroblock of a B slice.
+ * The neighbours A, B, C (C replaced by D where get_neighbors does that) are earlier macroblocks: their mv_info is final when the current macroblock's direct vectors are made,
+ * and still is when this tap runs.  Layout mirrored in tests/golden/make_direct_b.py. */
+typedef struct {
+  int32_t frame_no, mb_addr, slice_nr, direct_8x8_inference, weighted_bipred_idc, num_ref[2], col_long_term;
+  int8_t  nb_avail[4];                      /* get_neighbors(currMB, mb, 0, 0, 16): A, B, C (after the replacement), D */
+  int8_t  nb_ref[3][2];                     /* mv_info[..].ref_idx[list] of A, B, C (valid where available) */
+  int16_t nb_mv[3][2][2];                   /* ... .mv[list] {x, y} */
+  int8_t  direct_ref_idx[16][2], direct_pdir[16];        /* currSlice->direct_ref_idx / direct_pdir, 4x4 raster of the macroblock */
+  int16_t direct_mv[16][2][2];              /* currSlice->all_mv[list][max(direct_ref_idx, 0)][0][by][bx] */
+  int8_t  col_ref[16][2];                   /* listX[LIST_1][0]->mv_info at the co-located position get_colocated_info reads (RSD corners with direct_8x8_inference) */
+  int16_t col_mv[16][2][2];
+} MBREC_B;
+
+static void tap_b_slice(Macroblock *currMB)
+{
+  static FILE *f = NULL;
+  VideoParameters *p_Vid = currMB->p_Vid;
+  Slice *currSlice = currMB->p_Slice;
+  PicMotionParams **motion = p_Vid->enc_picture->mv_info;
+  StorablePicture *col = currSlice->listX[LIST_1][0];
+  const int inf = p_Vid->active_sps->direct_8x8_inference_flag;
+  PixelPos mb[4];
+  MBREC_B r;
+  int k, l, i, j;
+  if (!f) {
+    char path[1024];
+    const char *d = getenv("JM_TAP_DIR");
+    snprintf(path, sizeof path, "%s/mb_low_b.bin", d ? d : ".");
+    f = fopen(path, "wb");
+    if (!f) { perror(path); exit(3); }
+  }
+  memset(&r, 0, sizeof r);
+  r.frame_no = p_Vid->frame_no; r.mb_addr = currMB->mbAddrX; r.slice_nr = currMB->slice_nr; r.direct_8x8_inference = inf;
+  r.weighted_bipred_idc = p_Vid->active_pps->weighted_bipred_idc; r.num_ref[0] = currSlice->listXsize[LIST_0]; r.num_ref[1] = currSlice->listXsize[LIST_1];
+  r.col_long_term = col->is_long_term;
+  get_neighbors(currMB, mb, 0, 0, 16);
+  for (k = 0; k < 4; k++) r.nb_avail[k] = (int8_t)mb[k].available;
+  for (k = 0; k < 3; k++)
+    for (l = 0; l < 2; l++) {
+      r.nb_ref[k][l] = -1;
+      if (mb[k].available) {
+        const PicMotionParams *mp = &motion[mb[k].pos_y][mb[k].pos_x];
+        r.nb_ref[k][l] = mp->ref_idx[l]; r.nb_mv[k][l][0] = mp->mv[l].mv_x; r.nb_mv[k][l][1] = mp->mv[l].mv_y;
+      }
+    }
+  for (j = 0; j < 4; j++)
+    for (i = 0; i < 4; i++) {
+      const int by = currMB->block_y + j, bx = currMB->block_x + i, b = j * 4 + i;
+      const int cy = inf ? RSD(by) : by, cx = inf ? RSD(bx) : bx;
+      r.direct_pdir[b] = currSlice->direct_pdir[by][bx];
+      for (l = 0; l < 2; l++) {
+        const int ref = currSlice->direct_ref_idx[by][bx][l];
+        r.direct_ref_idx[b][l] = (int8_t)ref;
+        r.direct_mv[b][l][0] = currSlice->all_mv[l][ref < 0 ? 0 : ref][0][j][i].mv_x; r.direct_mv[b][l][1] = currSlice->all_mv[l][ref < 0 ? 0 : ref][0][j][i].mv_y;
+        r.col_ref[b][l] = col->mv_info[cy][cx].ref_idx[l];
+        r.col_mv[b][l][0] = col->mv_info[cy][cx].mv[l].mv_x; r.col_mv[b][l][1] = col->mv_info[cy][cx].mv[l].mv_y;
+      }
+    }
+  fwrite(&r, sizeof r, 1, f);
+  fflush(f);
+}
+
 extern void __real_encode_one_macroblock_low(Macroblock *currMB);
 void __wrap_encode_one_macroblock_low(Macroblock *currMB)
 {
@@ -61,6 +124,7 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
   int i, j, k, b8, b4, m;
 
   __real_encode_one_macroblock_low(currMB);
+  if (currSlice->slice_type == B_SLICE && getenv("JM_TAPMB_B")) tap_b_slice(currMB);
 
   if (maxn < 0) { const char *e = getenv("JM_TAPMB_MAX"); maxn = e ? atoi(e) : 1 << 30; }
   if (n >= maxn) return;

@@ -537,3 +537,26 @@ def test_oracle_intra8x8_prediction_matches_the_reference():
         mode, left, up = (int(v) for v in r[:3])
         assert np.array_equal(J.intrapred_8x8(r[3:28], mode, left, up), r[28:].reshape(8, 8).astype(np.uint8)), (mode, left, up, r[3:28].tolist())
     assert set(rec[:, 0].tolist()) == set(range(9)) and len(rec) > 300
+
+
+def test_direct_spatial_equals_the_reference_encoder():
+    """B slices, first building block: the spatial direct mode's references, prediction directions and vectors of every macroblock of the B slices of four
+    runs of the REAL encoder (tests/golden/direct_b.npz, oracle/ref_tap_mb.c tap_b_slice: foreman QCIF, motion clips, one or two B pictures between the P pictures, up to five
+    references, direct_8x8_inference on and off, slices) from the neighbours and the co-located motion the encoder itself read."""
+    z = np.load(os.path.join(G, "direct_b.npz"))
+    tags = [k for k in z.files if not k.endswith("_overrides")]
+    assert len(tags) >= 4
+    n = 0
+    for tag in tags:
+        recs = z[tag]
+        assert (recs["weighted_bipred_idc"] == 0).all()
+        for q in recs:
+            ro, po, mo = J.direct_spatial(q["nb_avail"], q["nb_ref"], q["nb_mv"], q["col_long_term"], q["col_ref"], q["col_mv"])
+            assert np.array_equal(ro, q["direct_ref_idx"]) and np.array_equal(po, q["direct_pdir"]), (tag, int(q["frame_no"]), int(q["mb_addr"]))
+            used = q["direct_ref_idx"] >= 0                      # a list that is not used keeps whatever all_mv held
+            assert np.array_equal(mo[used], q["direct_mv"][used]), (tag, int(q["frame_no"]), int(q["mb_addr"]), "vectors")
+            n += 1
+    assert n >= 1000
+    # both co-located rules and every prediction direction occur
+    assert {int(v) for t in tags for v in np.unique(z[t]["direct_8x8_inference"])} == {0, 1}
+    assert {int(v) for t in tags for v in np.unique(z[t]["direct_pdir"])} == {0, 1, 2}
