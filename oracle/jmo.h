@@ -249,7 +249,7 @@ void jmo_deblock_strength(uint8_t str[16], int dir, int edge, int mb_addr, int m
 #define JMO_MAX_REF 16
 typedef struct {
   int32_t width, height;        /* coded luma size (multiples of 16) */
-  int32_t slice_type;           /* 0 P, 2 I (SliceType, lcommon/inc/types.h) */
+  int32_t slice_type;           /* 0 P, 1 B (jmo_encode_slice_b), 2 I (SliceType, lcommon/inc/types.h) */
   int32_t first_mb, num_mb;     /* the slice: macroblocks [first_mb, first_mb + num_mb) in raster order */
   int32_t qp, qpc;              /* currMB->qp, currMB->qpc[0] (= qpc[1]) */
   int32_t search_range;         /* SearchRange (full-pel) */
@@ -310,13 +310,38 @@ typedef struct {
   int16_t  luma_dc[16];         /* Intra16x16 DC levels, scan order */
   int16_t  chroma_dc[2][8];     /* [uv][scan position]: four levels with 4:2:0, eight (SCAN_YUV422 order, block.c:88) with 4:2:2 */
   int16_t  chroma_ac[2][8][16]; /* [uv][4x4 block in raster order of the plane: four (4:2:0) or eight (4:2:2: cofAC[4 + 2 uv + (k >> 2)][k & 3])][1..15] */
-} jmo_mb_record;                /* 1216 bytes */
+  /* B slices (zero otherwise) */
+  int16_t  mv1[16][2];          /* enc_picture->mv_info[..].mv[LIST_1], 4x4 raster */
+  int8_t   b8ref1[4];           /* ... .ref_idx[LIST_1] of each 8x8 block */
+  int8_t   b8pdir[4];           /* currMB->b8x8[k].pdir: 0 list 0, 1 list 1, 2 both, -1 intra */
+  int8_t   b8bipred[4];         /* currMB->b8x8[k].bipred: 0, or 1 / 2 = the vectors of the bi-predictive search (currSlice->bipred_mv[bipred - 1]) */
+  int8_t   pad2[4];
+} jmo_mb_record;                /* 1296 bytes */
 
 typedef struct {                /* intermediate values, for localising a divergence (tests only) */
   int64_t motion_cost[8][4];    /* p_Vid->motion_cost[mode][LIST_0][0][block] */
   int16_t all_mv[8][16][2];     /* currSlice->all_mv[LIST_0][0][mode][by][bx] */
   int32_t best_mode, pad;
+  int64_t motion_cost1[8][4];   /* p_Vid->motion_cost[mode][LIST_1][0][block] (B slices) */
 } jmo_mb_debug;
+
+/* B slices (jmo_mbenc_b.inc): what the slice has beside cfg (cfg->num_ref = listXsize[LIST_0], cfg->inter_valid = InterSearch[1][..]: [0] = BSliceDirect) */
+typedef struct jmo_b_cfg_s {
+  int32_t num_ref1;             /* currSlice->listXsize[LIST_1] */
+  int32_t direct_8x8_inference; /* active_sps->direct_8x8_inference_flag (DirectModeType must be 1: spatial) */
+  int32_t col_long_term;        /* listX[LIST_1][0]->is_long_term */
+  int32_t bipred_me;            /* BiPredMotionEstimation */
+  int32_t bipred_search[4];     /* BiPredSearch16x16 / 16x8 / 8x16 / 8x8 (p_Vid->bipred_enabled[1..4], slice.c:410) */
+  int32_t bipred_refinements, bipred_range, bipred_subpel;   /* BiPredMERefinements, BiPredMESearchRange, BiPredMESubPel */
+  const int8_t *col_ref;        /* listX[LIST_1][0]->mv_info[..].ref_idx[list] at [(y4 * w4 + x4) * 2 + list] */
+  const int16_t *col_mv;        /* ... .mv[list] {x, y} at [((y4 * w4 + x4) * 2 + list) * 2] */
+} jmo_b_cfg;
+
+/* refs / refc: list 0, refs1 / refc1: list 1; mv / ref_idx: list 0 of enc_picture->mv_info, mv1 / ref_idx1: list 1 */
+int jmo_encode_slice_b(const jmo_mbenc_cfg *cfg, const jmo_b_cfg *bcfg, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
+                       const jmo_refpic *refs, const jmo_pel *const *refc, const jmo_refpic *refs1, const jmo_pel *const *refc1,
+                       jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v, int16_t *mv, int8_t *ref_idx, int16_t *mv1, int8_t *ref_idx1, int8_t *ipredmode,
+                       jmo_mb_record *out, jmo_mb_debug *dbg);
 
 int jmo_encode_slice(const jmo_mbenc_cfg *cfg, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
                      const jmo_refpic *refs, const jmo_pel *const *refc, jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v,

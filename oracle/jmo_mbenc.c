@@ -38,17 +38,21 @@ typedef struct {
   const jmo_mbenc_cfg *c;
   int wmb, hmb, w4;
   const jmo_pel *cur[3];          /* source planes at the coded size (pitch = width / width/2) */
-  const jmo_refpic *ref;          /* [num_ref] luma quarter-pel planes */
-  const jmo_pel *const *refc;     /* [num_ref][2] integer chroma planes (pitch width/2) */
+  const jmo_refpic *refl[2];      /* per list: [num_ref] luma quarter-pel planes (list 1: B slices) */
+  const jmo_pel *const *refcl[2]; /* per list: [num_ref][2] integer chroma planes (pitch width/2) */
+  int cl;                         /* the list the current search works on (mv_block->list): 0 outside B slices */
   jmo_pel *rec[3];                /* reconstruction (before the loop filter), written macroblock by macroblock */
-  mvinfo *mi;                     /* [h4][w4] enc_picture->mv_info */
+  mvinfo *mil[2];                 /* per list: [h4][w4] enc_picture->mv_info (.mv[list], .ref_idx[list]) */
   int8_t *ipm;                    /* [h4][w4] p_Vid->ipredmode */
   jmo_mv *spiral; int spiral_R;
   /* per macroblock */
   int mbx, mby, addr;
   int availA, availB, availC, availD;    /* left, up, up-right, up-left macroblock inside the slice */
-  jmo_mv all_mv[JMO_MAX_REF][8][4][4];   /* currSlice->all_mv[LIST_0][ref][mode][by][bx] */
-  jmo_dist motion_cost[8][JMO_MAX_REF][4];
+  jmo_mv all_mvl[2][JMO_MAX_REF][8][4][4];   /* currSlice->all_mv[list][ref][mode][by][bx] */
+  jmo_dist motion_costl[8][2][JMO_MAX_REF][4];   /* p_Vid->motion_cost[mode][list][ref][block] */
+  const struct jmo_b_cfg_s *bc;          /* B slices: list 1, direct mode, bi-predictive search (jmo_mbenc_b.inc) */
+  jmo_mv bipred_mv[2][2][8][4][4];       /* currSlice->bipred_mv[set][list][0][mode][by][bx] (reference 0 only) */
+  int8_t direct_ref[16][2], direct_pdir[16];   /* currSlice->direct_ref_idx / direct_pdir of the macroblock, 4x4 raster */
   jmo_pel orig[256];
   struct epzs_state *ez;                 /* SearchMode = 3: the slice's EPZS state (jmo_mbenc_epzs.inc) */
 } enc;
@@ -90,7 +94,7 @@ static jmo_mv mv_predictor(const enc *e, const nb b[4], int ref, int mb_x, int m
   const mvinfo *m[3];
   int r[3], k, type = 0;        /* 0 median, 1 L, 2 U, 3 UR */
   jmo_mv z = {0, 0}, p;
-  for (k = 0; k < 3; k++) { m[k] = b[k].avail ? &e->mi[b[k].y4 * e->w4 + b[k].x4] : NULL; r[k] = m[k] ? m[k]->ref : -1; }
+  for (k = 0; k < 3; k++) { m[k] = b[k].avail ? &e->mil[e->cl][b[k].y4 * e->w4 + b[k].x4] : NULL; r[k] = m[k] ? m[k]->ref : -1; }
   if (r[0] == ref && r[1] != ref && r[2] != ref) type = 1;
   else if (r[0] != ref && r[1] == ref && r[2] != ref) type = 2;
   else if (r[0] != ref && r[1] != ref && r[2] == ref) type = 3;
@@ -119,8 +123,8 @@ static jmo_mv skip_mv(const enc *e)
   jmo_mv z = {0, 0};
   int zl, za;
   get_neighbors(e, b, 0, 0, 16);
-  zl = !b[0].avail ? 1 : (e->mi[b[0].y4 * e->w4 + b[0].x4].ref == 0 && e->mi[b[0].y4 * e->w4 + b[0].x4].mv.x == 0 && e->mi[b[0].y4 * e->w4 + b[0].x4].mv.y == 0);
-  za = !b[1].avail ? 1 : (e->mi[b[1].y4 * e->w4 + b[1].x4].ref == 0 && e->mi[b[1].y4 * e->w4 + b[1].x4].mv.x == 0 && e->mi[b[1].y4 * e->w4 + b[1].x4].mv.y == 0);
+  zl = !b[0].avail ? 1 : (e->mil[e->cl][b[0].y4 * e->w4 + b[0].x4].ref == 0 && e->mil[e->cl][b[0].y4 * e->w4 + b[0].x4].mv.x == 0 && e->mil[e->cl][b[0].y4 * e->w4 + b[0].x4].mv.y == 0);
+  za = !b[1].avail ? 1 : (e->mil[e->cl][b[1].y4 * e->w4 + b[1].x4].ref == 0 && e->mil[e->cl][b[1].y4 * e->w4 + b[1].x4].mv.x == 0 && e->mil[e->cl][b[1].y4 * e->w4 + b[1].x4].mv.y == 0);
   if (za || zl) return z;
   return mv_predictor(e, b, 0, 0, 0, 16, 16);
 }
@@ -193,7 +197,7 @@ static jmo_dist block_motion_search_epzs(enc *e, int ref, int blocktype, int mb_
   mv.x = (int16_t)iclip3(c->mv_limit[0], c->mv_limit[1], mv.x);
   mv.y = (int16_t)iclip3(c->mv_limit[2], c->mv_limit[3], mv.y);
   memset(&B, 0, sizeof B);
-  B.e = e; B.s = (epzs *)e->ez; B.rp = &e->ref[ref]; B.orig = orig; B.bt = blocktype; B.bsx = bsx; B.bsy = bsy; B.ref = ref; B.mb_x = mb_x; B.mb_y = mb_y;
+  B.e = e; B.s = (epzs *)e->ez; B.rp = &e->refl[e->cl][ref]; B.orig = orig; B.bt = blocktype; B.bsx = bsx; B.bsy = bsy; B.ref = ref; B.mb_x = mb_x; B.mb_y = mb_y;
   B.pxp = (e->mbx * 16 + mb_x) << 2; B.pyp = (e->mby * 16 + mb_y) << 2; B.x4 = (e->mbx * 16 + mb_x) >> 2; B.y4 = (e->mby * 16 + mb_y) >> 2;
   B.lambda = c->lambda_mf[0]; B.pred = pred; B.mv = mv; B.max_x = max_x; B.max_y = max_y; B.b = b;
   min_mcost = epzs_integer(&B, blocktype > 4);
@@ -211,8 +215,8 @@ static jmo_dist block_motion_search_epzs(enc *e, int ref, int blocktype, int mb_
     jmo_pel pr[256];
     jmo_dist cost;
     int j, i;
-    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s;
-    jmo_luma_pred(&e->ref[0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mvl[e->cl][0][0][j][i] = s;
+    jmo_luma_pred(&e->refl[e->cl][0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
     cost = (c->transform8x8 ? satd_blocks8(e->orig, 16, pr, 16, 16, 16) : satd_blocks(e->orig, 16, pr, 16, 16, 16)) - (jmo_dist)c->lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = s; }
   }
@@ -224,7 +228,7 @@ static jmo_dist block_motion_search_epzs(enc *e, int ref, int blocktype, int mb_
 static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, int mb_y, int bsx, int bsy, jmo_mv *out)
 {
   const jmo_mbenc_cfg *c = e->c;
-  const jmo_refpic *rp = &e->ref[ref];
+  const jmo_refpic *rp = &e->refl[e->cl][ref];
   const int pos_x = e->mbx * 16 + mb_x, pos_y = e->mby * 16 + mb_y, pxp = pos_x << 2, pyp = pos_y << 2;
   nb b[4];
   jmo_mv pred, mv, center;
@@ -352,8 +356,8 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
     jmo_pel pr[256];
     jmo_dist cost;
     int j, i;
-    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s;
-    jmo_luma_pred(&e->ref[0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mvl[e->cl][0][0][j][i] = s;
+    jmo_luma_pred(&e->refl[e->cl][0], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, s, z, pr);
     cost = (c->transform8x8 ? satd_blocks8(e->orig, 16, pr, 16, 16, 16) : satd_blocks(e->orig, 16, pr, 16, 16, 16)) - (jmo_dist)c->lambda_mf[2] * 8;
     if (cost < min_mcost) { min_mcost = cost; mv = s; }
   }
@@ -364,7 +368,7 @@ static jmo_dist block_motion_search(enc *e, int ref, int blocktype, int mb_x, in
 static void set_me_parameters(enc *e, jmo_mv mv, int ref, int x4, int y4, int w4, int h4)   /* mv_search.c:100-113 */
 {
   int j, i;
-  for (j = y4; j < y4 + h4; j++) for (i = x4; i < x4 + w4; i++) { mvinfo *m = &e->mi[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i]; m->mv = mv; m->ref = (int8_t)ref; }
+  for (j = y4; j < y4 + h4; j++) for (i = x4; i < x4 + w4; i++) { mvinfo *m = &e->mil[e->cl][(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i]; m->mv = mv; m->ref = (int8_t)ref; }
 }
 
 static const int PART_W[8] = {16, 16, 16, 8, 8, 8, 4, 4}, PART_H[8] = {16, 16, 8, 16, 8, 4, 8, 4};
@@ -376,7 +380,7 @@ static jmo_dist list0_cost(const enc *e, int mode, int block, int *best_ref)
   jmo_dist bm = JMO_DIST_MAX;
   int ref;
   for (ref = 0; ref < e->c->num_ref; ref++) {
-    jmo_dist mc = e->motion_cost[mode][ref][block];
+    jmo_dist mc = e->motion_costl[mode][e->cl][ref][block];
     if (mc < bm) {
       mc += e->c->num_ref <= 1 ? 0 : (jmo_dist)ref_lambda * e->c->refbits[ref];
       if (mc < bm) { bm = mc; *best_ref = ref; }
@@ -457,7 +461,7 @@ static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref, int t8
   int coeff_cost = 0, by, bx, j, i;
   if (t8) {                                                    /* luma_transform_size_8x8_flag: one 8x8 prediction, one 8x8 transform (:991-1011) */
     jmo_pel p[64];
-    jmo_luma_pred(&e->ref[ref], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mv[ref][mode][mb_y >> 2][mb_x >> 2], z, p);
+    jmo_luma_pred(&e->refl[e->cl][ref], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mvl[e->cl][ref][mode][mb_y >> 2][mb_x >> 2], z, p);
     for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) L->pred[(mb_y + j) * 16 + mb_x + i] = p[j * 8 + i];
     if (tq8x8(e, e->orig + mb_y * 16 + mb_x, 16, L->pred + mb_y * 16 + mb_x, 16, 0, &L->lev[b8 * 4], &coeff_cost, L->rec + mb_y * 16 + mb_x, 16)) {
       L->cbp_blk |= (int64_t)51 << (4 * b8 - 2 * (b8 & 1));
@@ -466,7 +470,7 @@ static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref, int t8
   } else {
   if (mode < 5) {
     jmo_pel p[64];
-    jmo_luma_pred(&e->ref[ref], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mv[ref][mode][mb_y >> 2][mb_x >> 2], z, p);
+    jmo_luma_pred(&e->refl[e->cl][ref], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mvl[e->cl][ref][mode][mb_y >> 2][mb_x >> 2], z, p);
     for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) L->pred[(mb_y + j) * 16 + mb_x + i] = p[j * 8 + i];
   }
   for (by = mb_y; by < mb_y + 8; by += 4)
@@ -474,7 +478,7 @@ static int luma_rc_8x8(enc *e, luma_result *L, int b8, int mode, int ref, int t8
       const int b4 = ((by >> 2) & 1) * 2 + ((bx >> 2) & 1);
       if (mode >= 5) {
         jmo_pel p[16];
-        jmo_luma_pred(&e->ref[ref], NULL, 0, e->mbx * 16 + bx, e->mby * 16 + by, 4, 4, e->all_mv[ref][mode][by >> 2][bx >> 2], z, p);
+        jmo_luma_pred(&e->refl[e->cl][ref], NULL, 0, e->mbx * 16 + bx, e->mby * 16 + by, 4, 4, e->all_mvl[e->cl][ref][mode][by >> 2][bx >> 2], z, p);
         for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) L->pred[(by + j) * 16 + bx + i] = p[j * 4 + i];
       }
       if (tq4x4(e, e->orig + by * 16 + bx, 16, L->pred + by * 16 + bx, 16, 0, L->lev[b8 * 4 + b4], &coeff_cost, L->rec + by * 16 + bx, 16)) {
@@ -500,7 +504,7 @@ static void luma_rc_mb(enc *e, luma_result *L, int mode, const int ref8[4], int 
   jmo_mv z = {0, 0};
   memset(L, 0, sizeof *L);
   if (mode == 1) {
-    jmo_luma_pred(&e->ref[ref8[0]], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, e->all_mv[ref8[0]][1][0][0], z, L->pred);
+    jmo_luma_pred(&e->refl[e->cl][ref8[0]], NULL, 0, e->mbx * 16, e->mby * 16, 16, 16, e->all_mvl[e->cl][ref8[0]][1][0][0], z, L->pred);
     for (b8 = 0; b8 < 4; b8++) {                               /* luma_residual_coding_16x16 :841-908 */
       const int mb_y = (b8 >> 1) << 3, mb_x = (b8 & 1) << 3;
       int coeff_cost = 0, by, bx;
@@ -653,8 +657,8 @@ static void chroma_mb(enc *e, jmo_mb_record *o, int intra, int mode, const int8_
           jmo_pel out[16];
           int jj, h;
           memset(mv1, 0, sizeof mv1);
-          for (jj = 0; jj < 4; jj++) for (h = 0; h < 2; h++) mv0[jj][h] = e->all_mv[ref][md][y422 ? (j + jj) >> 2 : (j + jj) >> 1][(i + 2 * h) >> 1];
-          jmo_chroma_pred4x4(e->refc[ref * 2 + uv], NULL, CW, CW, CH, y422 ? 2 : 1, 0, cx + i, cy + j, mv0, mv1, out);
+          for (jj = 0; jj < 4; jj++) for (h = 0; h < 2; h++) mv0[jj][h] = e->all_mvl[e->cl][ref][md][y422 ? (j + jj) >> 2 : (j + jj) >> 1][(i + 2 * h) >> 1];
+          jmo_chroma_pred4x4(e->refcl[e->cl][ref * 2 + uv], NULL, CW, CW, CH, y422 ? 2 : 1, 0, cx + i, cy + j, mv0, mv1, out);
           for (jj = 0; jj < 4; jj++) for (h = 0; h < 4; h++) pred[(j + jj) * 8 + i + h] = out[jj * 4 + h];
         }
     for (j = 0; j < RH; j++) for (i = 0; i < 8; i++) orig[j * 8 + i] = e->cur[1 + uv][(cy + j) * CW + cx + i];
@@ -687,7 +691,7 @@ static int transform_decision(enc *e, int mode, const int ref8[4], jmo_dist *cos
   int b8, j, i;
   for (b8 = 0; b8 < 4; b8++) {
     const int mb_y = (b8 >> 1) << 3, mb_x = (b8 & 1) << 3;
-    jmo_luma_pred(&e->ref[ref8[b8]], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mv[ref8[b8]][mode][mb_y >> 2][mb_x >> 2], z, p);
+    jmo_luma_pred(&e->refl[e->cl][ref8[b8]], NULL, 0, e->mbx * 16 + mb_x, e->mby * 16 + mb_y, 8, 8, e->all_mvl[e->cl][ref8[b8]][mode][mb_y >> 2][mb_x >> 2], z, p);
     for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) pr[(mb_y + j) * 16 + mb_x + i] = p[j * 8 + i];
   }
   satd_4_and_8(e, pr, pr, &c4, &c8);
@@ -778,6 +782,8 @@ static void store_luma(enc *e, const jmo_pel *src)
   for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) e->rec[0][(e->mby * 16 + j) * W + e->mbx * 16 + i] = src[j * 16 + i];
 }
 
+#include "jmo_mbenc_b.inc"
+
 static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
 {
   const jmo_mbenc_cfg *c = e->c;
@@ -805,8 +811,8 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
   for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) e->orig[j * 16 + i] = e->cur[0][(e->mby * 16 + j) * W + e->mbx * 16 + i];
   { jmo_mv z = {0, 0}; set_me_parameters(e, z, -1, 0, 0, 4, 4); }            /* reset_macroblock macroblock.c:259-281 */
   memset(best_ref, 0, sizeof best_ref);
-  memset(e->motion_cost, 0, sizeof e->motion_cost);
-  memset(e->all_mv, 0, sizeof e->all_mv);
+  memset(e->motion_costl, 0, sizeof e->motion_costl);
+  memset(e->all_mvl[0], 0, sizeof e->all_mvl[0]);
 
   if (pslice) {
     /* ---- 16x16, 16x8, 8x16: md_low.c:185-263 ---- */
@@ -818,17 +824,17 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
         int bref = 0;
         for (ref = 0; ref < c->num_ref; ref++) {                                /* PartitionMotionSearch mv_search.c:1625-1660 */
           jmo_mv mv;
-          e->motion_cost[mode][ref][block] = block_motion_search(e, ref, mode, bx, by, bw, bh, &mv);
-          for (j = 0; j < bh / 4; j++) for (i = 0; i < bw / 4; i++) e->all_mv[ref][mode][by / 4 + j][bx / 4 + i] = mv;
+          e->motion_costl[mode][e->cl][ref][block] = block_motion_search(e, ref, mode, bx, by, bw, bh, &mv);
+          for (j = 0; j < bh / 4; j++) for (i = 0; i < bw / 4; i++) e->all_mvl[e->cl][ref][mode][by / 4 + j][bx / 4 + i] = mv;
           set_me_parameters(e, mv, ref, bx / 4, by / 4, bw / 4, bh / 4);
         }
         cost += list0_cost(e, mode, block, &bref);
         for (j = 0; j < bh / 4; j++)                                             /* assign_enc_picture_params rdopt.c:3580: vectors, not ref_idx */
-          for (i = 0; i < bw / 4; i++) e->mi[(e->mby * 4 + by / 4 + j) * e->w4 + e->mbx * 4 + bx / 4 + i].mv = e->all_mv[bref][mode][by / 4 + j][bx / 4 + i];
+          for (i = 0; i < bw / 4; i++) e->mil[e->cl][(e->mby * 4 + by / 4 + j) * e->w4 + e->mbx * 4 + bx / 4 + i].mv = e->all_mvl[e->cl][bref][mode][by / 4 + j][bx / 4 + i];
         if (mode == 1) for (k = 0; k < 4; k++) best_ref[1][k] = bref;          /* set_block8x8_info rdopt.c:3680 */
         else if (mode == 2) { best_ref[2][2 * block] = bref; best_ref[2][2 * block + 1] = bref; }
         else { best_ref[3][block] = bref; best_ref[3][block + 2] = bref; }
-        if (mode > 1 && block == 0) set_me_parameters(e, e->all_mv[bref][mode][0][0], bref, 0, 0, bw / 4, bh / 4);   /* set_ref_and_motion_vectors_P_slice */
+        if (mode > 1 && block == 0) set_me_parameters(e, e->all_mvl[e->cl][bref][mode][0][0], bref, 0, 0, bw / 4, bh / 4);   /* set_ref_and_motion_vectors_P_slice */
       }
       cur_t8 = 0;
       if (c->transform8x8) cur_t8 = transform_decision(e, mode, best_ref[mode], &cost);      /* md_low.c:244-249 */
@@ -855,17 +861,17 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
             any = 1;
             for (ref = 0; ref < c->num_ref; ref++) {                              /* SubPartitionMotionSearch mv_search.c:1796-1830 */
               int v, h;
-              e->motion_cost[mode][ref][block] = 0;
+              e->motion_costl[mode][e->cl][ref][block] = 0;
               for (v = y0; v < y0 + 8; v += bh)
                 for (h = x0; h < x0 + 8; h += bw) {
                   jmo_mv mv;
-                  e->motion_cost[mode][ref][block] += block_motion_search(e, ref, mode, h, v, bw, bh, &mv);
-                  for (j = 0; j < bh / 4; j++) for (i = 0; i < bw / 4; i++) e->all_mv[ref][mode][v / 4 + j][h / 4 + i] = mv;
+                  e->motion_costl[mode][e->cl][ref][block] += block_motion_search(e, ref, mode, h, v, bw, bh, &mv);
+                  for (j = 0; j < bh / 4; j++) for (i = 0; i < bw / 4; i++) e->all_mvl[e->cl][ref][mode][v / 4 + j][h / 4 + i] = mv;
                   set_me_parameters(e, mv, ref, h / 4, v / 4, bw / 4, bh / 4);
                 }
             }
             cost = list0_cost(e, mode, block, &bref);
-            for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) e->mi[(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i].ref = (int8_t)bref;   /* :847-854 */
+            for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) e->mil[e->cl][(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i].ref = (int8_t)bref;   /* :847-854 */
             if (cost != JMO_DIST_MAX) cost += (c->num_ref <= 1 ? 0 : (jmo_dist)c->lambda_mf[2] * c->refbits[mode - 4]) - 1;    /* :898-900: ref_cost(.., B8Mode2Value = mode - 4, ..) - 1 */
             if (cost < min8) { min8 = cost; bm = mode; br = bref; }
           }
@@ -880,11 +886,11 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
              * survives reset_block only with cost > 4.  Kept as JM writes it: */
             if (!cnt) PR->cbp &= ~(1 << block);
           }
-          if (pass) for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) p8tmv[(y0 / 4 + j) * 4 + x0 / 4 + i] = e->all_mv[br][bm][y0 / 4 + j][x0 / 4 + i];    /* store_8x8_motion_vectors */
+          if (pass) for (j = 0; j < 2; j++) for (i = 0; i < 2; i++) p8tmv[(y0 / 4 + j) * 4 + x0 / 4 + i] = e->all_mvl[e->cl][br][bm][y0 / 4 + j][x0 / 4 + i];    /* store_8x8_motion_vectors */
           for (j = 0; j < 2; j++)                                                  /* set_ref_and_motion_vectors_P_slice rdopt.c:2885, 8x8 region */
             for (i = 0; i < 2; i++) {
-              mvinfo *m = &e->mi[(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i];
-              m->mv = e->all_mv[br][bm][y0 / 4 + j][x0 / 4 + i]; m->ref = (int8_t)br;
+              mvinfo *m = &e->mil[e->cl][(e->mby * 4 + y0 / 4 + j) * e->w4 + e->mbx * 4 + x0 / 4 + i];
+              m->mv = e->all_mvl[e->cl][br][bm][y0 / 4 + j][x0 / 4 + i]; m->ref = (int8_t)br;
             }
         }
         if (pass) p8tcost = pcost; else p8cost = pcost;
@@ -905,7 +911,7 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
         cur_t8 = p8_t8;
       }
     }
-    { jmo_mv s = skip_mv(e); for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[0][0][j][i] = s; }        /* md_low.c:357-358 */
+    { jmo_mv s = skip_mv(e); for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mvl[e->cl][0][0][j][i] = s; }        /* md_low.c:357-358 */
   }
   min_rdcost = min_cost;
 
@@ -973,7 +979,7 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
       if (cur_t8 && P8T.cbp == 0) cur_t8 = 0;                    /* md_low.c:568-569: then the tr4x4 data are used */
       if (cur_t8) {
         for (k = 0; k < 4; k++) { o->b8mode[k] = p8tmode[k]; ref8[k] = p8tref[k]; }
-        for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mv[ref8[(j >> 1) * 2 + (i >> 1)]][4][j][i] = p8tmv[j * 4 + i];      /* RestoreMV8x8 */
+        for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) e->all_mvl[e->cl][ref8[(j >> 1) * 2 + (i >> 1)]][4][j][i] = p8tmv[j * 4 + i];      /* RestoreMV8x8 */
         memcpy(o->luma, P8T.lev, sizeof o->luma);
         if (P8T.cnt_nonz <= 5) { o->cbp = 0; o->cbp_blk = 0; store_luma(e, P8T.pred); }       /* _LUMA_8x8_COEFF_COST_ */
         else { o->cbp = (int16_t)P8T.cbp; o->cbp_blk = (uint64_t)P8T.cbp_blk; store_luma(e, P8T.rec); }
@@ -1004,26 +1010,26 @@ static void encode_mb(enc *e, jmo_mb_record *o, jmo_mb_debug *dbg)
     /* SetMotionVectorsMBPSlice md_common.c:172 + the reference indices of set_modes_and_refs_for_blocks_p_slice rdopt.c:1041-1130 */
     for (j = 0; j < 4; j++)
       for (i = 0; i < 4; i++) {
-        mvinfo *m = &e->mi[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i];
+        mvinfo *m = &e->mil[e->cl][(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i];
         const int b8 = (j >> 1) * 2 + (i >> 1);
         if (best_mode >= 9) { m->mv.x = m->mv.y = 0; m->ref = -1; }
-        else { m->ref = (int8_t)ref8[b8]; m->mv = e->all_mv[ref8[b8]][o->b8mode[b8]][j][i]; }
+        else { m->ref = (int8_t)ref8[b8]; m->mv = e->all_mvl[e->cl][ref8[b8]][o->b8mode[b8]][j][i]; }
       }
     /* the skip test md_low.c:658-665 */
     if (pslice && best_mode == 1 && o->cbp == 0 && ref8[0] == 0) {
-      const mvinfo *m = &e->mi[(e->mby * 4) * e->w4 + e->mbx * 4];
-      if (m->mv.x == e->all_mv[0][0][0][0].x && m->mv.y == e->all_mv[0][0][0][0].y) { o->mb_type = 0; memset(o->b8mode, 0, 4); cur_t8 = 0; }
+      const mvinfo *m = &e->mil[e->cl][(e->mby * 4) * e->w4 + e->mbx * 4];
+      if (m->mv.x == e->all_mvl[e->cl][0][0][0][0].x && m->mv.y == e->all_mvl[e->cl][0][0][0][0].y) { o->mb_type = 0; memset(o->b8mode, 0, 4); cur_t8 = 0; }
     }
     o->transform8x8 = (int8_t)cur_t8;
     if (best_mode == 10) { /* i16offset is derived by the caller: I16Offset(cbp, i16mode) rdopt.c:868 */ }
     for (j = 0; j < 4; j++)
-      for (i = 0; i < 4; i++) { const mvinfo *m = &e->mi[(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i]; o->mv[j * 4 + i][0] = m->mv.x; o->mv[j * 4 + i][1] = m->mv.y; }
+      for (i = 0; i < 4; i++) { const mvinfo *m = &e->mil[e->cl][(e->mby * 4 + j) * e->w4 + e->mbx * 4 + i]; o->mv[j * 4 + i][0] = m->mv.x; o->mv[j * 4 + i][1] = m->mv.y; }
   }
   if (dbg) {
     memset(dbg, 0, sizeof *dbg);
     for (mode = 1; mode < 8; mode++) {
-      for (k = 0; k < 4; k++) dbg->motion_cost[mode][k] = e->motion_cost[mode][0][k];
-      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { dbg->all_mv[mode][j * 4 + i][0] = e->all_mv[0][mode][j][i].x; dbg->all_mv[mode][j * 4 + i][1] = e->all_mv[0][mode][j][i].y; }
+      for (k = 0; k < 4; k++) dbg->motion_cost[mode][k] = e->motion_costl[mode][e->cl][0][k];
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { dbg->all_mv[mode][j * 4 + i][0] = e->all_mvl[e->cl][0][mode][j][i].x; dbg->all_mv[mode][j * 4 + i][1] = e->all_mvl[e->cl][0][mode][j][i].y; }
     }
     dbg->best_mode = best_mode;
     (void)p8_valid;
@@ -1061,17 +1067,56 @@ int jmo_encode_slice_ex(const jmo_mbenc_cfg *cfg, jmo_epzs_cfg *ez, const jmo_pe
   e->c = cfg; e->wmb = cfg->width / 16; e->hmb = cfg->height / 16; e->w4 = cfg->width / 4;
   n4 = e->w4 * (cfg->height / 4);
   e->cur[0] = cur_y; e->cur[1] = cur_u; e->cur[2] = cur_v;
-  e->ref = refs; e->refc = refc;
+  e->refl[0] = refs; e->refcl[0] = refc; e->cl = 0;
   e->rec[0] = rec_y; e->rec[1] = rec_u; e->rec[2] = rec_v;
-  e->mi = (mvinfo *)malloc(sizeof(mvinfo) * (size_t)n4);
-  for (k = 0; k < n4; k++) { e->mi[k].mv.x = mv[2 * k]; e->mi[k].mv.y = mv[2 * k + 1]; e->mi[k].ref = ref_idx[k]; }
+  e->mil[0] = (mvinfo *)malloc(sizeof(mvinfo) * (size_t)n4);
+  for (k = 0; k < n4; k++) { e->mil[e->cl][k].mv.x = mv[2 * k]; e->mil[e->cl][k].mv.y = mv[2 * k + 1]; e->mil[e->cl][k].ref = ref_idx[k]; }
   e->ipm = ipredmode;
   for (k = 0; k < cfg->num_mb; k++) {
     e->addr = cfg->first_mb + k; e->mbx = e->addr % e->wmb; e->mby = e->addr / e->wmb;
     encode_mb(e, &out[k], dbg ? &dbg[k] : NULL);
   }
-  for (k = 0; k < n4; k++) { mv[2 * k] = e->mi[k].mv.x; mv[2 * k + 1] = e->mi[k].mv.y; ref_idx[k] = e->mi[k].ref; }
+  for (k = 0; k < n4; k++) { mv[2 * k] = e->mil[e->cl][k].mv.x; mv[2 * k + 1] = e->mil[e->cl][k].mv.y; ref_idx[k] = e->mil[e->cl][k].ref; }
   epzs_free((epzs *)e->ez);
-  free(e->spiral); free(e->mi); free(e);
+  free(e->spiral); free(e->mil[0]); free(e);
+  return 0;
+}
+
+int jmo_encode_slice_b(const jmo_mbenc_cfg *cfg, const jmo_b_cfg *bcfg, const jmo_pel *cur_y, const jmo_pel *cur_u, const jmo_pel *cur_v,
+                       const jmo_refpic *refs, const jmo_pel *const *refc, const jmo_refpic *refs1, const jmo_pel *const *refc1,
+                       jmo_pel *rec_y, jmo_pel *rec_u, jmo_pel *rec_v, int16_t *mv, int8_t *ref_idx, int16_t *mv1, int8_t *ref_idx1, int8_t *ipredmode,
+                       jmo_mb_record *out, jmo_mb_debug *dbg)
+{
+  enc *e = (enc *)calloc(1, sizeof(enc));
+  int k, n4, l;
+  if (!e) return -1;
+  if (cfg->num_ref > JMO_MAX_REF || bcfg->num_ref1 > JMO_MAX_REF || cfg->num_ref < 1 || bcfg->num_ref1 < 1 || cfg->slice_type != 1 || cfg->search_mode == 3) { free(e); return -2; }
+  if (cfg->search_mode == 1) {                                    /* fast full search: see the scope note in block_motion_search */
+    const int rq = cfg->search_range << 2;
+    if (cfg->mv_limit[3] - rq < rq || cfg->mv_limit[2] + rq > -rq || cfg->mv_limit[1] - rq < rq || cfg->mv_limit[0] + rq > -rq) { free(e); return -4; }
+  }
+  e->c = cfg; e->bc = bcfg; e->wmb = cfg->width / 16; e->hmb = cfg->height / 16; e->w4 = cfg->width / 4;
+  n4 = e->w4 * (cfg->height / 4);
+  e->cur[0] = cur_y; e->cur[1] = cur_u; e->cur[2] = cur_v;
+  e->refl[0] = refs; e->refcl[0] = refc; e->refl[1] = refs1; e->refcl[1] = refc1; e->cl = 0;
+  e->rec[0] = rec_y; e->rec[1] = rec_u; e->rec[2] = rec_v;
+  for (l = 0; l < 2; l++) {
+    const int16_t *m = l ? mv1 : mv;
+    const int8_t *r = l ? ref_idx1 : ref_idx;
+    e->mil[l] = (mvinfo *)malloc(sizeof(mvinfo) * (size_t)n4);
+    for (k = 0; k < n4; k++) { e->mil[l][k].mv.x = m[2 * k]; e->mil[l][k].mv.y = m[2 * k + 1]; e->mil[l][k].ref = r[k]; }
+  }
+  e->ipm = ipredmode;
+  for (k = 0; k < cfg->num_mb; k++) {
+    e->addr = cfg->first_mb + k; e->mbx = e->addr % e->wmb; e->mby = e->addr / e->wmb;
+    encode_mb_b(e, &out[k], dbg ? &dbg[k] : NULL);
+  }
+  for (l = 0; l < 2; l++) {
+    int16_t *m = l ? mv1 : mv;
+    int8_t *r = l ? ref_idx1 : ref_idx;
+    for (k = 0; k < n4; k++) { m[2 * k] = e->mil[l][k].mv.x; m[2 * k + 1] = e->mil[l][k].mv.y; r[k] = e->mil[l][k].ref; }
+    free(e->mil[l]);
+  }
+  free(e->spiral); free(e);
   return 0;
 }

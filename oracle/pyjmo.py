@@ -488,9 +488,17 @@ EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, aggressive=0, temporal=1, spati
 MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("transform8x8", "i1"), ("cbp", "<i2"), ("pad1", "<i2"),
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
-                      ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16))])
-MB_DEBUG = np.dtype([("motion_cost", "<i8", (8, 4)), ("all_mv", "<i2", (8, 16, 2)), ("best_mode", "<i4"), ("pad", "<i4")])
-assert MB_RECORD.itemsize == 1216
+                      ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16)),
+                      # B slices (zero otherwise): list-1 vectors and references, prediction direction per 8x8 block, which set of bi-predictive vectors
+                      ("mv1", "<i2", (16, 2)), ("b8ref1", "i1", (4,)), ("b8pdir", "i1", (4,)), ("b8bipred", "i1", (4,)), ("pad2", "i1", (4,))])
+MB_DEBUG = np.dtype([("motion_cost", "<i8", (8, 4)), ("all_mv", "<i2", (8, 16, 2)), ("best_mode", "<i4"), ("pad", "<i4"), ("motion_cost1", "<i8", (8, 4))])
+assert MB_RECORD.itemsize == 1296
+
+
+class BCfg(C.Structure):
+    """jmo_b_cfg: what a B slice has beside MbEncCfg"""
+    _fields_ = [("num_ref1", C.c_int32), ("direct_8x8_inference", C.c_int32), ("col_long_term", C.c_int32), ("bipred_me", C.c_int32), ("bipred_search", C.c_int32 * 4),
+                ("bipred_refinements", C.c_int32), ("bipred_range", C.c_int32), ("bipred_subpel", C.c_int32), ("col_ref", C.c_void_p), ("col_mv", C.c_void_p)]
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
@@ -557,9 +565,10 @@ def slice_offsets(slice_type, offsets=None):
     if offsets is None:
         intra = 682 if slice_type == 2 else 342                      # Offset_intra_default_intra / _inter, Offset_inter_default (q_offsets.c:135-162)
         return [[[342] * 16, [intra] * 16] for _ in range(3)], [[342] * 64, [intra] * 64]
-    sfx = "INTRA" if slice_type == 2 else "INTERP"
-    o4 = [[offsets[f"INTER4X4_{pl}_INTERP"], offsets[f"INTRA4X4_{pl}_{sfx}"]] for pl in ("LUMA", "CHROMAU", "CHROMAV")]
-    return o4, [offsets["INTER8X8_LUMA_INTERP"], offsets[f"INTRA8X8_LUMA_{sfx}"]]
+    sfx = "INTRA" if slice_type == 2 else ("INTERB" if slice_type == 1 else "INTERP")       # B slices: the lists 12..14 / 6..8 (q_offsets.c:660-678)
+    isfx = "INTERB" if slice_type == 1 else "INTERP"
+    o4 = [[offsets[f"INTER4X4_{pl}_{isfx}"], offsets[f"INTRA4X4_{pl}_{sfx}"]] for pl in ("LUMA", "CHROMAU", "CHROMAV")]
+    return o4, [offsets[f"INTER8X8_LUMA_{isfx}"], offsets[f"INTRA8X8_LUMA_{sfx}"]]
 
 
 class Picture:
@@ -571,6 +580,8 @@ class Picture:
         self.rec = [np.zeros((height, width), np.uint16), np.zeros((ch, width // 2), np.uint16), np.zeros((ch, width // 2), np.uint16)]
         self.mv = np.zeros((height // 4, width // 4, 2), np.int16)
         self.ref_idx = np.full((height // 4, width // 4), -1, np.int8)
+        self.mv1 = np.zeros((height // 4, width // 4, 2), np.int16)           # list 1 (B slices)
+        self.ref_idx1 = np.full((height // 4, width // 4), -1, np.int8)
         self.ipredmode = np.full((height // 4, width // 4), 2, np.int8)
 
 
@@ -602,6 +613,40 @@ def encode_slice(cfg, cur, refs, refc, pic, debug=False, epzs=None):
         epzs["out"] = ez
     r = L.jmo_encode_slice_ex(C.byref(cfg), C.byref(ez) if ez is not None else None, _p(cy), _p(cu), _p(cv), ra, pa, _p(pic.rec[0]), _p(pic.rec[1]), _p(pic.rec[2]),
                               _p(pic.mv), _p(pic.ref_idx), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
+    assert r == 0, r
+    return (out, dbg) if debug else out
+
+
+def encode_slice_b(cfg, b, cur, refs0, refc0, refs1, refc1, pic, debug=False):
+    """A B slice (jmo_encode_slice_b): cfg.slice_type 1, cfg.num_ref = size of list 0; b: dict(num_ref1, direct_8x8_inference, col_ref (h4, w4, 2) int8, col_mv (h4, w4, 2, 2) int16 =
+    the motion of listX[LIST_1][0], col_long_term, bipred_me, bipred_search[4], bipred_refinements, bipred_range, bipred_subpel); refs0 / refc0, refs1 / refc1: the lists' RefPic / chroma planes"""
+    cy, cu, cv = [np.ascontiguousarray(p, np.uint16) for p in cur]
+    n = cfg.num_mb
+    out = np.zeros(n, MB_RECORD)
+    dbg = np.zeros(n, MB_DEBUG) if debug else None
+    keepers = []
+
+    def lists(refs, refc):
+        RA = RefPicS * max(1, len(refs))
+        ra = RA(*[r.s for r in refs])
+        keep = [np.ascontiguousarray(p, np.uint16) for pair in refc for p in pair]
+        PA = C.c_void_p * max(1, len(keep))
+        keepers.append((ra, keep))
+        return ra, PA(*[k.ctypes.data for k in keep])
+    ra0, pa0 = lists(refs0, refc0)
+    ra1, pa1 = lists(refs1, refc1)
+    bc = BCfg()
+    bc.num_ref1 = len(refs1)
+    bc.direct_8x8_inference = int(b.get("direct_8x8_inference", 1))
+    bc.col_long_term = int(b.get("col_long_term", 0))
+    bc.bipred_me = int(b.get("bipred_me", 0))
+    for i, v in enumerate(b.get("bipred_search", (1, 1, 1, 0))):
+        bc.bipred_search[i] = int(v)
+    bc.bipred_refinements, bc.bipred_range, bc.bipred_subpel = int(b.get("bipred_refinements", 3)), int(b.get("bipred_range", 16)), int(b.get("bipred_subpel", 2))
+    cr, cm = np.ascontiguousarray(b["col_ref"], np.int8), np.ascontiguousarray(b["col_mv"], np.int16)
+    bc.col_ref, bc.col_mv = cr.ctypes.data, cm.ctypes.data
+    r = L.jmo_encode_slice_b(C.byref(cfg), C.byref(bc), _p(cy), _p(cu), _p(cv), ra0, pa0, ra1, pa1, _p(pic.rec[0]), _p(pic.rec[1]), _p(pic.rec[2]),
+                             _p(pic.mv), _p(pic.ref_idx), _p(pic.mv1), _p(pic.ref_idx1), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
     assert r == 0, r
     return (out, dbg) if debug else out
 

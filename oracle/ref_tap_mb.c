@@ -46,6 +46,14 @@ typedef struct {
   uint8_t rec_u2[64], rec_v2[64];
   int32_t yuv_format;
   int32_t qpc_v;                            /* currMB->qpc[1] (qpc above is qpc[0]) */
+  /* B slices (zero otherwise) */
+  int16_t mv1[16][2];                       /* enc_picture->mv_info[..].mv[LIST_1] */
+  int8_t  ref_idx1[16];
+  int8_t  b8bipred[4];                      /* currMB->b8x8[k].bipred */
+  int32_t num_ref1;                         /* listXsize[LIST_1] */
+  int64_t motion_cost1[8][2][4];            /* p_Vid->motion_cost[mode][LIST_1][ref 0..1][block] */
+  int32_t poc_l1[4];                        /* listX[LIST_1][r]->poc */
+  int32_t direct_8x8_inference, pad_;
 } MBREC;
 #pragma pack(pop)
 
@@ -197,6 +205,20 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
           r.chroma2_run[m * 4 + b4][k] = currSlice->cofAC[5 + 2 * m][b4][1][k];
         }
   r.yuv_format = p_Vid->yuv_format; r.qpc_v = currMB->qpc[1];
+  r.direct_8x8_inference = p_Vid->active_sps->direct_8x8_inference_flag;
+  if (currSlice->slice_type == B_SLICE) {
+    r.num_ref1 = currSlice->listXsize[LIST_1];
+    for (i = 0; i < 4; i++) r.b8bipred[i] = currMB->b8x8[i].bipred;
+    for (j = 0; j < 4; j++)
+      for (i = 0; i < 4; i++) {
+        PicMotionParams *mp = &motion[currMB->block_y + j][currMB->block_x + i];
+        r.mv1[j * 4 + i][0] = mp->mv[LIST_1].mv_x; r.mv1[j * 4 + i][1] = mp->mv[LIST_1].mv_y; r.ref_idx1[j * 4 + i] = mp->ref_idx[LIST_1];
+      }
+    for (m = 1; m < 8; m++)
+      for (i = 0; i < 2 && i < currSlice->listXsize[LIST_1]; i++)
+        for (k = 0; k < 4; k++) r.motion_cost1[m][i][k] = p_Vid->motion_cost[m][LIST_1][i][k];
+    for (i = 0; i < 4 && i < currSlice->listXsize[LIST_1]; i++) r.poc_l1[i] = currSlice->listX[LIST_1][i]->poc;
+  }
   for (j = 0; j < 16; j++)
     for (i = 0; i < 16; i++) r.rec_y[j * 16 + i] = (uint8_t)p_Vid->enc_picture->imgY[currMB->pix_y + j][currMB->pix_x + i];
   if (p_Vid->yuv_format == YUV420)

@@ -100,6 +100,20 @@ CASES = {
     # BASELINE configs[4] at its own size: 1080p 4:2:2 synthetic, encoder_yuv422.cfg but for RDO / adaptive rounding / B pictures (and the level: five references of 1080p need 5.1)
     "g4y": (dict(RDO_OFF, NumberBFrames="0", InputFile="syn1080p422.yuv", SourceWidth="1920", SourceHeight="1080", OutputWidth="1920", OutputHeight="1080", FramesToBeEncoded="3", LevelIDC="51"),
             (1920, 1080), 3, "syn422", "jm_yuv422.cfg"),
+    # ---- B pictures (NumberBFrames 1, non-reference, spatial direct): coding order I P B P B ...; Main profile and up.  *b0: BiPredMotionEstimation 0; *b: as the shipped
+    # encoder_main.cfg / encoder_yuv422.cfg have it (BiPredMotionEstimation 1, three refinements, range 16, sub-pel 2, 16x16 / 16x8 / 8x16)
+    "q1b0": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", SymbolMode="0", BiPredMotionEstimation="0"), (176, 144), 3, False, "jm_main.cfg"),
+    "q1b": (dict(RDO_OFF), (176, 144), 3, False, "jm_main.cfg"),                                      # encoder_main.cfg as shipped but for RDO / adaptive rounding
+    "m3b0": (dict(RDO_OFF, SearchMode="0", SearchRange="16", NumberReferenceFrames="3", ProfileIDC="100", Transform8x8Mode="1", BiPredMotionEstimation="0",
+                  FramesToBeEncoded="7", SliceMode="1", SliceArgument="50", QPISlice="26", QPPSlice="27", QPBSlice="29"), (208, 160), 7, "motion:91", "jm_main.cfg"),
+    "m3b": (dict(RDO_OFF, SearchMode="0", SearchRange="32", NumberReferenceFrames="3", ProfileIDC="100", Transform8x8Mode="1", FramesToBeEncoded="7", QPISlice="30", QPPSlice="30", QPBSlice="32"),
+            (208, 160), 7, "motion:92", "jm_main.cfg"),
+    "m2b4": (dict(RDO_OFF, SearchMode="-1", SearchRange="8", NumberReferenceFrames="2", SymbolMode="0", BiPredMERefinements="1", BiPredMESearchRange="8", BiPredMESubPel="1",
+                  FramesToBeEncoded="5", QPISlice="22", QPPSlice="22", QPBSlice="22", BList1References="2"), (176, 144), 5, "motion:93", "jm_main.cfg"),
+    # encoder_yuv422.cfg with its B picture (4:2:2, CABAC, 8x8 transform, fast full search, q_offset.cfg), RDO off
+    "q5yb": (dict(RDO_OFF, NumberBFrames="1", NumberReferenceFrames="4"), (176, 144), 3, False, "jm_yuv422.cfg"),
+    # encoder_main.cfg's search and B settings at 1080p (fast full search SR 32, CABAC, BiPredMotionEstimation 1), two references: I P B
+    "g3b": (dict(RDO_OFF, **dict(SYN1080, SearchMode="0", NumberReferenceFrames="2", FramesToBeEncoded="3")), (1920, 1080), 3, True, "jm_main.cfg"),
 }
 
 
@@ -119,7 +133,9 @@ def run(tag):
                 if len(kv) == 2:
                     base.setdefault(name, {})[kv[0].strip()] = kv[1].strip().strip('"')
         for k in ("SymbolMode", "SearchMode", "SearchRange", "Transform8x8Mode", "NumberReferenceFrames", "ProfileIDC", "LevelIDC", "YUVFormat", "InputFile", "FramesToBeEncoded",
-                  "SliceMode", "SliceArgument", "QPISlice", "QPPSlice", "DFDisableRefPSlice", "OffsetMatrixPresentFlag"):
+                  "SliceMode", "SliceArgument", "QPISlice", "QPPSlice", "DFDisableRefPSlice", "OffsetMatrixPresentFlag", "NumberBFrames", "BiPredMotionEstimation", "BiPredMERefinements",
+                  "BiPredMESearchRange", "BiPredMESubPel", "BiPredSearch16x16", "BiPredSearch16x8", "BiPredSearch8x16", "BiPredSearch8x8", "DirectInferenceFlag", "DirectModeType", "QPBSlice",
+                  "BList0References", "BList1References"):
             if k in base[cfg] and k not in ov:
                 ov = dict(ov, **{k: base[cfg][k]})
     tmp = tempfile.mkdtemp(prefix="mbgold_")
@@ -160,6 +176,13 @@ def run(tag):
             pre.append([md5(np.ascontiguousarray(p).tobytes()) for p in (y, u, v)])
         t0 = tap[0]
         lam = {int(t["slice_type"]): list(t["lambda_mf"]) + [int(t["lambda_mdfp"])] for t in tap[::nmb]}
+        bfirst = [t for t in tap[::nmb] if int(t["slice_type"]) == 1]
+        bextra = {}
+        if bfirst:                                          # B pictures: the lists as the encoder ordered them (picture order counts), the B slices' QPs and lambdas
+            bextra = dict(lambda_b=np.array(lam[1], np.int32), qp_b=int(bfirst[0]["qp"]), qpc_b=int(bfirst[0]["qpc"]), qpc_v_b=int(bfirst[0]["qpc_v"]),
+                          num_ref_pic=tap["num_ref"][::nmb].astype(np.int32), num_ref1_pic=tap["num_ref1"][::nmb].astype(np.int32), poc_l1=tap["poc_l1"][::nmb].astype(np.int32),
+                          frame_no=tap["frame_no"][::nmb].astype(np.int32), direct_8x8_inference=int(bfirst[0]["direct_8x8_inference"]),
+                          motion_cost1=tap["motion_cost1"][:, 1:, 0, :].astype(np.int64) if sw * sh < 200000 else np.zeros(0, np.int64))
         np.savez_compressed(os.path.join(G, f"mb_low_{tag}.npz"),
                             records=mb_tap.tap_to_records(tap, int(ov.get("SymbolMode", 0))), slice_type=tap["slice_type"][::nmb].astype(np.int32), slice_nr=tap["slice_nr"].astype(np.int16),
                             lambda_i=np.array(lam.get(2, [0, 0, 0, 0]), np.int32), lambda_p=np.array(lam.get(0, [0, 0, 0, 0]), np.int32),
@@ -172,7 +195,7 @@ def run(tag):
                             md5_pre_deblock=np.array(pre), overrides=np.array(sorted(f"{k}={v}" for k, v in ov.items())), clip=str(syn), clip_md5=clip_md5, cfg=cfg, yuv_format=int(t0["yuv_format"]), qpc_v=int(t0["qpc_v"]),
                             qp_p=int(([int(t["qp"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qp"])])[0]),
                             qpc_p=int(([int(t["qpc"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qpc"])])[0]),      # the P pictures' chroma QPs (QPPSlice != QPISlice with chroma offsets)
-                            qpc_v_p=int(([int(t["qpc_v"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qpc_v"])])[0]))
+                            qpc_v_p=int(([int(t["qpc_v"]) for t in tap[::nmb] if int(t["slice_type"]) == 0] or [int(t0["qpc_v"])])[0]), **bextra)
         print(tag, "records", len(tap), "md5", md5(open(os.path.join(tmp, "o.264"), "rb").read()))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -17,7 +17,10 @@ TAP = np.dtype([("frame_no", "<i4"), ("mb_addr", "<i4"), ("slice_type", "<i4"), 
                 ("rec_y", "u1", (256,)), ("rec_u", "u1", (64,)), ("rec_v", "u1", (64,)),
                 ("poc", "<i4"), ("ref_poc", "<i4", (16,)), ("motion_cost_ref", "<i8", (8, 4, 4)),
                 ("luma8_level", "<i4", (4, 65)), ("luma8_run", "<i4", (4, 65)),
-                ("chroma2_level", "<i4", (8, 17)), ("chroma2_run", "<i4", (8, 17)), ("rec_u2", "u1", (64,)), ("rec_v2", "u1", (64,)), ("yuv_format", "<i4"), ("qpc_v", "<i4")])
+                ("chroma2_level", "<i4", (8, 17)), ("chroma2_run", "<i4", (8, 17)), ("rec_u2", "u1", (64,)), ("rec_v2", "u1", (64,)), ("yuv_format", "<i4"), ("qpc_v", "<i4"),
+                # B slices
+                ("mv1", "<i2", (16, 2)), ("ref_idx1", "i1", (16,)), ("b8bipred", "i1", (4,)), ("num_ref1", "<i4"), ("motion_cost1", "<i8", (8, 2, 4)), ("poc_l1", "<i4", (4,)),
+                ("direct_8x8_inference", "<i4"), ("pad_", "<i4")])
 
 
 def read(path):
@@ -138,13 +141,19 @@ def _record_dtype():
     return pyjmo.MB_RECORD
 
 
-def canonical(recs):
+def canonical(recs, bslice=False):
     """Normalise an array of macroblock records (oracle or device output): fields the bitstream writer and the loop filter never read for the
-    record's macroblock type are set to fixed values, coefficient arrays are masked by the coded block pattern."""
+    record's macroblock type are set to fixed values, coefficient arrays are masked by the coded block pattern.  bslice: the records of a B slice
+    (mb_type 0 = direct, list 1 / prediction directions kept); otherwise the B fields are zero."""
     out = np.array(recs, copy=True)
     for r in out:
         mbt, cbp = int(r["mb_type"]), int(r["cbp"])
         r["pad1"] = 0
+        r["pad2"] = 0
+        if not bslice:
+            r["mv1"], r["b8ref1"], r["b8pdir"], r["b8bipred"] = 0, 0, 0, 0
+        elif mbt >= 9:
+            r["mv1"], r["b8ref1"], r["b8pdir"], r["b8bipred"] = 0, -1, -1, 0
         luma, luma_dc, cdc, cac = visible_coeffs(r)
         r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = luma, luma_dc, cdc, cac
         if mbt >= 9:
@@ -167,7 +176,7 @@ def canonical(recs):
             r["ipredmode"] = 2
         if mbt != 8:
             r["b8mode"] = 11 if mbt == 9 else (13 if mbt == 13 else (0 if mbt in (0, 10) else mbt))
-        if mbt == 0:
+        if mbt == 0 and not bslice:
             r["b8ref"] = 0
         (cbp)
     return out
@@ -186,7 +195,14 @@ def tap_to_records(tap, cabac=0):
         r["b8ref"] = [int(t["ref_idx"][j * 8 + i * 2]) for j in range(2) for i in range(2)]
         r["ipredmode"], r["ipred_syntax"], r["mv"] = t["ipredmode"], t["ipred_syntax"], t["mv"]
         r["luma"], r["luma_dc"], r["chroma_dc"], r["chroma_ac"] = expected_coeffs(t, cabac)
-    return canonical(out)
+        if int(t["slice_type"]) == 1:
+            r["mv1"], r["b8pdir"], r["b8bipred"] = t["mv1"], t["b8pdir"], t["b8bipred"]
+            r["b8ref1"] = [int(t["ref_idx1"][j * 8 + i * 2]) for j in range(2) for i in range(2)]
+    bs = np.array([int(t["slice_type"]) == 1 for t in tap])
+    res = canonical(out)
+    if bs.any():
+        res[bs] = canonical(out[bs], bslice=True)
+    return res
 
 
 def widen(recs):

@@ -19,9 +19,9 @@ def slices_of(nmb, slice_mbs):
     return [(f, min(slice_mbs, nmb - f)) for f in range(0, nmb, slice_mbs)]
 
 
-def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_idc=0):
+def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_idc=0, ref_ids1=None):
     """records (nmb) + per-macroblock slice numbers -> (mbs (nmb, 12) in pyjmo.deblock_frame's order, motion (H/4, W/4, 2, 3)).
-    ref_ids[r] = picture identity of reference index r of this picture's list 0."""
+    ref_ids[r] = picture identity of reference index r of this picture's list 0 (ref_ids1: list 1, B slices)."""
     wmb = W // 16
     nmb = len(records)
     mbs = np.zeros((nmb, 12), np.int64)
@@ -38,6 +38,13 @@ def db_side_info(records, slice_nr, slice_type, qp, qpc, W, H, ref_ids, disable_
             for b8 in range(4):
                 rid = ref_ids[int(r["b8ref"][b8])]
                 mot[mby * 4 + (b8 >> 1) * 2:mby * 4 + (b8 >> 1) * 2 + 2, mbx * 4 + (b8 & 1) * 2:mbx * 4 + (b8 & 1) * 2 + 2, 0, 2] = rid
+            if slice_type == 1:                  # B: a list that a block does not use has reference index -1 (no picture), list 1 beside list 0
+                mot[mby * 4:mby * 4 + 4, mbx * 4:mbx * 4 + 4, 1, 0:2] = np.array(r["mv1"]).reshape(4, 4, 2)
+                for b8 in range(4):
+                    ys, xs = slice(mby * 4 + (b8 >> 1) * 2, mby * 4 + (b8 >> 1) * 2 + 2), slice(mbx * 4 + (b8 & 1) * 2, mbx * 4 + (b8 & 1) * 2 + 2)
+                    r0, r1 = int(r["b8ref"][b8]), int(r["b8ref1"][b8])
+                    mot[ys, xs, 0, 2] = ref_ids[r0] if r0 >= 0 else -1
+                    mot[ys, xs, 1, 2] = ref_ids1[r1] if r1 >= 0 else -1
     return mbs, mot
 
 
@@ -62,8 +69,41 @@ class SeqEncoder:
         self.npic = 0
         self.epzs_stats = []   # per P slice: (searches, alias_hits) of the oracle's EPZS
 
-    def encode(self, cur, debug=False):
-        """cur = (y, u, v) at the coded size.  Returns (records, debug records or None, reconstruction before the loop filter, after it)."""
+    def encode_b(self, cur, poc, l0_pocs, l1_pocs, lambdas_b, qp_b, b=None, debug=False, qpc_b=None, qpc_cr_delta_b=None, inter_valid_b=None):
+        """A non-reference B picture (slice type 1) with picture order count poc: its lists are the stored reference pictures with the given picture order counts (as the real
+        encoder ordered them), lambdas_b = (lambda_mf[3], lambda_mdfp) of B slices, qp_b = QPBSlice; b: the switches of pyjmo.encode_slice_b (bipred_me ...).
+        Nothing is stored: the next P picture refers to the reference pictures only."""
+        W, H = self.W, self.H
+        nmb = (W // 16) * (H // 16)
+        by_poc = {r[4]: r for r in self.refs}
+        L0, L1 = [by_poc[p] for p in l0_pocs], [by_poc[p] for p in l1_pocs]
+        pic = pyjmo.Picture(W, H, self.yuv_format)
+        recs = np.zeros(nmb, pyjmo.MB_RECORD)
+        dbg = np.zeros(nmb, pyjmo.MB_DEBUG) if debug else None
+        slice_nr = np.zeros(nmb, np.int32)
+        cur16 = [np.ascontiguousarray(p, np.uint16) for p in cur]
+        col = L1[0][5]                           # (mv0, ref_idx0, mv1, ref_idx1) of the stored picture
+        bb = dict(b or {}, col_ref=np.stack([col[1], col[3]], axis=-1), col_mv=np.stack([col[0], col[2]], axis=2))
+        qpc = None
+        for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
+            cfg = pyjmo.mbenc_cfg(W, H, 1, first, num, qp_b, self.R, len(L0), lambdas_b[0], lambdas_b[1], level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
+                                  yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=inter_valid_b, qpc=qpc_b, qpc_cr_delta=self.qpc_cr_delta_p if qpc_cr_delta_b is None else qpc_cr_delta_b)
+            qpc = cfg.qpc
+            res = pyjmo.encode_slice_b(cfg, bb, cur16, [r[0] for r in L0], [r[1] for r in L0], [r[0] for r in L1], [r[1] for r in L1], pic, debug=debug)
+            if debug:
+                recs[first:first + num], dbg[first:first + num] = res
+            else:
+                recs[first:first + num] = res
+            slice_nr[first:first + num] = sn
+        pre = [p.copy() for p in pic.rec]
+        mbs, mot = db_side_info(recs, slice_nr, 1, qp_b, (qpc, qpc + (self.qpc_cr_delta_p if qpc_cr_delta_b is None else qpc_cr_delta_b)), W, H, [r[2] for r in L0], self.disable_idc, [r[2] for r in L1])
+        y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], self.yuv_format, mbs, mot)
+        self.npic += 1
+        return recs, dbg, pre, (y, u, v)
+
+    def encode(self, cur, debug=False, poc=None):
+        """cur = (y, u, v) at the coded size.  Returns (records, debug records or None, reconstruction before the loop filter, after it).
+        poc: the picture's order count when the sequence has B pictures (default: 2 per coded picture)."""
         W, H = self.W, self.H
         nmb = (W // 16) * (H // 16)
         st = 2 if self.npic == 0 else 0
@@ -95,7 +135,7 @@ class SeqEncoder:
         refpoc = np.full(pic.ref_idx.shape, pyjmo.NO_REF, np.int32)     # the stored picture's motion, as EPZSSliceInit of later pictures reads it
         for k, r in enumerate(self.refs[:nref]):
             refpoc[pic.ref_idx == k] = 2 * r[2]
-        self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic, (pic.mv.copy(), refpoc)))
+        self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic, (pic.mv.copy(), refpoc), 2 * self.npic if poc is None else poc, (pic.mv.copy(), pic.ref_idx.copy(), pic.mv1.copy(), pic.ref_idx1.copy())))
         self.refs = self.refs[:self.num_ref]
         self.npic += 1
         return recs, dbg, pre, (y, u, v)

@@ -74,6 +74,62 @@ def source_frames(c, tag):
     return [pyjmo.load_frame(data[n * fs:(n + 1) * fs], c["sw"], c["sh"], c["W"], c["H"], yuv) for n in range(c["nfr"])]
 
 
+BSLICE_KEYS = ("BSliceDirect", "BSliceSearch16x16", "BSliceSearch16x8", "BSliceSearch8x16", "BSliceSearch8x8", "BSliceSearch8x4", "BSliceSearch4x8", "BSliceSearch4x4")
+
+
+def b_switches(ov, z):
+    """the B slices' switches of pyjmo.encode_slice_b from a case's overrides (defaults: the shipped .cfg files')"""
+    return dict(direct_8x8_inference=int(z["direct_8x8_inference"]), bipred_me=int(ov.get("BiPredMotionEstimation", 1)),
+                bipred_search=[int(ov.get(k, d)) for k, d in (("BiPredSearch16x16", 1), ("BiPredSearch16x8", 1), ("BiPredSearch8x16", 1), ("BiPredSearch8x8", 0))],
+                bipred_refinements=int(ov.get("BiPredMERefinements", 3)), bipred_range=int(ov.get("BiPredMESearchRange", 16)), bipred_subpel=int(ov.get("BiPredMESubPel", 2)))
+
+
+def run_case_b(tag, nmax=None):
+    """A sequence with B pictures (coding order I P B P B ...): the pictures in the order and with the reference lists the real encoder used (picture order counts in the golden)."""
+    c = load_case(tag)
+    z = c["z"]
+    ov = dict(s.split("=") for s in z["overrides"])
+    enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
+                                search_mode=c["search_mode"], epzs=c["epzs"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"],
+                                qpc=c["qpc"] if c["qp_p"] in (None, c["qp"]) or c["qpc_p"] is not None else None, qpc_cr_delta=c["qpc_cr_delta"], qp_p=c["qp_p"], qpc_p=c["qpc_p"], qpc_cr_delta_p=c["qpc_cr_delta_p"])
+    nmb = (c["W"] // 16) * (c["H"] // 16)
+    src = source_frames(c, tag)
+    lam_b = ([int(x) for x in z["lambda_b"][:3]], int(z["lambda_b"][3]))
+    bsw = b_switches(ov, z)
+    ivb = [int(ov.get(k, 1)) for k in BSLICE_KEYS] if any(k in ov for k in BSLICE_KEYS) else None
+    for n in range(len(z["slice_type"]) if nmax is None else nmax):
+        st, poc = int(z["slice_type"][n]), int(z["poc"][n])
+        cur = src[poc // 2]
+        if st == 1:
+            l0 = [int(p) for p in z["ref_poc"][n][:int(z["num_ref_pic"][n])]]
+            l1 = [int(p) for p in z["poc_l1"][n][:int(z["num_ref1_pic"][n])]]
+            recs, dbg, pre, post = enc.encode_b(cur, poc, l0, l1, lam_b, int(z["qp_b"]), bsw, debug=True, qpc_b=int(z["qpc_b"]), qpc_cr_delta_b=int(z["qpc_v_b"]) - int(z["qpc_b"]), inter_valid_b=ivb)
+        else:
+            recs, dbg, pre, post = enc.encode(cur, debug=True, poc=poc)
+        want = c["records"][n * nmb:(n + 1) * nmb]
+        got = mb_tap.canonical(recs, bslice=st == 1)
+        if st != 2 and z["motion_cost"].size:
+            mc = z["motion_cost"][n * nmb:(n + 1) * nmb]
+            badc = [k for k in range(nmb) if not np.array_equal(dbg["motion_cost"][k, 1:, :], mc[k])]
+            assert not badc, (tag, n, "motion costs, list 0", badc[:5], dbg["motion_cost"][badc[0], 1:, :].tolist(), mc[badc[0]].tolist())
+            if st == 1:
+                mc1 = z["motion_cost1"][n * nmb:(n + 1) * nmb]
+                badc = [k for k in range(nmb) if not np.array_equal(dbg["motion_cost1"][k, 1:, :], mc1[k])]
+                assert not badc, (tag, n, "motion costs, list 1", badc[:5], dbg["motion_cost1"][badc[0], 1:, :].tolist(), mc1[badc[0]].tolist())
+        bad = [k for k in range(nmb) if got[k].tobytes() != want[k].tobytes()]
+        assert not bad, (tag, n, st, len(bad), bad[:5], [(f, want[bad[0]][f].tolist(), got[bad[0]][f].tolist()) for f in mb_tap.diff_fields(want[bad[0]], got[bad[0]])][:6])
+        for p, m in zip(pre, z["md5_pre_deblock"][n]):
+            assert hashlib.md5(np.ascontiguousarray(p.astype(np.uint8)).tobytes()).hexdigest() == m, (tag, n, "reconstruction before the loop filter")
+    return enc
+
+
+# B pictures (jmo_mbenc_b.inc): spatial direct, LIST_0 / LIST_1 / BI_PRED per partition, the direct 8x8 sub-mode, with (q1b, m3b, m2b4, q5yb) and without (q1b0, m3b0) the bi-predictive
+# motion search; CAVLC / CABAC, 4x4 / 8x8 transform, full search / fast full search, slices, two list-1 references (m2b4), 4:2:2 with q_offset.cfg's B lists (q5yb)
+@pytest.mark.parametrize("tag", ["q1b0", "q1b", "m3b0", "m3b", "m2b4", "q5yb"])
+def test_oracle_b_pictures_equal_the_reference_encoder(tag):
+    run_case_b(tag)
+
+
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
@@ -191,7 +247,7 @@ def test_oracle_fast_full_search_1080p_full_size():
 
 
 def test_record_layout():
-    assert pyjmo.MB_RECORD.itemsize == 1216
+    assert pyjmo.MB_RECORD.itemsize == 1296
 
 
 def test_oracle_equals_the_tapped_encoder_on_random_configurations():
