@@ -572,17 +572,24 @@ typedef struct {
   int16_t  luma_dc[16];         /* Intra16x16 DC levels (cofDC[0]), scan order */
   int16_t  chroma_dc[2][8];     /* cofDC[1 + uv] at the levels' scan positions: four with 4:2:0, eight with 4:2:2 (SCAN_YUV422, block.c:88) */
   int16_t  chroma_ac[2][8][16]; /* levels at [1..15] of the plane's 4x4 blocks in raster order: 4:2:0 cofAC[4 + uv][k] (k < 4), 4:2:2 cofAC[4 + 2 uv + (k >> 2)][k & 3] (k < 8) */
-} jmhip_mb_record;              /* 1216 bytes */
+  /* B slices (slice_type 1; zero otherwise).  mb_type 0 is then B_Skip / Direct16x16 (Direct when cbp != 0), a sub-mode 0 of P8x8 a direct 8x8 block */
+  int16_t  mv1[16][2];          /* enc_picture->mv_info[..].mv[LIST_1], 4x4 raster */
+  int8_t   b8ref1[4];           /* ... .ref_idx[LIST_1] of each 8x8 block (-1: the block does not use list 1); b8ref is -1 where it does not use list 0 */
+  int8_t   b8pdir[4];           /* currMB->b8x8[k].pdir: 0 list 0, 1 list 1, 2 both (the average of the two predictions), -1 intra */
+  int8_t   b8bipred[4];         /* currMB->b8x8[k].bipred: 0, or 1 / 2 = the block's vectors are those of the bi-predictive search (currSlice->bipred_mv[bipred - 1]: write_motion_info
+                                   and the prediction take them from there) */
+  int8_t   reserved2_[4];
+} jmhip_mb_record;              /* 1296 bytes */
 
 typedef struct {
-  int32_t slice_type;           /* 0 P, 2 I */
+  int32_t slice_type;           /* 0 P, 1 B, 2 I */
   int32_t first_mb, num_mb;     /* macroblocks [first_mb, first_mb + num_mb) in raster order */
   int32_t slice_nr;             /* Macroblock.slice_nr (loop filter side information) */
   int32_t qp, qpc;              /* currMB->qp, currMB->qpc[0] (= qpc[1]) */
   int32_t search_range;         /* SearchRange (full-pel), <= the context's */
   int32_t num_ref;              /* currSlice->listXsize[LIST_0] */
-  int32_t ref_slot[JMHIP_MB_MAX_REF];  /* device slot of listX[LIST_0][r] */
-  int32_t ref_id[JMHIP_MB_MAX_REF];    /* identity of that picture for the loop filter's ref_pic comparison */
+  int32_t ref_slot[JMHIP_MB_MAX_REF];  /* device slot of listX[LIST_0][r]; B slices: listX[LIST_1][r] follows at [num_ref + r] (num_ref + num_ref1 <= 16) */
+  int32_t ref_id[JMHIP_MB_MAX_REF];    /* identity of that picture for the loop filter's ref_pic comparison (B slices: list 1 at [num_ref + r], as ref_slot) */
   int32_t lambda_mf[3];         /* p_Vid->lambda_mf[slice_type][qp][F_PEL, H_PEL, Q_PEL]: JM's double arithmetic, never recomputed */
   int32_t lambda_mdfp;          /* LAMBDA_FACTOR(p_Vid->lambda_md[slice_type][qp]) */
   int32_t max_mvd;              /* p_Vid->max_mvd (mv_search.c:327) */
@@ -604,12 +611,16 @@ typedef struct {
                                    the shipped settings: EPZS_integer_motion_estimation lencod/src/me_epzs_int.c:42, its sub-macroblock variant :437,
                                    EPZS_sub_pel_motion_estimation me_epzs_sub.c:30 (start_qp must be 1) */
   int32_t qpc_cr_delta;         /* currMB->qpc[1] - currMB->qpc[0]: not 0 when CrQPOffset != CbQPOffset (High profiles); q_chroma[1] / q_chroma_dc[1] are the Cr tables at that QP */
-  int32_t reserved_[1];
+  int32_t num_ref1;             /* B slices: currSlice->listXsize[LIST_1] (0 otherwise) */
   /* EPZS only (me_epzs_common.c:423 EPZSStructInit, :620 EPZSSliceInit); ignored with search_mode 0 */
   int32_t epzs_pattern, epzs_dual, epzs_fixed, epzs_aggressive, epzs_temporal, epzs_spatial_mem, epzs_blocktype;   /* EPZSPattern (0..5), EPZSDualRefinement (0..6),
                                    EPZSFixedPredictors (0..3), EPZSAggressiveWindow, EPZSTemporal, EPZSSpatialMem, EPZSBlockType */
   int32_t epzs_min_scale, epzs_med_scale, epzs_max_scale, epzs_sub_scale;   /* EPZSMinThresScale, EPZSMedThresScale, EPZSMaxThresScale, EPZSSubPelThresScale */
-  int32_t epzs_reserved_;
+  int32_t b_switches;           /* B slices: bit 0 active_sps->direct_8x8_inference_flag; bit 1 BiPredMotionEstimation, bits 2..4 BiPredSearch16x16 / 16x8 / 8x16 (BiPredSearch8x8
+                                   must be 0), bits 8..11 BiPredMERefinements, bits 16..23 BiPredMESearchRange, bits 24..25 BiPredMESubPel.  DirectModeType must be 1 (spatial),
+                                   WeightedBiprediction 0; the B picture is not used for reference.  Get_Direct_MV_Spatial_Normal lencod/src/mv_direct.c:522, the bslice branches of
+                                   encode_one_macroblock_low md_low.c:174-263 / :374-431, submacroblock_mode_decision_low mode_decision_P8x8.c:681, list_prediction_cost
+                                   mode_decision.c:275, BIDPartitionCost mv_search.c:1159, BiPredBlockMotionSearch :1033 */
   int32_t poc_cur;              /* enc_picture->poc */
   int32_t poc_ref[JMHIP_MB_MAX_REF];   /* listX[LIST_0][r]->poc: EPZS scales its predictors by picture distances; the temporal predictors are the vectors
                                    jmhip_reference_from_recon kept with slots ref_slot[0] / [1] (a slot loaded by jmhip_set_reference has none: zero vectors).  Every picture of

@@ -33,7 +33,7 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-// The six kernel instances are compiled as separate translation units (jm_amd/build.py: -DMBPIPE_PART=0..3, 5, 6, a kernel each; part 4 = the host side, which
+// The eight kernel instances are compiled as separate translation units (jm_amd/build.py: -DMBPIPE_PART=0..3, 5..8, a kernel each; part 4 = the host side, which
 // only declares them): one hipcc process per kernel instead of one for all -- minutes of build time, nothing else.  Without the macro: one unit.
 #ifndef MBPIPE_PART
 #define MBPIPE_PART -1
@@ -42,10 +42,12 @@ typedef uint8_t u8;
 
 #define MB_THREADS 512
 #define MAXC 0x7fffffff
-#define EDGE_WORDS 19                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
+#define EDGE_WORDS 27                       // u64 per macroblock edge record: 0-1 bottom luma row, 2-3 right luma column, 4/5 bottom U/V rows,
                                             // 6/7 right U/V columns, 8 ipredmode (bytes 0-3 bottom row, 4-7 right column), 9-12 / 13-16 mv_info of the
-                                            // bottom row / right column {packed vector, reference index}; 4:2:2: 17/18 rows 8..15 of the right U/V columns
+                                            // bottom row / right column {packed vector, reference index}; 4:2:2: 17/18 rows 8..15 of the right U/V columns;
+                                            // B slices: 19-22 / 23-26 the same mv_info of LIST_1
 #define EDGE_MV_END 17                      // words 9 .. 16 are the tagged vectors
+#define EDGE_MV1 19                         // ... and 19 .. 26 those of list 1
 #define SPIN_LIMIT (1u << 26)
 #define JMHIP_SEQ_MAX_FLIGHT 8              // references of a picture that may still be in the making when its launch starts (the most recent ones)
 
@@ -67,7 +69,7 @@ __device__ __forceinline__ int mvy(int p) { return p >> 16; }
 __device__ __forceinline__ int mvpack(int x, int y) { return (x & 0xffff) | (y << 16); }
 __device__ __forceinline__ int median3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
-static_assert(sizeof(jmhip_mb_record) == 1216 && sizeof(jmhip_slice_params) == 3200, "record sizes of include/jmhip.h");
+static_assert(sizeof(jmhip_mb_record) == 1296 && sizeof(jmhip_slice_params) == 3200, "record sizes of include/jmhip.h");
 
 // What one PICTURE of a launch is made of.  A launch of one picture (jmhip_encode_slice*, jmhip_seq_encode) carries it in its arguments (PipeArgs::v); a launch of several
 // consecutive pictures (jmhip_seq_batch) reads picture k's from PipeArgs::pics[k] when a workgroup draws a ticket of that picture.  Either way the workgroup works on its
@@ -94,6 +96,9 @@ struct PicView {
   u64 *mot_out;                              // EPZS: per 4x4 block of the picture {packed vector, poc of the picture referred to}: later pictures' temporal predictors
   const u64 *mot_ref[2];                     // EPZS in flight: the motion kept with the slots of references 0 / 1, read where k_epzs_coloc's whole-picture pass would have put the
                                              // co-located vectors (the reference may still be in the making); null: no temporal predictors
+  u8 *colz_out;                              // P / I pictures: per 4x4 block 1 where a B picture's spatial direct mode finds "the co-located block does not move" in this picture
+                                             // (get_colocated_info mv_direct.c:428: ref_idx[LIST_0] == 0 and a vector within +-1), else 0
+  const u8 *colz;                            // B pictures: that map of listX[LIST_1][0]
   u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
   u32 post_tag, war_tag, prev_tag, pad_;
   unsigned epoch;
@@ -127,6 +132,9 @@ struct PipeArgs {
   int fused;
   int direct8x8;                             // active_sps->direct_8x8_inference_flag (DeblockMb's skip rule for B_Skip: never met in P / I pictures)
   int reach_x, reach_y;                      // macroblock (X, r) reads reference samples that macroblocks up to (X + reach_x, r + reach_y) of the reference produce
+  unsigned char win_of[JMHIP_MB_MAX_REF];    // B slices: which LDS window holds reference r of the combined list (list 0, then list 1: the same picture may be in both)
+  int nwin;                                  // ... and how many windows there are; window w is loaded from reference win_src[w]
+  unsigned char win_src[JMHIP_MB_MAX_REF];
   int npics;                                 // > 0: a launch of several consecutive pictures (jmhip_seq_batch): pics[0 .. npics), tickets ordered by wavefront index + lag x picture
   const PicView *pics;
   PicView v;                                 // the picture of a one-picture launch
@@ -204,6 +212,17 @@ struct Shared {
   int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
   u64 fl_cbp_blk, fc_bits;
   u32 fin_cbp_blk;
+  // B slices (mbpipe_b.inc).  References are numbered through both lists: list 0's first, then list 1's (S.allmv, the windows, PicView::ref_y).
+  int mvi1[8][16][2];                        // per wave: mv_info of LIST_1 as that wave's chain sees it
+  int bpmv[2][2][4][16];                     // currSlice->bipred_mv[set][list][0][mode 1..3][4x4 raster]
+  int dmv[2][16], d_ref[2], d_pdir;          // the spatial direct mode: vectors per list and 4x4 block, direct_ref_idx and direct_pdir (alike for the whole macroblock)
+  int d_cost4[4], d_cost8[4];                // GetDirectCost8x8 of the four 8x8 blocks (4x4 Hadamards; 8x8 Hadamard)
+  int dflag;                                 // the direct vectors and costs are there (running count over the launch)
+  int m_info[4][4];                          // modes 1..3: b8x8info->best[mode][block] packed (binfo_pack)
+  int p8b_cost[4][5], p8b_info[4][5];        // [block][0 direct, 1..4 modes 4..7]
+  int p8_info[4], p8t_info[4];               // the parts the tr4x4 / tr8x8 pass of P8x8 decided
+  int fin_mv1[16], fin_ref1[16];             // the macroblock's final LIST_1 vectors and reference indices
+  u8 bpred[8][256];                          // per wave: a prediction being priced
   jmhip_mb_record out;
   PostShared post;
   PicView V;                                 // the picture the workgroup's current macroblock belongs to
@@ -266,17 +285,18 @@ __device__ __forceinline__ void st_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v,
 // Inside the macroblock: this chain's view (two ints); outside: the neighbour's edge record (words 9..12 bottom row, 13..16 right column: the vector
 // in the low half, the reference index in byte 4).  Both read as one 64-bit word: mv = low half, ref = sign-extended byte 4.
 // avm: bit n = neighbour n (A left, B up, C up-right, D up-left) is inside the picture and the slice.
-__device__ __forceinline__ const u64 *mvinfo_ptr(const Shared &S, int view, int avm, int x4, int y4, bool &ok)
+__device__ __forceinline__ const u64 *mvinfo_ptr(const Shared &S, int view, int avm, int x4, int y4, bool &ok, int list = 0)
 {
+  const int e0 = list ? EDGE_MV1 : 9;
   if (x4 < 0) {
-    if (y4 < 0) { ok = (avm >> 3) & 1; return &S.nb[3][9 + 3]; }
-    ok = y4 < 4 && (avm & 1); return &S.nb[0][13 + (y4 & 3)];
+    if (y4 < 0) { ok = (avm >> 3) & 1; return &S.nb[3][e0 + 3]; }
+    ok = y4 < 4 && (avm & 1); return &S.nb[0][e0 + 4 + (y4 & 3)];
   }
   if (x4 < 4) {
-    if (y4 < 0) { ok = (avm >> 1) & 1; return &S.nb[1][9 + x4]; }
-    ok = y4 < 4; return (const u64 *)&S.mvi[view][(y4 & 3) * 4 + x4][0];
+    if (y4 < 0) { ok = (avm >> 1) & 1; return &S.nb[1][e0 + x4]; }
+    ok = y4 < 4; return (const u64 *)&(list ? S.mvi1 : S.mvi)[view][(y4 & 3) * 4 + x4][0];
   }
-  ok = y4 < 0 && ((avm >> 2) & 1); return &S.nb[2][9 + 0];
+  ok = y4 < 0 && ((avm >> 2) & 1); return &S.nb[2][e0 + 0];
 }
 __device__ __forceinline__ void mvinfo_get(const u64 *p, bool ok, int &mv, int &ref)
 {
@@ -309,7 +329,7 @@ __device__ __forceinline__ u32 ptab_entry(int bt, int mb_x, int mb_y)
 
 // get_neighbors (mv_search.c:268-307) + GetMotionVectorPredictorNormal (lcommon/src/mv_prediction.c:194-325): one table read, then the four
 // candidates with one LDS read (a lane each)
-__device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, int ref, int mb_x, int mb_y, int bsx, int bsy, int lane)
+__device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, int ref, int mb_x, int mb_y, int bsx, int bsy, int lane, int list = 0)
 {
   const int bt = bsx == 16 ? (bsy == 16 ? 1 : 2) : (bsx == 8 ? (bsy == 16 ? 3 : (bsy == 8 ? 4 : 5)) : (bsy == 8 ? 6 : 7));
   const u32 codes = S.ptab[bt][(mb_y >> 2) * 4 + (mb_x >> 2)];
@@ -317,7 +337,7 @@ __device__ __forceinline__ int mv_predictor(const Shared &S, int view, int avm, 
   const bool inside = c < 16u;
   const int n = (int)(c - 16u) >> 3;
   const bool ok = c != 255u && (inside || ((avm >> n) & 1));
-  const u64 *p = inside ? (const u64 *)&S.mvi[view][c][0] : &S.nb[n & 3][9 + ((c - 16u) & 7u)];
+  const u64 *p = inside ? (const u64 *)&(list ? S.mvi1 : S.mvi)[view][c][0] : &S.nb[n & 3][(list ? EDGE_MV1 : 9) + ((c - 16u) & 7u)];
   const u64 w = *p;
   const int mvl = ok ? (int)(u32)w : 0, rfl_ = ok ? (int)(int8_t)(w >> 32) : -1;
   const u32 okm = (u32)__ballot(ok) & 15u;
@@ -795,9 +815,14 @@ __device__ __forceinline__ int scan9(const Shared &S, int wave, int lane, int mv
 // BlockMotionSearch (mv_search.c:857-1024) of one (block, reference) by one wave; RDOptimization = 0, SearchMode = -1.
 // view: which chain's picture of the macroblock's vectors the predictor reads; wave: this wave's own scratch (row table, SATD sums).
 template <bool T8>
-__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int mbx, int mby, int &out_mv)
+__device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const u8 *wins, int view, int wave, int avm, int lane, int ref, int bt, int mb_x, int mb_y, int mbx, int mby, int &out_mv,
+                                            int list = 0, int cr = -1, int widx = -1, int *pred_out = nullptr)
 {
+  // B slices: `ref` is the index within `list` (the predictor compares it with the neighbours' reference indices of that list); cr = the reference's number through both
+  // lists (planes, vectors), widx = its window in LDS.  P slices: list 0, cr = widx = ref.
   const jmhip_slice_params &P = A.p;
+  if (cr < 0) cr = ref;
+  if (widx < 0) widx = ref;
   const int BW = bt == 1 || bt == 2 ? 16 : (bt == 3 || bt == 4 || bt == 5 ? 8 : 4);
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = mby * A.wmb + mbx, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;     // (the macroblock's position comes from the caller: a division per search otherwise)
@@ -806,7 +831,8 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
                      mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
 #define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
-  const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH, lane));
+  const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH, lane, list));
+  if (pred_out) *pred_out = pred;
   BS_STAMP(19);
   int cx = ((mvx(pred) + 2) >> 2) * 4, cy = ((mvy(pred) + 2) >> 2) * 4;          // mv_search.c:931-932
   int min_x = -(R << 2), max_x = R << 2, min_y = min_x, max_y = max_x;
@@ -831,19 +857,19 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   FsCost c;
   c.lambda = P.lambda_mf[0]; c.cqx = cx; c.cqy = cy; c.pqx = mvx(pred); c.pqy = mvy(pred);
   c.Rs = min(max(min(max_x, max_y) >> 2, 0), R); c.R = R;
-  c.check00 = bt == 1 && ref == 0;
+  c.check00 = bt == 1 && ref == 0 && P.slice_type != 1;         // me_fullsearch.c:78: not in B slices
   const bool ffs = P.search_mode == 1;
   if (ffs) {
     // fast_full_search_motion_estimation (me_fullfast.c:618-689, rdopt == 0): every block of the macroblock is searched around ONE centre per reference, the
     // rounded 16x16 predictor (setup_fast_full_search :310-328; its neighbours lie outside the macroblock, so any chain's view gives it), over
     // imax(max_x, max_y) >> 2 rings (:633); the (0,0) vector is tried first (below); the max_mvd guard (:638, :671) cannot fire (checked by the host)
-    const int p16 = rfl(mv_predictor(S, view, avm, ref, 0, 0, 16, 16, lane));
+    const int p16 = rfl(mv_predictor(S, view, avm, ref, 0, 0, 16, 16, lane, list));
     cx = clampi3(-(R << 2), R << 2, ((mvx(p16) + 2) >> 2) * 4); cy = clampi3(-(R << 2), R << 2, ((mvy(p16) + 2) >> 2) * 4);
     cx = clampi3(P.mv_limit[0] + (R << 2), P.mv_limit[1] - (R << 2), cx); cy = clampi3(P.mv_limit[2] + (R << 2), P.mv_limit[3] - (R << 2), cy);
     c.cqx = cx; c.cqy = cy; c.Rs = min(max(max(max_x, max_y) >> 2, 0), R); c.check00 = 0;
   }
   c.count = A.prof != nullptr && A.prof_mode == 11;
-  const u8 *win = wins + (size_t)ref * A.win_h * A.win_p;
+  const u8 *win = wins + (size_t)widx * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
   const int i_lo = 0, i_hi = 2 * c.Rs;
@@ -856,7 +882,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   auto spec4 = [&](int mvg) {
     if (!P.subpel) return;
     spec_mv = mvg;
-    ref_rows4(A, ref, (px << 2) + mvx(mvg) + g_ox, (py << 2) + mvy(mvg) + g_oy, sr);
+    ref_rows4(A, cr, (px << 2) + mvx(mvg) + g_ox, (py << 2) + mvy(mvg) + g_oy, sr);
     __builtin_amdgcn_sched_barrier(0);
   };
   switch (bt) {
@@ -884,27 +910,27 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   }
 
   if (P.subpel) {                                             // sub_pel_motion_estimation me_fullsearch.c:186-289 (start_me_refinement_hp = 0)
-    const int check0 = ref == 0 && bt == 1 && mv == 0;
+    const int check0 = ref == 0 && bt == 1 && mv == 0 && P.slice_type != 1;
     const bool grid = bt == 7;
     const int mv0 = mv;
     const bool had8 = T8 && bt <= 4;                           // mv_block.test8x8 (mv_search.c:1624, :1768): 8x8 Hadamard sub-blocks in computeSATD
     auto sx9 = [](int k) { return sp9x(k); };
     auto sy9 = [](int k) { return sp9y(k); };
     if (grid) {                                               // subpel_grid49 with the rows fetched ahead, if the guess held
-      if (mv != spec_mv) ref_rows4(A, ref, (px << 2) + mvx(mv) + g_ox, (py << 2) + mvy(mv) + g_oy, sr);
+      if (mv != spec_mv) ref_rows4(A, cr, (px << 2) + mvx(mv) + g_ox, (py << 2) + mvy(mv) + g_oy, sr);
       u32 o[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) o[j] = S.cur_y[(mb_y + j) * 4 + (mb_x >> 2)];
       if (lane < 49) S.red[wave][lane] = satd4_rows(o, sr);
       wave_sync();
     }
-    else if (had8) subpel_satds8(S, A, S.red[wave], lane, ref, px, py, mb_x, mb_y, BW / 8, BH / 8, mv, 2, sx9, sy9);
-    else subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
+    else if (had8) subpel_satds8(S, A, S.red[wave], lane, cr, px, py, mb_x, mb_y, BW / 8, BH / 8, mv, 2, sx9, sy9);
+    else subpel_satds(S, A, wave, lane, cr, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 2);
     int best = scan9(S, wave, lane, mv, 2, P.lambda_mf[1], c.pqx, c.pqy, check0 ? P.lambda_mf[1] * 16 : 0, 0, 0, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + 2 * sp9x(best), mvy(mv) + 2 * sp9y(best));
     BS_STAMP(21);
-    if (had8) subpel_satds8(S, A, S.red[wave], lane, ref, px, py, mb_x, mb_y, BW / 8, BH / 8, mv, 1, sx9, sy9);
-    else if (!grid) subpel_satds(S, A, wave, lane, ref, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
+    if (had8) subpel_satds8(S, A, S.red[wave], lane, cr, px, py, mb_x, mb_y, BW / 8, BH / 8, mv, 1, sx9, sy9);
+    else if (!grid) subpel_satds(S, A, wave, lane, cr, px, py, mb_x, mb_y, BW / 4, BH / 4, mv, 1);
     best = scan9(S, wave, lane, mv, 1, P.lambda_mf[2], c.pqx, c.pqy, 0, min_mcost, P.start_qp, min_mcost, grid, mv0);
     mv = mvpack(mvx(mv) + sp9x(best), mvy(mv) + sp9y(best));
   }

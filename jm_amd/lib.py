@@ -80,7 +80,8 @@ MB_MAX_REF = 16
 MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1"), ("transform8x8", "i1"), ("cbp", "<i2"), ("reserved1_", "<i2"),
                       ("cbp_blk", "<u8"), ("min_rdcost", "<i8"), ("b8mode", "i1", (4,)), ("b8ref", "i1", (4,)), ("ipredmode", "i1", (16,)),
                       ("ipred_syntax", "i1", (16,)), ("mv", "<i2", (16, 2)), ("luma", "<i2", (16, 16)), ("luma_dc", "<i2", (16,)),
-                      ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16))])
+                      ("chroma_dc", "<i2", (2, 8)), ("chroma_ac", "<i2", (2, 8, 16)),
+                      ("mv1", "<i2", (16, 2)), ("b8ref1", "i1", (4,)), ("b8pdir", "i1", (4,)), ("b8bipred", "i1", (4,)), ("reserved2_", "i1", (4,))])      # B slices
 FRAME_FORMAT = np.dtype([("yuv_format", "<i4"), ("src_w", "<i4"), ("src_h", "<i4"), ("out_w", "<i4"), ("out_h", "<i4"), ("coded_w", "<i4"), ("coded_h", "<i4"),
                          ("symbol_bytes", "<i4"), ("src_depth", "<i4", (3,)), ("out_depth", "<i4", (3,))])
 # jmhip_seq_picture (include/jmhip.h): 8-byte pointers, the record pointer aligned behind 35 ints
@@ -92,12 +93,12 @@ SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", 
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
                          ("inter_valid", "<i4", (8,)), ("intra4_valid", "<i4"), ("intra16_valid", "<i4"), ("subpel", "<i4"), ("start_qp", "<i4"),
                          ("refbits", "<i4", (MB_MAX_REF,)), ("q_luma", "<i4", (2, 16, 3)), ("q_chroma", "<i4", (2, 2, 16, 3)),
-                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("num_slices", "<i4"), ("symbol_mode", "<i4"), ("search_mode", "<i4"), ("qpc_cr_delta", "<i4"), ("reserved_", "<i4", (1,)),
+                         ("df_disable_idc", "<i4"), ("df_alpha_c0", "<i4"), ("df_beta", "<i4"), ("num_slices", "<i4"), ("symbol_mode", "<i4"), ("search_mode", "<i4"), ("qpc_cr_delta", "<i4"), ("num_ref1", "<i4"),
                          ("epzs_pattern", "<i4"), ("epzs_dual", "<i4"), ("epzs_fixed", "<i4"), ("epzs_aggressive", "<i4"), ("epzs_temporal", "<i4"), ("epzs_spatial_mem", "<i4"),
-                         ("epzs_blocktype", "<i4"), ("epzs_min_scale", "<i4"), ("epzs_med_scale", "<i4"), ("epzs_max_scale", "<i4"), ("epzs_sub_scale", "<i4"), ("epzs_reserved_", "<i4"),
+                         ("epzs_blocktype", "<i4"), ("epzs_min_scale", "<i4"), ("epzs_med_scale", "<i4"), ("epzs_max_scale", "<i4"), ("epzs_sub_scale", "<i4"), ("b_switches", "<i4"),
                          ("poc_cur", "<i4"), ("poc_ref", "<i4", (MB_MAX_REF,)),
                          ("transform8x8", "<i4"), ("intra8_valid", "<i4"), ("q_luma8", "<i4", (2, 64, 3)), ("q_chroma_dc", "<i4", (2, 2, 3))])
-assert MB_RECORD.itemsize == 1216 and SLICE_PARAMS.itemsize == 3200
+assert MB_RECORD.itemsize == 1296 and SLICE_PARAMS.itemsize == 3200
 assert ME_JOB.itemsize == 192 and ME_RESULT.itemsize == 328 and SUBPEL_JOB.itemsize == 36 and TQ_OUT.itemsize == 104
 assert TQ_PARAMS.itemsize == 224 and DB_MB.itemsize == 28 and DB_MOTION.itemsize == 16 and CAND.itemsize == 16 and PRED_CAND.itemsize == 32
 
