@@ -135,3 +135,11 @@ def raw_frames(c, tag):
 @pytest.mark.parametrize("tag", ["q1b0", "m3b0"])
 def test_b_pictures_equal_the_reference_encoder(tag):
     run_case_b(tag)
+
+
+# with the bi-predictive motion search as the shipped files have it (BiPredMotionEstimation 1: BiPredBlockMotionSearch mv_search.c:1033, BI_PRED_L0 / _L1 in the decision):
+# encoder_main.cfg with RDO off (q1b: fast full search SR 32, CABAC), High profile on a clip with motion (m3b: 8x8 transform), one refinement / range 8 / one sub-pel level,
+# CAVLC, two list-1 references (m2b4), encoder_yuv422.cfg with its B picture (q5yb: 4:2:2, q_offset.cfg's B lists)
+@pytest.mark.parametrize("tag", ["q1b", "m3b", "m2b4", "q5yb"])
+def test_b_pictures_with_the_bipredictive_search_equal_the_reference_encoder(tag):
+    run_case_b(tag)
