@@ -1407,7 +1407,13 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->Intra4x4ParDisable || p->Intra4x4DiagDisable || p->Intra4x4DirDisable || p->Intra16x16ParDisable || p->Intra16x16PlaneDisable || p->ChromaIntraDisable) why = "intra mode restrictions";
     else if (!p->FastCrIntraDecision) why = "FastCrIntraDecision = 0";
     else if (p->SkipIntraInInterSlices || p->SelectiveIntraEnable || p->RandomIntraMBRefresh || p->intra_upd || p->CtxAdptLagrangeMult) why = "intra refresh / selective intra / CtxAdptLagrangeMult";
-    else if (p->NumberBFrames != 0 || p->sp_periodicity != 0) why = "B or SP pictures";
+    else if (p->sp_periodicity != 0) why = "SP pictures";
+    /* B pictures (mbpipe_b.inc): non-reference B pictures between the P pictures, spatial direct mode, the lists as init_lists leaves them */
+    else if (p->NumberBFrames != 0 && (!p->direct_spatial_mv_pred_flag || p->BRefPictures || p->LowDelay || p->ExplicitSeqCoding || p->EnableOpenGOP))
+      why = "B pictures with DirectModeType 0 (temporal), BReferencePictures, LowDelay, ExplicitSeqCoding or EnableOpenGOP";
+    else if (p->NumberBFrames != 0 && p->SearchMode[0] == EPZS) why = "B pictures with EPZS";
+    else if (p->NumberBFrames != 0 && p->BiPredMotionEstimation && (p->BiPredSearch[3] || p->BiPredMESearchRange[0] < 1 || p->BiPredMESearchRange[0] > 32 || p->BiPredMESubPel > 2 || p->BiPredMERefinements > 15))
+      why = "BiPredMotionEstimation with BiPredSearch8x8, or a search range / sub-pel level / refinement count outside the device's";
     else if (p->full_search != 2) why = "RestrictSearchRange != 2";
     else if (p->num_of_views != 1 || p->separate_colour_plane_flag) why = "MVC / separate colour planes";
     else if (!p->InterSearch[0][0][0]) why = "PSliceSkip = 0";
@@ -1587,6 +1593,17 @@ static void pipe_run_slice(Macroblock *currMB)
     if (prm.ref_slot[r] < 0) { fprintf(stderr, "jmhip adapter: pictures in flight: reference %d of picture %ld is not a picture the device holds\n", r, F.pic); exit(70); }
     prm.ref_id[r] = prm.ref_slot[r];
   }
+  if (currSlice->slice_type == B_SLICE) {                     /* list 1 behind list 0; the switches of the B slices' decision (include/jmhip.h: b_switches) */
+    prm.num_ref1 = currSlice->listXsize[LIST_1];
+    for (r = 0; r < prm.num_ref1; r++) {
+      prm.ref_slot[prm.num_ref + r] = slot_with_chroma(currSlice->listX[LIST_1][r]);
+      prm.ref_id[prm.num_ref + r] = prm.ref_slot[prm.num_ref + r];
+    }
+    prm.b_switches = (p_Vid->active_sps->direct_8x8_inference_flag ? 1 : 0);
+    if (p_Inp->BiPredMotionEstimation)
+      prm.b_switches |= 2 | (p_Inp->BiPredSearch[0] ? 4 : 0) | (p_Inp->BiPredSearch[1] ? 8 : 0) | (p_Inp->BiPredSearch[2] ? 16 : 0) | ((p_Inp->BiPredMERefinements & 15) << 8) |
+                        ((p_Inp->BiPredMESearchRange[0] & 255) << 16) | ((p_Inp->BiPredMESubPel & 3) << 24);
+  }
   for (m = 0; m < 3; m++) prm.lambda_mf[m] = enc_mb.lambda_mf[m];
   prm.lambda_mdfp = enc_mb.lambda_mdfp;
   prm.max_mvd = p_Vid->max_mvd;
@@ -1675,7 +1692,7 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
   const int mbt = r->mb_type, intra = mbt >= I4MB;
   int k, j, i, uv;
   currMB->mb_type = (short)mbt;
-  currMB->best_mode = (short)(mbt == 0 ? 1 : mbt);
+  currMB->best_mode = (short)((mbt == 0 && currSlice->slice_type != B_SLICE) ? 1 : mbt);
   currMB->ar_mode = currMB->best_mode;
   currMB->cbp = r->cbp; currMB->cbp_blk = (int64)r->cbp_blk;
   currMB->luma_transform_size_8x8_flag = (byte)(r->transform8x8 != 0);
@@ -1686,6 +1703,7 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
   for (k = 0; k < 4; k++) {
     currMB->b8x8[k].mode = r->b8mode[k]; currMB->b8x8[k].pdir = (char)(intra ? -1 : 0);
     currMB->b8x8[k].ref[LIST_0] = r->b8ref[k]; currMB->b8x8[k].ref[LIST_1] = -1; currMB->b8x8[k].bipred = 0;
+    if (currSlice->slice_type == B_SLICE) { currMB->b8x8[k].pdir = r->b8pdir[k]; currMB->b8x8[k].ref[LIST_1] = r->b8ref1[k]; currMB->b8x8[k].bipred = r->b8bipred[k]; }
   }
   memcpy(currMB->intra_pred_modes, r->ipred_syntax, 16);
   if (mbt == I8MB) memcpy(currMB->intra_pred_modes8x8, r->ipred_syntax, 16);       /* writeIntra8x8Modes (macroblock.c:1817) reads these, at [4 * b8] */
@@ -1697,6 +1715,11 @@ static void mb_from_record(Macroblock *currMB, const jmhip_mb_record *r)
       mp->mv[LIST_0].mv_x = r->mv[j * 4 + i][0]; mp->mv[LIST_0].mv_y = r->mv[j * 4 + i][1];
       mp->ref_idx[LIST_0] = (char)ref; mp->ref_pic[LIST_0] = ref < 0 ? NULL : currSlice->listX[LIST_0][ref];
       mp->mv[LIST_1].mv_x = mp->mv[LIST_1].mv_y = 0; mp->ref_idx[LIST_1] = -1; mp->ref_pic[LIST_1] = NULL;
+      if (currSlice->slice_type == B_SLICE) {
+        const int ref1 = intra ? -1 : r->b8ref1[(j >> 1) * 2 + (i >> 1)];
+        mp->mv[LIST_1].mv_x = r->mv1[j * 4 + i][0]; mp->mv[LIST_1].mv_y = r->mv1[j * 4 + i][1];
+        mp->ref_idx[LIST_1] = (char)ref1; mp->ref_pic[LIST_1] = ref1 < 0 ? NULL : currSlice->listX[LIST_1][ref1];
+      }
     }
   if (r->transform8x8 && mbt != I4MB && mbt != I16MB) {
     /* an 8x8 transform block: the record holds its 64 levels in zig-zag order; JM's writers read one 64-entry list (CABAC, residual_transform_quant_luma_8x8
@@ -1733,7 +1756,8 @@ void __wrap_encode_one_macroblock_low(Macroblock *currMB)
   Slice *currSlice = currMB->p_Slice;
   VideoParameters *p_Vid = currMB->p_Vid;
   double t0;
-  if (!adapter_on(p_Vid) || !pipe_config_ok(p_Vid) || (currSlice->slice_type != P_SLICE && currSlice->slice_type != I_SLICE) ||
+  if (!adapter_on(p_Vid) || !pipe_config_ok(p_Vid) || (currSlice->slice_type != P_SLICE && currSlice->slice_type != I_SLICE && currSlice->slice_type != B_SLICE) ||
+      (currSlice->slice_type == B_SLICE && (p_Vid->nal_reference_idc != 0 || currSlice->listXsize[LIST_0] + currSlice->listXsize[LIST_1] > JMHIP_MB_MAX_REF || p_Vid->active_pps->weighted_bipred_idc != 0)) ||
       currSlice->mb_aff_frame_flag || p_Vid->structure != FRAME) {
     if (P.n_slices) { fprintf(stderr, "jmhip adapter: macroblock pipeline: a slice outside its scope after %ld slices on the device\n", P.n_slices); exit(70); }
     G.n_passed++;
@@ -1792,6 +1816,7 @@ static int pipe_reference(StorablePicture *s)
   int k, rc;
   double t0 = now_s();
   if (!P.ok || P.pic != s || !P.deblocked) return 0;
+  if (!s->used_for_reference) return 1;                      /* a B picture: nobody predicts from it, it takes no slot and gets no planes */
   if (F.on) { G.n_interp++; return 1; }                     /* the planes are in the picture's slot already (flight_launch registered it) */
   k = slot_take(s);
   if (G.nctx > 1) { int c; for (c = 1; c < G.nctx; c++) if ((rc = jmhip_reference_from_recon(G.ctxs[c], k))) adapter_die("jmhip_reference_from_recon (dealt)", rc); }

@@ -143,3 +143,9 @@ def test_b_pictures_equal_the_reference_encoder(tag):
 @pytest.mark.parametrize("tag", ["q1b", "m3b", "m2b4", "q5yb"])
 def test_b_pictures_with_the_bipredictive_search_equal_the_reference_encoder(tag):
     run_case_b(tag)
+
+
+def test_b_picture_1080p_equals_the_reference_encoder():
+    """encoder_main.cfg's search and B settings at 1080p (fast full search SR 32, CABAC, the bi-predictive search), RDO off: I P B of the synthetic clip (g3b: 24 480 macroblocks
+    of the real encoder); the filtered pictures are not compared with the oracle here (minutes of CPU: tests/test_oracle_mbenc.py does that under JMO_LONG)"""
+    run_case_b("g3b", check_oracle_post=False)

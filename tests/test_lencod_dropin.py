@@ -170,7 +170,9 @@ def frame_times(stdout):
                                            ("m2pd", 396), ("m3pe", 300), ("q1pd", 297),                               # partitions switched off (PSliceSearch*)
                                            ("m2cq", 396), ("m2yc", 396),                                               # CbQPOffset != CrQPOffset
                                            ("m3fl", 175), ("m3fm", 175), ("m2sl", 192), ("m2el", 192),                               # level 1.1
-                                           ("m2es", 396), ("m5es", 192)])                                              # EPZS at SearchRange 2
+                                           ("m2es", 396), ("m5es", 192),                                               # EPZS at SearchRange 2
+                                           # B pictures (NumberBFrames 1; encoder_main.cfg / encoder_yuv422.cfg with RDO off: q1b, q5yb), without (*b0) and with the bi-predictive search
+                                           ("q1b0", 297), ("q1b", 297), ("m3b0", 910), ("m3b", 910), ("m2b4", 495), ("q5yb", 297)])
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction

@@ -130,6 +130,12 @@ def test_oracle_b_pictures_equal_the_reference_encoder(tag):
     run_case_b(tag)
 
 
+@pytest.mark.skipif(os.environ.get("JMO_LONG") != "1", reason="minutes of oracle searches: set JMO_LONG=1 (q1b pins the same configuration at QCIF)")
+def test_oracle_b_picture_1080p_full_size():
+    """encoder_main.cfg's search and B settings at 1080p, RDO off: I P B of the synthetic clip (g3b)"""
+    run_case_b("g3b")
+
+
 def run_case(tag):
     c = load_case(tag)
     enc = mbenc_util.SeqEncoder(c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"], cabac=c.get("cabac", 0),
