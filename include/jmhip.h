@@ -660,7 +660,9 @@ int jmhip_deblock_side_info_dev(jmhip_ctx *ctx, jmhip_db_mb **d_mbs, jmhip_db_mo
 /* One picture's slices dealt to several devices (SURVEY.md 8e / 8b viii: JM shards a picture only by slice, lencod/src/slice.c:431; BASELINE configs[3]): one process, n
  * contexts of the same picture size -- one per device (or several on one) --, context r has coded the slices that make up macroblock rows [r * band_mb_rows,
  * (r + 1) * band_mb_rows) of the current picture (jmhip_encode_slice[_dev / _begin]; the last band may be shorter).  The call gives EVERY context every band: the rows of
- * the un-deblocked reconstruction (Y, U, V) and of the loop filter's side information (jmhip_db_mb, jmhip_db_motion), so that each can run jmhip_deblock_picture_dev
+ * the un-deblocked reconstruction (Y, U, V), of the loop filter's side information (jmhip_db_mb, jmhip_db_motion) and of what jmhip_reference_from_recon keeps with the slot
+ * beside the samples -- the picture's motion (EPZS's temporal predictors read the co-located block below a block: the next band's first row, me_epzs_common.c:1575-1602)
+ * and its "does not move" map (a B picture's spatial direct mode) --, so that each can run jmhip_deblock_picture_dev
  * (DeblockFrame filters across slice edges unless DFDisableIdc = 2: loopFilter.c:159-165) and jmhip_reference_from_recon on the whole picture -- the next picture's
  * search windows reach into the neighbouring bands.  Peer-to-peer copies (hipMemcpyPeerAsync over xGMI between devices), each destination's copies on its own stream behind
  * an event of the source's stream; asynchronous like the launches around it.  (One process per GPU: the same exchange is one RCCL all-gather, jm_amd/shard.py BandGather.) */

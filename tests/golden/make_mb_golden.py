@@ -100,6 +100,9 @@ CASES = {
     # BASELINE configs[4] at its own size: 1080p 4:2:2 synthetic, encoder_yuv422.cfg but for RDO / adaptive rounding / B pictures (and the level: five references of 1080p need 5.1)
     "g4y": (dict(RDO_OFF, NumberBFrames="0", InputFile="syn1080p422.yuv", SourceWidth="1920", SourceHeight="1080", OutputWidth="1920", OutputHeight="1080", FramesToBeEncoded="3", LevelIDC="51"),
             (1920, 1080), 3, "syn422", "jm_yuv422.cfg"),
+    # EPZS with slices of whole macroblock rows (three per picture), temporal predictors on: what JMHIP_DEVICES deals to several contexts -- a band's last row reads the
+    # co-located vectors of the next band's first row (me_epzs_common.c:1575-1602), so the bands' motion has to be exchanged with the samples
+    "m2ed": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", SliceMode="1", SliceArgument="33", FramesToBeEncoded="5"), (176, 144), 5, "motion:95"),
     # ---- B pictures (NumberBFrames 1, non-reference, spatial direct): coding order I P B P B ...; Main profile and up.  *b0: BiPredMotionEstimation 0; *b: as the shipped
     # encoder_main.cfg / encoder_yuv422.cfg have it (BiPredMotionEstimation 1, three refinements, range 16, sub-pel 2, 16x16 / 16x8 / 8x16)
     "q1b0": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", SymbolMode="0", BiPredMotionEstimation="0"), (176, 144), 3, False, "jm_main.cfg"),

@@ -394,7 +394,7 @@ def test_lencod_macroblock_pipeline_configs3_2160p_8_slices(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,devices,nmb_total", [("q4r", "0,0,0", 297), ("G4r", "0,0", 64800), ("G4r", "0,0,0,0,0,0,0,0", 64800)])
+@pytest.mark.parametrize("tag,devices,nmb_total", [("q4r", "0,0,0", 297), ("m2ed", "0,0,0", 495), ("G4r", "0,0", 64800), ("G4r", "0,0,0,0,0,0,0,0", 64800)])
 def test_lencod_slices_dealt_to_several_contexts(tmp_path, tag, devices, nmb_total):
     """JMHIP_DEVICES: the slices of a picture dealt to several contexts of one process (here all on this box's one device; between devices the same calls are peer copies),
     the bands exchanged with jmhip_allgather_bands before DeblockFrame, every context keeping the whole reference: QCIF in three slices on three contexts, BASELINE configs[3]
