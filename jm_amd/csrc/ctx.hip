@@ -83,6 +83,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   jmhip_ctx *c = (jmhip_ctx *)calloc(1, sizeof(jmhip_ctx));
   if (!c) return jmhip_fail(NULL, JMHIP_ENOMEM, "out of host memory");
   c->cfg = *cfg;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (cfg->device != 0) g_jmhip_multi_device = 1;
   c->stream = (hipStream_t)cfg->stream;
   { const char *fg = getenv("JMHIP_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
@@ -190,6 +191,11 @@ extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
   if (!ctx) return JMHIP_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int r = jmhip_seq_sync_all(ctx);
+  if (r) return r;
+  // pictures in flight: what jmhip_seq_wait would have told about each of them (the first error is reported, every entry is taken out of flight: a sticky error word
+  // would otherwise make the entry's next launch a silent no-op)
+  for (int k = 0; k < ctx->seq_depth; k++)
+    if (ctx->seq[k].in_flight) { const int q = jmhip_seq_wait(ctx, k); if (q && !r) r = q; }
   if (r) return r;
   r = jmhip_check_job_error(ctx);
   if (r) return r;
@@ -300,6 +306,10 @@ extern "C" int jmhip_set_reference_chroma_dev(jmhip_ctx *ctx, int32_t slot, cons
     return ctx ? jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_set_reference_chroma_dev: bad argument") : JMHIP_EINVAL;
   int r = refc_slot(ctx, slot);
   if (r) return r;
+  if (ctx->seq && ctx->slot_entry && ctx->slot_entry[slot] >= 0) {      // a picture in flight reads or writes the slot's chroma: it comes first (as in jmhip_set_reference)
+    if ((r = jmhip_seq_sync_all(ctx))) return r;
+    ctx->slot_entry[slot] = -1;
+  }
   // one launch for both planes (two 2-D copies of the runtime were 5 us each at 1080p)
   const bool wide = !((ctx->cw | pitch_bytes) & 7) && !(((uintptr_t)d_u | (uintptr_t)d_v) & 7);
   const int units = wide ? ctx->cw / 8 : ctx->cw;

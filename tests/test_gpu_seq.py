@@ -383,3 +383,48 @@ def test_1080p_epzs_sequence_in_flight_equals_the_reference_encoder():
     for n in range(c["nfr"]):
         d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(got[n][0])))
         assert d is None, ("against the reference encoder, picture", n, d)
+
+
+def oracle_sequence(W, H, qp, R, num_ref, lam, frames, sw, sh, slice_mbs=0, disable_idc=0, **kw):
+    """the ORACLE's picture-after-picture sequence (mbenc_util.SeqEncoder: oracle/jmo_mbenc.c per slice, the oracle's loop filter and interpolation): records, filtered planes,
+    the sixteen sub-pel planes -- in the shape `compare` takes"""
+    yuv = kw.get("yuv_format", 1)
+    enc = mbenc_util.SeqEncoder(W, H, qp, R, num_ref, lam, slice_mbs, disable_idc=disable_idc, cabac=kw.get("cabac", 0), search_mode=kw.get("search_mode", -1),
+                                transform8x8=kw.get("transform8x8", 0), yuv_format=yuv)
+    out = []
+    for raw in frames:
+        recs, _, _, post = enc.encode(pyjmo.load_frame(raw, sw, sh, W, H, yuv))
+        out.append((recs, [np.asarray(p, np.uint8) for p in post], enc.refs[0][0].planes))
+    return out
+
+
+# The forms of this file compared with the ORACLE directly (not with the device's own picture-after-picture path: a defect common to both forms of mbpipe_final.inc would pass
+# there): slices that start mid-row + CABAC, 4:2:2, the 8x8 transform + CABAC, content chosen against the pruning and the tie-breaking -- each in flight AND in one launch
+@pytest.mark.parametrize("W,H,R,num_ref,qp,seed,kw", [
+    (320, 192, 16, 2, 28, 101, {"slice_mbs": 50, "cabac": 1}),
+    (320, 192, 16, 1, 28, 102, {"yuv_format": 2}),
+    (320, 192, 16, 1, 28, 103, {"transform8x8": 1, "cabac": 1}),
+    (208, 160, 16, 1, 28, 104, {"hard": "stripes"}),
+    (208, 160, 16, 1, 28, 105, {"hard": "noise"}),
+])
+def test_pictures_in_flight_and_in_one_launch_equal_the_oracle(W, H, R, num_ref, qp, seed, kw):
+    kw = dict(kw)
+    hard = kw.pop("hard", None)
+    nfr = 6
+    if hard:
+        frames = hard_clip(hard, W, H, nfr, seed)
+    elif kw.get("yuv_format") == 2:
+        frames = [np.concatenate([fr[:W * H], np.repeat(fr[W * H:].reshape(2, H // 2, W // 2), 2, axis=1).ravel()]) for fr in synthetic_clip(W, H, nfr, seed)]
+    else:
+        frames = synthetic_clip(W, H, nfr, seed)
+    want = oracle_sequence(W, H, qp, R, num_ref, LAMBDAS, frames, W, H, **kw)
+    fl = FlightEncoder(W, H, qp, R, num_ref, LAMBDAS, 4, 0, **kw)
+    for raw in frames:
+        fl.submit(raw, W, H)
+    got = fl.finish()
+    fl.J.close()
+    compare(want, got, ("in flight against the oracle", W, H, kw, hard))
+    be = BatchEncoder(W, H, qp, R, num_ref, LAMBDAS, [nfr - num_ref], nfr + 1, **kw)
+    got = be.run(frames, W, H)
+    be.J.close()
+    compare(want, got, ("in one launch against the oracle", W, H, kw, hard))
