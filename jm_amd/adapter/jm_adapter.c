@@ -1412,7 +1412,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->NumberBFrames != 0 && (!p->direct_spatial_mv_pred_flag || p->BRefPictures || p->LowDelay || p->ExplicitSeqCoding || p->EnableOpenGOP))
       why = "B pictures with DirectModeType 0 (temporal), BReferencePictures, LowDelay, ExplicitSeqCoding or EnableOpenGOP";
     else if (p->NumberBFrames != 0 && p->SearchMode[0] == EPZS) why = "B pictures with EPZS";
-    else if (p->NumberBFrames != 0 && p->BiPredMotionEstimation && (p->BiPredSearch[3] || p->BiPredMESearchRange[0] < 1 || p->BiPredMESearchRange[0] > 32 || p->BiPredMESubPel > 2 || p->BiPredMERefinements > 15))
+    else if (p->NumberBFrames != 0 && p->BiPredMotionEstimation && (p->BiPredSearch[3] || p->BiPredMESearchRange[0] < 1 || p->BiPredMESearchRange[0] > 16 || p->BiPredMESubPel > 2 || p->BiPredMERefinements > 15))
       why = "BiPredMotionEstimation with BiPredSearch8x8, or a search range / sub-pel level / refinement count outside the device's";
     else if (p->full_search != 2) why = "RestrictSearchRange != 2";
     else if (p->num_of_views != 1 || p->separate_colour_plane_flag) why = "MVC / separate colour planes";
@@ -1420,7 +1420,7 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->HierarchicalCoding || p->PicInterlace != FRAME_CODING || p->MbInterlace != FRAME_CODING) why = "hierarchical / interlaced coding";
     else if (R < 1 || R > 32) why = "SearchRange outside 1..32";
     else if (p_Vid->max_num_references > JMHIP_MB_MAX_REF) why = "more than 16 references";
-    else if (p->SearchMode[0] != EPZS && (size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 32 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
+    else if (p->SearchMode[0] != EPZS && (size_t)p_Vid->max_num_references * (16 + 4 * R) * (2 * ox + 20) + 20 * (2 * ox + 20) + 50 * 1024 > 160 * 1024) why = "references x search window beyond the LDS";
     else if (p_Vid->bitdepth_chroma_qp_scale != 0) why = "chroma QP scale";
     P.ok = why == NULL;
     if (!P.ok && G.part_mbpipe && p->rdopt == 0)

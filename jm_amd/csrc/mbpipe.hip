@@ -223,6 +223,7 @@ struct Shared {
   int p8_info[4], p8t_info[4];               // the parts the tr4x4 / tr8x8 pass of P8x8 decided
   int fin_mv1[16], fin_ref1[16];             // the macroblock's final LIST_1 vectors and reference indices
   u8 bpred[8][256];                          // per wave: a prediction being priced
+  __attribute__((aligned(4))) u8 bireg[3][48 * 52];   // waves 4..6: the samples a bi-predictive search's candidates cover (range <= 16: 48 rows of 52 bytes)
   jmhip_mb_record out;
   PostShared post;
   PicView V;                                 // the picture the workgroup's current macroblock belongs to
