@@ -52,17 +52,57 @@ def config(seed):
     return case + (("jm_yuv422.cfg",) if yuv == 2 else ())
 
 
+def config_b(seed):
+    """seeds from 1 000 000: sequences with non-reference B pictures (spatial direct; jm_main.cfg / jm_yuv422.cfg as the base), every B switch the oracle restates drawn at random"""
+    rng = np.random.default_rng(seed)
+    yuv = int(rng.choice([1, 1, 1, 2]))
+    t8, cabac = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    prof = 122 if yuv == 2 else (100 if t8 else 77)
+    sw, sh = 16 * int(rng.integers(3, 12)) - int(rng.choice([0, 0, 2, 8])), 16 * int(rng.integers(3, 9)) - int(rng.choice([0, 0, 2, 6]))
+    nb = int(rng.choice([1, 1, 2]))
+    nfr = int(rng.integers(3, 8))
+    sm = int(rng.choice([-1, 0]))
+    R = int(rng.choice([4, 8, 16, 32])) if rng.integers(0, 3) else int(rng.integers(2, 33))
+    qp = int(rng.integers(10, 45))
+    nref = int(rng.integers(1, 4 if R > 16 else 5))
+    ov = dict(RDOptimization=0, AdaptiveRounding=0, NumberBFrames=nb, FramesToBeEncoded=nfr, YUVFormat=yuv, ProfileIDC=prof, LevelIDC=40, SymbolMode=cabac, Transform8x8Mode=t8, SearchMode=sm,
+              SearchRange=R, NumberReferenceFrames=nref, QPISlice=qp, QPPSlice=qp if rng.integers(0, 2) else int(rng.integers(10, 45)), QPBSlice=int(rng.integers(10, 45)),
+              OffsetMatrixPresentFlag=int(yuv == 2 and rng.integers(0, 2)), SliceMode=0, SliceArgument=50, DFDisableRefPSlice=0, DirectModeType=1,
+              DirectInferenceFlag=int(rng.integers(0, 2)), BiPredMotionEstimation=int(rng.integers(0, 3) > 0))
+    if ov["BiPredMotionEstimation"]:
+        ov.update(BiPredMERefinements=int(rng.integers(0, 4)), BiPredMESearchRange=int(rng.choice([2, 4, 8, 16])), BiPredMESubPel=int(rng.integers(0, 3)),
+                  BiPredSearch16x16=int(rng.integers(0, 4) > 0), BiPredSearch16x8=int(rng.integers(0, 2)), BiPredSearch8x16=int(rng.integers(0, 2)), BiPredSearch8x8=0)
+    if rng.integers(0, 2):
+        ov.update(BList0References=int(rng.integers(0, nref + 1)), BList1References=int(rng.integers(0, 3)))
+    if rng.integers(0, 3) == 0:
+        ov.update(SliceMode=1, SliceArgument=int(rng.integers(3, ((sw + 15) // 16) * ((sh + 15) // 16))))
+    if rng.integers(0, 4) == 0:
+        for k in ("16x8", "8x16", "8x4", "4x8", "4x4"):
+            ov["PSliceSearch" + k] = int(rng.integers(0, 2))
+    if rng.integers(0, 3) == 0:
+        for k in ("16x16", "16x8", "8x16", "8x8", "8x4", "4x8", "4x4"):
+            ov["BSliceSearch" + k] = int(rng.integers(0, 4) > 0)
+        ov["BSliceDirect"] = int(rng.integers(0, 3) > 0)
+    if prof >= 100 and rng.integers(0, 3) == 0:
+        ov.update(CbQPOffset=int(rng.integers(-6, 7)), CrQPOffset=int(rng.integers(-6, 7)))
+    if rng.integers(0, 4) == 0:
+        d = int(rng.choice([1, 2]))
+        ov.update(DFParametersFlag=1, DFDisableRefISlice=d, DFDisableNRefISlice=d, DFDisableRefPSlice=d, DFDisableNRefPSlice=d, DFDisableRefBSlice=d, DFDisableNRefBSlice=d)
+    clip = ("motion422:" if yuv == 2 else "motion:") + str(seed)
+    return ({k: str(v) for k, v in ov.items()}, (sw, sh), nfr, clip, "jm_yuv422.cfg" if yuv == 2 else "jm_main.cfg")
+
+
 def one(seed):
     import make_mb_golden as M
     import test_oracle_mbenc as T
     tag = f"zz{seed}"
-    M.CASES[tag] = config(seed)
+    M.CASES[tag] = config_b(seed) if seed >= 1000000 else config(seed)
     path = os.path.join(G, f"mb_low_{tag}.npz")
     try:
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
             M.run(tag)
-        T.run_case(tag)
+        (T.run_case_b if seed >= 1000000 else T.run_case)(tag)
         return seed, None
     except subprocess.CalledProcessError:                    # JM itself refuses the configuration (a level too small for the picture / the references): not a case
         return seed, "refused"

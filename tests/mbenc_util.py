@@ -67,6 +67,7 @@ class SeqEncoder:
         self.offsets = offsets               # None, or pyjmo.load_q_offsets(q_offset.cfg) with OffsetMatrixPresentFlag = 1
         self.refs = []         # most recent first: (RefPic, (u, v), picture id, (mv, refpoc) per 4x4 block of the stored picture)
         self.npic = 0
+        self.keep = 0          # stored reference pictures when that is more than P's list (B pictures: a list 1 longer than any list 0 of the sequence)
         self.epzs_stats = []   # per P slice: (searches, alias_hits) of the oracle's EPZS
 
     def encode_b(self, cur, poc, l0_pocs, l1_pocs, lambdas_b, qp_b, b=None, debug=False, qpc_b=None, qpc_cr_delta_b=None, inter_valid_b=None):
@@ -136,7 +137,7 @@ class SeqEncoder:
         for k, r in enumerate(self.refs[:nref]):
             refpoc[pic.ref_idx == k] = 2 * r[2]
         self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic, (pic.mv.copy(), refpoc), 2 * self.npic if poc is None else poc, (pic.mv.copy(), pic.ref_idx.copy(), pic.mv1.copy(), pic.ref_idx1.copy())))
-        self.refs = self.refs[:self.num_ref]
+        self.refs = self.refs[:max(self.num_ref, self.keep)]
         self.npic += 1
         return recs, dbg, pre, (y, u, v)
 

@@ -79,8 +79,9 @@ def run_case_b(tag, check_oracle_post=True):
     args = (c["W"], c["H"], c["qp"], c["R"], c["num_ref"], c["lam"], c["slice_mbs"], c["mv_limit"], c["didc"])
     kw = dict(cabac=c.get("cabac", 0), search_mode=c["search_mode"], transform8x8=c["t8"], yuv_format=c["yuv"], offsets=c["offsets"], inter_valid=c["inter_valid"],
               qpc=c["qpc"] if c["qp_p"] in (None, c["qp"]) or c["qpc_p"] is not None else None, qpc_cr_delta=c["qpc_cr_delta"], qp_p=c["qp_p"])
-    dev = DevSeqEncoderB(*args, qpc_p=c["qpc_p"], qpc_cr_delta_p=c["qpc_cr_delta_p"], **kw)
+    dev = DevSeqEncoderB(*args, qpc_p=c["qpc_p"], qpc_cr_delta_p=c["qpc_cr_delta_p"], keep=TO.stored_refs(ov, z), **kw)
     orc = mbenc_util.SeqEncoder(*args, epzs=c["epzs"], qpc_p=c["qpc_p"], qpc_cr_delta_p=c["qpc_cr_delta_p"], **kw)
+    orc.keep = dev.keep
     nmb = (c["W"] // 16) * (c["H"] // 16)
     src = TO.source_frames(c, tag)
     raw = raw_frames(c, tag)

@@ -63,7 +63,7 @@ def slice_params(L, cfg, slice_nr, ref_slots, ref_ids, disable_idc=0, epzs=None,
 class DevSeqEncoder:
     """IPPP on the device: the counterpart of mbenc_util.SeqEncoder (the oracle), same parameters."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0, qp_p=None):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, slice_mbs=0, level_mv=(-8192, 8191, -2048, 2047), disable_idc=0, together=False, cabac=0, search_mode=-1, epzs=None, transform8x8=0, yuv_format=1, offsets=None, inter_valid=None, qpc=None, qpc_cr_delta=0, qp_p=None, keep=0):
         self.cabac = cabac
         self.qp_p = qp if qp_p is None else qp_p
         self.yuv_format, self.offsets, self.inter_valid, self.qpc, self.qpc_cr_delta = yuv_format, offsets, inter_valid, qpc, qpc_cr_delta
@@ -74,8 +74,9 @@ class DevSeqEncoder:
         self.L = L
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas = W, H, qp, R, num_ref, lambdas
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
-        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=num_ref + 1, yuv_format=yuv_format)
+        self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=max(num_ref, keep) + 1, yuv_format=yuv_format)
         self.refs = []          # most recent first: (slot, picture id)
+        self.keep = keep        # stored reference pictures when that is more than P's list (B pictures with a longer list 1)
         self.npic = 0
 
     def encode(self, raw, sw, sh, timing=None):
@@ -105,12 +106,12 @@ class DevSeqEncoder:
         pre = J.get_recon()
         J.deblock_picture_dev(1)
         post = J.get_recon()
-        used = {r[0] for r in self.refs[:max(self.num_ref - 1, 0)]}
-        slot = [s for s in range(self.num_ref + 1) if s not in used][0]
+        used = {r[0] for r in self.refs[:max(max(self.num_ref, self.keep) - 1, 0)]}
+        slot = [s for s in range(max(self.num_ref, self.keep) + 1) if s not in used][0]
         J.reference_from_recon(slot)
         J.synchronize()
         self.refs.insert(0, (slot, self.npic))
-        self.refs = self.refs[:self.num_ref]
+        self.refs = self.refs[:max(self.num_ref, self.keep)]
         self.npic += 1
         return recs, pre, post
 
