@@ -38,6 +38,10 @@ while time.time() - t0 < budget:
              bipred_refinements=int(rng.integers(0, 4)), bipred_range=int(rng.choice([r for r in (2, 4, 8, 16) if r <= R])), bipred_subpel=int(rng.integers(0, 3)))
     iv = [1] * 8 if rng.integers(0, 4) else [1, 1] + [int(rng.integers(0, 2)) for _ in range(6)]
     ivb = None if rng.integers(0, 3) else [int(rng.integers(0, 3) > 0)] + [int(rng.integers(0, 4) > 0) for _ in range(7)]
+    if t8:                                                    # the library turns Transform8x8Mode 1 without the 8x8 partition away (as the adapter does)
+        iv[4] = 1
+        if ivb:
+            ivb[4] = 1
     n0, n1 = int(rng.integers(1, keep + 1)), int(rng.integers(1, 3))       # B(List0/1)References
     ngop = int(rng.integers(1, 4))
     nfr = 1 + ngop * (nb + 1)
