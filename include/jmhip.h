@@ -697,7 +697,11 @@ int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
  * slice's edge.  The full searches (search_mode 0, 1) reach 2 SearchRange into the reference, so a
  * macroblock waits once, for the macroblock 5 to its right and 5 below it (SearchRange 32); an EPZS search (search_mode 3) goes wherever its predictor takes it inside the
  * level's vector range, so every search asks for what it is about to read when its centre is known; the temporal predictors read the motion kept with the slots of
- * references 0 / 1 directly (every picture of such a sequence, its I pictures too, is launched with search_mode 3 and its picture order counts).  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
+ * references 0 / 1 directly (every picture of such a sequence, its I pictures too, is launched with search_mode 3 and its picture order counts).
+ * A B picture (slice_type 1, non-reference: what jmhip_encode_slice accepts) is in flight too: its launch waits -- stream order -- for the launches that make its references,
+ * runs beside the pictures that follow those (a P picture does not need the B pictures before it), its loop filter follows on a stream the context keeps for B pictures, its
+ * filtered reconstruction is out_slot's integer planes (jmhip_seq_get_recon / jmhip_seq_recon_dev; no sub-pel planes, no post flags: nobody reads it as a reference; give it a
+ * slot that holds no reference of a picture still to be launched).  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
  * after jmhip_seq_wait of the entry that wrote them, or after jmhip_synchronize).
  * ------------------------------------------------------------------------------------------ */
 int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture /* 0: 256 / depth, at most 80; always cut to 248 / (depth - 1), so that the oldest picture in flight can never be

@@ -139,6 +139,7 @@ extern "C" int jmhip_deblock_frame_dev(jmhip_ctx *ctx, uint8_t *d_Y, int32_t pit
 {
   if (!ctx) return JMHIP_EINVAL;
   if (!d_Y || !d_mbs || !d_motion || (ctx->cfg.yuv_format && (!d_U || !d_V))) return jmhip_fail(ctx, JMHIP_EINVAL, "jmhip_deblock_frame_dev: bad argument");
+  if (ctx->bdb_used && ctx->stream != ctx->bdb_stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->bdb_ev, 0));      // the workspace: behind the B pictures in flight that were filtered last
   DbArgs A;
   A.Y = d_Y; A.U = d_U; A.V = d_V; A.pitchY = pitchY; A.pitchC = pitchC; A.mbs = d_mbs; A.motion = d_motion;
   A.mb_w = ctx->W / 16; A.mb_h = ctx->H / 16; A.yuv_format = ctx->cfg.yuv_format; A.direct8x8 = direct8x8;

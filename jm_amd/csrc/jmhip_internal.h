@@ -11,7 +11,8 @@
 // A picture in flight (jmhip_seq_*, mbpipe_host.inc): everything one launch of the macroblock pipeline owns, so that launches of consecutive pictures can run side by side
 struct jmhip_seq_entry {
   hipStream_t stream;
-  hipEvent_t done;       // recorded behind the entry's launch
+  hipEvent_t done;       // recorded behind the entry's launch (a B picture: behind its loop filter)
+  hipEvent_t coded;      // a B picture in flight: behind the coding launch, before the loop filter
   hipEvent_t t0, t1;     // jmhip_enable_timing: around the launch
   int timed;
   uint8_t *d_raw;        // the source picture as the file holds it (jmhip_seq_set_frame)
@@ -91,6 +92,7 @@ struct jmhip_ctx {
   unsigned *slot_tag;    // [num_ref_slots] tag of the slot's current / last picture made by a sequence launch
   int *slot_entry;       // [num_ref_slots] entry that makes / made the slot's picture, -1: filled by jmhip_set_reference* / jmhip_reference_from_recon
   hipEvent_t seq_ev;     // orders the context's own stream before an entry's
+  hipStream_t bdb_stream; hipEvent_t bdb_ev; int bdb_used;     // B pictures in flight: the stream their loop filters run on one after the other, and the last one's event
   // several pictures in ONE launch (jmhip_seq_batch): per picture a source picture, edge records, flags and loop-filter side information at a fixed stride; the
   // pictures' descriptors and the ticket order of the last batch
   uint8_t *d_batch; int batch_cap; void *d_batch_tab; size_t batch_tab_bytes; unsigned batch_epoch;

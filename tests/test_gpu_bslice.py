@@ -63,6 +63,8 @@ class DevSeqEncoderB(TG.DevSeqEncoder):
             prm = TG.slice_params(L, cfg, sn, [r[0] for r in L0 + L1], [r[1] for r in L0 + L1], self.disable_idc)
             prm["num_ref1"] = len(L1)
             prm["b_switches"] = b_switch_word(b)
+            if sn == 0:
+                self.log.append(dict(st=1, raw=raw, sw=sw, sh=sh, prm=prm.copy(), nslices=len(mbenc_util.slices_of(nmb, self.slice_mbs)), pic_id=None, d8=int(b.get("direct_8x8_inference", 1))))
             recs[first:first + num] = J.encode_slice(prm)
         pre = J.get_recon()
         J.deblock_picture_dev(int(b.get("direct_8x8_inference", 1)))
@@ -72,7 +74,9 @@ class DevSeqEncoderB(TG.DevSeqEncoder):
         return recs, pre, post
 
 
-def run_case_b(tag, check_oracle_post=True):
+def run_case_b(tag, check_oracle_post=True, flight=None):
+    """flight = (depth, workgroups, streamed records): the sequence once more with that many pictures in flight (jmhip_seq_*); records and filtered pictures must be the same"""
+    classic = []
     c = TO.load_case(tag)
     z = c["z"]
     ov = dict(s.split("=") for s in z["overrides"])
@@ -108,6 +112,13 @@ def run_case_b(tag, check_oracle_post=True):
         if check_oracle_post:
             for a, b_ in zip(post, opost):
                 assert np.array_equal(a, np.asarray(b_, np.uint8)), (tag, n, st, "the filtered picture differs from the oracle's")
+        classic.append((recs, post))
+    dev.J.close()
+    if flight:
+        got = replay_in_flight(dev, *flight)
+        for n, ((r0, p0), (r1, p1)) in enumerate(zip(classic, got)):
+            assert r0.tobytes() == r1.tobytes(), (tag, n, "records of the picture in flight", TG.first_difference(TG.as_oracle_records(r0), TG.as_oracle_records(r1)))
+            assert all(np.array_equal(a, b_) for a, b_ in zip(p0, p1)), (tag, n, "filtered picture of the picture in flight")
 
 
 def raw_frames(c, tag):
@@ -131,6 +142,54 @@ def raw_frames(c, tag):
     return [data[n * fs:(n + 1) * fs] for n in range(c["nfr"])]
 
 
+def replay_in_flight(dev, depth, workgroups=0, stream_records=False):
+    """The pictures of a finished picture-after-picture run (dev.log) once more through jmhip_seq_* with `depth` pictures in flight: the P pictures follow their references
+    macroblocks apart inside the device, a B picture starts when both its references are complete and runs beside the P pictures after them.  Returns per picture
+    (records, filtered planes)."""
+    L = dev.L
+    nmb = (dev.W // 16) * (dev.H // 16)
+    nslots = max(dev.num_ref, dev.keep) + depth + 1
+    J = L.JmHip(dev.W, dev.H, search_range=max(dev.R, 1), num_ref_slots=nslots, yuv_format=dev.yuv_format)
+    J.seq_open(depth, workgroups)
+    slot_of, stored, pending, out = {}, [], {}, {}          # picture id -> slot; ids of the stored references (most recent first); picture number -> slot, not collected yet
+    keep = max(dev.num_ref, dev.keep)
+
+    def collect(k):
+        e = k % depth
+        if stream_records:
+            recs = J.seq_records_streamed(e, 0, nmb)
+            J.seq_wait(e)
+        else:
+            J.seq_wait(e)
+            recs = J.seq_records(e)
+        out[k] = (recs, J.seq_get_recon(pending.pop(k)))
+
+    try:
+        for k, p in enumerate(dev.log):
+            if k >= depth:
+                collect(k - depth)
+            prm = p["prm"].copy()
+            nref_all = 0 if p["st"] == 2 else int(prm["num_ref"][0]) + (int(prm["num_ref1"][0]) if p["st"] == 1 else 0)
+            for r in range(nref_all):
+                prm["ref_slot"][0, r] = slot_of[int(prm["ref_id"][0, r])]
+            if p["nslices"] > 1:
+                prm["num_slices"] = p["nslices"]
+            busy = {slot_of[i] for i in stored} | set(pending.values())      # (the reconstruction is written while the oldest reference is still read)
+            slot = [s for s in range(nslots) if s not in busy][0]
+            J.seq_set_frame(k % depth, p["raw"], p["sw"], p["sh"])
+            J.seq_encode(k % depth, prm, slot, p["d8"], stream_records)
+            pending[k] = slot
+            if p["st"] != 1:
+                slot_of[p["pic_id"]] = slot
+                stored = ([p["pic_id"]] + stored)[:keep]
+        for k in sorted(pending):
+            collect(k)
+        J.synchronize()
+    finally:
+        J.close()
+    return [out[k] for k in range(len(dev.log))]
+
+
 # without the bi-predictive motion search (BiPredMotionEstimation 0): spatial direct, LIST_0 / LIST_1 / BI_PRED per partition, the direct 8x8 sub-mode; CAVLC full search (q1b0),
 # CABAC + 8x8 transform + fast full search + three references + slices that start mid-row (m3b0)
 @pytest.mark.parametrize("tag", ["q1b0", "m3b0"])
@@ -150,3 +209,10 @@ def test_b_picture_1080p_equals_the_reference_encoder():
     """encoder_main.cfg's search and B settings at 1080p (fast full search SR 32, CABAC, the bi-predictive search), RDO off: I P B of the synthetic clip (g3b: 24 480 macroblocks
     of the real encoder); the filtered pictures are not compared with the oracle here (minutes of CPU: tests/test_oracle_mbenc.py does that under JMO_LONG)"""
     run_case_b("g3b", check_oracle_post=False)
+
+
+# B pictures in flight (jmhip_seq_encode with slice_type 1): the sequences of the goldens once more with 3 / 6 pictures in flight -- P pictures following their references inside
+# the device, B pictures beside the P pictures after them --: every record and every filtered picture as picture after picture (which the tests above pin to the real encoder)
+@pytest.mark.parametrize("tag,flight", [("m3b", (3, 0, False)), ("m3b0", (6, 20, True)), ("m2b4", (4, 0, True)), ("q5yb", (3, 0, False)), ("q1b", (2, 0, False))])
+def test_b_pictures_in_flight_equal_picture_after_picture(tag, flight):
+    run_case_b(tag, check_oracle_post=False, flight=flight)

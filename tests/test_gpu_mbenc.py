@@ -76,6 +76,7 @@ class DevSeqEncoder:
         self.slice_mbs, self.level_mv, self.disable_idc = slice_mbs, level_mv, disable_idc
         self.J = L.JmHip(W, H, search_range=max(R, 1), num_ref_slots=max(num_ref, keep) + 1, yuv_format=yuv_format)
         self.refs = []          # most recent first: (slot, picture id)
+        self.log = []           # per picture: what it was launched with (the runs with pictures in flight replay it: tests/test_gpu_bslice.py)
         self.keep = keep        # stored reference pictures when that is more than P's list (B pictures with a longer list 1)
         self.npic = 0
 
@@ -92,6 +93,8 @@ class DevSeqEncoder:
             cfg = pyjmo.mbenc_cfg(self.W, self.H, st, first, num, self.qp if st == 2 else self.qp_p, self.R, nref, lam_mf, lam_md, level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
                                   yuv_format=self.yuv_format, offsets=self.offsets, inter_valid=self.inter_valid, qpc=self.qpc, qpc_cr_delta=self.qpc_cr_delta)
             prm = slice_params(L, cfg, sn, [r[0] for r in self.refs[:nref]], [r[1] for r in self.refs[:nref]], self.disable_idc, self.epzs, 2 * self.npic)
+            if sn == 0:
+                self.log.append(dict(st=st, raw=raw, sw=sw, sh=sh, prm=prm.copy(), nslices=len(slices), pic_id=self.npic, d8=1))
             if timing is not None:
                 J.enable_timing(True)
             if self.together and len(slices) > 1:
