@@ -441,28 +441,121 @@ def configs2_params(q, slice_type, poc_cur):
     return q
 
 
-def slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref, num_slices=0):
-    """jmhip_slice_params with JM's own values for configs[1] / configs[3] with RDO off (tests/golden/mb_low_g2r.npz holds what the encoder used)"""
+QUANT_COEF = [(13107, 5243, 8066), (11916, 4660, 7490), (10082, 4194, 6554), (9362, 3647, 5825), (8192, 3355, 5243), (7282, 2893, 4559)]      # quant_coef, by qp % 6 (q_matrix.c:20-27)
+DEQUANT_COEF = [(10, 16, 13), (11, 18, 14), (13, 20, 16), (14, 23, 18), (16, 25, 20), (18, 29, 23)]                                                # dequant_coef (q_matrix.c:29-36)
+
+
+def slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref, num_slices=0, qp=QP, qpc=QP, lam=192):
+    """jmhip_slice_params with JM's own values for configs[1] / configs[3] with RDO off (tests/golden/mb_low_g2r.npz holds what the encoder used); qp / qpc / lam: a B picture of
+    encoder_main.cfg (QPBSlice 30: chroma 29, lambda factor 256 -- tests/golden/mb_low_g3b.npz)"""
     p = np.zeros(1, SLICE_PARAMS)
-    p["slice_type"], p["first_mb"], p["num_mb"], p["slice_nr"], p["qp"], p["qpc"] = slice_type, first, num, slice_nr, QP, QP
+    p["slice_type"], p["first_mb"], p["num_mb"], p["slice_nr"], p["qp"], p["qpc"] = slice_type, first, num, slice_nr, qp, qpc
     p["search_range"], p["num_ref"], p["num_slices"] = R, num_ref, num_slices
-    p["lambda_mf"], p["lambda_mdfp"] = [192, 192, 192], 192               # lambda_mf / LAMBDA_FACTOR(lambda_md) at QP 28 with RDOptimization = 0
+    p["lambda_mf"], p["lambda_mdfp"] = [lam, lam, lam], lam               # lambda_mf / LAMBDA_FACTOR(lambda_md) with RDOptimization = 0: 192 at QP 28
     p["max_mvd"] = 1023                                                  # mv_search.c:327 at SearchRange 32
     p["mv_limit"] = [-8192, 8191, -2048, 2047]                           # level 5.1
     p["inter_valid"], p["intra4_valid"], p["intra16_valid"], p["subpel"], p["start_qp"] = 1, 1, 1, 1, 1
     bits = [1, 3, 3] + [5] * 4 + [7] * 8 + [9]
     p["refbits"] = bits
-    sc, ds = {0: 8192, 1: 3355, 2: 5243}, {0: 16, 1: 25, 2: 20}          # qp % 6 == 4 rows of quant_coef / dequant_coef (q_matrix.c:20-36)
     for intra in range(2):
         off = 682 if (intra and slice_type == 2) else 342                # q_offsets.c:135-162 default offsets
         for j in range(4):
             for i in range(4):
                 c = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 and j % 2) else 2)
-                q = (off << (15 + QP // 6 - 11), sc[c], ds[c] << 4)
-                p["q_luma"][0, intra, j * 4 + i] = q
-                p["q_chroma"][0, :, intra, j * 4 + i] = q
+                p["q_luma"][0, intra, j * 4 + i] = (off << (15 + qp // 6 - 11), QUANT_COEF[qp % 6][c], DEQUANT_COEF[qp % 6][c] << 4)
+                p["q_chroma"][0, :, intra, j * 4 + i] = (off << (15 + qpc // 6 - 11), QUANT_COEF[qpc % 6][c], DEQUANT_COEF[qpc % 6][c] << 4)
     p["df_disable_idc"] = 0                                              # DeblockFrame filters across slice edges (the .cfg files' DFDisableIdc = 0)
     return p
+
+
+def b_pictures_leg(local, frames, src_h, nmb, flight):
+    """encoder_main.cfg's settings with RDO off at 1080p (the shipped file's B picture: NumberBFrames 1, fast full search SR 32, CABAC, two references, spatial direct, the
+    bi-predictive search with three refinements / range 16 / two sub-pel levels -- tests/golden/mb_low_g3b.npz is the real encoder's I P B of this clip):
+    the B picture's launch alone (k_mb_pipe_b, records against the real encoder's), then I + 12 x (P B) with pictures in flight (jmhip_seq_encode: P pictures follow their
+    references inside the device, a B picture starts when both its references are complete and runs beside the P pictures after them)."""
+    import torch
+    from jm_amd import JmHip
+    from jm_amd.lib import SLICE_PARAMS, MB_RECORD
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import mb_tap
+    if len(frames) < 3:
+        frames = yuv_frames(3)
+    bsw = 1 | 2 | (7 << 2) | (3 << 8) | (16 << 16) | (2 << 24)          # direct_8x8_inference, BiPredMotionEstimation, 16x16 / 16x8 / 8x16, 3 refinements, range 16, sub-pel 2
+    ngop = 12
+    # entries: the P pictures' and the B pictures' own (a B macroblock takes ~600 us of a workgroup's time, a P macroblock of this search ~200; the B pictures are what fills
+    # the chip, the P pictures only have to stay ahead of them).  JMHIP_BENCH_B="P entries,B entries,workgroups per P picture,per B picture": measurement aid
+    n_p, n_b, wg_p, wg_b = (int(x) for x in os.environ.get("JMHIP_BENCH_B", "4,6,24,32").split(","))
+    depth = n_p + n_b
+    nring = 2 + n_p + 2                                                  # reference pictures: the window of two + those in flight + two
+    nslots = nring + n_b + 1                                             # ... and the B pictures' own slots behind them
+    ctx = JmHip(W, H, search_range=R, num_ref_slots=nslots, yuv_format=1, device=local)
+
+    def prm(st, refs0, refs1=()):
+        q = slice_params(SLICE_PARAMS, st, 0, nmb, 0, len(refs0), **(dict(qp=30, qpc=29, lam=256) if st == 1 else {}))
+        q["search_mode"], q["symbol_mode"] = 1, 1
+        for r, (slot, pid) in enumerate(list(refs0) + list(refs1)):
+            q["ref_slot"][0, r], q["ref_id"][0, r] = slot, pid
+        if st == 1:
+            q["num_ref1"], q["b_switches"] = len(refs1), bsw
+        return q
+    # ---- picture after picture: I (frame 0), P (frame 2), B (frame 1) against the real encoder's records
+    ctx.enable_timing(True)
+    ctx.set_current_frame(frames[0], W, src_h); r_i = ctx.encode_slice(prm(2, [])); ctx.deblock_picture_dev(1); ctx.reference_from_recon(0)
+    ctx.set_current_frame(frames[2], W, src_h); r_p = ctx.encode_slice(prm(0, [(0, 0)])); ctx.deblock_picture_dev(1); ctx.reference_from_recon(1)
+    ctx.set_current_frame(frames[1], W, src_h)
+    pb = prm(1, [(0, 0), (1, 1)], [(1, 1)])
+    bms = []
+    for i in range(3):
+        ctx.encode_slice_dev(pb)
+        ctx.synchronize()
+        bms.append(ctx.last_kernel_ms(5))
+    r_b = ctx.encode_slice(pb)
+    gold = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3b.npz"))["records"])
+    eq = all(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(np.frombuffer(r.tobytes(), gold.dtype).copy(), bslice=k == 2), gold[k * nmb:(k + 1) * nmb]))
+             for k, r in enumerate((r_i, r_p, r_b)))
+    types = np.bincount(r_b["mb_type"].astype(int), minlength=14)
+    # ---- the sequence with pictures in flight
+    ctx.seq_open(depth, wg_p)
+    ctx.seq_b_workgroups(wg_b)
+    d_raw = torch.from_numpy(np.stack(frames)).to(f"cuda:{local}")
+    npic = 1 + 2 * ngop
+    d_recs = torch.zeros((npic, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=f"cuda:{local}")
+    order = [(0, 2)] + [x for g in range(ngop) for x in ((2 * g + 2, 0), (2 * g + 1, 1))]      # (display number, slice type) in coding order
+    nf = len(frames)
+
+    def run():
+        stored, nref_pic, nb_pic = [], 0, 0                              # (slot, picture id) of the stored references, most recent first
+        for k, (disp, st) in enumerate(order):
+            e = n_p + nb_pic % n_b if st == 1 else nref_pic % n_p
+            ctx.seq_set_frame_dev(e, d_raw[disp % nf].data_ptr(), W, src_h)
+            if st == 1:
+                past, future = stored[1], stored[0]                      # the window of two: the picture before and the picture after this one
+                ctx.seq_encode(e, prm(1, [past, future], [future]), nring + nb_pic % (n_b + 1), 1, False, d_recs[k].data_ptr())
+                nb_pic += 1
+            else:
+                slot = nref_pic % nring
+                ctx.seq_encode(e, prm(st, stored[:2] if st == 0 else []), slot, 1, False, d_recs[k].data_ptr())
+                stored = ([(slot, k)] + stored)[:2]
+                nref_pic += 1
+    run()
+    torch.cuda.synchronize(); ctx.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.synchronize()
+    last_ms = [round(ctx.seq_kernel_ms(e), 1) for e in range(depth)]    # the coding launch each entry ran last (P and B pictures alternate over the entries)
+    r3 = d_recs[:3].cpu().numpy().view(MB_RECORD).reshape(3, nmb)
+    eq_fl = all(a.tobytes() == b.tobytes() for a, b in zip((r_i, r_p, r_b), r3))
+    ctx.seq_close()
+    ctx.close()
+    return {"workload": "encoder_main.cfg with RDO off at 1080p: I P B P B ... (NumberBFrames 1, non-reference B pictures, spatial direct), fast full search SR 32, CABAC, two references, "
+                        "BiPredMotionEstimation 1 (3 refinements, range 16, sub-pel 2; 16x16 / 16x8 / 8x16), QP 28 / 28 / 30",
+            "b_picture_alone": {"kernel": "k_mb_pipe_b", "avg_kernel_ms": round(float(np.mean(bms[1:])), 3), "macroblocks_per_s": round(nmb / (float(np.mean(bms[1:])) * 1e-3), 1),
+                                "mb_types_direct_16x16_16x8_8x16_p8x8_i4_i16": [int(types[k]) for k in (0, 1, 2, 3, 8, 9, 10)]},
+            "records_equal_jm_i_p_b": bool(eq),
+            "in_flight": {"pictures": npic, "b_pictures": ngop, "pictures_in_flight": depth, "entries_p_b": [n_p, n_b], "workgroups_per_p_b_picture": [wg_p, wg_b], "ms_per_picture": round(dt / npic * 1e3, 3), "macroblocks_per_s": round(nmb * npic / dt, 1),
+                          "last_launch_ms_by_entry": last_ms, "records_equal_picture_after_picture_first_three": bool(eq_fl)}}
 
 
 class _DevMem:
@@ -924,6 +1017,7 @@ def main():
             out["end_to_end"] = end_to_end(cpu)
         if not args.no_end_to_end and N == 1:
             out["configs2"] = dict(configs2_device, end_to_end=configs2_end_to_end())
+            out["b_pictures"] = b_pictures_leg(local, frames, src_h, nmb, args.flight)
             out["configs3"] = dict(configs3_end_to_end(), device=configs3_device(local))
             out["configs4"] = configs4_end_to_end()
         if args.streams > 1 and N == 1:

@@ -710,6 +710,9 @@ int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture
                    The count is in workgroups that fill a compute unit (eight waves).  An EPZS P picture with up to five references is launched as four-wave workgroups, two
                    to a compute unit (k_mb_pipe_epzs4*), and takes twice the count: sixteen such pictures in flight (depth 16, 2 x 16 workgroups each) are the fastest form
                    measured, 5.4 ms per 1080p picture (profiles/r04_epzs_four_wave.txt) */);
+int jmhip_seq_b_workgroups(jmhip_ctx *ctx, int32_t workgroups /* workgroups of a B picture in flight (0: as the other pictures).  A B picture's macroblock takes several times a P
+                   picture's and nothing waits for a B picture inside the device: a caller that keeps its B pictures in entries of their own (say 4 entries for the P pictures
+                   with 16 workgroups each, 6 for the B pictures with 32) fills the chip with them */);
 int jmhip_seq_close(jmhip_ctx *ctx);
 int jmhip_seq_set_frame(jmhip_ctx *ctx, int32_t entry, const uint8_t *raw, int32_t src_w, int32_t src_h);
 int jmhip_seq_set_frame_dev(jmhip_ctx *ctx, int32_t entry, const uint8_t *d_raw, int32_t src_w, int32_t src_h);

@@ -100,7 +100,12 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
  * are compared with the frame that was sent; any difference voids the pictures in flight and the picture is launched the ordinary way. */
 #define FL_MAX 16
 static struct {
-  int depth, nring;                   /* entries of jmhip_seq_open; device slots used in turn */
+  int depth, nring;                   /* entries of jmhip_seq_open; device slots the reference pictures (I, P) use in turn */
+  int nb, nring_b;                    /* NumberBFrames; the slots behind the first nring that the (non-reference) B pictures use in turn */
+  long refcount, bcount;              /* reference / B pictures met so far */
+  int st_n, st_slot[JMHIP_MB_MAX_REF + 1], window;   /* the stored reference pictures as the sliding window holds them, most recent first: slot and ... */
+  long st_disp[JMHIP_MB_MAX_REF + 1]; /* ... place in display order */
+  long first_frame_no; int regular;   /* the file's frame of picture 0; pictures so far arrived in the regular order I P B.. P B.. (display place fl_disp) */
   int on;
   int fd, have_file, src_w, src_h, cur_frame_no, frame_step;
   long header, frame_bytes, start_frame;
@@ -317,15 +322,19 @@ static int adapter_on(VideoParameters *p_Vid)
                                                                sixteen of them fill the chip (24 1080p pictures of configs[2]: 16 - 58 ms per later P picture with eight in flight, the device
                                                                running dry again and again; 17 - 23 ms with sixteen: profiles/r04_e2e_configs2_flight.txt) */
       const char *fl = getenv("JMHIP_ADAPTER_FLIGHT");
-      F.depth = fl ? atoi(fl) : (p_Inp->SearchMode[0] == EPZS ? 16 : 4);
+      F.depth = fl ? atoi(fl) : (p_Inp->SearchMode[0] == EPZS ? 16 : p_Inp->NumberBFrames ? 8 : 4);       /* (B pictures: ~6 x a P picture's time on the device, and nobody waits for them) */
       /* (SliceMode 1: the picture's slices go up in one launch either way; with pictures in flight the launch runs in the picture's wavefront order -- not with JMHIP_DEVICES,
          where the slices are dealt to several contexts) */
-      if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || (p_Inp->slice_mode != NO_SLICES && (p_Inp->slice_mode != FIXED_MB || getenv("JMHIP_DEVICES"))) || p_Inp->NumberBFrames != 0 ||
+      if (F.depth < 2 || !G.part_mbpipe || p_Inp->rdopt != 0 || (p_Inp->slice_mode != NO_SLICES && (p_Inp->slice_mode != FIXED_MB || getenv("JMHIP_DEVICES"))) ||
+          (p_Inp->NumberBFrames != 0 && (p_Inp->intra_period != 0 || p_Inp->idr_period != 0 || p_Inp->SearchMode[0] == EPZS)) ||
           (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH && p_Inp->SearchMode[0] != EPZS)) F.depth = 0;
       if (F.depth > FL_MAX) F.depth = FL_MAX;
       if (F.depth) {
-        F.nring = imin(MAX_SLOTS, p_Vid->max_num_references + F.depth + 1);
-        G.nslots = F.nring;
+        F.nb = p_Inp->NumberBFrames;
+        if (F.nb && F.depth > 10) F.depth = 10;
+        F.nring_b = F.nb ? F.depth + 1 : 0;                  /* a B picture's filtered reconstruction waits in its slot until JM has fetched it */
+        F.nring = imin(MAX_SLOTS - F.nring_b, p_Vid->max_num_references + F.depth + 1);
+        G.nslots = F.nring + F.nring_b;
         setenv("GPU_MAX_HW_QUEUES", F.depth > 8 ? "24" : "16", 0);       /* before HIP starts: a hardware queue per picture in flight (the runtime's default is 4) */
       }
     }
@@ -1465,6 +1474,9 @@ static void flight_begin(VideoParameters *p_Vid)
   if (F.on || !F.depth || P.n_slices) return;               /* decided at the sequence's first picture */
   F.total = p_Vid->p_Inp->no_frames;
   if ((rc = jmhip_seq_open(G.ctx, F.depth, 0))) adapter_die("jmhip_seq_open", rc);
+  /* B pictures: several times a P picture's time per macroblock, and no launch waits for them inside the device -- twice a P picture's workgroups (1080p, I P B P B ..., eight
+     in flight: 24 ms per picture against 28 with equal shares; profiles/r05_b_in_flight.txt) */
+  if (F.nb && (rc = jmhip_seq_b_workgroups(G.ctx, 64))) adapter_die("jmhip_seq_b_workgroups", rc);
   for (k = 0; k < F.depth; k++) F.sub[k].valid = 0;
   F.on = 1;
 }
@@ -1493,6 +1505,22 @@ static int flight_source_equal(VideoParameters *p_Vid, const uint8_t *raw)
   return 1;
 }
 
+/* place in display order of the n-th coded picture of the regular order I P B.. P B.. (NumberBFrames nb) */
+static long fl_disp(long n, int nb)
+{
+  if (n == 0 || nb == 0) return n;
+  { const long g = (n - 1) / (nb + 1), i = (n - 1) % (nb + 1); return i == 0 ? (g + 1) * (nb + 1) : g * (nb + 1) + i; }
+}
+/* a reference picture enters the sliding window (most recent first, `window` of them) */
+static void fl_store(int *slot, long *disp, int *n, int window, int s, long d)
+{
+  int a;
+  if (window > JMHIP_MB_MAX_REF) window = JMHIP_MB_MAX_REF;
+  for (a = imin(*n, window - 1); a > 0; a--) { slot[a] = slot[a - 1]; disp[a] = disp[a - 1]; }
+  slot[0] = s; disp[0] = d;
+  if (*n < window) (*n)++;
+}
+
 /* picture F.pic with the parameters JM really has: take the launch made ahead of time if it was given exactly these, else launch now; then launch ahead */
 static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
 {
@@ -1503,8 +1531,16 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
   hit = F.sub[e].valid && F.sub[e].pic == k && F.sub[e].slot == F.cur_slot && !memcmp(&F.sub[e].prm, prm, sizeof *prm) && flight_source_equal(p_Vid, F.sub[e].raw);
   if (hit) F.n_hit++;
   else {
-    for (j = 0; j < F.depth; j++)                           /* whatever is in flight was built on a picture that is not this one */
-      if (F.sub[j].valid && F.sub[j].pic >= k) { (void)jmhip_seq_wait(G.ctx, j); F.sub[j].valid = 0; F.n_void++; }
+    if (F.sub[e].valid && F.sub[e].pic == k && getenv("JMHIP_ADAPTER_DEBUG")) {          /* why a launch made ahead of time is not used */
+      size_t o = 0;
+      while (o < sizeof *prm && ((const unsigned char *)&F.sub[e].prm)[o] == ((const unsigned char *)prm)[o]) o++;
+      fprintf(stderr, "jmhip adapter: picture %ld (slice type %d) launched ahead of time is void: slot %d / %d, parameters differ from byte %zu of %zu (num_ref %d / %d, num_ref1 %d / %d, "
+                      "ref_slot %d %d %d %d / %d %d %d %d), source %s\n", k, prm->slice_type, F.sub[e].slot, F.cur_slot, o, sizeof *prm, F.sub[e].prm.num_ref, prm->num_ref, F.sub[e].prm.num_ref1, prm->num_ref1,
+              F.sub[e].prm.ref_slot[0], F.sub[e].prm.ref_slot[1], F.sub[e].prm.ref_slot[2], F.sub[e].prm.ref_slot[3], prm->ref_slot[0], prm->ref_slot[1], prm->ref_slot[2], prm->ref_slot[3],
+              flight_source_equal(p_Vid, F.sub[e].raw) ? "equal" : "differs");
+    }
+    for (j = 0; j < F.depth; j++)                           /* whatever is in flight was built on a picture that is not this one -- unless this one is a B picture: nothing is built on those */
+      if (F.sub[j].valid && (F.sub[j].pic == k || (F.sub[j].pic > k && prm->slice_type != B_SLICE))) { (void)jmhip_seq_wait(G.ctx, j); F.sub[j].valid = 0; F.n_void++; }
     rc = jmhip_seq_set_planes(G.ctx, e, p_Vid->pCurImg[0], (int)(p_Vid->pCurImg[1] - p_Vid->pCurImg[0]),
                               p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0]));
     if (rc) adapter_die("jmhip_seq_set_planes", rc);
@@ -1515,38 +1551,98 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
   F.tmpl[prm->slice_type] = *prm; F.have_tmpl[prm->slice_type] = 1;
   F.poc_step = k ? prm->poc_cur - F.poc_last : 2 * (1 + p_Inp->frame_skip);
   F.poc_last = prm->poc_cur; F.slot_poc[F.cur_slot] = prm->poc_cur;
-  /* ---- the next pictures: the frame from the file, the parameters of the last picture of the type the picture will have (IntraPeriod / IDRPeriod as
-   * get_idr_flag / set_slice_type apply them without B pictures; a wrong guess is found out above and costs the launch, never a byte) */
-  for (j = 1; j < F.depth && F.have_file; j++) {
-    const long n = k + j;
-    const int en = (int)(n % F.depth), sl = (int)(n % F.nring);
-    const int intra = (p_Inp->intra_period > 0 && n % p_Inp->intra_period == 0) || (p_Inp->idr_period > 0 && n % p_Inp->idr_period == 0);
-    jmhip_slice_params q;
-    int r, nref;
-    if (n >= F.total) break;
-    if (F.sub[en].valid && F.sub[en].pic == n) continue;    /* launched already */
-    if (!F.have_tmpl[intra ? I_SLICE : P_SLICE]) break;
-    q = F.tmpl[intra ? I_SLICE : P_SLICE];
-    if (!intra) {
-      /* list 0 of a P picture in a sliding window: the pictures before it, most recent first, as many as the last P picture had -- one more per picture while the window fills */
-      const int cap = p_Inp->P_List0_refs[0] ? imin(p_Inp->P_List0_refs[0], p_Vid->max_num_references) : p_Vid->max_num_references;
-      nref = imin(cap, (prm->slice_type == P_SLICE ? prm->num_ref : 0) + j);
-      if (p_Inp->idr_period > 0) nref = imin(nref, (int)(n % p_Inp->idr_period));
-      if (nref < 1) break;
-      q.num_ref = nref;
-      for (r = 0; r < JMHIP_MB_MAX_REF; r++) { q.ref_slot[r] = r < nref ? (int)((n - 1 - r) % F.nring) : 0; q.ref_id[r] = q.ref_slot[r]; }
+  /* ---- where the sequence stands: the picture's place in display order (from the frame JM read for it), the stored reference pictures as the sliding window now holds them */
+  if (k == 0) { F.first_frame_no = F.cur_frame_no; F.regular = 1; F.window = imax(1, (int)p_Vid->active_sps->num_ref_frames); F.st_n = 0; F.refcount = F.bcount = 0; }
+  {
+    const long disp = F.frame_step > 0 ? (F.cur_frame_no - F.first_frame_no) / F.frame_step : k;
+    if (disp != fl_disp(k, F.nb)) F.regular = 0;            /* (the sequence's tail: a last group of fewer pictures) -- nothing more is launched ahead of time */
+    if (prm->slice_type == B_SLICE) F.bcount++;
+    else {
+      if (p_Vid->currentPicture && p_Vid->currentPicture->idr_flag) F.st_n = 0;
+      fl_store(F.st_slot, F.st_disp, &F.st_n, F.window, F.cur_slot, disp);
+      F.refcount++;
     }
-    if (q.search_mode == 3) {                               /* EPZS scales its predictors by picture distances: the picture's own count continues the last step, its references' are the ring's */
-      q.poc_cur = F.poc_last + j * F.poc_step;
-      for (r = 0; r < JMHIP_MB_MAX_REF; r++) q.poc_ref[r] = (!intra && r < q.num_ref) ? F.slot_poc[q.ref_slot[r]] : 0;
-      F.slot_poc[sl] = q.poc_cur;
+  }
+  /* ---- the next pictures: the frame from the file, the parameters of the last picture of the type the picture will have (IntraPeriod / IDRPeriod as get_idr_flag /
+   * set_slice_type apply them without B pictures; with B pictures the regular order I P B.. P B.., the lists as init_lists_p_slice / init_lists_b_slice (list.c) build them in
+   * a sliding window; a wrong guess is found out above and costs the launch, never a byte) */
+  {
+    int sim_n = F.st_n, sim_slot[JMHIP_MB_MAX_REF + 1];
+    long sim_disp[JMHIP_MB_MAX_REF + 1], sim_ref = F.refcount, sim_b = F.bcount;
+    memcpy(sim_slot, F.st_slot, sizeof sim_slot); memcpy(sim_disp, F.st_disp, sizeof sim_disp);
+    for (j = 1; j < F.depth && F.have_file && F.regular; j++) {
+      const long n = k + j, d = fl_disp(n, F.nb);
+      const int en = (int)(n % F.depth);
+      const int isb = F.nb && (n - 1) % (F.nb + 1) != 0;
+      const int intra = !F.nb && ((p_Inp->intra_period > 0 && n % p_Inp->intra_period == 0) || (p_Inp->idr_period > 0 && n % p_Inp->idr_period == 0));
+      const int type = isb ? B_SLICE : intra ? I_SLICE : P_SLICE;
+      const int sl = isb ? F.nring + (int)(sim_b % F.nring_b) : (int)(sim_ref % F.nring);
+      jmhip_slice_params q;
+      int r, nref, ok = 1;
+      if (n >= F.total || d >= F.total) break;
+      if (!F.nb && p_Inp->idr_period > 0 && n % p_Inp->idr_period == 0) sim_n = 0;
+      if (!(F.sub[en].valid && F.sub[en].pic == n)) {         /* (else: launched already) */
+        if (!F.have_tmpl[type]) ok = 0;
+        else {
+          q = F.tmpl[type];
+          if (type == P_SLICE) {
+            /* list 0 of a P picture in a sliding window: the reference pictures before it, most recent first */
+            const int cap = p_Inp->P_List0_refs[0] ? imin(p_Inp->P_List0_refs[0], p_Vid->max_num_references) : p_Vid->max_num_references;
+            nref = imin(cap, sim_n);
+            if (nref < 1) ok = 0;
+            q.num_ref = nref;
+            for (r = 0; r < JMHIP_MB_MAX_REF; r++) { q.ref_slot[r] = r < nref ? sim_slot[r] : 0; q.ref_id[r] = q.ref_slot[r]; }
+          } else if (type == B_SLICE) {
+            /* list 0: the stored pictures before this one in display order, nearest first, then those after it, nearest first; list 1 the other way round; cut to
+             * B_List0_refs / B_List1_refs */
+            int l0[JMHIP_MB_MAX_REF + 1], l1[JMHIP_MB_MAX_REF + 1], n0 = 0, n1 = 0, a, pass;
+            const int cap0 = p_Inp->B_List0_refs[0] ? imin(p_Inp->B_List0_refs[0], p_Vid->max_num_references) : p_Vid->max_num_references;
+            const int cap1 = p_Inp->B_List1_refs[0] ? imin(p_Inp->B_List1_refs[0], p_Vid->max_num_references) : p_Vid->max_num_references;
+            for (pass = 0; pass < 2; pass++) {                /* pass 0: before (descending), pass 1: after (ascending); the stored pictures are few: selection by scanning */
+              long last = pass == 0 ? d : d;
+              for (;;) {
+                int best = -1;
+                for (a = 0; a < sim_n; a++) {
+                  if (pass == 0 ? (sim_disp[a] < last && (best < 0 || sim_disp[a] > sim_disp[best])) : (sim_disp[a] > last && (best < 0 || sim_disp[a] < sim_disp[best]))) best = a;
+                }
+                if (best < 0) break;
+                last = sim_disp[best];
+                if (pass == 0) l0[n0++] = sim_slot[best]; else l1[n1++] = sim_slot[best];
+              }
+            }
+            {                                                 /* l0 = before + after, l1 = after + before */
+              int b0 = n0, a1 = n1;
+              for (a = 0; a < a1; a++) l0[n0++] = l1[a];
+              for (a = 0; a < b0; a++) l1[n1++] = l0[a];
+            }
+            if (n1 > 1 && n0 == n1) {                         /* the two lists equal (no picture on one side): list 1's first two entries change places (list.c) */
+              int same = 1;
+              for (a = 0; a < n0; a++) same &= l0[a] == l1[a];
+              if (same) { const int t = l1[0]; l1[0] = l1[1]; l1[1] = t; }
+            }
+            n0 = imin(n0, cap0); n1 = imin(n1, cap1);
+            if (n0 < 1 || n1 < 1 || n0 + n1 > JMHIP_MB_MAX_REF) ok = 0;
+            q.num_ref = n0; q.num_ref1 = n1;
+            for (r = 0; r < JMHIP_MB_MAX_REF; r++) { q.ref_slot[r] = r < n0 ? l0[r] : r < n0 + n1 ? l1[r - n0] : 0; q.ref_id[r] = q.ref_slot[r]; }
+          }
+        }
+        if (ok && q.search_mode == 3) {                       /* EPZS scales its predictors by picture distances: the picture's own count continues the last step, its references' are the ring's */
+          q.poc_cur = F.poc_last + j * F.poc_step;
+          for (r = 0; r < JMHIP_MB_MAX_REF; r++) q.poc_ref[r] = (type == P_SLICE && r < q.num_ref) ? F.slot_poc[q.ref_slot[r]] : 0;
+          F.slot_poc[sl] = q.poc_cur;
+        }
+        if (ok) {
+          if (!F.sub[en].raw && !(F.sub[en].raw = (uint8_t *)malloc((size_t)F.frame_bytes))) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
+          if (pread(F.fd, F.sub[en].raw, (size_t)F.frame_bytes, (off_t)(F.header + F.frame_bytes * (F.first_frame_no + d * (long)F.frame_step + F.start_frame))) != (ssize_t)F.frame_bytes) break;
+          if ((rc = jmhip_seq_set_frame(G.ctx, en, F.sub[en].raw, F.src_w, F.src_h))) adapter_die("jmhip_seq_set_frame", rc);
+          if ((rc = jmhip_seq_encode(G.ctx, en, &q, sl, d8, 1, NULL))) adapter_die("jmhip_seq_encode (ahead of time)", rc);
+          F.sub[en].valid = 1; F.sub[en].pic = n; F.sub[en].slot = sl; F.sub[en].prm = q;
+          F.n_ahead++;
+        } else if (!isb) break;                               /* a reference picture that cannot be launched: the pictures behind it need it */
+      }
+      if (isb) sim_b++;
+      else { fl_store(sim_slot, sim_disp, &sim_n, F.window, sl, d); sim_ref++; }
     }
-    if (!F.sub[en].raw && !(F.sub[en].raw = (uint8_t *)malloc((size_t)F.frame_bytes))) { fprintf(stderr, "jmhip adapter: out of memory\n"); exit(70); }
-    if (pread(F.fd, F.sub[en].raw, (size_t)F.frame_bytes, (off_t)(F.header + F.frame_bytes * ((long)F.cur_frame_no + (long)j * F.frame_step + F.start_frame))) != (ssize_t)F.frame_bytes) break;
-    if ((rc = jmhip_seq_set_frame(G.ctx, en, F.sub[en].raw, F.src_w, F.src_h))) adapter_die("jmhip_seq_set_frame", rc);
-    if ((rc = jmhip_seq_encode(G.ctx, en, &q, sl, d8, 1, NULL))) adapter_die("jmhip_seq_encode (ahead of time)", rc);
-    F.sub[en].valid = 1; F.sub[en].pic = n; F.sub[en].slot = sl; F.sub[en].prm = q;
-    F.n_ahead++;
   }
   F.pic++;
 }
@@ -1568,7 +1664,8 @@ static void pipe_run_slice(Macroblock *currMB)
     flight_begin(p_Vid);
     if (F.on) {                                             /* the picture's place in the ring of slots; its source goes up in flight_launch (or went up ahead of time) */
       int s;
-      F.cur_entry = (int)(F.pic % F.depth); F.cur_slot = (int)(F.pic % F.nring);
+      F.cur_entry = (int)(F.pic % F.depth);
+      F.cur_slot = currSlice->slice_type == B_SLICE ? F.nring + (int)(F.bcount % F.nring_b) : (int)(F.refcount % F.nring);
       for (s = 0; s < G.nslots; s++) if (G.slot_pic[s] == p_Vid->enc_picture) G.slot_pic[s] = NULL;
       G.slot_pic[F.cur_slot] = p_Vid->enc_picture; G.slot_tick[F.cur_slot] = ++G.tick; G.slot_chroma[F.cur_slot] = 2;
     } else {
@@ -1596,7 +1693,8 @@ static void pipe_run_slice(Macroblock *currMB)
   if (currSlice->slice_type == B_SLICE) {                     /* list 1 behind list 0; the switches of the B slices' decision (include/jmhip.h: b_switches) */
     prm.num_ref1 = currSlice->listXsize[LIST_1];
     for (r = 0; r < prm.num_ref1; r++) {
-      prm.ref_slot[prm.num_ref + r] = slot_with_chroma(currSlice->listX[LIST_1][r]);
+      prm.ref_slot[prm.num_ref + r] = F.on ? slot_find(currSlice->listX[LIST_1][r]) : slot_with_chroma(currSlice->listX[LIST_1][r]);
+      if (prm.ref_slot[prm.num_ref + r] < 0) { fprintf(stderr, "jmhip adapter: pictures in flight: list-1 reference %d of picture %ld is not a picture the device holds\n", r, F.pic); exit(70); }
       prm.ref_id[prm.num_ref + r] = prm.ref_slot[prm.num_ref + r];
     }
     prm.b_switches = (p_Vid->active_sps->direct_8x8_inference_flag ? 1 : 0);

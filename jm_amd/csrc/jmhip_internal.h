@@ -9,6 +9,8 @@
 #define JMHIP_NKINDS 6
 
 // A picture in flight (jmhip_seq_*, mbpipe_host.inc): everything one launch of the macroblock pipeline owns, so that launches of consecutive pictures can run side by side
+#define JMHIP_SEQ_LAUNCH_EVENTS 256
+#define JMHIP_SEQ_SLOT_READERS 40
 struct jmhip_seq_entry {
   hipStream_t stream;
   hipEvent_t done;       // recorded behind the entry's launch (a B picture: behind its loop filter)
@@ -91,7 +93,13 @@ struct jmhip_ctx {
   unsigned **d_slot_post;// [num_ref_slots] per macroblock: slot_tag once the macroblock is filtered and interpolated
   unsigned *slot_tag;    // [num_ref_slots] tag of the slot's current / last picture made by a sequence launch
   int *slot_entry;       // [num_ref_slots] entry that makes / made the slot's picture, -1: filled by jmhip_set_reference* / jmhip_reference_from_recon
+  // who still reads or writes a slot, launch by launch (an entry's `done` event is re-recorded by the entry's next launch: with B pictures in flight the host is entries
+  // ahead of the device, and waiting for "the entry" would be waiting for the wrong picture): every sequence launch takes an event of its own from a pool
+  hipEvent_t *launch_ev; int launch_ev_next;                    // JMHIP_SEQ_LAUNCH_EVENTS of them, taken in turn (one is reused after that many launches: complete by then, or waited for)
+  hipEvent_t *slot_wev;                                         // [num_ref_slots] the launch that writes / wrote the slot's picture (null: none)
+  hipEvent_t *slot_rev; int *slot_nrev;                         // [num_ref_slots][JMHIP_SEQ_SLOT_READERS] launches reading the slot's picture since; their number (-1: more than fit -- wait for everything)
   hipEvent_t seq_ev;     // orders the context's own stream before an entry's
+  int seq_b_grid;        // workgroups of a B picture in flight (0: seq_grid)
   hipStream_t bdb_stream; hipEvent_t bdb_ev; int bdb_used;     // B pictures in flight: the stream their loop filters run on one after the other, and the last one's event
   // several pictures in ONE launch (jmhip_seq_batch): per picture a source picture, edge records, flags and loop-filter side information at a fixed stride; the
   // pictures' descriptors and the ticket order of the last batch

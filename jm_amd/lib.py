@@ -111,7 +111,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_set_reference_chroma", "jmhip_set_reference_chroma_dev", "jmhip_get_chroma_subplanes", "jmhip_mc_luma", "jmhip_mc_luma_dev", "jmhip_mc_chroma", "jmhip_mc_chroma_dev", "jmhip_mc_luma_wp", "jmhip_mc_luma_wp_dev", "jmhip_mc_chroma_wp", "jmhip_mc_chroma_wp_dev", "jmhip_distortion", "jmhip_intrapred4x4", "jmhip_intrapred8x8", "jmhip_intra_chroma", "jmhip_intra_chroma_dev", "jmhip_intra16_search", "jmhip_intra16_search_dev", "jmhip_mc_mb16_dev", "jmhip_tq_rec_to_plane_dev", "jmhip_mb16_recon_luma_dev", "jmhip_mc_mb16_chroma_dev", "jmhip_tqc_rec_to_planes_dev", "jmhip_tq_chroma_dev",
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
            "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
-           "jmhip_seq_open", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_planes", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
+           "jmhip_seq_open", "jmhip_seq_b_workgroups", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_planes", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
            "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_seq_batch_reserve", "jmhip_allgather_bands"]
 
 
@@ -645,6 +645,9 @@ class JmHip:
 
     def seq_set_frame_dev(self, entry, d_raw, src_w, src_h):
         self._ck(self.lib.jmhip_seq_set_frame_dev(self.h, int(entry), _vp(d_raw), src_w, src_h))
+
+    def seq_b_workgroups(self, workgroups):
+        self._ck(self.lib.jmhip_seq_b_workgroups(self.h, int(workgroups)))
 
     def seq_encode(self, entry, prm, out_slot, direct8x8=1, to_host=False, d_out=None):
         prm = np.ascontiguousarray(prm, SLICE_PARAMS).reshape(1)

@@ -453,6 +453,27 @@ def test_lencod_pictures_in_flight_are_verified_not_trusted(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["m3b", "m2b4"])
+def test_lencod_b_pictures_are_launched_ahead_of_time_too(tmp_path, tag):
+    """Sequences with B pictures (coding order I P B P B ...): the adapter predicts the order, the frames' places in the file and both reference lists of the pictures to come
+    (a sliding window's init_lists_p_slice / init_lists_b_slice) and launches them ahead of time -- the B pictures beside the P pictures that follow them --, every launch
+    checked against what JM really has when it gets there.  Pictures must have been served as launched, none voided, the bytes CPU JM's."""
+    import re as _re
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, z = run_rdo_off_case(tag, str(tmp_path))
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, err[-1500:]
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]) and md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), (tag, "differs from CPU JM")
+    m = _re.search(r"pictures in flight: (\d+) pictures, (\d+) launched ahead of time \(up to (\d+) in flight\), (\d+) of them served as launched, (\d+) voided", err)
+    assert m, err[-1500:]
+    pics, ahead, depth, hit, void = (int(x) for x in m.groups())
+    npic = len(z["slice_type"])
+    # the first B picture is launched when JM gets there (no B picture's parameters are known before); from then on everything is launched ahead
+    assert pics == npic and hit >= npic - 3 and void == 0, (tag, m.groups())
+
+
+@pytest.mark.gpu
 def test_lencod_configs3_full_size_2160p_per_call(tmp_path):
     """BASELINE.json configs[3] as SURVEY.md 8c states it (G4: RDO on, 2160p, 8 slices, md5 933ebd28...): the per-call path (every BlockMotionSearch of
     the P picture on the device one by one, sub-pel planes, deblocking), as the 1080p test does for configs[1].  Minutes, not seconds."""
