@@ -89,6 +89,38 @@ while time.time() - t0 < budget:
             ov.update(IDRPeriod=int(rng.choice([2, 3])))
         if rng.integers(0, 8) == 0:
             ov.update(ChangeQPFrame=2, ChangeQPI=int(rng.integers(10, 45)), ChangeQPP=int(rng.integers(10, 45)))
+    if seed >= 3000000:                                       # sequences with B pictures (round 5): what the pipeline takes (non-reference, spatial direct, full searches) and what it turns away
+        nb = int(rng.choice([1, 1, 2, 3]))
+        ov.update(NumberBFrames=nb, ProfileIDC=max(prof, 77), DirectModeType=int(rng.choice([1, 1, 1, 1, 0])), DirectInferenceFlag=int(rng.integers(0, 2)), QPBSlice=int(rng.integers(10, 45)),
+                  BiPredMotionEstimation=int(rng.integers(0, 3) > 0), FramesToBeEncoded=int(rng.integers(3, 10)), IntraPeriod=int(rng.choice([0, 0, 0, 0, 4])))
+        if ov["BiPredMotionEstimation"]:
+            ov.update(BiPredMERefinements=int(rng.integers(0, 4)), BiPredMESearchRange=int(rng.choice([r for r in (2, 4, 8, 16, 16, 16, 32) if r <= int(ov["SearchRange"])] or [int(ov["SearchRange"])])),
+                      BiPredMESubPel=int(rng.integers(0, 3)), BiPredSearch16x16=int(rng.integers(0, 4) > 0), BiPredSearch16x8=int(rng.integers(0, 2)), BiPredSearch8x16=int(rng.integers(0, 2)),
+                      BiPredSearch8x8=int(rng.integers(0, 6) == 0))
+        if rng.integers(0, 2):
+            ov.update(BList0References=int(rng.integers(0, int(ov["NumberReferenceFrames"]) + 1)), BList1References=int(rng.integers(0, 3)))
+        if rng.integers(0, 4) == 0:
+            for k in ("16x16", "16x8", "8x16", "8x8", "8x4", "4x8", "4x4"):
+                ov["BSliceSearch" + k] = int(rng.integers(0, 4) > 0)
+            ov["BSliceDirect"] = int(rng.integers(0, 3) > 0)
+            if t8:
+                ov["BSliceSearch8x8"] = 1
+        if "DFParametersFlag" in ov:
+            for k in ("RefBSlice", "NRefBSlice"):
+                ov["DFDisable" + k] = int(rng.choice([0, 0, 1, 2])); ov["DFAlpha" + k] = int(rng.integers(-3, 4)); ov["DFBeta" + k] = int(rng.integers(-3, 4))
+        if rng.integers(0, 10) == 0:
+            ov.update(BReferencePictures=1)
+        if rng.integers(0, 10) == 0:
+            ov.update(HierarchicalCoding=int(rng.choice([1, 2])))
+        if rng.integers(0, 6) == 0:
+            ov.update(WeightedBiprediction=int(rng.choice([1, 2])))
+        ov.pop("ChangeQPFrame", None); ov.pop("ChangeQPI", None); ov.pop("ChangeQPP", None)
+    if os.environ.get("FUZZ_LIST"):                            # (the generator alone: which seed made a configuration)
+        print(seed, (sw, sh), ov, flush=True)
+        seed += 1; done += 1
+        if done >= int(os.environ["FUZZ_LIST"]):
+            break
+        continue
     tmp = tempfile.mkdtemp(prefix="fz_")
     try:
         nsrc = (int(ov["FramesToBeEncoded"]) - 1) * (1 + int(ov.get("FrameSkip", 0))) + 1
@@ -99,7 +131,12 @@ while time.time() - t0 < budget:
             args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
             for k, v in dict(ov, OutputFile=f"{tag}.264", ReconFile=f"{tag}.yuv", TraceFile="/dev/null").items():
                 args += ["-p", f"{k}={v}"]
-            r = subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            env = dict(os.environ)
+            if exe == HIP and int(ov.get("NumberBFrames", 0)) and int(ov.get("BiPredMotionEstimation", 0)):
+                # a sequence the pipeline turns away falls to the per-call kernels, and the bi-predictive full search then asks for millions of single candidate distortions, a
+                # round trip each (part evalp; covered by the fixed cases G3a / G3b / G3w / G3wb of tests/test_lencod_dropin.py): every part but that one
+                env["JMHIP_ADAPTER_PARTS"] = "interp,fs,subpel,ffs,deblock,tq4,tq8,tqc,tq16,mcl,mcc,eval,evalbatch,ip4,ip8,i16,ic,interpc,load,mbpipe,nulltrace,readframe"
+            r = subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
             res.append(r)
         if os.environ.get("FUZZ_CPU_ONLY"):                    # (a dry run of the generator where there is no GPU: does JM take the configuration?)
             print(seed, res[0].returncode, res[0].stderr.decode(errors="replace")[-200:] if res[0].returncode else "", flush=True)
