@@ -111,6 +111,7 @@ struct PipeArgs {
   int W, H, wmb, hmb, cw, ch;
   unsigned role_perm;                        // role of hardware wave w = nibble w: which chain a wave runs (0-3 the P8x8 sub-modes, 4 16x16 + Intra16x16 + chroma decision, 5 16x8,
                                              // 6 8x16, 7 the Intra4x4 chain).  Waves w and w + 4 share a SIMD: the pairing decides who competes with the 4x4 chain for issue slots
+  int help;                                  // P pictures of the full searches with several references: waves that are done with their own role take references of the sub-mode waves' passes
   int c422;                                  // 4:2:2: chroma planes cw x H, 8 x 16 samples per macroblock (ch = H); else 4:2:0
   int total_mb;                              // tickets of the launch: macroblocks of num_slices slices of p.num_mb, cut at the end of the picture -- or of every picture of a batch
   int nbands, band_start[9];                 // 8 (or 1): the ticket order is cut into bands of macroblock rows, tickets band_start[b] .. band_start[b + 1] - 1 belong to band b, and
@@ -193,6 +194,11 @@ struct Shared {
                                              // everything left of and above it is filtered and interpolated (mbpipe_post.inc)
   int nbflag;                                // the neighbours' samples are in nb (running count over the launch)
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
+  // Several references, full searches: the passes of a sub-mode over the references are independent of each other until the costs are compared, so a wave that has finished its
+  // own role (4-7) takes references of sub-mode wave (role - 4)'s current 8x8 block (search_phase)
+  int hword[4];                              // per sub-mode wave: (phase number << 8) | next reference to take -- taken with a compare-and-swap by the wave itself and by its helper
+  int hcomp[4];                              // ... references of the phase whose pass is complete
+  int sbt[4][JMHIP_MB_MAX_REF];              // ... the passes' costs, by reference (the sub-mode wave compares them in JM's order once all are in)
   u32 ytab4[4][72];                          // the same for the four usual offsets of the predictor from the search centre (-2 .. 1 quarter-pels), full range: once per launch
   u32 ytab[8][72];                           // per wave: what a search's candidate row contributes to every key: (lambda * bits(vy - py)) << 8 | zero row << 7 | far rank
   int fin_mv[16], fin_ref[16], fin_type, fin_cbp;
