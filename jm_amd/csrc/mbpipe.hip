@@ -157,7 +157,7 @@ struct PostShared {
 
 // per-workgroup state in LDS
 struct Shared {
-  u32 cur_y[64];                             // the source macroblock, 16 rows of 4 dwords
+  alignas(16) u32 cur_y[64];                 // the source macroblock, 16 rows of 4 dwords
   u32 cur_c[2][32];                          // U, V: 8 (4:2:0) or 16 (4:2:2) rows of 2 dwords
   u64 nb[4][EDGE_WORDS];                     // edge records of A (left), B (up), C (up-right), D (up-left)
   u32 ptab[8][16];                           // mv_predictor's neighbour table: per (block type, 4x4 position of the block) four codes A, B, C, D (once per launch)
@@ -196,6 +196,7 @@ struct Shared {
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
   // Several references, full searches: the passes of a sub-mode over the references are independent of each other until the costs are compared, so a wave that has finished its
   // own role (4-7) takes references of sub-mode wave (role - 4)'s current 8x8 block (search_phase)
+  int prof_addr;                             // JMHIP_MB_PROF (B slices): the macroblock the time stamps belong to
   int hword[4];                              // per sub-mode wave: (phase number << 8) | next reference to take -- taken with a compare-and-swap by the wave itself and by its helper
   int hcomp[4];                              // ... references of the phase whose pass is complete
   int sbt[4][JMHIP_MB_MAX_REF];              // ... the passes' costs, by reference (the sub-mode wave compares them in JM's order once all are in)
@@ -228,7 +229,7 @@ struct Shared {
   int p8b_cost[4][5], p8b_info[4][5];        // [block][0 direct, 1..4 modes 4..7]
   int p8_info[4], p8t_info[4];               // the parts the tr4x4 / tr8x8 pass of P8x8 decided
   int fin_mv1[16], fin_ref1[16];             // the macroblock's final LIST_1 vectors and reference indices
-  u8 bpred[8][256];                          // per wave: a prediction being priced
+  alignas(16) u8 bpred[8][256];              // per wave: a prediction being priced
   __attribute__((aligned(4))) u8 bireg[3][48 * 52];   // waves 4..6: the samples a bi-predictive search's candidates cover (range <= 16: 48 rows of 52 bytes)
   jmhip_mb_record out;
   PostShared post;

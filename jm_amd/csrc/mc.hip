@@ -18,7 +18,7 @@ static_assert(sizeof(jmhip_mc_weights) == 12, "jmhip_mc_weights is 12 bytes in i
 
 struct __attribute__((packed)) u32un { uint32_t v; };
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const u32un *)p)->v; }
-__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }   // v_lerp_u8, round bit set: per byte (a + b + 1) >> 1
 
 // 16 lanes per block; a lane copies every 16th group of four samples (one group for 4x4 .. 8x8, four for 16x16)
 // weighted sample prediction (mc_prediction.c:38-73): one list clip1(((w * p + round) >> shift) + offset), both lists

@@ -98,7 +98,7 @@ class SeqEncoder:
             slice_nr[first:first + num] = sn
         pre = [p.copy() for p in pic.rec]
         mbs, mot = db_side_info(recs, slice_nr, 1, qp_b, (qpc, qpc + (self.qpc_cr_delta_p if qpc_cr_delta_b is None else qpc_cr_delta_b)), W, H, [r[2] for r in L0], self.disable_idc, [r[2] for r in L1])
-        y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], self.yuv_format, mbs, mot)
+        y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], self.yuv_format, mbs, mot, d8=int((b or {}).get("direct_8x8_inference", 1)))     # (loopFilter.c:180: a direct macroblock's inner edges)
         self.npic += 1
         return recs, dbg, pre, (y, u, v)
 
