@@ -1,4 +1,4 @@
-# round 4, the bench as it is now (the timed P pictures in ONE launch): bench.py without and with rocprofv3, plus the two PMC passes; usage: bash profiles/collect5.sh <tag>
+# round 4 / 5, the bench as it is now (the timed P pictures in ONE launch): bench.py without and with rocprofv3, plus the two PMC passes; usage: bash profiles/collect5.sh <tag>
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; rm -rf $O; mkdir -p $O
