@@ -219,6 +219,12 @@ struct Shared {
   int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
   u64 fl_cbp_blk, fc_bits;
   u32 fin_cbp_blk;
+  jmhip_mb_record out;
+  PostShared post;
+  PicView V;                                 // the picture the workgroup's current macroblock belongs to
+  PicView Vp;                                // ... and the one its PREVIOUS macroblock belonged to: that macroblock's post stage runs beside this one's staging (mbpipe_kernel.inc)
+  // ---- from here on: B slices only.  The other kernels' dynamic region (the references' windows / the EPZS tables) starts HERE (SHARED_COMMON): with two four-wave EPZS
+  // workgroups per compute unit every KB counts twice
   // B slices (mbpipe_b.inc).  References are numbered through both lists: list 0's first, then list 1's (S.allmv, the windows, PicView::ref_y).
   int mvi1[8][16][2];                        // per wave: mv_info of LIST_1 as that wave's chain sees it
   int bpmv[2][2][4][16];                     // currSlice->bipred_mv[set][list][0][mode 1..3][4x4 raster]
@@ -231,11 +237,9 @@ struct Shared {
   int fin_mv1[16], fin_ref1[16];             // the macroblock's final LIST_1 vectors and reference indices
   alignas(16) u8 bpred[8][256];              // per wave: a prediction being priced
   __attribute__((aligned(4))) u8 bireg[3][48 * 52];   // waves 4..6: the samples a bi-predictive search's candidates cover (range <= 16: 48 rows of 52 bytes)
-  jmhip_mb_record out;
-  PostShared post;
-  PicView V;                                 // the picture the workgroup's current macroblock belongs to
-  PicView Vp;                                // ... and the one its PREVIOUS macroblock belonged to: that macroblock's post stage runs beside this one's staging (mbpipe_kernel.inc)
 };
+#define SHARED_COMMON ((offsetof(Shared, mvi1) + 15) & ~(size_t)15)      // what the P / I kernels keep of Shared
+#define SHARED_ALL ((sizeof(Shared) + 15) & ~(size_t)15)
 extern __shared__ __attribute__((aligned(16))) u8 mb_smem[];
 #define PV (((Shared *)mb_smem)->V)
 #define PVP (((Shared *)mb_smem)->Vp)
