@@ -126,8 +126,8 @@ def run_lencod(exe, frames, timeout, flags=None, clip=None, cfg_name="jm_baselin
             return None
         out, err = r.stdout.decode(errors="replace"), r.stderr.decode(errors="replace")
         times = {}
-        for m in re.finditer(r"^\s*\d+\(\s*(IDR|I|P)\s*\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", out, re.M):
-            times.setdefault("P" if m.group(1) == "P" else "I", []).append(int(m.group(2)))
+        for m in re.finditer(r"^\s*\d+\(\s*(IDR|I|P|B)\s*\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", out, re.M):
+            times.setdefault(m.group(1) if m.group(1) in ("P", "B") else "I", []).append(int(m.group(2)))
         rep = re.search(r"jmhip adapter: macroblock pipeline: .*", err)
         return times, hashlib.md5(open(os.path.join(tmp, "o.264"), "rb").read()).hexdigest(), rep.group(0) if rep else None, wall
 
@@ -242,6 +242,28 @@ def configs4_end_to_end(max_seconds=400):
                                            "P pictures only, q_offset.cfg's quantiser offsets", "kernel": "k_mb_pipe_t8",
             "p_frame_ms_cpu_jm": c[0].get("P"), "p_frame_ms_hip": h[0].get("P"), "wall_s_cpu_jm": round(c[3], 2), "wall_s_hip": round(h[3], 2),
             "speedup_p_frames": round(sum(c[0]["P"]) / max(1, sum(h[0]["P"])), 2), "md5_equal": c[1] == h[1], "md5_is_g4y": h[1] == str(z["md5_264"]), "adapter": h[2]}
+
+
+def b_pictures_end_to_end(max_seconds=400):
+    """encoder_main.cfg with RDO off at 1080p through the drop-in encoder (tests/golden/mb_low_g3b.npz: I P B, the .264's md5 is CPU JM's), CPU JM beside it on the same three
+    pictures; then nine pictures (I P B P B ...) for the later pictures' times -- the adapter launches P and B pictures ahead of time, the B pictures beside the P pictures after them."""
+    cpu_exe, hip_exe = os.path.join(ROOT, "oracle", "_ref", "lencod.exe"), os.path.join(ROOT, "oracle", "_ref", "lencod_hip.exe")
+    if not all(os.path.exists(e) and os.access(e, os.X_OK) for e in (cpu_exe, hip_exe)):
+        return {"available": False, "why": "oracle/_ref/lencod.exe / lencod_hip.exe did not travel"}
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3b.npz"))
+    flags = tuple(str(f) for f in z["overrides"] if not str(f).startswith("FramesToBeEncoded")) + ("OutputFile=o.264", "ReconFile=o_rec.yuv", "TraceFile=/dev/null")
+    try:
+        c = run_lencod(cpu_exe, 3, max_seconds, flags, cfg_name=str(z["cfg"]))
+        h = run_lencod(hip_exe, 3, max_seconds, flags, cfg_name=str(z["cfg"]))
+        h9 = run_lencod(hip_exe, 9, max_seconds, flags, cfg_name=str(z["cfg"]))
+    except subprocess.TimeoutExpired:
+        return {"available": False, "why": "timeout"}
+    if not c or not h or not h9:
+        return {"available": False, "why": "an encoder failed"}
+    return {"available": True, "p_frame_ms_cpu_jm": c[0].get("P"), "b_frame_ms_cpu_jm": c[0].get("B"), "p_frame_ms_hip": h[0].get("P"), "b_frame_ms_hip": h[0].get("B"),
+            "wall_s_cpu_jm": round(c[3], 2), "wall_s_hip": round(h[3], 2), "md5_equal": c[1] == h[1], "md5_is_g3b": h[1] == str(z["md5_264"]),
+            "speedup_b_frame": round(sum(c[0].get("B", [0])) / max(1, sum(h[0].get("B", [1]))), 2),
+            "nine_pictures": {"p_frame_ms_hip": h9[0].get("P"), "b_frame_ms_hip": h9[0].get("B"), "wall_s_hip": round(h9[3], 2)}, "adapter": h9[2]}
 
 
 def configs3_end_to_end(max_seconds=400):
@@ -1017,7 +1039,7 @@ def main():
             out["end_to_end"] = end_to_end(cpu)
         if not args.no_end_to_end and N == 1:
             out["configs2"] = dict(configs2_device, end_to_end=configs2_end_to_end())
-            out["b_pictures"] = b_pictures_leg(local, frames, src_h, nmb, args.flight)
+            out["b_pictures"] = dict(b_pictures_leg(local, frames, src_h, nmb, args.flight), end_to_end=b_pictures_end_to_end())
             out["configs3"] = dict(configs3_end_to_end(), device=configs3_device(local))
             out["configs4"] = configs4_end_to_end()
         if args.streams > 1 and N == 1:
