@@ -506,7 +506,7 @@ def b_pictures_leg(local, frames, src_h, nmb, flight):
     ngop = 12
     # entries: the P pictures' and the B pictures' own (a B macroblock takes ~600 us of a workgroup's time, a P macroblock of this search ~200; the B pictures are what fills
     # the chip, the P pictures only have to stay ahead of them).  JMHIP_BENCH_B="P entries,B entries,workgroups per P picture,per B picture": measurement aid
-    n_p, n_b, wg_p, wg_b = (int(x) for x in os.environ.get("JMHIP_BENCH_B", "4,6,24,32").split(","))
+    n_p, n_b, wg_p, wg_b = (int(x) for x in os.environ.get("JMHIP_BENCH_B", "4,6,32,32").split(","))
     depth = n_p + n_b
     nring = 2 + n_p + 2                                                  # reference pictures: the window of two + those in flight + two
     nslots = nring + n_b + 1                                             # ... and the B pictures' own slots behind them
