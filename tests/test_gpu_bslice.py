@@ -142,7 +142,7 @@ def raw_frames(c, tag):
     return [data[n * fs:(n + 1) * fs] for n in range(c["nfr"])]
 
 
-def replay_in_flight(dev, depth, workgroups=0, stream_records=False):
+def replay_in_flight(dev, depth, workgroups=0, stream_records=False, b_workgroups=0):
     """The pictures of a finished picture-after-picture run (dev.log) once more through jmhip_seq_* with `depth` pictures in flight: the P pictures follow their references
     macroblocks apart inside the device, a B picture starts when both its references are complete and runs beside the P pictures after them.  Returns per picture
     (records, filtered planes)."""
@@ -151,6 +151,8 @@ def replay_in_flight(dev, depth, workgroups=0, stream_records=False):
     nslots = max(dev.num_ref, dev.keep) + depth + 1
     J = L.JmHip(dev.W, dev.H, search_range=max(dev.R, 1), num_ref_slots=nslots, yuv_format=dev.yuv_format)
     J.seq_open(depth, workgroups)
+    if b_workgroups:
+        J.seq_b_workgroups(b_workgroups)               # the B pictures' own share (jmhip_seq_b_workgroups)
     slot_of, stored, pending, out = {}, [], {}, {}          # picture id -> slot; ids of the stored references (most recent first); picture number -> slot, not collected yet
     keep = max(dev.num_ref, dev.keep)
 
@@ -213,6 +215,6 @@ def test_b_picture_1080p_equals_the_reference_encoder():
 
 # B pictures in flight (jmhip_seq_encode with slice_type 1): the sequences of the goldens once more with 3 / 6 pictures in flight -- P pictures following their references inside
 # the device, B pictures beside the P pictures after them --: every record and every filtered picture as picture after picture (which the tests above pin to the real encoder)
-@pytest.mark.parametrize("tag,flight", [("m3b", (3, 0, False)), ("m3b0", (6, 20, True)), ("m2b4", (4, 0, True)), ("q5yb", (3, 0, False)), ("q1b", (2, 0, False))])
+@pytest.mark.parametrize("tag,flight", [("m3b", (3, 0, False)), ("m3b0", (6, 20, True, 48)), ("m2b4", (4, 0, True, 7)), ("q5yb", (3, 0, False)), ("q1b", (2, 0, False))])
 def test_b_pictures_in_flight_equal_picture_after_picture(tag, flight):
     run_case_b(tag, check_oracle_post=False, flight=flight)
