@@ -474,6 +474,20 @@ def test_lencod_b_pictures_are_launched_ahead_of_time_too(tmp_path, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("depth", ["0", "2", "3", "10"])
+def test_lencod_b_pictures_with_any_number_of_pictures_in_flight(tmp_path, depth):
+    """m3b (I P B P B P B, three references, the bi-predictive search) with JMHIP_ADAPTER_FLIGHT = 0 (off: picture after picture), 2, 3 (fewer entries than a group of pictures
+    needs ahead) and 10: the same bytes as CPU JM's whatever the depth."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    r, z = run_rdo_off_case("m3b", str(tmp_path), env_extra={"JMHIP_ADAPTER_FLIGHT": depth})
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, err[-1500:]
+    assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]) and md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), (depth, "differs from CPU JM", err[-600:])
+    assert ("pictures in flight:" in err) == (depth != "0"), err[-800:]
+
+
+@pytest.mark.gpu
 def test_lencod_configs3_full_size_2160p_per_call(tmp_path):
     """BASELINE.json configs[3] as SURVEY.md 8c states it (G4: RDO on, 2160p, 8 slices, md5 933ebd28...): the per-call path (every BlockMotionSearch of
     the P picture on the device one by one, sub-pel planes, deblocking), as the 1080p test does for configs[1].  Minutes, not seconds."""
