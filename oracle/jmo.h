@@ -328,13 +328,18 @@ typedef struct {                /* intermediate values, for localising a diverge
 /* B slices (jmo_mbenc_b.inc): what the slice has beside cfg (cfg->num_ref = listXsize[LIST_0], cfg->inter_valid = InterSearch[1][..]: [0] = BSliceDirect) */
 typedef struct jmo_b_cfg_s {
   int32_t num_ref1;             /* currSlice->listXsize[LIST_1] */
-  int32_t direct_8x8_inference; /* active_sps->direct_8x8_inference_flag (DirectModeType must be 1: spatial) */
+  int32_t direct_8x8_inference; /* active_sps->direct_8x8_inference_flag */
   int32_t col_long_term;        /* listX[LIST_1][0]->is_long_term */
   int32_t bipred_me;            /* BiPredMotionEstimation */
   int32_t bipred_search[4];     /* BiPredSearch16x16 / 16x8 / 8x16 / 8x8 (p_Vid->bipred_enabled[1..4], slice.c:410) */
   int32_t bipred_refinements, bipred_range, bipred_subpel;   /* BiPredMERefinements, BiPredMESearchRange, BiPredMESubPel */
   const int8_t *col_ref;        /* listX[LIST_1][0]->mv_info[..].ref_idx[list] at [(y4 * w4 + x4) * 2 + list] */
   const int16_t *col_mv;        /* ... .mv[list] {x, y} at [((y4 * w4 + x4) * 2 + list) * 2] */
+  /* DirectModeType 0 (temporal direct, Get_Direct_MV_Temporal mv_direct.c:40; frame pictures): */
+  int32_t direct_temporal;      /* !currSlice->direct_spatial_mv_pred_flag */
+  int32_t poc_cur, poc_l0[16], poc_l1_0;   /* enc_picture->poc, listX[LIST_0][i]->poc, listX[LIST_1][0]->poc: compute_colocated's mvscale (mbuffer.c:3122) and the mapping of the
+                                              co-located block's reference picture into list 0 */
+  const int32_t *col_refpoc;    /* listX[LIST_1][0]->mv_info[..].ref_pic[list]->poc at [(y4 * w4 + x4) * 2 + list] (only read where col_ref >= 0) */
 } jmo_b_cfg;
 
 /* refs / refc: list 0, refs1 / refc1: list 1; mv / ref_idx: list 0 of enc_picture->mv_info, mv1 / ref_idx1: list 1 */

@@ -498,7 +498,8 @@ assert MB_RECORD.itemsize == 1296
 class BCfg(C.Structure):
     """jmo_b_cfg: what a B slice has beside MbEncCfg"""
     _fields_ = [("num_ref1", C.c_int32), ("direct_8x8_inference", C.c_int32), ("col_long_term", C.c_int32), ("bipred_me", C.c_int32), ("bipred_search", C.c_int32 * 4),
-                ("bipred_refinements", C.c_int32), ("bipred_range", C.c_int32), ("bipred_subpel", C.c_int32), ("col_ref", C.c_void_p), ("col_mv", C.c_void_p)]
+                ("bipred_refinements", C.c_int32), ("bipred_range", C.c_int32), ("bipred_subpel", C.c_int32), ("col_ref", C.c_void_p), ("col_mv", C.c_void_p),
+                ("direct_temporal", C.c_int32), ("poc_cur", C.c_int32), ("poc_l0", C.c_int32 * 16), ("poc_l1_0", C.c_int32), ("col_refpoc", C.c_void_p)]
 
 
 def mbenc_cfg(width, height, slice_type, first_mb, num_mb, qp, R, num_ref, lambda_mf, lambda_mdfp, level_mv=(-8192, 8191, -2048, 2047),
@@ -619,7 +620,8 @@ def encode_slice(cfg, cur, refs, refc, pic, debug=False, epzs=None):
 
 def encode_slice_b(cfg, b, cur, refs0, refc0, refs1, refc1, pic, debug=False):
     """A B slice (jmo_encode_slice_b): cfg.slice_type 1, cfg.num_ref = size of list 0; b: dict(num_ref1, direct_8x8_inference, col_ref (h4, w4, 2) int8, col_mv (h4, w4, 2, 2) int16 =
-    the motion of listX[LIST_1][0], col_long_term, bipred_me, bipred_search[4], bipred_refinements, bipred_range, bipred_subpel); refs0 / refc0, refs1 / refc1: the lists' RefPic / chroma planes"""
+    the motion of listX[LIST_1][0], col_long_term, bipred_me, bipred_search[4], bipred_refinements, bipred_range, bipred_subpel; with direct_temporal: poc_cur, poc_l0[], poc_l1_0,
+    col_refpoc (h4, w4, 2) int32 = the picture order counts of the co-located blocks' reference pictures); refs0 / refc0, refs1 / refc1: the lists' RefPic / chroma planes"""
     cy, cu, cv = [np.ascontiguousarray(p, np.uint16) for p in cur]
     n = cfg.num_mb
     out = np.zeros(n, MB_RECORD)
@@ -645,6 +647,13 @@ def encode_slice_b(cfg, b, cur, refs0, refc0, refs1, refc1, pic, debug=False):
     bc.bipred_refinements, bc.bipred_range, bc.bipred_subpel = int(b.get("bipred_refinements", 3)), int(b.get("bipred_range", 16)), int(b.get("bipred_subpel", 2))
     cr, cm = np.ascontiguousarray(b["col_ref"], np.int8), np.ascontiguousarray(b["col_mv"], np.int16)
     bc.col_ref, bc.col_mv = cr.ctypes.data, cm.ctypes.data
+    crp = None
+    if b.get("direct_temporal", 0):                          # DirectModeType 0: the picture order counts of the picture, of list 0 and of list 1's first picture; the co-located blocks' reference pictures'
+        bc.direct_temporal, bc.poc_cur, bc.poc_l1_0 = 1, int(b["poc_cur"]), int(b["poc_l1_0"])
+        for i, v in enumerate(b["poc_l0"]):
+            bc.poc_l0[i] = int(v)
+        crp = np.ascontiguousarray(b["col_refpoc"], np.int32)
+        bc.col_refpoc = crp.ctypes.data
     r = L.jmo_encode_slice_b(C.byref(cfg), C.byref(bc), _p(cy), _p(cu), _p(cv), ra0, pa0, ra1, pa1, _p(pic.rec[0]), _p(pic.rec[1]), _p(pic.rec[2]),
                              _p(pic.mv), _p(pic.ref_idx), _p(pic.mv1), _p(pic.ref_idx1), _p(pic.ipredmode), _p(out), _p(dbg) if debug else None)
     assert r == 0, r

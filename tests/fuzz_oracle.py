@@ -67,7 +67,7 @@ def config_b(seed):
     nref = int(rng.integers(1, 4 if R > 16 else 5))
     ov = dict(RDOptimization=0, AdaptiveRounding=0, NumberBFrames=nb, FramesToBeEncoded=nfr, YUVFormat=yuv, ProfileIDC=prof, LevelIDC=40, SymbolMode=cabac, Transform8x8Mode=t8, SearchMode=sm,
               SearchRange=R, NumberReferenceFrames=nref, QPISlice=qp, QPPSlice=qp if rng.integers(0, 2) else int(rng.integers(10, 45)), QPBSlice=int(rng.integers(10, 45)),
-              OffsetMatrixPresentFlag=int(yuv == 2 and rng.integers(0, 2)), SliceMode=0, SliceArgument=50, DFDisableRefPSlice=0, DirectModeType=1,
+              OffsetMatrixPresentFlag=int(yuv == 2 and rng.integers(0, 2)), SliceMode=0, SliceArgument=50, DFDisableRefPSlice=0, DirectModeType=1 if seed < 1100000 else int(rng.integers(0, 2)),
               DirectInferenceFlag=int(rng.integers(0, 2)), BiPredMotionEstimation=int(rng.integers(0, 3) > 0))
     if ov["BiPredMotionEstimation"]:
         ov.update(BiPredMERefinements=int(rng.integers(0, 4)), BiPredMESearchRange=int(rng.choice([2, 4, 8, 16])), BiPredMESubPel=int(rng.integers(0, 3)),

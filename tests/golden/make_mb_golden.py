@@ -115,6 +115,11 @@ CASES = {
                   FramesToBeEncoded="5", QPISlice="22", QPPSlice="22", QPBSlice="22", BList1References="2"), (176, 144), 5, "motion:93", "jm_main.cfg"),
     # encoder_yuv422.cfg with its B picture (4:2:2, CABAC, 8x8 transform, fast full search, q_offset.cfg), RDO off
     "q5yb": (dict(RDO_OFF, NumberBFrames="1", NumberReferenceFrames="4"), (176, 144), 3, False, "jm_yuv422.cfg"),
+    # DirectModeType 0 (temporal direct; DirectInferenceFlag 1 as every level from 3 on requires): the shipped file otherwise (q1bt), High profile with three references, slices
+    # that start mid-row and two B pictures between the references (m3bt)
+    "q1bt": (dict(RDO_OFF, DirectModeType="0"), (176, 144), 3, False, "jm_main.cfg"),
+    "m3bt": (dict(RDO_OFF, DirectModeType="0", SearchMode="0", SearchRange="16", NumberReferenceFrames="3", ProfileIDC="100", Transform8x8Mode="1", NumberBFrames="2",
+                  FramesToBeEncoded="7", SliceMode="1", SliceArgument="50", QPISlice="27", QPPSlice="27", QPBSlice="30"), (208, 160), 7, "motion:94", "jm_main.cfg"),
     # encoder_main.cfg's search and B settings at 1080p (fast full search SR 32, CABAC, BiPredMotionEstimation 1), two references: I P B
     "g3b": (dict(RDO_OFF, **dict(SYN1080, SearchMode="0", NumberReferenceFrames="2", FramesToBeEncoded="3")), (1920, 1080), 3, True, "jm_main.cfg"),
 }

@@ -85,6 +85,9 @@ class SeqEncoder:
         cur16 = [np.ascontiguousarray(p, np.uint16) for p in cur]
         col = L1[0][5]                           # (mv0, ref_idx0, mv1, ref_idx1) of the stored picture
         bb = dict(b or {}, col_ref=np.stack([col[1], col[3]], axis=-1), col_mv=np.stack([col[0], col[2]], axis=2))
+        if bb.get("direct_temporal", 0):                     # DirectModeType 0: picture order counts for compute_colocated's scales and the co-located blocks' reference pictures (list 0 only: stored pictures are I / P)
+            rp = L1[0][3][1]
+            bb.update(poc_cur=poc, poc_l0=list(l0_pocs), poc_l1_0=l1_pocs[0], col_refpoc=np.stack([rp, np.full(rp.shape, pyjmo.NO_REF, np.int32)], axis=-1))
         qpc = None
         for sn, (first, num) in enumerate(slices_of(nmb, self.slice_mbs)):
             cfg = pyjmo.mbenc_cfg(W, H, 1, first, num, qp_b, self.R, len(L0), lambdas_b[0], lambdas_b[1], level_mv=self.level_mv, cabac=self.cabac, search_mode=self.search_mode, transform8x8=self.transform8x8,
@@ -135,7 +138,7 @@ class SeqEncoder:
         y, u, v = pyjmo.deblock_frame(pic.rec[0], pic.rec[1], pic.rec[2], self.yuv_format, mbs, mot)
         refpoc = np.full(pic.ref_idx.shape, pyjmo.NO_REF, np.int32)     # the stored picture's motion, as EPZSSliceInit of later pictures reads it
         for k, r in enumerate(self.refs[:nref]):
-            refpoc[pic.ref_idx == k] = 2 * r[2]
+            refpoc[pic.ref_idx == k] = r[4]                  # (2 x the picture number in an IPPP sequence)
         self.refs.insert(0, (pyjmo.RefPic(y), (u, v), self.npic, (pic.mv.copy(), refpoc), 2 * self.npic if poc is None else poc, (pic.mv.copy(), pic.ref_idx.copy(), pic.mv1.copy(), pic.ref_idx1.copy())))
         self.refs = self.refs[:max(self.num_ref, self.keep)]
         self.npic += 1

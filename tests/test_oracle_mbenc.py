@@ -79,7 +79,7 @@ BSLICE_KEYS = ("BSliceDirect", "BSliceSearch16x16", "BSliceSearch16x8", "BSliceS
 
 def b_switches(ov, z):
     """the B slices' switches of pyjmo.encode_slice_b from a case's overrides (defaults: the shipped .cfg files')"""
-    return dict(direct_8x8_inference=int(z["direct_8x8_inference"]), bipred_me=int(ov.get("BiPredMotionEstimation", 1)),
+    return dict(direct_8x8_inference=int(z["direct_8x8_inference"]), direct_temporal=int(int(ov.get("DirectModeType", 1)) == 0), bipred_me=int(ov.get("BiPredMotionEstimation", 1)),
                 bipred_search=[int(ov.get(k, d)) for k, d in (("BiPredSearch16x16", 1), ("BiPredSearch16x8", 1), ("BiPredSearch8x16", 1), ("BiPredSearch8x8", 0))],
                 bipred_refinements=int(ov.get("BiPredMERefinements", 3)), bipred_range=int(ov.get("BiPredMESearchRange", 16)), bipred_subpel=int(ov.get("BiPredMESubPel", 2)))
 
@@ -134,7 +134,7 @@ def run_case_b(tag, nmax=None):
 
 # B pictures (jmo_mbenc_b.inc): spatial direct, LIST_0 / LIST_1 / BI_PRED per partition, the direct 8x8 sub-mode, with (q1b, m3b, m2b4, q5yb) and without (q1b0, m3b0) the bi-predictive
 # motion search; CAVLC / CABAC, 4x4 / 8x8 transform, full search / fast full search, slices, two list-1 references (m2b4), 4:2:2 with q_offset.cfg's B lists (q5yb)
-@pytest.mark.parametrize("tag", ["q1b0", "q1b", "m3b0", "m3b", "m2b4", "q5yb"])
+@pytest.mark.parametrize("tag", ["q1b0", "q1b", "m3b0", "m3b", "m2b4", "q5yb", "q1bt", "m3bt"])
 def test_oracle_b_pictures_equal_the_reference_encoder(tag):
     run_case_b(tag)
 
