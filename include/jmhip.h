@@ -617,8 +617,11 @@ typedef struct {
                                    EPZSFixedPredictors (0..3), EPZSAggressiveWindow, EPZSTemporal, EPZSSpatialMem, EPZSBlockType */
   int32_t epzs_min_scale, epzs_med_scale, epzs_max_scale, epzs_sub_scale;   /* EPZSMinThresScale, EPZSMedThresScale, EPZSMaxThresScale, EPZSSubPelThresScale */
   int32_t b_switches;           /* B slices: bit 0 active_sps->direct_8x8_inference_flag; bit 1 BiPredMotionEstimation, bits 2..4 BiPredSearch16x16 / 16x8 / 8x16 (BiPredSearch8x8
-                                   must be 0), bits 8..11 BiPredMERefinements, bits 16..23 BiPredMESearchRange, bits 24..25 BiPredMESubPel.  DirectModeType must be 1 (spatial),
-                                   WeightedBiprediction 0; the B picture is not used for reference.  Get_Direct_MV_Spatial_Normal lencod/src/mv_direct.c:522, the bslice branches of
+                                   must be 0), bits 8..11 BiPredMERefinements, bits 16..23 BiPredMESearchRange, bits 24..25 BiPredMESubPel; bit 5: DirectModeType 0 (temporal direct:
+                                   needs bit 0, poc_cur, poc_ref[] of list 0 and -- at [num_ref] -- of list 1's first picture, and reference pictures that the pipeline coded
+                                   with non-negative ref_id: their blocks' vectors and reference picture ids are kept with the slots; Get_Direct_MV_Temporal lencod/src/mv_direct.c:40,
+                                   compute_colocated mbuffer.c:3122), else spatial.  WeightedBiprediction 0; the B picture is not used for reference.
+                                   Get_Direct_MV_Spatial_Normal mv_direct.c:522, the bslice branches of
                                    encode_one_macroblock_low md_low.c:174-263 / :374-431, submacroblock_mode_decision_low mode_decision_P8x8.c:681, list_prediction_cost
                                    mode_decision.c:275, BIDPartitionCost mv_search.c:1159, BiPredBlockMotionSearch :1033 */
   int32_t poc_cur;              /* enc_picture->poc */

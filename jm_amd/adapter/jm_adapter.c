@@ -105,6 +105,7 @@ static struct {
   long refcount, bcount;              /* reference / B pictures met so far */
   int st_n, st_slot[JMHIP_MB_MAX_REF + 1], window;   /* the stored reference pictures as the sliding window holds them, most recent first: slot and ... */
   long st_disp[JMHIP_MB_MAX_REF + 1]; /* ... place in display order */
+  int poc0;                           /* picture order count of picture 0 */
   long first_frame_no; int regular;   /* the file's frame of picture 0; pictures so far arrived in the regular order I P B.. P B.. (display place fl_disp) */
   int on;
   int fd, have_file, src_w, src_h, cur_frame_no, frame_step;
@@ -1418,8 +1419,9 @@ static int pipe_config_ok(VideoParameters *p_Vid)
     else if (p->SkipIntraInInterSlices || p->SelectiveIntraEnable || p->RandomIntraMBRefresh || p->intra_upd || p->CtxAdptLagrangeMult) why = "intra refresh / selective intra / CtxAdptLagrangeMult";
     else if (p->sp_periodicity != 0) why = "SP pictures";
     /* B pictures (mbpipe_b.inc): non-reference B pictures between the P pictures, spatial direct mode, the lists as init_lists leaves them */
-    else if (p->NumberBFrames != 0 && (!p->direct_spatial_mv_pred_flag || p->BRefPictures || p->LowDelay || p->ExplicitSeqCoding || p->EnableOpenGOP))
-      why = "B pictures with DirectModeType 0 (temporal), BReferencePictures, LowDelay, ExplicitSeqCoding or EnableOpenGOP";
+    else if (p->NumberBFrames != 0 && (p->BRefPictures || p->LowDelay || p->ExplicitSeqCoding || p->EnableOpenGOP))
+      why = "B pictures with BReferencePictures, LowDelay, ExplicitSeqCoding or EnableOpenGOP";
+    else if (p->NumberBFrames != 0 && !p->direct_spatial_mv_pred_flag && !p->directInferenceFlag) why = "B pictures with DirectModeType 0 (temporal) and DirectInferenceFlag 0";
     else if (p->NumberBFrames != 0 && p->SearchMode[0] == EPZS) why = "B pictures with EPZS";
     else if (p->NumberBFrames != 0 && p->BiPredMotionEstimation && (p->BiPredSearch[3] || p->BiPredMESearchRange[0] < 1 || p->BiPredMESearchRange[0] > 16 || p->BiPredMESubPel > 2 || p->BiPredMERefinements > 15))
       why = "BiPredMotionEstimation with BiPredSearch8x8, or a search range / sub-pel level / refinement count outside the device's";
@@ -1552,7 +1554,7 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
   F.poc_step = k ? prm->poc_cur - F.poc_last : 2 * (1 + p_Inp->frame_skip);
   F.poc_last = prm->poc_cur; F.slot_poc[F.cur_slot] = prm->poc_cur;
   /* ---- where the sequence stands: the picture's place in display order (from the frame JM read for it), the stored reference pictures as the sliding window now holds them */
-  if (k == 0) { F.first_frame_no = F.cur_frame_no; F.regular = 1; F.window = imax(1, (int)p_Vid->active_sps->num_ref_frames); F.st_n = 0; F.refcount = F.bcount = 0; }
+  if (k == 0) { F.poc0 = p_Vid->enc_picture->poc; F.first_frame_no = F.cur_frame_no; F.regular = 1; F.window = imax(1, (int)p_Vid->active_sps->num_ref_frames); F.st_n = 0; F.refcount = F.bcount = 0; }
   {
     const long disp = F.frame_step > 0 ? (F.cur_frame_no - F.first_frame_no) / F.frame_step : k;
     if (disp != fl_disp(k, F.nb)) F.regular = 0;            /* (the sequence's tail: a last group of fewer pictures) -- nothing more is launched ahead of time */
@@ -1624,6 +1626,15 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
             if (n0 < 1 || n1 < 1 || n0 + n1 > JMHIP_MB_MAX_REF) ok = 0;
             q.num_ref = n0; q.num_ref1 = n1;
             for (r = 0; r < JMHIP_MB_MAX_REF; r++) { q.ref_slot[r] = r < n0 ? l0[r] : r < n0 + n1 ? l1[r - n0] : 0; q.ref_id[r] = q.ref_slot[r]; }
+            if (q.b_switches & 32) {                          /* temporal direct: picture order counts in step with the display order (2 (1 + FrameSkip) per picture: set_poc) */
+              const int unit = 2 * (1 + p_Inp->frame_skip);
+              q.poc_cur = F.poc0 + (int)d * unit;
+              for (r = 0; r < JMHIP_MB_MAX_REF; r++) {
+                int a2, pd = 0;
+                for (a2 = 0; a2 < sim_n; a2++) if (r < n0 + n1 && sim_slot[a2] == q.ref_slot[r]) pd = F.poc0 + (int)sim_disp[a2] * unit;
+                q.poc_ref[r] = r < n0 + n1 ? pd : 0;
+              }
+            }
           }
         }
         if (ok && q.search_mode == 3) {                       /* EPZS scales its predictors by picture distances: the picture's own count continues the last step, its references' are the ring's */
@@ -1697,7 +1708,12 @@ static void pipe_run_slice(Macroblock *currMB)
       if (prm.ref_slot[prm.num_ref + r] < 0) { fprintf(stderr, "jmhip adapter: pictures in flight: list-1 reference %d of picture %ld is not a picture the device holds\n", r, F.pic); exit(70); }
       prm.ref_id[prm.num_ref + r] = prm.ref_slot[prm.num_ref + r];
     }
-    prm.b_switches = (p_Vid->active_sps->direct_8x8_inference_flag ? 1 : 0);
+    prm.b_switches = (p_Vid->active_sps->direct_8x8_inference_flag ? 1 : 0) | (currSlice->direct_spatial_mv_pred_flag ? 0 : 32);
+    if (!currSlice->direct_spatial_mv_pred_flag) {            /* temporal direct: the picture distances of compute_colocated (mbuffer.c:3122) */
+      prm.poc_cur = p_Vid->enc_picture->poc;
+      for (r = 0; r < prm.num_ref; r++) prm.poc_ref[r] = currSlice->listX[LIST_0][r]->poc;
+      for (r = 0; r < prm.num_ref1; r++) prm.poc_ref[prm.num_ref + r] = currSlice->listX[LIST_1][r]->poc;
+    }
     if (p_Inp->BiPredMotionEstimation)
       prm.b_switches |= 2 | (p_Inp->BiPredSearch[0] ? 4 : 0) | (p_Inp->BiPredSearch[1] ? 8 : 0) | (p_Inp->BiPredSearch[2] ? 16 : 0) | ((p_Inp->BiPredMERefinements & 15) << 8) |
                         ((p_Inp->BiPredMESearchRange[0] & 255) << 16) | ((p_Inp->BiPredMESubPel & 3) << 24);

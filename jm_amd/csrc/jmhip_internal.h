@@ -85,6 +85,7 @@ struct jmhip_ctx {
   void *d_mot;           // the current picture's motion per 4x4 block {packed vector, poc referred to}: what jmhip_reference_from_recon keeps with the slot
   void **d_slot_mot;     // [num_ref_slots] the same of the pictures in the slots ({0, none} after jmhip_set_reference*)
   uint8_t *d_colz;       // the current picture's answer, per 4x4 block, to a B picture's spatial direct mode ("the co-located block does not move": PicView::colz_out)
+  uint64_t *d_colm, **d_slot_colm;   // ... and the blocks' vectors | reference picture ids << 32 (temporal direct), the current picture's and the slots'
   uint8_t **d_slot_colz; // [num_ref_slots] the same of the pictures in the slots (jmhip_reference_from_recon keeps it with the slot; pictures in flight write theirs there)
   // pictures in flight (jmhip_seq_open)
   int seq_depth, seq_grid;

@@ -96,9 +96,11 @@ struct PicView {
   u64 *mot_out;                              // EPZS: per 4x4 block of the picture {packed vector, poc of the picture referred to}: later pictures' temporal predictors
   const u64 *mot_ref[2];                     // EPZS in flight: the motion kept with the slots of references 0 / 1, read where k_epzs_coloc's whole-picture pass would have put the
                                              // co-located vectors (the reference may still be in the making); null: no temporal predictors
-  u8 *colz_out;                              // P / I pictures: per 4x4 block 1 where a B picture's spatial direct mode finds "the co-located block does not move" in this picture
+  u8 *colz_out;                              // P / I pictures: per 4x4 block bit 0 where a B picture's spatial direct mode finds "the co-located block does not move" in this picture, bit 1: the block is inter
+  u64 *colm_out;                             // ... and its vector | the picture id of its reference << 32 (a B picture's temporal direct mode: Get_Direct_MV_Temporal mv_direct.c:40)
                                              // (get_colocated_info mv_direct.c:428: ref_idx[LIST_0] == 0 and a vector within +-1), else 0
   const u8 *colz;                            // B pictures: that map of listX[LIST_1][0]
+  const u64 *colm;                           // ... and its motion
   u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
   u32 post_tag, war_tag, prev_tag, pad_;
   unsigned epoch;
@@ -228,7 +230,7 @@ struct Shared {
   // B slices (mbpipe_b.inc).  References are numbered through both lists: list 0's first, then list 1's (S.allmv, the windows, PicView::ref_y).
   int mvi1[8][16][2];                        // per wave: mv_info of LIST_1 as that wave's chain sees it
   int bpmv[2][2][4][16];                     // currSlice->bipred_mv[set][list][0][mode 1..3][4x4 raster]
-  int dmv[2][16], d_ref[2], d_pdir;          // the spatial direct mode: vectors per list and 4x4 block, direct_ref_idx and direct_pdir (alike for the whole macroblock)
+  int dmv[2][16], d_ref8[4][2], d_pdir8[4];  // the direct mode: vectors per list and 4x4 block; direct_ref_idx and direct_pdir per 8x8 block (spatial: alike for the whole macroblock; temporal: -1 = the block has none)
   int d_cost4[4], d_cost8[4];                // GetDirectCost8x8 of the four 8x8 blocks (4x4 Hadamards; 8x8 Hadamard)
   int dflag;                                 // the direct vectors and costs are there (running count over the launch)
   int m_info[4][4];                          // modes 1..3: b8x8info->best[mode][block] packed (binfo_pack)

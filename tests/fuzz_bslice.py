@@ -34,8 +34,10 @@ while time.time() - t0 < budget:
     nmb = (W // 16) * (H // 16)
     slice_mbs = 0 if rng.integers(0, 3) else int(rng.integers(2, nmb))
     offs = offsets if rng.integers(0, 3) == 0 else None
-    b = dict(direct_8x8_inference=int(rng.integers(0, 2)), bipred_me=int(rng.integers(0, 3) > 0), bipred_search=[int(rng.integers(0, 4) > 0), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0],
+    b = dict(direct_8x8_inference=int(rng.integers(0, 2)), direct_temporal=0, bipred_me=int(rng.integers(0, 3) > 0), bipred_search=[int(rng.integers(0, 4) > 0), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0],
              bipred_refinements=int(rng.integers(0, 4)), bipred_range=int(rng.choice([r for r in (2, 4, 8, 16) if r <= R])), bipred_subpel=int(rng.integers(0, 3)))
+    if seed >= 2500000 and rng.integers(0, 2):                # temporal direct (needs direct_8x8_inference on the device: one reference per 8x8 block in the record)
+        b.update(direct_temporal=1, direct_8x8_inference=1)
     iv = [1] * 8 if rng.integers(0, 4) else [1, 1] + [int(rng.integers(0, 2)) for _ in range(6)]
     ivb = None if rng.integers(0, 3) else [int(rng.integers(0, 3) > 0)] + [int(rng.integers(0, 4) > 0) for _ in range(7)]
     if t8:                                                    # the library turns Transform8x8Mode 1 without the 8x8 partition away (as the adapter does)
@@ -74,7 +76,7 @@ while time.time() - t0 < budget:
             if st == 1:
                 past, future = sorted([p for p in stored if p < poc], reverse=True), sorted(p for p in stored if p > poc)
                 l0, l1 = (past + future)[:n0], (future + past)[:n1]
-                recs, pre, post = dev.encode_b(raw, W, H, l0, l1, lam_b, qp_b, b, inter_valid_b=ivb)
+                recs, pre, post = dev.encode_b(raw, W, H, l0, l1, lam_b, qp_b, b, inter_valid_b=ivb, poc=poc)
                 orecs, _, opre, opost = ora.encode_b(src, poc, l0, l1, lam_b, qp_b, b, inter_valid_b=ivb)
                 nb_pics += 1
             else:

@@ -27,6 +27,8 @@ pytestmark = pytest.mark.gpu
 def b_switch_word(b):
     """jmhip_slice_params::b_switches from the switches of pyjmo.encode_slice_b"""
     w = int(b.get("direct_8x8_inference", 1)) & 1
+    if b.get("direct_temporal", 0):
+        w |= 32
     if b.get("bipred_me", 0):
         w |= 2
         for i in range(3):
@@ -50,7 +52,7 @@ class DevSeqEncoderB(TG.DevSeqEncoder):
         self.poc_of[self.refs[0][0]] = poc
         return recs, pre, post
 
-    def encode_b(self, raw, sw, sh, l0_pocs, l1_pocs, lambdas_b, qp_b, b, qpc_b=None, qpc_cr_delta_b=0, inter_valid_b=None):
+    def encode_b(self, raw, sw, sh, l0_pocs, l1_pocs, lambdas_b, qp_b, b, qpc_b=None, qpc_cr_delta_b=0, inter_valid_b=None, poc=0):
         L, J = self.L, self.J
         nmb = (self.W // 16) * (self.H // 16)
         by_poc = {self.poc_of[s]: (s, i) for s, i in self.refs}
@@ -63,6 +65,10 @@ class DevSeqEncoderB(TG.DevSeqEncoder):
             prm = TG.slice_params(L, cfg, sn, [r[0] for r in L0 + L1], [r[1] for r in L0 + L1], self.disable_idc)
             prm["num_ref1"] = len(L1)
             prm["b_switches"] = b_switch_word(b)
+            if b.get("direct_temporal", 0):                  # picture order counts: the temporal direct mode's scales (list 1 behind list 0)
+                prm["poc_cur"] = poc
+                for r, p in enumerate(list(l0_pocs) + list(l1_pocs)):
+                    prm["poc_ref"][0, r] = p
             if sn == 0:
                 self.log.append(dict(st=1, raw=raw, sw=sw, sh=sh, prm=prm.copy(), nslices=len(mbenc_util.slices_of(nmb, self.slice_mbs)), pic_id=None, d8=int(b.get("direct_8x8_inference", 1))))
             recs[first:first + num] = J.encode_slice(prm)
@@ -98,7 +104,7 @@ def run_case_b(tag, check_oracle_post=True, flight=None):
             l0 = [int(p) for p in z["ref_poc"][n][:int(z["num_ref_pic"][n])]]
             l1 = [int(p) for p in z["poc_l1"][n][:int(z["num_ref1_pic"][n])]]
             kb = dict(qpc_b=int(z["qpc_b"]), qpc_cr_delta_b=int(z["qpc_v_b"]) - int(z["qpc_b"]), inter_valid_b=ivb)
-            recs, pre, post = dev.encode_b(raw[poc // 2], c["sw"], c["sh"], l0, l1, lam_b, int(z["qp_b"]), bsw, **kb)
+            recs, pre, post = dev.encode_b(raw[poc // 2], c["sw"], c["sh"], l0, l1, lam_b, int(z["qp_b"]), bsw, poc=poc, **kb)
             orecs, _, opre, opost = orc.encode_b(src[poc // 2], poc, l0, l1, lam_b, int(z["qp_b"]), bsw, **kb)
         else:
             recs, pre, post = dev.encode_ref(raw[poc // 2], c["sw"], c["sh"], poc)
@@ -202,7 +208,7 @@ def test_b_pictures_equal_the_reference_encoder(tag):
 # with the bi-predictive motion search as the shipped files have it (BiPredMotionEstimation 1: BiPredBlockMotionSearch mv_search.c:1033, BI_PRED_L0 / _L1 in the decision):
 # encoder_main.cfg with RDO off (q1b: fast full search SR 32, CABAC), High profile on a clip with motion (m3b: 8x8 transform), one refinement / range 8 / one sub-pel level,
 # CAVLC, two list-1 references (m2b4), encoder_yuv422.cfg with its B picture (q5yb: 4:2:2, q_offset.cfg's B lists)
-@pytest.mark.parametrize("tag", ["q1b", "m3b", "m2b4", "q5yb"])
+@pytest.mark.parametrize("tag", ["q1b", "m3b", "m2b4", "q5yb", "q1bt", "m3bt"])          # *bt: DirectModeType 0 (temporal direct)
 def test_b_pictures_with_the_bipredictive_search_equal_the_reference_encoder(tag):
     run_case_b(tag)
 
@@ -215,6 +221,6 @@ def test_b_picture_1080p_equals_the_reference_encoder():
 
 # B pictures in flight (jmhip_seq_encode with slice_type 1): the sequences of the goldens once more with 3 / 6 pictures in flight -- P pictures following their references inside
 # the device, B pictures beside the P pictures after them --: every record and every filtered picture as picture after picture (which the tests above pin to the real encoder)
-@pytest.mark.parametrize("tag,flight", [("m3b", (3, 0, False)), ("m3b0", (6, 20, True, 48)), ("m2b4", (4, 0, True, 7)), ("q5yb", (3, 0, False)), ("q1b", (2, 0, False))])
+@pytest.mark.parametrize("tag,flight", [("m3b", (3, 0, False)), ("m3b0", (6, 20, True, 48)), ("m2b4", (4, 0, True, 7)), ("q5yb", (3, 0, False)), ("q1b", (2, 0, False)), ("m3bt", (4, 0, False))])
 def test_b_pictures_in_flight_equal_picture_after_picture(tag, flight):
     run_case_b(tag, check_oracle_post=False, flight=flight)

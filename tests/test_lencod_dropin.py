@@ -172,7 +172,9 @@ def frame_times(stdout):
                                            ("m3fl", 175), ("m3fm", 175), ("m2sl", 192), ("m2el", 192),                               # level 1.1
                                            ("m2es", 396), ("m5es", 192),                                               # EPZS at SearchRange 2
                                            # B pictures (NumberBFrames 1; encoder_main.cfg / encoder_yuv422.cfg with RDO off: q1b, q5yb), without (*b0) and with the bi-predictive search
-                                           ("q1b0", 297), ("q1b", 297), ("m3b0", 910), ("m3b", 910), ("m2b4", 495), ("q5yb", 297)])
+                                           ("q1b0", 297), ("q1b", 297), ("m3b0", 910), ("m3b", 910), ("m2b4", 495), ("q5yb", 297),
+                                           # DirectModeType 0 (temporal direct), one / two B pictures between the references
+                                           ("q1bt", 297), ("m3bt", 910)])
 def test_lencod_macroblock_pipeline_writes_jm_bitstream(tmp_path, tag, nmb_total):
     """RDOptimization = 0: encode_one_macroblock_low never runs on the host -- every macroblock of every slice is encoded by jmhip_encode_slice,
     JM's own write_macroblock codes the records, DeblockFrame and the sub-pel planes stay on the device.  The Annex-B output and the reconstruction
@@ -453,7 +455,7 @@ def test_lencod_pictures_in_flight_are_verified_not_trusted(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["m3b", "m2b4"])
+@pytest.mark.parametrize("tag", ["m3b", "m2b4", "m3bt"])
 def test_lencod_b_pictures_are_launched_ahead_of_time_too(tmp_path, tag):
     """Sequences with B pictures (coding order I P B P B ...): the adapter predicts the order, the frames' places in the file and both reference lists of the pictures to come
     (a sliding window's init_lists_p_slice / init_lists_b_slice) and launches them ahead of time -- the B pictures beside the P pictures that follow them --, every launch
