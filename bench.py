@@ -490,6 +490,43 @@ def slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref, num_sl
     return p
 
 
+def valu_issued_live(local, d_raw, src_h, nmb, npic=7):
+    """Absolute differences the integer searches of ONE P picture of the clip issue, from the kernel's own counters (JMHIP_MB_PROF=11: every wave adds up the window rows its
+    sliding lanes read and the candidates of its one-lane passes, mbpipe.hip fs_wave): a second context made with the counting on codes the clip's first pictures in one launch, outside
+    any clock; every macroblock address then holds the counts of the last picture that coded it.  None when it cannot be measured (the bench line then carries the constant)."""
+    import ctypes as C
+    from jm_amd import JmHip
+    from jm_amd.lib import SLICE_PARAMS
+    os.environ["JMHIP_MB_PROF"] = "11"
+    try:
+        c = JmHip(W, H, search_range=R, num_ref_slots=npic + 1, yuv_format=1, device=local)
+    finally:
+        del os.environ["JMHIP_MB_PROF"]
+    try:
+        c.seq_open(1)
+
+        def prm(k):
+            q = slice_params(SLICE_PARAMS, 2 if k == 0 else 0, 0, nmb, 0, 0 if k == 0 else 1)
+            if k:
+                q["ref_slot"][0, 0], q["ref_id"][0, 0] = k - 1, k - 1
+            return q
+        c.seq_set_frame_dev(0, d_raw[0].data_ptr(), W, src_h)
+        c.seq_encode(0, prm(0), 0, 1, False)
+        c.seq_wait(0)
+        import torch
+        from jm_amd.lib import MB_RECORD
+        d_rec = torch.zeros((npic, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=d_raw.device)
+        c.seq_batch(prm(1), [dict(d_raw=d_raw[k].data_ptr(), src_w=W, src_h=src_h, out_slot=k, ref_slot=[k - 1], ref_id=[k - 1], d_records=d_rec[k].data_ptr()) for k in range(1, npic)])
+        c.seq_wait(0)
+        c.synchronize()
+        st = np.zeros((nmb, 32), np.uint64)
+        if c.lib.jmhip_debug_read_mb_prof(c.h, st.ctypes.data_as(C.c_void_p), st.nbytes) != 0:
+            return None
+        return float(16 * st[:, 22:30].astype(np.int64).sum())
+    finally:
+        c.close()
+
+
 def b_pictures_leg(local, frames, src_h, nmb, flight):
     """encoder_main.cfg's settings with RDO off at 1080p (the shipped file's B picture: NumberBFrames 1, fast full search SR 32, CABAC, two references, spatial direct, the
     bi-predictive search with three refinements / range 16 / two sub-pel levels -- tests/golden/mb_low_g3b.npz is the real encoder's I P B of this clip):
@@ -974,6 +1011,12 @@ def main():
         configs2_device["in_flight"] = {"pictures": nq - 1, "pictures_in_flight": depth_e, "kernel": "k_mb_pipe_epzs4_t8 (four waves per workgroup, two workgroups per compute unit)", "ms_per_picture": round(te / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / te, 1),
                                         "records_equal_jm_first_two_pictures": bool(eq2)}
 
+    issued_live = None
+    if rank == 0 and N == 1:
+        try:
+            issued_live = valu_issued_live(local, d_raw, src_h, nmb)
+        except Exception:                                             # (an extra figure must not cost the line)
+            issued_live = None
     if rank == 0:
         total_mb = nmb * N * args.steps
         steps_chain = W // 16 + 2 * (H // 16 - 1)
@@ -996,7 +1039,10 @@ def main():
                                         "one launch = one picture; `depth` launches overlap, each slower than alone because they share the chip") +
                                        " -- achieved / frac above are the timed region's: algorithmic bytes of its launches over its wall time"},
                 "abs_diff_per_s_jm_equivalent": round(sad_ops * args.steps / dt / 1e12, 3), "valu_frac_jm_equivalent": round(sad_ops * args.steps / dt / 148.4e12, 5),
-                "valu_frac_issued": round(VALU_ISSUED_PER_PICTURE * args.steps / dt / 148.4e12, 5), "valu_issued_source": VALU_ISSUED_SOURCE,
+                "valu_frac_issued": round((issued_live or VALU_ISSUED_PER_PICTURE) * args.steps / dt / 148.4e12, 5),
+                "valu_issued_per_picture": issued_live or VALU_ISSUED_PER_PICTURE,
+                "valu_issued_source": ("measured in this run: the kernel's own counters (JMHIP_MB_PROF=11) over a P picture of this clip coded once more by a second context, outside the clock"
+                                       if issued_live else VALU_ISSUED_SOURCE),
                 "critical_path": {"steps": steps_chain, "us_per_step_alone": round(solo * 1e3 / steps_chain, 1) if solo else None,
                                   "note": "a macroblock waits for its left and upper-right neighbours' vectors: one picture is a chain of mb_w + 2 (mb_h - 1) macroblocks whatever the "
                                           "chip's width, with 27 of 8160 macroblocks in flight on average.  What fills the chip is the NEXT pictures: macroblock (X, r) of picture n + 1 "

@@ -81,6 +81,11 @@ static struct {
 
 static void pipe_report(void);
 static double now_s(void);
+/* JMHIP_INIT_PROF=1: where a run's first hundreds of milliseconds go (profiles/r05_init_prof.sh) -- stamps in ms since the process started */
+static double IP_t0;
+static int IP_on;
+static void init_prof(const char *what) { if (IP_on) fprintf(stderr, "jmhip adapter: init %8.1f ms  %s\n", 1e3 * (now_s() - IP_t0), what); }
+__attribute__((constructor)) static void init_prof_start(void) { IP_t0 = now_s(); IP_on = getenv("JMHIP_INIT_PROF") != NULL; }
 static double T_slice, T_pad, T_deblock, T_interp;
 /* per picture (the first 64): when encode_one_slice was entered and left, and the time inside DeblockFrame / getSubImagesLuma (JMHIP_ADAPTER_TIMELINE=1 prints them) */
 static double TL_in[64], TL_out[64], TL_db[64], TL_ip[64], TL_begun[64], TL_first[64], TL_last[64], TL_ended[64], TL_wait[64], TL_db_at[64], TL_ip_at[64];
@@ -132,8 +137,32 @@ static void adapter_report(void)
                   "weighted / bi-predictive candidate distortions on the MI355X: %ld; source pictures padded on the MI355X: %ld; chroma intra predictions on the MI355X: %ld macroblocks; Intra8x8 predictions on the MI355X: %ld blocks\n",
           G.n_interp, G.n_fs, G.n_subpel, G.n_ffs, G.n_deblock, G.n_cur, G.n_passed, G.n_tq4, G.n_tq8, G.n_tqc, G.n_mcl, G.n_mcc, G.n_tq16, G.n_eval,
           G.n_ip4, G.n_i16, G.n_interpc, G.n_evalp, G.n_load, G.n_ic, G.n_ip8);
-  { int k_; for (k_ = 1; k_ < G.nctx; k_++) if (G.ctxs[k_]) jmhip_destroy(G.ctxs[k_]); }
+  init_prof("exit: the report is written");
+}
+
+/* The process is over: JM has closed its files, the report above is written.  What would follow -- jmhip_destroy (33 ms at 1080p: pinned buffers, streams) and then the HIP
+ * runtime's own exit handlers (139 ms) -- frees what the kernel driver reclaims from a dead process anyway, and is more than a quarter of a two-picture run's wall time
+ * (profiles/r05_init_prof.txt).  So after a NORMAL end (status 0) with nothing in flight: flush every stdio stream and leave with _exit.  The full teardown stays for
+ * JMHIP_ADAPTER_FULL_EXIT=1, under a profiler that collects at exit (rocprofv3: ROCP_TOOL_LIBRARIES / LD_PRELOAD), in the -pg build (gmon.out is written by an exit
+ * handler) and after any failure. */
+static void adapter_exit(int status, void *unused)
+{
+  int k_, fast;
+  (void)unused;
+  if (!G.init_done) return;
+  adapter_report();
+#ifdef JMHIP_ADAPTER_KEEP_EXIT_HANDLERS
+  fast = 0;
+#else
+  fast = status == 0 && !G.off && !getenv("JMHIP_ADAPTER_FULL_EXIT") && !getenv("ROCP_TOOL_LIBRARIES") && !getenv("LD_PRELOAD");
+#endif
+  if (fast) {
+    for (k_ = 0; k_ < G.nctx; k_++) if (G.ctxs[k_] && jmhip_synchronize(G.ctxs[k_]) != JMHIP_OK) fast = 0;      /* nothing may be left running on the device */
+    if (fast) { init_prof("exit: leaving without the teardown"); fflush(NULL); _exit(0); }
+  }
+  for (k_ = 1; k_ < G.nctx; k_++) if (G.ctxs[k_]) jmhip_destroy(G.ctxs[k_]);
   if (G.ctx) jmhip_destroy(G.ctx);
+  init_prof("exit: jmhip_destroy done");
   G.ctx = NULL;
 }
 
@@ -299,7 +328,7 @@ static int adapter_on(VideoParameters *p_Vid)
     jmhip_config cfg;
     int rc;
     G.init_done = 1;
-    atexit(adapter_report);
+    on_exit(adapter_exit, NULL);
     G.part_interp = has_part(parts, "interp"); G.part_fs = has_part(parts, "fs"); G.part_subpel = has_part(parts, "subpel");
     G.part_ffs = has_part(parts, "ffs"); G.part_deblock = has_part(parts, "deblock");
     G.part_tq4 = has_part(parts, "tq4"); G.part_tq8 = has_part(parts, "tq8"); G.part_tqc = has_part(parts, "tqc");
@@ -349,7 +378,9 @@ static int adapter_on(VideoParameters *p_Vid)
       if (dl && G.part_mbpipe && p_Inp->rdopt == 0 && p_Inp->slice_mode == FIXED_MB)
         while (*dl && nd < 8) { devs[nd++] = atoi(dl); dl = strchr(dl, ','); if (!dl) break; dl++; }
       if (nd > 1) cfg.device = devs[0];
+      init_prof("adapter_on: before jmhip_create");
       rc = jmhip_create(&G.ctx, &cfg);
+      init_prof("adapter_on: jmhip_create done");
       if (rc != JMHIP_OK) {                                /* the library has no CPU fallback; say so and stop */
         fprintf(stderr, "jmhip adapter: jmhip_create failed (%d): %s\n", rc, jmhip_last_error(NULL));
         exit(70);
@@ -472,7 +503,9 @@ int __wrap_encode_one_slice(VideoParameters *p_Vid, int SliceGroupId, int TotalC
     G.n_cur++;
   }
   if (TotalCodedMBs == 0 && TL_n < 64) TL_in[TL_n++] = t0_;
+  if (TotalCodedMBs == 0 && TL_n <= 2) init_prof("encode_one_slice: entered (a picture's first slice)");
   n_ = __real_encode_one_slice(p_Vid, SliceGroupId, TotalCodedMBs);
+  if (TL_n <= 2) init_prof("encode_one_slice: left");
   T_slice += now_s() - t0_;
   if (TL_n) TL_out[TL_n - 1] = now_s();
   return n_;
@@ -1475,7 +1508,9 @@ static void flight_begin(VideoParameters *p_Vid)
   int rc, k;
   if (F.on || !F.depth || P.n_slices) return;               /* decided at the sequence's first picture */
   F.total = p_Vid->p_Inp->no_frames;
+  init_prof("flight_begin: before jmhip_seq_open");
   if ((rc = jmhip_seq_open(G.ctx, F.depth, 0))) adapter_die("jmhip_seq_open", rc);
+  init_prof("flight_begin: jmhip_seq_open done");
   /* B pictures: several times a P picture's time per macroblock, and no launch waits for them inside the device -- twice a P picture's workgroups (1080p, I P B P B ..., eight
      in flight: 24 ms per picture against 28 with equal shares; profiles/r05_b_in_flight.txt) */
   if (F.nb && (rc = jmhip_seq_b_workgroups(G.ctx, 64))) adapter_die("jmhip_seq_b_workgroups", rc);
@@ -1547,7 +1582,9 @@ static void flight_launch(VideoParameters *p_Vid, const jmhip_slice_params *prm)
                               p_Vid->pImgOrg[1][0], p_Vid->pImgOrg[2][0], (int)(p_Vid->pImgOrg[1][1] - p_Vid->pImgOrg[1][0]));
     if (rc) adapter_die("jmhip_seq_set_planes", rc);
     G.n_cur++;
+    if (TL_n <= 2) init_prof("flight_launch: jmhip_seq_set_planes done");
     if ((rc = jmhip_seq_encode(G.ctx, e, prm, F.cur_slot, d8, 1, NULL))) adapter_die("jmhip_seq_encode", rc);
+    if (TL_n <= 2) init_prof("flight_launch: jmhip_seq_encode done");
     F.sub[e].valid = 1; F.sub[e].pic = k; F.sub[e].slot = F.cur_slot; F.sub[e].prm = *prm;
   }
   F.tmpl[prm->slice_type] = *prm; F.have_tmpl[prm->slice_type] = 1;
@@ -1795,6 +1832,7 @@ static void pipe_run_slice(Macroblock *currMB)
   P.n_slices++; P.n_refs += prm.num_ref;
   P.t_dev += now_s() - t0;
   if (TL_n && first == 0) TL_begun[TL_n - 1] = now_s();
+  if (TL_n <= 2 && first == 0) init_prof("the picture's launch is queued");
 }
 
 /* one macroblock's record into what write_macroblock (macroblock.c:2810), the MV predictor of later macroblocks and JM's statistics read */

@@ -1,6 +1,7 @@
 // ctx.hip -- context, device-resident frames, host<->device staging for libjmhip.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <time.h>
 #include "jmhip_internal.h"
 
 char g_jmhip_create_err[512] = "";
@@ -69,8 +70,12 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   if (cfg->search_range < 1 || cfg->search_range > JMHIP_MAX_SEARCH_RANGE)
     return jmhip_fail(NULL, JMHIP_EINVAL, "search_range %d outside 1..%d", cfg->search_range, JMHIP_MAX_SEARCH_RANGE);
   if (cfg->num_ref_slots < 1 || cfg->num_ref_slots > 32) return jmhip_fail(NULL, JMHIP_EINVAL, "num_ref_slots %d outside 1..32", cfg->num_ref_slots);
+  static const bool iprof = getenv("JMHIP_INIT_PROF") != nullptr;      // measurement aid (profiles/r05_init_prof.sh): where jmhip_create's time goes
+  struct timespec ip0; clock_gettime(CLOCK_MONOTONIC, &ip0);
+#define IPROF(what) do { if (iprof) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "jmhip_create: %7.1f ms  %s\n", 1e3 * (t_.tv_sec - ip0.tv_sec) + 1e-6 * (t_.tv_nsec - ip0.tv_nsec), what); } } while (0)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
+  IPROF("hipGetDeviceCount (the runtime starts)");
   if (e != hipSuccess || ndev <= 0)
     return jmhip_fail(NULL, JMHIP_ENODEV, "no HIP device (%s); libjmhip has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
   if (cfg->device < 0 || cfg->device >= ndev) return jmhip_fail(NULL, JMHIP_ENODEV, "device %d not in 0..%d", cfg->device, ndev - 1);
@@ -80,6 +85,7 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return jmhip_fail(NULL, JMHIP_ENODEV, "device %d is %s; libjmhip is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
 
+  IPROF("hipSetDevice, hipGetDeviceProperties");
   jmhip_ctx *c = (jmhip_ctx *)calloc(1, sizeof(jmhip_ctx));
   if (!c) return jmhip_fail(NULL, JMHIP_ENOMEM, "out of host memory");
   c->cfg = *cfg;
@@ -107,17 +113,27 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
     CK(hipMalloc((void **)&c->d_sub[s], (size_t)c->plane_stride * 16));
     CK(hipMemsetAsync(c->d_sub[s], 0, (size_t)c->plane_stride * 16, c->stream));
   }
-  c->h_stage_bytes = (size_t)c->Wp * c->Hp * 16 * sizeof(uint16_t);
+  IPROF("reference slots: hipMalloc + hipMemsetAsync (the stream's queue, the fill kernel)");
+  // pinned staging: one padded plane or one picture's three planes as bytes at a time (every user checks its size against h_stage_bytes).  It was sixteen padded planes of
+  // uint16 (75 MB at 1080p: 10 - 15 ms of page pinning in front of a sequence's first picture, profiles/r05_init_prof.txt) although nothing ever staged more than one plane
+  {
+    const size_t a = (size_t)2 * c->Wp * c->Hp, b = (size_t)3 * c->cur_pitch * c->H;
+    c->h_stage_bytes = (a > b ? a : b) + 4096;
+    if (c->h_stage_bytes < ((size_t)1 << 18)) c->h_stage_bytes = (size_t)1 << 18;      // ... and the spiral table below (search range 64: 66 KB)
+  }
   CK(hipHostMalloc((void **)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+  IPROF("hipHostMalloc of the staging area");
   CK(hipMalloc((void **)&c->d_stage, (size_t)c->cur_pitch * c->H * 3));
   {
+    // (through the pinned staging area on the context's stream: a synchronous copy from pageable memory sets up the runtime's own staging and the null stream's queue,
+    // 11 ms before a sequence's first picture)
     int R = cfg->search_range, n = (2 * R + 1) * (2 * R + 1);
-    int16_t *sp = (int16_t *)malloc((size_t)(n > 9 ? n : 9) * 4);
-    spiral_fill(R, sp);
+    if ((size_t)(n > 9 ? n : 9) * 4 > c->h_stage_bytes) { jmhip_fail(NULL, JMHIP_EINVAL, "spiral table larger than staging"); jmhip_destroy(c); return JMHIP_EINVAL; }
+    spiral_fill(R, (int16_t *)c->h_stage);
     CK(hipMalloc((void **)&c->d_spiral, (size_t)n * 4));
-    CK(hipMemcpy(c->d_spiral, sp, (size_t)n * 4, hipMemcpyHostToDevice));
-    free(sp);
+    CK(hipMemcpyAsync(c->d_spiral, c->h_stage, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));      // (the stream is synchronised below, before anybody reuses the staging area)
   }
+  IPROF("spiral table");
   CK(hipMalloc((void **)&c->d_me_declined, 64));
   CK(hipMemsetAsync(c->d_me_declined, 0, 64, c->stream));
   CK(hipMemsetAsync(c->d_me_declined + 5, 0xff, 4, c->stream));       // index of the first bad job: none
@@ -127,8 +143,11 @@ extern "C" int jmhip_create(jmhip_ctx **out, const jmhip_config *cfg)
   CK(hipMalloc((void **)&c->d_db_flags, (size_t)(c->W / 16) * (c->H / 16) * 2 + 16));
   CK(hipMalloc(&c->d_db_tasks, 1024 * 8 + 256 * 8 * 8));      // task list + the task builder's row masks
   for (int k = 0; k < JMHIP_NKINDS; k++) { CK(hipEventCreate(&c->ev0[k])); CK(hipEventCreate(&c->ev1[k])); }
+  IPROF("small buffers, events");
   CK(hipStreamSynchronize(c->stream));
+  IPROF("hipStreamSynchronize");
 #undef CK
+#undef IPROF
   *out = c;
   return JMHIP_OK;
 }

@@ -22,6 +22,9 @@
 //     per-sub-block origin clamp (UMVLine4X), JM's strict-'<' scan replayed on the nine sums.
 // No MFMA: the path is byte / integer add, sub, shift, abs, min.
 #include <mutex>
+#include <thread>
+#include <unistd.h>
+#include <time.h>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>

@@ -306,6 +306,36 @@ def test_pictures_in_flight_streamed_records_and_repeated_runs():
         fl.J.close()
 
 
+def test_entries_made_beside_the_first_picture(monkeypatch):
+    """jmhip_seq_open makes its first entry itself and the others on a thread that starts with the first launch (mbpipe_host.inc: seq_join): a context closed before any launch,
+    one closed right after its first launch, a sequence whose FIRST launch names the last entry, and the same sequence with every entry made inside jmhip_seq_open all behave"""
+    import jm_amd.lib as L
+    W, H, R = 176, 144, 16
+    frames = synthetic_clip(W, H, 6, 77)
+    want = classic(W, H, 28, R, 1, LAMBDAS, frames)
+    J = L.JmHip(W, H, search_range=R, num_ref_slots=8, yuv_format=1)
+    J.seq_open(6)
+    J.seq_close()                                            # nothing was launched: the thread has nothing to make
+    J.seq_open(4)
+    J.seq_set_frame(3, frames[0], W, H)                     # the last entry first: joins the thread
+    J.seq_close()
+    J.close()
+    for inline in (False, True):
+        if inline:
+            monkeypatch.setenv("JMHIP_SEQ_OPEN_INLINE", "1")
+        fl = FlightEncoder(W, H, 28, R, 1, LAMBDAS, 4)
+        fl.submit(frames[0], W, H)
+        if not inline:
+            fl.J.seq_close()                                 # right behind the first launch: the thread is under way
+            fl.J.seq_open(4)
+            fl.npic, fl.results = 0, {}
+            fl.submit(frames[0], W, H)
+        for raw in frames[1:]:
+            fl.submit(raw, W, H)
+        compare(want, fl.finish(), ("inline", inline))
+        fl.J.close()
+
+
 def test_seq_refuses_what_it_does_not_cover():
     import jm_amd.lib as L
     W, H = 176, 144
