@@ -171,6 +171,9 @@ def end_to_end(cpu, max_seconds=300):
         return {"available": False, "why": "oracle/_ref/lencod_hip.exe did not travel (it is built from the reference's sources where /root/reference exists)"}
     try:
         two = run_lencod(exe, 2, max_seconds)            # the golden md5 is of two pictures
+        again = run_lencod(exe, 2, max_seconds)          # (its wall time once more: a process started while the driver still clears the previous one away waits for that, profiles/r05_init_prof.txt)
+        if two and again and again[3] < two[3]:
+            two = again
         more = run_lencod(exe, 6, max_seconds)           # steady state: later P pictures no longer pay first-launch costs
     except subprocess.TimeoutExpired:
         return {"available": False, "why": "timeout"}
@@ -181,7 +184,7 @@ def end_to_end(cpu, max_seconds=300):
     out = {"available": True, "p_frame_ms": p_ms, "p_frame_ms_all": p, "i_frame_ms": more[0].get("I", [None])[0], "macroblocks_per_s": round(8160 / (p_ms / 1000.0), 1),
            "md5_264_two_frames": two[1], "md5_ok": two[1] == G2R_MD5, "adapter": more[2],
            # whole runs, process start to exit (context creation, first launches, the I picture, file I/O): what a two-picture job really gains
-           "sequence_wall_s": {"pictures_2_hip": round(two[3], 2), "pictures_2_cpu_jm": cpu.get("wall_s_two_pictures") if cpu else None, "pictures_6_hip": round(more[3], 2),
+           "sequence_wall_s": {"pictures_2_hip": round(two[3], 2), "pictures_2_hip_is": "the shorter of two runs", "pictures_2_cpu_jm": cpu.get("wall_s_two_pictures") if cpu else None, "pictures_6_hip": round(more[3], 2),
                                "speedup_2_pictures": round(cpu["wall_s_two_pictures"] / two[3], 1) if cpu and cpu.get("wall_s_two_pictures") else None,
                                "note": "p_frame_ms is the median of the later P pictures of the six-picture run; the first P picture and the I picture also pay first-launch costs (p_frame_ms_all, i_frame_ms)"},
            "config": "lencod_hip.exe -d jm_baseline.cfg " + " ".join("-p " + f for f in G2R_FLAGS[:11]) + ": unmodified JM 19.0 host code, entropy coding on the host, one thread"}
@@ -574,7 +577,7 @@ def b_pictures_leg(local, frames, src_h, nmb, flight):
              for k, r in enumerate((r_i, r_p, r_b)))
     types = np.bincount(r_b["mb_type"].astype(int), minlength=14)
     # ---- the sequence with pictures in flight
-    ctx.seq_open(depth, wg_p)
+    ctx.seq_open(depth, wg_p, ready=True)
     ctx.seq_b_workgroups(wg_b)
     d_raw = torch.from_numpy(np.stack(frames)).to(f"cuda:{local}")
     npic = 1 + 2 * ngop
@@ -812,7 +815,7 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = JmHip(W, HP, search_range=R, num_ref_slots=nslots, yuv_format=1, device=local, stream=stream.cuda_stream)
-    ctx.seq_open(1 if batch else depth, 0 if batch else args.workgroups)
+    ctx.seq_open(1 if batch else depth, 0 if batch else args.workgroups, ready=True)
 
     def slice_prm(slice_type, first, num, slice_nr, num_ref):
         return slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref)
@@ -986,7 +989,7 @@ def main():
         # EPZS P pictures run as four-wave workgroups, two to a compute unit: sixteen pictures in flight x 2 x 16 workgroups fill the chip (profiles/r04_epzs_four_wave.txt)
         nq = 65                                                          # an I picture and 64 P pictures: the clip's pictures over and over (four fills of the sixteen entries; a launch takes ~20 x the steady state's time per picture)
         depth_e = depth if (one_gpu and world > 1) else max(1, min(16, nslots - 2, 2 * args.flight))
-        ctx.seq_open(depth_e, 0 if batch else args.workgroups)
+        ctx.seq_open(depth_e, 0 if batch else args.workgroups, ready=True)
         d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
 
         def estep(k):
@@ -1004,12 +1007,42 @@ def main():
         te = time.perf_counter() - te
         for e in range(depth_e):
             ctx.seq_wait(e)
+        # ... and with the P pictures in ONE launch (jmhip_seq_batch, round 5: the queue ordered for what EPZS usually reaches, every search checked against it -- a search
+        # that reaches further voids the launch with JMHIP_EREACH and the pictures go through the launches above): the same pictures, their records compared with that run's
+        one_launch = None
+        try:
+            d_r3 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
+            ctx.seq_batch_reserve(nq - 1)
+            ctx.set_pipeline_workgroups(args.workgroups if batch else 0)
+            estep(0)
+            ctx.seq_wait(0)
+            q1 = epzs_prm(0, 1, 2)
+            q1["poc_ref"][0, 0] = 0
+            pics = [dict(d_raw=d_raw[k % nseq].data_ptr(), src_w=W, src_h=src_h, out_slot=k % nslots, ref_slot=[(k - 1) % nslots], ref_id=[k - 1], poc_offset=2 * (k - 1),
+                         d_records=d_r3[k].data_ptr()) for k in range(1, nq)]
+            barrier()
+            tb = time.perf_counter()
+            ctx.seq_batch(q1, pics)
+            barrier()
+            tb = time.perf_counter() - tb
+            kms = ctx.last_kernel_ms(5)
+            try:
+                ctx.synchronize()
+                same3 = bool(torch.equal(d_r3[1:], d_r2[1:]))
+                one_launch = {"pictures": nq - 1, "kernel": "k_mb_pipe_epzs4_t8, one launch (jmhip_seq_batch)", "ms_per_picture": round(tb / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / tb, 1),
+                              "kernel_ms": round(kms, 3), "records_equal_pictures_in_flight": same3}
+            except Exception as ex:
+                one_launch = {"void": repr(ex)[:300], "note": "the launch was given up (JMHIP_EREACH): these pictures are coded by the launches in flight above"}
+            ctx.set_pipeline_workgroups(0)
+        except Exception as ex:                                           # (an extra figure must not cost the line)
+            one_launch = {"error": repr(ex)[:300]}
         ctx.seq_close()
         g3all = mb_tap.widen(np.load(os.path.join(ROOT, "tests", "golden", "mb_low_g3h.npz"))["records"])
         r2 = d_r2[:2].cpu().numpy().view(MB_RECORD).reshape(2, nmb)
         eq2 = all(all(a.tobytes() == b.tobytes() for a, b in zip(mb_tap.canonical(np.frombuffer(r2[k].tobytes(), g3all.dtype).copy()), g3all[k * nmb:(k + 1) * nmb])) for k in range(2))
         configs2_device["in_flight"] = {"pictures": nq - 1, "pictures_in_flight": depth_e, "kernel": "k_mb_pipe_epzs4_t8 (four waves per workgroup, two workgroups per compute unit)", "ms_per_picture": round(te / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / te, 1),
                                         "records_equal_jm_first_two_pictures": bool(eq2)}
+        configs2_device["one_launch"] = one_launch
 
     issued_live = None
     if rank == 0 and N == 1:

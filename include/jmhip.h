@@ -35,6 +35,7 @@ extern "C" {
 #define JMHIP_ENOMEM       -3
 #define JMHIP_EHIP         -4   /* a HIP runtime call failed */
 #define JMHIP_EUNSUPPORTED -5
+#define JMHIP_EREACH       -6   /* jmhip_seq_batch with EPZS: a search reached past what the queue's order covers (see there); the launch's pictures are void */
 
 #define JMHIP_PAD_X 32          /* IMG_PAD_SIZE_X, lencod/inc/defines.h:121 */
 #define JMHIP_PAD_Y 20          /* IMG_PAD_SIZE_Y, lencod/inc/defines.h:122 */
@@ -742,13 +743,20 @@ int jmhip_seq_get_recon(jmhip_ctx *ctx, int32_t slot, uint16_t *y, int32_t pitch
  * RDOptimization 0 and no rate control differ in nothing but their references); its ref_slot / ref_id are not read.  A slot is reused inside the batch as with the entries:
  * the picture that overwrites it starts once the last picture that read it is done, so num_ref + (pictures that overlap, PicHeightInMbs / 8 at 1080p) slots keep the
  * queue dense.  Asynchronous on the context's stream: jmhip_synchronize (which reports the launch's errors), then the records, jmhip_seq_get_recon / jmhip_seq_recon_dev,
- * jmhip_subplanes_dev.  Scope: the full searches (search_mode 0, 1), P slices, the whole picture (one slice or num_slices of them), num_ref <= 8, PicSizeInMbs < 65536, n <= 4096; needs jmhip_seq_open
- * (any depth).  Anything else JMHIP_EUNSUPPORTED.  Results: those of coding the pictures one after another (tests/test_gpu_seq.py). */
+ * jmhip_subplanes_dev.  Scope: search_mode 0, 1 and 3, P slices, the whole picture (one slice or num_slices of them), num_ref <= 8, PicSizeInMbs < 65536, n <= 4096; needs jmhip_seq_open
+ * (any depth).  Anything else JMHIP_EUNSUPPORTED.  Results: those of coding the pictures one after another (tests/test_gpu_seq.py).
+ * EPZS (search_mode 3, P slices; round 5): a full search reads its reference no further than SearchRange from the predictor it was staged for, EPZS wherever its predictors point
+ * (me_epzs_int.c:42: up to the level's vector range), so no lag covers every case.  The queue is ordered for a reach of SearchRange + 27 samples (lag 13 at SearchRange 32;
+ * JMHIP_EPZS_BATCH_LAG overrides) and every search asks for what IT reaches as with jmhip_seq_encode -- and waits only for a macroblock whose ticket is known to be handed
+ * out (an earlier place in the queue than its own, or all tickets up to that place drawn already: such a wait always ends).  A search that reaches further sets the launch's
+ * error word instead of waiting: jmhip_synchronize then returns JMHIP_EREACH, NOTHING of the launch is valid (records, slots), and the caller codes the same pictures with
+ * jmhip_seq_encode, whose launches wait for each other without a queue order to respect. */
 typedef struct {
   const uint8_t *d_raw;         /* device: the source picture as it lies in the file (8 bit planar) */
   int32_t src_w, src_h;         /* its size (<= the context's; padded as JM's reader pads: PadImage lencod/src/input.c:257) */
   int32_t out_slot;
   int32_t ref_slot[JMHIP_MB_MAX_REF], ref_id[JMHIP_MB_MAX_REF];   /* as jmhip_slice_params; the first prm->num_ref count */
+  int32_t poc_offset;           /* EPZS: this picture's order counts are prm's poc_cur / poc_ref[] + poc_offset (IPPP: 2 (1 + FrameSkip) x its place in the batch); in what was padding */
   jmhip_mb_record *d_records;   /* device: PicSizeInMbs records */
 } jmhip_seq_picture;
 int jmhip_seq_batch(jmhip_ctx *ctx, const jmhip_slice_params *prm, int32_t direct_8x8_inference, int32_t n, const jmhip_seq_picture *pics);

@@ -105,7 +105,12 @@ struct PicView {
   const u8 *colz;                            // B pictures: that map of listX[LIST_1][0]
   const u64 *colm;                           // ... and its motion
   u32 ref_tag[JMHIP_SEQ_MAX_FLIGHT];
-  u32 post_tag, war_tag, prev_tag, pad_;
+  u32 post_tag, war_tag, prev_tag;
+  int key0;                                  // a launch of several pictures: the queue key of this picture's macroblock (0, 0) -- macroblock (x, y) has key0 + x + 2 y, tickets go by key
+  int poc_off;                               // ... EPZS: this picture's order counts are the launch's poc_cur / poc_ref[] + poc_off (jmhip_seq_picture::poc_offset)
+  unsigned short ref_dkey[JMHIP_SEQ_MAX_FLIGHT];   // ... and how far behind the picture that reference r is (key0 - ITS key0; at most 8 x the keys of a picture), where ref_post[r] is set
+                                             // (EPZS: is the macroblock a search waits for handed out?)
+  int pad2_;
   unsigned epoch;
   int ref_id[JMHIP_MB_MAX_REF];              // identity of reference r for the loop filter's comparison (jmhip_slice_params::ref_id)
 };
@@ -143,6 +148,7 @@ struct PipeArgs {
   unsigned char win_src[JMHIP_MB_MAX_REF];
   int npics;                                 // > 0: a launch of several consecutive pictures (jmhip_seq_batch): pics[0 .. npics), tickets ordered by wavefront index + lag x picture
   const PicView *pics;
+                                             // ... behind the tickets (256-byte aligned): key_end[k] = tickets with keys <= k (EPZS: ez_ensure_ref; the arguments' 4 KB are full)
   PicView v;                                 // the picture of a one-picture launch
 };
 static_assert(sizeof(PipeArgs) <= 4096, "kernel arguments: 4 KB");

@@ -84,10 +84,10 @@ MB_RECORD = np.dtype([("mb_type", "i1"), ("i16mode", "i1"), ("c_ipred_mode", "i1
                       ("mv1", "<i2", (16, 2)), ("b8ref1", "i1", (4,)), ("b8pdir", "i1", (4,)), ("b8bipred", "i1", (4,)), ("reserved2_", "i1", (4,))])      # B slices
 FRAME_FORMAT = np.dtype([("yuv_format", "<i4"), ("src_w", "<i4"), ("src_h", "<i4"), ("out_w", "<i4"), ("out_h", "<i4"), ("coded_w", "<i4"), ("coded_h", "<i4"),
                          ("symbol_bytes", "<i4"), ("src_depth", "<i4", (3,)), ("out_depth", "<i4", (3,))])
-# jmhip_seq_picture (include/jmhip.h): 8-byte pointers, the record pointer aligned behind 35 ints
-SEQ_PICTURE = np.dtype({"names": ["d_raw", "src_w", "src_h", "out_slot", "ref_slot", "ref_id", "d_records"],
-                        "formats": ["<u8", "<i4", "<i4", "<i4", ("<i4", (16,)), ("<i4", (16,)), "<u8"],
-                        "offsets": [0, 8, 12, 16, 20, 84, 152], "itemsize": 160})
+# jmhip_seq_picture (include/jmhip.h): 8-byte pointers, the record pointer behind 36 ints
+SEQ_PICTURE = np.dtype({"names": ["d_raw", "src_w", "src_h", "out_slot", "ref_slot", "ref_id", "poc_offset", "d_records"],
+                        "formats": ["<u8", "<i4", "<i4", "<i4", ("<i4", (16,)), ("<i4", (16,)), "<i4", "<u8"],
+                        "offsets": [0, 8, 12, 16, 20, 84, 148, 152], "itemsize": 160})
 SLICE_PARAMS = np.dtype([("slice_type", "<i4"), ("first_mb", "<i4"), ("num_mb", "<i4"), ("slice_nr", "<i4"), ("qp", "<i4"), ("qpc", "<i4"),
                          ("search_range", "<i4"), ("num_ref", "<i4"), ("ref_slot", "<i4", (MB_MAX_REF,)), ("ref_id", "<i4", (MB_MAX_REF,)),
                          ("lambda_mf", "<i4", (3,)), ("lambda_mdfp", "<i4"), ("max_mvd", "<i4"), ("mv_limit", "<i4", (4,)),
@@ -189,7 +189,9 @@ class JmHip:
 
     def _ck(self, rc):
         if rc != 0:
-            raise JmHipError(f"libjmhip error {rc}: {self.lib.jmhip_last_error(self.h).decode()}")
+            err = JmHipError(f"libjmhip error {rc}: {self.lib.jmhip_last_error(self.h).decode()}")
+            err.code = rc                                                  # (JMHIP_EREACH = -6: an EPZS batch to be coded again picture by picture)
+            raise err
 
     def synchronize(self):
         self._ck(self.lib.jmhip_synchronize(self.h))
@@ -631,8 +633,12 @@ class JmHip:
         self._ck(self.lib.jmhip_reference_from_recon(self.h, slot))
 
     # ---- consecutive pictures of one sequence in flight side by side (include/jmhip.h: jmhip_seq_*)
-    def seq_open(self, depth, workgroups=0):
+    def seq_open(self, depth, workgroups=0, ready=False):
+        """jmhip_seq_open.  The library makes the entries beyond the first beside the first picture's coding (a thread, joined by the first call that names such an entry);
+        ready=True waits for them here -- what a measurement wants, so that no stream is being made inside its clock"""
         self._ck(self.lib.jmhip_seq_open(self.h, int(depth), int(workgroups)))
+        if ready and depth > 1:
+            self.seq_wait(depth - 1)
 
     def seq_close(self):
         self._ck(self.lib.jmhip_seq_close(self.h))
@@ -684,6 +690,7 @@ class JmHip:
             a[k]["d_raw"], a[k]["src_w"], a[k]["src_h"], a[k]["out_slot"], a[k]["d_records"] = int(q["d_raw"]), q["src_w"], q["src_h"], q["out_slot"], int(q["d_records"])
             a[k]["ref_slot"][:len(q["ref_slot"])] = q["ref_slot"]
             a[k]["ref_id"][:len(q["ref_id"])] = q["ref_id"]
+            a[k]["poc_offset"] = q.get("poc_offset", 0)                    # EPZS: the picture's order counts relative to prm's
         self._ck(self.lib.jmhip_seq_batch(self.h, _vp(prm), int(direct8x8), len(pictures), _vp(a)))
 
     def seq_batch_reserve(self, n):

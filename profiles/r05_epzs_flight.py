@@ -11,7 +11,7 @@ W, nmb, nslots = bench.W, 8160, 24
 frames = bench.yuv_frames(8)
 d_raw = torch.from_numpy(np.stack(frames)).cuda()
 ctx = JmHip(W, bench.H, search_range=32, num_ref_slots=nslots, yuv_format=1)
-ctx.seq_open(depth, 0)
+ctx.seq_open(depth, 0, ready=True)
 d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device="cuda")
 def estep(k):
     st = 2 if k == 0 else 0

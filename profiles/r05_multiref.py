@@ -39,7 +39,7 @@ for sm in (0, 1):
             ctx.reference_from_recon(k % nslots)
         alone = float(np.mean(ms[1:]))
         md5 = hashlib.md5(recs.tobytes()).hexdigest()[:12]
-        ctx.seq_open(depth, 0)
+        ctx.seq_open(depth, 0, ready=True)
         d_recs = torch.zeros((npic, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device="cuda")
         def run():
             for k in range(npic):

@@ -23,7 +23,7 @@ frames = bench.yuv_frames(npic)
 for depth in depths:
     nslots = depth + (4 if mode == "ffs3" else (6 if mode == "epzs5" else 2))
     ctx = JmHip(W, H, search_range=32, num_ref_slots=nslots, yuv_format=1)
-    ctx.seq_open(depth, wg)
+    ctx.seq_open(depth, wg, ready=True)
     ctx.enable_timing(True)
 
     def prm(k):

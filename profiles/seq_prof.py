@@ -18,7 +18,7 @@ nmb = (W // 16) * (H // 16)
 frames = bench.yuv_frames(npic)
 nslots = depth + 2
 ctx = JmHip(W, H, search_range=32, num_ref_slots=nslots, yuv_format=1)
-ctx.seq_open(depth, 0)
+ctx.seq_open(depth, 0, ready=True)
 for k in range(npic):
     p = bench.slice_params(SLICE_PARAMS, 2 if k == 0 else 0, 0, nmb, 0, 0 if k == 0 else 1)
     if k:

@@ -44,14 +44,14 @@ def test_sequence_picture_layout_is_the_headers(tmp_path):
     from jm_amd import lib as L
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "jmhip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(jmhip_seq_picture), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "jmhip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(jmhip_seq_picture), '
                    'offsetof(jmhip_seq_picture, d_raw), offsetof(jmhip_seq_picture, src_w), offsetof(jmhip_seq_picture, src_h), offsetof(jmhip_seq_picture, out_slot), '
-                   'offsetof(jmhip_seq_picture, ref_slot), offsetof(jmhip_seq_picture, ref_id), offsetof(jmhip_seq_picture, d_records), sizeof(jmhip_slice_params)); return 0; }\n')
+                   'offsetof(jmhip_seq_picture, ref_slot), offsetof(jmhip_seq_picture, ref_id), offsetof(jmhip_seq_picture, poc_offset), offsetof(jmhip_seq_picture, d_records), sizeof(jmhip_slice_params)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     f = L.SEQ_PICTURE.fields
-    assert got == [L.SEQ_PICTURE.itemsize] + [f[n][1] for n in ("d_raw", "src_w", "src_h", "out_slot", "ref_slot", "ref_id", "d_records")] + [L.SLICE_PARAMS.itemsize], got
+    assert got == [L.SEQ_PICTURE.itemsize] + [f[n][1] for n in ("d_raw", "src_w", "src_h", "out_slot", "ref_slot", "ref_id", "poc_offset", "d_records")] + [L.SLICE_PARAMS.itemsize], got
 
 
 def test_partition_table_is_the_abi_order():

@@ -79,9 +79,9 @@ class BatchEncoder:
     """IPPP with the P pictures in launches of several pictures each (jmhip_seq_batch): the I picture and the first P pictures (fewer references than num_ref) through
     jmhip_seq_encode, then batches of `sizes` pictures in turn; picture k goes to slot k % nslots."""
 
-    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0, slice_mbs=0, disable_idc=0, reserve=0):
+    def __init__(self, W, H, qp, R, num_ref, lambdas, sizes, nslots, cabac=0, search_mode=-1, transform8x8=0, yuv_format=1, workgroups=0, slice_mbs=0, disable_idc=0, reserve=0, epzs=None):
         import torch
-        self.slice_mbs, self.disable_idc = slice_mbs, disable_idc
+        self.slice_mbs, self.disable_idc, self.epzs = slice_mbs, disable_idc, dict(epzs or {})
         import jm_amd.lib as L
         self.L, self.torch = L, torch
         self.W, self.H, self.qp, self.R, self.num_ref, self.lambdas, self.sizes, self.nslots = W, H, qp, R, num_ref, lambdas, list(sizes), nslots
@@ -98,7 +98,7 @@ class BatchEncoder:
         lam_mf, lam_md = self.lambdas[st]
         per = self.slice_mbs if 0 < self.slice_mbs < nmb else nmb
         cfg = pyjmo.mbenc_cfg(self.W, self.H, st, 0, per, self.qp, self.R, nref, lam_mf, lam_md, **self.kw)
-        prm = slice_params(self.L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], self.disable_idc, {}, 2 * k)
+        prm = slice_params(self.L, cfg, 0, [(k - 1 - r) % self.nslots for r in range(nref)], [k - 1 - r for r in range(nref)], self.disable_idc, self.epzs, 2 * k)
         if per < nmb:
             prm["num_slices"] = (nmb + per - 1) // per
         return prm
@@ -125,7 +125,7 @@ class BatchEncoder:
             d_rec = torch.zeros(n * nmb * L.MB_RECORD.itemsize, dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()
             pics = [dict(d_raw=d_raw[i].data_ptr(), src_w=sw, src_h=sh, out_slot=(k + i) % self.nslots, ref_slot=[(k + i - 1 - r) % self.nslots for r in range(self.num_ref)],
-                         ref_id=[k + i - 1 - r for r in range(self.num_ref)], d_records=d_rec.data_ptr() + i * nmb * L.MB_RECORD.itemsize) for i in range(n)]
+                         ref_id=[k + i - 1 - r for r in range(self.num_ref)], poc_offset=2 * i, d_records=d_rec.data_ptr() + i * nmb * L.MB_RECORD.itemsize) for i in range(n)]
             J.seq_batch(self.params(k, 0, self.num_ref), pics)
             J.synchronize()
             recs = np.frombuffer(d_rec.cpu().numpy().tobytes(), L.MB_RECORD).reshape(n, nmb)
@@ -235,6 +235,13 @@ def test_pictures_in_flight_equal_picture_after_picture(W, H, R, num_ref, qp, de
     (320, 192, 16, 1, 30, [6], 4, 0, 32, {"yuv_format": 2, "search_mode": 1, "transform8x8": 1}),
     (320, 192, 32, 1, 28, [8], 10, 0, 33, {"slice_mbs": 60}),             # pictures of four slices
     (640, 368, 32, 2, 28, [6], 8, 0, 34, {"slice_mbs": 130, "disable_idc": 2, "cabac": 1}),      # slices that start mid-row, no filtering across their edges
+    # EPZS in the one queue (round 5): every search checks what it reaches against the queue's order (ez_ensure_ref)
+    (320, 192, 16, 2, 28, [6], 8, 0, 41, {"search_mode": 3}),
+    (208, 160, 8, 3, 24, [7], 9, 0, 42, {"search_mode": 3, "epzs": dict(pattern=5, dual=6, fixed=3, aggressive=1, temporal=1, spatial_mem=1, blocktype=1)}),
+    (320, 192, 16, 1, 28, [7], 4, 0, 43, {"search_mode": 3, "cabac": 1, "transform8x8": 1}),     # four slots in turn
+    (320, 192, 16, 2, 28, [5], 8, 0, 44, {"search_mode": 3, "yuv_format": 2, "epzs": dict(temporal=0, spatial_mem=0, blocktype=0)}),
+    (640, 368, 32, 2, 28, [2, 5, 1], 6, 0, 45, {"search_mode": 3, "cabac": 1}),                   # batch after batch, temporal predictors from the batch before
+    (640, 368, 32, 1, 32, [9], 12, 5, 46, {"search_mode": 3}),                                      # five workgroups (ten four-wave ones) for everything
 ])
 def test_pictures_in_one_launch_equal_picture_after_picture(W, H, R, num_ref, qp, sizes, nslots, wg, seed, kw):
     """jmhip_seq_batch: the macroblocks of several consecutive pictures from one queue, ordered by wavefront index + lag x picture"""
@@ -250,6 +257,34 @@ def test_pictures_in_one_launch_equal_picture_after_picture(W, H, R, num_ref, qp
     got = be.run(frames, W, H)
     be.J.close()
     compare(want, got, (W, H, R, num_ref, sizes, nslots))
+
+
+def test_epzs_launch_of_several_pictures_given_up_and_coded_again(monkeypatch):
+    """EPZS in the one queue: with a queue lag far below what the searches reach and one workgroup drawing the tickets, a search asks for a macroblock whose ticket is not
+    out -- the launch is given up (JMHIP_EREACH, -6) instead of waiting for good, and the same context then codes the same pictures launch by launch, with the results of
+    the pictures coded one after another; with the lag the library chooses the launch goes through"""
+    import jm_amd.lib as L
+    W, H, R = 320, 192, 16
+    frames = synthetic_clip(W, H, 9, 5)
+    want = classic(W, H, 28, R, 1, LAMBDAS, frames, search_mode=3)
+    monkeypatch.setenv("JMHIP_EPZS_BATCH_LAG", "4")
+    be = BatchEncoder(W, H, 28, R, 1, LAMBDAS, [8], 10, workgroups=1, search_mode=3)
+    with pytest.raises(L.JmHipError) as ei:
+        be.run(frames, W, H)
+    assert ei.value.code == -6, ei.value
+    J, got = be.J, []
+    for k, raw in enumerate(frames):                             # the same context, a launch per picture
+        J.seq_set_frame(0, raw, W, H)
+        J.seq_encode(0, be.params(k, 2 if k == 0 else 0, min(1, k)), k % be.nslots, 1, False)
+        J.seq_wait(0)
+        got.append((J.seq_records(0), J.seq_get_recon(k % be.nslots), J.get_subplanes(k % be.nslots)))
+    J.synchronize()
+    compare(want, got, "coded again")
+    monkeypatch.delenv("JMHIP_EPZS_BATCH_LAG")
+    be2 = BatchEncoder(W, H, 28, R, 1, LAMBDAS, [8], 10, workgroups=1, search_mode=3)
+    compare(want, be2.run(frames, W, H), "the library's lag")
+    J.close()
+    be2.J.close()
 
 
 def test_batch_refuses_what_it_does_not_cover():
@@ -269,10 +304,8 @@ def test_batch_refuses_what_it_does_not_cover():
         J.seq_batch(p, [pic])                                   # slot 0 was never filled
     with pytest.raises(L.JmHipError, match="its reference"):
         J.seq_batch(p, [dict(pic, out_slot=0)])
-    with pytest.raises(L.JmHipError, match="P pictures with a full search"):
+    with pytest.raises(L.JmHipError, match="P pictures"):
         J.seq_batch(slice_params(L, pyjmo.mbenc_cfg(W, H, 2, 0, nmb, 28, 16, 0, *LAMBDAS[2]), 0, [], []), [pic])
-    with pytest.raises(L.JmHipError, match="P pictures with a full search"):
-        J.seq_batch(slice_params(L, pyjmo.mbenc_cfg(W, H, 0, 0, nmb, 28, 16, 1, *LAMBDAS[0], search_mode=3), 0, [0], [0], 0, {}, 2), [pic])
     with pytest.raises(L.JmHipError):
         J.seq_batch(p, [dict(pic, d_records=0)])
     J.close()
