@@ -1,0 +1,64 @@
+"""Measurement aid (GPU box): configs[2]'s P pictures (1080p, EPZS, CABAC, 8x8 transform, one reference) in ONE launch (jmhip_seq_batch, round 5): ms per picture against
+the queue lag (JMHIP_EPZS_BATCH_LAG) and the launch's workgroups.   usage: python profiles/r05_epzs_batch.py [pictures]"""
+import os
+import sys
+import time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from jm_amd import JmHip
+from jm_amd.lib import SLICE_PARAMS, MB_RECORD
+npic = int(sys.argv[1]) if len(sys.argv) > 1 else 49
+W, H = 1920, 1088
+nmb = (W // 16) * (H // 16)
+frames = bench.yuv_frames(min(npic, 44))
+d_raw = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames]
+d_rec = torch.zeros((npic, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device="cuda")
+nslots = 24
+
+
+def prm(st, nref, poc):
+    return bench.configs2_params(bench.slice_params(SLICE_PARAMS, st, 0, nmb, 0, nref), st, poc)
+
+
+first = None
+for lag, wg in ((0, 0), (8, 0), (10, 0), (16, 0), (20, 0), (26, 0), (0, 128), (0, 192), (0, 320)):
+    if lag:
+        os.environ["JMHIP_EPZS_BATCH_LAG"] = str(lag)
+    else:
+        os.environ.pop("JMHIP_EPZS_BATCH_LAG", None)
+    ctx = JmHip(W, H, search_range=32, num_ref_slots=nslots, yuv_format=1)
+    ctx.seq_open(1)
+    ctx.seq_batch_reserve(npic - 1)
+    ctx.set_pipeline_workgroups(wg)
+    out = []
+    for rep in range(2):
+        ctx.seq_set_frame_dev(0, d_raw[0].data_ptr(), 1920, 1080)
+        ctx.seq_encode(0, prm(2, 0, 0), 0, 1, False)
+        ctx.seq_wait(0)
+        q = prm(0, 1, 2)
+        q["ref_slot"][0, 0], q["ref_id"][0, 0], q["poc_ref"][0, 0] = 0, 0, 0
+        pics = [dict(d_raw=d_raw[k % len(d_raw)].data_ptr(), src_w=1920, src_h=1080, out_slot=k % nslots, ref_slot=[(k - 1) % nslots], ref_id=[k - 1], poc_offset=2 * (k - 1),
+                     d_records=d_rec[k].data_ptr()) for k in range(1, npic)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.seq_batch(q, pics)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        try:
+            ctx.synchronize()
+            res = "ok"
+        except Exception as ex:
+            res = "void (%s)" % getattr(ex, "code", "?")
+        out.append(dt)
+    same = ""
+    if res == "ok":
+        r = d_rec[1:].cpu()
+        if first is None:
+            first = r
+        else:
+            same = ", records equal the first run's" if torch.equal(first, r) else ", RECORDS DIFFER from the first run's"
+    print(f"lag {lag or 'library'} workgroups {wg or 'library'}: {min(out) / (npic - 1) * 1e3:.3f} ms per picture ({npic - 1} P pictures, the faster of two launches), {res}{same}", flush=True)
+    ctx.close()
