@@ -103,6 +103,10 @@ CASES = {
     # EPZS with slices of whole macroblock rows (three per picture), temporal predictors on: what JMHIP_DEVICES deals to several contexts -- a band's last row reads the
     # co-located vectors of the next band's first row (me_epzs_common.c:1575-1602), so the bands' motion has to be exchanged with the samples
     "m2ed": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", SliceMode="1", SliceArgument="33", FramesToBeEncoded="5"), (176, 144), 5, "motion:95"),
+    # forty pictures of EPZS (two references, the shipped switches): JM's visited map is stamped with a 16-bit search count that wraps round every 65536 searches and is never
+    # cleared -- a stamp left 65536 searches ago would make JM skip a candidate; the oracle counts such hits (none here), the device has no such state.  What pins a LONG EPZS
+    # sequence in flight and in one launch (tests/test_gpu_seq.py)
+    "m2e40": (dict(RDO_OFF, SearchMode="3", SearchRange="16", NumberReferenceFrames="2", FramesToBeEncoded="40"), (176, 144), 40, "motion:97"),
     # ---- B pictures (NumberBFrames 1, non-reference, spatial direct): coding order I P B P B ...; Main profile and up.  *b0: BiPredMotionEstimation 0; *b: as the shipped
     # encoder_main.cfg / encoder_yuv422.cfg have it (BiPredMotionEstimation 1, three refinements, range 16, sub-pel 2, 16x16 / 16x8 / 8x16)
     "q1b0": (dict(RDO_OFF, SearchMode="-1", SearchRange="16", NumberReferenceFrames="2", SymbolMode="0", BiPredMotionEstimation="0"), (176, 144), 3, False, "jm_main.cfg"),

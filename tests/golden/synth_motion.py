@@ -30,7 +30,8 @@ def motion_clip(W, H, nfr, seed, yuv422=False):
                          tex=_texture(rng, h + 40, w + 40, 4 + 2 * (k % 3), 3), born=0 if k < 4 else 2, tx=float(rng.integers(-3, 4)) / 4))
     frames = []
     for n in range(nfr):
-        y = _shifted(bg, 40 + 0.5 * n, 40 + 1.75 * n, H, W)
+        m = 24 - abs(n % 48 - 24)                            # the background's drift and the textures' slide turn round every 24 pictures (m = n up to there): the margins are finite
+        y = _shifted(bg, 40 + 0.5 * m, 40 + 1.75 * m, H, W)
         for o in objs:
             if n < o["born"]:
                 continue
@@ -38,7 +39,7 @@ def motion_clip(W, H, nfr, seed, yuv422=False):
             xa, ya, xb, yb = max(0, x0), max(0, y0), min(W, x0 + o["w"]), min(H, y0 + o["h"])
             if xa >= xb or ya >= yb:
                 continue
-            patch = _shifted(o["tex"], 20 + (ya - y0), 20 + (xa - x0) + o["tx"] * n, yb - ya, xb - xa)
+            patch = _shifted(o["tex"], 20 + (ya - y0), 20 + (xa - x0) + o["tx"] * m, yb - ya, xb - xa)
             y[ya:yb, xa:xb] = patch
         y = np.clip(np.rint(y + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
         yd = y.reshape(H, W // 2, 2).mean(axis=2) if yuv422 else y.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))     # 4:2:2: chroma planes W / 2 x H

@@ -448,6 +448,31 @@ def test_1080p_epzs_sequence_in_flight_equals_the_reference_encoder():
         assert d is None, ("against the reference encoder, picture", n, d)
 
 
+def test_forty_epzs_pictures_in_flight_and_in_one_launch_equal_the_reference_encoder():
+    """A long EPZS sequence (tests/golden/mb_low_m2e40.npz: forty pictures, two references, the shipped switches -- JM's 16-bit visited-map stamp wraps round several times; the
+    oracle counts no aliased candidate on it, tests/test_oracle_mbenc.py): sixteen pictures in flight, and the P pictures in launches of 17 / 9 / the rest, every record
+    against the REAL encoder's"""
+    from test_gpu_mbenc import load_case, clip_bytes
+    c = load_case("m2e40")
+    W, H, nfr = c["W"], c["H"], c["nfr"]
+    nmb = (W // 16) * (H // 16)
+    data = clip_bytes("m2e40", c)
+    fs = len(data) // nfr
+    frames = [data[n * fs:(n + 1) * fs] for n in range(nfr)]
+    fl = FlightEncoder(W, H, c["qp"], c["R"], c["num_ref"], c["lam"], 16, cabac=c["cabac"], search_mode=3, epzs=c["epzs"])
+    for raw in frames:
+        fl.submit(raw, c["sw"], c["sh"])
+    got = fl.finish()
+    fl.J.close()
+    be = BatchEncoder(W, H, c["qp"], c["R"], c["num_ref"], c["lam"], [17, 9, 40], 20, cabac=c["cabac"], search_mode=3, epzs=c["epzs"])
+    got1 = be.run(frames, c["sw"], c["sh"])
+    be.J.close()
+    for what, g in (("in flight", got), ("in one launch", got1)):
+        for n in range(nfr):
+            d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(g[n][0])))
+            assert d is None, (what, "against the reference encoder, picture", n, d)
+
+
 def oracle_sequence(W, H, qp, R, num_ref, lam, frames, sw, sh, slice_mbs=0, disable_idc=0, **kw):
     """the ORACLE's picture-after-picture sequence (mbenc_util.SeqEncoder: oracle/jmo_mbenc.c per slice, the oracle's loop filter and interpolation): records, filtered planes,
     the sixteen sub-pel planes -- in the shape `compare` takes"""

@@ -204,6 +204,13 @@ def test_oracle_epzs_six_pictures_full_size():
     assert len(enc.epzs_stats) == 5 and sum(s for s, _ in enc.epzs_stats) > 4000000 and all(s > 65535 for s, _ in enc.epzs_stats) and all(a == 0 for _, a in enc.epzs_stats)
 
 
+def test_oracle_epzs_forty_pictures():
+    """Forty pictures of EPZS with two references (m2e40): JM's 16-bit visited-map stamp wraps round several times over the sequence; every picture's records equal the real
+    encoder's and the oracle meets no aliased candidate -- the sequence the device's long EPZS runs (in flight, in one launch) are pinned to."""
+    enc = run_case("m2e40")
+    assert len(enc.epzs_stats) == 39 and sum(s for s, _ in enc.epzs_stats) > 4 * 65536 and all(a == 0 for _, a in enc.epzs_stats), enc.epzs_stats[-3:]
+
+
 @pytest.mark.skipif(os.environ.get("JMO_LONG") != "1", reason="three minutes of oracle full searches: set JMO_LONG=1 (g2r pins the first two pictures of the same sequence)")
 def test_oracle_macroblock_pipeline_configs1_six_pictures():
     """BASELINE configs[1] with RDOptimization = 0, six pictures (g6r): what the device's pictures in flight are checked against (tests/test_gpu_seq.py, bench.py)."""
