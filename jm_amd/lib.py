@@ -115,6 +115,10 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_seq_batch_reserve", "jmhip_allgather_bands"]
 
 
+# return codes of include/jmhip.h (JmHipError.code)
+OK, EINVAL, ENODEV, ENOMEM, EHIP, EUNSUPPORTED, EREACH = 0, -1, -2, -3, -4, -5, -6
+
+
 class JmHipError(RuntimeError):
     pass
 

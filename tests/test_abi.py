@@ -54,6 +54,17 @@ def test_sequence_picture_layout_is_the_headers(tmp_path):
     assert got == [L.SEQ_PICTURE.itemsize] + [f[n][1] for n in ("d_raw", "src_w", "src_h", "out_slot", "ref_slot", "ref_id", "poc_offset", "d_records")] + [L.SLICE_PARAMS.itemsize], got
 
 
+def test_return_codes_are_the_headers():
+    """jm_amd.lib's return codes (JmHipError.code; EREACH = an EPZS launch of several pictures to be coded again launch by launch) against include/jmhip.h"""
+    import os
+    import re
+    from jm_amd import lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "jmhip.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+JMHIP_(OK|E[A-Z]+)\s+(-?\d+)", text)}
+    assert codes == {"OK": L.OK, "EINVAL": L.EINVAL, "ENODEV": L.ENODEV, "ENOMEM": L.ENOMEM, "EHIP": L.EHIP, "EUNSUPPORTED": L.EUNSUPPORTED, "EREACH": L.EREACH}, codes
+
+
 def test_partition_table_is_the_abi_order():
     from jm_amd.lib import PARTITIONS, NPART
     assert NPART == 41 and len(PARTITIONS) == 41
