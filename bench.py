@@ -1020,19 +1020,28 @@ def main():
             q1["poc_ref"][0, 0] = 0
             pics = [dict(d_raw=d_raw[k % nseq].data_ptr(), src_w=W, src_h=src_h, out_slot=k % nslots, ref_slot=[(k - 1) % nslots], ref_id=[k - 1], poc_offset=2 * (k - 1),
                          d_records=d_r3[k].data_ptr()) for k in range(1, nq)]
-            barrier()
-            tb = time.perf_counter()
-            ctx.seq_batch(q1, pics)
-            barrier()
-            tb = time.perf_counter() - tb
-            kms = ctx.last_kernel_ms(5)
-            try:
-                ctx.synchronize()
-                same3 = bool(torch.equal(d_r3[1:], d_r2[1:]))
-                one_launch = {"pictures": nq - 1, "kernel": "k_mb_pipe_epzs4_t8, one launch (jmhip_seq_batch)", "ms_per_picture": round(tb / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / tb, 1),
-                              "kernel_ms": round(kms, 3), "records_equal_pictures_in_flight": same3}
-            except Exception as ex:
-                one_launch = {"void": repr(ex)[:300], "note": "the launch was given up (JMHIP_EREACH): these pictures are coded by the launches in flight above"}
+            given_up = []
+            for lag in (0, 20, 32):                                       # the library's lag; a launch that is given up (JMHIP_EREACH) once more with its pictures further apart
+                ctx.seq_batch_lag(lag)
+                if given_up:
+                    estep(0)
+                    ctx.seq_wait(0)
+                barrier()
+                tb = time.perf_counter()
+                ctx.seq_batch(q1, pics)
+                barrier()
+                tb = time.perf_counter() - tb
+                kms = ctx.last_kernel_ms(5)
+                try:
+                    ctx.synchronize()
+                    same3 = bool(torch.equal(d_r3[1:], d_r2[1:]))
+                    one_launch = {"pictures": nq - 1, "kernel": "k_mb_pipe_epzs4_t8, one launch (jmhip_seq_batch)", "ms_per_picture": round(tb / (nq - 1) * 1e3, 3), "macroblocks_per_s": round(nmb * (nq - 1) / tb, 1),
+                                  "kernel_ms": round(kms, 3), "records_equal_pictures_in_flight": same3, "queue_lag": lag or "the library's (13 at SearchRange 32)", "given_up_with_lags": given_up}
+                    break
+                except Exception as ex:
+                    given_up.append(lag)
+                    one_launch = {"void": repr(ex)[:300], "given_up_with_lags": given_up, "note": "every launch was given up (JMHIP_EREACH): these pictures are coded by the launches in flight above"}
+            ctx.seq_batch_lag(0)
             ctx.set_pipeline_workgroups(0)
         except Exception as ex:                                           # (an extra figure must not cost the line)
             one_launch = {"error": repr(ex)[:300]}

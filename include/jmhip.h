@@ -760,6 +760,10 @@ typedef struct {
   jmhip_mb_record *d_records;   /* device: PicSizeInMbs records */
 } jmhip_seq_picture;
 int jmhip_seq_batch(jmhip_ctx *ctx, const jmhip_slice_params *prm, int32_t direct_8x8_inference, int32_t n, const jmhip_seq_picture *pics);
+/* EPZS launches of several pictures: the queue lag in wavefront keys (0: the library's, 3 ceil((SearchRange + 27) / 16) + 1).  A caller whose launch came back with JMHIP_EREACH may
+ * try the same pictures once more with a larger lag -- pictures further apart reach less of each other; a picture's whole wavefront, PicWidthInMbs + 2 (PicHeightInMbs - 1), is
+ * picture after picture inside one launch and never gives up -- before it falls back to a launch per picture. */
+int jmhip_seq_batch_lag(jmhip_ctx *ctx, int32_t lag);
 /* The device memory a launch of n pictures needs beside the slots (per picture: the source picture, edge records, flags, loop-filter side information; the launch's descriptors
  * and ticket table) is kept from launch to launch and grows with the first launch that needs more: a caller that knows its run length reserves it once, after jmhip_seq_open,
  * instead of paying a hipMalloc inside its first long launch (JM: the counterpart of init_global_buffers, lencod.c, which allocates per sequence, not per picture). */

@@ -106,6 +106,7 @@ struct jmhip_ctx {
   // several pictures in ONE launch (jmhip_seq_batch): per picture a source picture, edge records, flags and loop-filter side information at a fixed stride; the
   // pictures' descriptors and the ticket order of the last batch
   uint8_t *d_batch; int batch_cap; void *d_batch_tab; size_t batch_tab_bytes; unsigned batch_epoch;
+  int batch_lag;         // jmhip_seq_batch_lag: the EPZS launches' queue lag (0: the library's)
   int *d_batch_ez; size_t batch_ez_bytes;      // jmhip_seq_batch with EPZS: the pictures' PicView::ez_state
   int timing;
   int force_generic;     // JMHIP_FORCE_GENERIC=1: never use the tuned ME kernel (A/B testing)

@@ -112,7 +112,7 @@ EXPORTS = ["jmhip_create", "jmhip_destroy", "jmhip_last_error", "jmhip_synchroni
            "jmhip_deblock_frame", "jmhip_deblock_frame_dev", "jmhip_enable_timing", "jmhip_last_kernel_ms",
            "jmhip_encode_slice", "jmhip_encode_slice_dev", "jmhip_encode_slice_begin", "jmhip_slice_record", "jmhip_encode_slice_end", "jmhip_recon_planes_dev", "jmhip_deblock_side_info_dev", "jmhip_get_recon", "jmhip_deblock_picture_dev", "jmhip_reference_from_recon", "jmhip_set_pipeline_workgroups",
            "jmhip_seq_open", "jmhip_seq_b_workgroups", "jmhip_seq_close", "jmhip_seq_set_frame", "jmhip_seq_set_planes", "jmhip_seq_set_frame_dev", "jmhip_seq_encode", "jmhip_seq_record", "jmhip_seq_wait", "jmhip_seq_records", "jmhip_seq_records_dev",
-           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_seq_batch_reserve", "jmhip_allgather_bands"]
+           "jmhip_seq_recon_dev", "jmhip_seq_get_recon", "jmhip_seq_kernel_ms", "jmhip_seq_batch", "jmhip_seq_batch_reserve", "jmhip_seq_batch_lag", "jmhip_allgather_bands"]
 
 
 # return codes of include/jmhip.h (JmHipError.code)
@@ -696,6 +696,10 @@ class JmHip:
             a[k]["ref_id"][:len(q["ref_id"])] = q["ref_id"]
             a[k]["poc_offset"] = q.get("poc_offset", 0)                    # EPZS: the picture's order counts relative to prm's
         self._ck(self.lib.jmhip_seq_batch(self.h, _vp(prm), int(direct8x8), len(pictures), _vp(a)))
+
+    def seq_batch_lag(self, lag):
+        """jmhip_seq_batch_lag: the queue lag of EPZS launches of several pictures (0: the library's)"""
+        self._ck(self.lib.jmhip_seq_batch_lag(self.h, int(lag)))
 
     def seq_batch_reserve(self, n):
         """device memory for launches of up to n pictures (jmhip_seq_batch), ahead of the first one"""

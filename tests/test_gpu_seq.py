@@ -284,6 +284,12 @@ def test_epzs_launch_of_several_pictures_given_up_and_coded_again(monkeypatch):
     be2 = BatchEncoder(W, H, 28, R, 1, LAMBDAS, [8], 10, workgroups=1, search_mode=3)
     compare(want, be2.run(frames, W, H), "the library's lag")
     J.close()
+    be2.J.seq_batch_lag(4)                                       # the caller's knob (jmhip_seq_batch_lag): given up again, then a whole wavefront apart -- picture after picture in one launch
+    with pytest.raises(L.JmHipError) as ei:
+        be2.run(frames, W, H)
+    assert ei.value.code == L.EREACH
+    be2.J.seq_batch_lag(W // 16 + 2 * (H // 16 - 1) + 1)
+    compare(want, be2.run(frames, W, H), "a whole wavefront apart")
     be2.J.close()
 
 
