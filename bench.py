@@ -987,16 +987,22 @@ def main():
         # ... and the same search as a sequence with pictures in flight (every search asks for what it reaches of a reference in the making): I + 16 P pictures of the clip, one
         # reference; the first three pictures' records against the real encoder's (mb_low_g3h holds three: I, P with one reference, P with two -- the third differs by its reference count, so two are compared)
         # EPZS P pictures run as four-wave workgroups, two to a compute unit: sixteen pictures in flight x 2 x 16 workgroups fill the chip (profiles/r04_epzs_four_wave.txt)
-        nq = 65                                                          # an I picture and 64 P pictures: the clip's pictures over and over (four fills of the sixteen entries; a launch takes ~20 x the steady state's time per picture)
+        nq = 65                                                          # an I picture and 64 P pictures: the clip's pictures forwards and backwards (four fills of the sixteen entries; a launch takes ~20 x the steady state's time per picture)
         depth_e = depth if (one_gpu and world > 1) else max(1, min(16, nslots - 2, 2 * args.flight))
         ctx.seq_open(depth_e, 0 if batch else args.workgroups, ready=True)
         d_r2 = torch.zeros((nq, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device=dev)
+
+        def pp(k):
+            """the clip's pictures forwards, then backwards, ...: more pictures than the clip has without a scene cut where it would start again (a cut is where EPZS reaches furthest,
+            and a launch of several pictures is then given up every other run: profiles/r05_epzs_batch.txt)"""
+            m = k % (2 * (nseq - 1)) if nseq > 1 else 0
+            return m if m < nseq else 2 * (nseq - 1) - m
 
         def estep(k):
             q = epzs_prm(2 if k == 0 else 0, 0 if k == 0 else 1, 2 * k)
             if k:
                 q["ref_slot"][0, 0], q["ref_id"][0, 0], q["poc_ref"][0, 0] = (k - 1) % nslots, k - 1, 2 * (k - 1)
-            ctx.seq_set_frame_dev(k % depth_e, d_raw[k % nseq].data_ptr(), W, src_h)
+            ctx.seq_set_frame_dev(k % depth_e, d_raw[pp(k)].data_ptr(), W, src_h)
             ctx.seq_encode(k % depth_e, q, k % nslots, 1, False, d_r2[k].data_ptr())
         estep(0)
         barrier()
@@ -1018,7 +1024,7 @@ def main():
             ctx.seq_wait(0)
             q1 = epzs_prm(0, 1, 2)
             q1["poc_ref"][0, 0] = 0
-            pics = [dict(d_raw=d_raw[k % nseq].data_ptr(), src_w=W, src_h=src_h, out_slot=k % nslots, ref_slot=[(k - 1) % nslots], ref_id=[k - 1], poc_offset=2 * (k - 1),
+            pics = [dict(d_raw=d_raw[pp(k)].data_ptr(), src_w=W, src_h=src_h, out_slot=k % nslots, ref_slot=[(k - 1) % nslots], ref_id=[k - 1], poc_offset=2 * (k - 1),
                          d_records=d_r3[k].data_ptr()) for k in range(1, nq)]
             given_up = []
             for lag in (0, 20, 32):                                       # the library's lag; a launch that is given up (JMHIP_EREACH) once more with its pictures further apart

@@ -24,7 +24,8 @@ def prm(st, nref, poc):
 
 
 first = None
-for lag, wg in ((0, 0), (8, 0), (10, 0), (16, 0), (20, 0), (26, 0), (0, 128), (0, 192), (0, 320)):
+REPS = int(os.environ.get('REPS', '2'))
+for lag, wg in [(int(a), 0) for a in os.environ['LAGS'].split(',')] if os.environ.get('LAGS') else ((0, 0), (8, 0), (10, 0), (16, 0), (20, 0), (26, 0), (0, 128), (0, 192), (0, 320)):
     if lag:
         os.environ["JMHIP_EPZS_BATCH_LAG"] = str(lag)
     else:
@@ -33,8 +34,8 @@ for lag, wg in ((0, 0), (8, 0), (10, 0), (16, 0), (20, 0), (26, 0), (0, 128), (0
     ctx.seq_open(1)
     ctx.seq_batch_reserve(npic - 1)
     ctx.set_pipeline_workgroups(wg)
-    out = []
-    for rep in range(2):
+    out, voids = [], 0
+    for rep in range(REPS):
         ctx.seq_set_frame_dev(0, d_raw[0].data_ptr(), 1920, 1080)
         ctx.seq_encode(0, prm(2, 0, 0), 0, 1, False)
         ctx.seq_wait(0)
@@ -50,9 +51,10 @@ for lag, wg in ((0, 0), (8, 0), (10, 0), (16, 0), (20, 0), (26, 0), (0, 128), (0
         try:
             ctx.synchronize()
             res = "ok"
+            out.append(dt)
         except Exception as ex:
             res = "void (%s)" % getattr(ex, "code", "?")
-        out.append(dt)
+            voids += 1
     same = ""
     if res == "ok":
         r = d_rec[1:].cpu()
@@ -60,5 +62,5 @@ for lag, wg in ((0, 0), (8, 0), (10, 0), (16, 0), (20, 0), (26, 0), (0, 128), (0
             first = r
         else:
             same = ", records equal the first run's" if torch.equal(first, r) else ", RECORDS DIFFER from the first run's"
-    print(f"lag {lag or 'library'} workgroups {wg or 'library'}: {min(out) / (npic - 1) * 1e3:.3f} ms per picture ({npic - 1} P pictures, the faster of two launches), {res}{same}", flush=True)
+    print(f"lag {lag or 'library'} workgroups {wg or 'library'}: {(min(out) if out else 0) / (npic - 1) * 1e3:.3f} ms per picture ({npic - 1} P pictures, the fastest of {REPS} launches; {voids} of them given up), last: {res}{same}", flush=True)
     ctx.close()
