@@ -455,6 +455,47 @@ def test_lencod_pictures_in_flight_are_verified_not_trusted(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,ov,max_void,min_hit", [
+    ("intra period", {"IntraPeriod": "4"}, 6, 6),                                       # an I picture where a P picture was launched ahead of time: at most the pictures in flight (3) per event
+    ("IDR period", {"IDRPeriod": "4"}, 6, 6),                                           # ... and the reference list starts again behind it
+    ("both", {"IDRPeriod": "5", "IntraPeriod": "3"}, 9, 3),
+    ("QP change", {"ChangeQPFrame": "5", "ChangeQPP": "5", "ChangeQPI": "5"}, 3, 6),
+    ("EPZS, IDR period", {"SearchMode": "3", "IDRPeriod": "6"}, 15, 5),                 # sixteen entries: one IDR picture voids what is in flight behind it
+])
+def test_lencod_look_ahead_voids_are_bounded_and_harmless(tmp_path, name, ov, max_void, min_hit):
+    """Twelve pictures with events the adapter's look-ahead cannot foresee (intra / IDR periods, a QP change): the launches made ahead of time with the wrong parameters are
+    found out byte for byte and redone -- the .264 and the reconstruction are CPU JM's --, and what that costs is bounded: at most the pictures in flight per event are voided,
+    the others are served as launched (profiles/r05_void_probe.txt: 3 voided / 9 served for the full searches, 11 / 8 for EPZS with its sixteen entries)."""
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/lencod_hip.exe missing")
+    import re as _re
+    import sys as _sys
+    import numpy as np
+    _sys.path.insert(0, G)
+    import synth_motion
+    cpu = os.path.join(ROOT, "oracle", "_ref", "lencod.exe")
+    clip = np.concatenate(synth_motion.motion_clip(176, 144, 12, 123))
+    outs = []
+    for exe in (cpu, EXE):
+        d = os.path.join(str(tmp_path), "cpu" if exe == cpu else "hip")
+        os.makedirs(d)
+        clip.tofile(os.path.join(d, "motion.yuv"))
+        args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+        for k, v in dict({"InputFile": "motion.yuv", "RDOptimization": "0", "AdaptiveRounding": "0", "SearchMode": "-1", "SearchRange": "16", "NumberReferenceFrames": "2",
+                          "FramesToBeEncoded": "12", "FrameSkip": "0", "OutputFile": "o.264", "ReconFile": "o_rec.yuv", "TraceFile": "/dev/null"}, **ov).items():
+            args += ["-p", f"{k}={v}"]
+        r = subprocess.run(args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (name, r.stderr.decode(errors="replace")[-1500:])
+        outs.append((md5(os.path.join(d, "o.264")), md5(os.path.join(d, "o_rec.yuv")), r.stderr.decode(errors="replace")))
+    assert outs[0][:2] == outs[1][:2], (name, "the drop-in encoder's bytes differ from CPU JM's")
+    m = _re.search(r"pictures in flight: (\d+) pictures, (\d+) launched ahead of time \(up to (\d+) in flight\), (\d+) of them served as launched, (\d+) voided", outs[1][2])
+    assert m, outs[1][2][-1500:]
+    pics, ahead, depth, hit, void = (int(x) for x in m.groups())
+    assert pics == 12 and void <= max_void and hit >= min_hit, (name, m.groups())
+    assert "passed to JM's own code: 0 calls" in outs[1][2], outs[1][2][-800:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["m3b", "m2b4", "m3bt"])
 def test_lencod_b_pictures_are_launched_ahead_of_time_too(tmp_path, tag):
     """Sequences with B pictures (coding order I P B P B ...): the adapter predicts the order, the frames' places in the file and both reference lists of the pictures to come
