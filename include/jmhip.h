@@ -707,6 +707,8 @@ int jmhip_reference_from_recon(jmhip_ctx *ctx, int32_t slot);
  * filtered reconstruction is out_slot's integer planes (jmhip_seq_get_recon / jmhip_seq_recon_dev; no sub-pel planes, no post flags: nobody reads it as a reference; give it a
  * slot that holds no reference of a picture still to be launched).  Anything else is JMHIP_EUNSUPPORTED and the caller codes that picture the usual way (the slots are shared with the other entry points: use them
  * after jmhip_seq_wait of the entry that wrote them, or after jmhip_synchronize).
+ * jmhip_seq_open returns once entry 0 exists; the others (a stream and a pinned record buffer each: 10 - 12 ms) are made on a thread of the library's that starts when the first
+ * launch is queued and is joined by the first call that names one of them (or by jmhip_seq_close / jmhip_destroy); JMHIP_SEQ_OPEN_INLINE=1: all inside jmhip_seq_open.
  * ------------------------------------------------------------------------------------------ */
 int jmhip_seq_open(jmhip_ctx *ctx, int32_t depth, int32_t workgroups_per_picture /* 0: 256 / depth, at most 80; always cut to 248 / (depth - 1), so that the oldest picture in flight can never be
                    kept off the chip by the workgroups of later ones waiting for it.  HIP serves a process's streams from GPU_MAX_HW_QUEUES hardware queues (default 4): with
