@@ -259,6 +259,18 @@ def test_pictures_in_one_launch_equal_picture_after_picture(W, H, R, num_ref, qp
     compare(want, got, (W, H, R, num_ref, sizes, nslots))
 
 
+def test_epzs_pictures_in_one_launch_with_the_eight_wave_kernels(monkeypatch):
+    """EPZS in the one queue with JMHIP_EPZS_WAVES=8 (k_mb_pipe_epzs / _t8: the form a slice with more references than two four-wave workgroups' LDS allow falls back to)"""
+    monkeypatch.setenv("JMHIP_EPZS_WAVES", "8")
+    for (W, H, R, num_ref, kw) in ((320, 192, 16, 2, {}), (320, 192, 16, 1, {"cabac": 1, "transform8x8": 1})):
+        frames = synthetic_clip(W, H, num_ref + 7, 47)
+        want = classic(W, H, 28, R, num_ref, LAMBDAS, frames, search_mode=3, **kw)
+        be = BatchEncoder(W, H, 28, R, num_ref, LAMBDAS, [6], 8, search_mode=3, **kw)
+        got = be.run(frames, W, H)
+        be.J.close()
+        compare(want, got, ("eight waves", kw))
+
+
 def test_epzs_launch_of_several_pictures_given_up_and_coded_again(monkeypatch):
     """EPZS in the one queue: with a queue lag far below what the searches reach and one workgroup drawing the tickets, a search asks for a macroblock whose ticket is not
     out -- the launch is given up (JMHIP_EREACH, -6) instead of waiting for good, and the same context then codes the same pictures launch by launch, with the results of
