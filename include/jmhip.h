@@ -748,7 +748,7 @@ int jmhip_seq_get_recon(jmhip_ctx *ctx, int32_t slot, uint16_t *y, int32_t pitch
  * jmhip_subplanes_dev.  Scope: search_mode 0, 1 and 3, P slices, the whole picture (one slice or num_slices of them), num_ref <= 8, PicSizeInMbs < 65536, n <= 4096; needs jmhip_seq_open
  * (any depth).  Anything else JMHIP_EUNSUPPORTED.  Results: those of coding the pictures one after another (tests/test_gpu_seq.py).
  * EPZS (search_mode 3, P slices; round 5): a full search reads its reference no further than SearchRange from the predictor it was staged for, EPZS wherever its predictors point
- * (me_epzs_int.c:42: up to the level's vector range), so no lag covers every case.  The queue is ordered for a reach of SearchRange + 27 samples (lag 13 at SearchRange 32;
+ * (me_epzs_int.c:42: up to the level's vector range), so no lag covers every case.  The queue is ordered for a reach of SearchRange + 27 samples (lag 13 at SearchRange 32, 16 with several references;
  * JMHIP_EPZS_BATCH_LAG overrides) and every search asks for what IT reaches as with jmhip_seq_encode -- and waits only for a macroblock whose ticket is known to be handed
  * out (an earlier place in the queue than its own, or all tickets up to that place drawn already: such a wait always ends).  A search that reaches further sets the launch's
  * error word instead of waiting: jmhip_synchronize then returns JMHIP_EREACH, NOTHING of the launch is valid (records, slots), and the caller codes the same pictures with
@@ -762,7 +762,7 @@ typedef struct {
   jmhip_mb_record *d_records;   /* device: PicSizeInMbs records */
 } jmhip_seq_picture;
 int jmhip_seq_batch(jmhip_ctx *ctx, const jmhip_slice_params *prm, int32_t direct_8x8_inference, int32_t n, const jmhip_seq_picture *pics);
-/* EPZS launches of several pictures: the queue lag in wavefront keys (0: the library's, 3 ceil((SearchRange + 27) / 16) + 1).  A caller whose launch came back with JMHIP_EREACH may
+/* EPZS launches of several pictures: the queue lag in wavefront keys (0: the library's, 3 ceil((SearchRange + 27) / 16) + 1, three more with several references).  A caller whose launch came back with JMHIP_EREACH may
  * try the same pictures once more with a larger lag -- pictures further apart reach less of each other; a picture's whole wavefront, PicWidthInMbs + 2 (PicHeightInMbs - 1), is
  * picture after picture inside one launch and never gives up -- before it falls back to a launch per picture. */
 int jmhip_seq_batch_lag(jmhip_ctx *ctx, int32_t lag);
