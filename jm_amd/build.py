@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libjmhip.so")
 SOURCES = ["ctx.hip", "input.hip", "interp.hip", "me_fullsearch.hip", "me_fast.hip", "me_subpel.hip", "me_refine.hip", "tq.hip", "tq8.hip", "tq16.hip", "tq_chroma.hip", "mc.hip", "intra.hip", "distortion.hip", "deblock.hip", "deblock_rows.hip", "deblock_sparse.hip"]
-# mbpipe.hip is compiled eleven times: -DMBPIPE_PART=0..3, 5..10 one kernel instance each (7, 8: B slices; 9, 10: several references), 4 the host side (one unit takes six minutes, the parts side by side)
-MBPIPE_PARTS = (8, 3, 7, 10, 6, 1, 9, 5, 2, 0, 4)                                 # the slowest first
+# mbpipe.hip is compiled thirteen times: -DMBPIPE_PART=0..3, 5..11 one kernel instance each (7, 8: B slices; 9, 10: several references; 11: the six-wave form; 12: part 0's kernel with JMHIP_MB_PROF's time stamps, which part 0 itself is compiled without), 4 the host side (one unit takes six minutes, the parts side by side)
+MBPIPE_PARTS = (8, 3, 7, 10, 6, 1, 9, 5, 2, 0, 12, 11, 4)                                 # the slowest first
 # The macroblock pipeline's units are compiled without machine-level loop-invariant code motion: in a kernel whose one loop body is 240 KB of code every value hoisted to the
 # top is a value spilled (k_mb_pipe: 304 -> 208 bytes of scratch per lane, 2 % faster; profiles/r04_kernel_resources.txt).  JMHIP_MBPIPE_FLAGS adds flags (measurement aid).
 MBPIPE_FLAGS = ["-mllvm", "-disable-machine-licm"] + os.environ.get("JMHIP_MBPIPE_FLAGS", "").split()
@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
         src, part = job
         obj = os.path.join(objdir, os.path.basename(src) + (".o" if part is None else ".part%d.o" % part))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps(src)):
-            cmd = [hipcc()] + flags + ([] if part is None else ["-DMBPIPE_PART=%d" % part] + MBPIPE_FLAGS) + ["-c", src, "-o", obj]
+            cmd = [hipcc()] + flags + ([] if part is None else ["-DMBPIPE_PART=%d" % part] + (["-DMBPIPE_PROF_ON=0"] if part == 0 else []) + MBPIPE_FLAGS) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -70,6 +70,7 @@ struct jmhip_ctx {
   int mb_band_start[9];
   unsigned mb_epoch;
   int mb_launched;       // a pipeline launch has happened since its error word was last read
+  int mb_alloc_done;     // mb_alloc (mbpipe_host.inc) has completed: every buffer of the pipeline exists
   int mb_grid;           // jmhip_set_pipeline_workgroups (0: the device's compute units)
   int num_cus;           // hipDeviceProp_t::multiProcessorCount (256 on a whole MI355X; a partitioned one -- CPX / DPX -- has fewer): the persistent launches are sized by it
   void *d_mb_records;    // jmhip_mb_record per macroblock of the picture

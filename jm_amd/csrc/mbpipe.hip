@@ -42,6 +42,12 @@ typedef uint8_t u8;
 #define MBPIPE_PART -1
 #endif
 #define MBPIPE_HOST (MBPIPE_PART == -1 || MBPIPE_PART == 4)
+// JMHIP_MB_PROF's time stamps: a kernel instance compiled with -DMBPIPE_PROF_ON=0 has none of their tests (the headline instance k_mb_pipe: ~55 instructions of every search; its
+// twin k_mb_pipe_prof, part 12, keeps them and is what a context made under JMHIP_MB_PROF launches)
+#ifndef MBPIPE_PROF_ON
+#define MBPIPE_PROF_ON 1
+#endif
+#define APROF (MBPIPE_PROF_ON ? A.prof : (unsigned long long *)nullptr)
 
 #define MB_THREADS 512
 #define MAXC 0x7fffffff
@@ -273,7 +279,13 @@ __device__ __forceinline__ void lds_wait_ge(const int *f, int seq) { while (*(co
 
 // Cross-lane steps inside a row of 16 lanes as DPP operands of the ALU (no trip through the LDS crossbar that __shfl_xor takes):
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- after n of them every lane holds the result over its 2^n neighbours.
-template <int CTRL> __device__ __forceinline__ int dpp_(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// (every lane of these four patterns has a source lane: `old` is never used, and with old = 0 / bound_ctrl the compiler folds the move into the min / add that follows --
+// one instruction per step instead of mov, nop, mov_dpp, op)
+template <int CTRL> __device__ __forceinline__ int dpp_(int v)
+{
+  static_assert(CTRL == 0xB1 || CTRL == 0x4E || CTRL == 0x141 || CTRL == 0x140, "quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror");
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
 __device__ __forceinline__ u32 umin_(u32 a, u32 b) { return a < b ? a : b; }
 // minimum over each row of 16 lanes (every lane of the row gets it)
 __device__ __forceinline__ u32 row16_min_u32(u32 x)
@@ -432,6 +444,18 @@ __device__ __forceinline__ u64 fs_key(const FsCost &c, int sad, int dx, int dy, 
   return ((u64)cost << 32) | ((u64)spiral_index(dx, dy) << 16) | (u64)(((dy + 128) << 8) | (dx + 128));
 }
 
+// the compiler may not move the sums' updates across this point (they stay in their registers: no instruction is issued)
+template <int N> __device__ __forceinline__ void fence_regs(u32 (&a)[N])
+{
+  static_assert(N == 4 || N == 8 || N == 16, "block heights");
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+  if constexpr (N >= 8) asm volatile("" : "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+  if constexpr (N >= 16) {
+    asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
+    asm volatile("" : "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+  }
+}
+
 // win: the reference's window in LDS (picture row wy0 + y at row y); cur: the block's rows in LDS (S.cur_y + by * 4 + bx / 4);
 // (X0, Y0): window position of the candidate (dx, dy) = (-Rs, -Rs).  Returns the wave-wide minimum key.
 // NB candidate rows i0 .. i0 + NB - 1 (those beyond i_last do not count) of one column at once: every window row read before the first is used (left
@@ -457,13 +481,16 @@ __device__ __forceinline__ u32 rows_at_once(const u8 *pbase, int WP, int sh, con
   for (int r = 0; r < NR; r++)
 #pragma unroll
     for (int k = 0; k < BW / 4; k++) bb[r][k] = __builtin_amdgcn_alignbyte(aa[r][k + 1], aa[r][k], sh);
+  u32 vv[NB];
+#pragma unroll
+  for (int r = 0; r < BH; r++)                                   // (consecutive instructions belong to NB different sums)
+#pragma unroll
+    for (int q = 0; q < BW / 4; q++)
+#pragma unroll
+      for (int k = 0; k < NB; k++) vv[k] = __builtin_amdgcn_sad_u8(bb[k + r][q], cb[r][q], (r == 0 && q == 0) ? 0u : vv[k]);
 #pragma unroll
   for (int k = 0; k < NB; k++) {
-    u32 v = 0;
-#pragma unroll
-    for (int r = 0; r < BH; r++)
-#pragma unroll
-      for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(bb[k + r][q], cb[r][q], v);
+    const u32 v = vv[k];
     const int i = i0 + k, dy = i - Rs, ady = dy < 0 ? -dy : dy;
     const u32 kf = (v << 12) + rx7 + ytv[k];
     const u32 kn = (kf & ~127u) | (u32)(i + k1);
@@ -471,6 +498,24 @@ __device__ __forceinline__ u32 rows_at_once(const u8 *pbase, int WP, int sh, con
     bkey = (i <= i_last && key < bkey) ? key : bkey;
   }
   return bkey;
+}
+
+// the SAD of ONE candidate (the block at p): four sums side by side (a dependent v_sad_u8 issues only every 9.5 cycles), every row's loads issued before the first is used
+template <int BW, int BH>
+__device__ __forceinline__ u32 sad_block(const u8 *p, int WP, int sh, const u32 (&cb)[BH][BW / 4])
+{
+  u32 v[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r0 = 0; r0 < BH; r0 += 4) {
+    u32 b[4][BW / 4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) load_row<BW>(p + (r0 + r) * WP, sh, b[r]);
+#pragma unroll
+    for (int q = 0; q < BW / 4; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = __builtin_amdgcn_sad_u8(b[r][q], cb[r0 + r][q], v[r]);
+  }
+  return (v[0] + v[1]) + (v[2] + v[3]);
 }
 
 // spec(mv): called (pruned searches only) with the best integer vector of the first rows -- most often the search's result -- so that the caller can
@@ -508,6 +553,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   int d_lo2 = 0, d_hi2 = -1, d_dqx2 = -1;                      // what the decision after step 0 found (step 2 uses it as it is when step 1 read nothing)
   int ev_lo = a_lo, ev_hi = a_hi;                              // hull of the rows read by the sliding lanes
   u32 bound = 0xffffffffu;                                     // the best cost so far
+  bool fast = false;                                           // the rows of step 0 settled the search (below)
   const float rcp_lambda = __builtin_amdgcn_rcpf((float)(c.lambda > 0 ? c.lambda : 1));
   {                                                            // columns 0..63: a lane slides down its column
     // A lane beyond the last column repeats the last column's candidates (same keys: harmless).  The column keeps ONE 32-bit key per
@@ -573,15 +619,26 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
           const int i = s_lo + f - (BH - 1);
           yt[f] = ytab[i < 0 ? 0 : (i > 2 * Rs ? 2 * Rs : i)];
         }
+        // key = ((SAD << 5) + rate_x + rate_y) << 7 | rank.  With the row's (rate_y << 7 | far rank) from the table that is one shift-add and one add
+        // for the rows beyond |dx| (far rank); for the rows within, the low seven bits are replaced by dy + |dx|.  Rows that end no candidate of this segment give ~0.
+        auto key_of = [&](u32 fin_, u32 ytf_, int i) {           // i: the candidate row, the same for every lane
+          const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
+          const u32 kf = (fin_ << 12) + rx7 + ytf_;
+          const u32 kn = (kf & ~127u) | (u32)(i + k1);
+          const u32 key = (u32)ady <= (u32)adx ? kn : kf;
+          if (BW == 16 && BH == 16) sad00 = (c.check00 && c.cqy + 4 * dy == 0 && i >= s_lo) ? fin_ : sad00;     // the (0,0) vector's row, for its bonus below
+          return (i >= s_lo && i <= s_hi) ? key : 0xffffffffu;
+        };
+        constexpr bool IMM = BH >= 16;                           // sixteen-row blocks: a row's key at once (64 / 32 sums lie between two keys: nothing waits), not 48 registers of them
         for (int j0 = 0; j0 < nrows; j0 += BH) {               // rows past the last one (a partial final group) lie in the window's slack rows
-          u32 fin[BH], ytf[BH];
+          u32 fin[IMM ? 1 : BH], ytf[IMM ? 1 : BH];
 #pragma unroll
           for (int s = 0; s < BH; s++) {
             const int j = j0 + s;
             u32 b[BW / 4];
 #pragma unroll
             for (int k = 0; k < BW / 4; k++) b[k] = __builtin_amdgcn_alignbyte(a[s % PF][k + 1], a[s % PF][k], sh);
-            ytf[s] = yt[s % PF];
+            const u32 yts = yt[s % PF];
             {                                                  // row j + PF into the slot just freed
               const u8 *pn = p + (j + PF) * WP;
 #pragma unroll
@@ -590,36 +647,33 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
               yt[s % PF] = ytab[in < 0 ? 0 : (in > 2 * Rs ? 2 * Rs : in)];
             }
             __builtin_amdgcn_sched_barrier(0);                 // keeps the compiler from sinking the read-ahead to where the data is needed
+            // window row j is row r of the candidate that starts at row j - r.  Dword column by dword column, so that consecutive instructions belong to BH different
+            // sums (a lone wave issues a dependent v_sad_u8 only every 9.5 cycles: profiles/microbench/issue_rate.hip), and fenced row by row: left alone the compiler
+            // keeps sixteen aligned window rows in registers and sums a 16-row block candidate by candidate -- 64 dependent instructions in a row (round 6)
 #pragma unroll
-            for (int r = 0; r < BH; r++) {                     // window row j is row r of the candidate that starts at row j - r
-              const int k = (s - r + BH) % BH;
-              u32 v = r == 0 ? 0u : acc[k];
+            for (int q = 0; q < BW / 4; q++)
 #pragma unroll
-              for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
-              acc[k] = v;
-            }
-            fin[s] = acc[(s + 1) % BH];                        // the candidate that ends with this row
+              for (int r = 0; r < BH; r++) {
+                const int k = (s - r + BH) % BH;
+                acc[k] = __builtin_amdgcn_sad_u8(b[q], cb[r][q], (q == 0 && r == 0) ? 0u : acc[k]);
+              }
+            fence_regs<BH>(acc);
+            if constexpr (IMM) {
+              const u32 key = key_of(acc[(s + 1) % BH], yts, s_lo + j - (BH - 1));
+              bkey = key < bkey ? key : bkey;
+            } else { fin[s] = acc[(s + 1) % BH]; ytf[s] = yts; }   // the candidate that ends with this row
           }
-          // the group's keys side by side: BH independent chains (a lone wave issues a dependent instruction only every ~9 cycles), no branch:
-          // rows that end no candidate of this segment give the key ~0
-          u32 gk[BH];
+          if constexpr (!IMM) {
+            // the group's keys side by side: BH independent chains (a lone wave issues a dependent instruction only every ~9 cycles), no branch
+            u32 gk[BH];
 #pragma unroll
-          for (int s = 0; s < BH; s++) {
-            // key = ((SAD << 5) + rate_x + rate_y) << 7 | rank.  With the row's (rate_y << 7 | far rank) from the table that is one shift-add and one add
-            // for the rows beyond |dx| (far rank); for the rows within, the low seven bits are replaced by dy + |dx|.
-            const int i = s_lo + j0 + s - (BH - 1);            // the same for every lane
-            const int dy = i - Rs, ady = dy < 0 ? -dy : dy;
-            const u32 kf = (fin[s] << 12) + rx7 + ytf[s];
-            const u32 kn = (kf & ~127u) | (u32)(i + k1);
-            const u32 key = (u32)ady <= (u32)adx ? kn : kf;
-            if (BW == 16 && BH == 16) sad00 = (c.check00 && c.cqy + 4 * dy == 0 && i >= s_lo) ? fin[s] : sad00;     // the (0,0) vector's row, for its bonus below
-            gk[s] = (i >= s_lo && i <= s_hi) ? key : 0xffffffffu;
+            for (int s = 0; s < BH; s++) gk[s] = key_of(fin[s], ytf[s], s_lo + j0 + s - (BH - 1));
+#pragma unroll
+            for (int w = BH / 2; w >= 1; w >>= 1)
+#pragma unroll
+              for (int s = 0; s < w; s++) gk[s] = gk[s] < gk[s + w] ? gk[s] : gk[s + w];
+            bkey = gk[0] < bkey ? gk[0] : bkey;
           }
-#pragma unroll
-          for (int w = BH / 2; w >= 1; w >>= 1)
-#pragma unroll
-            for (int s = 0; s < w; s++) gk[s] = gk[s] < gk[s + w] ? gk[s] : gk[s + w];
-          bkey = gk[0] < bkey ? gk[0] : bkey;
         }
       }
       if (seg == 0 && prune) {
@@ -635,6 +689,16 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
         const int kq = (int)((float)bound * rcp_lambda) + 1;    // a candidate is worth reading while its vector's bits do not exceed bound / lambda (rounded up: safe)
         const int dq = bits_reach(kq - bx_min);                // ... a row, while |vy - py| <= dq
         const int lo2 = dq < 0 ? i_hi + 1 : max(i_lo, Rs + ((t_y - dq + 3) >> 2)), hi2 = dq < 0 ? i_lo - 1 : min(i_hi, Rs + ((t_y + dq) >> 2));
+        // The usual case of the small blocks: no row beyond the ones just read is worth reading, and the 65th column's cheapest candidate costs more than the bound too -- the
+        // search is over, its smallest cost IS the bound: steps 1 and 2, the 65th column and the first of the two reductions at the end are skipped (round 6)
+        if (lo2 >= a_lo && hi2 <= a_hi) {
+          bool c64_out = !(col64 && ncol > 64);
+          if (!c64_out) {
+            const int dyc = clampi3(-Rs, Rs, (t_y + 2) >> 2);
+            c64_out = (u32)c.lambda * (u32)(mvbits(c.cqx + 4 * (64 - Rs) - c.pqx) + mvbits(t_y - 4 * dyc)) > bound;
+          }
+          if (c64_out) { fast = true; break; }
+        }
         // h = 2 (no step 1) when step 2 then fits one pass -- the usual case, decided with a few scalar instructions
         int byo2 = 1 << 20;
         if (a_lo - 1 >= lo2) byo2 = min(byo2, mvbits(4 * (a_lo - 1 - Rs) - t_y));
@@ -684,7 +748,7 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
     }
   }
   if (pf && lane == 0) pf[7] = wall_clock64();
-  for (int col = 64; col < (col64 ? ncol : 64); col++) {                      // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
+  for (int col = 64; col < ((col64 && !fast) ? ncol : 64); col++) {           // the columns beyond the wave (SearchRange 32: one): lane = row, plain SADs
     const int dx = col - Rs, xl = X0 + col, sh = xl & 3;
     const int bits_x = mvbits(c.cqx + 4 * dx - c.pqx);
     {                                                          // the same bound: the column's bits + the cheapest row's against the best cost so far
@@ -695,18 +759,11 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       const int i = i0 + lane;
       const bool live = i <= ev_hi;
       const u8 *p = win + (xl & ~3) + (Y0 + (live ? i : ev_hi)) * WP;
-      u32 v = 0;
-#pragma unroll
-      for (int r = 0; r < BH; r++) {
-        u32 b[BW / 4];
-        load_row<BW>(p + r * WP, sh, b);
-#pragma unroll
-        for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
-      }
+      u32 v = sad_block<BW, BH>(p, WP, sh, cb);
       if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, bits_x); best = key < best ? key : best; }
     }
   }
-  if (prune) {                                                 // step 2: the rows beyond the hull, one lane per candidate
+  if (prune && !fast) {                                        // step 2: the rows beyond the hull, one lane per candidate
     int r_lo = d_lo2, r_hi = d_hi2, dqx = d_dqx2;
     if (step1) {                                               // a tighter bound since: once more
       const int kq = (int)((float)bound * rcp_lambda) + 1;
@@ -730,21 +787,14 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
       const int i = ri < n_up ? r_lo + ri : ev_hi + 1 + (ri - n_up);
       const int col = cl + ci, dx = col - Rs, xl = X0 + col, sh = xl & 3;
       const u8 *p = win + (xl & ~3) + (Y0 + i) * WP;
-      u32 v = 0;
-#pragma unroll
-      for (int r = 0; r < BH; r++) {
-        u32 b[BW / 4];
-        load_row<BW>(p + r * WP, sh, b);
-#pragma unroll
-        for (int q = 0; q < BW / 4; q++) v = __builtin_amdgcn_sad_u8(b[q], cb[r][q], v);
-      }
+      u32 v = sad_block<BW, BH>(p, WP, sh, cb);
       if (live) { const u64 key = fs_key(c, (int)v, dx, i - Rs, mvbits(c.cqx + 4 * dx - c.pqx)); best = key < best ? key : best; }
     }
   }
   if (c.count && lane == 0) { ytab_own[70] += (u32)dbg_steps; ytab_own[71] += (u32)dbg_items; }     // JMHIP_MB_PROF=11: per-wave totals (spare entries of the wave's row table)
   if (c.count && lane == 0) ytab_own[68] += (u32)(dbg_steps * 64 + dbg_items) * (u32)(BW * BH / 16);            // ... and the absolute differences issued, in units of 16 (a window row read by the 64 sliding lanes is BH rows of BW samples each)
   if (pf && lane == 0) { pf[23] = wall_clock64(); pf[26] = (unsigned long long)dbg_steps | ((unsigned long long)dbg_items << 16) | ((unsigned long long)(hi1 - lo1 + 1 > 0 ? hi1 - lo1 + 1 : 0) << 32); }
-  const u32 hi = wave_min_u32((u32)(best >> 32));              // the smallest cost, then the earliest spiral index among the candidates that have it
+  const u32 hi = fast ? bound : wave_min_u32((u32)(best >> 32));              // the smallest cost, then the earliest spiral index among the candidates that have it
   const u32 lo = wave_min_u32((u32)(best >> 32) == hi ? (u32)best : 0xffffffffu);
   return ((u64)hi << 32) | lo;
 }
@@ -850,9 +900,9 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
   const int BH = bt == 1 || bt == 3 ? 16 : (bt == 2 || bt == 4 || bt == 6 ? 8 : 4);
   const int addr_ = mby * A.wmb + mbx, px = mbx * 16 + mb_x, py = mby * 16 + mb_y;     // (the macroblock's position comes from the caller: a division per search otherwise)
   const int R = P.search_range;
-  const bool prof_ = A.prof && (((A.prof_mode == 1 || A.prof_mode == 10) && mb_x == 0 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
+  const bool prof_ = APROF && (((A.prof_mode == 1 || A.prof_mode == 10) && mb_x == 0 && bt == 7) || (A.prof_mode >= 5 && A.prof_mode <= 9 && mb_x == 0 && bt == (A.prof_mode == 5 ? 2 : (A.prof_mode == 6 ? 1 : A.prof_mode - 3)))) &&
                      mb_y == 0 && ref == 0 && lane == 0;       // modes 5 .. 9: the first 16x8 / 16x16 / 8x8 / 8x4 / 4x8 search
-#define BS_STAMP(k) do { if (prof_) A.prof[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
+#define BS_STAMP(k) do { if (prof_) APROF[(long)addr_ * 32 + (k)] = wall_clock64(); } while (0)
   BS_STAMP(18);
   const int pred = rfl(mv_predictor(S, view, avm, ref, mb_x, mb_y, BW, BH, lane, list));
   if (pred_out) *pred_out = pred;
@@ -891,7 +941,7 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     cx = clampi3(P.mv_limit[0] + (R << 2), P.mv_limit[1] - (R << 2), cx); cy = clampi3(P.mv_limit[2] + (R << 2), P.mv_limit[3] - (R << 2), cy);
     c.cqx = cx; c.cqy = cy; c.Rs = min(max(max(max_x, max_y) >> 2, 0), R); c.check00 = 0;
   }
-  c.count = A.prof != nullptr && A.prof_mode == 11;
+  c.count = APROF != nullptr && A.prof_mode == 11;
   const u8 *win = wins + (size_t)widx * A.win_h * A.win_p;
   const int X0 = mb_x + (cx >> 2) - c.Rs + A.win_ox, Y0 = mb_y + (cy >> 2) - c.Rs + 2 * R;
   const u32 *cur = S.cur_y + mb_y * 4 + (mb_x >> 2);
@@ -909,13 +959,13 @@ __device__ __forceinline__ int block_search(Shared &S, const PipeArgs &A, const 
     __builtin_amdgcn_sched_barrier(0);
   };
   switch (bt) {
-  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
-  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
-  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
-  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
-  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
-  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
-  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? A.prof + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, spec4); break;
+  case 1: key = fs_wave<16, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 2: key = fs_wave<16, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 3: key = fs_wave<8, 16>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 4: key = fs_wave<8, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 5: key = fs_wave<8, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  case 6: key = fs_wave<4, 8>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, nospec); break;
+  default: key = fs_wave<4, 4>(win, A.win_p, cur, X0, Y0, c, lane, S.ytab[wave], S.ytab4[0], prof_ ? APROF + (long)addr_ * 32 : nullptr, i_lo, i_hi, true, spec4); break;
   }
   const int klo = rfl((int)(u32)key), khi = rfl((int)(u32)(key >> 32));
   BS_STAMP(20);
