@@ -210,6 +210,7 @@ struct Shared {
   int ref_ok[3][JMHIP_SEQ_MAX_FLIGHT];       // EPZS in flight, per search chain and reference: the macroblock (column | row << 16) whose post flag the chain has seen (-1: none) --
                                              // everything left of and above it is filtered and interpolated (mbpipe_post.inc)
   int nbflag;                                // the neighbours' samples are in nb (running count over the launch)
+  int stagecnt;                              // waves that have staged their share of the current macroblock (running count over the launch: mbpipe_kernel.inc)
   int pflag[4];                              // waves 0-3: how many 8x8 blocks of the P8x8 chain each has finished (running count over the launch)
   // Several references, full searches: the passes of a sub-mode over the references are independent of each other until the costs are compared, so a wave that has finished its
   // own role (4-7) takes references of sub-mode wave (role - 4)'s current 8x8 block (search_phase)
@@ -544,7 +545,9 @@ __device__ __forceinline__ u64 fs_wave(const u8 *win, int WP, const u32 *cur, in
   // h is the one of 2, 3, 7, 15, 31, all that makes steps 1 + 2 cheapest (vector bits double their reach every two bits, hence the values).
   const int t_y = c.pqy - c.cqy, t_x = c.pqx - c.cqx;           // the predictor relative to the search centre, quarter-pel
   const int ip = clampi3(i_lo, i_hi, Rs + ((t_y + 2) >> 2));   // the row nearest the predictor
-  const bool prune = BW * BH <= 64 && !c.check00 && c.lambda > 0;
+  // (an 8x8 block's SAD << 5 dwarfs its vectors' cost unless lambda is large: below 400 -- QP 34 or so -- the bound leaves every row, and the rows of step 0 with their
+  // lead-in are read twice: one pass over everything is cheaper)
+  const bool prune = (BW * BH < 64 || (BW * BH == 64 && c.lambda >= 400)) && !c.check00 && c.lambda > 0;
   constexpr int NBH = BH == 4 ? 3 : 2;                          // step 0: rows within NBH of the predictor's (a block four rows high pays little for two more, and is then mostly done)
   const int a_lo = prune ? max(i_lo, ip - NBH) : i_lo, a_hi = prune ? min(i_hi, ip + NBH) : i_hi;
   const int bx_min = mvbits(t_x - 4 * clampi3(-Rs, Rs, (t_x + 2) >> 2));       // the cheapest column's bits
