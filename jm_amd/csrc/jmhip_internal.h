@@ -28,6 +28,7 @@ struct jmhip_seq_entry {
   int out_slot, num_ref, refs[JMHIP_MB_MAX_REF];
   int in_flight;         // launched and not yet waited for (jmhip_seq_wait)
   int streaming;
+  volatile int made;     // the entry exists (entries beyond the first are made by jmhip_seq_open's thread, one after the other: whoever names entry k waits for THAT one)
 };
 
 struct jmhip_ctx {
@@ -102,7 +103,7 @@ struct jmhip_ctx {
   hipEvent_t *slot_rev; int *slot_nrev;                         // [num_ref_slots][JMHIP_SEQ_SLOT_READERS] launches reading the slot's picture since; their number (-1: more than fit -- wait for everything)
   hipEvent_t seq_ev;     // orders the context's own stream before an entry's
   int seq_b_grid;        // workgroups of a B picture in flight (0: seq_grid)
-  void *seq_maker; int seq_maker_rc; volatile int seq_maker_go;      // jmhip_seq_open: the std::thread that makes entries 1 .. depth - 1 while the first picture is coded (joined by whoever names such an entry), its result
+  void *seq_maker; int seq_maker_rc; volatile int seq_maker_go, seq_maker_done;      // jmhip_seq_open: the std::thread that makes entries 1 .. depth - 1 while the first picture is coded (joined by whoever names such an entry), its result
   hipStream_t bdb_stream; hipEvent_t bdb_ev; int bdb_used;     // B pictures in flight: the stream their loop filters run on one after the other, and the last one's event
   // several pictures in ONE launch (jmhip_seq_batch): per picture a source picture, edge records, flags and loop-filter side information at a fixed stride; the
   // pictures' descriptors and the ticket order of the last batch

@@ -42,6 +42,8 @@ CASES = {
     "g6r": (dict(RDO_OFF, **dict(SYN1080, FramesToBeEncoded="6")), (1920, 1080), 6, True),
     # six pictures of configs[2]'s search (EPZS, five references configured, CABAC): the temporal predictors and spatial memory over a longer chain (a million searches a picture)
     "g6e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="6", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 6, True),
+    # eight pictures of the same search with ONE reference: every P picture alike, so that the P pictures go through ONE launch (jmhip_seq_batch) at configs[2]'s size (round 6)
+    "g8e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="1", FramesToBeEncoded="8", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 8, True),
     # EPZS (SearchMode = 3) with the shipped EPZS switches (pattern 2, dual 3, fixed 2, temporal, spatial memory, block type, sub-pel grid, EPZS sub-pel search)
     # BASELINE configs[2] without its 8x8 transform and B pictures: 1080p, Main profile, CABAC, EPZS, five references configured (two exist by the third picture)
     "g3e": (dict(RDO_OFF, **dict(SYN1080, SearchMode="3", NumberReferenceFrames="5", FramesToBeEncoded="3", SymbolMode="1", ProfileIDC="77")), (1920, 1080), 3, True),

@@ -118,11 +118,16 @@ def run_case_b(tag, check_oracle_post=True, flight=None):
         if check_oracle_post:
             for a, b_ in zip(post, opost):
                 assert np.array_equal(a, np.asarray(b_, np.uint8)), (tag, n, st, "the filtered picture differs from the oracle's")
-        classic.append((recs, post))
+        classic.append((recs, post, want, [np.asarray(x, np.uint8) for x in opost], st))
     dev.J.close()
     if flight:
         got = replay_in_flight(dev, *flight)
-        for n, ((r0, p0), (r1, p1)) in enumerate(zip(classic, got)):
+        for n, ((r0, p0, want, opost, st), (r1, p1)) in enumerate(zip(classic, got)):
+            # the pictures in flight DIRECTLY against the real encoder's records and the oracle's filtered pictures (round 6) ...
+            d = TG.first_difference(want, mb_tap.canonical(TG.as_oracle_records(r1), bslice=st == 1))
+            assert d is None, (tag, n, "records of the picture in flight against the reference encoder", d[:3])
+            assert all(np.array_equal(a, b_) for a, b_ in zip(opost, p1)), (tag, n, "filtered picture of the picture in flight against the oracle")
+            # ... and byte for byte against the picture-after-picture path (the fields a canonical record drops too)
             assert r0.tobytes() == r1.tobytes(), (tag, n, "records of the picture in flight", TG.first_difference(TG.as_oracle_records(r0), TG.as_oracle_records(r1)))
             assert all(np.array_equal(a, b_) for a, b_ in zip(p0, p1)), (tag, n, "filtered picture of the picture in flight")
 
@@ -224,3 +229,48 @@ def test_b_picture_1080p_equals_the_reference_encoder():
 @pytest.mark.parametrize("tag,flight", [("m3b", (3, 0, False)), ("m3b0", (6, 20, True, 48)), ("m2b4", (4, 0, True, 7)), ("q5yb", (3, 0, False)), ("q1b", (2, 0, False)), ("m3bt", (4, 0, False))])
 def test_b_pictures_in_flight_equal_picture_after_picture(tag, flight):
     run_case_b(tag, check_oracle_post=False, flight=flight)
+
+
+def test_many_b_pictures_in_flight_with_few_slots_and_a_starved_b_share():
+    """The slots' readers and writers under stress (round 5's bug class: a P picture overwrote a slot a B picture still read -- found by bench.py, not by a test): 41 pictures
+    I P B P B ... of a clip with motion, two references, every B picture given ONE workgroup (jmhip_seq_b_workgroups(1): a B launch then takes many P launches' time, the host runs
+    entries ahead of the device and every slot is written again while launches queued long ago still read it), as few slots as the sequence needs.  Picture after picture the
+    device equals the ORACLE (records, filtered pictures); in flight every picture must equal those again -- twice, with 3 and with 6 pictures in flight."""
+    import synth_motion
+    W, H, R, keep, nfr = 176, 144, 8, 2, 41
+    qp, qp_b = 27, 29
+    lam_of = lambda q: int(192 * 2 ** ((q - 28) / 6))
+    f, fb = lam_of(qp), lam_of(qp_b)
+    lam = {2: ([f] * 3, f), 0: ([f, f + 3, f + 5], f + 1)}
+    lam_b = ([fb + 1, fb + 2, fb + 6], fb + 2)
+    b = dict(direct_8x8_inference=1, direct_temporal=0, bipred_me=1, bipred_search=[1, 1, 1, 0], bipred_refinements=1, bipred_range=8, bipred_subpel=1)
+    args = (W, H, qp, R, keep, lam, 0)
+    kw = dict(cabac=1, search_mode=-1, transform8x8=0, yuv_format=1)
+    dev = DevSeqEncoderB(*args, **kw)
+    ora = mbenc_util.SeqEncoder(*args, **kw)
+    frames = synth_motion.motion_clip(W, H, nfr, 606)
+    order = [(0, 2)]
+    for g in range((nfr - 1) // 2):
+        order += [(2 * g + 2, 0), (2 * g + 1, 1)]
+    stored, classic = [], []
+    for disp, st in order:
+        raw, poc = frames[disp], 2 * disp
+        src = pyjmo.load_frame(raw, W, H, W, H, 1)
+        if st == 1:
+            l0, l1 = sorted([p for p in stored if p < poc], reverse=True)[:1], sorted(p for p in stored if p > poc)[:1]
+            recs, pre, post = dev.encode_b(raw, W, H, l0, l1, lam_b, qp_b, b, poc=poc)
+            orecs, _, opre, opost = ora.encode_b(src, poc, l0, l1, lam_b, qp_b, b)
+        else:
+            recs, pre, post = dev.encode_ref(raw, W, H, poc)
+            orecs, _, opre, opost = ora.encode(src, poc=poc)
+            stored = ([poc] + stored)[:keep]
+        d = TG.first_difference(mb_tap.canonical(orecs, bslice=st == 1), mb_tap.canonical(TG.as_oracle_records(recs), bslice=st == 1))
+        assert d is None, ("picture after picture against the oracle", disp, st, d[:3])
+        assert all(np.array_equal(a, np.asarray(x, np.uint8)) for a, x in zip(post, opost)), ("filtered picture against the oracle", disp, st)
+        classic.append((recs, post))
+    dev.J.close()
+    for depth, wg in ((3, 0), (6, 12)):
+        got = replay_in_flight(dev, depth, wg, False, 1)
+        for n, ((r0, p0), (r1, p1)) in enumerate(zip(classic, got)):
+            assert r0.tobytes() == r1.tobytes(), (depth, n, "records of the picture in flight", TG.first_difference(TG.as_oracle_records(r0), TG.as_oracle_records(r1)))
+            assert all(np.array_equal(a, b_) for a, b_ in zip(p0, p1)), (depth, n, "filtered picture of the picture in flight")

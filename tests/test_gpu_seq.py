@@ -466,6 +466,31 @@ def test_1080p_epzs_sequence_in_flight_equals_the_reference_encoder():
         assert d is None, ("against the reference encoder, picture", n, d)
 
 
+def test_1080p_epzs_pictures_in_one_launch_equal_the_reference_encoder():
+    """configs[2]'s search at its own size with the P pictures in ONE launch (jmhip_seq_batch, search_mode 3: every search checked against the queue's order): eight pictures of
+    the 1080p clip, EPZS with the shipped switches, CABAC, one reference -- so that all seven P pictures are one launch -- every record against the REAL encoder's
+    (tests/golden/mb_low_g8e.npz), and the same pictures in flight (sixteen entries: all eight at once) against the same records"""
+    import bench
+    from test_gpu_mbenc import load_case
+    c = load_case("g8e")
+    W, H = c["W"], c["H"]
+    nmb = (W // 16) * (H // 16)
+    assert c["num_ref"] == 1 and c["nfr"] == 8
+    frames = bench.yuv_frames(c["nfr"])
+    be = BatchEncoder(W, H, c["qp"], c["R"], 1, c["lam"], [7], 10, cabac=c["cabac"], search_mode=3, epzs=c["epzs"])
+    got = be.run(frames, c["sw"], c["sh"])
+    be.J.close()
+    fl = FlightEncoder(W, H, c["qp"], c["R"], 1, c["lam"], 8, cabac=c["cabac"], search_mode=3, epzs=c["epzs"])
+    for raw in frames:
+        fl.submit(raw, c["sw"], c["sh"])
+    got_f = fl.finish()
+    fl.J.close()
+    for what, g in (("in one launch", got), ("in flight", got_f)):
+        for n in range(c["nfr"]):
+            d = first_difference(c["records"][n * nmb:(n + 1) * nmb], mb_tap.canonical(as_oracle_records(g[n][0])))
+            assert d is None, (what, "against the reference encoder, picture", n, d)
+
+
 def test_forty_epzs_pictures_in_flight_and_in_one_launch_equal_the_reference_encoder():
     """A long EPZS sequence (tests/golden/mb_low_m2e40.npz: forty pictures, two references, the shipped switches -- JM's 16-bit visited-map stamp wraps round several times; the
     oracle counts no aliased candidate on it, tests/test_oracle_mbenc.py): sixteen pictures in flight, and the P pictures in launches of 17 / 9 / the rest, every record

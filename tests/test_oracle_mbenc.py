@@ -204,6 +204,12 @@ def test_oracle_epzs_six_pictures_full_size():
     assert len(enc.epzs_stats) == 5 and sum(s for s, _ in enc.epzs_stats) > 4000000 and all(s > 65535 for s, _ in enc.epzs_stats) and all(a == 0 for _, a in enc.epzs_stats)
 
 
+def test_oracle_epzs_eight_pictures_one_reference_full_size():
+    """Eight 1080p pictures of the same search with ONE reference (g8e): the sequence whose seven P pictures the device codes in one launch (tests/test_gpu_seq.py)."""
+    enc = run_case("g8e")
+    assert len(enc.epzs_stats) == 7 and all(a == 0 for _, a in enc.epzs_stats)
+
+
 def test_oracle_epzs_forty_pictures():
     """Forty pictures of EPZS with two references (m2e40): JM's 16-bit visited-map stamp wraps round several times over the sequence; every picture's records equal the real
     encoder's and the oracle meets no aliased candidate -- the sequence the device's long EPZS runs (in flight, in one launch) are pinned to."""
