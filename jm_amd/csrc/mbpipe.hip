@@ -241,6 +241,9 @@ struct Shared {
   PostShared post;
   PicView V;                                 // the picture the workgroup's current macroblock belongs to
   PicView Vp;                                // ... and the one its PREVIOUS macroblock belonged to: that macroblock's post stage runs beside this one's staging (mbpipe_kernel.inc)
+  PicView Vn;                                // ... and the one its NEXT macroblock belongs to, when that ticket was drawn ahead (mbpipe_kernel.inc: draw_ahead)
+  int nticket, npacked;                      // the ticket drawn ahead and its entry of the order table
+  int pad_n_[2];
   // ---- from here on: B slices only.  The other kernels' dynamic region (the references' windows / the EPZS tables) starts HERE (SHARED_COMMON): with two four-wave EPZS
   // workgroups per compute unit every KB counts twice
   // B slices (mbpipe_b.inc).  References are numbered through both lists: list 0's first, then list 1's (S.allmv, the windows, PicView::ref_y).
@@ -1271,6 +1274,43 @@ __device__ __forceinline__ void ihadamard4x4_jm(int (&m)[16])
   for (int i = 0; i < 4; i++) {
     const int e0 = u[i] + u[8 + i], e1 = u[i] - u[8 + i], o0 = u[4 + i] - u[12 + i], o1 = u[4 + i] + u[12 + i];
     m[i] = e0 + o1; m[4 + i] = e1 + o0; m[8 + i] = e1 - o0; m[12 + i] = e0 - o1;
+  }
+}
+
+// ------------------------------------------------------------------ staging a reference's integer window in LDS
+// Thread t of NT copies dwords t, t + NT, ... of the window (win_h rows of win_p bytes: picture rows wy0 .., columns wx0 ..; beyond the picture the edge samples).  (round 6)
+// Sixteen loads in flight per thread: the loop used to wait for every dword before it stored it -- fourteen trips to the L2 one after the other, 6 of the staging's 7 us.  A step
+// of NT dwords through the window is qn rows and rn dwords (no division per dword); a dword that crosses the picture's left or right edge (rare: the clamped load is issued
+// with the others, the edge bytes are fetched afterwards) goes the old way.
+__device__ __forceinline__ void stage_window(const PipeArgs &A, const u8 *pl, u32 *w, int wx0, int wy0, int t, int NT)
+{
+  const int dpr = A.win_p >> 2, nd = A.win_h * dpr;
+  const int qn = NT / dpr, rn = NT - qn * dpr;
+  constexpr int CH = 16;
+  int y = t / dpr, xq = t - y * dpr;
+  for (int d0 = t; d0 < nd; d0 += CH * NT) {
+    u32 v[CH], edge = 0;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      const int py = clampi3(0, A.H - 1, wy0 + y), px = wx0 + 4 * xq;
+      edge |= (px >= 0 && px + 3 < A.W) ? 0u : 1u << k;
+      v[k] = ldref32(pl + (long)py * A.ref_pitch + clampi3(0, A.W - 4, px));
+      xq += rn; y += qn;
+      if (xq >= dpr) { xq -= dpr; y++; }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      const int d = d0 + k * NT;
+      if (d < nd) {
+        u32 vv = v[k];
+        if ((edge >> k) & 1u) {
+          const int yy = d / dpr, px = wx0 + (d - yy * dpr) * 4;
+          const u8 *row = pl + (long)clampi3(0, A.H - 1, wy0 + yy) * A.ref_pitch;
+          vv = ldref8(row + clampi3(0, A.W - 1, px)) | (ldref8(row + clampi3(0, A.W - 1, px + 1)) << 8) | (ldref8(row + clampi3(0, A.W - 1, px + 2)) << 16) | (ldref8(row + clampi3(0, A.W - 1, px + 3)) << 24);
+        }
+        w[d] = vv;
+      }
+    }
   }
 }
 
