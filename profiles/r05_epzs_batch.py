@@ -13,7 +13,7 @@ from jm_amd.lib import SLICE_PARAMS, MB_RECORD
 npic = int(sys.argv[1]) if len(sys.argv) > 1 else 49
 W, H = 1920, 1088
 nmb = (W // 16) * (H // 16)
-frames = bench.yuv_frames(min(npic, 44))
+frames = bench.yuv_frames(int(os.environ.get("FRAMES", min(npic, 44))))            # FRAMES=24: the clip of bench.py --steps 20 (its 64 P pictures turn round more often)
 d_raw = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames]
 d_rec = torch.zeros((npic, nmb * MB_RECORD.itemsize), dtype=torch.uint8, device="cuda")
 nslots = 24
