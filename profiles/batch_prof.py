@@ -64,4 +64,9 @@ print(f"{mode}, {npic - 1} P pictures in one launch: macroblocks with stamps {ok
       f"DeblockMb {d(28, 29):.1f}, planes {d(29, 30):.1f}; ticket->post done {d(0, 30):.1f}")
 for a, b in ((2, 3), (3, 4), (4, 5), (5, 6), (6, 8), (8, 9), (8, 10), (8, 11), (8, 12), (8, 13), (8, 14), (8, 15), (8, 31), (31, 16)):
     print(f"   stamps {a}->{b}: median {d(a, b):.1f} us")
+q = lambda a, b: (st[ok, b] - st[ok, a]) / 100.0
+print(f"   the launch: {dt / (npic - 1) * 1e3:.3f} ms per picture with the stamps on ({nmb * (npic - 1) / dt / 1e6:.3f} M macroblocks/s)")
+for name, a, b in (("ticket->staged (incl. the wait for the neighbours' vectors)", 0, 1), ("chain (2->6)", 2, 6), ("ticket->published", 0, 17), ("vectors out after the ticket (0->31)", 0, 31), ("vectors out after the chain's start (2->31)", 2, 31)):
+    v = q(a, b)
+    print(f"   {name}: mean {v.mean():.1f}, median {np.median(v):.1f}, p90 {np.percentile(v, 90):.1f}, p99 {np.percentile(v, 99):.1f} us")
 ctx.close()
