@@ -120,7 +120,8 @@ def run_lencod(exe, frames, timeout, flags=None, clip=None, cfg_name="jm_baselin
         for kv in (flags or G2R_FLAGS) + (f"FramesToBeEncoded={frames}",):
             args += ["-p", kv]
         t0 = time.time()
-        r = subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        # (lencod_hip.exe: leave without the teardown once the files are closed -- a quarter of a two-picture run, profiles/r05_init_prof.txt; opt-in since round 6)
+        r = subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=dict(os.environ, JMHIP_ADAPTER_FAST_EXIT="1"))
         wall = time.time() - t0
         if r.returncode != 0:
             return None
@@ -140,6 +141,9 @@ def cpu_baseline(max_seconds=120):
     if os.path.exists(exe) and os.access(exe, os.X_OK):
         try:
             r = run_lencod(exe, 2, max_seconds)
+            r2 = run_lencod(exe, 2, max_seconds)          # the wall time as end_to_end takes lencod_hip.exe's: the shorter of two runs
+            if r and r2 and r2[3] < r[3]:
+                r = r2
         except subprocess.TimeoutExpired:
             r = None
         if r and r[0].get("P"):
@@ -184,7 +188,7 @@ def end_to_end(cpu, max_seconds=300):
     out = {"available": True, "p_frame_ms": p_ms, "p_frame_ms_all": p, "i_frame_ms": more[0].get("I", [None])[0], "macroblocks_per_s": round(8160 / (p_ms / 1000.0), 1),
            "md5_264_two_frames": two[1], "md5_ok": two[1] == G2R_MD5, "adapter": more[2],
            # whole runs, process start to exit (context creation, first launches, the I picture, file I/O): what a two-picture job really gains
-           "sequence_wall_s": {"pictures_2_hip": round(two[3], 2), "pictures_2_hip_is": "the shorter of two runs", "pictures_2_cpu_jm": cpu.get("wall_s_two_pictures") if cpu else None, "pictures_6_hip": round(more[3], 2),
+           "sequence_wall_s": {"pictures_2_hip": round(two[3], 2), "pictures_2_hip_is": "the shorter of two runs (CPU JM's too)", "pictures_2_cpu_jm": cpu.get("wall_s_two_pictures") if cpu else None, "pictures_6_hip": round(more[3], 2),
                                "speedup_2_pictures": round(cpu["wall_s_two_pictures"] / two[3], 1) if cpu and cpu.get("wall_s_two_pictures") else None,
                                "note": "p_frame_ms is the median of the later P pictures of the six-picture run; the first P picture and the I picture also pay first-launch costs (p_frame_ms_all, i_frame_ms)"},
            "config": "lencod_hip.exe -d jm_baseline.cfg " + " ".join("-p " + f for f in G2R_FLAGS[:11]) + ": unmodified JM 19.0 host code, entropy coding on the host, one thread"}

@@ -142,9 +142,10 @@ static void adapter_report(void)
 
 /* The process is over: JM has closed its files, the report above is written.  What would follow -- jmhip_destroy (33 ms at 1080p: pinned buffers, streams) and then the HIP
  * runtime's own exit handlers (139 ms) -- frees what the kernel driver reclaims from a dead process anyway, and is more than a quarter of a two-picture run's wall time
- * (profiles/r05_init_prof.txt).  So after a NORMAL end (status 0) with nothing in flight: flush every stdio stream and leave with _exit.  The full teardown stays for
- * JMHIP_ADAPTER_FULL_EXIT=1, under a profiler that collects at exit (rocprofv3: ROCP_TOOL_LIBRARIES / LD_PRELOAD), in the -pg build (gmon.out is written by an exit
- * handler) and after any failure. */
+ * (profiles/r05_init_prof.txt).  A caller that wants that time back asks for it: with JMHIP_ADAPTER_FAST_EXIT=1, after a NORMAL end (status 0) with nothing in flight, every
+ * stdio stream is flushed and the process leaves with _exit -- exit handlers registered before the adapter's (other libraries', coverage or sanitizer reports, the HIP runtime's
+ * own shutdown) then never run, which is why it is not the default.  The full teardown is what happens otherwise, and always under a profiler that collects
+ * at exit (rocprofv3: ROCP_TOOL_LIBRARIES / LD_PRELOAD), in the -pg build (gmon.out is written by an exit handler) and after any failure. */
 static void adapter_exit(int status, void *unused)
 {
   int k_, fast;
@@ -154,7 +155,7 @@ static void adapter_exit(int status, void *unused)
 #ifdef JMHIP_ADAPTER_KEEP_EXIT_HANDLERS
   fast = 0;
 #else
-  fast = status == 0 && !G.off && !getenv("JMHIP_ADAPTER_FULL_EXIT") && !getenv("ROCP_TOOL_LIBRARIES") && !getenv("LD_PRELOAD");
+  { const char *fe = getenv("JMHIP_ADAPTER_FAST_EXIT"); fast = status == 0 && !G.off && fe && fe[0] == '1' && !getenv("JMHIP_ADAPTER_FULL_EXIT") && !getenv("ROCP_TOOL_LIBRARIES") && !getenv("LD_PRELOAD"); }
 #endif
   if (fast) {
     for (k_ = 0; k_ < G.nctx; k_++) if (G.ctxs[k_] && jmhip_synchronize(G.ctxs[k_]) != JMHIP_OK) fast = 0;      /* nothing may be left running on the device */
@@ -359,6 +360,10 @@ static int adapter_on(VideoParameters *p_Vid)
           (p_Inp->NumberBFrames != 0 && (p_Inp->intra_period != 0 || p_Inp->idr_period != 0 || p_Inp->SearchMode[0] == EPZS)) ||
           (p_Inp->SearchMode[0] != FULL_SEARCH && p_Inp->SearchMode[0] != FAST_FULL_SEARCH && p_Inp->SearchMode[0] != EPZS)) F.depth = 0;
       if (F.depth > FL_MAX) F.depth = FL_MAX;
+      /* a run of n pictures never has more than n - 1 of them in flight behind its first: entries beyond that only cut every picture's share of the workgroups (jmhip_seq_open
+         deals 248 / (depth - 1) at most) -- configs[2]'s three-picture run: its first P picture alone on 2 x 16 four-wave workgroups 93 ms, 75 with the chip to itself
+         (profiles/r06_first_pictures.txt) */
+      if (!fl && F.depth > 2 && p_Inp->no_frames > 0 && F.depth > imax(2, p_Inp->no_frames - 1)) F.depth = imax(2, p_Inp->no_frames - 1);
       if (F.depth) {
         F.nb = p_Inp->NumberBFrames;
         if (F.nb && F.depth > 10) F.depth = 10;

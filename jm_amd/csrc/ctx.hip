@@ -213,8 +213,9 @@ extern "C" int jmhip_synchronize(jmhip_ctx *ctx)
   if (r) return r;
   // pictures in flight: what jmhip_seq_wait would have told about each of them (the first error is reported, every entry is taken out of flight: a sticky error word
   // would otherwise make the entry's next launch a silent no-op)
+  // (an entry that streams its records to the host keeps doing so: jmhip_seq_record still answers for its picture afterwards -- every flag is set by then)
   for (int k = 0; k < ctx->seq_depth; k++)
-    if (ctx->seq[k].in_flight) { const int q = jmhip_seq_wait(ctx, k); if (q && !r) r = q; }
+    if (ctx->seq[k].in_flight) { const int was = ctx->seq[k].streaming; const int q = jmhip_seq_wait(ctx, k); ctx->seq[k].streaming = was; if (q && !r) r = q; }
   if (r) return r;
   r = jmhip_check_job_error(ctx);
   if (r) return r;

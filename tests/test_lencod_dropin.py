@@ -533,12 +533,12 @@ def test_lencod_b_pictures_with_any_number_of_pictures_in_flight(tmp_path, depth
 @pytest.mark.gpu
 @pytest.mark.parametrize("full", [False, True])
 def test_lencod_leaves_with_and_without_the_teardown(tmp_path, full):
-    """After a normal end the adapter writes its report, flushes every stream and leaves with _exit (jmhip_destroy and the runtime's exit handlers free what the driver reclaims
-    anyway: INTEGRATION.md section 10); JMHIP_ADAPTER_FULL_EXIT=1 keeps the teardown.  Either way: exit status 0, the whole of stdout (JM's summary is its last output), the same
-    bytes as CPU JM."""
+    """After a normal end the adapter writes its report and tears its contexts down; with JMHIP_ADAPTER_FAST_EXIT=1 it flushes every stream and leaves with _exit instead
+    (jmhip_destroy and the runtime's exit handlers free what the driver reclaims anyway: INTEGRATION.md section 10).  Either way: exit status 0, the whole of stdout (JM's summary
+    is its last output), the same bytes as CPU JM."""
     if not os.path.exists(EXE):
         pytest.fail("oracle/_ref/lencod_hip.exe missing")
-    r, z = run_rdo_off_case("q1r", str(tmp_path), env_extra=dict({"JMHIP_INIT_PROF": "1"}, **({"JMHIP_ADAPTER_FULL_EXIT": "1"} if full else {})))
+    r, z = run_rdo_off_case("q1r", str(tmp_path), env_extra=dict({"JMHIP_INIT_PROF": "1"}, **({} if full else {"JMHIP_ADAPTER_FAST_EXIT": "1"})))
     out, err = r.stdout.decode(errors="replace"), r.stderr.decode(errors="replace")
     assert r.returncode == 0, err[-1500:]
     assert md5(os.path.join(str(tmp_path), "o.264")) == str(z["md5_264"]) and md5(os.path.join(str(tmp_path), "o_rec.yuv")) == str(z["md5_recon"]), ("differs from CPU JM", err[-600:])
