@@ -156,6 +156,9 @@ extern "C" void jmhip_destroy(jmhip_ctx *c)
 {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
+  // pictures in flight run on streams of their own (jmhip_seq_open) and read / write the slots freed below: nothing of theirs may still be running (the adapter's full
+  // teardown no longer has jmhip_synchronize in front of it: round 6)
+  if (c->seq) (void)jmhip_seq_sync_all(c);
   if (c->d_cur) (void)hipFree(c->d_cur);
   if (c->d_cur_c) (void)hipFree(c->d_cur_c);
   if (c->d_sub) { for (int s = 0; s < c->cfg.num_ref_slots; s++) if (c->d_sub[s]) (void)hipFree(c->d_sub[s]); free(c->d_sub); }
