@@ -497,6 +497,40 @@ def slice_params(SLICE_PARAMS, slice_type, first, num, slice_nr, num_ref, num_sl
     return p
 
 
+def traffic_live(args, max_seconds=240):
+    """HBM-side traffic of the timed launch, measured in THIS run (outside the clock): the same command once more under `rocprofv3 --pmc FETCH_SIZE` and once under
+    `--pmc WRITE_SIZE` (separate passes, kernel trace only: the MI355X guide's recipe), as child processes; the timed launch is the third k_mb_pipe dispatch (I picture, warm-up
+    launch, timed launch).  Bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KB, and FETCH_SIZE counts half of what is fetched on gfx950
+    (profiles/microbench/fetch_calib.hip, profiles/r01_v3_kernel_stats.md).  None when rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    vals = {}
+    t_end = time.time() + max_seconds
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(args.steps), "--warmup", str(args.warmup), "--launch", args.launch, "--slots", str(args.slots), "--workgroups", str(args.workgroups),
+                   "--flight", str(args.flight), "--no-cpu-baseline", "--no-end-to-end", "--streams", "0", "--no-traffic"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(30.0, t_end - time.time()))
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            if r.returncode != 0:
+                return None
+            rows = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                rows += [q for q in csv.DictReader(open(f)) if q.get("Kernel_Name", "").startswith("k_mb_pipe(") and q.get("Counter_Name", counter) == counter]
+            rows.sort(key=lambda q: int(q["Dispatch_Id"]))
+            if len(rows) < 3:
+                return None
+            vals[counter] = float(rows[2]["Counter_Value"])
+    return {"bytes_per_launch": int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"]}
+
+
 def valu_issued_live(local, d_raw, src_h, nmb, npic=7):
     """Absolute differences the integer searches of ONE P picture of the clip issue, from the kernel's own counters (JMHIP_MB_PROF=11: every wave adds up the window rows its
     sliding lanes read and the candidates of its one-lane passes, mbpipe.hip fs_wave): a second context made with the counting on codes the clip's first pictures in one launch, outside
@@ -776,6 +810,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (the committed constant is reported instead)")
     ap.add_argument("--flight", type=int, default=8, help="pictures of the sequence in flight side by side (jmhip_seq_open; 1 = one launch at a time)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per picture in flight (0: 256 / flight); with --launch batch: workgroups of the launch (0: 256)")
     ap.add_argument("--launch", choices=["batch", "pictures"], default="batch", help="batch: the timed P pictures in ONE launch, every picture's macroblocks from one queue (jmhip_seq_batch); "
@@ -1069,6 +1104,12 @@ def main():
             issued_live = valu_issued_live(local, d_raw, src_h, nmb)
         except Exception:                                             # (an extra figure must not cost the line)
             issued_live = None
+    traffic = None
+    if rank == 0 and N == 1 and world == 1 and batch and not args.no_traffic:
+        try:
+            traffic = traffic_live(args)
+        except Exception:                                             # (an extra figure must not cost the line)
+            traffic = None
     if rank == 0:
         total_mb = nmb * N * args.steps
         steps_chain = W // 16 + 2 * (H // 16 - 1)
@@ -1082,8 +1123,11 @@ def main():
         conc = pipe_ms * 1e-3 * (args.steps / per_launch) / dt           # launches in flight at a time, on average over the timed region
         solo = float(np.mean(solo_ms)) if solo_ms else None
         roof = {"kernel": "k_mb_pipe", "bound": "latency", "achieved": round(alg * args.steps / dt / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(alg * args.steps / dt / 8e12, 6), "traffic": PIPE_TRAFFIC_BYTES[args.launch] * per_launch if N == 1 else None,
-                "traffic_source": PIPE_TRAFFIC_SOURCE, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg * per_launch,
+                "frac": round(alg * args.steps / dt / 8e12, 6), "traffic": (traffic["bytes_per_launch"] if traffic else PIPE_TRAFFIC_BYTES[args.launch] * per_launch) if N == 1 else None,
+                "traffic_source": ("measured in this run, outside the clock: this command once more under rocprofv3 --pmc FETCH_SIZE and once under --pmc WRITE_SIZE (child processes, "
+                                   "kernel trace only), the timed launch's dispatch; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- KB units, FETCH_SIZE x 2 on gfx950; "
+                                   f"FETCH_SIZE {traffic['fetch_size_kb']:.0f} KB, WRITE_SIZE {traffic['write_size_kb']:.0f} KB" if traffic else PIPE_TRAFFIC_SOURCE),
+                "traffic_over_algorithmic": round((traffic["bytes_per_launch"] if traffic else PIPE_TRAFFIC_BYTES[args.launch] * per_launch) / (alg * per_launch), 2) if N == 1 else None, "avg_kernel_ms": round(pipe_ms, 3), "algorithmic_bytes_per_launch": alg * per_launch,
                 "pictures_per_launch": per_launch, "launches_in_flight": round(conc, 2),
                 "per_launch": {"achieved": round(alg * per_launch / (pipe_ms * 1e-3) / 1e9, 3), "frac": round(alg * per_launch / (pipe_ms * 1e-3) / 8e12, 6),
                                "one_picture_launch_alone_ms": round(solo, 3) if solo else None,

@@ -623,3 +623,39 @@ def test_vector_limits_below_the_search_range_go_to_jms_own_function(tmp_path):
         out[tag] = (md5(str(tmp_path / f"{tag}.264")), md5(str(tmp_path / f"{tag}.yuv")), r.stderr.decode(errors="replace"))
     assert out["c"][:2] == out["h"][:2]
     assert "macroblock pipeline not used (vector limits" in out["h"][2], out["h"][2][-1500:]
+
+
+@pytest.mark.gpu
+def test_lencod_small_picture_whose_workgroups_code_one_macroblock_each_many_times(tmp_path):
+    """fuzz_dropin's seed 700411 (round 6): 176 x 112, 4:2:2, 8x8 transform, fast full search with up to four references, IDRPeriod 3, a QP change at picture 2 -- 77 macroblocks
+    per picture against 80 workgroups per picture in flight, so every workgroup codes ONE macroblock and runs its post stage behind the loop.  One run in fifty left a macroblock's
+    chroma of picture 2 at zero: the post stage read its picture's descriptor (Shared::Vp) before the other waves' threads had copied it (profiles/r06_vp_race.txt).  Thirty runs
+    against CPU JM's bytes (the reference binary travels with the repo: oracle/_ref/lencod.exe)."""
+    import sys
+    import numpy as np
+    cpu = os.path.join(ROOT, "oracle", "_ref", "lencod.exe")
+    if not os.path.exists(EXE) or not os.path.exists(cpu):
+        pytest.fail("oracle/_ref/lencod_hip.exe / lencod.exe missing: run __graft_entry__.build() where /root/reference exists")
+    sys.path.insert(0, G)
+    import synth_motion
+    ov = dict(RDOptimization=0, AdaptiveRounding=0, InputFile="clip.yuv", SourceWidth=176, SourceHeight=112, OutputWidth=176, OutputHeight=112, FramesToBeEncoded=4, YUVFormat=2,
+              ProfileIDC=122, LevelIDC=40, SymbolMode=1, Transform8x8Mode=1, SearchMode=0, SearchRange=28, NumberReferenceFrames=4, QPISlice=50, QPPSlice=0, ChromaQPOffset=-3,
+              DisableSubpelME=0, IntraPeriod=3, NumberBFrames=0, OffsetMatrixPresentFlag=1, CbQPOffset=-4, CrQPOffset=1, ReferenceReorder=1, PocMemoryManagement=1, PicOrderCntType=2,
+              IDRPeriod=3, ChangeQPFrame=2, ChangeQPI=17, ChangeQPP=21)
+    tmp = str(tmp_path)
+    np.concatenate(synth_motion.motion_clip(176, 112, 4, 700411, yuv422=True)).tofile(os.path.join(tmp, "clip.yuv"))
+    shutil.copyfile(os.path.join(G, "q_offset.cfg"), os.path.join(tmp, "q_offset.cfg"))
+
+    def run(exe, tag):
+        args = [exe, "-d", os.path.join(G, "jm_baseline.cfg")]
+        for k, v in dict(ov, OutputFile=f"{tag}.264", ReconFile=f"{tag}.yuv", TraceFile="/dev/null").items():
+            args += ["-p", f"{k}={v}"]
+        return subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert run(cpu, "c").returncode == 0
+    want = md5(os.path.join(tmp, "c.264")), md5(os.path.join(tmp, "c.yuv"))
+    for k in range(30):
+        r = run(EXE, "h")
+        err = r.stderr.decode(errors="replace")
+        assert r.returncode == 0, (k, err[-1200:])
+        assert "macroblock pipeline:" in err and "pictures in flight:" in err, err[-800:]
+        assert (md5(os.path.join(tmp, "h.264")), md5(os.path.join(tmp, "h.yuv"))) == want, (k, "differs from CPU JM")
