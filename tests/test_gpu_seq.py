@@ -357,6 +357,24 @@ def test_pictures_in_flight_streamed_records_and_repeated_runs():
         fl.J.close()
 
 
+def test_streamed_records_are_still_there_after_synchronize():
+    """jmhip_synchronize waits for every picture in flight and takes it out of flight, but an entry that streams its records to the host keeps answering jmhip_seq_record for
+    its picture afterwards (the entry's streaming state used to be cleared, and the call then failed with JMHIP_EINVAL)."""
+    W, H, R = 208, 160, 16
+    frames = synthetic_clip(W, H, 3, 77)
+    want = classic(W, H, 28, R, 1, LAMBDAS, frames)
+    fl = FlightEncoder(W, H, 28, R, 1, LAMBDAS, 3, stream_records=True)
+    nmb = (W // 16) * (H // 16)
+    for raw in frames:
+        fl.submit(raw, W, H)                                  # three pictures, three entries: nothing collected yet
+    fl.J.synchronize()
+    for k in range(3):
+        recs = fl.J.seq_records_streamed(k, 0, nmb)
+        d = first_difference(mb_tap.canonical(as_oracle_records(want[k][0])), mb_tap.canonical(as_oracle_records(recs)))
+        assert d is None, ("picture", k, "record", d)
+    fl.J.close()
+
+
 def test_entries_made_beside_the_first_picture(monkeypatch):
     """jmhip_seq_open makes its first entry itself and the others on a thread that starts with the first launch (mbpipe_host.inc: seq_join): a context closed before any launch,
     one closed right after its first launch, a sequence whose FIRST launch names the last entry, and the same sequence with every entry made inside jmhip_seq_open all behave"""
