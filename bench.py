@@ -523,12 +523,25 @@ def traffic_live(args, max_seconds=240):
                 return None
             rows = []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-                rows += [q for q in csv.DictReader(open(f)) if q.get("Kernel_Name", "").startswith("k_mb_pipe(") and q.get("Counter_Name", counter) == counter]
-            rows.sort(key=lambda q: int(q["Dispatch_Id"]))
-            if len(rows) < 3:
+                rows += list(csv.DictReader(open(f)))
+            v = timed_launch_counter(rows, counter)
+            if v is None:
                 return None
-            vals[counter] = float(rows[2]["Counter_Value"])
-    return {"bytes_per_launch": int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"]}
+            vals[counter] = v
+    return traffic_bytes(vals["FETCH_SIZE"], vals["WRITE_SIZE"])
+
+
+def timed_launch_counter(rows, counter):
+    """rows of rocprofv3's counter_collection.csv -> the counter's value for the timed launch: the THIRD k_mb_pipe dispatch of a bench.py run (the I picture, the warm-up launch,
+    the timed launch; the instrumented twin k_mb_pipe_prof and the other instances have other names), or None"""
+    mine = [q for q in rows if q.get("Kernel_Name", "").startswith("k_mb_pipe(") and q.get("Counter_Name", counter) == counter]
+    mine.sort(key=lambda q: int(q["Dispatch_Id"]))
+    return float(mine[2]["Counter_Value"]) if len(mine) >= 3 else None
+
+
+def traffic_bytes(fetch_kb, write_kb):
+    """FETCH_SIZE / WRITE_SIZE (KB; FETCH_SIZE counts half of what is fetched on gfx950: profiles/microbench/fetch_calib.hip) -> bytes"""
+    return {"bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024)), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb}
 
 
 def valu_issued_live(local, d_raw, src_h, nmb, npic=7):

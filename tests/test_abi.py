@@ -87,3 +87,24 @@ def test_create_without_device_fails_loudly():
     with pytest.raises(JmHipError) as e:
         JmHip(176, 144)
     assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_bench_reads_the_timed_launch_from_a_counter_collection():
+    """bench.py measures roofline.traffic with two rocprofv3 --pmc passes over its own command (child processes, outside the clock): the value it takes is the THIRD k_mb_pipe
+    dispatch's (I picture, warm-up launch, timed launch) -- not the instrumented twin's, not another instance's, whatever order the rows come in; bytes = (2 x FETCH_SIZE +
+    WRITE_SIZE) x 1024."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = [{"Dispatch_Id": "9", "Kernel_Name": "k_mb_pipe(PipeArgs)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "3000.5"},       # the timed launch
+            {"Dispatch_Id": "2", "Kernel_Name": "k_mb_pipe(PipeArgs)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "100"},          # the I picture
+            {"Dispatch_Id": "5", "Kernel_Name": "k_mb_pipe(PipeArgs)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "700"},          # the warm-up launch
+            {"Dispatch_Id": "1", "Kernel_Name": "k_load_frame(unsigned char const*, int)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "1"},
+            {"Dispatch_Id": "7", "Kernel_Name": "k_mb_pipe_prof(PipeArgs)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "55555"},
+            {"Dispatch_Id": "8", "Kernel_Name": "k_mb_pipe_epzs4_t8(PipeArgs)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "44444"},
+            {"Dispatch_Id": "11", "Kernel_Name": "k_mb_pipe(PipeArgs)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "9"}]           # the check's launches behind it
+    assert bench.timed_launch_counter(rows, "FETCH_SIZE") == 3000.5
+    assert bench.timed_launch_counter(rows[:3][:2], "FETCH_SIZE") is None
+    assert bench.timed_launch_counter(rows, "WRITE_SIZE") is None
+    t = bench.traffic_bytes(3000.5, 1000.0)
+    assert t["bytes_per_launch"] == int(round((2 * 3000.5 + 1000.0) * 1024)) and t["fetch_size_kb"] == 3000.5 and t["write_size_kb"] == 1000.0
