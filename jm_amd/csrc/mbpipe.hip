@@ -236,6 +236,9 @@ struct Shared {
   int fin_t8;                                // the macroblock's final luma_transform_size_8x8_flag (loop-filter side information)
   int fl_cbp, fc_cr;                         // what the luma wave and the chroma wave of the final stage found
   u64 fl_cbp_blk, fc_bits;
+  u64 pre_cbp_blk, pre_bits;                 // the 16x16 mode coded AHEAD by the 16x8 / 8x16 waves once they are done (mbpipe_kernel.inc: PRE): what the final stage's two waves would find
+  int pre_cbp, pre_cr;
+  int m1flag, pre_pad_;                      // ... and: the 16x16 search is done, its vectors stand (running count over the launch)
   u32 fin_cbp_blk;
   jmhip_mb_record out;
   PostShared post;
