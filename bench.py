@@ -44,7 +44,7 @@ G2R_MD5 = "04ce4cdee722defe8c3c7c0b249eda7e"      # CPU JM's 
 # MI355X_MICROARCH.md prescribes (profiles/collect5.sh, profiles/r04_v7_kernel_stats.md).  The counters sit between the L2s and the fabric: they also count what the 256 MB
 # Infinity Cache serves.  Most of it is by design: every reference sample is read with an sc1 load (past the XCD's L2 -- another XCD may have written it microseconds ago), 670 MB
 # of reads per picture; WRITE_SIZE counts 32-byte sectors (a 16-byte write-through store counts twice: profiles/r04_write_calib.txt).  DESIGN.md section 0a.
-PIPE_TRAFFIC_BYTES = {"batch": 802973880, "pictures": 464000000}           # per picture: one launch for all timed pictures (r06_final) / a launch per picture, eight in flight (r04_v1); the fallback when traffic_live cannot run
+PIPE_TRAFFIC_BYTES = {"batch": 810710640, "pictures": 464000000}           # per picture: one launch for all timed pictures (r06_final) / a launch per picture, eight in flight (r04_v1); the fallback when traffic_live cannot run
 # absolute differences the integer searches of one P picture of the clip ISSUE (the kernel's own counters, JMHIP_MB_PROF=11: profiles/batch_prof.py 25 fs 11): 81.5 % of the 61.78 G
 # JM's full search visits -- the cost bound of me_fullsearch.c:83 skips the rest for the small blocks
 VALU_ISSUED_PER_PICTURE = 50.366e9
