@@ -57,7 +57,9 @@ typedef struct {
 int         jmhip_create(jmhip_ctx **out, const jmhip_config *cfg);
 void        jmhip_destroy(jmhip_ctx *ctx);
 const char *jmhip_last_error(const jmhip_ctx *ctx);     /* ctx may be NULL: error of the last failed create */
-int         jmhip_synchronize(jmhip_ctx *ctx);           /* wait for the context's stream */
+int         jmhip_synchronize(jmhip_ctx *ctx);           /* wait for the context's stream and for every picture in flight (jmhip_seq_*): each is taken out of flight and its
+                                                            device error word is read (the first error is returned); an entry that streams its records to the host keeps
+                                                            answering jmhip_seq_record for its picture afterwards */
 /* geometry of the resident padded planes: pitch (bytes), rows, bytes between the 16 sub-planes */
 int         jmhip_plane_geometry(const jmhip_ctx *ctx, int32_t *pitch, int32_t *rows, int64_t *plane_stride);
 
